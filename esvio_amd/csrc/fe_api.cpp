@@ -1,0 +1,1190 @@
+// fe_api.cpp — handle, device memory, per-frame orchestration and the C ABI (include/esvio_fe.h).
+//
+// The per-frame sequence mirrors FeatureTracker::trackEvent (reference:
+// feature_tracker/src/feature_tracker.cpp:340-603); every data-parallel stage is a HIP kernel
+// from fe_kernels.hip, the <= max_cnt-point bookkeeping stays on the host exactly where the
+// reference has it.  There is no CPU fallback: without a HIP device esvio_fe_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/esvio_fe.h"
+#include "fe_host.h"
+#include "fe_kernels.h"
+
+using namespace esvio;
+
+namespace {
+
+struct P2f {
+  float x, y;
+};
+
+const char* const kKernelNames[K_COUNT] = {
+    "k_sae_keys", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_sae_apply",
+    "k_time_surface", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_select"};
+
+struct KStat {
+  double ms = 0;
+  uint64_t launches = 0;
+  uint64_t bytes = 0;
+};
+
+struct ProfRec {
+  int id;
+  hipEvent_t a, b;
+  uint64_t bytes;
+};
+
+// buildOpticalFlowPyramid's level count [OpenCV video/lkpyramid.cpp]
+int pyr_levels(int w, int h, int win, int max_level) {
+  int sw = w, sh = h;
+  for (int level = 0; level <= max_level; ++level) {
+    sw = (sw + 1) / 2;
+    sh = (sh + 1) / 2;
+    if (sw <= win || sh <= win) return level;
+  }
+  return max_level;
+}
+
+struct PyrStore {
+  PyrDesc d{};
+  void* mem = nullptr;
+  size_t bytes = 0;
+  int w = 0, h = 0, max_level = -1;
+};
+
+}  // namespace
+
+struct esvio_fe_ctx {
+  esvio_fe_config cfg{};
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int W = 0, H = 0;
+  uint32_t P = 0;
+  int key_bits = 0;
+  uint32_t invalid_key = 0;
+  std::vector<int> hw;  // disc half-widths for min_dist
+
+  // ---- device state
+  double2* L2 = nullptr;  // [2P] {L[0],L[1]} per (cam,pixel)
+  double2* S2 = nullptr;  // [2P] {S[0],S[1]}
+  EventRec* d_ev = nullptr;
+  size_t ev_cap = 0;
+  uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr;
+  size_t sort_cap = 0, hist_cap = 0;
+  unsigned long long* d_rejected = nullptr;
+  PyrStore pyr[3];  // two left slots (prev/cur alternate) + right
+  int slot_prevL = 0, slot_curL = 0;
+  bool have_img = false;
+  PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images
+  // LK point buffers (device), each max_cnt
+  float2 *d_ptsA = nullptr, *d_ptsB = nullptr, *d_ptsC = nullptr, *d_ptsD = nullptr;
+  uint8_t *d_stA = nullptr, *d_stB = nullptr;
+  int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total
+  // arc / select
+  uint8_t* d_flags = nullptr;
+  uint32_t *d_cand_xy = nullptr, *d_cand_idx = nullptr, *d_cand_cnt = nullptr;
+  uint32_t *d_comp_xy = nullptr, *d_comp_idx = nullptr;
+  size_t arc_cap = 0;
+  uint32_t* d_mask_bits = nullptr;
+  int32_t* d_sel_idx = nullptr;
+  // pinned host staging (layout: pin_of())
+  uint8_t* h_pin = nullptr;
+  size_t h_pin_bytes = 0;
+
+  // ---- FeatureTracker state (feature_tracker.h:119-173)
+  int n_id = 0;
+  double cur_time = 0, prev_time = 0;
+  std::vector<P2f> prev_pts, cur_pts, cur_right_pts, n_pts;
+  std::vector<P2f> cur_un_pts, cur_un_right_pts, pts_velocity, right_pts_velocity;
+  std::vector<int> ids, ids_right, track_cnt, track_cnt_right;
+  std::map<int, P2f> cur_un_pts_map, prev_un_pts_map, cur_un_right_pts_map, prev_un_right_pts_map;
+  host::BitMask mask_event;
+
+  // ---- profiling
+  bool prof_on = false;
+  KStat stats[K_COUNT];
+  std::vector<ProfRec> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(esvio_fe_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    c->err = buf;
+  }
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail((c), ESVIO_FE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                  __FILE__, __LINE__);                                                       \
+  } while (0)
+
+// ---------------------------------------------------------------- profiling
+hipEvent_t get_event(esvio_fe_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ScopedKernel {  // brackets one launch with HIP events on the handle's stream
+  esvio_fe_ctx* c;
+  int id;
+  uint64_t bytes;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedKernel(esvio_fe_ctx* ctx, int kid, uint64_t alg_bytes) : c(ctx), id(kid), bytes(alg_bytes) {
+    if (c->prof_on) {
+      a = get_event(c);
+      b = get_event(c);
+      (void)hipEventRecord(a, c->stream);
+    }
+  }
+  ~ScopedKernel() {
+    if (c->prof_on) {
+      (void)hipEventRecord(b, c->stream);
+      c->pending.push_back(ProfRec{id, a, b, bytes});
+    }
+  }
+};
+
+void resolve_profile(esvio_fe_ctx* c) {  // caller guarantees the stream is idle
+  for (auto& r : c->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->stats[r.id].ms += ms;
+      c->stats[r.id].launches++;
+      c->stats[r.id].bytes += r.bytes;
+    }
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->pending.clear();
+}
+
+// ---------------------------------------------------------------- memory
+template <class T>
+int dev_alloc(esvio_fe_ctx* c, T** p, size_t count) {
+  HIPCHK(c, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+  return 0;
+}
+
+int ensure_event_capacity(esvio_fe_ctx* c, size_t n) {
+  if (n <= c->ev_cap) return 0;
+  size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
+  if (c->d_ev) (void)hipFree(c->d_ev);
+  c->d_ev = nullptr;
+  c->ev_cap = 0;
+  if (int rc = dev_alloc(c, &c->d_ev, cap)) return rc;
+  c->ev_cap = cap;
+  return 0;
+}
+
+int ensure_sort_capacity(esvio_fe_ctx* c, size_t n) {
+  if (n > c->sort_cap) {
+    size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
+    for (int i = 0; i < 2; i++) {
+      if (c->keys[i]) (void)hipFree(c->keys[i]);
+      if (c->vals[i]) (void)hipFree(c->vals[i]);
+      c->keys[i] = c->vals[i] = nullptr;
+    }
+    c->sort_cap = 0;
+    for (int i = 0; i < 2; i++) {
+      if (int rc = dev_alloc(c, &c->keys[i], cap)) return rc;
+      if (int rc = dev_alloc(c, &c->vals[i], cap)) return rc;
+    }
+    c->sort_cap = cap;
+  }
+  size_t hneed = (size_t)radix_blocks((uint32_t)c->sort_cap) << kRadixMaxBits;
+  if (hneed > c->hist_cap) {
+    if (c->hist) (void)hipFree(c->hist);
+    c->hist = nullptr;
+    c->hist_cap = 0;
+    if (int rc = dev_alloc(c, &c->hist, hneed)) return rc;
+    c->hist_cap = hneed;
+  }
+  return 0;
+}
+
+int ensure_arc_capacity(esvio_fe_ctx* c, size_t n) {
+  if (n <= c->arc_cap) return 0;
+  size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
+  cap = (cap + kArcBlock - 1) / kArcBlock * kArcBlock;
+  void* ptrs[] = {c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy, c->d_comp_idx};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  c->d_flags = nullptr;
+  c->d_cand_xy = c->d_cand_idx = c->d_cand_cnt = c->d_comp_xy = c->d_comp_idx = nullptr;
+  c->arc_cap = 0;
+  if (int rc = dev_alloc(c, &c->d_flags, cap)) return rc;
+  if (int rc = dev_alloc(c, &c->d_cand_xy, cap)) return rc;
+  if (int rc = dev_alloc(c, &c->d_cand_idx, cap)) return rc;
+  if (int rc = dev_alloc(c, &c->d_cand_cnt, cap / kArcBlock)) return rc;
+  if (int rc = dev_alloc(c, &c->d_comp_xy, cap)) return rc;
+  if (int rc = dev_alloc(c, &c->d_comp_idx, cap)) return rc;
+  c->arc_cap = cap;
+  return 0;
+}
+
+int pyr_alloc(esvio_fe_ctx* c, PyrStore& ps, int w, int h, int max_level) {
+  if (ps.mem && ps.w == w && ps.h == h && ps.max_level == max_level) return 0;
+  if (ps.mem) (void)hipFree(ps.mem);
+  ps = PyrStore();
+  const int levels = pyr_levels(w, h, kLkWin, max_level);
+  size_t off = 0, img_off[kMaxLevels], der_off[kMaxLevels];
+  int lw = w, lh = h;
+  for (int l = 0; l <= levels; l++) {
+    const size_t area = (size_t)(lw + 2 * kPad) * (lh + 2 * kPad);
+    img_off[l] = off;
+    off += (area + 255) / 256 * 256;
+    der_off[l] = off;
+    off += (area * 4 + 255) / 256 * 256;
+    ps.d.w[l] = lw;
+    ps.d.h[l] = lh;
+    lw = (lw + 1) / 2;
+    lh = (lh + 1) / 2;
+  }
+  HIPCHK(c, hipMalloc(&ps.mem, off));
+  HIPCHK(c, hipMemsetAsync(ps.mem, 0, off, c->stream));  // derivative borders stay 0 forever
+  for (int l = 0; l <= levels; l++) {
+    ps.d.img[l] = (uint8_t*)ps.mem + img_off[l];
+    ps.d.deriv[l] = (int16_t*)((uint8_t*)ps.mem + der_off[l]);
+  }
+  for (int l = levels + 1; l < kMaxLevels; l++) {
+    ps.d.img[l] = ps.d.img[levels];
+    ps.d.deriv[l] = ps.d.deriv[levels];
+    ps.d.w[l] = ps.d.w[levels];
+    ps.d.h[l] = ps.d.h[levels];
+  }
+  ps.d.levels = levels;
+  ps.bytes = off;
+  ps.w = w;
+  ps.h = h;
+  ps.max_level = max_level;
+  return 0;
+}
+
+// level 0 interior already written -> pyrDown chain, border fill, Scharr
+void pyr_build(esvio_fe_ctx* c, const PyrDesc* p, int nimg) {
+  uint64_t px0 = (uint64_t)p[0].w[0] * p[0].h[0] * nimg;
+  for (int l = 0; l < p[0].levels; l++) {
+    uint64_t src = (uint64_t)p[0].w[l] * p[0].h[l], dst = (uint64_t)p[0].w[l + 1] * p[0].h[l + 1];
+    ScopedKernel k(c, K_PYR_DOWN, (src + dst) * nimg);
+    launch_pyr_down(c->stream, p, nimg, l);
+  }
+  {
+    ScopedKernel k(c, K_PYR_PAD, 0);
+    launch_pyr_pad(c->stream, p, nimg);
+  }
+  {
+    uint64_t all = 0;
+    for (int l = 0; l <= p[0].levels; l++) all += (uint64_t)p[0].w[l] * p[0].h[l];
+    ScopedKernel k(c, K_SCHARR, all * 5 * nimg);  // 1 B read + 4 B written per pixel
+    launch_scharr(c->stream, p, nimg);
+  }
+  (void)px0;
+}
+
+// ---------------------------------------------------------------- SAE update (both cameras)
+int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR,
+               uint32_t nR) {
+  const uint32_t n = nL + nR;
+  if (!n) return 0;
+  if (int rc = ensure_sort_capacity(c, n)) return rc;
+  {
+    ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);
+    launch_sae_keys(c->stream, evL, nL, evR, nR, c->W, c->H, c->keys[0], c->vals[0], c->invalid_key,
+                    c->d_rejected);
+  }
+  const int passes = (c->key_bits + 6) / 7;
+  const int bits = (c->key_bits + passes - 1) / passes;
+  int cur = 0;
+  const uint32_t nblk = radix_blocks(n);
+  for (int p = 0; p < passes; p++) {
+    const int shift = p * bits;
+    {
+      ScopedKernel k(c, K_RADIX_HIST, (uint64_t)n * 4);
+      launch_radix_hist(c->stream, c->keys[cur], n, shift, bits, c->hist);
+    }
+    {
+      ScopedKernel k(c, K_RADIX_SCAN, ((uint64_t)nblk << bits) * 8);
+      launch_radix_scan(c->stream, c->hist, nblk, bits);
+    }
+    {
+      ScopedKernel k(c, K_RADIX_SCATTER, (uint64_t)n * 16);
+      launch_radix_scatter(c->stream, c->keys[cur], c->vals[cur], n, shift, bits, c->hist,
+                           c->keys[cur ^ 1], c->vals[cur ^ 1]);
+    }
+    cur ^= 1;
+  }
+  {
+    ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
+    launch_sae_apply(c->stream, c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
+                     c->cfg.feature_filter_threshold, c->invalid_key);
+  }
+  return 0;
+}
+
+// stage host events into the handle's device buffer; returns device pointers
+int stage_events(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL,
+                 const esvio_fe_event* right, size_t nR, int space, const EventRec** dL,
+                 const EventRec** dR) {
+  if (space == ESVIO_FE_DEVICE) {
+    *dL = (const EventRec*)left;
+    *dR = (const EventRec*)right;
+    return 0;
+  }
+  if (space != ESVIO_FE_HOST) return fail(c, ESVIO_FE_EINVAL, "bad memory space %d", space);
+  if (int rc = ensure_event_capacity(c, nL + nR)) return rc;
+  if (nL) HIPCHK(c, hipMemcpyAsync(c->d_ev, left, nL * 16, hipMemcpyHostToDevice, c->stream));
+  if (nR)
+    HIPCHK(c, hipMemcpyAsync(c->d_ev + nL, right, nR * 16, hipMemcpyHostToDevice, c->stream));
+  *dL = c->d_ev;
+  *dR = c->d_ev + nL;
+  return 0;
+}
+
+void render_ts(esvio_fe_ctx* c, double t_sync, uint8_t* dst0, uint8_t* dst1, int ncam,
+               const double2* S2) {
+  ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * ncam);
+  launch_time_surface(c->stream, S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
+                      c->cfg.ignore_polarity, dst0, dst1, ncam);
+}
+
+void run_lk(esvio_fe_ctx* c, const PyrDesc& P, const PyrDesc& N, const float2* prev, float2* next,
+            uint8_t* status, const int* n_ptr, int n_max, int max_level, int max_count, double eps,
+            int flags) {
+  LkArgs a;
+  a.P = P;
+  a.N = N;
+  a.prev_pts = prev;
+  a.next_pts = next;
+  a.status = status;
+  a.n_ptr = n_ptr;
+  a.n_max = n_max;
+  a.max_level = std::min(max_level, P.levels);
+  // TermCriteria normalisation of calcOpticalFlowPyrLK [OpenCV]
+  a.max_count = std::min(std::max(max_count, 0), 100);
+  double e = std::min(std::max(eps, 0.), 10.);
+  a.eps2 = e * e;
+  a.flags = flags;
+  ScopedKernel k(c, K_LK, (uint64_t)n_max * (a.max_level + 1) * kLkWin * kLkWin * 5);
+  launch_lk(c->stream, a);
+}
+
+int copy_level0_out(esvio_fe_ctx* c, const PyrDesc& d, uint8_t* out) {
+  const int stride = d.w[0] + 2 * kPad;
+  HIPCHK(c, hipMemcpy2DAsync(out, d.w[0], d.img[0] + (size_t)kPad * stride + kPad, stride, d.w[0],
+                             d.h[0], hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int copy_level0_in(esvio_fe_ctx* c, const PyrDesc& d, const uint8_t* in) {
+  const int stride = d.w[0] + 2 * kPad;
+  HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, in, d.w[0], d.w[0],
+                             d.h[0], hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------- host bookkeeping (reference
+// helpers in feature_tracker.cpp)
+template <class T>
+void reduce_vector(std::vector<T>& v, const std::vector<uint8_t>& status) {  // :56-81
+  int j = 0;
+  for (int i = 0; i < int(v.size()); i++)
+    if (status[i]) v[j++] = v[i];
+  v.resize(j);
+}
+
+bool in_border_event(const esvio_fe_ctx* c, const P2f& pt) {  // :48-54
+  const int BORDER_SIZE = 1;
+  const int img_x = host::cv_round(pt.x), img_y = host::cv_round(pt.y);
+  return BORDER_SIZE <= img_x && img_x < c->W - BORDER_SIZE && BORDER_SIZE <= img_y &&
+         img_y < c->H - BORDER_SIZE;
+}
+
+double pt_distance(const P2f& a, const P2f& b) {  // :1314-1319
+  const double dx = a.x - b.x, dy = a.y - b.y;
+  return std::sqrt(dx * dx + dy * dy);
+}
+
+// Event_setMask (:123-151): std::sort on the same element type/comparator as the reference so
+// the (unstable) permutation of equal track counts is inherited from libstdc++.
+void event_set_mask(esvio_fe_ctx* c) {
+  c->mask_event.reset(c->W, c->H);
+  std::vector<std::pair<int, std::pair<P2f, int>>> cnt_pts_id;
+  for (unsigned int i = 0; i < c->cur_pts.size(); i++)
+    cnt_pts_id.push_back(std::make_pair(c->track_cnt[i], std::make_pair(c->cur_pts[i], c->ids[i])));
+  std::sort(cnt_pts_id.begin(), cnt_pts_id.end(),
+            [](const std::pair<int, std::pair<P2f, int>>& a,
+               const std::pair<int, std::pair<P2f, int>>& b) { return a.first > b.first; });
+  c->cur_pts.clear();
+  c->ids.clear();
+  c->track_cnt.clear();
+  for (auto& it : cnt_pts_id) {
+    const int px = host::cv_round(it.second.first.x), py = host::cv_round(it.second.first.y);
+    if (px < 0 || px >= c->W || py < 0 || py >= c->H) continue;  // cannot happen after inBorder
+    if (!c->mask_event.test(px, py)) {
+      c->cur_pts.push_back(it.second.first);
+      c->ids.push_back(it.second.second);
+      c->track_cnt.push_back(it.first);
+      c->mask_event.stamp_disc(px, py, c->cfg.min_dist, c->hw);
+    }
+  }
+}
+
+std::vector<P2f> undistorted_pts(const std::vector<P2f>& pts, const esvio_fe_camera& cam) {  // :991
+  std::vector<P2f> un;
+  un.reserve(pts.size());
+  for (const P2f& p : pts) {
+    double b[3];
+    host::lift_projective(cam, (double)p.x, (double)p.y, b);
+    un.push_back(P2f{(float)(b[0] / b[2]), (float)(b[1] / b[2])});
+  }
+  return un;
+}
+
+// ptsVelocity (:1004-1045) incl. its quirk: with no previous map the result is sized by the LEFT
+// cur_pts whichever camera it is called for.
+std::vector<P2f> pts_velocity_fn(esvio_fe_ctx* c, std::vector<int>& ids, std::vector<P2f>& pts,
+                                 std::map<int, P2f>& cur_id_pts, std::map<int, P2f>& prev_id_pts) {
+  std::vector<P2f> vel;
+  cur_id_pts.clear();
+  for (unsigned int i = 0; i < ids.size(); i++) cur_id_pts.insert(std::make_pair(ids[i], pts[i]));
+  if (!prev_id_pts.empty()) {
+    const double dt = c->cur_time - c->prev_time;
+    for (unsigned int i = 0; i < pts.size(); i++) {
+      if (ids[i] != -1) {
+        auto it = prev_id_pts.find(ids[i]);
+        if (it != prev_id_pts.end()) {
+          const double v_x = (pts[i].x - it->second.x) / dt;
+          const double v_y = (pts[i].y - it->second.y) / dt;
+          vel.push_back(P2f{(float)v_x, (float)v_y});
+        } else {
+          vel.push_back(P2f{0, 0});
+        }
+      } else {
+        vel.push_back(P2f{0, 0});
+      }
+    }
+  } else {
+    for (unsigned int i = 0; i < c->cur_pts.size(); i++) vel.push_back(P2f{0, 0});
+  }
+  return vel;
+}
+
+void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
+  if (c->cur_pts.size() >= 8) {
+    const esvio_fe_camera& cam = c->cfg.cam[0];
+    const double FOCAL = c->cfg.focal_length;
+    std::vector<float> un_cur(c->cur_pts.size() * 2), un_prev(c->prev_pts.size() * 2);
+    for (unsigned int i = 0; i < c->prev_pts.size(); i++) {
+      double p[3];
+      host::lift_projective(cam, c->prev_pts[i].x, c->prev_pts[i].y, p);
+      un_prev[2 * i] = (float)(FOCAL * p[0] / p[2] + c->W / 2.0);
+      un_prev[2 * i + 1] = (float)(FOCAL * p[1] / p[2] + c->H / 2.0);
+      host::lift_projective(cam, c->cur_pts[i].x, c->cur_pts[i].y, p);
+      un_cur[2 * i] = (float)(FOCAL * p[0] / p[2] + c->W / 2.0);
+      un_cur[2 * i + 1] = (float)(FOCAL * p[1] / p[2] + c->H / 2.0);
+    }
+    std::vector<uint8_t> status(c->cur_pts.size());
+    host::find_fundamental_mat(un_prev.data(), un_cur.data(), (int)c->cur_pts.size(),
+                               c->cfg.f_threshold, 0.99, status.data());
+    reduce_vector(c->prev_pts, status);
+    reduce_vector(c->cur_pts, status);
+    reduce_vector(c->ids, status);
+    reduce_vector(c->track_cnt, status);
+  }
+}
+
+// pinned staging layout (all sized by max_cnt = M):
+struct Pin {
+  float2* ptsA;   // H2D prev_pts / kept cur_pts ; D2H cur_pts
+  float2* ptsB;   // D2H temporal cur / right pts
+  float2* ptsC;   // D2H reverse pts
+  float2* ptsD;   // D2H new corners
+  uint8_t* stA;
+  uint8_t* stB;
+  int* counts;    // [2]
+  uint32_t* mask;  // H*wpr words
+};
+
+Pin pin_of(esvio_fe_ctx* c) {
+  const size_t M = std::max(c->cfg.max_cnt, 1);
+  Pin p;
+  uint8_t* b = c->h_pin;
+  p.ptsA = (float2*)b;
+  b += M * 8;
+  p.ptsB = (float2*)b;
+  b += M * 8;
+  p.ptsC = (float2*)b;
+  b += M * 8;
+  p.ptsD = (float2*)b;
+  b += M * 8;
+  p.counts = (int*)b;
+  b += 64;
+  p.mask = (uint32_t*)b;
+  b += (size_t)c->H * ((c->W + 31) / 32) * 4;
+  p.stA = b;
+  b += (M + 63) / 64 * 64;
+  p.stB = b;
+  return p;
+}
+
+size_t pin_bytes(const esvio_fe_config& cfg) {
+  const size_t M = std::max(cfg.max_cnt, 1);
+  return M * 8 * 4 + 64 + (size_t)cfg.height * ((cfg.width + 31) / 32) * 4 + 2 * ((M + 63) / 64 * 64);
+}
+
+void clear_tracker_state(esvio_fe_ctx* c) {
+  c->prev_pts.clear();
+  c->cur_pts.clear();
+  c->cur_right_pts.clear();
+  c->n_pts.clear();
+  c->cur_un_pts.clear();
+  c->cur_un_right_pts.clear();
+  c->pts_velocity.clear();
+  c->right_pts_velocity.clear();
+  c->ids.clear();
+  c->ids_right.clear();
+  c->track_cnt.clear();
+  c->track_cnt_right.clear();
+  c->cur_un_pts_map.clear();
+  c->prev_un_pts_map.clear();
+  c->cur_un_right_pts_map.clear();
+  c->prev_un_right_pts_map.clear();
+  c->have_img = false;
+  c->slot_prevL = c->slot_curL = 0;
+  c->cur_time = c->prev_time = 0;
+}
+
+SelectArgs make_select_args(esvio_fe_ctx* c, uint32_t nblk, int max_corners, float2* out_pts,
+                            int out_base, int32_t* out_idx) {
+  SelectArgs s{};
+  s.cand_xy = c->d_cand_xy;
+  s.cand_idx = c->d_cand_idx;
+  s.cand_cnt = c->d_cand_cnt;
+  s.nblk = nblk;
+  s.comp_xy = c->d_comp_xy;
+  s.comp_idx = c->d_comp_idx;
+  s.W = c->W;
+  s.H = c->H;
+  s.wpr = (c->W + 31) / 32;
+  s.max_corners = max_corners;
+  s.radius = c->cfg.min_dist;
+  for (int i = 0; i <= kMaxDiscR; i++) s.hw[i] = i < (int)c->hw.size() ? (int8_t)c->hw[i] : -1;
+  s.out_pts = out_pts;
+  s.out_idx = out_idx;
+  s.out_base = out_base;
+  s.n_out = c->d_counts;
+  s.n_total = c->d_counts + 1;
+  return s;
+}
+
+size_t select_lds_bytes(const esvio_fe_ctx* c) {
+  return ((size_t)c->H * ((c->W + 31) / 32) + 32) * 4;
+}
+
+// Arc* flags (+ ordered per-block candidate lists) for the left events
+void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool use_mask,
+             bool want_flags, bool want_cand) {
+  ArcArgs a{};
+  a.ev = ev;
+  a.n = n;
+  a.L2 = c->L2;
+  a.S2 = c->S2;
+  a.W = c->W;
+  a.H = c->H;
+  a.filter_threshold = c->cfg.feature_filter_threshold;
+  a.border = c->cfg.min_dist + 1;
+  a.ts = use_ts ? c->pyr[c->slot_curL].d.img[0] : nullptr;
+  a.ts_stride = c->W + 2 * kPad;
+  a.ts_lk_threshold = c->cfg.ts_lk_threshold;
+  a.mask_bits = use_mask ? c->d_mask_bits : nullptr;
+  a.wpr = (c->W + 31) / 32;
+  a.flags = want_flags ? c->d_flags : nullptr;
+  a.cand_xy = want_cand ? c->d_cand_xy : nullptr;
+  a.cand_idx = want_cand ? c->d_cand_idx : nullptr;
+  a.cand_cnt = want_cand ? c->d_cand_cnt : nullptr;
+  ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
+  launch_arc(c->stream, a);
+}
+
+// ---------------------------------------------------------------- trackEvent
+int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* left, size_t nL,
+                     const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME) {
+  const esvio_fe_config& cfg = c->cfg;
+  const int M = cfg.max_cnt;
+  Pin pin = pin_of(c);
+  c->cur_time = _cur_time;
+
+  const EventRec *dL = nullptr, *dR = nullptr;
+  if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
+  // createSAE_left / createSAE_right loops (:356-362)
+  if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) return rc;
+
+  // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; prev/cur slot rotation
+  // replaces the cv::Mat header swaps of :390-403,:585.
+  const bool first = !c->have_img;
+  c->slot_curL = first ? 0 : (c->slot_prevL ^ 1);
+  if (first) c->slot_prevL = 0;  // prev_img_left = cur_img_left = img_left (:391)
+  PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[2].d};
+  render_ts(c, c->cur_time, cur2[0].img[0], cur2[1].img[0], 2, c->S2);
+  pyr_build(c, cur2, 2);
+  c->have_img = true;
+  const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
+  const PyrDesc& curL = c->pyr[c->slot_curL].d;
+  const PyrDesc& curR = c->pyr[2].d;
+
+  c->cur_pts.clear();
+  c->cur_right_pts.clear();
+
+  if (c->prev_pts.size() > 0) {  // :405-437
+    const int n = (int)c->prev_pts.size();
+    std::memcpy(pin.ptsA, c->prev_pts.data(), (size_t)n * 8);
+    HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    // forward: prevL -> curL, maxLevel 3 (:410)
+    run_lk(c, prevL, curL, c->d_ptsA, c->d_ptsB, c->d_stA, nullptr, n, 3, 30, 0.01, 0);
+    if (cfg.flow_back) {
+      // reverse: curL -> prevL, maxLevel 1, USE_INITIAL_FLOW seeded with prev_pts (:416-418)
+      HIPCHK(c, hipMemcpyAsync(c->d_ptsC, c->d_ptsA, (size_t)n * 8, hipMemcpyDeviceToDevice,
+                               c->stream));
+      run_lk(c, curL, prevL, c->d_ptsB, c->d_ptsC, c->d_stB, nullptr, n, 1, 30, 0.01,
+             ESVIO_FE_LK_USE_INITIAL_FLOW);
+      HIPCHK(c, hipMemcpyAsync(pin.ptsC, c->d_ptsC, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(pin.stB, c->d_stB, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(pin.ptsB, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pin.stA, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint8_t> status(pin.stA, pin.stA + n);
+    c->cur_pts.resize(n);
+    std::memcpy(c->cur_pts.data(), pin.ptsB, (size_t)n * 8);
+    if (cfg.flow_back) {
+      const P2f* reverse_pts = (const P2f*)pin.ptsC;
+      for (int i = 0; i < n; i++) {
+        if (status[i] && pin.stB[i] && pt_distance(c->prev_pts[i], reverse_pts[i]) <= 0.5)
+          status[i] = 1;
+        else
+          status[i] = 0;
+      }
+    }
+    for (int i = 0; i < n; i++)
+      if (status[i] && !in_border_event(c, c->cur_pts[i])) status[i] = 0;
+    reduce_vector(c->prev_pts, status);
+    reduce_vector(c->cur_pts, status);
+    reduce_vector(c->ids, status);
+    reduce_vector(c->track_cnt, status);
+  }
+
+  for (auto& n : c->track_cnt) n++;  // :439-440
+
+  bool detect = false;
+  int n_kept = 0;
+  if (PUB_THIS_FRAME) {  // :442-469
+    if (cfg.f_ransac) reject_with_f_event(c);
+    event_set_mask(c);
+    const int n_max_cnt = M - (int)c->cur_pts.size();
+    n_kept = (int)c->cur_pts.size();
+    if (n_max_cnt > 0) {
+      detect = true;
+      if (int rc = ensure_arc_capacity(c, nL)) return rc;
+      std::memcpy(pin.mask, c->mask_event.bits.data(), c->mask_event.bits.size() * 4);
+      HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
+                               hipMemcpyHostToDevice, c->stream));
+      run_arc(c, dL, (uint32_t)nL, true, true, false, true);
+    }
+  } else {
+    n_kept = (int)c->cur_pts.size();
+  }
+  // kept points -> device (stereo LK input), new corners get appended on device by k_select
+  if (n_kept) {
+    std::memcpy(pin.ptsA, c->cur_pts.data(), (size_t)n_kept * 8);
+    HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n_kept * 8, hipMemcpyHostToDevice,
+                             c->stream));
+  }
+  const int n_lk_max = detect ? M : n_kept;
+  if (detect) {
+    const uint32_t nblk = (uint32_t)((nL + kArcBlock - 1) / kArcBlock);
+    SelectArgs s = make_select_args(c, nblk, M - n_kept, c->d_ptsA, n_kept, nullptr);
+    ScopedKernel k(c, K_SELECT, 0);
+    launch_select(c->stream, s, select_lds_bytes(c));
+  }
+  // stereo: curL -> curR (:490) and back curR -> curL (:495), both maxLevel 3
+  if (n_lk_max > 0) {
+    const int* n_ptr = detect ? c->d_counts + 1 : nullptr;
+    run_lk(c, curL, curR, c->d_ptsA, c->d_ptsB, c->d_stA, n_ptr, n_lk_max, 3, 30, 0.01, 0);
+    if (cfg.flow_back)
+      run_lk(c, curR, curL, c->d_ptsB, c->d_ptsC, c->d_stB, n_ptr, n_lk_max, 3, 30, 0.01, 0);
+    if (detect) {
+      HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(pin.ptsD, c->d_ptsA, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(pin.ptsB, c->d_ptsB, (size_t)n_lk_max * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pin.stA, c->d_stA, (size_t)n_lk_max, hipMemcpyDeviceToHost, c->stream));
+    if (cfg.flow_back) {
+      HIPCHK(c, hipMemcpyAsync(pin.ptsC, c->d_ptsC, (size_t)n_lk_max * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(pin.stB, c->d_stB, (size_t)n_lk_max, hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+
+  if (PUB_THIS_FRAME) {
+    c->n_pts.clear();
+    if (detect) {
+      const int n_new = pin.counts[0];
+      const P2f* np = (const P2f*)pin.ptsD + n_kept;
+      for (int i = 0; i < n_new; i++) c->n_pts.push_back(np[i]);
+    }
+    for (auto& p : c->n_pts) {  // :463-468
+      c->cur_pts.push_back(p);
+      c->ids.push_back(c->n_id++);
+      c->track_cnt.push_back(1);
+    }
+  }
+  c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);  // :470-473
+  c->pts_velocity = pts_velocity_fn(c, c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map);
+
+  {  // :475-575
+    c->ids_right.clear();
+    c->cur_right_pts.clear();
+    c->cur_un_right_pts.clear();
+    c->right_pts_velocity.clear();
+    c->cur_un_right_pts_map.clear();
+    c->track_cnt_right.clear();
+    if (!c->cur_pts.empty()) {
+      const int n = (int)c->cur_pts.size();
+      std::vector<uint8_t> status(pin.stA, pin.stA + n);
+      c->cur_right_pts.resize(n);
+      std::memcpy(c->cur_right_pts.data(), pin.ptsB, (size_t)n * 8);
+      if (cfg.flow_back && !c->cur_right_pts.empty()) {
+        const P2f* reverseLeftPts = (const P2f*)pin.ptsC;
+        for (int i = 0; i < n; i++) {
+          if (status[i] && pin.stB[i] && in_border_event(c, c->cur_right_pts[i]) &&
+              pt_distance(c->cur_pts[i], reverseLeftPts[i]) <= 0.5)
+            status[i] = 1;
+          else
+            status[i] = 0;
+        }
+      }
+      c->ids_right = c->ids;
+      reduce_vector(c->cur_right_pts, status);
+      reduce_vector(c->ids_right, status);
+      for (size_t i = 0; i < c->cur_right_pts.size(); i++) c->track_cnt_right.push_back(1);
+      c->cur_un_right_pts = undistorted_pts(c->cur_right_pts, cfg.cam[1]);
+      c->right_pts_velocity = pts_velocity_fn(c, c->ids_right, c->cur_un_right_pts,
+                                              c->cur_un_right_pts_map, c->prev_un_right_pts_map);
+    }
+    c->prev_un_right_pts_map = c->cur_un_right_pts_map;
+  }
+  c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left (:585)
+  c->prev_pts = c->cur_pts;
+  c->prev_un_pts_map = c->cur_un_pts_map;
+  c->prev_time = c->cur_time;
+  if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+}  // namespace
+
+// ==================================================================================== C ABI
+extern "C" {
+
+const char* esvio_fe_version(void) { return "esvio_fe 0.1 (gfx950)"; }
+
+const char* esvio_fe_last_error(esvio_fe_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int esvio_fe_destroy(esvio_fe_handle c) {
+  if (!c) return ESVIO_FE_EINVAL;
+  (void)hipSetDevice(c->dev);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
+                  c->d_rejected, c->d_ptsA, c->d_ptsB, c->d_ptsC, c->d_ptsD, c->d_stA, c->d_stB,
+                  c->d_counts, c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy,
+                  c->d_comp_idx, c->d_mask_bits, c->d_sel_idx, c->pyr[0].mem, c->pyr[1].mem,
+                  c->pyr[2].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  for (auto& r : c->pending) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
+  if (!cfg || !out) return ESVIO_FE_EINVAL;
+  *out = nullptr;
+  if (cfg->width < 2 * kLkWin || cfg->height < 2 * kLkWin || cfg->width > 8192 || cfg->height > 8192)
+    return ESVIO_FE_EINVAL;
+  if (cfg->max_cnt < 1 || cfg->max_cnt > 65536) return ESVIO_FE_EINVAL;
+  if (cfg->min_dist < 3 || cfg->min_dist > kMaxDiscR) return ESVIO_FE_EINVAL;  // Arc* ring r=4
+  if (cfg->lk_accum != 1) return ESVIO_FE_EINVAL;
+  if (cfg->median_blur_kernel_size != 0 || cfg->equalize != 0) return ESVIO_FE_ENOTIMPL;
+  if (!(cfg->decay_ms > 0)) return ESVIO_FE_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ESVIO_FE_ENODEVICE;
+  int dev = cfg->device;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) return ESVIO_FE_ENODEVICE;
+  }
+  if (dev >= ndev) return ESVIO_FE_ENODEVICE;
+  if (hipSetDevice(dev) != hipSuccess) return ESVIO_FE_ENODEVICE;
+
+  esvio_fe_ctx* c = new esvio_fe_ctx();
+  c->cfg = *cfg;
+  c->dev = dev;
+  c->W = cfg->width;
+  c->H = cfg->height;
+  c->P = (uint32_t)c->W * c->H;
+  c->invalid_key = 2 * c->P;
+  c->key_bits = 1;
+  while ((1ull << c->key_bits) <= (unsigned long long)c->invalid_key) c->key_bits++;
+  c->hw = host::disc_halfwidths(cfg->min_dist);
+  c->mask_event.reset(c->W, c->H);
+
+  auto bail = [&](int rc) {
+    esvio_fe_destroy(c);
+    return rc;
+  };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(ESVIO_FE_EHIP);
+  const size_t M = cfg->max_cnt;
+  int rc = 0;
+  if ((rc = dev_alloc(c, &c->L2, (size_t)2 * c->P))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->S2, (size_t)2 * c->P))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_rejected, 1))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_ptsA, M))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_ptsB, M))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_ptsC, M))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_stA, M))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_stB, M))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_counts, 16))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_sel_idx, M))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_mask_bits, (size_t)c->H * ((c->W + 31) / 32)))) return bail(rc);
+  for (int i = 0; i < 3; i++)
+    if ((rc = pyr_alloc(c, c->pyr[i], c->W, c->H, 3))) return bail(rc);
+  c->h_pin_bytes = pin_bytes(*cfg);
+  if (hipHostMalloc((void**)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess)
+    return bail(ESVIO_FE_EHIP);
+  if (hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->stream) != hipSuccess ||
+      hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->stream) != hipSuccess ||
+      hipMemsetAsync(c->d_rejected, 0, 8, c->stream) != hipSuccess ||
+      hipMemsetAsync(c->d_counts, 0, 64, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess)
+    return bail(ESVIO_FE_EHIP);
+  size_t lds = select_lds_bytes(c);
+  if (lds > 160 * 1024) return bail(ESVIO_FE_EINVAL);
+  *out = c;
+  return 0;
+}
+
+int esvio_fe_reset(esvio_fe_handle c) {
+  if (!c) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  clear_tracker_state(c);
+  return 0;
+}
+
+int esvio_fe_create_sae_stereo(esvio_fe_handle c, const esvio_fe_event* left, size_t nL,
+                               const esvio_fe_event* right, size_t nR, int space,
+                               uint64_t* n_rejected) {
+  if (!c || (nL && !left) || (nR && !right)) return ESVIO_FE_EINVAL;
+  if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  HIPCHK(c, hipSetDevice(c->dev));
+  const EventRec *dL, *dR;
+  if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->stream));
+  if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) return rc;
+  unsigned long long rej = 0;
+  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_rejected) *n_rejected = rej;
+  if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+int esvio_fe_create_sae(esvio_fe_handle c, int cam, const esvio_fe_event* ev, size_t n, int space,
+                        uint64_t* n_rejected) {
+  if (cam == 0) return esvio_fe_create_sae_stereo(c, ev, n, nullptr, 0, space, n_rejected);
+  if (cam == 1) return esvio_fe_create_sae_stereo(c, nullptr, 0, ev, n, space, n_rejected);
+  return ESVIO_FE_EINVAL;
+}
+
+int esvio_fe_sae_to_time_surface(esvio_fe_handle c, int cam, double t_sync, uint8_t* out) {
+  if (!c || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  const PyrDesc& d = cam ? c->pyr[2].d : c->pyr[c->slot_curL].d;
+  render_ts(c, t_sync, d.img[0], d.img[0], 1, c->S2 + (size_t)cam * c->P);
+  if (out) return copy_level0_out(c, d, out);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+int esvio_fe_get_time_surface(esvio_fe_handle c, int cam, uint8_t* out) {
+  if (!c || !out || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  return copy_level0_out(c, cam ? c->pyr[2].d : c->pyr[c->slot_curL].d, out);
+}
+
+int esvio_fe_is_corner(esvio_fe_handle c, const esvio_fe_event* ev, size_t n, int space,
+                       uint8_t* flags) {
+  if (!c || (n && (!ev || !flags))) return ESVIO_FE_EINVAL;
+  if (!n) return 0;
+  HIPCHK(c, hipSetDevice(c->dev));
+  const EventRec *dL, *dR;
+  if (int rc = stage_events(c, ev, n, nullptr, 0, space, &dL, &dR)) return rc;
+  if (int rc = ensure_arc_capacity(c, n)) return rc;
+  run_arc(c, dL, (uint32_t)n, false, false, true, false);
+  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+int esvio_fe_features_to_track(esvio_fe_handle c, const esvio_fe_event* ev, size_t n, int space,
+                               int max_corners, const uint8_t* mask, float* out_xy,
+                               int32_t* out_idx, int32_t* n_out) {
+  if (!c || !n_out || (n && !ev)) return ESVIO_FE_EINVAL;
+  *n_out = 0;
+  if (max_corners <= 0 || !n) return 0;
+  if (max_corners > c->cfg.max_cnt) return fail(c, ESVIO_FE_EINVAL, "max_corners > max_cnt");
+  if (!out_xy) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  const EventRec *dL, *dR;
+  if (int rc = stage_events(c, ev, n, nullptr, 0, space, &dL, &dR)) return rc;
+  if (int rc = ensure_arc_capacity(c, n)) return rc;
+  Pin pin = pin_of(c);
+  host::BitMask bm;
+  bm.reset(c->W, c->H);
+  if (mask) bm.from_bytes(mask);
+  std::memcpy(pin.mask, bm.bits.data(), bm.bits.size() * 4);
+  HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, bm.bits.size() * 4, hipMemcpyHostToDevice,
+                           c->stream));
+  run_arc(c, dL, (uint32_t)n, true, true, false, true);
+  const uint32_t nblk = (uint32_t)((n + kArcBlock - 1) / kArcBlock);
+  SelectArgs s = make_select_args(c, nblk, max_corners, c->d_ptsD, 0, c->d_sel_idx);
+  {
+    ScopedKernel k(c, K_SELECT, 0);
+    launch_select(c->stream, s, select_lds_bytes(c));
+  }
+  HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int k = pin.counts[0];
+  if (k > 0) {
+    HIPCHK(c, hipMemcpy(out_xy, c->d_ptsD, (size_t)k * 8, hipMemcpyDeviceToHost));
+    if (out_idx) HIPCHK(c, hipMemcpy(out_idx, c->d_sel_idx, (size_t)k * 4, hipMemcpyDeviceToHost));
+  }
+  *n_out = k;
+  if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+static int planes_io(esvio_fe_handle c, int cam, double* L0, double* L1, double* S0, double* S1,
+                     const double* iL0, const double* iL1, const double* iS0, const double* iS1,
+                     bool set) {
+  if (!c || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  std::vector<double> l((size_t)2 * c->P), s((size_t)2 * c->P);
+  if (set) {
+    for (uint32_t i = 0; i < c->P; i++) {
+      l[2 * i] = iL0[i];
+      l[2 * i + 1] = iL1[i];
+      s[2 * i] = iS0[i];
+      s[2 * i + 1] = iS1[i];
+    }
+    HIPCHK(c, hipMemcpy(c->L2 + (size_t)cam * c->P, l.data(), (size_t)c->P * 16, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->S2 + (size_t)cam * c->P, s.data(), (size_t)c->P * 16, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(l.data(), c->L2 + (size_t)cam * c->P, (size_t)c->P * 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(s.data(), c->S2 + (size_t)cam * c->P, (size_t)c->P * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < c->P; i++) {
+      L0[i] = l[2 * i];
+      L1[i] = l[2 * i + 1];
+      S0[i] = s[2 * i];
+      S1[i] = s[2 * i + 1];
+    }
+  }
+  return 0;
+}
+
+int esvio_fe_get_sae(esvio_fe_handle c, int cam, double* L0, double* L1, double* S0, double* S1) {
+  if (!L0 || !L1 || !S0 || !S1) return ESVIO_FE_EINVAL;
+  return planes_io(c, cam, L0, L1, S0, S1, nullptr, nullptr, nullptr, nullptr, false);
+}
+int esvio_fe_set_sae(esvio_fe_handle c, int cam, const double* L0, const double* L1,
+                     const double* S0, const double* S1) {
+  if (!L0 || !L1 || !S0 || !S1) return ESVIO_FE_EINVAL;
+  return planes_io(c, cam, nullptr, nullptr, nullptr, nullptr, L0, L1, S0, S1, true);
+}
+
+static int prep_tmp_pyr(esvio_fe_handle c, int slot, const uint8_t* img, int w, int hgt,
+                        int max_level) {
+  if (int rc = pyr_alloc(c, c->tmp_pyr[slot], w, hgt, max_level)) return rc;
+  return copy_level0_in(c, c->tmp_pyr[slot].d, img);
+}
+
+int esvio_fe_calc_optical_flow_pyr_lk(esvio_fe_handle c, const uint8_t* prev_img,
+                                      const uint8_t* next_img, int w, int hgt,
+                                      const float* prev_pts, float* next_pts, uint8_t* status,
+                                      int n, int max_level, int max_count, double eps, int flags) {
+  if (!c || !prev_img || !next_img || n < 0 || (n && (!prev_pts || !next_pts || !status)))
+    return ESVIO_FE_EINVAL;
+  if (w < 2 * kLkWin || hgt < 2 * kLkWin || max_level < 0 || max_level >= kMaxLevels)
+    return ESVIO_FE_EINVAL;
+  if (n > c->cfg.max_cnt) return fail(c, ESVIO_FE_EINVAL, "n > max_cnt");
+  if (!n) return 0;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = prep_tmp_pyr(c, 0, prev_img, w, hgt, max_level)) return rc;
+  if (int rc = prep_tmp_pyr(c, 1, next_img, w, hgt, max_level)) return rc;
+  PyrDesc two[2] = {c->tmp_pyr[0].d, c->tmp_pyr[1].d};
+  pyr_build(c, two, 2);
+  HIPCHK(c, hipMemcpyAsync(c->d_ptsA, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  if (flags & ESVIO_FE_LK_USE_INITIAL_FLOW)
+    HIPCHK(c, hipMemcpyAsync(c->d_ptsB, next_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  run_lk(c, two[0], two[1], c->d_ptsA, c->d_ptsB, c->d_stA, nullptr, n, max_level, max_count, eps,
+         flags);
+  HIPCHK(c, hipMemcpyAsync(next_pts, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(status, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+int esvio_fe_build_pyramid(esvio_fe_handle c, const uint8_t* img, int w, int hgt, int max_level,
+                           int level, uint8_t* out_img, int16_t* out_deriv, int32_t* lw,
+                           int32_t* lh, int32_t* n_levels) {
+  if (!c || !img || max_level < 0 || max_level >= kMaxLevels || w < 2 * kLkWin || hgt < 2 * kLkWin)
+    return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = prep_tmp_pyr(c, 0, img, w, hgt, max_level)) return rc;
+  const PyrDesc& d = c->tmp_pyr[0].d;
+  pyr_build(c, &d, 1);
+  if (n_levels) *n_levels = d.levels + 1;
+  if (level < 0 || level > d.levels) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return level < 0 ? 0 : ESVIO_FE_EINVAL;
+  }
+  if (lw) *lw = d.w[level];
+  if (lh) *lh = d.h[level];
+  const int stride = d.w[level] + 2 * kPad;
+  if (out_img)
+    HIPCHK(c, hipMemcpy2DAsync(out_img, d.w[level], d.img[level] + (size_t)kPad * stride + kPad,
+                               stride, d.w[level], d.h[level], hipMemcpyDeviceToHost, c->stream));
+  if (out_deriv)
+    HIPCHK(c, hipMemcpy2DAsync(out_deriv, (size_t)d.w[level] * 4,
+                               d.deriv[level] + ((size_t)kPad * stride + kPad) * 2, (size_t)stride * 4,
+                               (size_t)d.w[level] * 4, d.h[level], hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, double thr, double conf,
+                                  uint8_t* status, int32_t* n_inliers) {
+  if (n < 0 || (n && (!p1 || !p2 || !status))) return ESVIO_FE_EINVAL;
+  const int k = host::find_fundamental_mat(p1, p2, n, thr, conf, status);
+  if (n_inliers) *n_inliers = k;
+  return 0;
+}
+
+int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, double* out3) {
+  if (!cam || !out3) return ESVIO_FE_EINVAL;
+  host::lift_projective(*cam, u, v, out3);
+  return 0;
+}
+
+int esvio_fe_track_event(esvio_fe_handle c, double cur_time, const esvio_fe_event* left, size_t nL,
+                         const esvio_fe_event* right, size_t nR, int space, int pub_this_frame,
+                         esvio_fe_tracks* out) {
+  if (!c) return ESVIO_FE_EINVAL;
+  if (nL == 0 || !left) return fail(c, ESVIO_FE_EINVAL, "left batch must not be empty (node:150)");
+  if (nR && !right) return ESVIO_FE_EINVAL;
+  if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = track_event_impl(c, cur_time, left, nL, right, nR, space, pub_this_frame != 0))
+    return rc;
+  if (out) {
+    out->n_left = (int32_t)c->ids.size();
+    out->n_right = (int32_t)c->ids_right.size();
+    const size_t nl = c->ids.size(), nr = c->ids_right.size();
+    if (out->ids) std::memcpy(out->ids, c->ids.data(), nl * 4);
+    if (out->track_cnt) std::memcpy(out->track_cnt, c->track_cnt.data(), nl * 4);
+    if (out->cur_pts) std::memcpy(out->cur_pts, c->cur_pts.data(), nl * 8);
+    if (out->cur_un_pts) std::memcpy(out->cur_un_pts, c->cur_un_pts.data(), nl * 8);
+    if (out->pts_velocity) std::memcpy(out->pts_velocity, c->pts_velocity.data(), nl * 8);
+    if (out->ids_right) std::memcpy(out->ids_right, c->ids_right.data(), nr * 4);
+    if (out->cur_right_pts) std::memcpy(out->cur_right_pts, c->cur_right_pts.data(), nr * 8);
+    if (out->cur_un_right_pts) std::memcpy(out->cur_un_right_pts, c->cur_un_right_pts.data(), nr * 8);
+    if (out->right_pts_velocity)
+      std::memcpy(out->right_pts_velocity, c->right_pts_velocity.data(), nr * 8);
+  }
+  return 0;
+}
+
+int esvio_fe_set_profiling(esvio_fe_handle c, int on) {
+  if (!c) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  resolve_profile(c);
+  c->prof_on = on != 0;
+  return 0;
+}
+int esvio_fe_kernel_count(void) { return K_COUNT; }
+const char* esvio_fe_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+int esvio_fe_get_kernel_stats(esvio_fe_handle c, int id, double* total_ms, uint64_t* launches,
+                              uint64_t* alg_bytes) {
+  if (!c || id < 0 || id >= K_COUNT) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  resolve_profile(c);
+  if (total_ms) *total_ms = c->stats[id].ms;
+  if (launches) *launches = c->stats[id].launches;
+  if (alg_bytes) *alg_bytes = c->stats[id].bytes;
+  return 0;
+}
+int esvio_fe_reset_kernel_stats(esvio_fe_handle c) {
+  if (!c) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  resolve_profile(c);
+  for (auto& s : c->stats) s = KStat();
+  return 0;
+}
+void* esvio_fe_stream(esvio_fe_handle c) { return c ? (void*)c->stream : nullptr; }
+
+}  // extern "C"

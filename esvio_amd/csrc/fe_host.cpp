@@ -1,0 +1,436 @@
+// fe_host.cpp — host-side geometry of the event front-end (see fe_host.h).
+// Compiled with -ffp-contract=off like the kernels (the reference build has no FMA contraction).
+#include "fe_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+namespace esvio {
+namespace host {
+
+int cv_round(double v) {
+  // SSE2 cvtsd2si semantics: ties-to-even, 0x80000000 when the value does not fit
+  if (!(v > -2147483648.5 && v < 2147483647.5)) return INT_MIN;
+  const double r = std::nearbyint(v);
+  if (r > 2147483647.0 || r < -2147483648.0) return INT_MIN;
+  return (int)r;
+}
+
+int cv_floor(float v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+
+// ---------------------------------------------------------------------------- pinhole
+// PinholeCamera::distortion (PinholeCamera.cc:646-662): radial-tangential displacement d_u(p_u)
+static void radtan(const esvio_fe_camera& c, double x, double y, double& dx, double& dy) {
+  const double x2 = x * x, y2 = y * y, xy = x * y;
+  const double rho2 = x2 + y2;
+  const double rad = c.k1 * rho2 + c.k2 * rho2 * rho2;
+  dx = x * rad + 2.0 * c.p1 * xy + c.p2 * (rho2 + 2.0 * x2);
+  dy = y * rad + 2.0 * c.p2 * xy + c.p1 * (rho2 + 2.0 * y2);
+}
+
+void lift_projective(const esvio_fe_camera& c, double u, double v, double out[3]) {
+  // m_inv_K11 = 1/fx, m_inv_K13 = -cx/fx, ... (PinholeCamera.cc:824-827)
+  const double xd = (1.0 / c.fx) * u + (-c.cx / c.fx);
+  const double yd = (1.0 / c.fy) * v + (-c.cy / c.fy);
+  double xu = xd, yu = yd;
+  const bool no_distortion = c.k1 == 0.0 && c.k2 == 0.0 && c.p1 == 0.0 && c.p2 == 0.0;
+  if (!no_distortion) {
+    // "recursive distortion model", n = 8 fixed-point iterations (:490-504)
+    double dx, dy;
+    radtan(c, xd, yd, dx, dy);
+    xu = xd - dx;
+    yu = yd - dy;
+    for (int it = 1; it < 8; ++it) {
+      radtan(c, xu, yu, dx, dy);
+      xu = xd - dx;
+      yu = yd - dy;
+    }
+  }
+  out[0] = xu;
+  out[1] = yu;
+  out[2] = 1.0;
+}
+
+// ---------------------------------------------------------------------------- disc / bitmap
+std::vector<int> disc_halfwidths(int r) {
+  std::vector<int> hw(r + 1, -1);
+  int err = 0, dx = r, dy = 0, plus = 1, minus = (r << 1) - 1;
+  while (dx >= dy) {
+    hw[dy] = std::max(hw[dy], dx);
+    hw[dx] = std::max(hw[dx], dy);
+    dy++;
+    err += plus;
+    plus += 2;
+    const int mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+  return hw;
+}
+
+void BitMask::reset(int w, int h) {
+  W = w;
+  H = h;
+  wpr = (w + 31) / 32;
+  bits.assign((size_t)wpr * h, 0u);
+}
+
+void BitMask::stamp_disc(int cx, int cy, int r, const std::vector<int>& hw) {
+  for (int oy = -r; oy <= r; oy++) {
+    const int y = cy + oy;
+    if (y < 0 || y >= H) continue;
+    const int h = hw[oy < 0 ? -oy : oy];
+    if (h < 0) continue;
+    const int x0 = std::max(cx - h, 0), x1 = std::min(cx + h, W - 1);
+    if (x1 < x0) continue;
+    for (int w = x0 >> 5; w <= (x1 >> 5); w++) {
+      const int lo = std::max(x0 - (w << 5), 0), hi = std::min(x1 - (w << 5), 31);
+      const uint32_t m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+      bits[(size_t)y * wpr + w] |= m;
+    }
+  }
+}
+
+void BitMask::from_bytes(const uint8_t* mask) {
+  std::fill(bits.begin(), bits.end(), 0u);
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++)
+      if (mask[(size_t)y * W + x] == 255) bits[(size_t)y * wpr + (x >> 5)] |= 1u << (x & 31);
+}
+
+// ---------------------------------------------------------------------------- F-matrix RANSAC
+namespace {
+
+struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-1 by the registrators
+  uint64_t s = ~0ull;
+  unsigned next() {
+    s = (uint64_t)(unsigned)s * 4164903690U + (unsigned)(s >> 32);
+    return (unsigned)s;
+  }
+  int uniform(int lo, int hi) { return lo == hi ? lo : (int)(next() % (unsigned)(hi - lo) + lo); }
+};
+
+// Two null vectors of the 7x9 epipolar system = eigenvectors of A^T A with the two smallest
+// eigenvalues (cyclic Jacobi).  [OpenCV takes rows 7,8 of V^T from SVDecomp; the null space is
+// the same plane, so the cubic below has the same F solutions.]
+void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
+  double M[9][9], V[9][9];
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j < 9; j++) {
+      double s = 0;
+      for (int k = 0; k < 7; k++) s += A[k][i] * A[k][j];
+      M[i][j] = s;
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = 0;
+    for (int i = 0; i < 9; i++)
+      for (int j = i + 1; j < 9; j++) off += M[i][j] * M[i][j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 8; p++)
+      for (int q = p + 1; q < 9; q++) {
+        if (std::fabs(M[p][q]) < 1e-300) continue;
+        const double theta = (M[q][q] - M[p][p]) / (2.0 * M[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 9; k++) {
+          const double kp = M[k][p], kq = M[k][q];
+          M[k][p] = c * kp - s * kq;
+          M[k][q] = s * kp + c * kq;
+        }
+        for (int k = 0; k < 9; k++) {
+          const double pk = M[p][k], qk = M[q][k];
+          M[p][k] = c * pk - s * qk;
+          M[q][k] = s * pk + c * qk;
+        }
+        for (int k = 0; k < 9; k++) {
+          const double kp = V[k][p], kq = V[k][q];
+          V[k][p] = c * kp - s * kq;
+          V[k][q] = s * kp + c * kq;
+        }
+      }
+  }
+  int order[9];
+  for (int i = 0; i < 9; i++) order[i] = i;
+  std::sort(order, order + 9, [&](int a, int b) { return M[a][a] > M[b][b]; });
+  for (int i = 0; i < 9; i++) {
+    f1[i] = V[i][order[7]];
+    f2[i] = V[i][order[8]];
+  }
+}
+
+// cv::solveCubic [OpenCV core/mathfuncs.cpp]
+int solve_cubic(const double coef[4], double roots[3]) {
+  double a0 = coef[0], a1 = coef[1], a2 = coef[2], a3 = coef[3];
+  double x0 = 0, x1 = 0, x2 = 0;
+  int n = 0;
+  if (a0 == 0) {
+    if (a1 == 0) {
+      if (a2 == 0) {
+        n = a3 == 0 ? -1 : 0;
+      } else {
+        x0 = -a3 / a2;
+        n = 1;
+      }
+    } else {
+      double d = a2 * a2 - 4 * a1 * a3;
+      if (d >= 0) {
+        d = std::sqrt(d);
+        const double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+        if (std::fabs(q1) > std::fabs(q2)) {
+          x0 = q1 / a1;
+          x1 = a3 / q1;
+        } else {
+          x0 = q2 / a1;
+          x1 = a3 / q2;
+        }
+        n = d > 0 ? 2 : 1;
+      }
+    }
+  } else {
+    a0 = 1. / a0;
+    a1 *= a0;
+    a2 *= a0;
+    a3 *= a0;
+    const double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+    const double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+    const double Qcubed = Q * Q * Q;
+    double d = Qcubed - R * R;
+    const double kPi = 3.1415926535897932384626433832795;
+    if (d > 0) {
+      const double theta = std::acos(R / std::sqrt(Qcubed));
+      const double sqrtQ = std::sqrt(Q);
+      const double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+      x0 = t0 * std::cos(t1) - t2;
+      x1 = t0 * std::cos(t1 + (2. * kPi / 3)) - t2;
+      x2 = t0 * std::cos(t1 + (4. * kPi / 3)) - t2;
+      n = 3;
+    } else if (d == 0) {
+      if (R >= 0) {
+        x0 = -2 * std::pow(R, 1. / 3) - a1 / 3;
+        x1 = std::pow(R, 1. / 3) - a1 / 3;
+      } else {
+        x0 = 2 * std::pow(-R, 1. / 3) - a1 / 3;
+        x1 = -std::pow(-R, 1. / 3) - a1 / 3;
+      }
+      x2 = 0;
+      n = x0 == x1 ? 1 : 2;
+      x1 = x0 == x1 ? 0 : x1;
+    } else {
+      d = std::sqrt(-d);
+      double e = std::pow(d + std::fabs(R), 1. / 3);
+      if (R > 0) e = -e;
+      x0 = (e + Q / e) - a1 * (1. / 3);
+      n = 1;
+    }
+  }
+  roots[0] = x0;
+  roots[1] = x1;
+  roots[2] = x2;
+  return n;
+}
+
+// FMEstimatorCallback::run7Point [OpenCV calib3d/fundam.cpp]; F: up to 3 row-major 3x3
+int seven_point(const float* m1, const float* m2, double* F) {
+  double A[7][9];
+  for (int i = 0; i < 7; i++) {
+    const double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
+    const double row[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1};
+    std::memcpy(A[i], row, sizeof(row));
+  }
+  double f1[9], f2[9];
+  epipolar_nullspace(A, f1, f2);
+  for (int i = 0; i < 9; i++) f1[i] -= f2[i];
+  double c[4], r[3] = {0, 0, 0};
+  double t0 = f2[4] * f2[8] - f2[5] * f2[7];
+  double t1 = f2[3] * f2[8] - f2[5] * f2[6];
+  double t2 = f2[3] * f2[7] - f2[4] * f2[6];
+  c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+  c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+         f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+         f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+         f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+  t0 = f1[4] * f1[8] - f1[5] * f1[7];
+  t1 = f1[3] * f1[8] - f1[5] * f1[6];
+  t2 = f1[3] * f1[7] - f1[4] * f1[6];
+  c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+  c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+         f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+         f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+         f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+  const int n = solve_cubic(c, r);
+  if (n < 1 || n > 3) return n;
+  for (int k = 0; k < n; k++, F += 9) {
+    double lambda = r[k], mu = 1.;
+    const double s = f1[8] * r[k] + f2[8];
+    if (std::fabs(s) > DBL_EPSILON) {
+      mu = 1. / s;
+      lambda *= mu;
+      F[8] = 1.;
+    } else {
+      F[8] = 0.;
+    }
+    for (int i = 0; i < 8; i++) F[i] = f1[i] * lambda + f2[i] * mu;
+  }
+  return n;
+}
+
+// FMEstimatorCallback::computeError: max of the two squared point-to-epipolar-line distances
+void epipolar_errors(const float* m1, const float* m2, int n, const double* F, float* err) {
+  for (int i = 0; i < n; i++) {
+    const double x1 = m1[2 * i], y1 = m1[2 * i + 1], x2 = m2[2 * i], y2 = m2[2 * i + 1];
+    double a = F[0] * x1 + F[1] * y1 + F[2];
+    double b = F[3] * x1 + F[4] * y1 + F[5];
+    double c = F[6] * x1 + F[7] * y1 + F[8];
+    const double s2 = 1. / (a * a + b * b);
+    const double d2 = x2 * a + y2 * b + c;
+    a = F[0] * x2 + F[3] * y2 + F[6];
+    b = F[1] * x2 + F[4] * y2 + F[7];
+    c = F[2] * x2 + F[5] * y2 + F[8];
+    const double s1 = 1. / (a * a + b * b);
+    const double d1 = x1 * a + y1 * b + c;
+    err[i] = (float)std::max(d1 * d1 * s1, d2 * d2 * s2);
+  }
+}
+
+bool last_point_collinear(const float* m, int count) {  // haveCollinearPoints
+  const int i = count - 1;
+  for (int j = 0; j < i; j++) {
+    const double dx1 = m[2 * j] - m[2 * i], dy1 = m[2 * j + 1] - m[2 * i + 1];
+    for (int k = 0; k < j; k++) {
+      const double dx2 = m[2 * k] - m[2 * i], dy2 = m[2 * k + 1] - m[2 * i + 1];
+      if (std::fabs(dx2 * dy1 - dy2 * dx1) <=
+          FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2)))
+        return true;
+    }
+  }
+  return false;
+}
+
+// RANSACPointSetRegistrator::getSubset for modelPoints = 7
+bool draw_subset(const float* m1, const float* m2, int count, float* s1, float* s2, OcvRng& rng,
+                 int max_attempts) {
+  int idx[7];
+  int i = 0, iters = 0;
+  for (; iters < max_attempts; iters++) {
+    for (i = 0; i < 7 && iters < max_attempts;) {
+      int pick, j;
+      for (;;) {
+        pick = idx[i] = rng.uniform(0, count);
+        for (j = 0; j < i; j++)
+          if (pick == idx[j]) break;
+        if (j == i) break;
+      }
+      s1[2 * i] = m1[2 * pick];
+      s1[2 * i + 1] = m1[2 * pick + 1];
+      s2[2 * i] = m2[2 * pick];
+      s2[2 * i + 1] = m2[2 * pick + 1];
+      i++;
+    }
+    if (i == 7 && (last_point_collinear(s1, i) || last_point_collinear(s2, i))) continue;
+    break;
+  }
+  return i == 7 && iters < max_attempts;
+}
+
+int update_num_iters(double p, double ep, int model_points, int max_iters) {  // RANSACUpdateNumIters
+  p = std::min(std::max(p, 0.), 1.);
+  ep = std::min(std::max(ep, 0.), 1.);
+  double num = std::max(1. - p, DBL_MIN);
+  double denom = 1. - std::pow(1. - ep, model_points);
+  if (denom < DBL_MIN) return 0;
+  num = std::log(num);
+  denom = std::log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : cv_round(num / denom);
+}
+
+int mark_inliers(const float* m1, const float* m2, int n, const double* F, std::vector<float>& err,
+                 uint8_t* mask, double thresh) {
+  epipolar_errors(m1, m2, n, F, err.data());
+  const float t = (float)(thresh * thresh);
+  int good = 0;
+  for (int i = 0; i < n; i++) {
+    const int f = err[i] <= t;
+    mask[i] = (uint8_t)f;
+    good += f;
+  }
+  return good;
+}
+
+}  // namespace
+
+int find_fundamental_mat(const float* m1, const float* m2, int count, double thr, double conf,
+                         uint8_t* status) {
+  const int kModelPoints = 7, kMaxIters = 1000;
+  std::fill(status, status + count, (uint8_t)0);
+  if (count < 7) return 0;
+  if (thr <= 0) thr = 3;
+  if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+  std::vector<float> err(count);
+  std::vector<uint8_t> mask(count);
+  float s1[14], s2[14];
+  double models[27], best[9];
+  OcvRng rng;
+  if (count == 7) {
+    const int n = seven_point(m1, m2, models);
+    std::fill(status, status + count, (uint8_t)1);
+    return n > 0 ? count : 0;
+  }
+  if (count >= 15) {  // RANSAC
+    int niters = kMaxIters, best_good = 0;
+    for (int iter = 0; iter < niters; iter++) {
+      if (!draw_subset(m1, m2, count, s1, s2, rng, 10000)) {
+        if (iter == 0) return 0;
+        break;
+      }
+      const int nm = seven_point(s1, s2, models);
+      if (nm <= 0) continue;
+      for (int k = 0; k < nm; k++) {
+        const int good = mark_inliers(m1, m2, count, models + 9 * k, err, mask.data(), thr);
+        if (good > std::max(best_good, kModelPoints - 1)) {
+          std::memcpy(status, mask.data(), count);
+          best_good = good;
+          niters = update_num_iters(conf, (double)(count - good) / count, kModelPoints, niters);
+        }
+      }
+    }
+    return best_good;
+  }
+  // LMedS for 8..14 points
+  const int niters = update_num_iters(conf, 0.45, kModelPoints, kMaxIters);
+  double min_median = DBL_MAX;
+  std::vector<float> errs(count);
+  for (int iter = 0; iter < niters; iter++) {
+    if (!draw_subset(m1, m2, count, s1, s2, rng, 300)) {
+      if (iter == 0) return 0;
+      break;
+    }
+    const int nm = seven_point(s1, s2, models);
+    if (nm <= 0) continue;
+    for (int k = 0; k < nm; k++) {
+      epipolar_errors(m1, m2, count, models + 9 * k, errs.data());
+      std::nth_element(errs.begin(), errs.begin() + count / 2, errs.end());
+      const double median = errs[count / 2];
+      if (median < min_median) {
+        min_median = median;
+        std::memcpy(best, models + 9 * k, sizeof(best));
+      }
+    }
+  }
+  if (min_median < DBL_MAX) {
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (count - kModelPoints)) * std::sqrt(min_median);
+    sigma = std::max(sigma, 0.001);
+    return mark_inliers(m1, m2, count, best, err, status, sigma);
+  }
+  return 0;
+}
+
+}  // namespace host
+}  // namespace esvio

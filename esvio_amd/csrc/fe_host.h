@@ -1,0 +1,41 @@
+// fe_host.h — host-side pieces of trackEvent that stay on the CPU (<= max_cnt points per frame):
+// pinhole lift, cv::circle disc table, the blocked-pixel bitmap, F-matrix RANSAC.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/esvio_fe.h"
+
+namespace esvio {
+namespace host {
+
+// OpenCV rounding helpers [core/fast_math.hpp]
+int cv_round(double v);   // round-half-even; INT_MIN when out of int32 range
+int cv_floor(float v);
+
+// camodocal PinholeCamera::liftProjective (camera_model/src/camera_models/PinholeCamera.cc:450-510)
+void lift_projective(const esvio_fe_camera& cam, double u, double v, double out[3]);
+
+// half-width per |dy| of cv::circle(img, c, r, color, -1) [OpenCV imgproc/drawing.cpp Circle()]
+std::vector<int> disc_halfwidths(int r);
+
+// Blocked-pixel bitmap, one bit per pixel, wpr 32-bit words per row (bit set = 255.0 in the
+// reference's CV_64F mask_event).
+struct BitMask {
+  int W = 0, H = 0, wpr = 0;
+  std::vector<uint32_t> bits;
+  void reset(int w, int h);
+  bool test(int x, int y) const { return (bits[(size_t)y * wpr + (x >> 5)] >> (x & 31)) & 1u; }
+  void stamp_disc(int cx, int cy, int r, const std::vector<int>& hw);
+  void from_bytes(const uint8_t* mask);  // 255 -> set
+};
+
+// cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, conf, status) [OpenCV calib3d fundam.cpp +
+// ptsetreg.cpp]: 7-point minimal solver, RANSAC for n >= 15, LMedS for 8..14, cv::RNG sequence.
+// Returns the number of inliers; status has n entries.
+int find_fundamental_mat(const float* p1, const float* p2, int n, double thr, double conf,
+                         uint8_t* status);
+
+}  // namespace host
+}  // namespace esvio

@@ -1,0 +1,141 @@
+// fe_kernels.h — internal launch API of the gfx950 kernels (fe_kernels.hip).
+// Not part of the public boundary; the C ABI is include/esvio_fe.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace esvio {
+
+// dvs_msgs::Event, 16 B AoS (reference: feature_tracker/src/dvs_msgs/Event.h:42-52)
+struct __attribute__((aligned(16))) EventRec {
+  uint16_t x, y;
+  uint32_t sec, nsec;
+  uint8_t pol;
+  uint8_t pad[3];
+};
+static_assert(sizeof(EventRec) == 16, "event record must be 16 B");
+
+constexpr int kPad = 24;        // image border kept around every pyramid level (>= LK win 21)
+constexpr int kMaxLevels = 4;   // LK maxLevel 3 -> 4 levels
+constexpr int kLkWin = 21;      // cv::Size(21,21) at every call site (feature_tracker.cpp:410..495)
+constexpr int kArcBlock = 256;  // events per block of the Arc* kernel
+constexpr int kMaxDiscR = 63;   // max min_dist supported by the selection kernel
+
+// One image pyramid resident in HBM.  Level l is stored padded by kPad on every side
+// (BORDER_REFLECT_101 for the image, zeros for the Scharr derivatives), row stride
+// w[l]+2*kPad; pointers address the padded buffer's origin.
+struct PyrDesc {
+  uint8_t* img[kMaxLevels];
+  int16_t* deriv[kMaxLevels];  // interleaved (Ix,Iy)
+  int w[kMaxLevels], h[kMaxLevels];
+  int levels;  // maxLevel (inclusive) actually built
+};
+
+enum KernelId {
+  K_SAE_KEYS = 0,
+  K_RADIX_HIST,
+  K_RADIX_SCAN,
+  K_RADIX_SCATTER,
+  K_SAE_APPLY,
+  K_TIME_SURFACE,
+  K_PYR_DOWN,
+  K_PYR_PAD,
+  K_SCHARR,
+  K_LK,
+  K_ARC,
+  K_SELECT,
+  K_COUNT
+};
+
+// ---- SAE update -------------------------------------------------------------------------
+// keys[i] = cam*P + y*W + x (or invalid_key for out-of-sensor events), vals[i] = i, for the
+// virtual concatenation [left; right].
+void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR,
+                     uint32_t nR, int W, int H, uint32_t* keys, uint32_t* vals,
+                     uint32_t invalid_key, unsigned long long* n_rejected);
+
+constexpr int kRadixTile = 2048;  // keys per block
+constexpr int kRadixMaxBits = 8;
+inline uint32_t radix_blocks(uint32_t n) { return (n + kRadixTile - 1) / kRadixTile; }
+// one stable LSD pass on digit (key >> shift) & ((1<<bits)-1); hist must hold
+// radix_blocks(n) << bits words.
+void launch_radix_hist(hipStream_t s, const uint32_t* keys, uint32_t n, int shift, int bits,
+                       uint32_t* hist);
+void launch_radix_scan(hipStream_t s, uint32_t* hist, uint32_t nblk, int bits);
+void launch_radix_scatter(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in,
+                          uint32_t n, int shift, int bits, const uint32_t* offsets,
+                          uint32_t* keys_out, uint32_t* vals_out);
+// walk every same-pixel segment of the sorted keys in stream order applying the SAE rule
+// (event_detector.cc:149-166). L2/S2: double2 per (cam,pixel): {L[0],L[1]} and {S[0],S[1]}.
+void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals, uint32_t n,
+                      const EventRec* evL, uint32_t nL, const EventRec* evR, double2* L2,
+                      double2* S2, double filter_threshold, uint32_t invalid_key);
+
+// ---- time surface -----------------------------------------------------------------------
+// renders ncam cameras (S2 + cam*P) into level-0 interiors of dst[cam]
+void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
+                         double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
+                         int ncam);
+
+// ---- pyramid ----------------------------------------------------------------------------
+void launch_pyr_down(hipStream_t s, const PyrDesc* p, int nimg, int src_level);
+void launch_pyr_pad(hipStream_t s, const PyrDesc* p, int nimg);
+void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg);
+
+// ---- LK ---------------------------------------------------------------------------------
+struct LkArgs {
+  PyrDesc P;  // prev pyramid (+ derivatives)
+  PyrDesc N;  // next pyramid (images only)
+  const float2* prev_pts;
+  float2* next_pts;  // in (USE_INITIAL_FLOW) / out
+  uint8_t* status;
+  const int* n_ptr;  // device count (may be NULL -> n_max)
+  int n_max;
+  int max_level;
+  int max_count;
+  double eps2;
+  int flags;
+};
+void launch_lk(hipStream_t s, const LkArgs& a);
+
+// ---- Arc* + selection -------------------------------------------------------------------
+struct ArcArgs {
+  const EventRec* ev;
+  uint32_t n;
+  const double2* L2;  // left planes
+  const double2* S2;
+  int W, H;
+  double filter_threshold;
+  int border;                  // MIN_DIST + 1
+  const uint8_t* ts;           // left level-0 padded image origin, or NULL (skip TS test)
+  int ts_stride;
+  double ts_lk_threshold;
+  const uint32_t* mask_bits;   // H * wpr words, bit set = blocked; or NULL
+  int wpr;
+  uint8_t* flags;              // [n] or NULL
+  uint32_t* cand_xy;           // [nblk*kArcBlock] per-block ordered candidates (x | y<<16), or NULL
+  uint32_t* cand_idx;          // [nblk*kArcBlock]
+  uint32_t* cand_cnt;          // [nblk]
+};
+void launch_arc(hipStream_t s, const ArcArgs& a);
+
+struct SelectArgs {
+  const uint32_t* cand_xy;
+  const uint32_t* cand_idx;
+  const uint32_t* cand_cnt;
+  uint32_t nblk;
+  uint32_t* comp_xy;   // [>= total candidates] scratch
+  uint32_t* comp_idx;
+  int W, H, wpr;
+  int max_corners;
+  int radius;
+  int8_t hw[kMaxDiscR + 1];  // cv::circle half-widths per |dy|
+  float2* out_pts;           // accepted corners are written at out_pts[out_base + k]
+  int32_t* out_idx;          // may be NULL
+  int out_base;
+  int* n_out;                // number accepted
+  int* n_total;              // out_base + accepted (feeds the LK kernels' n_ptr), may be NULL
+};
+void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes);
+
+}  // namespace esvio

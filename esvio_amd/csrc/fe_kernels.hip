@@ -1,0 +1,841 @@
+// fe_kernels.hip — hand-written CDNA4 (gfx950) kernels of the ESVIO event front-end.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (bit-exactness with the reference's
+// x86-64 -O3 build, which has no FMA contraction, needs every fp64/fp32 mul+add kept separate).
+// wave = 64 lanes everywhere; no MFMA (scatter / stencil / reduction kernels, HBM- or
+// latency-bound).  Reference semantics are cited per kernel (paths relative to the reference
+// tree); OpenCV-internal arithmetic is marked [OpenCV].
+#include "fe_kernels.h"
+
+namespace esvio {
+
+// ============================================================================ helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ros::Time::toSec(): (double)sec + 1e-9*(double)nsec, two roundings
+__device__ __forceinline__ double ev_time(uint32_t sec, uint32_t nsec) {
+  return __dadd_rn((double)sec, __dmul_rn(1e-9, (double)nsec));
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  // cv::borderInterpolate(p, len, BORDER_REFLECT_101) for -len < p < 2*len-1
+  p = p < 0 ? -p : p;
+  return p >= len ? 2 * len - 2 - p : p;
+}
+
+// wave64 sum of a 64-bit integer with DPP (no LDS, no bpermute): xor-butterfly inside each row
+// of 16, then row_bcast:15 / row_bcast:31; the total lands in lane 63 and is read back uniformly.
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#define ESVIO_DPP_STEP(ctrl, rmask)                                                       \
+  {                                                                                        \
+    int lo = (int)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);          \
+    int tlo = __builtin_amdgcn_update_dpp(0, lo, ctrl, rmask, 0xf, false);                 \
+    int thi = __builtin_amdgcn_update_dpp(0, hi, ctrl, rmask, 0xf, false);                 \
+    v += (long long)(((unsigned long long)(unsigned)thi << 32) | (unsigned)tlo);           \
+  }
+  ESVIO_DPP_STEP(0xB1, 0xf)   // quad_perm [1,0,3,2]
+  ESVIO_DPP_STEP(0x4E, 0xf)   // quad_perm [2,3,0,1]
+  ESVIO_DPP_STEP(0x141, 0xf)  // row_half_mirror
+  ESVIO_DPP_STEP(0x140, 0xf)  // row_mirror
+  ESVIO_DPP_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1,3
+  ESVIO_DPP_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2,3
+#undef ESVIO_DPP_STEP
+  int lo = __builtin_amdgcn_readlane((int)(unsigned long long)v, 63);
+  int hi = __builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), 63);
+  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// ============================================================================ SAE keys
+// Coalesced 16 B/lane read of the raw AoS stream; one u32 key + one u32 index out per event.
+__global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL, uint32_t nL,
+                                                  const uint4* __restrict__ evR, uint32_t nR,
+                                                  int W, int H, uint32_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ vals,
+                                                  uint32_t invalid_key,
+                                                  unsigned long long* n_rejected) {
+  const uint32_t n = nL + nR;
+  const uint32_t P = (uint32_t)W * (uint32_t)H;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const bool right = i >= nL;
+    const uint4 e = right ? evR[i - nL] : evL[i];
+    const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
+    const bool ok = x < (uint32_t)W && y < (uint32_t)H;
+    keys[i] = ok ? (right ? P : 0u) + y * (uint32_t)W + x : invalid_key;
+    vals[i] = i;
+    if (!ok) atomicAdd(n_rejected, 1ull);
+  }
+}
+
+void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR,
+                     uint32_t nR, int W, int H, uint32_t* keys, uint32_t* vals,
+                     uint32_t invalid_key, unsigned long long* n_rejected) {
+  const uint32_t n = nL + nR;
+  if (!n) return;
+  uint32_t grid = (n + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_sae_keys, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
+                     (const uint4*)evR, nR, W, H, keys, vals, invalid_key, n_rejected);
+}
+
+// ============================================================================ stable radix sort
+// LSD, <= 8-bit digits, tile = 2048 keys per 256-thread block.  Stability (stream order inside a
+// pixel) is what makes the parallel SAE update equal to the reference's sequential loop.
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n,
+                                                    int shift, int bits,
+                                                    uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[1 << kRadixMaxBits];
+  const int bins = 1 << bits;
+  for (int i = threadIdx.x; i < bins; i += 256) h[i] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kRadixTile;
+#pragma unroll
+  for (int k = 0; k < kRadixTile / 256; k++) {
+    uint32_t i = base + k * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (bins - 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bins; i += 256) hist[(size_t)blockIdx.x * bins + i] = h[i];
+}
+
+// hist[blk][bin] -> exclusive offsets: (sum of all smaller bins) + (same bin in earlier blocks).
+// One 1024-thread block: thread = (part, bin); parts split the block range.
+__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk,
+                                                     int bits) {
+  __shared__ uint32_t part_sum[1024];
+  __shared__ uint32_t bin_base[1 << kRadixMaxBits];
+  const int bins = 1 << bits;
+  const int parts = 1024 / bins;
+  const int bin = threadIdx.x & (bins - 1);
+  const int part = threadIdx.x >> bits;
+  const uint32_t chunk = (nblk + parts - 1) / parts;
+  const uint32_t b0 = part * chunk;
+  const uint32_t b1 = min(b0 + chunk, nblk);
+  uint32_t sum = 0;
+  for (uint32_t b = b0; b < b1; b++) sum += hist[(size_t)b * bins + bin];
+  part_sum[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x < bins) {  // per-bin totals, then exclusive scan over bins (serial: <=256)
+    uint32_t run = 0;
+    for (int p = 0; p < parts; p++) {
+      uint32_t t = part_sum[p * bins + threadIdx.x];
+      part_sum[p * bins + threadIdx.x] = run;  // exclusive over parts
+      run += t;
+    }
+    bin_base[threadIdx.x] = run;  // total of this bin
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < bins; i++) {
+      uint32_t t = bin_base[i];
+      bin_base[i] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  uint32_t run = bin_base[bin] + part_sum[threadIdx.x];
+  for (uint32_t b = b0; b < b1; b++) {
+    uint32_t t = hist[(size_t)b * bins + bin];
+    hist[(size_t)b * bins + bin] = run;
+    run += t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
+                                                       const uint32_t* __restrict__ vals_in,
+                                                       uint32_t n, int shift, int bits,
+                                                       const uint32_t* __restrict__ offsets,
+                                                       uint32_t* __restrict__ keys_out,
+                                                       uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t wave_cnt_s[4][1 << kRadixMaxBits];
+  volatile uint32_t(*wave_cnt)[1 << kRadixMaxBits] = wave_cnt_s;
+  const int bins = 1 << bits;
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  for (int i = threadIdx.x; i < 4 * (1 << kRadixMaxBits); i += 256)
+    (&wave_cnt_s[0][0])[i] = 0;
+  __syncthreads();
+
+  constexpr int ROUNDS = kRadixTile / 256;  // 8 rounds of 64 consecutive keys per wave
+  uint32_t key[ROUNDS], val[ROUNDS], rank[ROUNDS];
+  const uint32_t wbase = blockIdx.x * kRadixTile + wave * (kRadixTile / 4);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint32_t i = wbase + r * 64 + lane;
+    const bool ok = i < n;
+    key[r] = ok ? keys_in[i] : 0xffffffffu;
+    val[r] = ok ? vals_in[i] : 0u;
+    const uint32_t d = (key[r] >> shift) & (bins - 1);
+    // match-any on the digit: lanes holding the same digit, in lane (= stream) order
+    unsigned long long m = __ballot(ok);
+    for (int b = 0; b < bits; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t before = __popcll(m & lt);
+    const uint32_t cnt = __popcll(m);
+    uint32_t base = 0;
+    if (ok) base = wave_cnt[wave][d];
+    rank[r] = base + before;
+    if (ok && before == 0) wave_cnt[wave][d] = base + cnt;  // one leader per digit
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < bins) {
+    uint32_t run = offsets[(size_t)blockIdx.x * bins + threadIdx.x];
+    for (int w = 0; w < 4; w++) {
+      uint32_t t = wave_cnt[w][threadIdx.x];
+      wave_cnt[w][threadIdx.x] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint32_t i = wbase + r * 64 + lane;
+    if (i < n) {
+      const uint32_t d = (key[r] >> shift) & (bins - 1);
+      const uint32_t pos = wave_cnt[wave][d] + rank[r];
+      keys_out[pos] = key[r];
+      vals_out[pos] = val[r];
+    }
+  }
+}
+
+void launch_radix_hist(hipStream_t s, const uint32_t* keys, uint32_t n, int shift, int bits,
+                       uint32_t* hist) {
+  hipLaunchKernelGGL(k_radix_hist, dim3(radix_blocks(n)), dim3(256), 0, s, keys, n, shift, bits,
+                     hist);
+}
+void launch_radix_scan(hipStream_t s, uint32_t* hist, uint32_t nblk, int bits) {
+  hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, hist, nblk, bits);
+}
+void launch_radix_scatter(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in,
+                          uint32_t n, int shift, int bits, const uint32_t* offsets,
+                          uint32_t* keys_out, uint32_t* vals_out) {
+  hipLaunchKernelGGL(k_radix_scatter, dim3(radix_blocks(n)), dim3(256), 0, s, keys_in, vals_in, n,
+                     shift, bits, offsets, keys_out, vals_out);
+}
+
+// ============================================================================ SAE apply
+// createSAE_left/right (event_detector.cc:149-166, :212-228) for a whole batch.  After the stable
+// sort every pixel's events are one contiguous segment in stream order; the segment's head lane
+// walks it with the four plane values in registers:
+//     pass = (t > L[p] + thr) || (L[!p] > L[p]);  L[p] = t;  if (pass) S[p] = t;
+__global__ __launch_bounds__(256) void k_sae_apply(const uint32_t* __restrict__ keys,
+                                                   const uint32_t* __restrict__ vals, uint32_t n,
+                                                   const uint4* __restrict__ evL, uint32_t nL,
+                                                   const uint4* __restrict__ evR,
+                                                   double2* __restrict__ L2,
+                                                   double2* __restrict__ S2, double thr,
+                                                   uint32_t invalid_key) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  if (k == invalid_key) return;
+  if (i > 0 && keys[i - 1] == k) return;  // not a segment head
+  double2 Lv = L2[k], Sv = S2[k];
+  double L[2] = {Lv.x, Lv.y}, S[2] = {Sv.x, Sv.y};
+  for (uint32_t j = i; j < n && keys[j] == k; j++) {
+    const uint32_t idx = vals[j];
+    const uint4 e = idx >= nL ? evR[idx - nL] : evL[idx];
+    const double t = ev_time(e.y, e.z);
+    const bool p = (e.w & 0xffu) != 0;
+    const double t_last = p ? L[1] : L[0];
+    const double t_last_inv = p ? L[0] : L[1];
+    const bool pass = (t > __dadd_rn(t_last, thr)) || (t_last_inv > t_last);
+    if (p) {
+      L[1] = t;
+      if (pass) S[1] = t;
+    } else {
+      L[0] = t;
+      if (pass) S[0] = t;
+    }
+  }
+  L2[k] = make_double2(L[0], L[1]);
+  S2[k] = make_double2(S[0], S[1]);
+}
+
+void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals, uint32_t n,
+                      const EventRec* evL, uint32_t nL, const EventRec* evR, double2* L2,
+                      double2* S2, double filter_threshold, uint32_t invalid_key) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_sae_apply, dim3((n + 255) / 256), dim3(256), 0, s, keys, vals, n,
+                     (const uint4*)evL, nL, (const uint4*)evR, L2, S2, filter_threshold,
+                     invalid_key);
+}
+
+// ============================================================================ time surface
+// SAEtoTimeSurface_left/right (event_detector.cc:230-305): one 16 B {S0,S1} read and one u8 write
+// per pixel.  u8 = saturate_cast<uchar>(cvRound(v*127.5+127.5)) (ignore_polarity: v*255+0).
+__device__ __forceinline__ uint8_t ts_pixel(double2 s, double t_sync, double decay_sec,
+                                            int ignore_polarity) {
+  const bool pos = s.y > s.x;
+  const double m = pos ? s.y : s.x;
+  double v = 0.0;
+  if (m > 0) {
+    const double dt = __dsub_rn(t_sync, m);
+    v = exp(-dt / decay_sec);
+    if (!ignore_polarity) v = pos ? v : -v;
+  }
+  const double sc = ignore_polarity ? __dadd_rn(__dmul_rn(v, 255.0), 0.0)
+                                    : __dadd_rn(__dmul_rn(v, 127.5), 127.5);
+  // cvRound: SSE2 cvtsd2si -> "integer indefinite" (INT_MIN) when out of int32 range / NaN,
+  // which saturate_cast<uchar> then maps to 0 [OpenCV]
+  int iv;
+  if (!(sc > -2147483648.5 && sc < 2147483647.5)) {
+    iv = INT_MIN;
+  } else {
+    const double r = rint(sc);
+    iv = (r > 2147483647.0 || r < -2147483648.0) ? INT_MIN : (int)r;
+  }
+  return (uint8_t)((unsigned)iv <= 255u ? iv : iv > 0 ? 255 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_time_surface(const double2* __restrict__ S2, int W,
+                                                      int H, double t_sync, double decay_sec,
+                                                      int ignore_polarity,
+                                                      uint8_t* __restrict__ dst0,
+                                                      uint8_t* __restrict__ dst1) {
+  const int cam = blockIdx.y;
+  const uint32_t P = (uint32_t)W * H;
+  const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= P) return;
+  uint8_t* dst = cam ? dst1 : dst0;
+  const double2 s = S2[(size_t)cam * P + px];
+  const uint32_t y = px / (uint32_t)W, x = px - y * (uint32_t)W;
+  const int stride = W + 2 * kPad;
+  dst[(size_t)(y + kPad) * stride + x + kPad] = ts_pixel(s, t_sync, decay_sec, ignore_polarity);
+}
+
+void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
+                         double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
+                         int ncam) {
+  const uint32_t P = (uint32_t)W * H;
+  hipLaunchKernelGGL(k_time_surface, dim3((P + 255) / 256, ncam), dim3(256), 0, s, S2, W, H,
+                     t_sync, decay_sec, ignore_polarity, dst0, dst1);
+}
+
+// ============================================================================ pyramid
+struct PyrPack {
+  PyrDesc p[3];
+};
+
+// cv::pyrDown u8 [OpenCV imgproc/pyramids.cpp]: [1 4 6 4 1]x[1 4 6 4 1], (sum+128)>>8,
+// BORDER_REFLECT_101, dst size ((w+1)/2,(h+1)/2). Reads the source interior only.
+__global__ __launch_bounds__(256) void k_pyr_down(PyrPack pk, int src_level) {
+  const PyrDesc& p = pk.p[blockIdx.z];
+  const int sw = p.w[src_level], sh = p.h[src_level];
+  const int dw = p.w[src_level + 1], dh = p.h[src_level + 1];
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= dw || y >= dh) return;
+  const int sstride = sw + 2 * kPad, dstride = dw + 2 * kPad;
+  const uint8_t* src = p.img[src_level] + (size_t)kPad * sstride + kPad;
+  const int wk[5] = {1, 4, 6, 4, 1};
+  int xs[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) xs[k] = reflect101(2 * x + k - 2, sw);
+  int acc = 0;
+#pragma unroll
+  for (int ky = 0; ky < 5; ky++) {
+    const uint8_t* row = src + (size_t)reflect101(2 * y + ky - 2, sh) * sstride;
+    int r = 0;
+#pragma unroll
+    for (int kx = 0; kx < 5; kx++) r += wk[kx] * (int)row[xs[kx]];
+    acc += wk[ky] * r;
+  }
+  p.img[src_level + 1][(size_t)(y + kPad) * dstride + x + kPad] = (uint8_t)((acc + 128) >> 8);
+}
+
+// copyMakeBorder(level, BORDER_REFLECT_101) for every level [OpenCV buildOpticalFlowPyramid]
+__global__ __launch_bounds__(256) void k_pyr_pad(PyrPack pk) {
+  const PyrDesc& p = pk.p[blockIdx.z];
+  const int level = blockIdx.y;
+  if (level > p.levels) return;
+  const int w = p.w[level], h = p.h[level];
+  const int pw = w + 2 * kPad, ph = h + 2 * kPad;
+  // enumerate only the border ring: top+bottom bands (pw*kPad each), then left+right bands
+  const int band = pw * kPad;
+  const int side = kPad * h;
+  const int total = 2 * band + 2 * side;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int x, y;
+    if (i < band) {
+      y = i / pw;
+      x = i - y * pw;
+    } else if (i < 2 * band) {
+      const int j = i - band;
+      y = j / pw;
+      x = j - y * pw;
+      y += kPad + h;
+    } else if (i < 2 * band + side) {
+      const int j = i - 2 * band;
+      y = j / kPad;
+      x = j - y * kPad;
+      y += kPad;
+    } else {
+      const int j = i - 2 * band - side;
+      y = j / kPad;
+      x = j - y * kPad;
+      y += kPad;
+      x += kPad + w;
+    }
+    const int sx = reflect101(x - kPad, w), sy = reflect101(y - kPad, h);
+    uint8_t* img = p.img[level];
+    img[(size_t)y * pw + x] = img[(size_t)(sy + kPad) * pw + sx + kPad];
+  }
+  (void)ph;
+}
+
+// calcSharrDeriv [OpenCV video/lkpyramid.cpp]: Ix = [3 10 3]^T (x) [-1 0 1],
+// Iy = [-1 0 1]^T (x) [3 10 3], REFLECT_101 (read from the padded image), int16 interleaved.
+__global__ __launch_bounds__(256) void k_scharr(PyrPack pk) {
+  const PyrDesc& p = pk.p[blockIdx.z];
+  const int level = blockIdx.y;
+  if (level > p.levels) return;
+  const int w = p.w[level], h = p.h[level];
+  const int stride = w + 2 * kPad;
+  const uint8_t* img = p.img[level] + (size_t)kPad * stride + kPad;
+  int* deriv = (int*)(p.deriv[level]) + (size_t)kPad * stride + kPad;
+  const int total = w * h;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int y = i / w, x = i - y * w;
+    const uint8_t* r0 = img + (ptrdiff_t)(y - 1) * stride + x;
+    const uint8_t* r1 = r0 + stride;
+    const uint8_t* r2 = r1 + stride;
+    const int a0 = r0[-1], a1 = r0[0], a2 = r0[1];
+    const int b0 = r1[-1], b2 = r1[1];
+    const int c0 = r2[-1], c1 = r2[0], c2 = r2[1];
+    const int ix = ((a2 + c2) * 3 + b2 * 10) - ((a0 + c0) * 3 + b0 * 10);
+    const int iy = ((c2 - a2) + (c0 - a0)) * 3 + (c1 - a1) * 10;
+    deriv[(size_t)y * stride + x] = (int)(((unsigned)(uint16_t)(int16_t)iy << 16) | (uint16_t)(int16_t)ix);
+  }
+}
+
+static PyrPack make_pack(const PyrDesc* p, int nimg) {
+  PyrPack pk;
+  for (int i = 0; i < nimg; i++) pk.p[i] = p[i];
+  for (int i = nimg; i < 3; i++) pk.p[i] = p[0];
+  return pk;
+}
+
+void launch_pyr_down(hipStream_t s, const PyrDesc* p, int nimg, int src_level) {
+  const int dw = p[0].w[src_level + 1], dh = p[0].h[src_level + 1];
+  hipLaunchKernelGGL(k_pyr_down, dim3((dw + 31) / 32, (dh + 7) / 8, nimg), dim3(256), 0, s,
+                     make_pack(p, nimg), src_level);
+}
+void launch_pyr_pad(hipStream_t s, const PyrDesc* p, int nimg) {
+  const int pw = p[0].w[0] + 2 * kPad;
+  const int total = 2 * pw * kPad + 2 * kPad * p[0].h[0];
+  hipLaunchKernelGGL(k_pyr_pad, dim3((total + 255) / 256, p[0].levels + 1, nimg), dim3(256), 0, s,
+                     make_pack(p, nimg));
+}
+void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg) {
+  const int total = p[0].w[0] * p[0].h[0];
+  int gx = (total + 255) / 256;
+  hipLaunchKernelGGL(k_scharr, dim3(gx, p[0].levels + 1, nimg), dim3(256), 0, s,
+                     make_pack(p, nimg));
+}
+
+// ============================================================================ pyramidal LK
+// cv::calcOpticalFlowPyrLK's LKTrackerInvoker [OpenCV video/lkpyramid.cpp], one wave64 per point,
+// all levels in one launch.  The 21x21 window (441 px) is spread 7 px per lane; the patch
+// (I, Ix, Iy) lives in registers across iterations; the normal-equation sums A11/A12/A22 and
+// the mismatch vector b1/b2 are exact int64 wave reductions (OpenCV's integer-accumulator build
+// of the same loop), so results do not depend on reduction order.
+#define CV_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+__global__ __launch_bounds__(256) void k_lk(LkArgs a) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int pt = blockIdx.x * 4 + wave;
+  const int n = a.n_ptr ? *a.n_ptr : a.n_max;
+  if (pt >= n || pt >= a.n_max) return;
+
+  constexpr int WIN = kLkWin, NPX = WIN * WIN, R = (NPX + 63) / 64;  // 7 px per lane
+  const float halfWin = (WIN - 1) * 0.5f;
+  const int W_BITS = 14;
+  const float FLT_SCALE = 1.f / (1 << 20);
+
+  const float2 prev0 = a.prev_pts[pt];
+  float2 np = (a.flags & 4) ? a.next_pts[pt] : make_float2(0.f, 0.f);  // nextPts[ptidx]
+  int st = 1;
+
+  // per-lane window coordinates
+  int wx[R], wy[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int idx = r * 64 + lane;
+    wy[r] = idx / WIN;
+    wx[r] = idx - wy[r] * WIN;
+  }
+
+  for (int level = a.max_level; level >= 0; level--) {
+    const int cols = a.P.w[level], rows = a.P.h[level];
+    const int stride = cols + 2 * kPad;
+    const uint8_t* I = a.P.img[level] + (size_t)kPad * stride + kPad;
+    const uint8_t* J = a.N.img[level] + (size_t)kPad * stride + kPad;
+    const int* dI = (const int*)a.P.deriv[level] + (size_t)kPad * stride + kPad;
+
+    const float sc = 1.f / (float)(1 << level);
+    float prevX = prev0.x * sc, prevY = prev0.y * sc;
+    float nextX, nextY;
+    if (level == a.max_level) {
+      if (a.flags & 4) {
+        nextX = np.x * sc;
+        nextY = np.y * sc;
+      } else {
+        nextX = prevX;
+        nextY = prevY;
+      }
+    } else {
+      nextX = np.x * 2.f;
+      nextY = np.y * 2.f;
+    }
+    np = make_float2(nextX, nextY);
+
+    prevX -= halfWin;
+    prevY -= halfWin;
+    const int iprevX = (int)floorf(prevX), iprevY = (int)floorf(prevY);
+    if (iprevX < -WIN || iprevX >= cols || iprevY < -WIN || iprevY >= rows) {
+      if (level == 0) st = 0;
+      continue;
+    }
+    float fa = prevX - iprevX, fb = prevY - iprevY;
+    int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+    int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+    int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+    int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+
+    int pI[R], pIx[R], pIy[R];
+    long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      pI[r] = 0;
+      pIx[r] = 0;
+      pIy[r] = 0;
+      if (r * 64 + lane < NPX) {
+        const ptrdiff_t o = (ptrdiff_t)(wy[r] + iprevY) * stride + iprevX + wx[r];
+        const uint8_t* src = I + o;
+        const int* ds = dI + o;
+        const int ival = CV_DESCALE((int)src[0] * iw00 + (int)src[1] * iw01 +
+                                        (int)src[stride] * iw10 + (int)src[stride + 1] * iw11,
+                                    W_BITS - 5);
+        const int d00 = ds[0], d01 = ds[1], d10 = ds[stride], d11 = ds[stride + 1];
+        const int ixval = CV_DESCALE((int)(int16_t)d00 * iw00 + (int)(int16_t)d01 * iw01 +
+                                         (int)(int16_t)d10 * iw10 + (int)(int16_t)d11 * iw11,
+                                     W_BITS);
+        const int iyval = CV_DESCALE((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 +
+                                         (d11 >> 16) * iw11,
+                                     W_BITS);
+        pI[r] = (int)(int16_t)ival;
+        pIx[r] = (int)(int16_t)ixval;
+        pIy[r] = (int)(int16_t)iyval;
+        sA11 += (long long)(ixval * ixval);
+        sA12 += (long long)(ixval * iyval);
+        sA22 += (long long)(iyval * iyval);
+      }
+    }
+    const float A11 = (float)wave_sum_i64(sA11) * FLT_SCALE;
+    const float A12 = (float)wave_sum_i64(sA12) * FLT_SCALE;
+    const float A22 = (float)wave_sum_i64(sA22) * FLT_SCALE;
+
+    float D = A11 * A22 - A12 * A12;
+    const float minEig =
+        (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+    if (minEig < 1e-4f || D < 1.1920929e-07f /*FLT_EPSILON*/) {
+      if (level == 0) st = 0;
+      continue;
+    }
+    D = 1.f / D;
+
+    nextX -= halfWin;
+    nextY -= halfWin;
+    float prevDx = 0.f, prevDy = 0.f;
+    for (int j = 0; j < a.max_count; j++) {
+      const int inextX = (int)floorf(nextX), inextY = (int)floorf(nextY);
+      if (inextX < -WIN || inextX >= cols || inextY < -WIN || inextY >= rows) {
+        if (level == 0) st = 0;
+        break;
+      }
+      fa = nextX - inextX;
+      fb = nextY - inextY;
+      iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+      iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+      iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+      iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+      int sb1 = 0, sb2 = 0;  // 7 terms of <= 2^25 each fit int32
+      long long lb1 = 0, lb2 = 0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (r * 64 + lane < NPX) {
+          const uint8_t* Jp = J + (ptrdiff_t)(wy[r] + inextY) * stride + inextX + wx[r];
+          const int diff = CV_DESCALE((int)Jp[0] * iw00 + (int)Jp[1] * iw01 +
+                                          (int)Jp[stride] * iw10 + (int)Jp[stride + 1] * iw11,
+                                      W_BITS - 5) -
+                           pI[r];
+          sb1 += diff * pIx[r];
+          sb2 += diff * pIy[r];
+        }
+      }
+      lb1 = sb1;
+      lb2 = sb2;
+      const float b1 = (float)wave_sum_i64(lb1) * FLT_SCALE;
+      const float b2 = (float)wave_sum_i64(lb2) * FLT_SCALE;
+      const float dx = (A12 * b2 - A22 * b1) * D;
+      const float dy = (A12 * b1 - A11 * b2) * D;
+      nextX += dx;
+      nextY += dy;
+      np = make_float2(nextX + halfWin, nextY + halfWin);
+      if ((double)dx * (double)dx + (double)dy * (double)dy <= a.eps2) break;
+      if (j > 0 && (double)fabsf(dx + prevDx) < 0.01 && (double)fabsf(dy + prevDy) < 0.01) {
+        np.x -= dx * 0.5f;
+        np.y -= dy * 0.5f;
+        break;
+      }
+      prevDx = dx;
+      prevDy = dy;
+    }
+    if (st && level == 0) {  // the `err` block of the tracker re-validates the final position
+      const float fx = np.x - halfWin, fy = np.y - halfWin;
+      const int ix = (int)floorf(fx), iy = (int)floorf(fy);
+      if (ix < -WIN || ix >= cols || iy < -WIN || iy >= rows) st = 0;
+    }
+  }
+  if (lane == 0) {
+    a.next_pts[pt] = np;
+    a.status[pt] = (uint8_t)st;
+  }
+}
+
+void launch_lk(hipStream_t s, const LkArgs& a) {
+  if (a.n_max <= 0) return;
+  hipLaunchKernelGGL(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
+}
+
+// ============================================================================ Arc*
+// event_detector.cc:14-22
+__constant__ int8_t c_small[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},  {3, 0},  {3, -1},
+                                      {2, -2}, {1, -3},  {0, -3},  {-1, -3}, {-2, -2}, {-3, -1},
+                                      {-3, 0}, {-3, 1},  {-2, 2},  {-1, 3}};
+__constant__ int8_t c_large[20][2] = {{0, 4},   {1, 4},   {2, 3},   {3, 2},  {4, 1},  {4, 0},  {4, -1},
+                                      {3, -2},  {2, -3},  {1, -4},  {0, -4}, {-1, -4}, {-2, -3}, {-3, -2},
+                                      {-4, -1}, {-4, 0},  {-4, 1},  {-3, 2}, {-2, 3},  {-1, 4}};
+
+// one ring of isCorner (event_detector.cc:337-435 small / :438-541 large). `ring` is this
+// thread's private column of an LDS tile laid out [ring index][thread] (bank-conflict free).
+template <int N, int KMIN, int KMAX>
+__device__ __forceinline__ bool arc_ring(const volatile double* ring, int tstride) {
+  double segment_new_min_t = ring[0];
+  int arc_right_idx = 0;
+#pragma unroll
+  for (int i = 1; i < N; i++) {
+    const double t = ring[i * tstride];
+    if (t > segment_new_min_t) {
+      segment_new_min_t = t;
+      arc_right_idx = i;
+    }
+  }
+  int arc_left_idx = (arc_right_idx - 1 + N) % N;
+  arc_right_idx = (arc_right_idx + 1) % N;
+  double arc_left_value = ring[arc_left_idx * tstride];
+  double arc_right_value = ring[arc_right_idx * tstride];
+  double arc_left_min_t = arc_left_value;
+  double arc_right_min_t = arc_right_value;
+  int newest_segment_size = KMIN;
+  for (int iteration = 1; iteration < N; iteration++) {
+    const bool right = arc_right_value > arc_left_value;
+    const double v = right ? arc_right_value : arc_left_value;
+    const double mn = right ? arc_right_min_t : arc_left_min_t;
+    if (iteration < KMIN) {
+      if (mn < segment_new_min_t) segment_new_min_t = mn;
+    } else if (v >= segment_new_min_t) {
+      newest_segment_size = iteration + 1;
+      if (mn < segment_new_min_t) segment_new_min_t = mn;
+    }
+    if (right) {
+      arc_right_idx = (arc_right_idx + 1) % N;
+      arc_right_value = ring[arc_right_idx * tstride];
+      if (arc_right_value < arc_right_min_t) arc_right_min_t = arc_right_value;
+    } else {
+      arc_left_idx = (arc_left_idx - 1 + N) % N;
+      arc_left_value = ring[arc_left_idx * tstride];
+      if (arc_left_value < arc_left_min_t) arc_left_min_t = arc_left_value;
+    }
+  }
+  return (newest_segment_size <= KMAX) ||
+         ((newest_segment_size >= (N - KMAX)) && (newest_segment_size <= (N - KMIN)));
+}
+
+// EventDetector::isCorner (event_detector.cc:308-544) for every event of the batch in parallel,
+// fused with the two cheap tests Event_FeaturesToTrack does first (feature_tracker.cpp:25-26:
+// blocked-mask bit and time-surface == TS_LK_THRESHOLD), and an in-block ordered compaction of
+// the survivors (ballot + popcount), so the sequential greedy stage only sees candidates.
+__global__ __launch_bounds__(kArcBlock) void k_arc(ArcArgs a) {
+  __shared__ double ring_s[20 * kArcBlock];  // 40 KiB: [ring idx][thread]
+  __shared__ uint32_t wave_cnt[kArcBlock / 64];
+  const uint32_t i = blockIdx.x * kArcBlock + threadIdx.x;
+  bool corner = false;
+  uint32_t x = 0, y = 0;
+  if (i < a.n) {
+    const uint4 e = ((const uint4*)a.ev)[i];
+    x = e.x & 0xffffu;
+    y = e.x >> 16;
+    if (x < (uint32_t)a.W && y < (uint32_t)a.H) {
+      const int pol = (e.w & 0xffu) ? 1 : 0;
+      const uint32_t px = y * (uint32_t)a.W + x;
+      bool ok = true;
+      if (a.mask_bits) ok = !((a.mask_bits[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+      if (ok && a.ts)
+        ok = (double)a.ts[(size_t)(y + kPad) * a.ts_stride + x + kPad] != a.ts_lk_threshold;
+      if (ok) {
+        const double et = ev_time(e.y, e.z);
+        const double2 Lv = a.L2[px];
+        const double t_last = pol ? Lv.y : Lv.x;
+        const double t_last_inv = pol ? Lv.x : Lv.y;
+        if ((et > __dadd_rn(t_last, a.filter_threshold)) || (t_last_inv > t_last)) ok = false;
+      }
+      if (ok && ((int)x < a.border || (int)x >= a.W - a.border || (int)y < a.border ||
+                 (int)y >= a.H - a.border))
+        ok = false;
+      if (ok) {
+        const double* S = (const double*)a.S2 + pol;
+        volatile double* ring = ring_s + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          ring[k * kArcBlock] =
+              S[2 * ((size_t)(y + c_small[k][1]) * a.W + (x + c_small[k][0]))];
+        if (arc_ring<16, 4, 6>(ring, kArcBlock)) {
+#pragma unroll
+          for (int k = 0; k < 20; k++)
+            ring[k * kArcBlock] =
+                S[2 * ((size_t)(y + c_large[k][1]) * a.W + (x + c_large[k][0]))];
+          corner = arc_ring<20, 5, 8>(ring, kArcBlock);
+        }
+      }
+    }
+    if (a.flags) a.flags[i] = corner ? 1 : 0;
+  }
+  if (a.cand_cnt) {
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const unsigned long long m = __ballot(corner);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wave_cnt[w];
+    if (corner) {
+      const uint32_t pos = blockIdx.x * kArcBlock + base + __popcll(m & ((1ull << lane) - 1ull));
+      a.cand_xy[pos] = x | (y << 16);
+      a.cand_idx[pos] = i;
+    }
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < kArcBlock / 64; w++) t += wave_cnt[w];
+      a.cand_cnt[blockIdx.x] = t;
+    }
+  }
+}
+
+void launch_arc(hipStream_t s, const ArcArgs& a) {
+  if (!a.n) return;
+  hipLaunchKernelGGL(k_arc, dim3((a.n + kArcBlock - 1) / kArcBlock), dim3(kArcBlock), 0, s, a);
+}
+
+// ============================================================================ greedy selection
+// Event_FeaturesToTrack (feature_tracker.cpp:13-38): candidates in stream order; accept iff the
+// pixel is not blocked; stamp cv::circle(r = MIN_DIST, filled) [OpenCV midpoint disc]; stop at
+// max_corners.  One 1024-thread block: all waves compact the per-block candidate lists, then
+// wave 0 runs the inherently sequential greedy with the blocked-bitmap in LDS.
+__global__ __launch_bounds__(1024) void k_select(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  volatile uint32_t* bitmap = lds;                  // H * wpr words
+  uint32_t* scan = lds + (size_t)a.H * a.wpr;      // 1024 + 1 words
+  const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+  for (int i = tid; i < a.H * a.wpr; i += 1024) lds[i] = 0;
+
+  // ---- ordered compaction of the per-arc-block lists ----
+  uint32_t total = 0;
+  for (uint32_t b0 = 0; b0 < a.nblk; b0 += 1024) {
+    const uint32_t b = b0 + tid;
+    const uint32_t c = b < a.nblk ? a.cand_cnt[b] : 0;
+    // block exclusive scan of c
+    uint32_t v = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(v, o);
+      if (lane >= o) v += t;
+    }
+    __syncthreads();
+    if (lane == 63) scan[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t run = 0;
+      for (int w = 0; w < 16; w++) {
+        const uint32_t t = scan[w];
+        scan[w] = run;
+        run += t;
+      }
+      scan[16] = run;
+    }
+    __syncthreads();
+    const uint32_t off = total + scan[wave] + v - c;
+    for (uint32_t k = 0; k < c; k++) {
+      a.comp_xy[off + k] = a.cand_xy[(size_t)b * kArcBlock + k];
+      a.comp_idx[off + k] = a.cand_idx[(size_t)b * kArcBlock + k];
+    }
+    total += scan[16];
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (wave != 0) return;
+
+  // ---- sequential greedy, wave 0 ----
+  int accepted = 0;
+  const int r = a.radius;
+  for (uint32_t base = 0; base < total && accepted < a.max_corners; base += 64) {
+    const uint32_t i = base + lane;
+    const bool have = i < total;
+    const uint32_t xy = have ? a.comp_xy[i] : 0u;
+    const uint32_t ci = have ? a.comp_idx[i] : 0u;
+    const int x = xy & 0xffff, y = xy >> 16;
+    bool alive = have && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+    while (accepted < a.max_corners) {
+      const unsigned long long m = __ballot(alive);
+      if (!m) break;
+      const int first = __ffsll((long long)m) - 1;
+      const int ax = __builtin_amdgcn_readlane(x, first);
+      const int ay = __builtin_amdgcn_readlane(y, first);
+      const int ai = __builtin_amdgcn_readlane((int)ci, first);
+      if (lane == 0) {
+        a.out_pts[a.out_base + accepted] = make_float2((float)ax, (float)ay);
+        if (a.out_idx) a.out_idx[accepted] = ai;
+      }
+      accepted++;
+      // stamp the disc: one lane per row
+      for (int row = lane; row < 2 * r + 1; row += 64) {
+        const int yy = ay - r + row;
+        if (yy < 0 || yy >= a.H) continue;
+        const int hw = a.hw[row < r ? r - row : row - r];
+        if (hw < 0) continue;
+        const int x0 = max(ax - hw, 0), x1 = min(ax + hw, a.W - 1);
+        if (x1 < x0) continue;
+        for (int w = x0 >> 5; w <= (x1 >> 5); w++) {
+          const int lo = max(x0 - (w << 5), 0), hi = min(x1 - (w << 5), 31);
+          const uint32_t bits = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+          bitmap[yy * a.wpr + w] |= bits;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      alive = alive && lane > first && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+    }
+  }
+  if (lane == 0) {
+    *a.n_out = accepted;
+    if (a.n_total) *a.n_total = a.out_base + accepted;
+  }
+}
+
+void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
+  hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), lds_bytes, s, a);
+}
+
+}  // namespace esvio

@@ -1,0 +1,381 @@
+"""Host-side mirror of the reference's feature_tracker interface over the C ABI.
+
+``FeatureTracker`` / ``EventDetector`` keep the reference's names and argument meaning
+(feature_tracker/src/feature_tracker.h:49-173, event_detector/event_detector.h:18-80) so the
+parity tests read like calls into the reference.  Everything here is ctypes plumbing over
+``libesvio_fe.so`` (include/esvio_fe.h); there is no Python compute path and no CPU fallback —
+if the library or a GPU is missing, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST, DEVICE = 0, 1
+LK_USE_INITIAL_FLOW = 4
+
+
+class FrontendError(RuntimeError):
+    pass
+
+
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("decay_ms", C.c_double),
+        ("ignore_polarity", C.c_int32), ("median_blur_kernel_size", C.c_int32),
+        ("feature_filter_threshold", C.c_double),
+        ("ts_lk_threshold", C.c_double),
+        ("max_cnt", C.c_int32), ("min_dist", C.c_int32),
+        ("flow_back", C.c_int32), ("equalize", C.c_int32),
+        ("f_threshold", C.c_double),
+        ("f_ransac", C.c_int32), ("lk_accum", C.c_int32),
+        ("focal_length", C.c_int32), ("device", C.c_int32),
+        ("cam", Camera * 2),
+    ]
+
+
+class Tracks(C.Structure):
+    _fields_ = [
+        ("n_left", C.c_int32), ("n_right", C.c_int32),
+        ("ids", C.c_void_p), ("track_cnt", C.c_void_p),
+        ("cur_pts", C.c_void_p), ("cur_un_pts", C.c_void_p), ("pts_velocity", C.c_void_p),
+        ("ids_right", C.c_void_p), ("cur_right_pts", C.c_void_p),
+        ("cur_un_right_pts", C.c_void_p), ("right_pts_velocity", C.c_void_p),
+    ]
+
+
+# every symbol include/esvio_fe.h declares
+ABI_SYMBOLS = [
+    "esvio_fe_create", "esvio_fe_destroy", "esvio_fe_reset", "esvio_fe_last_error",
+    "esvio_fe_version", "esvio_fe_create_sae", "esvio_fe_create_sae_stereo",
+    "esvio_fe_sae_to_time_surface", "esvio_fe_is_corner", "esvio_fe_features_to_track",
+    "esvio_fe_get_sae", "esvio_fe_set_sae", "esvio_fe_calc_optical_flow_pyr_lk",
+    "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
+    "esvio_fe_track_event", "esvio_fe_get_time_surface", "esvio_fe_set_profiling",
+    "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
+    "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
+]
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "libesvio_fe.so")
+
+
+def load_library(build_if_missing=True):
+    """dlopen libesvio_fe.so (building it in-tree if absent).  Raises if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if build_if_missing and _build.needs_build():
+        _build.build()
+    if not os.path.exists(path):
+        raise FrontendError("libesvio_fe.so is missing: run `python -m esvio_amd.build`")
+    L = C.CDLL(path)
+    vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+    L.esvio_fe_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.esvio_fe_destroy.argtypes = [vp]
+    L.esvio_fe_reset.argtypes = [vp]
+    L.esvio_fe_last_error.restype = C.c_char_p
+    L.esvio_fe_last_error.argtypes = [vp]
+    L.esvio_fe_version.restype = C.c_char_p
+    L.esvio_fe_create_sae.argtypes = [vp, i, vp, sz, i, C.POINTER(C.c_uint64)]
+    L.esvio_fe_create_sae_stereo.argtypes = [vp, vp, sz, vp, sz, i, C.POINTER(C.c_uint64)]
+    L.esvio_fe_sae_to_time_surface.argtypes = [vp, i, d, vp]
+    L.esvio_fe_is_corner.argtypes = [vp, vp, sz, i, vp]
+    L.esvio_fe_features_to_track.argtypes = [vp, vp, sz, i, i, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.esvio_fe_get_sae.argtypes = [vp, i, vp, vp, vp, vp]
+    L.esvio_fe_set_sae.argtypes = [vp, i, vp, vp, vp, vp]
+    L.esvio_fe_calc_optical_flow_pyr_lk.argtypes = [vp, vp, vp, i, i, vp, vp, vp, i, i, i, d, i]
+    L.esvio_fe_build_pyramid.argtypes = [vp, vp, i, i, i, i, vp, vp, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.esvio_fe_find_fundamental_mat.argtypes = [vp, vp, i, d, d, vp, C.POINTER(C.c_int32)]
+    L.esvio_fe_lift_projective.argtypes = [C.POINTER(Camera), d, d, vp]
+    L.esvio_fe_track_event.argtypes = [vp, d, vp, sz, vp, sz, i, i, C.POINTER(Tracks)]
+    L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
+    L.esvio_fe_set_profiling.argtypes = [vp, i]
+    L.esvio_fe_kernel_name.restype = C.c_char_p
+    L.esvio_fe_kernel_name.argtypes = [i]
+    L.esvio_fe_get_kernel_stats.argtypes = [vp, i, C.POINTER(d), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64)]
+    L.esvio_fe_reset_kernel_stats.argtypes = [vp]
+    L.esvio_fe_stream.restype = vp
+    L.esvio_fe_stream.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def make_config(W, H, device=-1, **kw):
+    """esvio_fe_config with the shipped defaults of config/esio_DSEC/esio.yaml:77-94
+    (equalize forced 0) unless overridden."""
+    c = Config()
+    c.width, c.height = W, H
+    c.decay_ms = kw.get("decay_ms", 20.0)
+    c.ignore_polarity = kw.get("ignore_polarity", 0)
+    c.median_blur_kernel_size = kw.get("median_blur_kernel_size", 0)
+    c.feature_filter_threshold = kw.get("feature_filter_threshold", 0.01)
+    c.ts_lk_threshold = kw.get("ts_lk_threshold", 128.0)
+    c.max_cnt = kw.get("max_cnt", 300)
+    c.min_dist = kw.get("min_dist", 10)
+    c.flow_back = kw.get("flow_back", 1)
+    c.equalize = kw.get("equalize", 0)
+    c.f_threshold = kw.get("f_threshold", 1.0)
+    c.f_ransac = kw.get("f_ransac", 1)
+    c.lk_accum = 1
+    c.focal_length = kw.get("focal_length", 460)
+    c.device = device
+    cams = kw.get("cams")
+    if cams is None:
+        cams = [dict(fx=0.9 * W, fy=0.9 * W, cx=W / 2.0, cy=H / 2.0, k1=-0.05, k2=0.01, p1=1e-4,
+                     p2=-2e-4)] * 2
+    for k in range(2):
+        for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2"):
+            setattr(c.cam[k], n, float(cams[k][n]))
+    return c
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _events_arg(ev):
+    """numpy EVENT_DTYPE array -> (pointer, n, HOST); (device_ptr:int, n) tuple -> DEVICE."""
+    if isinstance(ev, tuple):
+        return C.c_void_p(ev[0]), int(ev[1]), DEVICE, None
+    ev = np.ascontiguousarray(ev)
+    if ev.dtype.itemsize != 16:
+        raise ValueError("events must be 16-byte records (esvio_amd.events.EVENT_DTYPE)")
+    return _p(ev), ev.shape[0], HOST, ev
+
+
+class _Handle:
+    def __init__(self, cfg):
+        self.L = load_library()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.L.esvio_fe_create(C.byref(cfg), C.byref(h))
+        if rc != 0 or not h:
+            raise FrontendError("esvio_fe_create failed rc=%d (no GPU / bad config)" % rc)
+        self.h = h
+
+    def check(self, rc):
+        if rc != 0:
+            raise FrontendError("rc=%d: %s" % (rc, self.L.esvio_fe_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.esvio_fe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class EventDetector:
+    """esvio::EventDetector (event_detector.h:18-80) — batch forms of its per-event methods."""
+
+    def __init__(self, cfg=None, handle=None, **kw):
+        if handle is None:
+            handle = _Handle(cfg if cfg is not None else make_config(**kw))
+        self._hd = handle
+        self.W, self.H = handle.cfg.width, handle.cfg.height
+
+    def createSAE_left(self, events):
+        return self._create_sae(0, events)
+
+    def createSAE_right(self, events):
+        return self._create_sae(1, events)
+
+    def _create_sae(self, cam, events):
+        ptr, n, space, keep = _events_arg(events)
+        rej = C.c_uint64(0)
+        self._hd.check(self._hd.L.esvio_fe_create_sae(self._hd.h, cam, ptr, n, space, C.byref(rej)))
+        return rej.value
+
+    def createSAE_stereo(self, left, right):
+        pl, nl, sl, k1 = _events_arg(left)
+        pr, nr, sr, k2 = _events_arg(right)
+        assert sl == sr
+        rej = C.c_uint64(0)
+        self._hd.check(self._hd.L.esvio_fe_create_sae_stereo(self._hd.h, pl, nl, pr, nr, sl,
+                                                             C.byref(rej)))
+        return rej.value
+
+    def SAEtoTimeSurface_left(self, external_sync_time):
+        return self._ts(0, external_sync_time)
+
+    def SAEtoTimeSurface_right(self, external_sync_time):
+        return self._ts(1, external_sync_time)
+
+    def _ts(self, cam, t):
+        out = np.empty((self.H, self.W), np.uint8)
+        self._hd.check(self._hd.L.esvio_fe_sae_to_time_surface(self._hd.h, cam, float(t), _p(out)))
+        return out
+
+    def isCorner(self, events):
+        """isCorner(e.ts.toSec(), e.x, e.y, e.polarity) for every event -> uint8 flags."""
+        ptr, n, space, keep = _events_arg(events)
+        flags = np.zeros(n, np.uint8)
+        self._hd.check(self._hd.L.esvio_fe_is_corner(self._hd.h, ptr, n, space, _p(flags)))
+        return flags
+
+    def get_sae(self, cam):
+        planes = [np.empty((self.H, self.W), np.float64) for _ in range(4)]
+        self._hd.check(self._hd.L.esvio_fe_get_sae(self._hd.h, cam, *[_p(a) for a in planes]))
+        return planes  # L0, L1, S0, S1
+
+    def set_sae(self, cam, L0, L1, S0, S1):
+        arrs = [np.ascontiguousarray(a, np.float64) for a in (L0, L1, S0, S1)]
+        self._hd.check(self._hd.L.esvio_fe_set_sae(self._hd.h, cam, *[_p(a) for a in arrs]))
+
+
+class FeatureTracker:
+    """FeatureTracker (feature_tracker.h:49-173): trackEvent + the public result members."""
+
+    def __init__(self, cfg=None, **kw):
+        self.cfg = cfg if cfg is not None else make_config(**kw)
+        self._hd = _Handle(self.cfg)
+        self.detector = EventDetector(handle=self._hd)
+        m = max(self.cfg.max_cnt, 1)
+        self._bufs = dict(
+            ids=np.zeros(m, np.int32), track_cnt=np.zeros(m, np.int32),
+            cur_pts=np.zeros((m, 2), np.float32), cur_un_pts=np.zeros((m, 2), np.float32),
+            pts_velocity=np.zeros((m, 2), np.float32),
+            ids_right=np.zeros(m, np.int32), cur_right_pts=np.zeros((m, 2), np.float32),
+            cur_un_right_pts=np.zeros((m, 2), np.float32),
+            right_pts_velocity=np.zeros((m, 2), np.float32))
+        self._tr = Tracks()
+        for k, a in self._bufs.items():
+            setattr(self._tr, k, a.ctypes.data)
+        for k in self._bufs:
+            setattr(self, k, self._bufs[k][:0])
+
+    def close(self):
+        self._hd.close()
+
+    def trackEvent(self, cur_time, event_left, event_right, PUB_THIS_FRAME=True, copy=True):
+        pl, nl, sl, k1 = _events_arg(event_left)
+        pr, nr, sr, k2 = _events_arg(event_right)
+        assert sl == sr
+        self._hd.check(self._hd.L.esvio_fe_track_event(self._hd.h, float(cur_time), pl, nl, pr, nr,
+                                                       sl, int(PUB_THIS_FRAME), C.byref(self._tr)))
+        nl_, nr_ = self._tr.n_left, self._tr.n_right
+        for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"):
+            v = self._bufs[k][:nl_]
+            setattr(self, k, v.copy() if copy else v)
+        for k in ("ids_right", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity"):
+            v = self._bufs[k][:nr_]
+            setattr(self, k, v.copy() if copy else v)
+        return self
+
+    def reset(self):
+        self._hd.check(self._hd.L.esvio_fe_reset(self._hd.h))
+
+    def gettimesurface(self, cam=0):
+        out = np.empty((self.cfg.height, self.cfg.width), np.uint8)
+        self._hd.check(self._hd.L.esvio_fe_get_time_surface(self._hd.h, cam, _p(out)))
+        return out
+
+    # ---- stage-level entry points used by the parity tests
+    def Event_FeaturesToTrack(self, last_event, maxCorners, event_mask=None):
+        ptr, n, space, keep = _events_arg(last_event)
+        xy = np.zeros((max(maxCorners, 1), 2), np.float32)
+        idx = np.zeros(max(maxCorners, 1), np.int32)
+        k = C.c_int32(0)
+        mask = None if event_mask is None else np.ascontiguousarray(event_mask, np.uint8)
+        self._hd.check(self._hd.L.esvio_fe_features_to_track(
+            self._hd.h, ptr, n, space, int(maxCorners), _p(mask), _p(xy), _p(idx), C.byref(k)))
+        return xy[:k.value].copy(), idx[:k.value].copy()
+
+    def calcOpticalFlowPyrLK(self, prev_img, next_img, prev_pts, next_pts=None, maxLevel=3,
+                             max_count=30, eps=0.01, flags=0):
+        prev_img = np.ascontiguousarray(prev_img, np.uint8)
+        next_img = np.ascontiguousarray(next_img, np.uint8)
+        h, w = prev_img.shape
+        prev_pts = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        n = prev_pts.shape[0]
+        nxt = (np.zeros((n, 2), np.float32) if next_pts is None
+               else np.array(next_pts, np.float32).reshape(-1, 2).copy())
+        status = np.zeros(n, np.uint8)
+        self._hd.check(self._hd.L.esvio_fe_calc_optical_flow_pyr_lk(
+            self._hd.h, _p(prev_img), _p(next_img), w, h, _p(prev_pts), _p(nxt), _p(status), n,
+            maxLevel, max_count, eps, flags))
+        return nxt, status
+
+    def build_pyramid(self, img, max_level=3):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        nl, lw, lh = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._hd.check(self._hd.L.esvio_fe_build_pyramid(self._hd.h, _p(img), w, h, max_level, -1,
+                                                         None, None, None, None, C.byref(nl)))
+        levels = []
+        for l in range(nl.value):
+            self._hd.check(self._hd.L.esvio_fe_build_pyramid(
+                self._hd.h, _p(img), w, h, max_level, l, None, None, C.byref(lw), C.byref(lh),
+                C.byref(nl)))
+            im = np.empty((lh.value, lw.value), np.uint8)
+            dv = np.empty((lh.value, lw.value, 2), np.int16)
+            self._hd.check(self._hd.L.esvio_fe_build_pyramid(
+                self._hd.h, _p(img), w, h, max_level, l, _p(im), _p(dv), C.byref(lw), C.byref(lh),
+                C.byref(nl)))
+            levels.append((im, dv))
+        return levels
+
+    # ---- measurement
+    def set_profiling(self, on=True):
+        self._hd.check(self._hd.L.esvio_fe_set_profiling(self._hd.h, int(on)))
+
+    def reset_kernel_stats(self):
+        self._hd.check(self._hd.L.esvio_fe_reset_kernel_stats(self._hd.h))
+
+    def kernel_stats(self):
+        L = self._hd.L
+        out = {}
+        for k in range(L.esvio_fe_kernel_count()):
+            ms, n, b = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+            self._hd.check(L.esvio_fe_get_kernel_stats(self._hd.h, k, C.byref(ms), C.byref(n),
+                                                       C.byref(b)))
+            out[L.esvio_fe_kernel_name(k).decode()] = dict(ms=ms.value, launches=n.value,
+                                                           alg_bytes=b.value)
+        return out
+
+    @property
+    def stream(self):
+        return self._hd.L.esvio_fe_stream(self._hd.h)
+
+
+def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99):
+    """cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, conf, status) (host-side stage)."""
+    L = load_library()
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    n = p1.shape[0]
+    status = np.zeros(n, np.uint8)
+    k = C.c_int32(0)
+    rc = L.esvio_fe_find_fundamental_mat(_p(p1), _p(p2), n, thr, conf, _p(status), C.byref(k))
+    if rc:
+        raise FrontendError("find_fundamental_mat rc=%d" % rc)
+    return k.value, status
+
+
+def lift_projective(cam, u, v):
+    L = load_library()
+    c = Camera(**{k: float(cam[k]) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")})
+    out = np.empty(3, np.float64)
+    rc = L.esvio_fe_lift_projective(C.byref(c), float(u), float(v), _p(out))
+    if rc:
+        raise FrontendError("lift_projective rc=%d" % rc)
+    return out

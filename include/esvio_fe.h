@@ -1,0 +1,183 @@
+/*
+ * esvio_fe.h — C ABI of the MI355X-native ESVIO event front-end (libesvio_fe.so).
+ *
+ * Drop-in boundary for the hot path of arclab-hku/ESVIO's `feature_tracker` event node:
+ * the calls FeatureTracker::trackEvent makes into esvio::EventDetector and OpenCV, and the
+ * result vectors the ROS node reads back.  The reference has no FFI of its
+ * own; each entry point below names the reference interface it replaces (file:line relative
+ * to the reference tree).  Plain pointers and sizes only — no C++/torch types.
+ *
+ * Threading: one caller per handle (the reference has exactly one worker thread,
+ * feature_tracker/src/stereo_event_tracker_node.cpp:366).  Different handles are independent
+ * (one per GPU / per rig).  All functions return 0 on success, <0 on error
+ * (see ESVIO_FE_E*), never abort; esvio_fe_last_error() gives a message.
+ *
+ * Every compute entry point runs hand-written HIP kernels on the handle's device; there is no
+ * CPU fallback — creating a handle without a usable GPU fails with ESVIO_FE_ENODEVICE.
+ */
+#ifndef ESVIO_FE_H
+#define ESVIO_FE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESVIO_FE_OK 0
+#define ESVIO_FE_EINVAL (-1)      /* bad argument / unsupported config value */
+#define ESVIO_FE_ENODEVICE (-2)   /* no usable HIP device */
+#define ESVIO_FE_EHIP (-3)        /* HIP runtime error */
+#define ESVIO_FE_ENOTIMPL (-4)    /* config asks for a stage that is not built yet */
+#define ESVIO_FE_EINTERNAL (-5)   /* device-side invariant violated (bounded spin expired …) */
+
+/* dvs_msgs::Event as laid out in memory (feature_tracker/src/dvs_msgs/Event.h:42-52):
+ * uint16 x; uint16 y; ros::Time ts {uint32 sec; uint32 nsec}; uint8 polarity => 16 B AoS.
+ * A `std::vector<dvs_msgs::Event>::data()` pointer can be passed as-is. */
+typedef struct esvio_fe_event {
+  uint16_t x, y;
+  uint32_t sec, nsec;
+  uint8_t polarity;
+  uint8_t _pad[3];
+} esvio_fe_event;
+
+/* camodocal pinhole + radtan parameters (camera_model/src/camera_models/PinholeCamera.cc) */
+typedef struct esvio_fe_camera {
+  double fx, fy, cx, cy, k1, k2, p1, p2;
+} esvio_fe_camera;
+
+/* The YAML knobs readParameters_event loads into globals
+ * (feature_tracker/src/parameters.cpp:183-282), as one plain struct. */
+typedef struct esvio_fe_config {
+  int32_t width, height;            /* event_width / event_height -> COL_event, ROW_event */
+  double decay_ms;                  /* decay_ms */
+  int32_t ignore_polarity;          /* ignore_polarity */
+  int32_t median_blur_kernel_size;  /* must be 0 (every shipped config); else ENOTIMPL */
+  double feature_filter_threshold;  /* feature_filter_threshold [s] */
+  double ts_lk_threshold;           /* TS_LK_threshold (128.0) */
+  int32_t max_cnt;                  /* max_cnt */
+  int32_t min_dist;                 /* min_dist */
+  int32_t flow_back;                /* flow_back */
+  int32_t equalize;                 /* equalize: must be 0 for now (CLAHE is §8f N2) */
+  double f_threshold;               /* F_threshold [px] */
+  int32_t f_ransac;                 /* 1: run rejectWithF_event's RANSAC on host; 0: skip */
+  int32_t lk_accum;                 /* reserved, must be 1 (exact integer LK sums) */
+  int32_t focal_length;             /* FOCAL_LENGTH, 460 (parameters.cpp:274) */
+  int32_t device;                   /* HIP device ordinal, -1 = current device */
+  esvio_fe_camera cam[2];           /* event_left_calib / event_right_calib */
+} esvio_fe_config;
+
+/* What stereo_event_tracker_node.cpp:289-322 reads from FeatureTracker after trackEvent.
+ * Caller-owned buffers, each sized for max_cnt entries (xy arrays: 2*max_cnt floats). */
+typedef struct esvio_fe_tracks {
+  int32_t n_left;             /* ids.size() */
+  int32_t n_right;            /* ids_right.size() */
+  int32_t* ids;               /* FeatureTracker::ids */
+  int32_t* track_cnt;         /* ::track_cnt */
+  float* cur_pts;             /* ::cur_pts (u,v) */
+  float* cur_un_pts;          /* ::cur_un_pts */
+  float* pts_velocity;        /* ::pts_velocity */
+  int32_t* ids_right;         /* ::ids_right */
+  float* cur_right_pts;       /* ::cur_right_pts */
+  float* cur_un_right_pts;    /* ::cur_un_right_pts */
+  float* right_pts_velocity;  /* ::right_pts_velocity */
+} esvio_fe_tracks;
+
+typedef struct esvio_fe_ctx* esvio_fe_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+/* replaces: global `esvio::EventDetector detector` (feature_tracker.cpp:7), `trackerData`
+ * (stereo_event_tracker_node.cpp:45), EventDetector::init (event_detector.cc:47-70). */
+int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out);
+int esvio_fe_destroy(esvio_fe_handle h);
+/* stream-discontinuity path (stereo_event_tracker_node.cpp:163-173): clears SAE planes,
+ * images, tracks and ids as a freshly created handle (n_id keeps counting). */
+int esvio_fe_reset(esvio_fe_handle h);
+const char* esvio_fe_last_error(esvio_fe_handle h);
+const char* esvio_fe_version(void);
+
+/* ---- EventDetector stages ------------------------------------------------------------ */
+/* memory space of an event pointer argument */
+#define ESVIO_FE_HOST 0
+#define ESVIO_FE_DEVICE 1
+
+/* createSAE_left (cam 0, event_detector.cc:149-166) / createSAE_right (cam 1, :212-228)
+ * applied to n events in stream order.  Events with x>=width or y>=height are skipped and
+ * counted in *n_rejected (the reference would abort on an Eigen assert). */
+int esvio_fe_create_sae(esvio_fe_handle h, int cam, const esvio_fe_event* ev, size_t n,
+                        int space, uint64_t* n_rejected);
+/* both cameras in one submission (what trackEvent does at feature_tracker.cpp:356-362) */
+int esvio_fe_create_sae_stereo(esvio_fe_handle h, const esvio_fe_event* left, size_t nL,
+                               const esvio_fe_event* right, size_t nR, int space,
+                               uint64_t* n_rejected);
+/* SAEtoTimeSurface_left/right (event_detector.cc:230-305).  Renders into the handle's current
+ * image of that camera; if out != NULL also copies the width*height u8 image to host. */
+int esvio_fe_sae_to_time_surface(esvio_fe_handle h, int cam, double external_sync_time,
+                                 uint8_t* out);
+/* isCorner (event_detector.cc:308-544) for n events against the LEFT planes; flags[i] in {0,1}
+ * (host buffer).  Out-of-sensor events give 0. */
+int esvio_fe_is_corner(esvio_fe_handle h, const esvio_fe_event* ev, size_t n, int space,
+                       uint8_t* flags);
+/* Event_FeaturesToTrack (feature_tracker.cpp:13-38): greedy scan of `ev` in stream order.
+ * mask: width*height bytes on host, 255 = blocked (the reference's CV_64F 255.0), may be NULL.
+ * Uses the handle's current left time surface for the TS_LK_threshold test.  Writes up to
+ * max_corners (x,y) pairs and (optionally) their event indices. */
+int esvio_fe_features_to_track(esvio_fe_handle h, const esvio_fe_event* ev, size_t n, int space,
+                               int max_corners, const uint8_t* mask, float* out_xy,
+                               int32_t* out_idx, int32_t* n_out);
+/* test taps: copy a camera's four planes (each width*height doubles, index x + y*width) */
+int esvio_fe_get_sae(esvio_fe_handle h, int cam, double* L0, double* L1, double* S0, double* S1);
+int esvio_fe_set_sae(esvio_fe_handle h, int cam, const double* L0, const double* L1,
+                     const double* S0, const double* S1);
+
+/* ---- OpenCV stages used by trackEvent ------------------------------------------------- */
+#define ESVIO_FE_LK_USE_INITIAL_FLOW 4 /* cv::OPTFLOW_USE_INITIAL_FLOW */
+/* cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(21,21), max_level,
+ * TermCriteria(COUNT+EPS, max_count, eps), flags) as called at feature_tracker.cpp:410,417,
+ * 490,495.  Host u8 images of w*h (w,h need not equal the config's sensor size). */
+int esvio_fe_calc_optical_flow_pyr_lk(esvio_fe_handle h, const uint8_t* prev_img,
+                                      const uint8_t* next_img, int w, int hgt,
+                                      const float* prev_pts, float* next_pts, uint8_t* status,
+                                      int n, int max_level, int max_count, double eps, int flags);
+/* test tap: the pyramid the LK stage builds for a host image: level `level` u8 image
+ * (lw*lh bytes) and its Scharr derivatives (lw*lh*2 int16, interleaved Ix,Iy). Either output
+ * may be NULL. Returns the number of levels built (maxLevel+1) in *n_levels. */
+int esvio_fe_build_pyramid(esvio_fe_handle h, const uint8_t* img, int w, int hgt, int max_level,
+                           int level, uint8_t* out_img, int16_t* out_deriv, int32_t* lw,
+                           int32_t* lh, int32_t* n_levels);
+/* cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, conf, status) as used by rejectWithF_event
+ * (feature_tracker.cpp:935); host-side. Returns the inlier count in *n_inliers. */
+int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, double thr,
+                                  double conf, uint8_t* status, int32_t* n_inliers);
+/* camodocal PinholeCamera::liftProjective (PinholeCamera.cc:450-510); host-side. */
+int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, double* out3);
+
+/* ---- the fused per-frame call -------------------------------------------------------- */
+/* FeatureTracker::trackEvent(cur_time, event_left, event_right) (feature_tracker.cpp:340-603)
+ * with PUB_THIS_FRAME passed explicitly (global at parameters.cpp:276, set by
+ * stereo_event_tracker_node.cpp:177-188).  nL must be > 0 (node:150 returns early otherwise).
+ * `out` may be NULL. */
+int esvio_fe_track_event(esvio_fe_handle h, double cur_time, const esvio_fe_event* left,
+                         size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                         int pub_this_frame, esvio_fe_tracks* out);
+/* FeatureTracker::gettimesurface() tap (feature_tracker.cpp:894): current left/right image */
+int esvio_fe_get_time_surface(esvio_fe_handle h, int cam, uint8_t* out);
+
+/* ---- measurement --------------------------------------------------------------------- */
+/* Per-kernel HIP-event timing on the handle's stream (off by default; when on, every launch is
+ * bracketed by hipEventRecord and resolved lazily). */
+int esvio_fe_set_profiling(esvio_fe_handle h, int on);
+int esvio_fe_kernel_count(void);
+const char* esvio_fe_kernel_name(int kernel_id);
+/* total_ms / launches / algorithmic bytes accumulated since the last reset_kernel_stats */
+int esvio_fe_get_kernel_stats(esvio_fe_handle h, int kernel_id, double* total_ms,
+                              uint64_t* launches, uint64_t* alg_bytes);
+int esvio_fe_reset_kernel_stats(esvio_fe_handle h);
+/* the hipStream_t the handle launches on (as void*) */
+void* esvio_fe_stream(esvio_fe_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESVIO_FE_H */

@@ -1,0 +1,210 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bars: SAE planes, time-surface bytes, corner flags and selected corner indices bit-exact;
+pyramid / Scharr bit-exact; LK positions bit-exact against the oracle's exact-sum mode (both
+sides accumulate the normal equations in int64) and <= 1e-4 px against its float-sum mode
+on >= 99% of points (status flips counted and bounded).
+"""
+import numpy as np
+import pytest
+
+from esvio_amd import frontend as FE
+from esvio_amd.events import EVENT_DTYPE, event_times, make_events
+from esvio_amd.synth import SceneStream, uniform_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(W, H, **kw):
+    return FE.FeatureTracker(FE.make_config(W, H, **kw))
+
+
+def _planes_equal(a, b):
+    for x, y, name in zip(a, b, ("L0", "L1", "S0", "S1")):
+        assert np.array_equal(x, y), "plane %s differs at %d pixels" % (name, (x != y).sum())
+
+
+@pytest.mark.parametrize("W,H,n", [(346, 260, 33000), (640, 480, 167000)])
+def test_sae_and_time_surface_uniform(oracle, W, H, n):
+    rng = np.random.default_rng(12345)
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    t0 = 1_700_000_000_000_000
+    for b in range(3):
+        L = uniform_batch(W, H, n, t0 + b * 33333, 33333, rng)
+        R = uniform_batch(W, H, n, t0 + b * 33333, 33333, rng)
+        assert ft.detector.createSAE_stereo(L, R) == 0
+        det.create_sae(0, L)
+        det.create_sae(1, R)
+        for cam in (0, 1):
+            _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+        t_sync = event_times(L)[-1]
+        for cam, f in ((0, ft.detector.SAEtoTimeSurface_left), (1, ft.detector.SAEtoTimeSurface_right)):
+            assert np.array_equal(f(t_sync), det.time_surface(cam, t_sync))
+    ft.close()
+
+
+def test_sae_adversarial_duplicates(oracle):
+    """many events on few pixels, equal timestamps, alternating polarity, border pixels,
+    out-of-sensor events (skipped + counted)"""
+    W, H = 346, 260
+    rng = np.random.default_rng(7)
+    n = 50000
+    hot = np.array([[0, 0], [W - 1, H - 1], [5, 5], [100, 100], [101, 100], [W - 1, 0]])
+    pick = rng.integers(0, len(hot), n)
+    x, y = hot[pick, 0].copy(), hot[pick, 1].copy()
+    t = np.sort(rng.integers(0, 2000, n)) * 5 + 5_000_000  # many exact ties
+    p = rng.integers(0, 2, n)
+    p[::7] = 1 - p[::7]
+    x[100] = W  # out of sensor
+    y[200] = H
+    ev = make_events(x, y, t, p)
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    assert ft.detector.createSAE_left(ev) == 2
+    assert det.create_sae(0, ev) == 2
+    _planes_equal(ft.detector.get_sae(0), det.get_sae(0))
+    # second batch continues from carried state, some events older than the state (time reversal)
+    ev2 = make_events(x, y, t - 1000, 1 - p)
+    ft.detector.createSAE_left(ev2)
+    det.create_sae(0, ev2)
+    _planes_equal(ft.detector.get_sae(0), det.get_sae(0))
+    ft.close()
+
+
+def test_time_surface_edge_cases(oracle):
+    W, H = 346, 260
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    rng = np.random.default_rng(3)
+    S0 = np.where(rng.random((H, W)) < 0.5, rng.uniform(10.0, 10.2, (H, W)), 0.0)
+    S1 = np.where(rng.random((H, W)) < 0.5, rng.uniform(10.0, 10.2, (H, W)), 0.0)
+    S1[0, :50] = S0[0, :50]  # ties: polarity -1
+    Z = np.zeros((H, W))
+    ft.detector.set_sae(1, Z, Z, S0, S1)
+    det.set_sae(1, Z, Z, S0, S1)
+    for t_sync in (10.2, 10.1, 10.0, 9.5, 8.0, 11.0, 10.2 + 1e-9):
+        # t_sync earlier than stamps: exp(+x) saturates; far earlier: cvRound overflow -> 0
+        assert np.array_equal(ft.detector.SAEtoTimeSurface_right(t_sync), det.time_surface(1, t_sync)), t_sync
+    ft.close()
+    ft = FE.FeatureTracker(FE.make_config(W, H, ignore_polarity=1))
+    det = oracle.Detector(W, H, ignore_polarity=1)
+    ft.detector.set_sae(0, Z, Z, S0, S1)
+    det.set_sae(0, Z, Z, S0, S1)
+    for t_sync in (10.2, 10.0, 9.9):
+        assert np.array_equal(ft.detector.SAEtoTimeSurface_left(t_sync), det.time_surface(0, t_sync))
+    ft.close()
+
+
+@pytest.mark.parametrize("W,H,rate", [(346, 260, 1e6), (640, 480, 5e6)])
+def test_corner_flags_and_selection_scene(oracle, W, H, rate):
+    s = SceneStream(W, H, rate=rate, seed=5, n_rect=12 if W < 400 else 28)
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    total_corners = 0
+    for b in range(3):
+        L, R, _ = s.next_batch()
+        ft.detector.createSAE_stereo(L, R)
+        det.create_sae(0, L)
+        det.create_sae(1, R)
+        t_sync = event_times(L)[-1]
+        ts_gpu = ft.detector.SAEtoTimeSurface_left(t_sync)
+        ts_cpu = det.time_surface(0, t_sync)
+        assert np.array_equal(ts_gpu, ts_cpu)
+        fg = ft.detector.isCorner(L)
+        fc = det.corner_flags(L)
+        assert np.array_equal(fg, fc), "%d flag mismatches" % (fg != fc).sum()
+        total_corners += int(fc.sum())
+        # greedy selection with a random pre-blocked mask
+        mask = np.zeros((H, W), np.uint8)
+        rng = np.random.default_rng(b)
+        for _ in range(20):
+            oracle.circle_fill(mask, int(rng.integers(0, W)), int(rng.integers(0, H)), 10)
+        for maxc in (1, 37, 300):
+            xy_g, idx_g = ft.Event_FeaturesToTrack(L, maxc, mask)
+            xy_c, idx_c = det.features_to_track(L, maxc, 10, mask, ts_cpu)
+            assert np.array_equal(idx_g, idx_c)
+            assert np.array_equal(xy_g, xy_c)
+    assert total_corners > 100  # the scene stream must actually exercise Arc*
+    ft.close()
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (346, 260), (173, 131)])
+def test_pyramid_and_scharr(oracle, W, H):
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    ft = _mk(640, 480)
+    levels = ft.build_pyramid(img, 3)
+    assert len(levels) == oracle.pyr_levels(W, H) + 1
+    cur = img
+    for l, (im, dv) in enumerate(levels):
+        if l > 0:
+            cur = oracle.pyr_down(cur)
+        assert np.array_equal(im, cur), "level %d image" % l
+        assert np.array_equal(dv, oracle.scharr(cur)), "level %d scharr" % l
+    ft.close()
+
+
+def _texture(W, H, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.random((H // 8 + 3, W // 8 + 3))
+    img = np.kron(base, np.ones((8, 8)))[:H + 16, :W + 16]
+    k = np.ones(5) / 5
+    for ax in (0, 1):
+        img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, img)
+    return img
+
+
+def test_lk_parity(oracle):
+    W, H = 640, 480
+    tex = _texture(W, H, 2)
+    prev = (tex[8:8 + H, 8:8 + W] * 255).astype(np.uint8)
+    nxt = (tex[6:6 + H, 11:11 + W] * 255).astype(np.uint8)  # shift (-3, +2)
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(-5, W + 5, 300), rng.uniform(-5, H + 5, 300)], 1).astype(np.float32)
+    ft = _mk(W, H)
+    for (ml, flags) in ((3, 0), (1, FE.LK_USE_INITIAL_FLOW), (0, 0)):
+        init = pts + rng.uniform(-2, 2, pts.shape).astype(np.float32)
+        g_pts, g_st = ft.calcOpticalFlowPyrLK(prev, nxt, pts, init, maxLevel=ml, flags=flags)
+        c_pts, c_st = oracle.lk(prev, nxt, pts, init, max_level=ml, flags=flags, accum=1)
+        assert np.array_equal(g_st, c_st)
+        assert np.array_equal(g_pts.view(np.uint32), c_pts.view(np.uint32)), \
+            "max |d| = %g" % np.abs(g_pts - c_pts).max()
+        # float-accumulator oracle (OpenCV's default scalar loop): 1e-4 px on tracked points
+        f_pts, f_st = oracle.lk(prev, nxt, pts, init, max_level=ml, flags=flags, accum=0)
+        both = (f_st == 1) & (g_st == 1)
+        flips = int((f_st != g_st).sum())
+        close = np.abs(f_pts[both] - g_pts[both]).max(axis=1) <= 1e-4
+        assert flips <= 3 and close.mean() >= 0.99, (flips, close.mean())
+    ok = g_st == 1
+    assert ok.sum() > 150
+    ft.close()
+
+
+def test_track_event_end_to_end(oracle):
+    """12 frames of the stereo scene stream through trackEvent; every public result vector of
+    FeatureTracker must equal the oracle's (ids, track_cnt exact; float vectors bit-exact because
+    LK sums are exact on both sides)."""
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=5e6, seed=1)
+    kw = dict(f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(12):
+        L, R, _ = s.next_batch()
+        pub = (f % 3) != 2  # mix published and non-published frames
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pub)
+        r = tr.track_event(t, L, R, pub)
+        assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+        assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1))
+        assert np.array_equal(ft.ids, r.ids), f
+        assert np.array_equal(ft.track_cnt, r.track_cnt)
+        assert np.array_equal(ft.ids_right, r.ids_right)
+        for k in ("cur_pts", "cur_un_pts", "pts_velocity", "cur_right_pts", "cur_un_right_pts",
+                  "right_pts_velocity"):
+            a, b = getattr(ft, k), getattr(r, k)
+            assert a.shape == b.shape, (f, k)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (f, k, np.abs(a - b).max())
+    assert len(ft.ids) > 100 and len(ft.ids_right) > 50 and ft.track_cnt.max() >= 4
+    ft.close()
