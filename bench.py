@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X event front-end hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one stereo event batch: SAE update (both cameras) ->
+time surfaces -> pyramids -> temporal LK fwd/back -> [published frames: F-RANSAC, mask, Arc*
+detection + greedy selection] -> stereo LK fwd/back -> undistort/velocity, exactly the sequence
+of FeatureTracker::trackEvent (reference feature_tracker.cpp:340-603).  Workload at N=1:
+BASELINE config C3 (superset of C2): stereo 640x480 synthetic scene stream, 5 Mev/s per camera
+in 30 Hz batches (~167 k events per camera per step), shipped DSEC parameters
+(max_cnt 300, min_dist 10, flow_back 1, equalize 0), frames published at freq=15 Hz like
+stereo_event_tracker_node.cpp:177-188.  Events are resident in HBM before the timed region.
+
+N>1: one process per GPU (torch.distributed / RCCL); every rank runs an independent stereo rig
+(weak scaling, no data-path collective); the tracked-corner records of every published frame are
+merged with one asynchronous all_gather (north-star hand-off to the estimator).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--rate", type=float, default=5e6, help="events/s per camera")
+    ap.add_argument("--batch-hz", type=float, default=30.0)
+    ap.add_argument("--freq", type=int, default=15, help="publish rate (config freq)")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="oracle frames for cpu_baseline (0=skip)")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--seed", type=int, default=12345)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from esvio_amd import frontend as FE
+    from esvio_amd.events import event_times
+    from esvio_amd.node import FreqControl, pack_track_records
+    from esvio_amd.synth import SceneStream
+
+    W, H = args.width, args.height
+    n_frames = args.warmup + args.steps
+    n_prof = 0 if args.no_profile_pass else min(args.steps, 30)
+    # ---- synthetic stream (per rank: an independent rig, different seed), resident in HBM
+    scene = SceneStream(W, H, rate=args.rate, batch_hz=args.batch_hz, seed=args.seed + 1000 * rank)
+    host_batches, dev_batches = [], []
+    for _ in range(n_frames + n_prof):
+        L, R, _ = scene.next_batch()
+        host_batches.append((L, R))
+        tl = torch.from_numpy(L.view(np.uint8).reshape(-1)).cuda()
+        tr = torch.from_numpy(R.view(np.uint8).reshape(-1)).cuda()
+        dev_batches.append((tl, tr, len(L), len(R), event_times(L)[-1]))
+    torch.cuda.synchronize()
+
+    cfg = FE.make_config(W, H, device=local_rank, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1)
+    ft = FE.FeatureTracker(cfg)
+    fc = FreqControl(args.freq)
+    rec_dev = torch.zeros((cfg.max_cnt * 2, 8), dtype=torch.float32, device="cuda")
+    gathered = [torch.zeros_like(rec_dev) for _ in range(world)] if world > 1 else None
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+    pending = None
+
+    def step(i):
+        nonlocal pending
+        tl, tr, nl, nr, t_last = dev_batches[i]
+        pub = fc.pub_this_frame(t_last)
+        ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
+        if pub:
+            fc.published()
+            if world > 1:  # merge tracked corners of all rigs (async, overlaps the next frame)
+                if pending is not None:
+                    pending.wait()
+                rec = pack_track_records(ft, cfg.max_cnt)
+                with torch.cuda.stream(comm_stream):
+                    rec_dev.copy_(torch.from_numpy(rec), non_blocking=False)
+                    pending = dist.all_gather(gathered, rec_dev, async_op=True)
+        return nl + nr
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    n_events = 0
+    for i in range(args.warmup, n_frames):
+        n_events += step(i)
+    if pending is not None:
+        pending.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([float(n_events), elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        ev_t = tot.clone()
+        dist.all_reduce(ev_t[0:1], op=dist.ReduceOp.SUM)
+        dist.all_reduce(ev_t[1:2], op=dist.ReduceOp.MAX)
+        tot = ev_t
+    total_events, max_elapsed = float(tot[0].item()), float(tot[1].item())
+    n_tracks = (len(ft.ids), len(ft.ids_right))
+
+    # ---- per-kernel pass: same stream continued, HIP events around every launch on the handle's
+    # stream (kept out of the timed region above because event records cost host time)
+    roof = None
+    kernels = {}
+    if n_prof and rank == 0:
+        ft.set_profiling(True)
+        ft.reset_kernel_stats()
+        tp0 = time.perf_counter()
+        for i in range(n_frames, n_frames + n_prof):
+            step(i)
+        torch.cuda.synchronize()
+        prof_ms_per_step = (time.perf_counter() - tp0) / n_prof * 1e3
+        stats = ft.kernel_stats()
+        ft.set_profiling(False)
+        for k, s in stats.items():
+            if s["launches"]:
+                avg_us = s["ms"] / s["launches"] * 1e3
+                gbs = (s["alg_bytes"] / s["launches"]) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+                kernels[k] = dict(total_ms=round(s["ms"], 4), launches=s["launches"],
+                                  avg_us=round(avg_us, 3),
+                                  alg_bytes_per_launch=s["alg_bytes"] // s["launches"],
+                                  achieved_GBs=round(gbs, 2))
+        dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+        if dom:
+            d = kernels[dom]
+            roof = dict(bound="hbm", kernel=dom, achieved=d["achieved_GBs"], peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=round(d["achieved_GBs"] / HBM_PEAK_GBS, 6), traffic=None,
+                        avg_launch_us=d["avg_us"], alg_bytes_per_launch=d["alg_bytes_per_launch"],
+                        profiled_ms_per_step=round(prof_ms_per_step, 4))
+    elif n_prof:
+        for i in range(n_frames, n_frames + n_prof):
+            pass
+
+    # ---- CPU baseline: the oracle (single-threaded port of the reference path) on a bounded sample
+    cpu = None
+    if rank == 0 and args.cpu_frames > 0:
+        from oracle import oracle as O
+        ocfg = O.make_config(W, H, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1, lk_accum=1)
+        tr_o = O.Tracker(ocfg)
+        fco = FreqControl(args.freq)
+        nfr = min(args.cpu_frames, len(host_batches))
+        ev = 0
+        tc0 = time.perf_counter()
+        for i in range(nfr):
+            L, R = host_batches[i]
+            t_last = event_times(L)[-1]
+            pub = fco.pub_this_frame(t_last)
+            tr_o.track_event(t_last, L, R, pub)
+            if pub:
+                fco.published()
+            ev += len(L) + len(R)
+        tc = time.perf_counter() - tc0
+        st = tr_o.stage_seconds()
+        cpu = dict(value=round(ev / tc / 1e6, 3), unit="Mevents/s", cores=1, kind="port",
+                   sample="%d stereo batches (%d events) of the same stream, oracle/liboracle.so, 1 thread"
+                          % (nfr, ev),
+                   ms_per_step=round(tc / nfr * 1e3, 3),
+                   stage_ms_per_step={k: round(v / nfr * 1e3, 3) for k, v in st.items()},
+                   host_cpus=os.cpu_count())
+
+    if rank == 0:
+        out = {
+            "metric": "Mevents/s through time-surface+detect+track @640x480",
+            "value": round(total_events / max_elapsed / 1e6, 3),
+            "unit": "Mevents/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(max_elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 timestamps / u8 images / int64 LK sums",
+            "data": "synthetic",
+            "config": {
+                "workload": "C3 (superset of C2): stereo %dx%d scene stream, %.1f Mev/s per camera, "
+                            "%g Hz batches, full SAE+TS+pyramid+LK(temporal,stereo)+Arc*+select, "
+                            "max_cnt 300 min_dist 10 flow_back 1 equalize 0 freq %d"
+                            % (W, H, args.rate / 1e6, args.batch_hz, args.freq),
+                "events_per_step_per_gpu": int(n_events / args.steps),
+                "parallelism": "1 rig per GPU" if world > 1 else "single GPU",
+                "tracks_last_frame": n_tracks,
+            },
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+        }
+        print(json.dumps(out))
+    ft.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

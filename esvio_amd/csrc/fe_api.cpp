@@ -7,9 +7,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -110,6 +112,12 @@ struct esvio_fe_ctx {
   std::vector<int> ids, ids_right, track_cnt, track_cnt_right;
   std::map<int, P2f> cur_un_pts_map, prev_un_pts_map, cur_un_right_pts_map, prev_un_right_pts_map;
   host::BitMask mask_event;
+
+  // ---- host phase trace (ESVIO_FE_TRACE=1): stage, sae+ts enqueue, sync A, host A, enqueue B,
+  // sync B, host B
+  bool trace = false;
+  double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t phase_frames = 0;
 
   // ---- profiling
   bool prof_on = false;
@@ -642,6 +650,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   const int M = cfg.max_cnt;
   Pin pin = pin_of(c);
   c->cur_time = _cur_time;
+  using clk = std::chrono::steady_clock;
+  auto tp = clk::now();
+  auto lap = [&](int i) {
+    if (!c->trace) return;
+    auto now = clk::now();
+    c->phase_ms[i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    tp = now;
+  };
 
   const EventRec *dL = nullptr, *dR = nullptr;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
@@ -663,6 +679,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
 
   c->cur_pts.clear();
   c->cur_right_pts.clear();
+  lap(0);
 
   if (c->prev_pts.size() > 0) {  // :405-437
     const int n = (int)c->prev_pts.size();
@@ -681,7 +698,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     }
     HIPCHK(c, hipMemcpyAsync(pin.ptsB, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(pin.stA, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    lap(1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    lap(2);
     std::vector<uint8_t> status(pin.stA, pin.stA + n);
     c->cur_pts.resize(n);
     std::memcpy(c->cur_pts.data(), pin.ptsB, (size_t)n * 8);
@@ -706,8 +725,10 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
 
   bool detect = false;
   int n_kept = 0;
+  lap(3);
   if (PUB_THIS_FRAME) {  // :442-469
     if (cfg.f_ransac) reject_with_f_event(c);
+    lap(4);
     event_set_mask(c);
     const int n_max_cnt = M - (int)c->cur_pts.size();
     n_kept = (int)c->cur_pts.size();
@@ -752,7 +773,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       HIPCHK(c, hipMemcpyAsync(pin.stB, c->d_stB, (size_t)n_lk_max, hipMemcpyDeviceToHost, c->stream));
     }
   }
+  lap(5);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  lap(6);
 
   if (PUB_THIS_FRAME) {
     c->n_pts.clear();
@@ -806,6 +829,8 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->prev_pts = c->cur_pts;
   c->prev_un_pts_map = c->cur_un_pts_map;
   c->prev_time = c->cur_time;
+  lap(7);
+  c->phase_frames++;
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -823,6 +848,13 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   (void)hipSetDevice(c->dev);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->trace && c->phase_frames) {
+    static const char* nm[8] = {"enqueue sae+ts+pyr", "enqueue temporal LK", "sync A", "host filter",
+                                "host ransac", "host mask + enqueue detect/stereo", "sync B", "host tail"};
+    fprintf(stderr, "[esvio_fe trace] %llu frames, ms/frame:", (unsigned long long)c->phase_frames);
+    for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.3f", nm[i], c->phase_ms[i] / c->phase_frames);
+    fprintf(stderr, "\n");
+  }
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
                   c->d_rejected, c->d_ptsA, c->d_ptsB, c->d_ptsC, c->d_ptsD, c->d_stA, c->d_stB,
                   c->d_counts, c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy,
@@ -870,6 +902,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->key_bits = 1;
   while ((1ull << c->key_bits) <= (unsigned long long)c->invalid_key) c->key_bits++;
   c->hw = host::disc_halfwidths(cfg->min_dist);
+  c->trace = getenv("ESVIO_FE_TRACE") != nullptr;
   c->mask_event.reset(c->W, c->H);
 
   auto bail = [&](int rc) {

@@ -117,53 +117,65 @@ struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-
   int uniform(int lo, int hi) { return lo == hi ? lo : (int)(next() % (unsigned)(hi - lo) + lo); }
 };
 
-// Two null vectors of the 7x9 epipolar system = eigenvectors of A^T A with the two smallest
-// eigenvalues (cyclic Jacobi).  [OpenCV takes rows 7,8 of V^T from SVDecomp; the null space is
-// the same plane, so the cubic below has the same F solutions.]
+// Two vectors spanning the null space of the 7x9 epipolar system: Gauss-Jordan elimination with
+// complete pivoting, the two free columns give the basis, then Gram-Schmidt.  [OpenCV takes rows
+// 7,8 of V^T from SVDecomp; the null space is the same plane, so the cubic below has the same F
+// solutions.]
 void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
-  double M[9][9], V[9][9];
-  for (int i = 0; i < 9; i++)
-    for (int j = 0; j < 9; j++) {
-      double s = 0;
-      for (int k = 0; k < 7; k++) s += A[k][i] * A[k][j];
-      M[i][j] = s;
-      V[i][j] = (i == j) ? 1.0 : 0.0;
+  double M[7][9];
+  std::memcpy(M, A, sizeof(M));
+  int col_of[9];
+  for (int j = 0; j < 9; j++) col_of[j] = j;
+  int rank = 0;
+  for (int k = 0; k < 7; k++) {
+    int pr = k, pc = k;
+    double best = 0;
+    for (int i = k; i < 7; i++)
+      for (int j = k; j < 9; j++)
+        if (std::fabs(M[i][j]) > best) {
+          best = std::fabs(M[i][j]);
+          pr = i;
+          pc = j;
+        }
+    if (best == 0) break;
+    if (pr != k)
+      for (int j = 0; j < 9; j++) std::swap(M[pr][j], M[k][j]);
+    if (pc != k) {
+      for (int i = 0; i < 7; i++) std::swap(M[i][pc], M[i][k]);
+      std::swap(col_of[pc], col_of[k]);
     }
-  for (int sweep = 0; sweep < 64; sweep++) {
-    double off = 0;
-    for (int i = 0; i < 9; i++)
-      for (int j = i + 1; j < 9; j++) off += M[i][j] * M[i][j];
-    if (off < 1e-300) break;
-    for (int p = 0; p < 8; p++)
-      for (int q = p + 1; q < 9; q++) {
-        if (std::fabs(M[p][q]) < 1e-300) continue;
-        const double theta = (M[q][q] - M[p][p]) / (2.0 * M[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 9; k++) {
-          const double kp = M[k][p], kq = M[k][q];
-          M[k][p] = c * kp - s * kq;
-          M[k][q] = s * kp + c * kq;
-        }
-        for (int k = 0; k < 9; k++) {
-          const double pk = M[p][k], qk = M[q][k];
-          M[p][k] = c * pk - s * qk;
-          M[q][k] = s * pk + c * qk;
-        }
-        for (int k = 0; k < 9; k++) {
-          const double kp = V[k][p], kq = V[k][q];
-          V[k][p] = c * kp - s * kq;
-          V[k][q] = s * kp + c * kq;
-        }
-      }
+    const double inv = 1.0 / M[k][k];
+    for (int j = k; j < 9; j++) M[k][j] *= inv;
+    for (int i = 0; i < 7; i++) {
+      if (i == k) continue;
+      const double f = M[i][k];
+      if (f == 0) continue;
+      for (int j = k; j < 9; j++) M[i][j] -= f * M[k][j];
+    }
+    rank++;
   }
-  int order[9];
-  for (int i = 0; i < 9; i++) order[i] = i;
-  std::sort(order, order + 9, [&](int a, int b) { return M[a][a] > M[b][b]; });
+  // free (permuted) columns: the last two; x_pivot = -M[pivot][free]
+  double* out[2] = {f1, f2};
+  for (int v = 0; v < 2; v++) {
+    const int fc = 7 + v;
+    double x[9] = {0};
+    x[fc] = 1.0;
+    for (int k = 0; k < rank; k++) x[k] = -M[k][fc];
+    for (int j = 0; j < 9; j++) out[v][col_of[j]] = x[j];
+  }
+  double n1 = 0;
+  for (int i = 0; i < 9; i++) n1 += f1[i] * f1[i];
+  n1 = std::sqrt(n1);
+  for (int i = 0; i < 9; i++) f1[i] /= n1;
+  double dot = 0;
+  for (int i = 0; i < 9; i++) dot += f1[i] * f2[i];
+  double n2 = 0;
   for (int i = 0; i < 9; i++) {
-    f1[i] = V[i][order[7]];
-    f2[i] = V[i][order[8]];
+    f2[i] -= dot * f1[i];
+    n2 += f2[i] * f2[i];
   }
+  n2 = std::sqrt(n2);
+  for (int i = 0; i < 9; i++) f2[i] /= n2;
 }
 
 // cv::solveCubic [OpenCV core/mathfuncs.cpp]

@@ -1,0 +1,125 @@
+"""Host harness mirroring the caller of trackEvent: ``handle_stereo_event`` of the reference's
+stereo_event_tracker node (feature_tracker/src/stereo_event_tracker_node.cpp:145-344) without ROS:
+first-frame drop, stream-discontinuity reset, publish-rate control, PointCloud-equivalent packing.
+
+Plain host bookkeeping over the FeatureTracker mirror; no compute happens here.
+"""
+import numpy as np
+
+from .events import event_times
+
+NUM_OF_CAM_stereo = 2
+
+
+class FreqControl:
+    """PUB_THIS_FRAME logic of stereo_event_tracker_node.cpp:155-188 (first frame handled by the
+    caller): publish while round(pub_count / (t - first_image_time)) <= FREQ, re-arm the window
+    when the running rate is within 1 % of FREQ."""
+
+    def __init__(self, freq):
+        self.FREQ = freq if freq != 0 else 100  # parameters.cpp:278-279
+        self.first_image_time = None
+        self.pub_count = 1
+
+    def pub_this_frame(self, msg_timestamp):
+        if self.first_image_time is None:
+            self.first_image_time = msg_timestamp
+            return False
+        dt = msg_timestamp - self.first_image_time
+        if dt <= 0:
+            return False
+        rate = 1.0 * self.pub_count / dt
+        if round(rate) <= self.FREQ:
+            if abs(rate - self.FREQ) < 0.01 * self.FREQ:
+                self.first_image_time = msg_timestamp
+                self.pub_count = 0
+            return True
+        return False
+
+    def published(self):
+        self.pub_count += 1
+
+
+def pack_point_cloud(ft):
+    """sensor_msgs/PointCloud equivalent (node:273-329): rows of
+    (x_un, y_un, 1, id*2+cam as float32, u, v, vx, vy); left entries with track_cnt > 1 first, then
+    right entries whose id is in the left set."""
+    rows = []
+    hash_ids = set()
+    for j in range(len(ft.ids)):
+        if ft.track_cnt[j] > 1:
+            fid = int(ft.ids[j])
+            hash_ids.add(fid)
+            rows.append((ft.cur_un_pts[j, 0], ft.cur_un_pts[j, 1], 1.0,
+                         np.float32(fid * NUM_OF_CAM_stereo + 0), ft.cur_pts[j, 0], ft.cur_pts[j, 1],
+                         ft.pts_velocity[j, 0], ft.pts_velocity[j, 1]))
+    for j in range(len(ft.ids_right)):
+        fid = int(ft.ids_right[j])
+        if fid in hash_ids:
+            rows.append((ft.cur_un_right_pts[j, 0], ft.cur_un_right_pts[j, 1], 1.0,
+                         np.float32(fid * NUM_OF_CAM_stereo + 1), ft.cur_right_pts[j, 0],
+                         ft.cur_right_pts[j, 1], ft.right_pts_velocity[j, 0],
+                         ft.right_pts_velocity[j, 1]))
+    return np.asarray(rows, np.float32).reshape(-1, 8)
+
+
+def pack_track_records(ft, max_cnt):
+    """fixed-size (2*max_cnt, 8) float32 block of the PointCloud rows (padding rows have id -1):
+    the unit the multi-GPU all_gather exchanges."""
+    rec = np.zeros((2 * max_cnt, 8), np.float32)
+    rec[:, 3] = -1.0
+    pc = pack_point_cloud(ft)
+    rec[:len(pc)] = pc[:2 * max_cnt]
+    return rec
+
+
+class StereoEventTrackerNode:
+    """handle_stereo_event (node:145-344).  ``handle(left, right, msg_timestamp)`` returns the
+    published PointCloud rows or None (first frame, reset, non-published frame, swallowed first
+    publish)."""
+
+    def __init__(self, tracker, freq):
+        self.trackerData = tracker
+        self.freq = freq
+        self.first_image_flag = True
+        self.first_image_time = 0.0
+        self.last_image_time = 0.0
+        self.pub_count = 1
+        self.init_pub = False
+        self.restart_count = 0
+        self.FREQ = freq if freq != 0 else 100
+
+    def handle(self, event_left, event_right, msg_timestamp):
+        if len(event_left) == 0:  # node:150
+            return None
+        if self.first_image_flag:  # node:155-161
+            self.first_image_flag = False
+            self.first_image_time = msg_timestamp
+            self.last_image_time = msg_timestamp
+            return None
+        if msg_timestamp - self.last_image_time > 1.0 or msg_timestamp < self.last_image_time:
+            self.first_image_flag = True  # node:163-173
+            self.last_image_time = 0
+            self.pub_count = 1
+            self.restart_count += 1
+            self.trackerData.reset()
+            return None
+        self.last_image_time = msg_timestamp
+        rate = 1.0 * self.pub_count / (msg_timestamp - self.first_image_time)
+        if round(rate) <= self.FREQ:  # node:177-188
+            pub = True
+            if abs(rate - self.FREQ) < 0.01 * self.FREQ:
+                self.first_image_time = msg_timestamp
+                self.pub_count = 0
+        else:
+            pub = False
+        msg_timestamp_left = event_times(event_left[-1:])[0]  # node:190
+        self.trackerData.trackEvent(msg_timestamp_left, event_left, event_right, pub)
+        if not pub:
+            return None
+        self.pub_count += 1
+        pc = pack_point_cloud(self.trackerData)
+        if not self.init_pub:  # node:334-339: the first publishable frame is swallowed
+            self.init_pub = True
+            return None
+        return pc
