@@ -32,7 +32,7 @@ struct P2f {
 
 const char* const kKernelNames[K_COUNT] = {
     "k_sae_keys", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_sae_apply",
-    "k_time_surface", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_select"};
+    "k_time_surface", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select"};
 
 struct KStat {
   double ms = 0;
@@ -90,9 +90,13 @@ struct esvio_fe_ctx {
   bool have_img = false;
   PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images
   // LK point buffers (device), each max_cnt
+  // one allocation, laid out [ptsB | ptsC | stA | stB | counts | ptsA] so that each host sync
+  // needs a single D2H copy
+  uint8_t* d_res = nullptr;
+  size_t res_bytes = 0, res_temporal_bytes = 0;
   float2 *d_ptsA = nullptr, *d_ptsB = nullptr, *d_ptsC = nullptr, *d_ptsD = nullptr;
   uint8_t *d_stA = nullptr, *d_stB = nullptr;
-  int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total
+  int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total [2]=#candidates
   // arc / select
   uint8_t* d_flags = nullptr;
   uint32_t *d_cand_xy = nullptr, *d_cand_idx = nullptr, *d_cand_cnt = nullptr;
@@ -266,7 +270,8 @@ int pyr_alloc(esvio_fe_ctx* c, PyrStore& ps, int w, int h, int max_level) {
   size_t off = 0, img_off[kMaxLevels], der_off[kMaxLevels];
   int lw = w, lh = h;
   for (int l = 0; l <= levels; l++) {
-    const size_t area = (size_t)(lw + 2 * kPad) * (lh + 2 * kPad);
+    ps.d.stride[l] = pyr_stride(lw);
+    const size_t area = (size_t)ps.d.stride[l] * (lh + 2 * kPad);
     img_off[l] = off;
     off += (area + 255) / 256 * 256;
     der_off[l] = off;
@@ -287,6 +292,7 @@ int pyr_alloc(esvio_fe_ctx* c, PyrStore& ps, int w, int h, int max_level) {
     ps.d.deriv[l] = ps.d.deriv[levels];
     ps.d.w[l] = ps.d.w[levels];
     ps.d.h[l] = ps.d.h[levels];
+    ps.d.stride[l] = ps.d.stride[levels];
   }
   ps.d.levels = levels;
   ps.bytes = off;
@@ -380,16 +386,17 @@ void render_ts(esvio_fe_ctx* c, double t_sync, uint8_t* dst0, uint8_t* dst1, int
                const double2* S2) {
   ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * ncam);
   launch_time_surface(c->stream, S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
-                      c->cfg.ignore_polarity, dst0, dst1, ncam);
+                      c->cfg.ignore_polarity, dst0, dst1, c->pyr[0].d.stride[0], ncam);
 }
 
-void run_lk(esvio_fe_ctx* c, const PyrDesc& P, const PyrDesc& N, const float2* prev, float2* next,
-            uint8_t* status, const int* n_ptr, int n_max, int max_level, int max_count, double eps,
-            int flags) {
+LkArgs make_lk(const PyrDesc& P, const PyrDesc& N, const float2* prev, const float2* init,
+               float2* next, uint8_t* status, const int* n_ptr, int n_max, int max_level,
+               int max_count, double eps, int flags) {
   LkArgs a;
   a.P = P;
   a.N = N;
   a.prev_pts = prev;
+  a.init_pts = init ? init : next;
   a.next_pts = next;
   a.status = status;
   a.n_ptr = n_ptr;
@@ -400,12 +407,20 @@ void run_lk(esvio_fe_ctx* c, const PyrDesc& P, const PyrDesc& N, const float2* p
   double e = std::min(std::max(eps, 0.), 10.);
   a.eps2 = e * e;
   a.flags = flags;
-  ScopedKernel k(c, K_LK, (uint64_t)n_max * (a.max_level + 1) * kLkWin * kLkWin * 5);
-  launch_lk(c->stream, a);
+  return a;
+}
+
+// forward call (+ optional backward call fused into the same launch)
+void run_lk(esvio_fe_ctx* c, const LkArgs& f, const LkArgs* b, float2* back_pts,
+            uint8_t* back_status) {
+  uint64_t bytes = (uint64_t)f.n_max * (f.max_level + 1) * kLkWin * kLkWin * 5;
+  if (b) bytes += (uint64_t)f.n_max * (b->max_level + 1) * kLkWin * kLkWin * 5;
+  ScopedKernel k(c, K_LK, bytes);
+  launch_lk(c->stream, f, b, back_pts, back_status);
 }
 
 int copy_level0_out(esvio_fe_ctx* c, const PyrDesc& d, uint8_t* out) {
-  const int stride = d.w[0] + 2 * kPad;
+  const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(out, d.w[0], d.img[0] + (size_t)kPad * stride + kPad, stride, d.w[0],
                              d.h[0], hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -413,7 +428,7 @@ int copy_level0_out(esvio_fe_ctx* c, const PyrDesc& d, uint8_t* out) {
 }
 
 int copy_level0_in(esvio_fe_ctx* c, const PyrDesc& d, const uint8_t* in) {
-  const int stride = d.w[0] + 2 * kPad;
+  const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, in, d.w[0], d.w[0],
                              d.h[0], hipMemcpyHostToDevice, c->stream));
   return 0;
@@ -530,43 +545,62 @@ void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
   }
 }
 
-// pinned staging layout (all sized by max_cnt = M):
+// pinned staging: a mirror of the device result block (D2H) + upload areas (H2D)
 struct Pin {
-  float2* ptsA;   // H2D prev_pts / kept cur_pts ; D2H cur_pts
-  float2* ptsB;   // D2H temporal cur / right pts
-  float2* ptsC;   // D2H reverse pts
-  float2* ptsD;   // D2H new corners
+  float2* ptsB;   // D2H LK forward result
+  float2* ptsC;   // D2H LK backward result
   uint8_t* stA;
   uint8_t* stB;
-  int* counts;    // [2]
-  uint32_t* mask;  // H*wpr words
+  int* counts;    // [16]
+  float2* ptsD;   // D2H mirror of d_ptsA (kept + newly selected corners)
+  float2* ptsA;   // H2D prev_pts / kept cur_pts
+  uint32_t* mask; // H2D H*wpr words
 };
+
+size_t res_layout(size_t M, size_t* oB, size_t* oC, size_t* oSA, size_t* oSB, size_t* oCnt,
+                  size_t* oA) {
+  const size_t stM = (M + 63) / 64 * 64;
+  size_t o = 0;
+  *oB = o;
+  o += M * 8;
+  *oC = o;
+  o += M * 8;
+  *oSA = o;
+  o += stM;
+  *oSB = o;
+  o += stM;
+  *oCnt = o;
+  o += 64;
+  *oA = o;
+  o += M * 8;
+  return o;
+}
 
 Pin pin_of(esvio_fe_ctx* c) {
   const size_t M = std::max(c->cfg.max_cnt, 1);
+  size_t oB, oC, oSA, oSB, oCnt, oA;
+  const size_t res = res_layout(M, &oB, &oC, &oSA, &oSB, &oCnt, &oA);
   Pin p;
   uint8_t* b = c->h_pin;
+  p.ptsB = (float2*)(b + oB);
+  p.ptsC = (float2*)(b + oC);
+  p.stA = b + oSA;
+  p.stB = b + oSB;
+  p.counts = (int*)(b + oCnt);
+  p.ptsD = (float2*)(b + oA);
+  b += (res + 255) / 256 * 256;
   p.ptsA = (float2*)b;
-  b += M * 8;
-  p.ptsB = (float2*)b;
-  b += M * 8;
-  p.ptsC = (float2*)b;
-  b += M * 8;
-  p.ptsD = (float2*)b;
-  b += M * 8;
-  p.counts = (int*)b;
-  b += 64;
+  b += (M * 8 + 255) / 256 * 256;
   p.mask = (uint32_t*)b;
-  b += (size_t)c->H * ((c->W + 31) / 32) * 4;
-  p.stA = b;
-  b += (M + 63) / 64 * 64;
-  p.stB = b;
   return p;
 }
 
 size_t pin_bytes(const esvio_fe_config& cfg) {
   const size_t M = std::max(cfg.max_cnt, 1);
-  return M * 8 * 4 + 64 + (size_t)cfg.height * ((cfg.width + 31) / 32) * 4 + 2 * ((M + 63) / 64 * 64);
+  size_t o[6];
+  const size_t res = res_layout(M, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
+  return (res + 255) / 256 * 256 + (M * 8 + 255) / 256 * 256 +
+         (size_t)cfg.height * ((cfg.width + 31) / 32) * 4 + 256;
 }
 
 void clear_tracker_state(esvio_fe_ctx* c) {
@@ -591,15 +625,12 @@ void clear_tracker_state(esvio_fe_ctx* c) {
   c->cur_time = c->prev_time = 0;
 }
 
-SelectArgs make_select_args(esvio_fe_ctx* c, uint32_t nblk, int max_corners, float2* out_pts,
-                            int out_base, int32_t* out_idx) {
+SelectArgs make_select_args(esvio_fe_ctx* c, int max_corners, float2* out_pts, int out_base,
+                            int32_t* out_idx) {
   SelectArgs s{};
-  s.cand_xy = c->d_cand_xy;
-  s.cand_idx = c->d_cand_idx;
-  s.cand_cnt = c->d_cand_cnt;
-  s.nblk = nblk;
   s.comp_xy = c->d_comp_xy;
   s.comp_idx = c->d_comp_idx;
+  s.total = (const uint32_t*)(c->d_counts + 2);
   s.W = c->W;
   s.H = c->H;
   s.wpr = (c->W + 31) / 32;
@@ -618,6 +649,20 @@ size_t select_lds_bytes(const esvio_fe_ctx* c) {
   return ((size_t)c->H * ((c->W + 31) / 32) + 32) * 4;
 }
 
+// ordered compaction of the Arc* candidates, then the sequential greedy (Event_FeaturesToTrack)
+void run_select(esvio_fe_ctx* c, uint32_t n_events, int max_corners, float2* out_pts, int out_base,
+                int32_t* out_idx) {
+  const uint32_t nblk = (n_events + kArcBlock - 1) / kArcBlock;
+  {
+    ScopedKernel k(c, K_COMPACT, 0);
+    launch_compact(c->stream, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, nblk, c->d_comp_xy,
+                   c->d_comp_idx, (uint32_t*)(c->d_counts + 2));
+  }
+  SelectArgs s = make_select_args(c, max_corners, out_pts, out_base, out_idx);
+  ScopedKernel k(c, K_SELECT, 0);
+  launch_select(c->stream, s, select_lds_bytes(c));
+}
+
 // Arc* flags (+ ordered per-block candidate lists) for the left events
 void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool use_mask,
              bool want_flags, bool want_cand) {
@@ -631,7 +676,7 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool 
   a.filter_threshold = c->cfg.feature_filter_threshold;
   a.border = c->cfg.min_dist + 1;
   a.ts = use_ts ? c->pyr[c->slot_curL].d.img[0] : nullptr;
-  a.ts_stride = c->W + 2 * kPad;
+  a.ts_stride = c->pyr[c->slot_curL].d.stride[0];
   a.ts_lk_threshold = c->cfg.ts_lk_threshold;
   a.mask_bits = use_mask ? c->d_mask_bits : nullptr;
   a.wpr = (c->W + 31) / 32;
@@ -685,19 +730,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     const int n = (int)c->prev_pts.size();
     std::memcpy(pin.ptsA, c->prev_pts.data(), (size_t)n * 8);
     HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    // forward: prevL -> curL, maxLevel 3 (:410)
-    run_lk(c, prevL, curL, c->d_ptsA, c->d_ptsB, c->d_stA, nullptr, n, 3, 30, 0.01, 0);
-    if (cfg.flow_back) {
-      // reverse: curL -> prevL, maxLevel 1, USE_INITIAL_FLOW seeded with prev_pts (:416-418)
-      HIPCHK(c, hipMemcpyAsync(c->d_ptsC, c->d_ptsA, (size_t)n * 8, hipMemcpyDeviceToDevice,
-                               c->stream));
-      run_lk(c, curL, prevL, c->d_ptsB, c->d_ptsC, c->d_stB, nullptr, n, 1, 30, 0.01,
-             ESVIO_FE_LK_USE_INITIAL_FLOW);
-      HIPCHK(c, hipMemcpyAsync(pin.ptsC, c->d_ptsC, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(pin.stB, c->d_stB, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipMemcpyAsync(pin.ptsB, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(pin.stA, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
+    // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
+    LkArgs f = make_lk(prevL, curL, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n, 3, 30, 0.01, 0);
+    LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
+                       ESVIO_FE_LK_USE_INITIAL_FLOW);
+    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_temporal_bytes, hipMemcpyDeviceToHost,
+                             c->stream));
     lap(1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     lap(2);
@@ -750,28 +790,17 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                              c->stream));
   }
   const int n_lk_max = detect ? M : n_kept;
-  if (detect) {
-    const uint32_t nblk = (uint32_t)((nL + kArcBlock - 1) / kArcBlock);
-    SelectArgs s = make_select_args(c, nblk, M - n_kept, c->d_ptsA, n_kept, nullptr);
-    ScopedKernel k(c, K_SELECT, 0);
-    launch_select(c->stream, s, select_lds_bytes(c));
-  }
-  // stereo: curL -> curR (:490) and back curR -> curL (:495), both maxLevel 3
+  if (detect) run_select(c, (uint32_t)nL, M - n_kept, c->d_ptsA, n_kept, nullptr);
+  // stereo: curL -> curR (:490) and back curR -> curL (:495), both maxLevel 3, one launch
   if (n_lk_max > 0) {
     const int* n_ptr = detect ? c->d_counts + 1 : nullptr;
-    run_lk(c, curL, curR, c->d_ptsA, c->d_ptsB, c->d_stA, n_ptr, n_lk_max, 3, 30, 0.01, 0);
-    if (cfg.flow_back)
-      run_lk(c, curR, curL, c->d_ptsB, c->d_ptsC, c->d_stB, n_ptr, n_lk_max, 3, 30, 0.01, 0);
-    if (detect) {
-      HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(pin.ptsD, c->d_ptsA, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipMemcpyAsync(pin.ptsB, c->d_ptsB, (size_t)n_lk_max * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(pin.stA, c->d_stA, (size_t)n_lk_max, hipMemcpyDeviceToHost, c->stream));
-    if (cfg.flow_back) {
-      HIPCHK(c, hipMemcpyAsync(pin.ptsC, c->d_ptsC, (size_t)n_lk_max * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(pin.stB, c->d_stB, (size_t)n_lk_max, hipMemcpyDeviceToHost, c->stream));
-    }
+    LkArgs f = make_lk(curL, curR, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, n_ptr, n_lk_max, 3, 30,
+                       0.01, 0);
+    LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, n_ptr, n_lk_max, 3, 30, 0.01, 0);
+    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->stream));
+  } else if (detect) {
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->stream));
   }
   lap(5);
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -856,8 +885,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
     fprintf(stderr, "\n");
   }
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
-                  c->d_rejected, c->d_ptsA, c->d_ptsB, c->d_ptsC, c->d_ptsD, c->d_stA, c->d_stB,
-                  c->d_counts, c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy,
+                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy,
                   c->d_comp_idx, c->d_mask_bits, c->d_sel_idx, c->pyr[0].mem, c->pyr[1].mem,
                   c->pyr[2].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem};
   for (void* p : ptrs)
@@ -916,13 +944,19 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if ((rc = dev_alloc(c, &c->L2, (size_t)2 * c->P))) return bail(rc);
   if ((rc = dev_alloc(c, &c->S2, (size_t)2 * c->P))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_rejected, 1))) return bail(rc);
-  if ((rc = dev_alloc(c, &c->d_ptsA, M))) return bail(rc);
-  if ((rc = dev_alloc(c, &c->d_ptsB, M))) return bail(rc);
-  if ((rc = dev_alloc(c, &c->d_ptsC, M))) return bail(rc);
+  {
+    size_t oB, oC, oSA, oSB, oCnt, oA;
+    c->res_bytes = res_layout(M, &oB, &oC, &oSA, &oSB, &oCnt, &oA);
+    c->res_temporal_bytes = oCnt;  // ptsB..stB
+    if ((rc = dev_alloc(c, &c->d_res, c->res_bytes))) return bail(rc);
+    c->d_ptsB = (float2*)(c->d_res + oB);
+    c->d_ptsC = (float2*)(c->d_res + oC);
+    c->d_stA = c->d_res + oSA;
+    c->d_stB = c->d_res + oSB;
+    c->d_counts = (int*)(c->d_res + oCnt);
+    c->d_ptsA = (float2*)(c->d_res + oA);
+  }
   if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
-  if ((rc = dev_alloc(c, &c->d_stA, M))) return bail(rc);
-  if ((rc = dev_alloc(c, &c->d_stB, M))) return bail(rc);
-  if ((rc = dev_alloc(c, &c->d_counts, 16))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_sel_idx, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_mask_bits, (size_t)c->H * ((c->W + 31) / 32)))) return bail(rc);
   for (int i = 0; i < 3; i++)
@@ -1029,12 +1063,7 @@ int esvio_fe_features_to_track(esvio_fe_handle c, const esvio_fe_event* ev, size
   HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, bm.bits.size() * 4, hipMemcpyHostToDevice,
                            c->stream));
   run_arc(c, dL, (uint32_t)n, true, true, false, true);
-  const uint32_t nblk = (uint32_t)((n + kArcBlock - 1) / kArcBlock);
-  SelectArgs s = make_select_args(c, nblk, max_corners, c->d_ptsD, 0, c->d_sel_idx);
-  {
-    ScopedKernel k(c, K_SELECT, 0);
-    launch_select(c->stream, s, select_lds_bytes(c));
-  }
+  run_select(c, (uint32_t)n, max_corners, c->d_ptsD, 0, c->d_sel_idx);
   HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int k = pin.counts[0];
@@ -1110,8 +1139,9 @@ int esvio_fe_calc_optical_flow_pyr_lk(esvio_fe_handle c, const uint8_t* prev_img
   HIPCHK(c, hipMemcpyAsync(c->d_ptsA, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
   if (flags & ESVIO_FE_LK_USE_INITIAL_FLOW)
     HIPCHK(c, hipMemcpyAsync(c->d_ptsB, next_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-  run_lk(c, two[0], two[1], c->d_ptsA, c->d_ptsB, c->d_stA, nullptr, n, max_level, max_count, eps,
-         flags);
+  LkArgs f = make_lk(two[0], two[1], c->d_ptsA, c->d_ptsB, c->d_ptsB, c->d_stA, nullptr, n, max_level,
+                     max_count, eps, flags);
+  run_lk(c, f, nullptr, nullptr, nullptr);
   HIPCHK(c, hipMemcpyAsync(next_pts, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(status, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1135,7 +1165,7 @@ int esvio_fe_build_pyramid(esvio_fe_handle c, const uint8_t* img, int w, int hgt
   }
   if (lw) *lw = d.w[level];
   if (lh) *lh = d.h[level];
-  const int stride = d.w[level] + 2 * kPad;
+  const int stride = d.stride[level];
   if (out_img)
     HIPCHK(c, hipMemcpy2DAsync(out_img, d.w[level], d.img[level] + (size_t)kPad * stride + kPad,
                                stride, d.w[level], d.h[level], hipMemcpyDeviceToHost, c->stream));

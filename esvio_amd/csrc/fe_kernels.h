@@ -26,10 +26,12 @@ constexpr int kMaxDiscR = 63;   // max min_dist supported by the selection kerne
 // w[l]+2*kPad; pointers address the padded buffer's origin.
 struct PyrDesc {
   uint8_t* img[kMaxLevels];
-  int16_t* deriv[kMaxLevels];  // interleaved (Ix,Iy)
+  int16_t* deriv[kMaxLevels];  // interleaved (Ix,Iy), same stride (in pixels) as the image
   int w[kMaxLevels], h[kMaxLevels];
+  int stride[kMaxLevels];  // row stride in pixels: (w + 2*kPad) rounded up to 16
   int levels;  // maxLevel (inclusive) actually built
 };
+inline int pyr_stride(int w) { return (w + 2 * kPad + 15) & ~15; }
 
 enum KernelId {
   K_SAE_KEYS = 0,
@@ -43,6 +45,7 @@ enum KernelId {
   K_SCHARR,
   K_LK,
   K_ARC,
+  K_COMPACT,
   K_SELECT,
   K_COUNT
 };
@@ -75,7 +78,7 @@ void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals,
 // renders ncam cameras (S2 + cam*P) into level-0 interiors of dst[cam]
 void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
                          double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
-                         int ncam);
+                         int dst_stride, int ncam);
 
 // ---- pyramid ----------------------------------------------------------------------------
 void launch_pyr_down(hipStream_t s, const PyrDesc* p, int nimg, int src_level);
@@ -87,7 +90,8 @@ struct LkArgs {
   PyrDesc P;  // prev pyramid (+ derivatives)
   PyrDesc N;  // next pyramid (images only)
   const float2* prev_pts;
-  float2* next_pts;  // in (USE_INITIAL_FLOW) / out
+  const float2* init_pts;  // initial nextPts when flags has USE_INITIAL_FLOW (may alias next_pts)
+  float2* next_pts;        // out
   uint8_t* status;
   const int* n_ptr;  // device count (may be NULL -> n_max)
   int n_max;
@@ -96,7 +100,11 @@ struct LkArgs {
   double eps2;
   int flags;
 };
-void launch_lk(hipStream_t s, const LkArgs& a);
+// one launch runs call `f`; if `b` != NULL the same wave then runs call `b` with prevPts = f's
+// result and initial flow = f's prevPts (the forward/backward check of feature_tracker.cpp:410-418
+// and :490-495); b->prev_pts/init_pts/next_pts/status are ignored.
+void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts,
+               uint8_t* back_status);
 
 // ---- Arc* + selection -------------------------------------------------------------------
 struct ArcArgs {
@@ -119,13 +127,15 @@ struct ArcArgs {
 };
 void launch_arc(hipStream_t s, const ArcArgs& a);
 
+// ordered compaction of the per-block candidate lists (parallel; one block per Arc* block)
+void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand_idx,
+                    const uint32_t* cand_cnt, uint32_t nblk, uint32_t* comp_xy, uint32_t* comp_idx,
+                    uint32_t* total);
+
 struct SelectArgs {
-  const uint32_t* cand_xy;
-  const uint32_t* cand_idx;
-  const uint32_t* cand_cnt;
-  uint32_t nblk;
-  uint32_t* comp_xy;   // [>= total candidates] scratch
-  uint32_t* comp_idx;
+  const uint32_t* comp_xy;   // compacted candidates in stream order
+  const uint32_t* comp_idx;
+  const uint32_t* total;     // number of candidates
   int W, H, wpr;
   int max_corners;
   int radius;

@@ -23,28 +23,6 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p >= len ? 2 * len - 2 - p : p;
 }
 
-// wave64 sum of a 64-bit integer with DPP (no LDS, no bpermute): xor-butterfly inside each row
-// of 16, then row_bcast:15 / row_bcast:31; the total lands in lane 63 and is read back uniformly.
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#define ESVIO_DPP_STEP(ctrl, rmask)                                                       \
-  {                                                                                        \
-    int lo = (int)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);          \
-    int tlo = __builtin_amdgcn_update_dpp(0, lo, ctrl, rmask, 0xf, false);                 \
-    int thi = __builtin_amdgcn_update_dpp(0, hi, ctrl, rmask, 0xf, false);                 \
-    v += (long long)(((unsigned long long)(unsigned)thi << 32) | (unsigned)tlo);           \
-  }
-  ESVIO_DPP_STEP(0xB1, 0xf)   // quad_perm [1,0,3,2]
-  ESVIO_DPP_STEP(0x4E, 0xf)   // quad_perm [2,3,0,1]
-  ESVIO_DPP_STEP(0x141, 0xf)  // row_half_mirror
-  ESVIO_DPP_STEP(0x140, 0xf)  // row_mirror
-  ESVIO_DPP_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1,3
-  ESVIO_DPP_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2,3
-#undef ESVIO_DPP_STEP
-  int lo = __builtin_amdgcn_readlane((int)(unsigned long long)v, 63);
-  int hi = __builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), 63);
-  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-
 // ============================================================================ SAE keys
 // Coalesced 16 B/lane read of the raw AoS stream; one u32 key + one u32 index out per event.
 __global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL, uint32_t nL,
@@ -295,7 +273,7 @@ __global__ __launch_bounds__(256) void k_time_surface(const double2* __restrict_
                                                       int H, double t_sync, double decay_sec,
                                                       int ignore_polarity,
                                                       uint8_t* __restrict__ dst0,
-                                                      uint8_t* __restrict__ dst1) {
+                                                      uint8_t* __restrict__ dst1, int stride) {
   const int cam = blockIdx.y;
   const uint32_t P = (uint32_t)W * H;
   const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
@@ -303,16 +281,15 @@ __global__ __launch_bounds__(256) void k_time_surface(const double2* __restrict_
   uint8_t* dst = cam ? dst1 : dst0;
   const double2 s = S2[(size_t)cam * P + px];
   const uint32_t y = px / (uint32_t)W, x = px - y * (uint32_t)W;
-  const int stride = W + 2 * kPad;
   dst[(size_t)(y + kPad) * stride + x + kPad] = ts_pixel(s, t_sync, decay_sec, ignore_polarity);
 }
 
 void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
                          double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
-                         int ncam) {
+                         int dst_stride, int ncam) {
   const uint32_t P = (uint32_t)W * H;
   hipLaunchKernelGGL(k_time_surface, dim3((P + 255) / 256, ncam), dim3(256), 0, s, S2, W, H,
-                     t_sync, decay_sec, ignore_polarity, dst0, dst1);
+                     t_sync, decay_sec, ignore_polarity, dst0, dst1, dst_stride);
 }
 
 // ============================================================================ pyramid
@@ -329,7 +306,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrPack pk, int src_level) {
   const int x = blockIdx.x * 32 + (threadIdx.x & 31);
   const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (x >= dw || y >= dh) return;
-  const int sstride = sw + 2 * kPad, dstride = dw + 2 * kPad;
+  const int sstride = p.stride[src_level], dstride = p.stride[src_level + 1];
   const uint8_t* src = p.img[src_level] + (size_t)kPad * sstride + kPad;
   const int wk[5] = {1, 4, 6, 4, 1};
   int xs[5];
@@ -353,7 +330,7 @@ __global__ __launch_bounds__(256) void k_pyr_pad(PyrPack pk) {
   const int level = blockIdx.y;
   if (level > p.levels) return;
   const int w = p.w[level], h = p.h[level];
-  const int pw = w + 2 * kPad, ph = h + 2 * kPad;
+  const int pw = w + 2 * kPad, ph = h + 2 * kPad, stride = p.stride[level];
   // enumerate only the border ring: top+bottom bands (pw*kPad each), then left+right bands
   const int band = pw * kPad;
   const int side = kPad * h;
@@ -382,7 +359,7 @@ __global__ __launch_bounds__(256) void k_pyr_pad(PyrPack pk) {
     }
     const int sx = reflect101(x - kPad, w), sy = reflect101(y - kPad, h);
     uint8_t* img = p.img[level];
-    img[(size_t)y * pw + x] = img[(size_t)(sy + kPad) * pw + sx + kPad];
+    img[(size_t)y * stride + x] = img[(size_t)(sy + kPad) * stride + sx + kPad];
   }
   (void)ph;
 }
@@ -394,7 +371,7 @@ __global__ __launch_bounds__(256) void k_scharr(PyrPack pk) {
   const int level = blockIdx.y;
   if (level > p.levels) return;
   const int w = p.w[level], h = p.h[level];
-  const int stride = w + 2 * kPad;
+  const int stride = p.stride[level];
   const uint8_t* img = p.img[level] + (size_t)kPad * stride + kPad;
   int* deriv = (int*)(p.deriv[level]) + (size_t)kPad * stride + kPad;
   const int total = w * h;
@@ -439,48 +416,80 @@ void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg) {
 
 // ============================================================================ pyramidal LK
 // cv::calcOpticalFlowPyrLK's LKTrackerInvoker [OpenCV video/lkpyramid.cpp], one wave64 per point,
-// all levels in one launch.  The 21x21 window (441 px) is spread 7 px per lane; the patch
-// (I, Ix, Iy) lives in registers across iterations; the normal-equation sums A11/A12/A22 and
-// the mismatch vector b1/b2 are exact int64 wave reductions (OpenCV's integer-accumulator build
-// of the same loop), so results do not depend on reduction order.
+// all levels — and optionally the forward AND the backward call of a forward/backward check — in
+// one launch.  The loop is instruction-latency bound (one wave per SIMD, <=30 dependent
+// iterations per level), so everything here is about a short dependent chain:
+//  * lane = (window row, 7-px run): 63 lanes cover the 21x21 window, each lane owns 7 horizontally
+//    adjacent pixels, so the 4-tap bilinear needs 8 bytes from each of two rows (not 28 taps);
+//  * the patch (I, Ix, Iy) lives in registers across the <=30 iterations of a level;
+//  * the search region of the next image is staged once per level into a 34x40 B LDS tile
+//    (window + 6 px margin, dword-aligned origin), read back as aligned dwords + v_alignbyte, and
+//    re-staged only if the window drifts out;
+//  * 24-bit integer multiplies (v_mul_i32_i24 / v_mad_i32_i24) everywhere: all operands fit;
+//  * A11/A12/A22 and b1/b2 are exact integer sums (OpenCV's int64-accumulator build of the same
+//    loop): 3 DPP butterflies in int32, 8 v_readlane + scalar adds, one exact i64->f64->f32
+//    conversion, so the result does not depend on reduction order and equals the oracle's bits.
 #define CV_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
-__global__ __launch_bounds__(256) void k_lk(LkArgs a) {
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  const int pt = blockIdx.x * 4 + wave;
-  const int n = a.n_ptr ? *a.n_ptr : a.n_max;
-  if (pt >= n || pt >= a.n_max) return;
+constexpr int kLkMargin = 6;
+constexpr int kLkRegW = 40;                              // staged bytes per row (10 dwords)
+constexpr int kLkRegH = kLkWin + 1 + 2 * kLkMargin;      // 34 rows
+constexpr int kLkRegDw = kLkRegW / 4 * kLkRegH;          // 340 dwords per wave
 
-  constexpr int WIN = kLkWin, NPX = WIN * WIN, R = (NPX + 63) / 64;  // 7 px per lane
+// sums over the wave of two per-lane values with |v| < 2^28 (interleaved chains)
+__device__ __forceinline__ void wave_sum2_small(int a, int b, long long& ta, long long& tb) {
+  a += __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  b += __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xf, 0xf, false);
+  a += __builtin_amdgcn_update_dpp(0, a, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  b += __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xf, 0xf, false);
+  a += __builtin_amdgcn_update_dpp(0, a, 0x141, 0xf, 0xf, false);  // row_half_mirror: 8-lane sums
+  b += __builtin_amdgcn_update_dpp(0, b, 0x141, 0xf, 0xf, false);
+  ta = 0;
+  tb = 0;
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    ta += (long long)__builtin_amdgcn_readlane(a, g * 8);
+    tb += (long long)__builtin_amdgcn_readlane(b, g * 8);
+  }
+}
+// exact for |t| < 2^53: one rounding, identical to (float)(int64) on the host
+__device__ __forceinline__ float i64_to_f32(long long t) { return (float)(double)t; }
+
+struct LkCall {
+  PyrDesc P;  // prev pyramid (+ derivatives)
+  PyrDesc N;  // next pyramid (images only)
+  int max_level;
+  int max_count;
+  double eps2;
+  int flags;
+};
+
+// one calcOpticalFlowPyrLK call for one point; returns nextPts[pt] and status
+__device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, const float2 init,
+                                         uint32_t* regJ, int lane, float2& np_out, int& st_out) {
+  constexpr int WIN = kLkWin, NP = 7;
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
   const float FLT_SCALE = 1.f / (1 << 20);
+  const bool on = lane < 63;
+  const int row = on ? lane / 3 : 0;
+  const int x0 = on ? (lane - row * 3) * NP : 0;
 
-  const float2 prev0 = a.prev_pts[pt];
-  float2 np = (a.flags & 4) ? a.next_pts[pt] : make_float2(0.f, 0.f);  // nextPts[ptidx]
+  float2 np = (c.flags & 4) ? init : make_float2(0.f, 0.f);  // nextPts[ptidx]
   int st = 1;
 
-  // per-lane window coordinates
-  int wx[R], wy[R];
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    const int idx = r * 64 + lane;
-    wy[r] = idx / WIN;
-    wx[r] = idx - wy[r] * WIN;
-  }
-
-  for (int level = a.max_level; level >= 0; level--) {
-    const int cols = a.P.w[level], rows = a.P.h[level];
-    const int stride = cols + 2 * kPad;
-    const uint8_t* I = a.P.img[level] + (size_t)kPad * stride + kPad;
-    const uint8_t* J = a.N.img[level] + (size_t)kPad * stride + kPad;
-    const int* dI = (const int*)a.P.deriv[level] + (size_t)kPad * stride + kPad;
+  for (int level = c.max_level; level >= 0; level--) {
+    const int cols = c.P.w[level], rows = c.P.h[level];
+    const int stride = c.P.stride[level];
+    const uint8_t* I = c.P.img[level] + (size_t)kPad * stride + kPad;
+    const uint8_t* J = c.N.img[level] + (size_t)kPad * stride + kPad;
+    const int* dI = (const int*)c.P.deriv[level] + (size_t)kPad * stride + kPad;
 
     const float sc = 1.f / (float)(1 << level);
     float prevX = prev0.x * sc, prevY = prev0.y * sc;
     float nextX, nextY;
-    if (level == a.max_level) {
-      if (a.flags & 4) {
+    if (level == c.max_level) {
+      if (c.flags & 4) {
         nextX = np.x * sc;
         nextY = np.y * sc;
       } else {
@@ -506,38 +515,49 @@ __global__ __launch_bounds__(256) void k_lk(LkArgs a) {
     int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
     int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-    int pI[R], pIx[R], pIy[R];
-    long long sA11 = 0, sA12 = 0, sA22 = 0;
+    // ---- patch of the previous image: I (x32), Ix, Iy for this lane's 7 pixels
+    int pI[NP], pIx[NP], pIy[NP];
+    int sA11 = 0, sA12 = 0, sA22 = 0;  // 7 terms <= 2^24 each
+    {
+      const ptrdiff_t o = (ptrdiff_t)(row + iprevY) * stride + iprevX + x0;
+      const uint8_t* s0 = I + o;
+      const uint8_t* s1 = s0 + stride;
+      const int* d0 = dI + o;
+      const int* d1 = d0 + stride;
+      int t0[NP + 1], t1[NP + 1], g0[NP + 1], g1[NP + 1];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      pI[r] = 0;
-      pIx[r] = 0;
-      pIy[r] = 0;
-      if (r * 64 + lane < NPX) {
-        const ptrdiff_t o = (ptrdiff_t)(wy[r] + iprevY) * stride + iprevX + wx[r];
-        const uint8_t* src = I + o;
-        const int* ds = dI + o;
-        const int ival = CV_DESCALE((int)src[0] * iw00 + (int)src[1] * iw01 +
-                                        (int)src[stride] * iw10 + (int)src[stride + 1] * iw11,
+      for (int k = 0; k <= NP; k++) {
+        t0[k] = s0[k];
+        t1[k] = s1[k];
+        g0[k] = d0[k];
+        g1[k] = d1[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int ival = CV_DESCALE(__mul24(t0[k], iw00) + __mul24(t0[k + 1], iw01) +
+                                        __mul24(t1[k], iw10) + __mul24(t1[k + 1], iw11),
                                     W_BITS - 5);
-        const int d00 = ds[0], d01 = ds[1], d10 = ds[stride], d11 = ds[stride + 1];
-        const int ixval = CV_DESCALE((int)(int16_t)d00 * iw00 + (int)(int16_t)d01 * iw01 +
-                                         (int)(int16_t)d10 * iw10 + (int)(int16_t)d11 * iw11,
+        const int ixval =
+            CV_DESCALE(__mul24((int)(int16_t)g0[k], iw00) + __mul24((int)(int16_t)g0[k + 1], iw01) +
+                           __mul24((int)(int16_t)g1[k], iw10) + __mul24((int)(int16_t)g1[k + 1], iw11),
+                       W_BITS);
+        const int iyval = CV_DESCALE(__mul24(g0[k] >> 16, iw00) + __mul24(g0[k + 1] >> 16, iw01) +
+                                         __mul24(g1[k] >> 16, iw10) + __mul24(g1[k + 1] >> 16, iw11),
                                      W_BITS);
-        const int iyval = CV_DESCALE((d00 >> 16) * iw00 + (d01 >> 16) * iw01 + (d10 >> 16) * iw10 +
-                                         (d11 >> 16) * iw11,
-                                     W_BITS);
-        pI[r] = (int)(int16_t)ival;
-        pIx[r] = (int)(int16_t)ixval;
-        pIy[r] = (int)(int16_t)iyval;
-        sA11 += (long long)(ixval * ixval);
-        sA12 += (long long)(ixval * iyval);
-        sA22 += (long long)(iyval * iyval);
+        pI[k] = (int)(int16_t)ival;
+        pIx[k] = on ? (int)(int16_t)ixval : 0;
+        pIy[k] = on ? (int)(int16_t)iyval : 0;
+        sA11 += __mul24(pIx[k], pIx[k]);
+        sA12 += __mul24(pIx[k], pIy[k]);
+        sA22 += __mul24(pIy[k], pIy[k]);
       }
     }
-    const float A11 = (float)wave_sum_i64(sA11) * FLT_SCALE;
-    const float A12 = (float)wave_sum_i64(sA12) * FLT_SCALE;
-    const float A22 = (float)wave_sum_i64(sA22) * FLT_SCALE;
+    long long tA11, tA12, tA22, tdummy;
+    wave_sum2_small(sA11, sA12, tA11, tA12);
+    wave_sum2_small(sA22, 0, tA22, tdummy);
+    const float A11 = i64_to_f32(tA11) * FLT_SCALE;
+    const float A12 = i64_to_f32(tA12) * FLT_SCALE;
+    const float A22 = i64_to_f32(tA22) * FLT_SCALE;
 
     float D = A11 * A22 - A12 * A12;
     const float minEig =
@@ -551,42 +571,78 @@ __global__ __launch_bounds__(256) void k_lk(LkArgs a) {
     nextX -= halfWin;
     nextY -= halfWin;
     float prevDx = 0.f, prevDy = 0.f;
-    for (int j = 0; j < a.max_count; j++) {
-      const int inextX = (int)floorf(nextX), inextY = (int)floorf(nextY);
+    int rx0 = 0, ry0 = 0;
+    bool staged = false;
+    for (int j = 0; j < c.max_count; j++) {
+      const float flX = floorf(nextX), flY = floorf(nextY);
+      const int inextX = (int)flX, inextY = (int)flY;
       if (inextX < -WIN || inextX >= cols || inextY < -WIN || inextY >= rows) {
         if (level == 0) st = 0;
         break;
       }
-      fa = nextX - inextX;
-      fb = nextY - inextY;
+      int offx = inextX - rx0, offy = inextY - ry0;
+      if (!staged || (unsigned)offx > (unsigned)(kLkRegW - (WIN + 1)) ||
+          (unsigned)offy > (unsigned)(kLkRegH - (WIN + 1))) {
+        // (re)stage the search region around the current window, origin dword-aligned
+        rx0 = (inextX - kLkMargin) & ~3;
+        ry0 = inextY - kLkMargin;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int k = 0; k < (kLkRegDw + 63) / 64; k++) {
+          const int d = k * 64 + lane;
+          if (d < kLkRegDw) {
+            const int ry = d / (kLkRegW / 4), rw = d - ry * (kLkRegW / 4);
+            int gy = ry0 + ry, gx = rx0 + 4 * rw;
+            // clamp into the padded buffer; clamped bytes are never used by a valid window
+            gy = min(max(gy, -kPad), rows + kPad - 1);
+            gx = min(max(gx, -kPad), stride - kPad - 4);
+            regJ[d] = *(const uint32_t*)(J + (ptrdiff_t)gy * stride + gx);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        staged = true;
+        offx = inextX - rx0;
+        offy = inextY - ry0;
+      }
+      fa = nextX - flX;
+      fb = nextY - flY;
       iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
       iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
       iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
       iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-      int sb1 = 0, sb2 = 0;  // 7 terms of <= 2^25 each fit int32
-      long long lb1 = 0, lb2 = 0;
+      // 8 bytes of two consecutive staged rows: 3 aligned dwords per row + funnel shift
+      const int bo = (row + offy) * kLkRegW + offx + x0;
+      const uint32_t* rp = regJ + (bo >> 2);
+      const uint32_t sh = (uint32_t)bo & 3u;
+      const uint32_t a0 = rp[0], a1 = rp[1], a2 = rp[2];
+      const uint32_t c0 = rp[kLkRegW / 4], c1 = rp[kLkRegW / 4 + 1], c2 = rp[kLkRegW / 4 + 2];
+      const uint32_t w0[2] = {__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh)};
+      const uint32_t w1[2] = {__builtin_amdgcn_alignbyte(c1, c0, sh), __builtin_amdgcn_alignbyte(c2, c1, sh)};
+      int q0[NP + 1], q1[NP + 1];
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (r * 64 + lane < NPX) {
-          const uint8_t* Jp = J + (ptrdiff_t)(wy[r] + inextY) * stride + inextX + wx[r];
-          const int diff = CV_DESCALE((int)Jp[0] * iw00 + (int)Jp[1] * iw01 +
-                                          (int)Jp[stride] * iw10 + (int)Jp[stride + 1] * iw11,
-                                      W_BITS - 5) -
-                           pI[r];
-          sb1 += diff * pIx[r];
-          sb2 += diff * pIy[r];
-        }
+      for (int k = 0; k <= NP; k++) {
+        q0[k] = (int)((w0[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        q1[k] = (int)((w1[k >> 2] >> (8 * (k & 3))) & 0xffu);
       }
-      lb1 = sb1;
-      lb2 = sb2;
-      const float b1 = (float)wave_sum_i64(lb1) * FLT_SCALE;
-      const float b2 = (float)wave_sum_i64(lb2) * FLT_SCALE;
+      int sb1 = 0, sb2 = 0;  // 7 terms of <= 2^25 each
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int t = __mul24(q0[k], iw00) + __mul24(q0[k + 1], iw01) + __mul24(q1[k], iw10) +
+                      __mul24(q1[k + 1], iw11);
+        const int diff = CV_DESCALE(t, W_BITS - 5) - pI[k];
+        sb1 += __mul24(diff, pIx[k]);
+        sb2 += __mul24(diff, pIy[k]);
+      }
+      long long tb1, tb2;
+      wave_sum2_small(sb1, sb2, tb1, tb2);
+      const float b1 = i64_to_f32(tb1) * FLT_SCALE;
+      const float b2 = i64_to_f32(tb2) * FLT_SCALE;
       const float dx = (A12 * b2 - A22 * b1) * D;
       const float dy = (A12 * b1 - A11 * b2) * D;
       nextX += dx;
       nextY += dy;
       np = make_float2(nextX + halfWin, nextY + halfWin);
-      if ((double)dx * (double)dx + (double)dy * (double)dy <= a.eps2) break;
+      if ((double)dx * (double)dx + (double)dy * (double)dy <= c.eps2) break;
       if (j > 0 && (double)fabsf(dx + prevDx) < 0.01 && (double)fabsf(dy + prevDy) < 0.01) {
         np.x -= dx * 0.5f;
         np.y -= dy * 0.5f;
@@ -601,14 +657,78 @@ __global__ __launch_bounds__(256) void k_lk(LkArgs a) {
       if (ix < -WIN || ix >= cols || iy < -WIN || iy >= rows) st = 0;
     }
   }
+  np_out = np;
+  st_out = st;
+}
+
+struct LkKernelArgs {
+  LkCall fwd;
+  LkCall back;       // used when have_back: prevPts = fwd result, init = fwd prevPts
+  int have_back;
+  const float2* prev_pts;
+  const float2* init_pts;  // fwd initial flow (USE_INITIAL_FLOW), may be NULL
+  float2* next_pts;        // fwd result
+  uint8_t* status;         // fwd status
+  float2* back_pts;        // back result
+  uint8_t* back_status;
+  const int* n_ptr;        // device count (may be NULL -> n_max)
+  int n_max;
+};
+
+__global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int pt = blockIdx.x * 4 + wave;
+  const int n = a.n_ptr ? *a.n_ptr : a.n_max;
+  if (pt >= n || pt >= a.n_max) return;
+  const float2 prev0 = a.prev_pts[pt];
+  const float2 init = (a.fwd.flags & 4) ? a.init_pts[pt] : make_float2(0.f, 0.f);
+  float2 np;
+  int st;
+  lk_point(a.fwd, prev0, init, regJ_s[wave], lane, np, st);
   if (lane == 0) {
     a.next_pts[pt] = np;
     a.status[pt] = (uint8_t)st;
   }
+  if (a.have_back) {
+    float2 bp;
+    int bs;
+    lk_point(a.back, np, prev0, regJ_s[wave], lane, bp, bs);
+    if (lane == 0) {
+      a.back_pts[pt] = bp;
+      a.back_status[pt] = (uint8_t)bs;
+    }
+  }
 }
 
-void launch_lk(hipStream_t s, const LkArgs& a) {
-  if (a.n_max <= 0) return;
+void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts,
+               uint8_t* back_status) {
+  if (f.n_max <= 0) return;
+  LkKernelArgs a;
+  a.fwd.P = f.P;
+  a.fwd.N = f.N;
+  a.fwd.max_level = f.max_level;
+  a.fwd.max_count = f.max_count;
+  a.fwd.eps2 = f.eps2;
+  a.fwd.flags = f.flags;
+  a.have_back = b ? 1 : 0;
+  a.back = a.fwd;
+  if (b) {
+    a.back.P = b->P;
+    a.back.N = b->N;
+    a.back.max_level = b->max_level;
+    a.back.max_count = b->max_count;
+    a.back.eps2 = b->eps2;
+    a.back.flags = b->flags;
+  }
+  a.prev_pts = f.prev_pts;
+  a.init_pts = f.init_pts;
+  a.next_pts = f.next_pts;
+  a.status = f.status;
+  a.back_pts = back_pts;
+  a.back_status = back_status;
+  a.n_ptr = f.n_ptr;
+  a.n_max = f.n_max;
   hipLaunchKernelGGL(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
 }
 
@@ -743,52 +863,56 @@ void launch_arc(hipStream_t s, const ArcArgs& a) {
 // ============================================================================ greedy selection
 // Event_FeaturesToTrack (feature_tracker.cpp:13-38): candidates in stream order; accept iff the
 // pixel is not blocked; stamp cv::circle(r = MIN_DIST, filled) [OpenCV midpoint disc]; stop at
-// max_corners.  One 1024-thread block: all waves compact the per-block candidate lists, then
-// wave 0 runs the inherently sequential greedy with the blocked-bitmap in LDS.
-__global__ __launch_bounds__(1024) void k_select(SelectArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  volatile uint32_t* bitmap = lds;                  // H * wpr words
-  uint32_t* scan = lds + (size_t)a.H * a.wpr;      // 1024 + 1 words
-  const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-  for (int i = tid; i < a.H * a.wpr; i += 1024) lds[i] = 0;
-
-  // ---- ordered compaction of the per-arc-block lists ----
-  uint32_t total = 0;
-  for (uint32_t b0 = 0; b0 < a.nblk; b0 += 1024) {
-    const uint32_t b = b0 + tid;
-    const uint32_t c = b < a.nblk ? a.cand_cnt[b] : 0;
-    // block exclusive scan of c
-    uint32_t v = c;
+// max_corners.  k_compact turns the per-block candidate lists into one ordered list (parallel),
+// k_select is the inherently sequential greedy: ONE wave, blocked-bitmap of new discs in LDS,
+// 64 candidates tested per step, ballot picks the first alive one.
+__global__ __launch_bounds__(kArcBlock) void k_compact(const uint32_t* __restrict__ cand_xy,
+                                                       const uint32_t* __restrict__ cand_idx,
+                                                       const uint32_t* __restrict__ cand_cnt,
+                                                       uint32_t nblk, uint32_t* __restrict__ comp_xy,
+                                                       uint32_t* __restrict__ comp_idx,
+                                                       uint32_t* __restrict__ total) {
+  __shared__ uint32_t part[kArcBlock / 64];
+  const uint32_t b = blockIdx.x;
+  // exclusive prefix of the counts of all earlier blocks (every block recomputes its own)
+  uint32_t s = 0;
+  for (uint32_t j = threadIdx.x; j < b; j += kArcBlock) s += cand_cnt[j];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(v, o);
-      if (lane >= o) v += t;
-    }
-    __syncthreads();
-    if (lane == 63) scan[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t run = 0;
-      for (int w = 0; w < 16; w++) {
-        const uint32_t t = scan[w];
-        scan[w] = run;
-        run += t;
-      }
-      scan[16] = run;
-    }
-    __syncthreads();
-    const uint32_t off = total + scan[wave] + v - c;
-    for (uint32_t k = 0; k < c; k++) {
-      a.comp_xy[off + k] = a.cand_xy[(size_t)b * kArcBlock + k];
-      a.comp_idx[off + k] = a.cand_idx[(size_t)b * kArcBlock + k];
-    }
-    total += scan[16];
-  }
-  __threadfence_block();
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane_id() == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (wave != 0) return;
+  uint32_t off = 0;
+  for (int w = 0; w < kArcBlock / 64; w++) off += part[w];
+  const uint32_t c = cand_cnt[b];
+  if (threadIdx.x < c) {
+    comp_xy[off + threadIdx.x] = cand_xy[(size_t)b * kArcBlock + threadIdx.x];
+    comp_idx[off + threadIdx.x] = cand_idx[(size_t)b * kArcBlock + threadIdx.x];
+  }
+  if (b == nblk - 1 && threadIdx.x == 0) *total = off + c;
+}
 
-  // ---- sequential greedy, wave 0 ----
+void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand_idx,
+                    const uint32_t* cand_cnt, uint32_t nblk, uint32_t* comp_xy, uint32_t* comp_idx,
+                    uint32_t* total) {
+  if (!nblk) return;
+  hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(kArcBlock), 0, s, cand_xy, cand_idx, cand_cnt, nblk,
+                     comp_xy, comp_idx, total);
+}
+
+__global__ __launch_bounds__(64) void k_select(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  volatile uint32_t* bitmap = lds;  // H * wpr words, bit set = inside a disc stamped by this call
+  const int lane = lane_id();
+  const int nwords = a.H * a.wpr;
+  for (int i = lane * 4; i < nwords; i += 256) {
+    if (i + 3 < nwords) {
+      *(uint4*)(lds + i) = make_uint4(0, 0, 0, 0);
+    } else {
+      for (int k = i; k < nwords; k++) lds[k] = 0;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const uint32_t total = *a.total;
   int accepted = 0;
   const int r = a.radius;
   for (uint32_t base = 0; base < total && accepted < a.max_corners; base += 64) {
@@ -811,15 +935,15 @@ __global__ __launch_bounds__(1024) void k_select(SelectArgs a) {
       }
       accepted++;
       // stamp the disc: one lane per row
-      for (int row = lane; row < 2 * r + 1; row += 64) {
-        const int yy = ay - r + row;
+      for (int rowi = lane; rowi < 2 * r + 1; rowi += 64) {
+        const int yy = ay - r + rowi;
         if (yy < 0 || yy >= a.H) continue;
-        const int hw = a.hw[row < r ? r - row : row - r];
+        const int hw = a.hw[rowi < r ? r - rowi : rowi - r];
         if (hw < 0) continue;
-        const int x0 = max(ax - hw, 0), x1 = min(ax + hw, a.W - 1);
-        if (x1 < x0) continue;
-        for (int w = x0 >> 5; w <= (x1 >> 5); w++) {
-          const int lo = max(x0 - (w << 5), 0), hi = min(x1 - (w << 5), 31);
+        const int xa = max(ax - hw, 0), xb = min(ax + hw, a.W - 1);
+        if (xb < xa) continue;
+        for (int w = xa >> 5; w <= (xb >> 5); w++) {
+          const int lo = max(xa - (w << 5), 0), hi = min(xb - (w << 5), 31);
           const uint32_t bits = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
           bitmap[yy * a.wpr + w] |= bits;
         }
@@ -835,7 +959,7 @@ __global__ __launch_bounds__(1024) void k_select(SelectArgs a) {
 }
 
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
-  hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), lds_bytes, s, a);
+  hipLaunchKernelGGL(k_select, dim3(1), dim3(64), lds_bytes, s, a);
 }
 
 }  // namespace esvio

@@ -356,6 +356,9 @@ void scharr_padded(const uint8_t* src, int w, int h, int pad, std::vector<int16_
                 sizeof(int16_t) * 2 * w);
 }
 
+// diagnostics: total LK iterations / (point,level) visits since the last reset
+unsigned long long g_lk_iters = 0, g_lk_visits = 0, g_lk_maxed = 0;
+
 // LKTrackerInvoker::operator() for all points at one level (video/src/lkpyramid.cpp) [OpenCV]
 // I, J: level images padded by `win` with BORDER_REFLECT_101; dI: Scharr (Ix,Iy) of I padded by
 // `win` with BORDER_CONSTANT 0 — exactly the buffers OpenCV's tracker indexes.  cols/rows are
@@ -459,7 +462,10 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
     nextX -= halfWinX;
     nextY -= halfWinY;
     float prevDeltaX = 0, prevDeltaY = 0;
+    g_lk_visits++;
     for (int j = 0; j < maxCount; j++) {
+      g_lk_iters++;
+      if (j == maxCount - 1) g_lk_maxed++;
       int inextX = cv_floor_f(nextX), inextY = cv_floor_f(nextY);
       if (inextX < -win || inextX >= cols || inextY < -win || inextY >= rows) {
         if (level == 0) status[ptidx] = 0;
@@ -1406,6 +1412,12 @@ void oracle_tracker_time_surface(void* tv, int cam, uint8_t* out) {
   std::memcpy(out, s.data(), s.size());
 }
 void* oracle_tracker_detector(void* tv) { return &((Tracker*)tv)->det; }
+void oracle_lk_iter_stats(unsigned long long* out3, int reset) {
+  out3[0] = g_lk_iters;
+  out3[1] = g_lk_visits;
+  out3[2] = g_lk_maxed;
+  if (reset) g_lk_iters = g_lk_visits = g_lk_maxed = 0;
+}
 void oracle_tracker_stage_seconds(void* tv, double* out6) {
   std::memcpy(out6, ((Tracker*)tv)->stage_s, sizeof(double) * 6);
 }

@@ -134,6 +134,8 @@ int oracle_track_event(void* t, double cur_time, const oracle_event* left, size_
 /* taps */
 void oracle_tracker_time_surface(void* t, int cam, uint8_t* out);
 void* oracle_tracker_detector(void* t);
+/* diagnostics: {LK iterations, (point,level) visits, visits that hit maxCount} */
+void oracle_lk_iter_stats(unsigned long long* out3, int reset);
 /* per-stage wall-clock accumulators (seconds): sae, ts, lk_temporal, detect, lk_stereo, host */
 void oracle_tracker_stage_seconds(void* t, double* out6);
 
