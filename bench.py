@@ -67,6 +67,7 @@ def main():
 
     from esvio_amd import frontend as FE
     from esvio_amd.events import event_times
+    from esvio_amd.dist import TrackExchange
     from esvio_amd.node import FreqControl, pack_track_records
     from esvio_amd.synth import SceneStream
 
@@ -87,25 +88,17 @@ def main():
     cfg = FE.make_config(W, H, device=local_rank, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1)
     ft = FE.FeatureTracker(cfg)
     fc = FreqControl(args.freq)
-    rec_dev = torch.zeros((cfg.max_cnt * 2, 8), dtype=torch.float32, device="cuda")
-    gathered = [torch.zeros_like(rec_dev) for _ in range(world)] if world > 1 else None
-    comm_stream = torch.cuda.Stream() if world > 1 else None
-    pending = None
+    exch = (TrackExchange(cfg.max_cnt, world, device="cuda", dist=dist, stream=torch.cuda.Stream())
+            if world > 1 else None)
 
     def step(i):
-        nonlocal pending
         tl, tr, nl, nr, t_last = dev_batches[i]
         pub = fc.pub_this_frame(t_last)
         ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
         if pub:
             fc.published()
-            if world > 1:  # merge tracked corners of all rigs (async, overlaps the next frame)
-                if pending is not None:
-                    pending.wait()
-                rec = pack_track_records(ft, cfg.max_cnt)
-                with torch.cuda.stream(comm_stream):
-                    rec_dev.copy_(torch.from_numpy(rec), non_blocking=False)
-                    pending = dist.all_gather(gathered, rec_dev, async_op=True)
+            if exch is not None:  # merge tracked corners of all rigs (async, overlaps next frame)
+                exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
         return nl + nr
 
     def barrier():
@@ -120,8 +113,8 @@ def main():
     n_events = 0
     for i in range(args.warmup, n_frames):
         n_events += step(i)
-    if pending is not None:
-        pending.wait()
+    if exch is not None:
+        exch.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -1,0 +1,61 @@
+"""Multi-GPU plumbing (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" for CPU tests).
+
+The hot path shards by independent unit — one stereo rig (or one time-ordered stream) per rank,
+no data-path collective.  The only exchange is the north-star's merge step: one all_gather per
+published frame of the fixed-size tracked-corner records (2*max_cnt rows x 8 float32 =
+19.2 KB at max_cnt 300), so that every rank / the estimator on rank 0 sees all rigs' tracks.
+The payload is latency-bound; xGMI bandwidth is irrelevant.
+"""
+import numpy as np
+
+
+def shard_units(n_units, world, rank):
+    """round-robin assignment of independent rigs/streams to ranks"""
+    return [u for u in range(n_units) if u % world == rank]
+
+
+class TrackExchange:
+    """one (async) all_gather of track records per published frame."""
+
+    def __init__(self, max_cnt, world, device="cpu", dist=None, stream=None):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.world = world
+        self.rows = 2 * max_cnt
+        self.send = torch.zeros((self.rows, 8), dtype=torch.float32, device=device)
+        self.recv = [torch.zeros_like(self.send) for _ in range(world)]
+        self.stream = stream
+        self.pending = None
+
+    def submit(self, rec, async_op=True):
+        """rec: (2*max_cnt, 8) float32 numpy block from node.pack_track_records"""
+        self.wait()
+        t = self.torch.from_numpy(np.ascontiguousarray(rec, np.float32))
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                self.send.copy_(t)
+                self.pending = self.dist.all_gather(self.recv, self.send, async_op=async_op)
+        else:
+            self.send.copy_(t)
+            self.pending = self.dist.all_gather(self.recv, self.send, async_op=async_op)
+        return self.pending
+
+    def wait(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+
+    def result(self):
+        """(world, rows, 8) array; rows with id (column 3) < 0 are padding"""
+        self.wait()
+        return np.stack([r.detach().cpu().numpy() for r in self.recv])
+
+
+def merged_point_cloud(gathered):
+    """concatenate every rank's valid PointCloud rows, tagging the rig (rank) in a 9th column"""
+    out = []
+    for rk, block in enumerate(gathered):
+        valid = block[block[:, 3] >= 0]
+        out.append(np.c_[valid, np.full(len(valid), rk, np.float32)])
+    return np.concatenate(out, 0) if out else np.zeros((0, 9), np.float32)

@@ -1,0 +1,59 @@
+"""Committed regression vectors (tests/golden/scene_192x144.npz, made by tests/golden/make_golden.py
+from the CPU oracle — the reference has no fixtures and cannot run here).  CPU: the oracle still
+reproduces them.  GPU: the HIP path reproduces them bit for bit through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from esvio_amd.events import EVENT_DTYPE
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_192x144.npz")
+KEYS = ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity", "ids_right", "cur_right_pts",
+        "cur_un_right_pts", "right_pts_velocity")
+
+
+def _load():
+    z = np.load(G)
+    kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+    return z, int(z["W"]), int(z["H"]), int(z["n_batches"]), kw
+
+
+def _events(z, name):
+    return np.ascontiguousarray(z[name]).view(EVENT_DTYPE).reshape(-1)
+
+
+def _check(z, b, ts_l, ts_r, flags, res):
+    assert np.array_equal(ts_l, z["tsL%d" % b]) and np.array_equal(ts_r, z["tsR%d" % b])
+    assert np.array_equal(flags, z["flags%d" % b])
+    for k in KEYS:
+        a, e = getattr(res, k), z["%s%d" % (k, b)]
+        assert a.shape == e.shape and np.array_equal(a, e), (b, k)
+
+
+def test_oracle_reproduces_golden(oracle):
+    z, W, H, NB, kw = _load()
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for b in range(NB):
+        L, R = _events(z, "L%d" % b), _events(z, "R%d" % b)
+        r = tr.track_event(float(z["t%d" % b]), L, R, bool(z["pub%d" % b]))
+        _check(z, b, tr.time_surface(0), tr.time_surface(1), tr.detector().corner_flags(L), r)
+    det = tr.detector()
+    for cam in (0, 1):
+        for name, p in zip(("L0", "L1", "S0", "S1"), det.get_sae(cam)):
+            assert np.array_equal(p, z["sae_cam%d_%s" % (cam, name)])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden():
+    from esvio_amd import frontend as FE
+    z, W, H, NB, kw = _load()
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    for b in range(NB):
+        L, R = _events(z, "L%d" % b), _events(z, "R%d" % b)
+        ft.trackEvent(float(z["t%d" % b]), L, R, bool(z["pub%d" % b]))
+        _check(z, b, ft.gettimesurface(0), ft.gettimesurface(1), ft.detector.isCorner(L), ft)
+    for cam in (0, 1):
+        for name, p in zip(("L0", "L1", "S0", "S1"), ft.detector.get_sae(cam)):
+            assert np.array_equal(p, z["sae_cam%d_%s" % (cam, name)])
+    ft.close()

@@ -1,0 +1,151 @@
+"""Host-side logic around the kernels: the node harness mirror (handle_stereo_event) and the
+multi-rank track exchange, on CPU (gloo, world_size 2)."""
+import os
+import socket
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from esvio_amd.events import make_events
+from esvio_amd.node import FreqControl, StereoEventTrackerNode, pack_point_cloud, pack_track_records
+
+
+def _fake_tracker():
+    ft = SimpleNamespace()
+    ft.ids = np.array([7, 3, 9, 12], np.int32)
+    ft.track_cnt = np.array([5, 1, 2, 3], np.int32)
+    ft.cur_pts = np.arange(8, dtype=np.float32).reshape(4, 2)
+    ft.cur_un_pts = ft.cur_pts / 100
+    ft.pts_velocity = ft.cur_pts / 10
+    ft.ids_right = np.array([3, 9, 12], np.int32)
+    ft.cur_right_pts = np.arange(6, dtype=np.float32).reshape(3, 2) + 50
+    ft.cur_un_right_pts = ft.cur_right_pts / 100
+    ft.right_pts_velocity = ft.cur_right_pts / 10
+    return ft
+
+
+def test_point_cloud_packing_rules():
+    """node:273-329: left entries need track_cnt > 1; right entries need their id in the left set;
+    channel 0 is id*2+cam as float32; z == 1"""
+    pc = pack_point_cloud(_fake_tracker())
+    assert pc.shape == (5, 8)
+    assert pc[:, 3].tolist() == [14.0, 18.0, 24.0, 19.0, 25.0]  # 7,9,12 left; 9,12 right (3 dropped)
+    assert (pc[:, 2] == 1.0).all()
+    v = (pc[:, 3] + 0.5).astype(int)  # the estimator's decode (stereo_estimator_node.cpp:388-401)
+    assert (v // 2).tolist() == [7, 9, 12, 9, 12] and (v % 2).tolist() == [0, 0, 0, 1, 1]
+    assert pc[3, 4] == 52.0 and pc[3, 5] == 53.0
+    rec = pack_track_records(_fake_tracker(), 4)
+    assert rec.shape == (8, 8) and (rec[5:, 3] == -1).all() and np.array_equal(rec[:5], pc)
+
+
+def test_freq_control_publishes_at_freq():
+    """node:177-188 at 30 Hz input and freq 15: about every other frame is published"""
+    fc = FreqControl(15)
+    t0 = 100.0
+    pubs = []
+    for k in range(300):
+        p = fc.pub_this_frame(t0 + k / 30.0)
+        pubs.append(p)
+        if p:
+            fc.published()
+    rate = sum(pubs) / (299 / 30.0)
+    assert 14.0 <= rate <= 16.5
+    assert not pubs[0]
+
+
+class _StubTracker:
+    def __init__(self):
+        self.calls = []
+        self.resets = 0
+        f = _fake_tracker()
+        self.__dict__.update(f.__dict__)
+
+    def trackEvent(self, t, L, R, pub):
+        self.calls.append((t, len(L), len(R), pub))
+
+    def reset(self):
+        self.resets += 1
+
+
+def test_handle_stereo_event_flow():
+    tr = _StubTracker()
+    node = StereoEventTrackerNode(tr, freq=15)
+    ev = make_events([1, 2], [1, 2], [5_000_000, 5_010_000], [1, 0])
+    empty = ev[:0]
+    assert node.handle(empty, ev, 5.0) is None and not tr.calls            # node:150
+    assert node.handle(ev, ev, 5.0) is None and not tr.calls               # first frame (node:155)
+    out = node.handle(ev, ev, 5.0333)
+    # pub_count starts at 1: 1/0.0333 = 30 Hz > FREQ -> tracked but not published (node:177-188);
+    # cur_time is the last LEFT event's stamp (node:190)
+    assert len(tr.calls) == 1 and tr.calls[0][0] == 5.01 and tr.calls[0][3] is False
+    assert out is None
+    out = node.handle(ev, ev, 5.0 + 2 / 30.0)                               # 1/0.0667 = 15 -> publish
+    assert tr.calls[-1][3] is True and out is None                         # first publish swallowed
+    out = node.handle(ev, ev, 5.0 + 4 / 30.0)
+    assert tr.calls[-1][3] is True and out is not None and out.shape[1] == 8
+    got = [node.handle(ev, ev, 5.2 + k / 30.0) for k in range(30)]
+    assert any(g is not None and g.shape[1] == 8 for g in got)
+    # time gap > 1 s: reset, next frame is treated as first (node:163-173)
+    n = len(tr.calls)
+    assert node.handle(ev, ev, 9.0) is None and tr.resets == 1 and len(tr.calls) == n
+    assert node.handle(ev, ev, 9.03) is None and len(tr.calls) == n
+    node.handle(ev, ev, 9.06)
+    assert len(tr.calls) == n + 1
+    # time going backwards also resets
+    node.handle(ev, ev, 8.0)
+    assert tr.resets == 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from esvio_amd.dist import TrackExchange, merged_point_cloud, shard_units
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert shard_units(5, world, rank) == ([0, 2, 4] if rank == 0 else [1, 3])
+        ex = TrackExchange(4, world, device="cpu", dist=dist)
+        for frame in range(3):
+            ft = _fake_tracker()
+            ft.ids = ft.ids + 100 * rank + 1000 * frame
+            ft.ids_right = ft.ids_right + 100 * rank + 1000 * frame
+            ex.submit(pack_track_records(ft, 4), async_op=True)
+            g = ex.result()
+            assert g.shape == (world, 8, 8)
+            merged = merged_point_cloud(g)
+            ids = ((merged[:, 3] + 0.5).astype(int) // 2).tolist()
+            exp = []
+            for rk in range(world):
+                exp += [x + 100 * rk + 1000 * frame for x in (7, 9, 12, 9, 12)]
+            assert ids == exp, (ids, exp)
+            assert merged[:, 8].tolist() == [0.0] * 5 + [1.0] * 5
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_track_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -1,0 +1,419 @@
+"""Known-answer tests that pin the CPU oracle to the reference's semantics by hand-derived cases
+(the reference ships no tests or fixtures for this path — the oracle is otherwise UNPINNED, see
+oracle/esvio_oracle.h).  Each case cites the reference lines it was derived from."""
+import numpy as np
+import pytest
+
+from esvio_amd.events import event_times, make_events
+
+
+def _ev(x, y, t_us, p):
+    return make_events(np.atleast_1d(x), np.atleast_1d(y), np.atleast_1d(t_us), np.atleast_1d(p))
+
+
+# ------------------------------------------------------------------ SAE rule (event_detector.cc:149-166)
+def test_sae_rule_hand_cases(oracle):
+    d = oracle.Detector(32, 24, filter_threshold=0.01)
+    W = 32
+
+    def planes():
+        return [p.reshape(-1) for p in d.get_sae(0)]
+
+    # 1) first event at a pixel: t=1.0 > 0 + 0.01 -> passes: L1=S1=1.0
+    d.create_sae(0, _ev(3, 2, 1_000_000, 1))
+    L0, L1, S0, S1 = planes()
+    i = 3 + 2 * W
+    assert (L1[i], S1[i], L0[i], S0[i]) == (1.0, 1.0, 0.0, 0.0)
+    # 2) same polarity 5 ms later: 1.005 > 1.0+0.01 false, L0(0) > L1(1.0) false -> filtered:
+    #    L1 updated, S1 unchanged
+    d.create_sae(0, _ev(3, 2, 1_005_000, 1))
+    L0, L1, S0, S1 = planes()
+    assert (L1[i], S1[i]) == (1.005, 1.0)
+    # 3) refractory is measured from the last event incl. filtered ones: 1.012 > 1.005+0.01 false
+    d.create_sae(0, _ev(3, 2, 1_012_000, 1))
+    L0, L1, S0, S1 = planes()
+    assert (L1[i], S1[i]) == (1.012, 1.0)
+    # 4) opposite polarity: 1.013 > 0+0.01 -> passes
+    d.create_sae(0, _ev(3, 2, 1_013_000, 0))
+    L0, L1, S0, S1 = planes()
+    assert (L0[i], S0[i]) == (1.013, 1.013)
+    # 5) polarity flips back within the refractory window: L0(1.013) > L1(1.012) -> passes
+    d.create_sae(0, _ev(3, 2, 1_014_000, 1))
+    L0, L1, S0, S1 = planes()
+    assert (L1[i], S1[i]) == (1.014, 1.014)
+    # 6) right camera has its own planes (event_detector.cc:212-228)
+    d.create_sae(1, _ev(3, 2, 2_000_000, 1))
+    assert d.get_sae(1)[3].reshape(-1)[i] == 2.0 and planes()[3][i] == 1.014
+    # 7) strict comparisons: exactly thr later does NOT pass (t > L + thr is false at equality)
+    d2 = oracle.Detector(8, 8, filter_threshold=0.5)
+    d2.create_sae(0, _ev([1, 1], [1, 1], [1_000_000, 1_500_000], [1, 1]))
+    assert d2.get_sae(0)[3][1, 1] == 1.0 and d2.get_sae(0)[1][1, 1] == 1.5
+    # 8) index is x + y*W (MatrixXd(W,H) indexed (x,y), event_detector.cc:52-63)
+    d3 = oracle.Detector(8, 4)
+    d3.create_sae(0, _ev(7, 1, 5_000_000, 0))
+    assert d3.get_sae(0)[2][1, 7] == 5.0
+    # out-of-sensor events are skipped and counted
+    assert d3.create_sae(0, _ev([8, 0], [0, 4], [6_000_000, 6_000_001], [1, 1])) == 2
+
+
+def test_event_time_is_ros_toSec():
+    ev = _ev(0, 0, 1_700_000_000_123_456, 1)
+    assert ev["sec"][0] == 1_700_000_000 and ev["nsec"][0] == 123_456_000
+    assert event_times(ev)[0] == 1_700_000_000.0 + 1e-9 * 123_456_000.0
+
+
+# ------------------------------------------------------------------ time surface (event_detector.cc:230-267)
+def test_time_surface_known_values(oracle):
+    W, H = 16, 8
+    d = oracle.Detector(W, H, decay_ms=20.0)
+    Z = np.zeros((H, W))
+    S0, S1 = Z.copy(), Z.copy()
+    S1[0, 0] = 10.0          # positive, dt = 0      -> exp(0)=1   -> 255
+    S0[0, 1] = 10.0          # negative, dt = 0      -> -1         -> 0
+    S1[0, 2] = 10.0 - 0.02   # positive, dt = decay  -> e^-1       -> round(127.5*e^-1+127.5)
+    S0[0, 3] = 10.0 - 0.02   # negative, dt = decay
+    S1[0, 4] = 9.0           # old: exp(-50) ~ 0     -> 127.5 -> 128 (ties-to-even)
+    S0[0, 5] = 9.0
+    S0[0, 6] = S1[0, 6] = 10.0   # tie S1 > S0 false -> negative polarity
+    S1[0, 7] = 10.001        # newer than t_sync: exp(+0.05) > 1 -> saturates at 255
+    S0[0, 8] = 10.2          # negative, 10 decay constants newer: huge negative -> 0
+    S1[0, 9] = 11.0          # exp(50)*127.5 overflows int32 in cvRound -> INT_MIN -> saturate -> 0
+    d.set_sae(0, Z, Z, S0, S1)
+    ts = d.time_surface(0, 10.0)
+    e1 = np.exp(-1.0)
+    assert ts[0, 0] == 255 and ts[0, 1] == 0
+    assert ts[0, 2] == int(np.rint(127.5 * e1 + 127.5)) == 174
+    assert ts[0, 3] == int(np.rint(-127.5 * e1 + 127.5)) == 81
+    assert ts[0, 4] == 128 and ts[0, 5] == 128
+    assert ts[0, 6] == 0
+    assert ts[0, 7] == 255 and ts[0, 8] == 0 and ts[0, 9] == 0
+    assert (ts[1:] == 128).all()      # empty pixels: 0 -> 127.5 -> 128 == TS_LK_THRESHOLD
+    d2 = oracle.Detector(W, H, decay_ms=20.0, ignore_polarity=1)
+    d2.set_sae(0, Z, Z, S0, S1)
+    ts2 = d2.time_surface(0, 10.0)
+    assert ts2[0, 0] == 255 and ts2[0, 1] == 255 and ts2[0, 2] == int(np.rint(255 * e1)) == 94
+    assert ts2[1, 0] == 0
+
+
+# ------------------------------------------------------------------ Arc* (event_detector.cc:308-544)
+def _arc_python(S, x, y):
+    """independent transcription of the reference loop, used only to cross-check the oracle"""
+    small = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3),
+             (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    large = [(0, 4), (1, 4), (2, 3), (3, 2), (4, 1), (4, 0), (4, -1), (3, -2), (2, -3), (1, -4),
+             (0, -4), (-1, -4), (-2, -3), (-3, -2), (-4, -1), (-4, 0), (-4, 1), (-3, 2), (-2, 3),
+             (-1, 4)]
+
+    def ring(c, kmin, kmax):
+        N = len(c)
+        v = [S[y + dy, x + dx] for dx, dy in c]
+        seg = v[0]
+        ri = 0
+        for i in range(1, N):
+            if v[i] > seg:
+                seg, ri = v[i], i
+        li = (ri - 1 + N) % N
+        ri = (ri + 1) % N
+        lv, rv = v[li], v[ri]
+        lmin, rmin = lv, rv
+        size = kmin
+        for it in range(1, N):
+            if rv > lv:
+                if it < kmin:
+                    seg = min(seg, rmin)
+                elif rv >= seg:
+                    size = it + 1
+                    seg = min(seg, rmin)
+                ri = (ri + 1) % N
+                rv = v[ri]
+                rmin = min(rmin, rv)
+            else:
+                if it < kmin:
+                    seg = min(seg, lmin)
+                elif lv >= seg:
+                    size = it + 1
+                    seg = min(seg, lmin)
+                li = (li - 1 + N) % N
+                lv = v[li]
+                lmin = min(lmin, lv)
+        return size <= kmax or (N - kmax <= size <= N - kmin)
+    return ring(small, 4, 6) and ring(large, 5, 8)
+
+
+def test_arc_star_hand_patterns(oracle):
+    W, H = 64, 48
+    Z = np.zeros((H, W))
+
+    def run(S1, x, y, L1=None, L0=None, et=5.0, md=10):
+        d = oracle.Detector(W, H, min_dist=md)
+        # L planes: the event under test is the latest of its polarity at its pixel (post-batch)
+        d.set_sae(0, Z if L0 is None else L0, np.full((H, W), 5.0) if L1 is None else L1, Z, S1)
+        return d.is_corner(et, x, y, 1)
+
+    cx, cy = 30, 24
+    yy, xx = np.mgrid[0:H, 0:W]
+    NEW, OLD = 5.0, 1.0
+    # Two-level surfaces: the newest segment is exactly the set of ring pixels in the NEW region
+    # (the arc always grows toward the larger frontier value, so it consumes NEW pixels first; an
+    # OLD pixel never satisfies `value >= segment_new_min_t`).
+    # a) 90 deg wedge: 5 of 16 small-ring and 6 of 20 large-ring pixels are NEW -> 5<=6 and 6<=8
+    S = np.where((xx >= cx) & (yy >= cy), NEW, OLD)
+    assert run(S, cx, cy)
+    # b) straight edge (half plane): 9 of 16 NEW -> neither <=6 nor in [10,12] -> rejected
+    S = np.where(xx >= cx, NEW, OLD)
+    assert not run(S, cx, cy)
+    # c) flat surface: all 16 equal -> size 16 -> rejected
+    assert not run(np.full((H, W), 2.0), cx, cy)
+    # d) 270 deg wedge (the "majority" branch :433): 11 of 16 and 14 of 20 NEW -> [10,12], [12,15]
+    S = np.where((xx >= cx) & (yy >= cy), OLD, NEW)
+    assert run(S, cx, cy)
+    # e) a thin ray (3 NEW pixels on the small ring < kSmallMinThresh): the unconditional first
+    #    expansions swallow OLD pixels, the segment minimum drops to OLD and everything joins
+    S = np.where((np.abs(xx - cx) <= 1) & (yy > cy), NEW, OLD)
+    assert not run(S, cx, cy)
+    # f) border rejection (:320-324): kBorderLimit = MIN_DIST + 1 = 11
+    S = np.where((xx >= 10) & (yy >= 24), NEW, OLD)
+    assert not run(S, 10, 24)
+    S = np.where((xx >= 11) & (yy >= 24), NEW, OLD)
+    assert run(S, 11, 24)
+    # g) refractory / polarity pre-check (:315) against the post-batch L planes
+    S = np.where((xx >= cx) & (yy >= cy), NEW, OLD)
+    L1 = np.full((H, W), 5.0)
+    L0 = np.zeros((H, W))
+    assert run(S, cx, cy, L1=L1, L0=L0)
+    L0b = L0.copy()
+    L0b[cy, cx] = 5.5                      # a newer opposite-polarity event at the pixel
+    assert not run(S, cx, cy, L1=L1, L0=L0b)
+    assert not run(S, cx, cy, L1=L1, L0=L0, et=5.0 + 0.011)  # et > L1 + thr
+    # the hand patterns agree with the independent transcription too
+    for S in (np.where((xx >= cx) & (yy >= cy), NEW, OLD), np.where(xx >= cx, NEW, OLD),
+              np.where((xx >= cx) & (yy >= cy), OLD, NEW)):
+        assert run(S, cx, cy) == _arc_python(S, cx, cy)
+
+
+def test_arc_star_matches_independent_transcription(oracle):
+    rng = np.random.default_rng(42)
+    W, H = 48, 40
+    d = oracle.Detector(W, H, min_dist=4)
+    n_true = 0
+    for trial in range(40):
+        # piecewise-smooth random surfaces produce a healthy mix of corners / non-corners
+        a, b = rng.uniform(-1, 1, 2)
+        yy, xx = np.mgrid[0:H, 0:W]
+        S1 = np.where((xx - 24) * a + (yy - 20) * b > rng.uniform(-3, 3),
+                      5.0 + 0.01 * rng.random((H, W)), 1.0 + 0.01 * rng.random((H, W)))
+        S1 = np.where((xx - 24) * b - (yy - 20) * a > rng.uniform(-3, 3), S1, 0.5 * rng.random((H, W)))
+        d.set_sae(0, np.zeros((H, W)), np.full((H, W), 9.0), np.zeros((H, W)), S1)
+        for x in range(8, 40, 3):
+            for y in range(8, 32, 3):
+                got = d.is_corner(1.0, x, y, 1)
+                assert got == _arc_python(S1, x, y), (trial, x, y)
+                n_true += got
+    assert n_true > 20
+
+
+# ------------------------------------------------------------------ cv::circle / mask / greedy
+def test_disc_is_opencv_midpoint_circle(oracle):
+    # hand-runs of drawing.cpp Circle(): (dx,dy) visited for r=1: (1,0); r=2: (2,0)(1,1);
+    # r=3: (3,0)(2,1)(2,2).  r=1 is a plus, r=2 a diamond, and every radius has the single-pixel
+    # nub at the four extremes that cv::circle is known for.
+    assert list(oracle.disc_halfwidths(1)) == [1, 0]
+    assert list(oracle.disc_halfwidths(2)) == [2, 1, 0]
+    assert list(oracle.disc_halfwidths(3)) == [3, 2, 2, 0]
+    hw10 = list(oracle.disc_halfwidths(10))
+    img = np.zeros((31, 31), np.uint8)
+    oracle.circle_fill(img, 15, 15, 10)
+    assert img[15, 5] == 255 and img[15, 4] == 0 and img[5, 15] == 255 and img[4, 15] == 0
+    assert (img == img.T).all() and (img == img[::-1]).all() and (img == img[:, ::-1]).all()
+    rows = [(img[15 + dy] == 255).sum() for dy in range(0, 11)]
+    assert rows == [2 * h + 1 for h in hw10]
+    # clipping at the border
+    img2 = np.zeros((12, 12), np.uint8)
+    oracle.circle_fill(img2, 0, 0, 3)
+    assert img2[0, 3] == 255 and img2[0, 4] == 0 and img2[3, 0] == 255 and img2[3, 1] == 0
+    assert img2[2, 2] == 255 and img2[2, 3] == 0
+
+
+def test_midpoint_disc_r10_table(oracle):
+    """independent re-implementation of the midpoint recurrence, r = 10, 20, 30 (shipped min_dist)"""
+    def ref(r):
+        hw = [-1] * (r + 1)
+        err, dx, dy, plus, minus = 0, r, 0, 1, 2 * r - 1
+        while dx >= dy:
+            hw[dy] = max(hw[dy], dx)
+            hw[dx] = max(hw[dx], dy)
+            dy += 1
+            err += plus
+            plus += 2
+            if err > 0:
+                err -= minus
+                dx -= 1
+                minus -= 2
+        return hw
+    for r in (3, 10, 20, 30):
+        assert list(oracle.disc_halfwidths(r)) == ref(r)
+    # r=10: (dx,dy) visited = (10,0)(9,1)(9,2)(9,3)(9,4)(8,5)(8,6)(7,7); rows 8..10 get their width
+    # from the transposed spans: row 8 <- dy=6, row 9 <- dy=4, row 10 <- dy=0 (the nub)
+    assert ref(10) == [10, 9, 9, 9, 9, 8, 8, 7, 6, 4, 0]
+    # and it is NOT the Euclidean disc x^2+y^2<=r^2 (which would give 9,9,.. 4 at |dy|=9 but 0 at 10
+    # only by coincidence): compare row 1
+    assert ref(10)[1] == 9 and int((10 ** 2 - 1) ** 0.5) == 9 and ref(20)[1] == 19
+
+
+def test_greedy_selection_semantics(oracle):
+    """Event_FeaturesToTrack (feature_tracker.cpp:13-38): stream order, mask, TS==128 skip, disc
+    exclusion, early exit at maxCorners."""
+    W, H = 64, 48
+    d = oracle.Detector(W, H, min_dist=5)
+    yy, xx = np.mgrid[0:H, 0:W]
+    # two identical wedge corners at (20,20) and (23,20) (inside each other's r=5 disc), one at (40,30)
+    S1 = np.full((H, W), 1.0)
+    for (cx, cy) in ((20, 20), (40, 30)):
+        S1 = np.where((xx >= cx) & (yy >= cy) & (xx < cx + 12) & (yy < cy + 12),
+                      5.0 - 0.001 * (xx - cx + yy - cy), S1)
+    L1 = np.full((H, W), 5.0)
+    d.set_sae(0, np.zeros((H, W)), L1, np.zeros((H, W)), S1)
+    assert d.is_corner(5.0, 20, 20, 1) and d.is_corner(5.0, 40, 30, 1)
+    ts = np.full((H, W), 200, np.uint8)
+    mask = np.zeros((H, W), np.uint8)
+    ev = _ev([20, 20, 40, 40], [20, 20, 30, 30], [5_000_000] * 4, [1, 1, 1, 1])
+    xy, idx = d.features_to_track(ev, 10, 5, mask, ts)
+    assert idx.tolist() == [0, 2]             # duplicates fall inside the stamped discs
+    xy, idx = d.features_to_track(ev, 1, 5, mask, ts)
+    assert idx.tolist() == [0]                # early exit
+    ts2 = ts.copy()
+    ts2[20, 20] = 128
+    xy, idx = d.features_to_track(ev, 10, 5, mask, ts2)
+    assert idx.tolist() == [2]                # TS == TS_LK_THRESHOLD skipped
+    m2 = mask.copy()
+    m2[30, 40] = 255
+    xy, idx = d.features_to_track(ev, 10, 5, m2, ts)
+    assert idx.tolist() == [0]                # pre-blocked pixel
+    assert d.features_to_track(ev, 0, 5, mask, ts)[1].size == 0
+
+
+# ------------------------------------------------------------------ pyramid / Scharr / LK [OpenCV]
+def test_pyr_down_known_answers(oracle):
+    assert oracle.pyr_levels(640, 480) == 3 and oracle.pyr_levels(346, 260) == 3
+    # a level is built, then the NEXT size is tested: stop when it would be <= winSize (21)
+    assert oracle.pyr_levels(86, 86) == 2      # 86, 43, 22 built; 11 would be <= 21
+    assert oracle.pyr_levels(44, 44) == 1 and oracle.pyr_levels(42, 42) == 0
+    c = np.full((33, 47), 77, np.uint8)
+    assert (oracle.pyr_down(c) == 77).all() and oracle.pyr_down(c).shape == (17, 24)
+    imp = np.zeros((20, 20), np.uint8)
+    imp[10, 10] = 255
+    o = oracle.pyr_down(imp)
+    # kernel [1 4 6 4 1]^2/256 sampled at even positions: centre 36/256, neighbours 6/256, 1/256
+    assert o[5, 5] == (255 * 36 + 128) >> 8 and o[5, 4] == (255 * 6 + 128) >> 8
+    assert o[4, 4] == (255 * 1 + 128) >> 8 and o[5, 7] == 0
+    # REFLECT_101 at the border: a horizontal ramp stays a ramp in the interior
+    ramp = np.tile((np.arange(40) * 4).astype(np.uint8), (30, 1))
+    assert (oracle.pyr_down(ramp)[:, 1:-1] == (np.arange(20) * 8)[1:-1]).all()
+
+
+def test_scharr_known_answers(oracle):
+    ramp = np.tile(np.arange(40, dtype=np.uint8) * 2, (30, 1))
+    d = oracle.scharr(ramp)
+    assert (d[:, 1:-1, 0] == 16 * 2 * 2).all() and (d[..., 1] == 0).all()  # (3+10+3)*(I[x+1]-I[x-1])
+    assert (d[:, 0, 0] == 0).all() and (d[:, -1, 0] == 0).all()            # reflect101: I[1]-I[1]
+    d2 = oracle.scharr(ramp.T.copy())
+    assert (d2[1:-1, :, 1] == 64).all() and (d2[..., 0] == 0).all()
+
+
+def _smooth(W, H, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.random((H // 8 + 4, W // 8 + 4))
+    img = np.kron(base, np.ones((8, 8)))
+    k = np.ones(7) / 7
+    for ax in (0, 1):
+        img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, img)
+    return img
+
+
+def test_lk_recovers_integer_shift(oracle):
+    W, H = 320, 240
+    tex = _smooth(W, H, 1)
+    prev = (tex[8:8 + H, 8:8 + W] * 255).astype(np.uint8)
+    nxt = (tex[5:5 + H, 12:12 + W] * 255).astype(np.uint8)  # content moves by (-4, +3)
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(40, W - 40, 60), rng.uniform(40, H - 40, 60)], 1).astype(np.float32)
+    for accum in (0, 1):
+        out, st = oracle.lk(prev, nxt, pts, accum=accum)
+        ok = st == 1
+        assert ok.mean() > 0.9
+        err = np.abs(out[ok] - pts[ok] - np.array([-4, 3], np.float32))
+        assert np.median(err) < 1e-2 and err.max() < 0.2
+    # identical images: zero motion, converges in one iteration, all tracked
+    out, st = oracle.lk(prev, prev, pts)
+    assert st.all() and np.abs(out - pts).max() < 1e-3
+    # far outside the image: status 0 (window test at level 0)
+    out, st = oracle.lk(prev, nxt, np.array([[-40.0, 10.0], [W + 40.0, 10.0]], np.float32))
+    assert not st.any()
+    # a flat image has minEig < 1e-4: status 0
+    flat = np.full((H, W), 90, np.uint8)
+    assert not oracle.lk(flat, flat, pts[:5])[1].any()
+    # USE_INITIAL_FLOW with maxLevel 1 (the temporal back-check call, feature_tracker.cpp:417)
+    out, st = oracle.lk(prev, nxt, pts, pts + np.float32([-3.5, 2.5]), max_level=1, flags=4)
+    ok = st == 1
+    assert np.median(np.abs(out[ok] - pts[ok] - np.array([-4, 3], np.float32))) < 1e-2
+
+
+def test_lk_float_vs_exact_accumulators(oracle):
+    """the two OpenCV accumulator builds (float / int64) agree to ~1e-4 px; this is the band the
+    reference itself is only defined up to."""
+    W, H = 320, 240
+    tex = _smooth(W, H, 3)
+    prev = (tex[8:8 + H, 8:8 + W] * 255).astype(np.uint8)
+    nxt = (tex[7:7 + H, 10:10 + W] * 255).astype(np.uint8)
+    rng = np.random.default_rng(1)
+    pts = np.stack([rng.uniform(30, W - 30, 120), rng.uniform(30, H - 30, 120)], 1).astype(np.float32)
+    a, sa = oracle.lk(prev, nxt, pts, accum=1)
+    f, sf = oracle.lk(prev, nxt, pts, accum=0)
+    both = (sa == 1) & (sf == 1)
+    d = np.abs(a[both] - f[both]).max(1)
+    assert (sa != sf).sum() <= 2 and np.median(d) < 1e-4 and d.max() < 2e-3
+
+
+# ------------------------------------------------------------------ camera / RANSAC
+def test_lift_projective_inverts_distortion(oracle):
+    cam = dict(fx=560.0, fy=555.0, cx=320.5, cy=239.0, k1=-0.31, k2=0.11, p1=4e-4, p2=-7e-4)
+    rng = np.random.default_rng(0)
+    for u, v in rng.uniform(60, 420, (20, 2)):
+        P = oracle.lift_projective(cam, u, v)
+        x, y = P[0], P[1]
+        r2 = x * x + y * y
+        rad = cam["k1"] * r2 + cam["k2"] * r2 * r2
+        xd = x + x * rad + 2 * cam["p1"] * x * y + cam["p2"] * (r2 + 2 * x * x)
+        yd = y + y * rad + 2 * cam["p2"] * x * y + cam["p1"] * (r2 + 2 * y * y)
+        assert abs(cam["fx"] * xd + cam["cx"] - u) < 1e-3 and abs(cam["fy"] * yd + cam["cy"] - v) < 1e-3
+        assert P[2] == 1.0
+
+
+def test_ransac_rng_and_inliers(oracle):
+    # cv::RNG(-1) first draws: state = lo*4164903690 + hi
+    s = (1 << 64) - 1
+    seq = []
+    for _ in range(3):
+        s = ((s & 0xffffffff) * 4164903690 + (s >> 32)) & ((1 << 64) - 1)
+        seq.append(s & 0xffffffff)
+    assert seq[0] == (0xffffffff * 4164903690 + 0xffffffff) & 0xffffffff
+    rng = np.random.default_rng(0)
+    n = 200
+    X = rng.uniform(-1, 1, (n, 3)) + np.array([0, 0, 4.0])
+    K = np.array([[500, 0, 320], [0, 500, 240], [0, 0, 1.0]])
+
+    def proj(X, t):
+        x = (K @ (X + t).T).T
+        return (x[:, :2] / x[:, 2:]).astype(np.float32)
+    p1 = proj(X, np.zeros(3))
+    p2 = proj(X, np.array([0.15, 0.03, 0.05]))
+    p2[:25] += rng.normal(0, 10, (25, 2)).astype(np.float32)
+    cnt, status, F = oracle.find_fundamental(p1, p2, 1.0, 0.99)
+    assert status[25:].mean() > 0.97 and status[:25].mean() < 0.3 and cnt == status.sum()
+    x1 = np.c_[p1[25:], np.ones(n - 25)]
+    x2 = np.c_[p2[25:], np.ones(n - 25)]
+    assert np.abs(np.einsum("ij,jk,ik->i", x2, F, x1)).max() < 5.0  # x2^T F x1 ~ 0
+    # LMedS branch (8..14 points) and the degenerate sizes
+    cnt, status, _ = oracle.find_fundamental(p1[30:42], p2[30:42], 1.0, 0.99)
+    assert cnt >= 10
+    assert oracle.find_fundamental(p1[:6], p2[:6])[0] == 0
