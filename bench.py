@@ -32,6 +32,31 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this same
+    command (profiles/*_bench_c3.json, made by tools/rocprof_summary.py from separate
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).  Units are KB; per MI355X_MICROARCH.md §HBM the
+    gfx950 FETCH_SIZE counter reports half of a coalesced read stream, hence 2*FETCH + WRITE."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_c3.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        f = w = None
+        for name, v in d["pmc"].get("FETCH_SIZE", {}).items():
+            if ("::" + kernel + "(") in name or name.startswith(kernel):
+                f = v["avg"]
+        for name, v in d["pmc"].get("WRITE_SIZE", {}).items():
+            if ("::" + kernel + "(") in name or name.startswith(kernel):
+                w = v["avg"]
+        if f is None or w is None:
+            return None, None
+        return int((2.0 * f + w) * 1024), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,10 +179,14 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
         if dom:
             d = kernels[dom]
+            traffic, src = pmc_traffic(dom)
             roof = dict(bound="hbm", kernel=dom, achieved=d["achieved_GBs"], peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(d["achieved_GBs"] / HBM_PEAK_GBS, 6), traffic=None,
-                        avg_launch_us=d["avg_us"], alg_bytes_per_launch=d["alg_bytes_per_launch"],
-                        profiled_ms_per_step=round(prof_ms_per_step, 4))
+                        unit="GB/s", frac=round(d["achieved_GBs"] / HBM_PEAK_GBS, 6), traffic=traffic,
+                        traffic_source=src, avg_launch_us=d["avg_us"],
+                        alg_bytes_per_launch=d["alg_bytes_per_launch"],
+                        profiled_ms_per_step=round(prof_ms_per_step, 4),
+                        note="k_lk is dependent-instruction-latency bound (one wave per point, <=30 "
+                             "serial iterations per level), not HBM bound; see DESIGN.md section 4")
     elif n_prof:
         for i in range(n_frames, n_frames + n_prof):
             pass
