@@ -96,6 +96,10 @@ struct esvio_fe_ctx {
   size_t res_bytes = 0, res_temporal_bytes = 0;
   float2 *d_ptsA = nullptr, *d_ptsB = nullptr, *d_ptsC = nullptr, *d_ptsD = nullptr;
   uint8_t *d_stA = nullptr, *d_stB = nullptr;
+  // second LK result set + newly selected corners (stereo LK of the new corners runs as its own
+  // launch after the speculative stereo LK of the temporal survivors)
+  float2 *d_new = nullptr, *d_ptsB2 = nullptr, *d_ptsC2 = nullptr;
+  uint8_t *d_stA2 = nullptr, *d_stB2 = nullptr;
   int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total [2]=#candidates
   // arc / select
   uint8_t* d_flags = nullptr;
@@ -114,6 +118,7 @@ struct esvio_fe_ctx {
   std::vector<P2f> prev_pts, cur_pts, cur_right_pts, n_pts;
   std::vector<P2f> cur_un_pts, cur_un_right_pts, pts_velocity, right_pts_velocity;
   std::vector<int> ids, ids_right, track_cnt, track_cnt_right;
+  std::vector<int> src_idx;  // per cur_pts entry: index into the speculative stereo-LK results
   std::map<int, P2f> cur_un_pts_map, prev_un_pts_map, cur_un_right_pts_map, prev_un_right_pts_map;
   host::BitMask mask_event;
 
@@ -466,9 +471,13 @@ void event_set_mask(esvio_fe_ctx* c) {
   std::sort(cnt_pts_id.begin(), cnt_pts_id.end(),
             [](const std::pair<int, std::pair<P2f, int>>& a,
                const std::pair<int, std::pair<P2f, int>>& b) { return a.first > b.first; });
+  // ids are unique, so the permutation can be recovered afterwards for src_idx
+  std::map<int, int> src_of_id;
+  for (unsigned int i = 0; i < c->ids.size(); i++) src_of_id[c->ids[i]] = c->src_idx[i];
   c->cur_pts.clear();
   c->ids.clear();
   c->track_cnt.clear();
+  c->src_idx.clear();
   for (auto& it : cnt_pts_id) {
     const int px = host::cv_round(it.second.first.x), py = host::cv_round(it.second.first.y);
     if (px < 0 || px >= c->W || py < 0 || py >= c->H) continue;  // cannot happen after inBorder
@@ -476,6 +485,7 @@ void event_set_mask(esvio_fe_ctx* c) {
       c->cur_pts.push_back(it.second.first);
       c->ids.push_back(it.second.second);
       c->track_cnt.push_back(it.first);
+      c->src_idx.push_back(src_of_id[it.second.second]);
       c->mask_event.stamp_disc(px, py, c->cfg.min_dist, c->hw);
     }
   }
@@ -542,53 +552,63 @@ void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
     reduce_vector(c->cur_pts, status);
     reduce_vector(c->ids, status);
     reduce_vector(c->track_cnt, status);
+    reduce_vector(c->src_idx, status);
   }
+}
+
+// device result block (and its pinned mirror): set 1 = temporal LK, then stereo LK of the temporal
+// survivors; set 2 = stereo LK of the newly selected corners
+struct ResLayout {
+  size_t B1, C1, SA1, SB1, CNT, A, NEW, B2, C2, SA2, SB2, total;
+};
+
+ResLayout res_layout(size_t M) {
+  const size_t stM = (M + 63) / 64 * 64;
+  ResLayout L;
+  size_t o = 0;
+  L.B1 = o;  o += M * 8;
+  L.C1 = o;  o += M * 8;
+  L.SA1 = o; o += stM;
+  L.SB1 = o; o += stM;
+  L.CNT = o; o += 64;
+  L.A = o;   o += M * 8;
+  L.NEW = o; o += M * 8;
+  L.B2 = o;  o += M * 8;
+  L.C2 = o;  o += M * 8;
+  L.SA2 = o; o += stM;
+  L.SB2 = o; o += stM;
+  L.total = o;
+  return L;
 }
 
 // pinned staging: a mirror of the device result block (D2H) + upload areas (H2D)
 struct Pin {
-  float2* ptsB;   // D2H LK forward result
-  float2* ptsC;   // D2H LK backward result
-  uint8_t* stA;
-  uint8_t* stB;
-  int* counts;    // [16]
-  float2* ptsD;   // D2H mirror of d_ptsA (kept + newly selected corners)
-  float2* ptsA;   // H2D prev_pts / kept cur_pts
-  uint32_t* mask; // H2D H*wpr words
+  float2 *ptsB, *ptsC;    // set 1
+  uint8_t *stA, *stB;
+  int* counts;            // [16]
+  float2* news;           // newly selected corners
+  float2 *ptsB2, *ptsC2;  // set 2
+  uint8_t *stA2, *stB2;
+  float2* ptsA;           // H2D prev_pts / survivors
+  uint32_t* mask;         // H2D H*wpr words
 };
-
-size_t res_layout(size_t M, size_t* oB, size_t* oC, size_t* oSA, size_t* oSB, size_t* oCnt,
-                  size_t* oA) {
-  const size_t stM = (M + 63) / 64 * 64;
-  size_t o = 0;
-  *oB = o;
-  o += M * 8;
-  *oC = o;
-  o += M * 8;
-  *oSA = o;
-  o += stM;
-  *oSB = o;
-  o += stM;
-  *oCnt = o;
-  o += 64;
-  *oA = o;
-  o += M * 8;
-  return o;
-}
 
 Pin pin_of(esvio_fe_ctx* c) {
   const size_t M = std::max(c->cfg.max_cnt, 1);
-  size_t oB, oC, oSA, oSB, oCnt, oA;
-  const size_t res = res_layout(M, &oB, &oC, &oSA, &oSB, &oCnt, &oA);
+  const ResLayout L = res_layout(M);
   Pin p;
   uint8_t* b = c->h_pin;
-  p.ptsB = (float2*)(b + oB);
-  p.ptsC = (float2*)(b + oC);
-  p.stA = b + oSA;
-  p.stB = b + oSB;
-  p.counts = (int*)(b + oCnt);
-  p.ptsD = (float2*)(b + oA);
-  b += (res + 255) / 256 * 256;
+  p.ptsB = (float2*)(b + L.B1);
+  p.ptsC = (float2*)(b + L.C1);
+  p.stA = b + L.SA1;
+  p.stB = b + L.SB1;
+  p.counts = (int*)(b + L.CNT);
+  p.news = (float2*)(b + L.NEW);
+  p.ptsB2 = (float2*)(b + L.B2);
+  p.ptsC2 = (float2*)(b + L.C2);
+  p.stA2 = b + L.SA2;
+  p.stB2 = b + L.SB2;
+  b += (L.total + 255) / 256 * 256;
   p.ptsA = (float2*)b;
   b += (M * 8 + 255) / 256 * 256;
   p.mask = (uint32_t*)b;
@@ -597,9 +617,8 @@ Pin pin_of(esvio_fe_ctx* c) {
 
 size_t pin_bytes(const esvio_fe_config& cfg) {
   const size_t M = std::max(cfg.max_cnt, 1);
-  size_t o[6];
-  const size_t res = res_layout(M, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
-  return (res + 255) / 256 * 256 + (M * 8 + 255) / 256 * 256 +
+  const ResLayout L = res_layout(M);
+  return (L.total + 255) / 256 * 256 + (M * 8 + 255) / 256 * 256 +
          (size_t)cfg.height * ((cfg.width + 31) / 32) * 4 + 256;
 }
 
@@ -763,15 +782,32 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
 
   for (auto& n : c->track_cnt) n++;  // :439-440
 
-  bool detect = false;
-  int n_kept = 0;
+  // ---- speculative stereo LK of every temporal survivor (a superset of the points that survive
+  // rejectWithF_event / Event_setMask): per-point results do not depend on the other points, so
+  // this is exactly cv::calcOpticalFlowPyrLK(curL, curR, cur_pts, ...) (:490) and its reverse (:495)
+  // for the kept points — launched now so that it overlaps the host-side RANSAC + mask.
+  const int n_surv = (int)c->cur_pts.size();
+  c->src_idx.resize(n_surv);
+  for (int i = 0; i < n_surv; i++) c->src_idx[i] = i;
   lap(3);
+  if (n_surv) {
+    std::memcpy(pin.ptsA, c->cur_pts.data(), (size_t)n_surv * 8);
+    HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n_surv * 8, hipMemcpyHostToDevice,
+                             c->stream));
+    LkArgs f = make_lk(curL, curR, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n_surv, 3, 30,
+                       0.01, 0);
+    LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
+    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
+  }
+
+  bool detect = false;
+  int n_kept = n_surv;
   if (PUB_THIS_FRAME) {  // :442-469
     if (cfg.f_ransac) reject_with_f_event(c);
     lap(4);
     event_set_mask(c);
-    const int n_max_cnt = M - (int)c->cur_pts.size();
     n_kept = (int)c->cur_pts.size();
+    const int n_max_cnt = M - n_kept;
     if (n_max_cnt > 0) {
       detect = true;
       if (int rc = ensure_arc_capacity(c, nL)) return rc;
@@ -779,38 +815,27 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
                                hipMemcpyHostToDevice, c->stream));
       run_arc(c, dL, (uint32_t)nL, true, true, false, true);
+      run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, 0, nullptr);
+      // stereo LK of the new corners only (count known on the device)
+      LkArgs f = make_lk(curL, curR, c->d_new, nullptr, c->d_ptsB2, c->d_stA2, c->d_counts, n_max_cnt,
+                         3, 30, 0.01, 0);
+      LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, c->d_counts, n_max_cnt, 3, 30,
+                         0.01, 0);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC2, c->d_stB2);
     }
-  } else {
-    n_kept = (int)c->cur_pts.size();
   }
-  // kept points -> device (stereo LK input), new corners get appended on device by k_select
-  if (n_kept) {
-    std::memcpy(pin.ptsA, c->cur_pts.data(), (size_t)n_kept * 8);
-    HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n_kept * 8, hipMemcpyHostToDevice,
-                             c->stream));
-  }
-  const int n_lk_max = detect ? M : n_kept;
-  if (detect) run_select(c, (uint32_t)nL, M - n_kept, c->d_ptsA, n_kept, nullptr);
-  // stereo: curL -> curR (:490) and back curR -> curL (:495), both maxLevel 3, one launch
-  if (n_lk_max > 0) {
-    const int* n_ptr = detect ? c->d_counts + 1 : nullptr;
-    LkArgs f = make_lk(curL, curR, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, n_ptr, n_lk_max, 3, 30,
-                       0.01, 0);
-    LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, n_ptr, n_lk_max, 3, 30, 0.01, 0);
-    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
+  if (n_surv || detect)
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->stream));
-  } else if (detect) {
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->stream));
-  }
   lap(5);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   lap(6);
 
+  int n_new = 0;
   if (PUB_THIS_FRAME) {
     c->n_pts.clear();
     if (detect) {
-      const int n_new = pin.counts[0];
-      const P2f* np = (const P2f*)pin.ptsD + n_kept;
+      n_new = pin.counts[0];
+      const P2f* np = (const P2f*)pin.news;
       for (int i = 0; i < n_new; i++) c->n_pts.push_back(np[i]);
     }
     for (auto& p : c->n_pts) {  // :463-468
@@ -831,13 +856,30 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     c->track_cnt_right.clear();
     if (!c->cur_pts.empty()) {
       const int n = (int)c->cur_pts.size();
-      std::vector<uint8_t> status(pin.stA, pin.stA + n);
+      // gather the stereo results: kept points from set 1 (by survivor index), new ones from set 2
+      std::vector<uint8_t> status(n), statusRightLeft(n);
+      std::vector<P2f> reverseLeftPts(n);
       c->cur_right_pts.resize(n);
-      std::memcpy(c->cur_right_pts.data(), pin.ptsB, (size_t)n * 8);
+      const P2f *B1 = (const P2f*)pin.ptsB, *C1 = (const P2f*)pin.ptsC;
+      const P2f *B2 = (const P2f*)pin.ptsB2, *C2 = (const P2f*)pin.ptsC2;
+      for (int i = 0; i < n; i++) {
+        if (i < n_kept) {
+          const int j = c->src_idx[i];
+          c->cur_right_pts[i] = B1[j];
+          status[i] = pin.stA[j];
+          reverseLeftPts[i] = C1[j];
+          statusRightLeft[i] = pin.stB[j];
+        } else {
+          const int j = i - n_kept;
+          c->cur_right_pts[i] = B2[j];
+          status[i] = pin.stA2[j];
+          reverseLeftPts[i] = C2[j];
+          statusRightLeft[i] = pin.stB2[j];
+        }
+      }
       if (cfg.flow_back && !c->cur_right_pts.empty()) {
-        const P2f* reverseLeftPts = (const P2f*)pin.ptsC;
         for (int i = 0; i < n; i++) {
-          if (status[i] && pin.stB[i] && in_border_event(c, c->cur_right_pts[i]) &&
+          if (status[i] && statusRightLeft[i] && in_border_event(c, c->cur_right_pts[i]) &&
               pt_distance(c->cur_pts[i], reverseLeftPts[i]) <= 0.5)
             status[i] = 1;
           else
@@ -945,16 +987,21 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if ((rc = dev_alloc(c, &c->S2, (size_t)2 * c->P))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_rejected, 1))) return bail(rc);
   {
-    size_t oB, oC, oSA, oSB, oCnt, oA;
-    c->res_bytes = res_layout(M, &oB, &oC, &oSA, &oSB, &oCnt, &oA);
-    c->res_temporal_bytes = oCnt;  // ptsB..stB
+    const ResLayout L = res_layout(M);
+    c->res_bytes = L.total;
+    c->res_temporal_bytes = L.CNT;  // ptsB..stB of set 1
     if ((rc = dev_alloc(c, &c->d_res, c->res_bytes))) return bail(rc);
-    c->d_ptsB = (float2*)(c->d_res + oB);
-    c->d_ptsC = (float2*)(c->d_res + oC);
-    c->d_stA = c->d_res + oSA;
-    c->d_stB = c->d_res + oSB;
-    c->d_counts = (int*)(c->d_res + oCnt);
-    c->d_ptsA = (float2*)(c->d_res + oA);
+    c->d_ptsB = (float2*)(c->d_res + L.B1);
+    c->d_ptsC = (float2*)(c->d_res + L.C1);
+    c->d_stA = c->d_res + L.SA1;
+    c->d_stB = c->d_res + L.SB1;
+    c->d_counts = (int*)(c->d_res + L.CNT);
+    c->d_ptsA = (float2*)(c->d_res + L.A);
+    c->d_new = (float2*)(c->d_res + L.NEW);
+    c->d_ptsB2 = (float2*)(c->d_res + L.B2);
+    c->d_ptsC2 = (float2*)(c->d_res + L.C2);
+    c->d_stA2 = c->d_res + L.SA2;
+    c->d_stB2 = c->d_res + L.SB2;
   }
   if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_sel_idx, M))) return bail(rc);

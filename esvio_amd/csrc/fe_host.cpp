@@ -117,65 +117,47 @@ struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-
   int uniform(int lo, int hi) { return lo == hi ? lo : (int)(next() % (unsigned)(hi - lo) + lo); }
 };
 
-// Two vectors spanning the null space of the 7x9 epipolar system: Gauss-Jordan elimination with
-// complete pivoting, the two free columns give the basis, then Gram-Schmidt.  [OpenCV takes rows
-// 7,8 of V^T from SVDecomp; the null space is the same plane, so the cubic below has the same F
-// solutions.]
+// Two orthonormal vectors spanning the null space of the 7x9 epipolar system: Householder QR of
+// A^T (9x7); the last two columns of Q.  [OpenCV takes rows 7,8 of V^T from SVDecomp; for a
+// rank-7 system that is the same plane, so the cubic below has the same F solutions.]  The
+// operation order matches the oracle's restatement exactly, so both produce identical bits (two
+// different null-space bases differ by rounding and can flip a knife-edge inlier decision).
 void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
-  double M[7][9];
-  std::memcpy(M, A, sizeof(M));
-  int col_of[9];
-  for (int j = 0; j < 9; j++) col_of[j] = j;
-  int rank = 0;
-  for (int k = 0; k < 7; k++) {
-    int pr = k, pc = k;
-    double best = 0;
-    for (int i = k; i < 7; i++)
-      for (int j = k; j < 9; j++)
-        if (std::fabs(M[i][j]) > best) {
-          best = std::fabs(M[i][j]);
-          pr = i;
-          pc = j;
-        }
-    if (best == 0) break;
-    if (pr != k)
-      for (int j = 0; j < 9; j++) std::swap(M[pr][j], M[k][j]);
-    if (pc != k) {
-      for (int i = 0; i < 7; i++) std::swap(M[i][pc], M[i][k]);
-      std::swap(col_of[pc], col_of[k]);
+  constexpr int M = 9, N = 7;
+  double R[M][N], Q[M][M];
+  for (int i = 0; i < M; i++) {
+    for (int j = 0; j < N; j++) R[i][j] = A[j][i];
+    for (int j = 0; j < M; j++) Q[i][j] = (i == j);
+  }
+  for (int k = 0; k < N; k++) {
+    double norm = 0;
+    for (int i = k; i < M; i++) norm += R[i][k] * R[i][k];
+    norm = std::sqrt(norm);
+    if (norm == 0) continue;
+    const double alpha = R[k][k] > 0 ? -norm : norm;
+    double v[M] = {0};
+    for (int i = k; i < M; i++) v[i] = R[i][k];
+    v[k] -= alpha;
+    double vn = 0;
+    for (int i = k; i < M; i++) vn += v[i] * v[i];
+    if (vn == 0) continue;
+    for (int j = 0; j < N; j++) {  // R <- H R
+      double t = 0;
+      for (int i = k; i < M; i++) t += v[i] * R[i][j];
+      t = 2 * t / vn;
+      for (int i = k; i < M; i++) R[i][j] -= t * v[i];
     }
-    const double inv = 1.0 / M[k][k];
-    for (int j = k; j < 9; j++) M[k][j] *= inv;
-    for (int i = 0; i < 7; i++) {
-      if (i == k) continue;
-      const double f = M[i][k];
-      if (f == 0) continue;
-      for (int j = k; j < 9; j++) M[i][j] -= f * M[k][j];
+    for (int j = 0; j < M; j++) {  // Q <- Q H
+      double t = 0;
+      for (int i = k; i < M; i++) t += Q[j][i] * v[i];
+      t = 2 * t / vn;
+      for (int i = k; i < M; i++) Q[j][i] -= t * v[i];
     }
-    rank++;
   }
-  // free (permuted) columns: the last two; x_pivot = -M[pivot][free]
-  double* out[2] = {f1, f2};
-  for (int v = 0; v < 2; v++) {
-    const int fc = 7 + v;
-    double x[9] = {0};
-    x[fc] = 1.0;
-    for (int k = 0; k < rank; k++) x[k] = -M[k][fc];
-    for (int j = 0; j < 9; j++) out[v][col_of[j]] = x[j];
+  for (int i = 0; i < M; i++) {
+    f1[i] = Q[i][7];
+    f2[i] = Q[i][8];
   }
-  double n1 = 0;
-  for (int i = 0; i < 9; i++) n1 += f1[i] * f1[i];
-  n1 = std::sqrt(n1);
-  for (int i = 0; i < 9; i++) f1[i] /= n1;
-  double dot = 0;
-  for (int i = 0; i < 9; i++) dot += f1[i] * f2[i];
-  double n2 = 0;
-  for (int i = 0; i < 9; i++) {
-    f2[i] -= dot * f1[i];
-    n2 += f2[i] * f2[i];
-  }
-  n2 = std::sqrt(n2);
-  for (int i = 0; i < 9; i++) f2[i] /= n2;
 }
 
 // cv::solveCubic [OpenCV core/mathfuncs.cpp]

@@ -32,7 +32,13 @@ class SceneStream:
 
     def __init__(self, W=640, H=480, rate=5e6, batch_hz=30.0, n_rect=28, disparity=12,
                  noise_frac=0.07, events_per_crossing=3, t0_us=1_000_000_000, seed=12345,
-                 speed=(180.0, 420.0), size=(50.0, 150.0)):
+                 speed=(180.0, 420.0), size=(50.0, 150.0), ego=True, mover_frac=0.15,
+                 ego_flip_batches=12):
+        """ego=True: a static scene seen from a laterally translating camera — every rectangle
+        moves along one common direction with speed ~ 1/depth (one consistent epipolar geometry,
+        what a VIO front-end actually sees), except a fraction `mover_frac` of independent movers
+        (outliers for the F-RANSAC); the camera reverses every `ego_flip_batches` batches so the
+        scene stays in view.  ego=False: every rectangle moves independently (no common F)."""
         self.W, self.H = W, H
         self.rate = rate
         self.dur_us = int(round(1e6 / batch_hz))
@@ -47,6 +53,17 @@ class SceneStream:
         ang = r.uniform(0, 2 * np.pi, n_rect)
         spd = r.uniform(speed[0], speed[1], n_rect)
         self.v = np.stack([np.cos(ang) * spd, np.sin(ang) * spd], 1)  # px/s
+        self.ego = ego
+        self.ego_flip = ego_flip_batches
+        self.batch_idx = 0
+        self.is_mover = np.ones(n_rect, bool)
+        if ego:
+            cam_ang = r.uniform(0, 2 * np.pi)
+            cam_dir = np.array([np.cos(cam_ang), np.sin(cam_ang)])
+            self.is_mover = r.random(n_rect) < mover_frac
+            for k in range(n_rect):
+                if not self.is_mover[k]:
+                    self.v[k] = cam_dir * spd[k]  # speed ~ focal * v_cam / depth
         self.half = np.stack([r.uniform(size[0], size[1], n_rect) / 2, r.uniform(size[0], size[1], n_rect) / 2], 1)
         self.rot = r.uniform(0, np.pi / 2, n_rect)
         self.sign = r.choice([-1.0, 1.0], n_rect)
@@ -131,9 +148,14 @@ class SceneStream:
             t_us = np.clip(np.floor(t * 1e6).astype(np.int64), 0, self.dur_us - 1) + self.t_us
             order = np.argsort(t_us, kind="stable")
             out.append(make_events(x[order], y[order], t_us[order], p[order]))
-        # advance scene, bounce at the borders
+        # advance scene; independent movers bounce at the borders, the camera reverses periodically
         self.c += self.v * dur_s
+        self.batch_idx += 1
+        if self.ego and self.batch_idx % self.ego_flip == self.ego_flip // 2:
+            self.v[~self.is_mover] *= -1.0
         for k in range(self.n_rect):
+            if not self.is_mover[k]:
+                continue
             for a, lim in ((0, self.W), (1, self.H)):
                 if self.c[k, a] < 0.05 * lim and self.v[k, a] < 0:
                     self.v[k, a] = -self.v[k, a]

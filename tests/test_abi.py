@@ -73,3 +73,28 @@ def test_host_stages_run_without_gpu(oracle):
         assert np.array_equal(a, b)
     nodist = dict(cam, k1=0.0, k2=0.0, p1=0.0, p2=0.0)
     assert np.allclose(FE.lift_projective(nodist, 320.5, 239.0), [0, 0, 1])
+
+
+def test_host_ransac_matches_oracle(oracle):
+    """esvio_fe_find_fundamental_mat (host stage of rejectWithF_event) vs the oracle on two-view
+    problems: general motion with outliers, pure translation, LMedS sizes (8..14), tiny sets."""
+    rng = np.random.default_rng(5)
+    K = np.array([[500, 0, 320], [0, 500, 240], [0, 0, 1.0]])
+    for trial in range(60):
+        n = int(rng.integers(8, 300))
+        X = rng.uniform(-1, 1, (n, 3)) * np.array([2, 1.5, 1]) + np.array([0, 0, 4.0])
+        w = rng.normal(0, 0.01, 3)
+        R = np.eye(3) + np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+
+        def proj(X, R, t):
+            x = (K @ ((R @ X.T).T + t).T).T
+            return (x[:, :2] / x[:, 2:]).astype(np.float32)
+        p1 = proj(X, np.eye(3), np.zeros(3))
+        p2 = proj(X, R if trial % 3 else np.eye(3), rng.normal(0, 0.05, 3))
+        p2 += rng.normal(0, 0.05, p2.shape).astype(np.float32)
+        k = int(0.15 * n)
+        p2[:k] += rng.normal(0, 6, (k, 2)).astype(np.float32)
+        cnt_o, st_o, _ = oracle.find_fundamental(p1, p2, 1.0, 0.99)
+        cnt_p, st_p = FE.find_fundamental_mat(p1, p2, 1.0, 0.99)
+        assert cnt_o == cnt_p and np.array_equal(st_o, st_p), (trial, n)
+    assert FE.find_fundamental_mat(p1[:5], p2[:5])[0] == 0
