@@ -31,7 +31,7 @@ struct P2f {
 };
 
 const char* const kKernelNames[K_COUNT] = {
-    "k_sae_keys", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_sae_apply",
+    "k_sae_keys", "k_radix_pass", "k_sae_apply",
     "k_time_surface", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select"};
 
 struct KStat {
@@ -126,7 +126,7 @@ struct esvio_fe_ctx {
   // sync B, host B
   bool trace = false;
   double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t phase_frames = 0;
+  uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
 
   // ---- profiling
   bool prof_on = false;
@@ -236,12 +236,15 @@ int ensure_sort_capacity(esvio_fe_ctx* c, size_t n) {
     }
     c->sort_cap = cap;
   }
-  size_t hneed = (size_t)radix_blocks((uint32_t)c->sort_cap) << kRadixMaxBits;
+  // [ghist + tickets | lookback for every pass]
+  const size_t head = ((size_t)kRadixMaxPasses << kRadixMaxBits) + 64;
+  size_t hneed = head + (size_t)kRadixMaxPasses * (radix_blocks((uint32_t)c->sort_cap) << kRadixMaxBits);
   if (hneed > c->hist_cap) {
     if (c->hist) (void)hipFree(c->hist);
     c->hist = nullptr;
     c->hist_cap = 0;
     if (int rc = dev_alloc(c, &c->hist, hneed)) return rc;
+    HIPCHK(c, hipMemsetAsync(c->hist, 0, hneed * 4, c->stream));
     c->hist_cap = hneed;
   }
   return 0;
@@ -334,36 +337,31 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
   const uint32_t n = nL + nR;
   if (!n) return 0;
   if (int rc = ensure_sort_capacity(c, n)) return rc;
+  const int passes = (c->key_bits + 6) / 7;
+  const int bits = (c->key_bits + passes - 1) / passes;
+  const uint32_t nblk = radix_blocks(n);
+  const uint32_t head = ((uint32_t)kRadixMaxPasses << kRadixMaxBits) + 64;
+  uint32_t* ghist = c->hist;                                        // [passes << bits]
+  uint32_t* tickets = c->hist + ((size_t)kRadixMaxPasses << kRadixMaxBits);  // [passes]
+  uint32_t* lookback = c->hist + head;                              // [passes][nblk << bits]
+  const uint32_t lb_words = (uint32_t)passes * (nblk << bits);
   {
     ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);
     launch_sae_keys(c->stream, evL, nL, evR, nR, c->W, c->H, c->keys[0], c->vals[0], c->invalid_key,
-                    c->d_rejected);
+                    c->d_rejected, passes, bits, ghist, lookback, lb_words);
   }
-  const int passes = (c->key_bits + 6) / 7;
-  const int bits = (c->key_bits + passes - 1) / passes;
   int cur = 0;
-  const uint32_t nblk = radix_blocks(n);
   for (int p = 0; p < passes; p++) {
-    const int shift = p * bits;
-    {
-      ScopedKernel k(c, K_RADIX_HIST, (uint64_t)n * 4);
-      launch_radix_hist(c->stream, c->keys[cur], n, shift, bits, c->hist);
-    }
-    {
-      ScopedKernel k(c, K_RADIX_SCAN, ((uint64_t)nblk << bits) * 8);
-      launch_radix_scan(c->stream, c->hist, nblk, bits);
-    }
-    {
-      ScopedKernel k(c, K_RADIX_SCATTER, (uint64_t)n * 16);
-      launch_radix_scatter(c->stream, c->keys[cur], c->vals[cur], n, shift, bits, c->hist,
-                           c->keys[cur ^ 1], c->vals[cur ^ 1]);
-    }
+    ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 16);
+    launch_radix_pass(c->stream, c->keys[cur], c->vals[cur], n, p * bits, bits, ghist + ((size_t)p << bits),
+                      lookback + (size_t)p * (nblk << bits), tickets + p, c->keys[cur ^ 1],
+                      c->vals[cur ^ 1], c->d_counts + 3);
     cur ^= 1;
   }
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
     launch_sae_apply(c->stream, c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
-                     c->cfg.feature_filter_threshold, c->invalid_key);
+                     c->cfg.feature_filter_threshold, c->invalid_key, c->hist, head);
   }
   return 0;
 }
@@ -829,12 +827,17 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   lap(5);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   lap(6);
+  if ((n_surv || detect) && pin.counts[3] != 0)
+    return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
 
   int n_new = 0;
   if (PUB_THIS_FRAME) {
     c->n_pts.clear();
     if (detect) {
       n_new = pin.counts[0];
+      c->tr_cand += (uint64_t)pin.counts[2];
+      c->tr_new += (uint64_t)n_new;
+      c->tr_detect++;
       const P2f* np = (const P2f*)pin.news;
       for (int i = 0; i < n_new; i++) c->n_pts.push_back(np[i]);
     }
@@ -894,14 +897,17 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       c->right_pts_velocity = pts_velocity_fn(c, c->ids_right, c->cur_un_right_pts,
                                               c->cur_un_right_pts_map, c->prev_un_right_pts_map);
     }
-    c->prev_un_right_pts_map = c->cur_un_right_pts_map;
+    // reference: prev = cur (copy); cur is cleared before its next use in ptsVelocity, so a swap
+    // is equivalent and avoids re-allocating ~300 map nodes per frame
+    c->prev_un_right_pts_map.swap(c->cur_un_right_pts_map);
   }
   c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left (:585)
   c->prev_pts = c->cur_pts;
-  c->prev_un_pts_map = c->cur_un_pts_map;
+  c->prev_un_pts_map.swap(c->cur_un_pts_map);
   c->prev_time = c->cur_time;
   lap(7);
   c->phase_frames++;
+  c->tr_surv += (uint64_t)n_surv;
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -924,7 +930,10 @@ int esvio_fe_destroy(esvio_fe_handle c) {
                                 "host ransac", "host mask + enqueue detect/stereo", "sync B", "host tail"};
     fprintf(stderr, "[esvio_fe trace] %llu frames, ms/frame:", (unsigned long long)c->phase_frames);
     for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.3f", nm[i], c->phase_ms[i] / c->phase_frames);
-    fprintf(stderr, "\n");
+    fprintf(stderr, "\n[esvio_fe trace] survivors/frame=%.1f; detect frames=%llu: candidates/frame=%.0f new/frame=%.1f\n",
+            (double)c->tr_surv / c->phase_frames, (unsigned long long)c->tr_detect,
+            c->tr_detect ? (double)c->tr_cand / c->tr_detect : 0.0,
+            c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy,
@@ -1044,8 +1053,11 @@ int esvio_fe_create_sae_stereo(esvio_fe_handle c, const esvio_fe_event* left, si
   HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->stream));
   if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) return rc;
   unsigned long long rej = 0;
+  int sort_err = 0;
   HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&sort_err, c->d_counts + 3, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (sort_err) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
   if (n_rejected) *n_rejected = rej;
   if (c->prof_on) resolve_profile(c);
   return 0;

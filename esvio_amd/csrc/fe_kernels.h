@@ -35,9 +35,7 @@ inline int pyr_stride(int w) { return (w + 2 * kPad + 15) & ~15; }
 
 enum KernelId {
   K_SAE_KEYS = 0,
-  K_RADIX_HIST,
-  K_RADIX_SCAN,
-  K_RADIX_SCATTER,
+  K_RADIX_PASS,
   K_SAE_APPLY,
   K_TIME_SURFACE,
   K_PYR_DOWN,
@@ -51,28 +49,28 @@ enum KernelId {
 };
 
 // ---- SAE update -------------------------------------------------------------------------
-// keys[i] = cam*P + y*W + x (or invalid_key for out-of-sensor events), vals[i] = i, for the
-// virtual concatenation [left; right].
-void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR,
-                     uint32_t nR, int W, int H, uint32_t* keys, uint32_t* vals,
-                     uint32_t invalid_key, unsigned long long* n_rejected);
-
 constexpr int kRadixTile = 2048;  // keys per block
 constexpr int kRadixMaxBits = 8;
+constexpr int kRadixMaxPasses = 4;
 inline uint32_t radix_blocks(uint32_t n) { return (n + kRadixTile - 1) / kRadixTile; }
-// one stable LSD pass on digit (key >> shift) & ((1<<bits)-1); hist must hold
-// radix_blocks(n) << bits words.
-void launch_radix_hist(hipStream_t s, const uint32_t* keys, uint32_t n, int shift, int bits,
-                       uint32_t* hist);
-void launch_radix_scan(hipStream_t s, uint32_t* hist, uint32_t nblk, int bits);
-void launch_radix_scatter(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in,
-                          uint32_t n, int shift, int bits, const uint32_t* offsets,
-                          uint32_t* keys_out, uint32_t* vals_out);
+// sort scratch layout (uint32 words): [ghist: passes<<bits][tickets: passes] cleared by k_sae_apply,
+// then [lookback: passes * radix_blocks(n) << bits] cleared by k_sae_keys
+// keys[i] = cam*P + y*W + x (or invalid_key for out-of-sensor events), vals[i] = i, for the
+// virtual concatenation [left; right]; also fills the per-pass global digit histograms.
+void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR,
+                     uint32_t nR, int W, int H, uint32_t* keys, uint32_t* vals,
+                     uint32_t invalid_key, unsigned long long* n_rejected, int passes, int bits,
+                     uint32_t* ghist, uint32_t* lookback, uint32_t lookback_words);
+// one stable LSD pass on digit (key >> shift) & ((1<<bits)-1) with decoupled look-back
+void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
+                       int shift, int bits, const uint32_t* ghist, uint32_t* lookback,
+                       uint32_t* ticket, uint32_t* keys_out, uint32_t* vals_out, int* err);
 // walk every same-pixel segment of the sorted keys in stream order applying the SAE rule
 // (event_detector.cc:149-166). L2/S2: double2 per (cam,pixel): {L[0],L[1]} and {S[0],S[1]}.
 void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals, uint32_t n,
                       const EventRec* evL, uint32_t nL, const EventRec* evR, double2* L2,
-                      double2* S2, double filter_threshold, uint32_t invalid_key);
+                      double2* S2, double filter_threshold, uint32_t invalid_key,
+                      uint32_t* sort_scratch, uint32_t sort_scratch_words);
 
 // ---- time surface -----------------------------------------------------------------------
 // renders ncam cameras (S2 + cam*P) into level-0 interiors of dst[cam]

@@ -25,12 +25,21 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 // ============================================================================ SAE keys
 // Coalesced 16 B/lane read of the raw AoS stream; one u32 key + one u32 index out per event.
+// Also: per-pass global digit histograms of the keys (LDS pre-aggregation, one global atomic per
+// non-empty bin per block) and clearing of the look-back words the sort passes use.
 __global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL, uint32_t nL,
                                                   const uint4* __restrict__ evR, uint32_t nR,
                                                   int W, int H, uint32_t* __restrict__ keys,
                                                   uint32_t* __restrict__ vals,
                                                   uint32_t invalid_key,
-                                                  unsigned long long* n_rejected) {
+                                                  unsigned long long* n_rejected, int passes,
+                                                  int bits, uint32_t* __restrict__ ghist,
+                                                  uint32_t* __restrict__ lookback,
+                                                  uint32_t lookback_words) {
+  __shared__ uint32_t h[kRadixMaxPasses << kRadixMaxBits];
+  const int bins = 1 << bits;
+  for (int i = threadIdx.x; i < passes * bins; i += 256) h[i] = 0;
+  __syncthreads();
   const uint32_t n = nL + nR;
   const uint32_t P = (uint32_t)W * (uint32_t)H;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -38,104 +47,75 @@ __global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL,
     const uint4 e = right ? evR[i - nL] : evL[i];
     const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
     const bool ok = x < (uint32_t)W && y < (uint32_t)H;
-    keys[i] = ok ? (right ? P : 0u) + y * (uint32_t)W + x : invalid_key;
+    const uint32_t key = ok ? (right ? P : 0u) + y * (uint32_t)W + x : invalid_key;
+    keys[i] = key;
     vals[i] = i;
     if (!ok) atomicAdd(n_rejected, 1ull);
+    for (int p = 0; p < passes; p++) atomicAdd(&h[p * bins + ((key >> (p * bits)) & (bins - 1))], 1u);
   }
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < lookback_words;
+       i += gridDim.x * blockDim.x)
+    lookback[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < passes * bins; i += 256)
+    if (h[i]) atomicAdd(&ghist[i], h[i]);
 }
 
 void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR,
                      uint32_t nR, int W, int H, uint32_t* keys, uint32_t* vals,
-                     uint32_t invalid_key, unsigned long long* n_rejected) {
+                     uint32_t invalid_key, unsigned long long* n_rejected, int passes, int bits,
+                     uint32_t* ghist, uint32_t* lookback, uint32_t lookback_words) {
   const uint32_t n = nL + nR;
   if (!n) return;
-  uint32_t grid = (n + 255) / 256;
-  if (grid > 2048) grid = 2048;
+  uint32_t grid = (n + 1023) / 1024;  // ~4 events per thread: keeps the global atomics few
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_sae_keys, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
-                     (const uint4*)evR, nR, W, H, keys, vals, invalid_key, n_rejected);
+                     (const uint4*)evR, nR, W, H, keys, vals, invalid_key, n_rejected, passes, bits,
+                     ghist, lookback, lookback_words);
 }
 
 // ============================================================================ stable radix sort
-// LSD, <= 8-bit digits, tile = 2048 keys per 256-thread block.  Stability (stream order inside a
-// pixel) is what makes the parallel SAE update equal to the reference's sequential loop.
-__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n,
-                                                    int shift, int bits,
-                                                    uint32_t* __restrict__ hist) {
-  __shared__ uint32_t h[1 << kRadixMaxBits];
-  const int bins = 1 << bits;
-  for (int i = threadIdx.x; i < bins; i += 256) h[i] = 0;
-  __syncthreads();
-  const uint32_t base = blockIdx.x * kRadixTile;
-#pragma unroll
-  for (int k = 0; k < kRadixTile / 256; k++) {
-    uint32_t i = base + k * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (bins - 1)], 1u);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < bins; i += 256) hist[(size_t)blockIdx.x * bins + i] = h[i];
-}
+// LSD radix sort, one kernel per 7/8-bit digit ("onesweep" form): a block ranks its 2048-key tile
+// stably (wave-level match-any by ballots keeps stream order), publishes its per-digit counts and
+// obtains the counts of all earlier tiles by decoupled look-back instead of a separate
+// histogram + scan pass.  Stability (stream order inside a pixel) is what makes the parallel SAE
+// update equal to the reference's sequential loop.
+//
+// Inter-workgroup protocol (placement independent): one 32-bit word per (tile, digit) holds
+// {status:2, count:30}; it is written and read with relaxed AGENT-scope atomics (sc1, L2-served),
+// data and flag travel in the same word so no fence is needed; tiles are numbered by an atomic
+// ticket so a tile only ever waits for tiles that have already started; every spin is bounded and
+// raises *err instead of hanging.
+constexpr uint32_t kLbAgg = 1u << 30, kLbPrefix = 2u << 30, kLbMask = (1u << 30) - 1u;
 
-// hist[blk][bin] -> exclusive offsets: (sum of all smaller bins) + (same bin in earlier blocks).
-// One 1024-thread block: thread = (part, bin); parts split the block range.
-__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk,
-                                                     int bits) {
-  __shared__ uint32_t part_sum[1024];
-  __shared__ uint32_t bin_base[1 << kRadixMaxBits];
-  const int bins = 1 << bits;
-  const int parts = 1024 / bins;
-  const int bin = threadIdx.x & (bins - 1);
-  const int part = threadIdx.x >> bits;
-  const uint32_t chunk = (nblk + parts - 1) / parts;
-  const uint32_t b0 = part * chunk;
-  const uint32_t b1 = min(b0 + chunk, nblk);
-  uint32_t sum = 0;
-  for (uint32_t b = b0; b < b1; b++) sum += hist[(size_t)b * bins + bin];
-  part_sum[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x < bins) {  // per-bin totals, then exclusive scan over bins (serial: <=256)
-    uint32_t run = 0;
-    for (int p = 0; p < parts; p++) {
-      uint32_t t = part_sum[p * bins + threadIdx.x];
-      part_sum[p * bins + threadIdx.x] = run;  // exclusive over parts
-      run += t;
-    }
-    bin_base[threadIdx.x] = run;  // total of this bin
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < bins; i++) {
-      uint32_t t = bin_base[i];
-      bin_base[i] = run;
-      run += t;
-    }
-  }
-  __syncthreads();
-  uint32_t run = bin_base[bin] + part_sum[threadIdx.x];
-  for (uint32_t b = b0; b < b1; b++) {
-    uint32_t t = hist[(size_t)b * bins + bin];
-    hist[(size_t)b * bins + bin] = run;
-    run += t;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
-                                                       const uint32_t* __restrict__ vals_in,
-                                                       uint32_t n, int shift, int bits,
-                                                       const uint32_t* __restrict__ offsets,
-                                                       uint32_t* __restrict__ keys_out,
-                                                       uint32_t* __restrict__ vals_out) {
+__global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__ keys_in,
+                                                    const uint32_t* __restrict__ vals_in,
+                                                    uint32_t n, int shift, int bits,
+                                                    const uint32_t* __restrict__ ghist,
+                                                    uint32_t* __restrict__ lookback,
+                                                    uint32_t* __restrict__ ticket,
+                                                    uint32_t* __restrict__ keys_out,
+                                                    uint32_t* __restrict__ vals_out,
+                                                    int* __restrict__ err) {
   __shared__ uint32_t wave_cnt_s[4][1 << kRadixMaxBits];
-  volatile uint32_t(*wave_cnt)[1 << kRadixMaxBits] = wave_cnt_s;
+  __shared__ uint32_t bin_base[1 << kRadixMaxBits];
+  __shared__ uint32_t s_tile;
+  // NOTE: plain LDS accesses (a volatile generic pointer here turns every access into a
+  // flat_load sc0 sc1 + vmcnt(0)); same-wave ordering between rounds is given by the in-order
+  // LDS queue plus the wavefront-scope LDS fence below.
+  uint32_t(*wave_cnt)[1 << kRadixMaxBits] = wave_cnt_s;
   const int bins = 1 << bits;
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  for (int i = threadIdx.x; i < 4 * (1 << kRadixMaxBits); i += 256)
-    (&wave_cnt_s[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < 4 * (1 << kRadixMaxBits); i += 256) (&wave_cnt_s[0][0])[i] = 0;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  if ((int)threadIdx.x < bins) bin_base[threadIdx.x] = ghist[threadIdx.x];
   __syncthreads();
+  const uint32_t tile = s_tile;
 
   constexpr int ROUNDS = kRadixTile / 256;  // 8 rounds of 64 consecutive keys per wave
   uint32_t key[ROUNDS], val[ROUNDS], rank[ROUNDS];
-  const uint32_t wbase = blockIdx.x * kRadixTile + wave * (kRadixTile / 4);
+  const uint32_t wbase = tile * kRadixTile + wave * (kRadixTile / 4);
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++) {
@@ -143,6 +123,11 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     const bool ok = i < n;
     key[r] = ok ? keys_in[i] : 0xffffffffu;
     val[r] = ok ? vals_in[i] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint32_t i = wbase + r * 64 + lane;
+    const bool ok = i < n;
     const uint32_t d = (key[r] >> shift) & (bins - 1);
     // match-any on the digit: lanes holding the same digit, in lane (= stream) order
     unsigned long long m = __ballot(ok);
@@ -156,12 +141,54 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     if (ok) base = wave_cnt[wave][d];
     rank[r] = base + before;
     if (ok && before == 0) wave_cnt[wave][d] = base + cnt;  // one leader per digit
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  }
+  __syncthreads();
+  // exclusive scan of the global digit totals (serial, <= 256 bins, one thread)
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < bins; i++) {
+      const uint32_t t = bin_base[i];
+      bin_base[i] = run;
+      run += t;
+    }
+  }
+  uint32_t excl = 0;
+  if ((int)threadIdx.x < bins) {
+    const int d = threadIdx.x;
+    uint32_t cnt = 0;
+    for (int w = 0; w < 4; w++) cnt += wave_cnt[w][d];
+    uint32_t* my = lookback + (size_t)tile * bins + d;
+    if (tile == 0) {
+      __hip_atomic_store(my, kLbPrefix | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(my, kLbAgg | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int j = (int)tile - 1;
+      uint32_t spins = 0;
+      while (j >= 0) {
+        const uint32_t w = __hip_atomic_load(lookback + (size_t)j * bins + d, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t st = w & ~kLbMask;
+        if (st == 0) {
+          if (++spins > (1u << 20)) {  // bounded: never hang the GPU
+            *err = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += w & kLbMask;
+        if (st == kLbPrefix) break;
+        j--;
+      }
+      __hip_atomic_store(my, kLbPrefix | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
   if ((int)threadIdx.x < bins) {
-    uint32_t run = offsets[(size_t)blockIdx.x * bins + threadIdx.x];
+    uint32_t run = bin_base[threadIdx.x] + excl;
     for (int w = 0; w < 4; w++) {
-      uint32_t t = wave_cnt[w][threadIdx.x];
+      const uint32_t t = wave_cnt[w][threadIdx.x];
       wave_cnt[w][threadIdx.x] = run;
       run += t;
     }
@@ -179,19 +206,11 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
   }
 }
 
-void launch_radix_hist(hipStream_t s, const uint32_t* keys, uint32_t n, int shift, int bits,
-                       uint32_t* hist) {
-  hipLaunchKernelGGL(k_radix_hist, dim3(radix_blocks(n)), dim3(256), 0, s, keys, n, shift, bits,
-                     hist);
-}
-void launch_radix_scan(hipStream_t s, uint32_t* hist, uint32_t nblk, int bits) {
-  hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, hist, nblk, bits);
-}
-void launch_radix_scatter(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in,
-                          uint32_t n, int shift, int bits, const uint32_t* offsets,
-                          uint32_t* keys_out, uint32_t* vals_out) {
-  hipLaunchKernelGGL(k_radix_scatter, dim3(radix_blocks(n)), dim3(256), 0, s, keys_in, vals_in, n,
-                     shift, bits, offsets, keys_out, vals_out);
+void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
+                       int shift, int bits, const uint32_t* ghist, uint32_t* lookback,
+                       uint32_t* ticket, uint32_t* keys_out, uint32_t* vals_out, int* err) {
+  hipLaunchKernelGGL(k_radix_pass, dim3(radix_blocks(n)), dim3(256), 0, s, keys_in, vals_in, n, shift,
+                     bits, ghist, lookback, ticket, keys_out, vals_out, err);
 }
 
 // ============================================================================ SAE apply
@@ -205,8 +224,12 @@ __global__ __launch_bounds__(256) void k_sae_apply(const uint32_t* __restrict__ 
                                                    const uint4* __restrict__ evR,
                                                    double2* __restrict__ L2,
                                                    double2* __restrict__ S2, double thr,
-                                                   uint32_t invalid_key) {
+                                                   uint32_t invalid_key,
+                                                   uint32_t* __restrict__ sort_scratch,
+                                                   uint32_t sort_scratch_words) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  // the sort of this batch is finished: clear its digit histograms and tickets for the next one
+  if (i < sort_scratch_words) sort_scratch[i] = 0;
   if (i >= n) return;
   const uint32_t k = keys[i];
   if (k == invalid_key) return;
@@ -235,11 +258,13 @@ __global__ __launch_bounds__(256) void k_sae_apply(const uint32_t* __restrict__ 
 
 void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals, uint32_t n,
                       const EventRec* evL, uint32_t nL, const EventRec* evR, double2* L2,
-                      double2* S2, double filter_threshold, uint32_t invalid_key) {
+                      double2* S2, double filter_threshold, uint32_t invalid_key,
+                      uint32_t* sort_scratch, uint32_t sort_scratch_words) {
   if (!n) return;
-  hipLaunchKernelGGL(k_sae_apply, dim3((n + 255) / 256), dim3(256), 0, s, keys, vals, n,
+  const uint32_t need = n > sort_scratch_words ? n : sort_scratch_words;
+  hipLaunchKernelGGL(k_sae_apply, dim3((need + 255) / 256), dim3(256), 0, s, keys, vals, n,
                      (const uint4*)evL, nL, (const uint4*)evR, L2, S2, filter_threshold,
-                     invalid_key);
+                     invalid_key, sort_scratch, sort_scratch_words);
 }
 
 // ============================================================================ time surface
@@ -436,24 +461,47 @@ constexpr int kLkRegW = 40;                              // staged bytes per row
 constexpr int kLkRegH = kLkWin + 1 + 2 * kLkMargin;      // 34 rows
 constexpr int kLkRegDw = kLkRegW / 4 * kLkRegH;          // 340 dwords per wave
 
-// sums over the wave of two per-lane values with |v| < 2^28 (interleaved chains)
-__device__ __forceinline__ void wave_sum2_small(int a, int b, long long& ta, long long& tb) {
-  a += __builtin_amdgcn_update_dpp(0, a, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-  b += __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xf, 0xf, false);
-  a += __builtin_amdgcn_update_dpp(0, a, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-  b += __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xf, 0xf, false);
-  a += __builtin_amdgcn_update_dpp(0, a, 0x141, 0xf, 0xf, false);  // row_half_mirror: 8-lane sums
-  b += __builtin_amdgcn_update_dpp(0, b, 0x141, 0xf, 0xf, false);
-  ta = 0;
-  tb = 0;
-#pragma unroll
-  for (int g = 0; g < 8; g++) {
-    ta += (long long)__builtin_amdgcn_readlane(a, g * 8);
-    tb += (long long)__builtin_amdgcn_readlane(b, g * 8);
-  }
+// Exact wave64 sums of two per-lane integers with |v| < 2^28, result as float (one rounding, equal
+// to (float)(int64 sum)) in EVERY lane, VALU only (no readlane / scalar hop):
+//   3 DPP butterflies in int32 (8-lane sums < 2^31), split into 12 low bits and the rest so the
+//   remaining xor-8/16/32 steps stay in int32 (row_mirror DPP, v_permlane16_swap, v_permlane32_swap),
+//   then hi*4096+lo exactly in fp64 and one cvt to fp32.
+template <int CTRL>
+__device__ __forceinline__ int xor_add_dpp_t(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
-// exact for |t| < 2^53: one rounding, identical to (float)(int64) on the host
-__device__ __forceinline__ float i64_to_f32(long long t) { return (float)(double)t; }
+#define xor_add_dpp(v, ctrl) xor_add_dpp_t<ctrl>(v)
+__device__ __forceinline__ int xor16_add(int v) {
+  auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return (int)r[0] + (int)r[1];
+}
+__device__ __forceinline__ int xor32_add(int v) {
+  auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return (int)r[0] + (int)r[1];
+}
+__device__ __forceinline__ void wave_sum2_exact(int a, int b, float& fa, float& fb) {
+  a = xor_add_dpp(a, 0xB1);  // quad_perm [1,0,3,2]
+  b = xor_add_dpp(b, 0xB1);
+  a = xor_add_dpp(a, 0x4E);  // quad_perm [2,3,0,1]
+  b = xor_add_dpp(b, 0x4E);
+  a = xor_add_dpp(a, 0x141);  // row_half_mirror -> 8-lane sums
+  b = xor_add_dpp(b, 0x141);
+  int alo = a & 0xfff, ahi = a >> 12, blo = b & 0xfff, bhi = b >> 12;
+  alo = xor_add_dpp(alo, 0x140);  // row_mirror -> 16-lane sums
+  ahi = xor_add_dpp(ahi, 0x140);
+  blo = xor_add_dpp(blo, 0x140);
+  bhi = xor_add_dpp(bhi, 0x140);
+  alo = xor16_add(alo);
+  ahi = xor16_add(ahi);
+  blo = xor16_add(blo);
+  bhi = xor16_add(bhi);
+  alo = xor32_add(alo);
+  ahi = xor32_add(ahi);
+  blo = xor32_add(blo);
+  bhi = xor32_add(bhi);
+  fa = (float)__dadd_rn(__dmul_rn((double)ahi, 4096.0), (double)alo);
+  fb = (float)__dadd_rn(__dmul_rn((double)bhi, 4096.0), (double)blo);
+}
 
 struct LkCall {
   PyrDesc P;  // prev pyramid (+ derivatives)
@@ -464,10 +512,41 @@ struct LkCall {
   int flags;
 };
 
+// dword-aligned 34x40 B region of image J around window origin (wx,wy) -> registers
+__device__ __forceinline__ void lk_region_load(const uint8_t* J, int stride, int rows, int wx, int wy,
+                                               int lane, int& rx0, int& ry0,
+                                               uint32_t (&reg)[(kLkRegDw + 63) / 64]) {
+  rx0 = (wx - kLkMargin) & ~3;
+  ry0 = wy - kLkMargin;
+#pragma unroll
+  for (int k = 0; k < (kLkRegDw + 63) / 64; k++) {
+    const int d = k * 64 + lane;
+    reg[k] = 0;
+    if (d < kLkRegDw) {
+      const int ry = d / (kLkRegW / 4), rw = d - ry * (kLkRegW / 4);
+      int gy = ry0 + ry, gx = rx0 + 4 * rw;
+      // clamp into the padded buffer; clamped bytes are never used by a valid window
+      gy = min(max(gy, -kPad), rows + kPad - 1);
+      gx = min(max(gx, -kPad), stride - kPad - 4);
+      reg[k] = *(const uint32_t*)(J + (ptrdiff_t)gy * stride + gx);
+    }
+  }
+}
+__device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
+                                                const uint32_t (&reg)[(kLkRegDw + 63) / 64]) {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+  for (int k = 0; k < (kLkRegDw + 63) / 64; k++) {
+    const int d = k * 64 + lane;
+    if (d < kLkRegDw) regJ[d] = reg[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
 // one calcOpticalFlowPyrLK call for one point; returns nextPts[pt] and status
 __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, const float2 init,
                                          uint32_t* regJ, int lane, float2& np_out, int& st_out) {
-  constexpr int WIN = kLkWin, NP = 7;
+  constexpr int WIN = kLkWin, NP = 7, NL = kMaxLevels;
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
   const float FLT_SCALE = 1.f / (1 << 20);
@@ -475,141 +554,143 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   const int row = on ? lane / 3 : 0;
   const int x0 = on ? (lane - row * 3) * NP : 0;
 
+  // ---- phase A: the previous-image side of EVERY level depends only on prevPts, so all
+  // levels' patches (I, Ix, Iy in registers) and 2x2 matrices are built up front with the
+  // global loads of all levels in flight together (one memory round trip instead of one per level)
+  int pI[NL][NP], pIx[NL][NP], pIy[NL][NP];
+  bool win_ok[NL], eig_ok[NL];
+  float A11[NL], A12[NL], A22[NL], Dinv[NL];
+  {
+    int t0[NL][NP + 1], t1[NL][NP + 1], g0[NL][NP + 1], g1[NL][NP + 1];
+    int w00[NL], w01[NL], w10[NL], w11[NL];
+#pragma unroll
+    for (int L = 0; L < NL; L++) {
+      win_ok[L] = false;
+      eig_ok[L] = false;
+      if (L > c.max_level) continue;
+      const int cols = c.P.w[L], rows = c.P.h[L], stride = c.P.stride[L];
+      const float sc = 1.f / (float)(1 << L);
+      const float prevX = prev0.x * sc - halfWin, prevY = prev0.y * sc - halfWin;
+      const float flx = floorf(prevX), fly = floorf(prevY);
+      const int iprevX = (int)flx, iprevY = (int)fly;
+      win_ok[L] = !(iprevX < -WIN || iprevX >= cols || iprevY < -WIN || iprevY >= rows);
+      const float fa = prevX - flx, fb = prevY - fly;
+      w00[L] = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+      w01[L] = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+      w10[L] = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+      w11[L] = (1 << W_BITS) - w00[L] - w01[L] - w10[L];
+      // clamp the window origin for the loads of an out-of-range window (values unused)
+      const int lx = min(max(iprevX, -WIN), cols - 1), ly = min(max(iprevY, -WIN), rows - 1);
+      const ptrdiff_t o = (ptrdiff_t)(kPad + row + ly) * stride + kPad + lx + x0;
+      const uint8_t* s0 = c.P.img[L] + o;
+      const uint8_t* s1 = s0 + stride;
+      const int* d0 = (const int*)c.P.deriv[L] + o;
+      const int* d1 = d0 + stride;
+#pragma unroll
+      for (int k = 0; k <= NP; k++) {
+        t0[L][k] = s0[k];
+        t1[L][k] = s1[k];
+        g0[L][k] = d0[k];
+        g1[L][k] = d1[k];
+      }
+    }
+#pragma unroll
+    for (int L = 0; L < NL; L++) {
+      if (L > c.max_level) continue;
+      int sA11 = 0, sA12 = 0, sA22 = 0;  // 7 terms <= 2^24 each
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int ival = CV_DESCALE(__mul24(t0[L][k], w00[L]) + __mul24(t0[L][k + 1], w01[L]) +
+                                        __mul24(t1[L][k], w10[L]) + __mul24(t1[L][k + 1], w11[L]),
+                                    W_BITS - 5);
+        const int ixval = CV_DESCALE(
+            __mul24((int)(int16_t)g0[L][k], w00[L]) + __mul24((int)(int16_t)g0[L][k + 1], w01[L]) +
+                __mul24((int)(int16_t)g1[L][k], w10[L]) + __mul24((int)(int16_t)g1[L][k + 1], w11[L]),
+            W_BITS);
+        const int iyval = CV_DESCALE(__mul24(g0[L][k] >> 16, w00[L]) + __mul24(g0[L][k + 1] >> 16, w01[L]) +
+                                         __mul24(g1[L][k] >> 16, w10[L]) + __mul24(g1[L][k + 1] >> 16, w11[L]),
+                                     W_BITS);
+        pI[L][k] = (int)(int16_t)ival;
+        pIx[L][k] = on ? (int)(int16_t)ixval : 0;
+        pIy[L][k] = on ? (int)(int16_t)iyval : 0;
+        sA11 += __mul24(pIx[L][k], pIx[L][k]);
+        sA12 += __mul24(pIx[L][k], pIy[L][k]);
+        sA22 += __mul24(pIy[L][k], pIy[L][k]);
+      }
+      float f11, f12, f22, fdummy;
+      wave_sum2_exact(sA11, sA12, f11, f12);
+      wave_sum2_exact(sA22, 0, f22, fdummy);
+      A11[L] = f11 * FLT_SCALE;
+      A12[L] = f12 * FLT_SCALE;
+      A22[L] = f22 * FLT_SCALE;
+      const float D = A11[L] * A22[L] - A12[L] * A12[L];
+      const float minEig =
+          (A22[L] + A11[L] - sqrtf((A11[L] - A22[L]) * (A11[L] - A22[L]) + 4.f * A12[L] * A12[L])) /
+          (float)(2 * WIN * WIN);
+      eig_ok[L] = !(minEig < 1e-4f || D < 1.1920929e-07f /*FLT_EPSILON*/);
+      Dinv[L] = 1.f / D;
+    }
+  }
+
+  // ---- phase B: coarse-to-fine iterations
   float2 np = (c.flags & 4) ? init : make_float2(0.f, 0.f);  // nextPts[ptidx]
   int st = 1;
-
-  for (int level = c.max_level; level >= 0; level--) {
-    const int cols = c.P.w[level], rows = c.P.h[level];
-    const int stride = c.P.stride[level];
-    const uint8_t* I = c.P.img[level] + (size_t)kPad * stride + kPad;
-    const uint8_t* J = c.N.img[level] + (size_t)kPad * stride + kPad;
-    const int* dI = (const int*)c.P.deriv[level] + (size_t)kPad * stride + kPad;
-
-    const float sc = 1.f / (float)(1 << level);
-    float prevX = prev0.x * sc, prevY = prev0.y * sc;
+#pragma unroll
+  for (int L = NL - 1; L >= 0; L--) {
+    if (L > c.max_level) continue;
+    const int cols = c.P.w[L], rows = c.P.h[L];
+    const int stride = c.P.stride[L];
+    const uint8_t* J = c.N.img[L] + (size_t)kPad * stride + kPad;
+    const float sc = 1.f / (float)(1 << L);
     float nextX, nextY;
-    if (level == c.max_level) {
+    if (L == c.max_level) {
       if (c.flags & 4) {
         nextX = np.x * sc;
         nextY = np.y * sc;
       } else {
-        nextX = prevX;
-        nextY = prevY;
+        nextX = prev0.x * sc;
+        nextY = prev0.y * sc;
       }
     } else {
       nextX = np.x * 2.f;
       nextY = np.y * 2.f;
     }
     np = make_float2(nextX, nextY);
-
-    prevX -= halfWin;
-    prevY -= halfWin;
-    const int iprevX = (int)floorf(prevX), iprevY = (int)floorf(prevY);
-    if (iprevX < -WIN || iprevX >= cols || iprevY < -WIN || iprevY >= rows) {
-      if (level == 0) st = 0;
+    if (!win_ok[L] || !eig_ok[L]) {
+      if (L == 0) st = 0;
       continue;
     }
-    float fa = prevX - iprevX, fb = prevY - iprevY;
-    int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-    int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
-    int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
-    int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-
-    // ---- patch of the previous image: I (x32), Ix, Iy for this lane's 7 pixels
-    int pI[NP], pIx[NP], pIy[NP];
-    int sA11 = 0, sA12 = 0, sA22 = 0;  // 7 terms <= 2^24 each
-    {
-      const ptrdiff_t o = (ptrdiff_t)(row + iprevY) * stride + iprevX + x0;
-      const uint8_t* s0 = I + o;
-      const uint8_t* s1 = s0 + stride;
-      const int* d0 = dI + o;
-      const int* d1 = d0 + stride;
-      int t0[NP + 1], t1[NP + 1], g0[NP + 1], g1[NP + 1];
-#pragma unroll
-      for (int k = 0; k <= NP; k++) {
-        t0[k] = s0[k];
-        t1[k] = s1[k];
-        g0[k] = d0[k];
-        g1[k] = d1[k];
-      }
-#pragma unroll
-      for (int k = 0; k < NP; k++) {
-        const int ival = CV_DESCALE(__mul24(t0[k], iw00) + __mul24(t0[k + 1], iw01) +
-                                        __mul24(t1[k], iw10) + __mul24(t1[k + 1], iw11),
-                                    W_BITS - 5);
-        const int ixval =
-            CV_DESCALE(__mul24((int)(int16_t)g0[k], iw00) + __mul24((int)(int16_t)g0[k + 1], iw01) +
-                           __mul24((int)(int16_t)g1[k], iw10) + __mul24((int)(int16_t)g1[k + 1], iw11),
-                       W_BITS);
-        const int iyval = CV_DESCALE(__mul24(g0[k] >> 16, iw00) + __mul24(g0[k + 1] >> 16, iw01) +
-                                         __mul24(g1[k] >> 16, iw10) + __mul24(g1[k + 1] >> 16, iw11),
-                                     W_BITS);
-        pI[k] = (int)(int16_t)ival;
-        pIx[k] = on ? (int)(int16_t)ixval : 0;
-        pIy[k] = on ? (int)(int16_t)iyval : 0;
-        sA11 += __mul24(pIx[k], pIx[k]);
-        sA12 += __mul24(pIx[k], pIy[k]);
-        sA22 += __mul24(pIy[k], pIy[k]);
-      }
-    }
-    long long tA11, tA12, tA22, tdummy;
-    wave_sum2_small(sA11, sA12, tA11, tA12);
-    wave_sum2_small(sA22, 0, tA22, tdummy);
-    const float A11 = i64_to_f32(tA11) * FLT_SCALE;
-    const float A12 = i64_to_f32(tA12) * FLT_SCALE;
-    const float A22 = i64_to_f32(tA22) * FLT_SCALE;
-
-    float D = A11 * A22 - A12 * A12;
-    const float minEig =
-        (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-    if (minEig < 1e-4f || D < 1.1920929e-07f /*FLT_EPSILON*/) {
-      if (level == 0) st = 0;
-      continue;
-    }
-    D = 1.f / D;
-
     nextX -= halfWin;
     nextY -= halfWin;
+    // stage the search region for the initial window right away
+    int rx0, ry0;
+    {
+      uint32_t reg[(kLkRegDw + 63) / 64];
+      lk_region_load(J, stride, rows, (int)floorf(nextX), (int)floorf(nextY), lane, rx0, ry0, reg);
+      lk_region_store(regJ, lane, reg);
+    }
     float prevDx = 0.f, prevDy = 0.f;
-    int rx0 = 0, ry0 = 0;
-    bool staged = false;
     for (int j = 0; j < c.max_count; j++) {
       const float flX = floorf(nextX), flY = floorf(nextY);
       const int inextX = (int)flX, inextY = (int)flY;
       if (inextX < -WIN || inextX >= cols || inextY < -WIN || inextY >= rows) {
-        if (level == 0) st = 0;
+        if (L == 0) st = 0;
         break;
       }
       int offx = inextX - rx0, offy = inextY - ry0;
-      if (!staged || (unsigned)offx > (unsigned)(kLkRegW - (WIN + 1)) ||
+      if ((unsigned)offx > (unsigned)(kLkRegW - (WIN + 1)) ||
           (unsigned)offy > (unsigned)(kLkRegH - (WIN + 1))) {
-        // (re)stage the search region around the current window, origin dword-aligned
-        rx0 = (inextX - kLkMargin) & ~3;
-        ry0 = inextY - kLkMargin;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-        for (int k = 0; k < (kLkRegDw + 63) / 64; k++) {
-          const int d = k * 64 + lane;
-          if (d < kLkRegDw) {
-            const int ry = d / (kLkRegW / 4), rw = d - ry * (kLkRegW / 4);
-            int gy = ry0 + ry, gx = rx0 + 4 * rw;
-            // clamp into the padded buffer; clamped bytes are never used by a valid window
-            gy = min(max(gy, -kPad), rows + kPad - 1);
-            gx = min(max(gx, -kPad), stride - kPad - 4);
-            regJ[d] = *(const uint32_t*)(J + (ptrdiff_t)gy * stride + gx);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        staged = true;
+        uint32_t reg[(kLkRegDw + 63) / 64];  // the window drifted out of the staged region
+        lk_region_load(J, stride, rows, inextX, inextY, lane, rx0, ry0, reg);
+        lk_region_store(regJ, lane, reg);
         offx = inextX - rx0;
         offy = inextY - ry0;
       }
-      fa = nextX - flX;
-      fb = nextY - flY;
-      iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-      iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
-      iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
-      iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+      const float fa = nextX - flX, fb = nextY - flY;
+      const int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+      const int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+      const int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+      const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
       // 8 bytes of two consecutive staged rows: 3 aligned dwords per row + funnel shift
       const int bo = (row + offy) * kLkRegW + offx + x0;
       const uint32_t* rp = regJ + (bo >> 2);
@@ -629,16 +710,16 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       for (int k = 0; k < NP; k++) {
         const int t = __mul24(q0[k], iw00) + __mul24(q0[k + 1], iw01) + __mul24(q1[k], iw10) +
                       __mul24(q1[k + 1], iw11);
-        const int diff = CV_DESCALE(t, W_BITS - 5) - pI[k];
-        sb1 += __mul24(diff, pIx[k]);
-        sb2 += __mul24(diff, pIy[k]);
+        const int diff = CV_DESCALE(t, W_BITS - 5) - pI[L][k];
+        sb1 += __mul24(diff, pIx[L][k]);
+        sb2 += __mul24(diff, pIy[L][k]);
       }
-      long long tb1, tb2;
-      wave_sum2_small(sb1, sb2, tb1, tb2);
-      const float b1 = i64_to_f32(tb1) * FLT_SCALE;
-      const float b2 = i64_to_f32(tb2) * FLT_SCALE;
-      const float dx = (A12 * b2 - A22 * b1) * D;
-      const float dy = (A12 * b1 - A11 * b2) * D;
+      float b1, b2;
+      wave_sum2_exact(sb1, sb2, b1, b2);
+      b1 *= FLT_SCALE;
+      b2 *= FLT_SCALE;
+      const float dx = (A12[L] * b2 - A22[L] * b1) * Dinv[L];
+      const float dy = (A12[L] * b1 - A11[L] * b2) * Dinv[L];
       nextX += dx;
       nextY += dy;
       np = make_float2(nextX + halfWin, nextY + halfWin);
@@ -651,7 +732,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       prevDx = dx;
       prevDy = dy;
     }
-    if (st && level == 0) {  // the `err` block of the tracker re-validates the final position
+    if (st && L == 0) {  // the `err` block of the tracker re-validates the final position
       const float fx = np.x - halfWin, fy = np.y - halfWin;
       const int ix = (int)floorf(fx), iy = (int)floorf(fy);
       if (ix < -WIN || ix >= cols || iy < -WIN || iy >= rows) st = 0;
@@ -744,7 +825,7 @@ __constant__ int8_t c_large[20][2] = {{0, 4},   {1, 4},   {2, 3},   {3, 2},  {4,
 // one ring of isCorner (event_detector.cc:337-435 small / :438-541 large). `ring` is this
 // thread's private column of an LDS tile laid out [ring index][thread] (bank-conflict free).
 template <int N, int KMIN, int KMAX>
-__device__ __forceinline__ bool arc_ring(const volatile double* ring, int tstride) {
+__device__ __forceinline__ bool arc_ring(const double* ring, int tstride) {
   double segment_new_min_t = ring[0];
   int arc_right_idx = 0;
 #pragma unroll
@@ -819,7 +900,7 @@ __global__ __launch_bounds__(kArcBlock) void k_arc(ArcArgs a) {
         ok = false;
       if (ok) {
         const double* S = (const double*)a.S2 + pol;
-        volatile double* ring = ring_s + threadIdx.x;
+        double* ring = ring_s + threadIdx.x;  // thread-private LDS column
 #pragma unroll
         for (int k = 0; k < 16; k++)
           ring[k * kArcBlock] =
@@ -901,7 +982,7 @@ void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand
 
 __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  volatile uint32_t* bitmap = lds;  // H * wpr words, bit set = inside a disc stamped by this call
+  uint32_t* const bitmap = lds;  // H * wpr words, bit set = inside a disc stamped by this call
   const int lane = lane_id();
   const int nwords = a.H * a.wpr;
   for (int i = lane * 4; i < nwords; i += 256) {
@@ -915,41 +996,71 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   const uint32_t total = *a.total;
   int accepted = 0;
   const int r = a.radius;
-  for (uint32_t base = 0; base < total && accepted < a.max_corners; base += 64) {
-    const uint32_t i = base + lane;
-    const bool have = i < total;
-    const uint32_t xy = have ? a.comp_xy[i] : 0u;
-    const uint32_t ci = have ? a.comp_idx[i] : 0u;
-    const int x = xy & 0xffff, y = xy >> 16;
-    bool alive = have && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
-    while (accepted < a.max_corners) {
-      const unsigned long long m = __ballot(alive);
-      if (!m) break;
-      const int first = __ffsll((long long)m) - 1;
-      const int ax = __builtin_amdgcn_readlane(x, first);
-      const int ay = __builtin_amdgcn_readlane(y, first);
-      const int ai = __builtin_amdgcn_readlane((int)ci, first);
-      if (lane == 0) {
-        a.out_pts[a.out_base + accepted] = make_float2((float)ax, (float)ay);
-        if (a.out_idx) a.out_idx[accepted] = ai;
-      }
-      accepted++;
-      // stamp the disc: one lane per row
-      for (int rowi = lane; rowi < 2 * r + 1; rowi += 64) {
-        const int yy = ay - r + rowi;
-        if (yy < 0 || yy >= a.H) continue;
-        const int hw = a.hw[rowi < r ? r - rowi : rowi - r];
-        if (hw < 0) continue;
-        const int xa = max(ax - hw, 0), xb = min(ax + hw, a.W - 1);
-        if (xb < xa) continue;
-        for (int w = xa >> 5; w <= (xb >> 5); w++) {
-          const int lo = max(xa - (w << 5), 0), hi = min(xb - (w << 5), 31);
-          const uint32_t bits = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-          bitmap[yy * a.wpr + w] |= bits;
+  // this lane's disc rows (row index lane and lane+64) and their half-widths, kept in registers so
+  // an accept never touches memory for the table
+  const int row_a = lane, row_b = lane + 64;
+  const int hw_a = row_a < 2 * r + 1 ? a.hw[row_a < r ? r - row_a : row_a - r] : -1;
+  const int hw_b = row_b < 2 * r + 1 ? a.hw[row_b < r ? r - row_b : row_b - r] : -1;
+  // 256 candidates per step (4 sub-chunks of 64 in stream order); the next step's loads are issued
+  // before the current one is processed so the serial loop never waits on HBM/L2 latency
+  constexpr int SUB = 4;
+  uint32_t nxy[SUB], nci[SUB];
+#pragma unroll
+  for (int j = 0; j < SUB; j++) {
+    const uint32_t i = j * 64 + lane;
+    nxy[j] = i < total ? a.comp_xy[i] : 0u;
+    nci[j] = i < total ? a.comp_idx[i] : 0u;
+  }
+  for (uint32_t base = 0; base < total && accepted < a.max_corners; base += 64 * SUB) {
+    uint32_t cxy[SUB], cci[SUB];
+#pragma unroll
+    for (int j = 0; j < SUB; j++) {
+      cxy[j] = nxy[j];
+      cci[j] = nci[j];
+      const uint32_t i = base + 64 * SUB + j * 64 + lane;
+      nxy[j] = i < total ? a.comp_xy[i] : 0u;
+      nci[j] = i < total ? a.comp_idx[i] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < SUB; j++) {
+      const uint32_t i = base + j * 64 + lane;
+      const bool have = i < total;
+      const int x = cxy[j] & 0xffff, y = cxy[j] >> 16;
+      bool alive = have && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+      while (accepted < a.max_corners) {
+        const unsigned long long m = __ballot(alive);
+        if (!m) break;
+        const int first = __ffsll((long long)m) - 1;
+        const int ax = __builtin_amdgcn_readlane(x, first);
+        const int ay = __builtin_amdgcn_readlane(y, first);
+        const int ai = __builtin_amdgcn_readlane((int)cci[j], first);
+        if (lane == 0) {
+          a.out_pts[a.out_base + accepted] = make_float2((float)ax, (float)ay);
+          if (a.out_idx) a.out_idx[accepted] = ai;
         }
+        accepted++;
+        // stamp the disc: one lane per row (two rows per lane when r > 31), LDS atomic OR
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int hw = h ? hw_b : hw_a;
+          const int yy = ay - r + (h ? row_b : row_a);
+          if (hw < 0 || yy < 0 || yy >= a.H) continue;
+          const int xa = max(ax - hw, 0), xb = min(ax + hw, a.W - 1);
+          if (xb < xa) continue;
+          for (int w = xa >> 5; w <= (xb >> 5); w++) {
+            const int lo = max(xa - (w << 5), 0), hi = min(xb - (w << 5), 31);
+            const uint32_t bits =
+                (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            __hip_atomic_fetch_or(lds + yy * a.wpr + w, bits, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+        }
+        // order the LDS stamps before the re-test (LDS only: the global stores above must not be
+        // waited for — a full fence here costs a memory round trip per accepted corner)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+        alive = alive && lane > first && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      alive = alive && lane > first && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+      if (accepted >= a.max_corners) break;
     }
   }
   if (lane == 0) {
