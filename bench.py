@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=40, help="oracle frames for cpu_baseline (0=skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the N>1 path)")
     return ap.parse_args()
 
 
@@ -82,13 +84,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    xdev = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     from esvio_amd import frontend as FE
     from esvio_amd.events import event_times
@@ -110,19 +117,20 @@ def main():
         dev_batches.append((tl, tr, len(L), len(R), event_times(L)[-1]))
     torch.cuda.synchronize()
 
-    cfg = FE.make_config(W, H, device=local_rank, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1)
+    cfg = FE.make_config(W, H, device=dev_index, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1)
     ft = FE.FeatureTracker(cfg)
     fc = FreqControl(args.freq)
-    exch = (TrackExchange(cfg.max_cnt, world, device="cuda", dist=dist, stream=torch.cuda.Stream())
+    exch = (TrackExchange(cfg.max_cnt, world, device=xdev, dist=dist,
+                          stream=torch.cuda.Stream() if xdev == "cuda" else None)
             if world > 1 else None)
 
-    def step(i):
+    def step(i, exchange=True):
         tl, tr, nl, nr, t_last = dev_batches[i]
         pub = fc.pub_this_frame(t_last)
         ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
         if pub:
             fc.published()
-            if exch is not None:  # merge tracked corners of all rigs (async, overlaps next frame)
+            if exch is not None and exchange:  # merge all rigs' tracked corners (async)
                 exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
         return nl + nr
 
@@ -145,7 +153,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(n_events), elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(n_events), elapsed], dtype=torch.float64, device=xdev)
     if world > 1:
         ev_t = tot.clone()
         dist.all_reduce(ev_t[0:1], op=dist.ReduceOp.SUM)
@@ -163,7 +171,7 @@ def main():
         ft.reset_kernel_stats()
         tp0 = time.perf_counter()
         for i in range(n_frames, n_frames + n_prof):
-            step(i)
+            step(i, exchange=False)  # rank-0-only pass: no collectives
         torch.cuda.synchronize()
         prof_ms_per_step = (time.perf_counter() - tp0) / n_prof * 1e3
         stats = ft.kernel_stats()
@@ -187,9 +195,6 @@ def main():
                         profiled_ms_per_step=round(prof_ms_per_step, 4),
                         note="k_lk is dependent-instruction-latency bound (one wave per point, <=30 "
                              "serial iterations per level), not HBM bound; see DESIGN.md section 4")
-    elif n_prof:
-        for i in range(n_frames, n_frames + n_prof):
-            pass
 
     # ---- CPU baseline: the oracle (single-threaded port of the reference path) on a bounded sample
     cpu = None
