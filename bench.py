@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=40, help="oracle frames for cpu_baseline (0=skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--split", choices=["rigs", "camera"], default="rigs",
+                    help="N>1 sharding: one independent stereo rig per GPU (weak scaling, default) or "
+                         "BASELINE C4: left/right cameras of ONE rig on 2 GPUs")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the N>1 path)")
     return ap.parse_args()
@@ -99,7 +102,7 @@ def main():
 
     from esvio_amd import frontend as FE
     from esvio_amd.events import event_times
-    from esvio_amd.dist import TrackExchange
+    from esvio_amd.dist import CameraSplitRig, TrackExchange
     from esvio_amd.node import FreqControl, pack_track_records
     from esvio_amd.synth import SceneStream
 
@@ -107,7 +110,11 @@ def main():
     n_frames = args.warmup + args.steps
     n_prof = 0 if args.no_profile_pass else min(args.steps, 30)
     # ---- synthetic stream (per rank: an independent rig, different seed), resident in HBM
-    scene = SceneStream(W, H, rate=args.rate, batch_hz=args.batch_hz, seed=args.seed + 1000 * rank)
+    cam_split = args.split == "camera" and world > 1
+    if cam_split and world != 2:
+        raise SystemExit("--split camera needs exactly 2 ranks")
+    scene = SceneStream(W, H, rate=args.rate, batch_hz=args.batch_hz,
+                        seed=args.seed + (0 if cam_split else 1000 * rank))
     host_batches, dev_batches = [], []
     for _ in range(n_frames + n_prof):
         L, R, _ = scene.next_batch()
@@ -124,9 +131,18 @@ def main():
                           stream=torch.cuda.Stream() if xdev == "cuda" else None)
             if world > 1 else None)
 
+    rig = CameraSplitRig(ft, rank, dist, device=xdev) if cam_split else None
+
     def step(i, exchange=True):
         tl, tr, nl, nr, t_last = dev_batches[i]
         pub = fc.pub_this_frame(t_last)
+        if rig is not None:  # C4: rank 0 = left camera + tracking, rank 1 = right camera
+            rig.track(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub)
+            if pub:
+                fc.published()
+                if exchange:
+                    exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
+            return nl if rank == 0 else nr
         ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
         if pub:
             fc.published()
@@ -166,7 +182,7 @@ def main():
     # stream (kept out of the timed region above because event records cost host time)
     roof = None
     kernels = {}
-    if n_prof and rank == 0:
+    if n_prof and (rank == 0 or cam_split):  # camera split: the rig needs both ranks every frame
         ft.set_profiling(True)
         ft.reset_kernel_stats()
         tp0 = time.perf_counter()
@@ -233,7 +249,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if cam_split else "weak",
             "vs_baseline": None,
             "dtype": "f64 timestamps / u8 images / int64 LK sums",
             "data": "synthetic",
@@ -243,7 +259,8 @@ def main():
                             "max_cnt 300 min_dist 10 flow_back 1 equalize 0 freq %d"
                             % (W, H, args.rate / 1e6, args.batch_hz, args.freq),
                 "events_per_step_per_gpu": int(n_events / args.steps),
-                "parallelism": "1 rig per GPU" if world > 1 else "single GPU",
+                "parallelism": ("left/right camera split, 1 rig on 2 GPUs" if cam_split else
+                                "1 rig per GPU") if world > 1 else "single GPU",
                 "tracks_last_frame": n_tracks,
             },
             "roofline": roof,

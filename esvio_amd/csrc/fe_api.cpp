@@ -88,6 +88,7 @@ struct esvio_fe_ctx {
   PyrStore pyr[3];  // two left slots (prev/cur alternate) + right
   int slot_prevL = 0, slot_curL = 0;
   bool have_img = false;
+  bool ext_right_pending = false;  // esvio_fe_import_image(cam=1) done for the next frame
   PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images
   // LK point buffers (device), each max_cnt
   // one allocation, laid out [ptsB | ptsC | stA | stB | counts | ptsA] so that each host sync
@@ -732,7 +733,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->slot_curL = first ? 0 : (c->slot_prevL ^ 1);
   if (first) c->slot_prevL = 0;  // prev_img_left = cur_img_left = img_left (:391)
   PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[2].d};
-  render_ts(c, c->cur_time, cur2[0].img[0], cur2[1].img[0], 2, c->S2);
+  // camera split: the right image was imported from the GPU that owns the right camera
+  render_ts(c, c->cur_time, cur2[0].img[0], cur2[1].img[0], c->ext_right_pending ? 1 : 2, c->S2);
+  c->ext_right_pending = false;
   pyr_build(c, cur2, 2);
   c->have_img = true;
   const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
@@ -1085,6 +1088,34 @@ int esvio_fe_get_time_surface(esvio_fe_handle c, int cam, uint8_t* out) {
   if (!c || !out || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   return copy_level0_out(c, cam ? c->pyr[2].d : c->pyr[c->slot_curL].d, out);
+}
+
+int esvio_fe_export_image(esvio_fe_handle c, int cam, uint8_t* dst, int space) {
+  if (!c || !dst || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
+  if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  const PyrDesc& d = cam ? c->pyr[2].d : c->pyr[c->slot_curL].d;
+  const int stride = d.stride[0];
+  HIPCHK(c, hipMemcpy2DAsync(dst, c->W, d.img[0] + (size_t)kPad * stride + kPad, stride, c->W, c->H,
+                             space == ESVIO_FE_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                             c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int esvio_fe_import_image(esvio_fe_handle c, int cam, const uint8_t* src, int space) {
+  if (!c || !src) return ESVIO_FE_EINVAL;
+  if (cam != 1) return fail(c, ESVIO_FE_EINVAL, "only the right camera's image can be imported");
+  if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  const PyrDesc& d = c->pyr[2].d;
+  const int stride = d.stride[0];
+  HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, src, c->W, c->W, c->H,
+                             space == ESVIO_FE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                             c->stream));
+  if (space == ESVIO_FE_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse src
+  c->ext_right_pending = true;
+  return 0;
 }
 
 int esvio_fe_is_corner(esvio_fe_handle c, const esvio_fe_event* ev, size_t n, int space,

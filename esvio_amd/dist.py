@@ -59,3 +59,50 @@ def merged_point_cloud(gathered):
         valid = block[block[:, 3] >= 0]
         out.append(np.c_[valid, np.full(len(valid), rk, np.float32)])
     return np.concatenate(out, 0) if out else np.zeros((0, 9), np.float32)
+
+
+class CameraSplitRig:
+    """BASELINE config C4: one stereo rig on two GPUs, rank 0 owns the left camera (SAE, time
+    surface, temporal LK, detection, stereo LK), rank 1 owns the right camera's SAE + time surface
+    and ships its 1 byte/pixel image every frame (W*H bytes: 307 KB at 640x480 — ~2 us of one xGMI
+    link; latency-, not bandwidth-bound).  The left rank's tracks equal the single-GPU result bit
+    for bit because the two cameras never share SAE state (event_detector.h:74-79) and both time
+    surfaces use the LEFT batch's end time (feature_tracker.cpp:367-368)."""
+
+    def __init__(self, tracker, rank, dist, device="cpu"):
+        import torch
+        assert dist.get_world_size() == 2
+        self.torch = torch
+        self.ft = tracker
+        self.rank = rank
+        self.dist = dist
+        W, H = tracker.cfg.width, tracker.cfg.height
+        self.img = torch.zeros((H, W), dtype=torch.uint8, device=device)
+        self.on_gpu = device != "cpu"
+        self._empty = None
+
+    def track(self, cur_time, event_left, event_right, pub_this_frame):
+        """cur_time = last LEFT event's stamp (node:190).  Returns the tracker on rank 0."""
+        if self.rank == 1:
+            self.ft.detector.createSAE_right(event_right)
+            if self.on_gpu:
+                self.ft._hd.check(self.ft._hd.L.esvio_fe_sae_to_time_surface(
+                    self.ft._hd.h, 1, float(cur_time), None))
+                self.ft.export_image(1, dst=self.img.data_ptr())
+            else:
+                self.img.copy_(self.torch.from_numpy(self.ft.detector.SAEtoTimeSurface_right(cur_time)))
+        self.dist.broadcast(self.img, src=1)
+        if self.rank == 0:
+            if self.on_gpu:
+                self.torch.cuda.current_stream().synchronize()
+                self.ft.import_image(1, self.img.data_ptr())
+            else:
+                self.ft.import_image(1, self.img.numpy())
+            if self._empty is None:
+                import numpy as np
+                from .events import EVENT_DTYPE
+                self._empty = np.zeros(0, EVENT_DTYPE)
+            empty = (0, 0) if isinstance(event_left, tuple) else self._empty
+            self.ft.trackEvent(cur_time, event_left, empty, pub_this_frame, copy=False)
+            return self.ft
+        return None

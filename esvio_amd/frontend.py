@@ -59,7 +59,8 @@ ABI_SYMBOLS = [
     "esvio_fe_sae_to_time_surface", "esvio_fe_is_corner", "esvio_fe_features_to_track",
     "esvio_fe_get_sae", "esvio_fe_set_sae", "esvio_fe_calc_optical_flow_pyr_lk",
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
-    "esvio_fe_track_event", "esvio_fe_get_time_surface", "esvio_fe_set_profiling",
+    "esvio_fe_track_event", "esvio_fe_get_time_surface", "esvio_fe_export_image",
+    "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
     "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
 ]
@@ -103,6 +104,8 @@ def load_library(build_if_missing=True):
     L.esvio_fe_lift_projective.argtypes = [C.POINTER(Camera), d, d, vp]
     L.esvio_fe_track_event.argtypes = [vp, d, vp, sz, vp, sz, i, i, C.POINTER(Tracks)]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
+    L.esvio_fe_export_image.argtypes = [vp, i, vp, i]
+    L.esvio_fe_import_image.argtypes = [vp, i, vp, i]
     L.esvio_fe_set_profiling.argtypes = [vp, i]
     L.esvio_fe_kernel_name.restype = C.c_char_p
     L.esvio_fe_kernel_name.argtypes = [i]
@@ -288,6 +291,24 @@ class FeatureTracker:
         out = np.empty((self.cfg.height, self.cfg.width), np.uint8)
         self._hd.check(self._hd.L.esvio_fe_get_time_surface(self._hd.h, cam, _p(out)))
         return out
+
+    # ---- camera split (right camera on another GPU)
+    def export_image(self, cam, dst=None):
+        """current image of `cam` -> numpy (H,W) u8, or into a device buffer given as int pointer"""
+        if dst is None:
+            out = np.empty((self.cfg.height, self.cfg.width), np.uint8)
+            self._hd.check(self._hd.L.esvio_fe_export_image(self._hd.h, cam, _p(out), HOST))
+            return out
+        self._hd.check(self._hd.L.esvio_fe_export_image(self._hd.h, cam, C.c_void_p(int(dst)), DEVICE))
+        return None
+
+    def import_image(self, cam, src):
+        """numpy (H,W) u8 or device pointer (int): right image for the next trackEvent"""
+        if isinstance(src, np.ndarray):
+            src = np.ascontiguousarray(src, np.uint8)
+            self._hd.check(self._hd.L.esvio_fe_import_image(self._hd.h, cam, _p(src), HOST))
+        else:
+            self._hd.check(self._hd.L.esvio_fe_import_image(self._hd.h, cam, C.c_void_p(int(src)), DEVICE))
 
     # ---- stage-level entry points used by the parity tests
     def Event_FeaturesToTrack(self, last_event, maxCorners, event_mask=None):

@@ -164,6 +164,17 @@ int esvio_fe_track_event(esvio_fe_handle h, double cur_time, const esvio_fe_even
 /* FeatureTracker::gettimesurface() tap (feature_tracker.cpp:894): current left/right image */
 int esvio_fe_get_time_surface(esvio_fe_handle h, int cam, uint8_t* out);
 
+/* ---- camera split across GPUs (BASELINE config C4) ----------------------- */
+/* The left and right cameras have disjoint SAE state (sae_/sae_latest_ vs sae_right/
+ * sae_latest_right, event_detector.h:74-79), so a second GPU can own the right camera: it runs
+ * esvio_fe_create_sae(cam=1) + esvio_fe_sae_to_time_surface(cam=1, t_sync = LEFT batch end,
+ * feature_tracker.cpp:367-368) and ships the 1-byte/pixel image.  export: copy the current image
+ * of `cam` into a contiguous width*height buffer (host or device).  import: hand the left GPU's
+ * handle the right image for the NEXT esvio_fe_track_event call (one shot), which then skips the
+ * right camera's SAE update and rendering (pass nR = 0) and uses this image for stereo LK. */
+int esvio_fe_export_image(esvio_fe_handle h, int cam, uint8_t* dst, int space);
+int esvio_fe_import_image(esvio_fe_handle h, int cam, const uint8_t* src, int space);
+
 /* ---- measurement --------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the handle's stream (off by default; when on, every launch is
  * bracketed by hipEventRecord and resolved lazily). */
