@@ -32,7 +32,7 @@ struct P2f {
 
 const char* const kKernelNames[K_COUNT] = {
     "k_sae_keys", "k_radix_pass", "k_sae_apply",
-    "k_time_surface", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select"};
+    "k_time_surface", "k_clahe", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select"};
 
 struct KStat {
   double ms = 0;
@@ -90,6 +90,10 @@ struct esvio_fe_ctx {
   bool have_img = false;
   bool ext_right_pending = false;  // esvio_fe_import_image(cam=1) done for the next frame
   PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images
+  // equalize: raw time surfaces (single padded level each, left/right) + CLAHE scratch
+  PyrStore raw[2];
+  uint8_t* d_lut = nullptr;
+  int* d_minmax = nullptr;
   // LK point buffers (device), each max_cnt
   // one allocation, laid out [ptsB | ptsC | stA | stB | counts | ptsA] so that each host sync
   // needs a single D2H copy
@@ -393,6 +397,47 @@ void render_ts(esvio_fe_ctx* c, double t_sync, uint8_t* dst0, uint8_t* dst1, int
                       c->cfg.ignore_polarity, dst0, dst1, c->pyr[0].d.stride[0], ncam);
 }
 
+inline uint8_t* px00(const PyrDesc& d) { return d.img[0] + (size_t)kPad * d.stride[0] + kPad; }
+
+// the image trackEvent feeds to LK: the raw time surface, or CLAHE + normalize of it when
+// `equalize` (feature_tracker.cpp:375-387).  cams: bit 0 left, bit 1 right.  Raw surfaces stay
+// available for the TS_LK_THRESHOLD test and gettimesurface().
+void render_lk_images(esvio_fe_ctx* c, double t_sync, int cams) {
+  const PyrDesc& L = c->pyr[c->slot_curL].d;
+  const PyrDesc& R = c->pyr[2].d;
+  if (!c->cfg.equalize) {
+    if (cams == 3) render_ts(c, t_sync, L.img[0], R.img[0], 2, c->S2);
+    else if (cams == 1) render_ts(c, t_sync, L.img[0], L.img[0], 1, c->S2);
+    else if (cams == 2) render_ts(c, t_sync, R.img[0], R.img[0], 1, c->S2 + c->P);
+    return;
+  }
+  const PyrDesc& rl = c->raw[0].d;
+  const PyrDesc& rr = c->raw[1].d;
+  int nimg;
+  const uint8_t *s0, *s1;
+  uint8_t *d0, *d1;
+  if (cams == 3) {
+    render_ts(c, t_sync, rl.img[0], rr.img[0], 2, c->S2);
+    nimg = 2; s0 = px00(rl); s1 = px00(rr); d0 = px00(L); d1 = px00(R);
+  } else if (cams == 1) {
+    render_ts(c, t_sync, rl.img[0], rl.img[0], 1, c->S2);
+    nimg = 1; s0 = s1 = px00(rl); d0 = d1 = px00(L);
+  } else {
+    render_ts(c, t_sync, rr.img[0], rr.img[0], 1, c->S2 + c->P);
+    nimg = 1; s0 = s1 = px00(rr); d0 = d1 = px00(R);
+  }
+  for (int stage = 0; stage < 3; stage++) {
+    ScopedKernel k(c, K_CLAHE, stage == 0 ? (uint64_t)c->P * nimg : (uint64_t)c->P * 2 * nimg);
+    launch_clahe(c->stream, s0, s1, rl.stride[0], d0, d1, L.stride[0], c->W, c->H, c->d_lut,
+                 c->d_minmax, nimg, stage);
+  }
+}
+
+const PyrDesc& raw_ts_desc(const esvio_fe_ctx* c, int cam) {
+  if (c->cfg.equalize) return c->raw[cam].d;
+  return cam ? c->pyr[2].d : c->pyr[c->slot_curL].d;
+}
+
 LkArgs make_lk(const PyrDesc& P, const PyrDesc& N, const float2* prev, const float2* init,
                float2* next, uint8_t* status, const int* n_ptr, int n_max, int max_level,
                int max_count, double eps, int flags) {
@@ -693,8 +738,8 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool 
   a.H = c->H;
   a.filter_threshold = c->cfg.feature_filter_threshold;
   a.border = c->cfg.min_dist + 1;
-  a.ts = use_ts ? c->pyr[c->slot_curL].d.img[0] : nullptr;
-  a.ts_stride = c->pyr[c->slot_curL].d.stride[0];
+  a.ts = use_ts ? raw_ts_desc(c, 0).img[0] : nullptr;  // RAW left time surface (:26)
+  a.ts_stride = raw_ts_desc(c, 0).stride[0];
   a.ts_lk_threshold = c->cfg.ts_lk_threshold;
   a.mask_bits = use_mask ? c->d_mask_bits : nullptr;
   a.wpr = (c->W + 31) / 32;
@@ -734,7 +779,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   if (first) c->slot_prevL = 0;  // prev_img_left = cur_img_left = img_left (:391)
   PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[2].d};
   // camera split: the right image was imported from the GPU that owns the right camera
-  render_ts(c, c->cur_time, cur2[0].img[0], cur2[1].img[0], c->ext_right_pending ? 1 : 2, c->S2);
+  render_lk_images(c, c->cur_time, c->ext_right_pending ? 1 : 3);
   c->ext_right_pending = false;
   pyr_build(c, cur2, 2);
   c->have_img = true;
@@ -941,7 +986,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy,
                   c->d_comp_idx, c->d_mask_bits, c->d_sel_idx, c->pyr[0].mem, c->pyr[1].mem,
-                  c->pyr[2].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem};
+                  c->pyr[2].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->raw[0].mem, c->raw[1].mem,
+                  c->d_lut, c->d_minmax};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -963,7 +1009,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if (cfg->max_cnt < 1 || cfg->max_cnt > 65536) return ESVIO_FE_EINVAL;
   if (cfg->min_dist < 3 || cfg->min_dist > kMaxDiscR) return ESVIO_FE_EINVAL;  // Arc* ring r=4
   if (cfg->lk_accum != 1) return ESVIO_FE_EINVAL;
-  if (cfg->median_blur_kernel_size != 0 || cfg->equalize != 0) return ESVIO_FE_ENOTIMPL;
+  if (cfg->median_blur_kernel_size != 0) return ESVIO_FE_ENOTIMPL;
+  if (cfg->equalize != 0 && cfg->equalize != 1) return ESVIO_FE_EINVAL;
   if (!(cfg->decay_ms > 0)) return ESVIO_FE_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ESVIO_FE_ENODEVICE;
@@ -1020,6 +1067,12 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if ((rc = dev_alloc(c, &c->d_mask_bits, (size_t)c->H * ((c->W + 31) / 32)))) return bail(rc);
   for (int i = 0; i < 3; i++)
     if ((rc = pyr_alloc(c, c->pyr[i], c->W, c->H, 3))) return bail(rc);
+  if (cfg->equalize) {
+    for (int i = 0; i < 2; i++)
+      if ((rc = pyr_alloc(c, c->raw[i], c->W, c->H, 0))) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_lut, (size_t)2 * 64 * 256))) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_minmax, 4))) return bail(rc);
+  }
   c->h_pin_bytes = pin_bytes(*cfg);
   if (hipHostMalloc((void**)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
@@ -1076,9 +1129,8 @@ int esvio_fe_create_sae(esvio_fe_handle c, int cam, const esvio_fe_event* ev, si
 int esvio_fe_sae_to_time_surface(esvio_fe_handle c, int cam, double t_sync, uint8_t* out) {
   if (!c || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  const PyrDesc& d = cam ? c->pyr[2].d : c->pyr[c->slot_curL].d;
-  render_ts(c, t_sync, d.img[0], d.img[0], 1, c->S2 + (size_t)cam * c->P);
-  if (out) return copy_level0_out(c, d, out);
+  render_lk_images(c, t_sync, cam ? 2 : 1);
+  if (out) return copy_level0_out(c, raw_ts_desc(c, cam), out);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->prof_on) resolve_profile(c);
   return 0;
@@ -1087,7 +1139,7 @@ int esvio_fe_sae_to_time_surface(esvio_fe_handle c, int cam, double t_sync, uint
 int esvio_fe_get_time_surface(esvio_fe_handle c, int cam, uint8_t* out) {
   if (!c || !out || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  return copy_level0_out(c, cam ? c->pyr[2].d : c->pyr[c->slot_curL].d, out);
+  return copy_level0_out(c, raw_ts_desc(c, cam), out);
 }
 
 int esvio_fe_export_image(esvio_fe_handle c, int cam, uint8_t* dst, int space) {

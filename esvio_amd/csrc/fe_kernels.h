@@ -38,6 +38,7 @@ enum KernelId {
   K_RADIX_PASS,
   K_SAE_APPLY,
   K_TIME_SURFACE,
+  K_CLAHE,
   K_PYR_DOWN,
   K_PYR_PAD,
   K_SCHARR,
@@ -77,6 +78,12 @@ void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals,
 void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
                          double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
                          int dst_stride, int ncam);
+
+// ---- CLAHE + normalize (equalize: 1) ---------------------------------------------------------
+// stage 0: per-tile LUTs, stage 1: LUT blending + min/max, stage 2: MINMAX normalisation in place
+void launch_clahe(hipStream_t s, const uint8_t* raw0, const uint8_t* raw1, int raw_stride,
+                  uint8_t* dst0, uint8_t* dst1, int dst_stride, int W, int H, uint8_t* lut,
+                  int* minmax, int nimg, int stage);
 
 // ---- pyramid ----------------------------------------------------------------------------
 void launch_pyr_down(hipStream_t s, const PyrDesc* p, int nimg, int src_level);

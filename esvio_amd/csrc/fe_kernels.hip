@@ -317,6 +317,167 @@ void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double 
                      t_sync, decay_sec, ignore_polarity, dst0, dst1, dst_stride);
 }
 
+// ============================================================================ CLAHE + normalize
+// cv::createCLAHE()->apply (clipLimit 40, 8x8 tiles) then cv::normalize(.,0,255,NORM_MINMAX) —
+// the `equalize: 1` branch of trackEvent (feature_tracker.cpp:375-382) [OpenCV imgproc/clahe.cpp,
+// core/norm.cpp].  One block per tile builds the clipped-histogram LUT; one thread per pixel blends
+// the four neighbouring LUTs and tracks the image min/max; a third pass rescales to 0..255.
+constexpr int kClaheTiles = 8;
+
+struct ClaheArgs {
+  const uint8_t* raw[2];  // pixel (0,0) of the raw time surfaces
+  int raw_stride;
+  uint8_t* dst[2];        // pixel (0,0) of the LK level-0 images
+  int dst_stride;
+  int W, H;
+  uint8_t* lut;           // [nimg][64][256]
+  int* minmax;            // [nimg][2]
+};
+
+__global__ __launch_bounds__(256) void k_clahe_lut(ClaheArgs a) {
+  __shared__ int hist[256];
+  __shared__ int part[4];
+  const int img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int W = a.W, H = a.H;
+  int EW = W, EH = H;
+  if (!(W % kClaheTiles == 0 && H % kClaheTiles == 0)) {
+    EW = W + (kClaheTiles - (W % kClaheTiles));
+    EH = H + (kClaheTiles - (H % kClaheTiles));
+  }
+  const int tw = EW / kClaheTiles, th = EH / kClaheTiles, area = tw * th;
+  const int ty = tile / kClaheTiles, tx = tile - ty * kClaheTiles;
+  hist[tid] = 0;
+  if (tile == 0 && tid == 0) {
+    a.minmax[2 * img] = 255;
+    a.minmax[2 * img + 1] = 0;
+  }
+  __syncthreads();
+  const uint8_t* src = a.raw[img];
+  for (int p = tid; p < area; p += 256) {
+    const int py = p / tw, px = p - py * tw;
+    const int y = reflect101(ty * th + py, H), x = reflect101(tx * tw + px, W);
+    atomicAdd(&hist[src[(size_t)y * a.raw_stride + x]], 1);
+  }
+  __syncthreads();
+  int clip = (int)(40.0 * area / 256);
+  clip = max(clip, 1);
+  int h = hist[tid];
+  int over = h > clip ? h - clip : 0;
+  h = min(h, clip);
+  int v = over;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((tid & 63) == 0) part[tid >> 6] = v;
+  __syncthreads();
+  const int clipped = part[0] + part[1] + part[2] + part[3];
+  const int redistBatch = clipped / 256;
+  const int residual = clipped - redistBatch * 256;
+  h += redistBatch;
+  if (residual != 0) {
+    const int step = max(256 / residual, 1);
+    if (tid % step == 0 && tid / step < residual) h++;
+  }
+  // inclusive scan over the 256 bins
+  int sum = h;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(sum, o);
+    if ((tid & 63) >= o) sum += t;
+  }
+  __syncthreads();
+  if ((tid & 63) == 63) part[tid >> 6] = sum;
+  __syncthreads();
+  for (int w = 0; w < (tid >> 6); w++) sum += part[w];
+  const float lutScale = (float)255 / (float)area;
+  const int r = __float2int_rn((float)sum * lutScale);
+  a.lut[((size_t)img * 64 + tile) * 256 + tid] = (uint8_t)((unsigned)r <= 255u ? r : r > 0 ? 255 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_clahe_interp(ClaheArgs a) {
+  const int img = blockIdx.y;
+  const int W = a.W, H = a.H;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int EW = W, EH = H;
+  if (!(W % kClaheTiles == 0 && H % kClaheTiles == 0)) {
+    EW = W + (kClaheTiles - (W % kClaheTiles));
+    EH = H + (kClaheTiles - (H % kClaheTiles));
+  }
+  const int tw = EW / kClaheTiles, th = EH / kClaheTiles;
+  int res8 = -1;
+  if (i < W * H) {
+    const int y = i / W, x = i - y * W;
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    const float tyf = y * inv_th - 0.5f;
+    const float fty = floorf(tyf);
+    int ty1 = (int)fty, ty2 = ty1 + 1;
+    const float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0);
+    ty2 = min(ty2, kClaheTiles - 1);
+    const float txf = x * inv_tw - 0.5f;
+    const float ftx = floorf(txf);
+    int tx1 = (int)ftx, tx2 = tx1 + 1;
+    const float xa = txf - tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0);
+    tx2 = min(tx2, kClaheTiles - 1);
+    const int v = a.raw[img][(size_t)y * a.raw_stride + x];
+    const uint8_t* lut = a.lut + (size_t)img * 64 * 256;
+    const float l11 = lut[(ty1 * 8 + tx1) * 256 + v], l12 = lut[(ty1 * 8 + tx2) * 256 + v];
+    const float l21 = lut[(ty2 * 8 + tx1) * 256 + v], l22 = lut[(ty2 * 8 + tx2) * 256 + v];
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    const int r = __float2int_rn(res);
+    res8 = (unsigned)r <= 255u ? r : r > 0 ? 255 : 0;
+    a.dst[img][(size_t)y * a.dst_stride + x] = (uint8_t)res8;
+  }
+  // block min/max -> one atomic pair per block
+  int mn = res8 < 0 ? 255 : res8, mx = res8 < 0 ? 0 : res8;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = min(mn, __shfl_xor(mn, o));
+    mx = max(mx, __shfl_xor(mx, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&a.minmax[2 * img], mn);
+    atomicMax(&a.minmax[2 * img + 1], mx);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_normalize(ClaheArgs a) {
+  const int img = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.W * a.H) return;
+  const double smin = a.minmax[2 * img], smax = a.minmax[2 * img + 1];
+  const double scale = 255.0 * (__dsub_rn(smax, smin) > 2.2204460492503131e-16 ? 1. / __dsub_rn(smax, smin) : 0);
+  const double shift = __dsub_rn(0.0, __dmul_rn(smin, scale));
+  const float fa = (float)scale, fb = (float)shift;
+  const int y = i / a.W, x = i - y * a.W;
+  uint8_t* p = a.dst[img] + (size_t)y * a.dst_stride + x;
+  const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)*p, fa), fb));
+  *p = (uint8_t)((unsigned)r <= 255u ? r : r > 0 ? 255 : 0);
+}
+
+void launch_clahe(hipStream_t s, const uint8_t* raw0, const uint8_t* raw1, int raw_stride,
+                  uint8_t* dst0, uint8_t* dst1, int dst_stride, int W, int H, uint8_t* lut,
+                  int* minmax, int nimg, int stage) {
+  ClaheArgs a;
+  a.raw[0] = raw0;
+  a.raw[1] = raw1;
+  a.raw_stride = raw_stride;
+  a.dst[0] = dst0;
+  a.dst[1] = dst1;
+  a.dst_stride = dst_stride;
+  a.W = W;
+  a.H = H;
+  a.lut = lut;
+  a.minmax = minmax;
+  const int nb = (W * H + 255) / 256;
+  if (stage == 0)
+    hipLaunchKernelGGL(k_clahe_lut, dim3(64, nimg), dim3(256), 0, s, a);
+  else if (stage == 1)
+    hipLaunchKernelGGL(k_clahe_interp, dim3(nb, nimg), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_normalize, dim3(nb, nimg), dim3(256), 0, s, a);
+}
+
 // ============================================================================ pyramid
 struct PyrPack {
   PyrDesc p[3];

@@ -59,7 +59,7 @@ typedef struct esvio_fe_config {
   int32_t max_cnt;                  /* max_cnt */
   int32_t min_dist;                 /* min_dist */
   int32_t flow_back;                /* flow_back */
-  int32_t equalize;                 /* equalize: must be 0 for now (CLAHE is §8f N2) */
+  int32_t equalize;                 /* equalize: 1 = CLAHE(40, 8x8) + normalize(0,255) before LK */
   double f_threshold;               /* F_threshold [px] */
   int32_t f_ransac;                 /* 1: run rejectWithF_event's RANSAC on host; 0: skip */
   int32_t lk_accum;                 /* reserved, must be 1 (exact integer LK sums) */
@@ -111,8 +111,9 @@ int esvio_fe_create_sae(esvio_fe_handle h, int cam, const esvio_fe_event* ev, si
 int esvio_fe_create_sae_stereo(esvio_fe_handle h, const esvio_fe_event* left, size_t nL,
                                const esvio_fe_event* right, size_t nR, int space,
                                uint64_t* n_rejected);
-/* SAEtoTimeSurface_left/right (event_detector.cc:230-305).  Renders into the handle's current
- * image of that camera; if out != NULL also copies the width*height u8 image to host. */
+/* SAEtoTimeSurface_left/right (event_detector.cc:230-305).  Renders the camera's time surface
+ * (and, with equalize, the CLAHE+normalize image trackEvent derives from it, feature_tracker.cpp:
+ * 375-382) into the handle; if out != NULL also copies the raw width*height u8 surface to host. */
 int esvio_fe_sae_to_time_surface(esvio_fe_handle h, int cam, double external_sync_time,
                                  uint8_t* out);
 /* isCorner (event_detector.cc:308-544) for n events against the LEFT planes; flags[i] in {0,1}

@@ -567,6 +567,95 @@ void calc_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const float
   lk_pyr(P, dP, N, prev_pts, next_pts, status, n, win, max_count, eps, flags, accum, P.levels);
 }
 
+// ---------------------------------------------------------------- CLAHE + normalize [OpenCV]
+// cv::createCLAHE() defaults: clipLimit 40.0, tileGridSize 8x8 (feature_tracker.cpp:377-379);
+// imgproc/src/clahe.cpp for CV_8UC1: per-tile clipped histogram -> LUT, bilinear LUT blending.
+void clahe_apply(const uint8_t* src, int W, int H, uint8_t* dst) {
+  const int tilesX = 8, tilesY = 8, histSize = 256;
+  const double clipLimitD = 40.0;
+  // extend with BORDER_REFLECT_101 when the size is not divisible by the grid
+  int EW = W, EH = H;
+  if (!(W % tilesX == 0 && H % tilesY == 0)) {
+    EW = W + (tilesX - (W % tilesX));
+    EH = H + (tilesY - (H % tilesY));
+  }
+  const int tw = EW / tilesX, th = EH / tilesY;
+  const int tileSizeTotal = tw * th;
+  const float lutScale = static_cast<float>(histSize - 1) / tileSizeTotal;
+  int clipLimit = static_cast<int>(clipLimitD * tileSizeTotal / histSize);
+  clipLimit = std::max(clipLimit, 1);
+  std::vector<uint8_t> lut((size_t)tilesX * tilesY * histSize);
+  for (int k = 0; k < tilesX * tilesY; k++) {  // CLAHE_CalcLut_Body
+    const int ty = k / tilesX, tx = k % tilesX;
+    int tileHist[256] = {0};
+    for (int y = ty * th; y < (ty + 1) * th; y++)
+      for (int x = tx * tw; x < (tx + 1) * tw; x++)
+        tileHist[src[(size_t)reflect101(y, H) * W + reflect101(x, W)]]++;
+    int clipped = 0;
+    for (int i = 0; i < histSize; ++i) {
+      if (tileHist[i] > clipLimit) {
+        clipped += tileHist[i] - clipLimit;
+        tileHist[i] = clipLimit;
+      }
+    }
+    int redistBatch = clipped / histSize;
+    int residual = clipped - redistBatch * histSize;
+    for (int i = 0; i < histSize; ++i) tileHist[i] += redistBatch;
+    if (residual != 0) {
+      int residualStep = std::max(histSize / residual, 1);
+      for (int i = 0; i < histSize && residual > 0; i += residualStep, residual--) tileHist[i]++;
+    }
+    int sum = 0;
+    uint8_t* tileLut = &lut[(size_t)k * histSize];
+    for (int i = 0; i < histSize; ++i) {
+      sum += tileHist[i];
+      tileLut[i] = saturate_u8(cv_round_f(sum * lutScale));
+    }
+  }
+  // CLAHE_Interpolation_Body
+  const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+  for (int y = 0; y < H; y++) {
+    float tyf = y * inv_th - 0.5f;
+    int ty1 = cv_floor_f(tyf);
+    int ty2 = ty1 + 1;
+    float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = std::max(ty1, 0);
+    ty2 = std::min(ty2, tilesY - 1);
+    const uint8_t* lutPlane1 = &lut[(size_t)ty1 * tilesX * histSize];
+    const uint8_t* lutPlane2 = &lut[(size_t)ty2 * tilesX * histSize];
+    for (int x = 0; x < W; x++) {
+      float txf = x * inv_tw - 0.5f;
+      int tx1 = cv_floor_f(txf);
+      int tx2 = tx1 + 1;
+      float xa = txf - tx1, xa1 = 1.0f - xa;
+      tx1 = std::max(tx1, 0);
+      tx2 = std::min(tx2, tilesX - 1);
+      int srcVal = src[(size_t)y * W + x];
+      int ind1 = tx1 * histSize + srcVal;
+      int ind2 = tx2 * histSize + srcVal;
+      float res = (lutPlane1[ind1] * xa1 + lutPlane1[ind2] * xa) * ya1 +
+                  (lutPlane2[ind1] * xa1 + lutPlane2[ind2] * xa) * ya;
+      dst[(size_t)y * W + x] = saturate_u8(cv_round_f(res));
+    }
+  }
+}
+
+// cv::normalize(img, img, 0, 255, NORM_MINMAX) on CV_8U (core/src/norm.cpp + convertTo 8u->8u with
+// float scale/shift, unfused multiply-add — the SSE2 baseline of convert_scale)
+void normalize_minmax_u8(uint8_t* img, size_t n) {
+  if (!n) return;
+  int mn = 255, mx = 0;
+  for (size_t i = 0; i < n; i++) {
+    mn = std::min(mn, (int)img[i]);
+    mx = std::max(mx, (int)img[i]);
+  }
+  const double smin = mn, smax = mx, dmin = 0, dmax = 255;
+  const double scale = (dmax - dmin) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
+  const double shift = dmin - smin * scale;
+  const float a = (float)scale, b = (float)shift;
+  for (size_t i = 0; i < n; i++) img[i] = saturate_u8(cv_round_f(img[i] * a + b));
+}
+
 // ---------------------------------------------------------------- camera
 // PinholeCamera::liftProjective (camera_model/src/camera_models/PinholeCamera.cc:450-510),
 // distortion (:646-662), m_inv_K* (:824-827)
@@ -1142,10 +1231,17 @@ int track_event(Tracker* t, double _cur_time, const oracle_event* left, size_t n
   auto t2 = clk::now();
   t->stage_s[0] += secs(t0, t1);
   t->stage_s[1] += secs(t1, t2);
-  if (c.equalize) return -2;  // CLAHE+normalize (:375-382) not restated yet
-
-  const std::vector<uint8_t>& img_left = t->ts_left;
-  const std::vector<uint8_t>& img_right = t->ts_right;
+  std::vector<uint8_t> eq_left, eq_right;
+  if (c.equalize) {  // :375-382: CLAHE then normalize(0,255,MINMAX); detection keeps the raw surface
+    eq_left.resize((size_t)W * H);
+    eq_right.resize((size_t)W * H);
+    clahe_apply(t->ts_left.data(), W, H, eq_left.data());
+    clahe_apply(t->ts_right.data(), W, H, eq_right.data());
+    normalize_minmax_u8(eq_left.data(), eq_left.size());
+    normalize_minmax_u8(eq_right.data(), eq_right.size());
+  }
+  const std::vector<uint8_t>& img_left = c.equalize ? eq_left : t->ts_left;
+  const std::vector<uint8_t>& img_right = c.equalize ? eq_right : t->ts_right;
   if (t->cur_img_left.empty()) {  // :390-395
     t->prev_img_left = t->cur_img_left = img_left;
   } else {
@@ -1351,6 +1447,8 @@ void oracle_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const flo
   calc_lk(prev, next, w, h, prev_pts, next_pts, status, n, win, max_level, max_count, eps, flags,
           accum);
 }
+void oracle_clahe(const uint8_t* src, int w, int h, uint8_t* dst) { clahe_apply(src, w, h, dst); }
+void oracle_normalize_minmax(uint8_t* img, size_t n) { normalize_minmax_u8(img, n); }
 void oracle_lift_projective(const oracle_camera* cam, double u, double v, double* out3) {
   lift_projective(cam, u, v, out3);
 }

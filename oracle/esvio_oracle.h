@@ -49,7 +49,7 @@ typedef struct {
   int32_t max_cnt;                   /* MAX_CNT */
   int32_t min_dist;                  /* MIN_DIST */
   int32_t flow_back;                 /* FLOW_BACK */
-  int32_t equalize;                  /* EQUALIZE (must be 0: CLAHE not restated yet) */
+  int32_t equalize;                  /* EQUALIZE: CLAHE + normalize before LK */
   double f_threshold;                /* F_THRESHOLD */
   int32_t f_ransac;                  /* 0: skip rejectWithF_event; 1: restated RANSAC */
   int32_t lk_accum;                  /* 0: float scalar-order sums; 1: exact int64 sums */
@@ -100,6 +100,11 @@ int oracle_pyr_levels(int w, int h, int win, int max_level);
 void oracle_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const float* prev_pts,
                float* next_pts, uint8_t* status, int n, int win, int max_level, int max_count,
                double eps, int flags, int accum);
+
+/* cv::createCLAHE()->apply (clip 40, 8x8 tiles) and cv::normalize(.,0,255,NORM_MINMAX) on u8
+ * (feature_tracker.cpp:377-381) */
+void oracle_clahe(const uint8_t* src, int w, int h, uint8_t* dst);
+void oracle_normalize_minmax(uint8_t* img, size_t n);
 
 /* ------------------------------------------------------------------ camera */
 void oracle_lift_projective(const oracle_camera* cam, double u, double v, double* out3);

@@ -83,6 +83,8 @@ def lib():
         L.oracle_pyr_levels.argtypes = [i, i, i, i]
         L.oracle_lk.argtypes = [vp, vp, i, i, vp, vp, vp, i, i, i, i, d, i, i]
         L.oracle_lift_projective.argtypes = [C.POINTER(Camera), d, d, vp]
+        L.oracle_clahe.argtypes = [vp, i, i, vp]
+        L.oracle_normalize_minmax.argtypes = [vp, sz]
         L.oracle_find_fundamental_ransac.restype = i
         L.oracle_find_fundamental_ransac.argtypes = [vp, vp, i, d, d, vp, vp]
         L.oracle_tracker_create.restype = vp
@@ -236,6 +238,20 @@ def lk(prev, nxt, prev_pts, next_pts=None, win=21, max_level=3, max_count=30, ep
     lib().oracle_lk(_p(prev), _p(nxt), w, h, _p(prev_pts), _p(next_pts), _p(status), n, win,
                     max_level, max_count, eps, flags, accum)
     return next_pts, status
+
+
+def clahe(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().oracle_clahe(_p(img), w, h, _p(out))
+    return out
+
+
+def normalize_minmax(img):
+    out = np.ascontiguousarray(img, np.uint8).copy()
+    lib().oracle_normalize_minmax(_p(out), out.size)
+    return out
 
 
 def lift_projective(cam, u, v):

@@ -417,3 +417,25 @@ def test_ransac_rng_and_inliers(oracle):
     cnt, status, _ = oracle.find_fundamental(p1[30:42], p2[30:42], 1.0, 0.99)
     assert cnt >= 10
     assert oracle.find_fundamental(p1[:6], p2[:6])[0] == 0
+
+
+# ------------------------------------------------------------------ CLAHE / normalize [OpenCV]
+def test_clahe_hand_cases(oracle):
+    # flat 64x64 image of value 77: tiles are 8x8 = 64 px, clipLimit = max(int(40*64/256),1) = 10;
+    # hist[77] = 64 -> clipped 54, redistBatch 0, residual 54, step 256/54 = 4: bins 0,4,..,212 get +1.
+    # LUT[77] = (#bins {0,4,..,76} = 20) + 10 = 30 -> 30*255/64 = 119.53 -> 120 everywhere.
+    flat = np.full((64, 64), 77, np.uint8)
+    assert (oracle.clahe(flat) == 120).all()
+    # MINMAX normalize of a flat image: scale 0 -> everything 0; otherwise min->0, max->255
+    assert (oracle.normalize_minmax(flat) == 0).all()
+    img = np.array([[10, 20], [30, 110]], np.uint8)
+    assert oracle.normalize_minmax(img).tolist() == [[0, 26], [51, 255]]  # 2.55*(v-10), half-even
+    # two-level image: the LUT is monotone, so order is preserved and the output spans more range
+    rng = np.random.default_rng(0)
+    img = np.where(rng.random((480, 640)) < 0.5, 100, 140).astype(np.uint8)
+    out = oracle.clahe(img)
+    assert out[img == 100].max() < out[img == 140].min()
+    assert int(out.max()) - int(out.min()) > 40
+    # sizes not divisible by 8 take the REFLECT_101 extension path and keep the shape
+    odd = rng.integers(0, 256, (260, 346), dtype=np.uint8)
+    assert oracle.clahe(odd).shape == (260, 346)

@@ -211,3 +211,48 @@ def test_track_event_end_to_end(oracle):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (f, k, np.abs(a - b).max())
     assert len(ft.ids) > 100 and len(ft.ids_right) > 50 and ft.track_cnt.max() >= 4
     ft.close()
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (346, 260)])
+def test_equalize_clahe_normalize(oracle, W, H):
+    """equalize: 1 (config/esio_DSEC/esio.yaml:90): CLAHE(40, 8x8) + normalize(0,255,MINMAX) of the
+    time surface is what LK sees (feature_tracker.cpp:375-382); 346x260 exercises the
+    BORDER_REFLECT_101 extension for sizes not divisible by the 8x8 grid."""
+    s = SceneStream(W, H, rate=2e6 if W > 400 else 6e5, seed=4, n_rect=14)
+    ft = FE.FeatureTracker(FE.make_config(W, H, equalize=1))
+    det = oracle.Detector(W, H)
+    for b in range(2):
+        L, R, _ = s.next_batch()
+        ft.detector.createSAE_stereo(L, R)
+        det.create_sae(0, L)
+        det.create_sae(1, R)
+        t = event_times(L)[-1]
+        for cam, f in ((0, ft.detector.SAEtoTimeSurface_left), (1, ft.detector.SAEtoTimeSurface_right)):
+            raw = f(t)
+            assert np.array_equal(raw, det.time_surface(cam, t))      # the function returns the RAW surface
+            eq = ft.export_image(cam)                                  # what LK will see
+            assert np.array_equal(eq, oracle.normalize_minmax(oracle.clahe(raw))), (b, cam)
+    ft.close()
+
+
+def test_track_event_end_to_end_equalize(oracle):
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=5e6, seed=2)
+    kw = dict(f_ransac=1, equalize=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(8):
+        L, R, _ = s.next_batch()
+        pub = (f % 3) != 2
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pub)
+        r = tr.track_event(t, L, R, pub)
+        assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))  # raw surfaces
+        assert np.array_equal(ft.ids, r.ids), f
+        assert np.array_equal(ft.track_cnt, r.track_cnt) and np.array_equal(ft.ids_right, r.ids_right)
+        for k in ("cur_pts", "cur_un_pts", "pts_velocity", "cur_right_pts", "cur_un_right_pts",
+                  "right_pts_velocity"):
+            a, b = getattr(ft, k), getattr(r, k)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (f, k)
+    assert len(ft.ids) > 100 and len(ft.ids_right) > 50
+    ft.close()
