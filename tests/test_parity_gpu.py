@@ -256,3 +256,91 @@ def test_track_event_end_to_end_equalize(oracle):
             assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (f, k)
     assert len(ft.ids) > 100 and len(ft.ids_right) > 50
     ft.close()
+
+
+def _compare_tracks(ft, r, tag, id_offset=0):
+    assert np.array_equal(ft.ids, r.ids + id_offset), tag
+    assert np.array_equal(ft.track_cnt, r.track_cnt) and np.array_equal(ft.ids_right, r.ids_right + id_offset), tag
+    for k in ("cur_pts", "cur_un_pts", "pts_velocity", "cur_right_pts", "cur_un_right_pts",
+              "right_pts_velocity"):
+        a, b = getattr(ft, k), getattr(r, k)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (tag, k)
+
+
+def test_empty_right_batches_reset_and_capacity_growth(oracle):
+    """right batch may be empty (node:150 only guards the left one); buffers grow when a later batch
+    is larger; esvio_fe_reset (node:163-173) behaves like a fresh tracker except that ids keep
+    counting (n_id is a static in the reference, feature_tracker.cpp:9)."""
+    W, H = 346, 260
+    kw = dict(max_cnt=80, min_dist=10, f_ransac=1)
+    small = SceneStream(W, H, rate=2e5, seed=21, n_rect=8, size=(30.0, 80.0))
+    big = SceneStream(W, H, rate=3e6, seed=22, n_rect=12, size=(30.0, 80.0), t0_us=2_000_000_000)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    empty = np.zeros(0, EVENT_DTYPE)
+    for f in range(4):  # tiny batches, right camera silent on odd frames
+        L, R, _ = small.next_batch()
+        if f % 2:
+            R = empty
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, True)
+        _compare_tracks(ft, tr.track_event(t, L, R, True), ("small", f))
+    ft.reset()
+    n_before = int(ft.ids.max()) + 1 if len(ft.ids) else 0
+    tr2 = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(4):  # 15x larger batches after the reset: every device buffer is re-grown
+        L, R, _ = big.next_batch()
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, f != 2)
+        r = tr2.track_event(t, L, R, f != 2)
+        off = int(ft.ids.min() - r.ids.min()) if len(r.ids) else 0
+        assert off >= n_before or f > 0
+        _compare_tracks(ft, r, ("big", f), id_offset=off)
+        assert np.array_equal(ft.gettimesurface(1), tr2.time_surface(1))
+    assert len(ft.ids) > 40
+    ft.close()
+
+
+def test_sae_time_surface_1280x720(oracle):
+    """largest BASELINE resolution (C5): 21-bit keys (3 x 7-bit passes), ~0.9 M events per camera"""
+    W, H = 1280, 720
+    rng = np.random.default_rng(99)
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    t0 = 3_000_000_000
+    for b in range(2):
+        n = 900_000
+        L = uniform_batch(W, H, n, t0 + b * 33333, 33333, rng)
+        R = uniform_batch(W, H, n // 3, t0 + b * 33333, 33333, rng)
+        # concentrate a third of the left events on a 40x40 patch: long same-pixel segments
+        L["x"][::3] = 600 + (L["x"][::3] % 40)
+        L["y"][::3] = 300 + (L["y"][::3] % 40)
+        assert ft.detector.createSAE_stereo(L, R) == 0
+        det.create_sae(0, L)
+        det.create_sae(1, R)
+        for cam in (0, 1):
+            _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+        t = event_times(L)[-1]
+        assert np.array_equal(ft.detector.SAEtoTimeSurface_left(t), det.time_surface(0, t))
+    ft.close()
+
+
+def test_selection_large_radius(oracle):
+    """min_dist 40 (> 31: two disc rows per lane in k_select) and a tiny max_cnt"""
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=2e6, seed=8)
+    ft = FE.FeatureTracker(FE.make_config(W, H, min_dist=40, max_cnt=25))
+    det = oracle.Detector(W, H, min_dist=40)
+    for b in range(2):
+        L, R, _ = s.next_batch()
+        ft.detector.createSAE_stereo(L, R)
+        det.create_sae(0, L)
+        t = event_times(L)[-1]
+        ts = ft.detector.SAEtoTimeSurface_left(t)
+        assert np.array_equal(ft.detector.isCorner(L), det.corner_flags(L))
+        for maxc in (5, 25):
+            xy_g, idx_g = ft.Event_FeaturesToTrack(L, maxc, None)
+            xy_c, idx_c = det.features_to_track(L, maxc, 40, np.zeros((H, W), np.uint8), ts)
+            assert np.array_equal(idx_g, idx_c) and np.array_equal(xy_g, xy_c)
+            assert len(idx_g) >= 3
+    ft.close()
