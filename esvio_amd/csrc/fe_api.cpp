@@ -21,6 +21,7 @@
 #include "../../include/esvio_fe.h"
 #include "fe_host.h"
 #include "fe_kernels.h"
+#include "fe_mc.h"
 
 using namespace esvio;
 
@@ -337,8 +338,43 @@ void pyr_build(esvio_fe_ctx* c, const PyrDesc* p, int nimg) {
 }
 
 // ---------------------------------------------------------------- SAE update (both cameras)
+// Motion_correction_value -> kernel parameters; first_left_host: left.events[0] (host copy)
+McParams make_mc_params(const esvio_fe_motion* m, const esvio_fe_event& first_left) {
+  McParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.enabled = 1;
+  p.t0 = (double)first_left.sec + 1e-9 * (double)first_left.nsec;  // ros::Time::toSec()
+  p.dt_batch = m->t1 - p.t0;
+  const double an = std::sqrt(std::pow((double)m->accel[0], 2) + std::pow((double)m->accel[1], 2) +
+                              std::pow((double)m->accel[2], 2));
+  p.active = an > 5;  // a_motion_compensation_threshold (event_detector.h:51)
+  for (int i = 0; i < 3; i++) {
+    p.vsum[i] = (float)m->v[i] + m->v_pre[i];
+    p.omega[i] = m->omega[i];
+  }
+  M3f K;
+  std::memset(&K, 0, sizeof(K));
+  K.m[0][0] = (float)m->fx;
+  K.m[0][2] = (float)m->cx;
+  K.m[1][1] = (float)m->fy;
+  K.m[1][2] = (float)m->cy;
+  K.m[2][2] = 1.f;
+  p.K = K;
+  p.Kinv = mc_inverse(K);
+  return p;
+}
+
+int first_event_host(esvio_fe_ctx* c, const esvio_fe_event* left, int space, esvio_fe_event* out) {
+  if (space == ESVIO_FE_HOST) {
+    *out = left[0];
+    return 0;
+  }
+  HIPCHK(c, hipMemcpy(out, left, sizeof(*out), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR,
-               uint32_t nR) {
+               uint32_t nR, const McParams* mc = nullptr) {
   const uint32_t n = nL + nR;
   if (!n) return 0;
   if (int rc = ensure_sort_capacity(c, n)) return rc;
@@ -353,7 +389,7 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
   {
     ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);
     launch_sae_keys(c->stream, evL, nL, evR, nR, c->W, c->H, c->keys[0], c->vals[0], c->invalid_key,
-                    c->d_rejected, passes, bits, ghist, lookback, lb_words);
+                    c->d_rejected, passes, bits, ghist, lookback, lb_words, mc);
   }
   int cur = 0;
   for (int p = 0; p < passes; p++) {
@@ -753,7 +789,8 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool 
 
 // ---------------------------------------------------------------- trackEvent
 int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* left, size_t nL,
-                     const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME) {
+                     const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME,
+                     const esvio_fe_motion* motion = nullptr) {
   const esvio_fe_config& cfg = c->cfg;
   const int M = cfg.max_cnt;
   Pin pin = pin_of(c);
@@ -769,8 +806,15 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
 
   const EventRec *dL = nullptr, *dR = nullptr;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
-  // createSAE_left / createSAE_right loops (:356-362)
-  if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) return rc;
+  // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
+  if (motion) {
+    esvio_fe_event first;
+    if (int rc = first_event_host(c, left, space, &first)) return rc;
+    const McParams mc = make_mc_params(motion, first);
+    if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
+  } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) {
+    return rc;
+  }
 
   // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; prev/cur slot rotation
   // replaces the cv::Mat header swaps of :390-403,:585.
@@ -1119,6 +1163,26 @@ int esvio_fe_create_sae_stereo(esvio_fe_handle c, const esvio_fe_event* left, si
   return 0;
 }
 
+int esvio_fe_create_sae_stereo_mc(esvio_fe_handle c, const esvio_fe_event* left, size_t nL,
+                                  const esvio_fe_event* right, size_t nR, int space,
+                                  const esvio_fe_motion* motion, uint64_t* n_rejected) {
+  if (!c || !motion || !nL || !left || (nR && !right)) return ESVIO_FE_EINVAL;
+  if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  HIPCHK(c, hipSetDevice(c->dev));
+  esvio_fe_event first;
+  if (int rc = first_event_host(c, left, space, &first)) return rc;
+  const McParams mc = make_mc_params(motion, first);
+  const EventRec *dL, *dR;
+  if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->stream));
+  if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
+  unsigned long long rej = 0;
+  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_rejected) *n_rejected = rej;
+  return 0;
+}
+
 int esvio_fe_create_sae(esvio_fe_handle c, int cam, const esvio_fe_event* ev, size_t n, int space,
                         uint64_t* n_rejected) {
   if (cam == 0) return esvio_fe_create_sae_stereo(c, ev, n, nullptr, 0, space, n_rejected);
@@ -1334,15 +1398,16 @@ int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, dou
   return 0;
 }
 
-int esvio_fe_track_event(esvio_fe_handle c, double cur_time, const esvio_fe_event* left, size_t nL,
-                         const esvio_fe_event* right, size_t nR, int space, int pub_this_frame,
-                         esvio_fe_tracks* out) {
+static int track_event_entry(esvio_fe_handle c, double cur_time, const esvio_fe_event* left,
+                             size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                             int pub_this_frame, const esvio_fe_motion* motion,
+                             esvio_fe_tracks* out) {
   if (!c) return ESVIO_FE_EINVAL;
   if (nL == 0 || !left) return fail(c, ESVIO_FE_EINVAL, "left batch must not be empty (node:150)");
   if (nR && !right) return ESVIO_FE_EINVAL;
   if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
   HIPCHK(c, hipSetDevice(c->dev));
-  if (int rc = track_event_impl(c, cur_time, left, nL, right, nR, space, pub_this_frame != 0))
+  if (int rc = track_event_impl(c, cur_time, left, nL, right, nR, space, pub_this_frame != 0, motion))
     return rc;
   if (out) {
     out->n_left = (int32_t)c->ids.size();
@@ -1360,6 +1425,20 @@ int esvio_fe_track_event(esvio_fe_handle c, double cur_time, const esvio_fe_even
       std::memcpy(out->right_pts_velocity, c->right_pts_velocity.data(), nr * 8);
   }
   return 0;
+}
+
+int esvio_fe_track_event(esvio_fe_handle c, double cur_time, const esvio_fe_event* left, size_t nL,
+                         const esvio_fe_event* right, size_t nR, int space, int pub_this_frame,
+                         esvio_fe_tracks* out) {
+  return track_event_entry(c, cur_time, left, nL, right, nR, space, pub_this_frame, nullptr, out);
+}
+
+int esvio_fe_track_event_mc(esvio_fe_handle c, double cur_time, const esvio_fe_event* left,
+                            size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                            int pub_this_frame, const esvio_fe_motion* motion,
+                            esvio_fe_tracks* out) {
+  if (!motion) return ESVIO_FE_EINVAL;
+  return track_event_entry(c, cur_time, left, nL, right, nR, space, pub_this_frame, motion, out);
 }
 
 int esvio_fe_set_profiling(esvio_fe_handle c, int on) {

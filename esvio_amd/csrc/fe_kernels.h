@@ -61,7 +61,8 @@ inline uint32_t radix_blocks(uint32_t n) { return (n + kRadixTile - 1) / kRadixT
 void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR,
                      uint32_t nR, int W, int H, uint32_t* keys, uint32_t* vals,
                      uint32_t invalid_key, unsigned long long* n_rejected, int passes, int bits,
-                     uint32_t* ghist, uint32_t* lookback, uint32_t lookback_words);
+                     uint32_t* ghist, uint32_t* lookback, uint32_t lookback_words,
+                     const struct McParams* mc /* NULL: no motion compensation */);
 // one stable LSD pass on digit (key >> shift) & ((1<<bits)-1) with decoupled look-back
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
                        int shift, int bits, const uint32_t* ghist, uint32_t* lookback,

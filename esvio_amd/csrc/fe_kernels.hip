@@ -6,6 +6,7 @@
 // latency-bound).  Reference semantics are cited per kernel (paths relative to the reference
 // tree); OpenCV-internal arithmetic is marked [OpenCV].
 #include "fe_kernels.h"
+#include "fe_mc.h"
 
 namespace esvio {
 
@@ -27,6 +28,7 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // Coalesced 16 B/lane read of the raw AoS stream; one u32 key + one u32 index out per event.
 // Also: per-pass global digit histograms of the keys (LDS pre-aggregation, one global atomic per
 // non-empty bin per block) and clearing of the look-back words the sort passes use.
+template <bool MC>
 __global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL, uint32_t nL,
                                                   const uint4* __restrict__ evR, uint32_t nR,
                                                   int W, int H, uint32_t* __restrict__ keys,
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL,
                                                   unsigned long long* n_rejected, int passes,
                                                   int bits, uint32_t* __restrict__ ghist,
                                                   uint32_t* __restrict__ lookback,
-                                                  uint32_t lookback_words) {
+                                                  uint32_t lookback_words, McParams mc) {
   __shared__ uint32_t h[kRadixMaxPasses << kRadixMaxBits];
   const int bins = 1 << bits;
   for (int i = threadIdx.x; i < passes * bins; i += 256) h[i] = 0;
@@ -45,8 +47,19 @@ __global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL,
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const bool right = i >= nL;
     const uint4 e = right ? evR[i - nL] : evL[i];
-    const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
+    uint32_t x = e.x & 0xffffu, y = e.x >> 16;
     const bool ok = x < (uint32_t)W && y < (uint32_t)H;
+    if (MC && ok) {
+      // trackEvent's per-event gate (feature_tracker.cpp:627-641) + createSAE_* with
+      // Motion_correction_value (event_detector.cc:102-147): the event is written at the warped pixel
+      const double et = ev_time(e.y, e.z);
+      if (mc.dt_batch > 0 && (et - mc.t0) / mc.dt_batch < 1 && mc.active) {
+        int ox, oy;
+        mc_warp(mc, W, H, (int)x, (int)y, et - mc.t0, &ox, &oy);
+        x = (uint32_t)ox;
+        y = (uint32_t)oy;
+      }
+    }
     const uint32_t key = ok ? (right ? P : 0u) + y * (uint32_t)W + x : invalid_key;
     keys[i] = key;
     vals[i] = i;
@@ -64,15 +77,23 @@ __global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL,
 void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR,
                      uint32_t nR, int W, int H, uint32_t* keys, uint32_t* vals,
                      uint32_t invalid_key, unsigned long long* n_rejected, int passes, int bits,
-                     uint32_t* ghist, uint32_t* lookback, uint32_t lookback_words) {
+                     uint32_t* ghist, uint32_t* lookback, uint32_t lookback_words,
+                     const McParams* mc) {
   const uint32_t n = nL + nR;
   if (!n) return;
   uint32_t grid = (n + 1023) / 1024;  // ~4 events per thread: keeps the global atomics few
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_sae_keys, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
-                     (const uint4*)evR, nR, W, H, keys, vals, invalid_key, n_rejected, passes, bits,
-                     ghist, lookback, lookback_words);
+  McParams m = McParams();  // value-initialised: enabled = 0
+  if (mc) m = *mc;
+  if (m.enabled)
+    hipLaunchKernelGGL(k_sae_keys<true>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
+                       (const uint4*)evR, nR, W, H, keys, vals, invalid_key, n_rejected, passes, bits,
+                       ghist, lookback, lookback_words, m);
+  else
+    hipLaunchKernelGGL(k_sae_keys<false>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
+                       (const uint4*)evR, nR, W, H, keys, vals, invalid_key, n_rejected, passes, bits,
+                       ghist, lookback, lookback_words, m);
 }
 
 // ============================================================================ stable radix sort

@@ -42,6 +42,25 @@ class Config(C.Structure):
     ]
 
 
+class Motion(C.Structure):
+    """esvio_fe_motion: the Motion_correction_value fields createSAE_* reads + detector.init's K"""
+    _fields_ = [("t1", C.c_double), ("v", C.c_double * 3), ("v_pre", C.c_float * 3),
+                ("accel", C.c_float * 3), ("omega", C.c_float * 3),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+
+def make_motion(t1, v, v_pre, accel, omega, fx, fy, cx, cy):
+    m = Motion()
+    m.t1 = float(t1)
+    for i in range(3):
+        m.v[i] = float(v[i])
+        m.v_pre[i] = float(v_pre[i])
+        m.accel[i] = float(accel[i])
+        m.omega[i] = float(omega[i])
+    m.fx, m.fy, m.cx, m.cy = float(fx), float(fy), float(cx), float(cy)
+    return m
+
+
 class Tracks(C.Structure):
     _fields_ = [
         ("n_left", C.c_int32), ("n_right", C.c_int32),
@@ -59,7 +78,8 @@ ABI_SYMBOLS = [
     "esvio_fe_sae_to_time_surface", "esvio_fe_is_corner", "esvio_fe_features_to_track",
     "esvio_fe_get_sae", "esvio_fe_set_sae", "esvio_fe_calc_optical_flow_pyr_lk",
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
-    "esvio_fe_track_event", "esvio_fe_get_time_surface", "esvio_fe_export_image",
+    "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
+    "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
     "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
@@ -103,6 +123,10 @@ def load_library(build_if_missing=True):
     L.esvio_fe_find_fundamental_mat.argtypes = [vp, vp, i, d, d, vp, C.POINTER(C.c_int32)]
     L.esvio_fe_lift_projective.argtypes = [C.POINTER(Camera), d, d, vp]
     L.esvio_fe_track_event.argtypes = [vp, d, vp, sz, vp, sz, i, i, C.POINTER(Tracks)]
+    L.esvio_fe_track_event_mc.argtypes = [vp, d, vp, sz, vp, sz, i, i, C.POINTER(Motion),
+                                          C.POINTER(Tracks)]
+    L.esvio_fe_create_sae_stereo_mc.argtypes = [vp, vp, sz, vp, sz, i, C.POINTER(Motion),
+                                                C.POINTER(C.c_uint64)]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
     L.esvio_fe_export_image.argtypes = [vp, i, vp, i]
     L.esvio_fe_import_image.argtypes = [vp, i, vp, i]
@@ -217,6 +241,16 @@ class EventDetector:
                                                              C.byref(rej)))
         return rej.value
 
+    def createSAE_stereo_mc(self, left, right, motion):
+        """createSAE_left/right(et, ex, ey, ep, measurements) loops (feature_tracker.cpp:627-641)"""
+        pl, nl, sl, k1 = _events_arg(left)
+        pr, nr, sr, k2 = _events_arg(right)
+        assert sl == sr
+        rej = C.c_uint64(0)
+        self._hd.check(self._hd.L.esvio_fe_create_sae_stereo_mc(self._hd.h, pl, nl, pr, nr, sl,
+                                                                C.byref(motion), C.byref(rej)))
+        return rej.value
+
     def SAEtoTimeSurface_left(self, external_sync_time):
         return self._ts(0, external_sync_time)
 
@@ -269,12 +303,20 @@ class FeatureTracker:
     def close(self):
         self._hd.close()
 
-    def trackEvent(self, cur_time, event_left, event_right, PUB_THIS_FRAME=True, copy=True):
+    def trackEvent(self, cur_time, event_left, event_right, PUB_THIS_FRAME=True, copy=True,
+                   measurements=None):
+        """both overloads of FeatureTracker::trackEvent (feature_tracker.h:51-52); `measurements`
+        is an esvio_fe_motion (frontend.make_motion) for the motion-compensated one"""
         pl, nl, sl, k1 = _events_arg(event_left)
         pr, nr, sr, k2 = _events_arg(event_right)
         assert sl == sr
-        self._hd.check(self._hd.L.esvio_fe_track_event(self._hd.h, float(cur_time), pl, nl, pr, nr,
-                                                       sl, int(PUB_THIS_FRAME), C.byref(self._tr)))
+        if measurements is None:
+            self._hd.check(self._hd.L.esvio_fe_track_event(
+                self._hd.h, float(cur_time), pl, nl, pr, nr, sl, int(PUB_THIS_FRAME), C.byref(self._tr)))
+        else:
+            self._hd.check(self._hd.L.esvio_fe_track_event_mc(
+                self._hd.h, float(cur_time), pl, nl, pr, nr, sl, int(PUB_THIS_FRAME),
+                C.byref(measurements), C.byref(self._tr)))
         nl_, nr_ = self._tr.n_left, self._tr.n_right
         for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"):
             v = self._bufs[k][:nl_]

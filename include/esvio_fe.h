@@ -162,6 +162,32 @@ int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, dou
 int esvio_fe_track_event(esvio_fe_handle h, double cur_time, const esvio_fe_event* left,
                          size_t nL, const esvio_fe_event* right, size_t nR, int space,
                          int pub_this_frame, esvio_fe_tracks* out);
+/* The fields of Motion_correction_value (event_detector.h:16) that createSAE_left/right with
+ * motion compensation read (event_detector.cc:102-147,168-210), as handle_stereo_event fills them
+ * (stereo_event_tracker_node.cpp:192-254), plus the K that detector.init(COL,ROW,fx,fy,cx,cy)
+ * receives (feature_tracker.cpp:616; the fx,fy,cx,cy globals of parameters.cpp:222-225). */
+typedef struct esvio_fe_motion {
+  double t1;       /* event_left.header.stamp.toSec() (feature_tracker.cpp:622) */
+  double v[3];     /* State_[0..2]: current linear velocity (node:215-217) */
+  float v_pre[3];  /* previous velocity (node:220-222) */
+  float accel[3];  /* temp_a (node:230-232); the warp is applied when |accel| > 5 m/s^2 */
+  float omega[3];  /* IMU angular velocity (node:244-246) */
+  double fx, fy, cx, cy;
+} esvio_fe_motion;
+
+/* FeatureTracker::trackEvent(cur_time, event_left, event_right, measurements)
+ * (feature_tracker.cpp:605-877, configs with Do_motion_correction: 1): events of the first part of
+ * the batch are warped to the batch start before the SAE update; everything else as
+ * esvio_fe_track_event. */
+int esvio_fe_track_event_mc(esvio_fe_handle h, double cur_time, const esvio_fe_event* left,
+                            size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                            int pub_this_frame, const esvio_fe_motion* motion,
+                            esvio_fe_tracks* out);
+/* the createSAE_left/right(…, measurements) loops alone (feature_tracker.cpp:627-641) */
+int esvio_fe_create_sae_stereo_mc(esvio_fe_handle h, const esvio_fe_event* left, size_t nL,
+                                  const esvio_fe_event* right, size_t nR, int space,
+                                  const esvio_fe_motion* motion, uint64_t* n_rejected);
+
 /* FeatureTracker::gettimesurface() tap (feature_tracker.cpp:894): current left/right image */
 int esvio_fe_get_time_surface(esvio_fe_handle h, int cam, uint8_t* out);
 

@@ -203,6 +203,187 @@ bool is_corner(const Detector* d, double et, int ex, int ey, bool ep) {
   return arc_ring<20>(d->sae[0][pol], d->W, ex, ey, kLargeCircle, 5, 8);
 }
 
+// ---------------------------------------------------------------- IMU motion compensation
+// EventDetector::motioncorrection (event_detector.cc:547-591) and the 5-argument createSAE_*
+// (:102-147, :168-210).  All matrix arithmetic is Eigen single precision; the evaluation order of
+// Eigen's fixed-size 3x3 kernels is restated as recalled [upstream-Eigen 3.3, recalled — unpinned]:
+// coefficient-based products with the 3-term reduction a0 + (a1 + a2), the cofactor inverse,
+// MatrixBase::exp() = Pade 3/5/7 + partial-pivot LU solve + squarings (unsupported/MatrixFunctions).
+struct Mat3f {
+  float m[3][3];
+};
+inline float red3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+inline Mat3f m3_mul(const Mat3f& A, const Mat3f& B) {
+  Mat3f C;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      C.m[i][j] = red3(A.m[i][0] * B.m[0][j], A.m[i][1] * B.m[1][j], A.m[i][2] * B.m[2][j]);
+  return C;
+}
+inline Mat3f m3_identity() {
+  Mat3f I = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
+  return I;
+}
+inline Mat3f m3_transpose(const Mat3f& A) {
+  Mat3f T;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) T.m[i][j] = A.m[j][i];
+  return T;
+}
+// Eigen compute_inverse<.,.,3>: cofactors of column 0, det = sum(cof0 .* col0), rest * invdet
+inline float cof3(const Mat3f& M, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return M.m[i1][j1] * M.m[i2][j2] - M.m[i1][j2] * M.m[i2][j1];
+}
+inline Mat3f m3_inverse(const Mat3f& M) {
+  const float c0 = cof3(M, 0, 0), c1 = cof3(M, 1, 0), c2 = cof3(M, 2, 0);
+  const float det = red3(c0 * M.m[0][0], c1 * M.m[1][0], c2 * M.m[2][0]);
+  const float invdet = 1.0f / det;
+  Mat3f R;
+  R.m[0][0] = c0 * invdet;
+  R.m[0][1] = c1 * invdet;
+  R.m[0][2] = c2 * invdet;
+  R.m[1][0] = cof3(M, 0, 1) * invdet;
+  R.m[1][1] = cof3(M, 1, 1) * invdet;
+  R.m[1][2] = cof3(M, 2, 1) * invdet;
+  R.m[2][0] = cof3(M, 0, 2) * invdet;
+  R.m[2][1] = cof3(M, 1, 2) * invdet;
+  R.m[2][2] = cof3(M, 2, 2) * invdet;
+  return R;
+}
+// denom.partialPivLu().solve(numer), 3x3: unblocked LU with row pivoting, then the matrix-RHS
+// triangular solves (axpy order, upper solve multiplies by the reciprocal diagonal)
+inline Mat3f m3_lu_solve(Mat3f LU, Mat3f X) {
+  for (int k = 0; k < 3; k++) {
+    int piv = k;
+    float best = std::fabs(LU.m[k][k]);
+    for (int i = k + 1; i < 3; i++)
+      if (std::fabs(LU.m[i][k]) > best) {
+        best = std::fabs(LU.m[i][k]);
+        piv = i;
+      }
+    if (piv != k)
+      for (int j = 0; j < 3; j++) {
+        std::swap(LU.m[k][j], LU.m[piv][j]);
+        std::swap(X.m[k][j], X.m[piv][j]);
+      }
+    if (best != 0.0f)
+      for (int i = k + 1; i < 3; i++) LU.m[i][k] /= LU.m[k][k];
+    for (int i = k + 1; i < 3; i++)
+      for (int j = k + 1; j < 3; j++) LU.m[i][j] -= LU.m[i][k] * LU.m[k][j];
+  }
+  for (int c = 0; c < 3; c++) {  // unit lower, then upper
+    for (int k = 0; k < 3; k++)
+      for (int i = k + 1; i < 3; i++) X.m[i][c] -= X.m[k][c] * LU.m[i][k];
+    for (int k = 2; k >= 0; k--) {
+      const float a = 1.0f / LU.m[k][k];
+      X.m[k][c] *= a;
+      for (int i = 0; i < k; i++) X.m[i][c] -= X.m[k][c] * LU.m[i][k];
+    }
+  }
+  return X;
+}
+inline Mat3f m3_lin(float a, const Mat3f& A, float b, const Mat3f& B) {  // a*A + b*B per coefficient
+  Mat3f C;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) C.m[i][j] = a * A.m[i][j] + b * B.m[i][j];
+  return C;
+}
+Mat3f m3_exp(const Mat3f& arg) {
+  float l1 = 0;
+  for (int j = 0; j < 3; j++) {
+    const float cs = red3(std::fabs(arg.m[0][j]), std::fabs(arg.m[1][j]), std::fabs(arg.m[2][j]));
+    if (j == 0 || cs > l1) l1 = cs;
+  }
+  const Mat3f I = m3_identity();
+  Mat3f U, V, A = arg;
+  int squarings = 0;
+  if (l1 < 4.258730016922831e-001f) {
+    const Mat3f A2 = m3_mul(A, A);
+    const Mat3f tmp = m3_lin(1.f, A2, 60.f, I);
+    U = m3_mul(A, tmp);
+    V = m3_lin(12.f, A2, 120.f, I);
+  } else if (l1 < 1.880152677804762e+000f) {
+    const Mat3f A2 = m3_mul(A, A), A4 = m3_mul(A2, A2);
+    Mat3f tmp, v;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        tmp.m[i][j] = (1.f * A4.m[i][j] + 420.f * A2.m[i][j]) + 15120.f * I.m[i][j];
+        v.m[i][j] = (30.f * A4.m[i][j] + 3360.f * A2.m[i][j]) + 30240.f * I.m[i][j];
+      }
+    U = m3_mul(A, tmp);
+    V = v;
+  } else {
+    const float maxnorm = 3.925724783138660f;
+    std::frexp(l1 / maxnorm, &squarings);
+    if (squarings < 0) squarings = 0;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) A.m[i][j] = std::ldexp(arg.m[i][j], -squarings);
+    const Mat3f A2 = m3_mul(A, A), A4 = m3_mul(A2, A2), A6 = m3_mul(A4, A2);
+    Mat3f tmp, v;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        tmp.m[i][j] = ((1.f * A6.m[i][j] + 1512.f * A4.m[i][j]) + 277200.f * A2.m[i][j]) +
+                      8648640.f * I.m[i][j];
+        v.m[i][j] = ((56.f * A6.m[i][j] + 25200.f * A4.m[i][j]) + 1995840.f * A2.m[i][j]) +
+                    17297280.f * I.m[i][j];
+      }
+    U = m3_mul(A, tmp);
+    V = v;
+  }
+  Mat3f numer, denom;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      numer.m[i][j] = U.m[i][j] + V.m[i][j];
+      denom.m[i][j] = -U.m[i][j] + V.m[i][j];
+    }
+  Mat3f R = m3_lu_solve(denom, numer);
+  for (int i = 0; i < squarings; i++) R = m3_mul(R, R);
+  return R;
+}
+
+struct MotionComp {  // what createSAE_* (5 args) reads from Motion_correction_value
+  double t0;         // first LEFT event time (feature_tracker.cpp:621)
+  double dt_batch;   // header stamp - t0 (:623)
+  bool active;       // |accel| > a_motion_compensation_threshold (event_detector.cc:125)
+  float v[3], v_pre[3], omega[3];
+  Mat3f K, Kinv;
+};
+
+// motioncorrection (event_detector.cc:547-591): returns the (possibly warped) pixel
+inline void motion_correct(const MotionComp& mc, int W, int H, int ex_i, int ey_i, double dt,
+                           int* ox, int* oy) {
+  const double ex = ex_i, ey = ey_i;
+  const int kBorder = 6;
+  *ox = ex_i;
+  *oy = ey_i;
+  if (ex > kBorder && ex <= (W - kBorder) && ey > kBorder && ey <= (H - kBorder)) {
+    const float fdt = (float)dt;  // Vector3f * double: the scalar is converted to float
+    const float rx = mc.omega[0] * fdt, ry = mc.omega[1] * fdt, rz = mc.omega[2] * fdt;
+    const Mat3f skew = {{{0, -rz, ry}, {rz, 0, -rx}, {-ry, rx, 0}}};
+    const Mat3f R = m3_exp(skew);
+    const Mat3f rot_K = m3_mul(m3_mul(mc.K, m3_transpose(R)), mc.Kinv);
+    const float h = (float)(0.5 * dt);
+    float tk[3];
+    for (int i = 0; i < 3; i++) tk[i] = h * (mc.v[i] + mc.v_pre[i]);
+    float kt[3], tr[3];
+    for (int i = 0; i < 3; i++)
+      kt[i] = red3(mc.Kinv.m[i][0] * tk[0], mc.Kinv.m[i][1] * tk[1], mc.Kinv.m[i][2] * tk[2]);
+    for (int i = 0; i < 3; i++)
+      tr[i] = red3((-rot_K.m[i][0]) * kt[0], (-rot_K.m[i][1]) * kt[1], (-rot_K.m[i][2]) * kt[2]);
+    float ev[3] = {(float)ex, (float)ey, 1.f}, w[3];
+    for (int i = 0; i < 3; i++)
+      w[i] = red3(rot_K.m[i][0] * ev[0], rot_K.m[i][1] * ev[1], rot_K.m[i][2] * ev[2]) + tr[i];
+    w[0] = w[0] / w[2];  // ConvertToHomogeneous (feature_tracker.h)
+    w[1] = w[1] / w[2];
+    const int xc = (int)std::floor(w[0]), yc = (int)std::floor(w[1]);
+    if (xc > 0 && xc < W - 1 && yc > 0 && yc < H - 1) {
+      *ox = xc;
+      *oy = yc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- cv::circle fill [OpenCV]
 // imgproc/src/drawing.cpp Circle(): midpoint circle with horizontal fills. Returns the union
 // half-width per |row offset| (hlines are centred, so the union is the max half-width).
@@ -1207,8 +1388,38 @@ inline double secs(clk::time_point a, clk::time_point b) {
 }
 
 // FeatureTracker::trackEvent (feature_tracker.cpp:340-603)
+MotionComp make_motion(const oracle_motion* m, const oracle_event* left) {
+  MotionComp mc;
+  mc.t0 = ev_time(left[0]);
+  mc.dt_batch = m->t1 - mc.t0;
+  const double an = std::sqrt(std::pow((double)m->accel[0], 2) + std::pow((double)m->accel[1], 2) +
+                              std::pow((double)m->accel[2], 2));
+  mc.active = an > 5;
+  for (int i = 0; i < 3; i++) {
+    mc.v[i] = (float)m->v[i];
+    mc.v_pre[i] = m->v_pre[i];
+    mc.omega[i] = m->omega[i];
+  }
+  const Mat3f K = {{{(float)m->fx, 0.f, (float)m->cx}, {0.f, (float)m->fy, (float)m->cy}, {0.f, 0.f, 1.f}}};
+  mc.K = K;
+  mc.Kinv = m3_inverse(K);
+  return mc;
+}
+
+// createSAE_left/right with Motion_correction_value (event_detector.cc:102-147,168-210) under the
+// per-event gate of trackEvent (feature_tracker.cpp:627-641)
+inline void create_sae_mc(Detector* d, int cam, const MotionComp& mc, const oracle_event& e) {
+  const double et = ev_time(e);
+  int ex = e.x, ey = e.y;
+  if (mc.dt_batch > 0 && (et - mc.t0) / mc.dt_batch < 1) {
+    if (mc.active) motion_correct(mc, d->W, d->H, ex, ey, et - mc.t0, &ex, &ey);
+  }
+  create_sae_one(d, cam, et, ex, ey, e.polarity != 0);
+}
+
 int track_event(Tracker* t, double _cur_time, const oracle_event* left, size_t nL,
-                const oracle_event* right, size_t nR, bool PUB_THIS_FRAME) {
+                const oracle_event* right, size_t nR, bool PUB_THIS_FRAME,
+                const oracle_motion* motion = nullptr) {
   const oracle_config& c = t->cfg;
   const int W = c.width, H = c.height, WIN = 21;
   t->cur_time = _cur_time;
@@ -1217,12 +1428,20 @@ int track_event(Tracker* t, double _cur_time, const oracle_event* left, size_t n
     t->det.reset();
   }
   auto t0 = clk::now();
-  for (size_t i = 0; i < nL; i++)  // :356-358
-    if (left[i].x < W && left[i].y < H)
-      create_sae_one(&t->det, 0, ev_time(left[i]), left[i].x, left[i].y, left[i].polarity != 0);
-  for (size_t i = 0; i < nR; i++)  // :360-362
-    if (right[i].x < W && right[i].y < H)
-      create_sae_one(&t->det, 1, ev_time(right[i]), right[i].x, right[i].y, right[i].polarity != 0);
+  if (motion) {  // overload with Motion_correction_value (:605-641)
+    const MotionComp mc = make_motion(motion, left);
+    for (size_t i = 0; i < nL; i++)
+      if (left[i].x < W && left[i].y < H) create_sae_mc(&t->det, 0, mc, left[i]);
+    for (size_t i = 0; i < nR; i++)
+      if (right[i].x < W && right[i].y < H) create_sae_mc(&t->det, 1, mc, right[i]);
+  } else {
+    for (size_t i = 0; i < nL; i++)  // :356-358
+      if (left[i].x < W && left[i].y < H)
+        create_sae_one(&t->det, 0, ev_time(left[i]), left[i].x, left[i].y, left[i].polarity != 0);
+    for (size_t i = 0; i < nR; i++)  // :360-362
+      if (right[i].x < W && right[i].y < H)
+        create_sae_one(&t->det, 1, ev_time(right[i]), right[i].x, right[i].y, right[i].polarity != 0);
+  }
   auto t1 = clk::now();
   t->ts_left.resize((size_t)W * H);
   t->ts_right.resize((size_t)W * H);
@@ -1472,13 +1691,7 @@ void* oracle_tracker_create(const oracle_config* cfg) {
 }
 void oracle_tracker_destroy(void* t) { delete (Tracker*)t; }
 
-int oracle_track_event(void* tv, double cur_time, const oracle_event* left, size_t nL,
-                       const oracle_event* right, size_t nR, int pub_this_frame,
-                       oracle_tracks* out) {
-  Tracker* t = (Tracker*)tv;
-  if (nL == 0) return -1;
-  int rc = track_event(t, cur_time, left, nL, right, nR, pub_this_frame != 0);
-  if (rc) return rc;
+static void fill_tracks(Tracker* t, oracle_tracks* out) {
   if (out) {
     out->n_left = (int32_t)t->ids.size();
     for (size_t i = 0; i < t->ids.size(); i++) {
@@ -1502,7 +1715,47 @@ int oracle_track_event(void* tv, double cur_time, const oracle_event* left, size
       out->right_pts_velocity[2 * i + 1] = t->right_pts_velocity[i].y;
     }
   }
+}
+
+int oracle_track_event(void* tv, double cur_time, const oracle_event* left, size_t nL,
+                       const oracle_event* right, size_t nR, int pub_this_frame,
+                       oracle_tracks* out) {
+  Tracker* t = (Tracker*)tv;
+  if (nL == 0) return -1;
+  int rc = track_event(t, cur_time, left, nL, right, nR, pub_this_frame != 0);
+  if (rc) return rc;
+  fill_tracks(t, out);
   return 0;
+}
+int oracle_track_event_mc(void* tv, double cur_time, const oracle_event* left, size_t nL,
+                          const oracle_event* right, size_t nR, int pub_this_frame,
+                          const oracle_motion* motion, oracle_tracks* out) {
+  Tracker* t = (Tracker*)tv;
+  if (nL == 0 || !motion) return -1;
+  int rc = track_event(t, cur_time, left, nL, right, nR, pub_this_frame != 0, motion);
+  if (rc) return rc;
+  fill_tracks(t, out);
+  return 0;
+}
+size_t oracle_create_sae_mc(void* dv, int cam, const oracle_event* ev, size_t n,
+                            const oracle_event* first_left, const oracle_motion* motion) {
+  Detector* d = (Detector*)dv;
+  const MotionComp mc = make_motion(motion, first_left);
+  size_t rejected = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (ev[i].x >= d->W || ev[i].y >= d->H) {
+      rejected++;
+      continue;
+    }
+    create_sae_mc(d, cam, mc, ev[i]);
+  }
+  return rejected;
+}
+void oracle_matrix_exp3f(const float* a9, float* out9) {
+  Mat3f A;
+  std::memcpy(A.m, a9, sizeof(A.m));
+  Mat3f R = m3_exp(A);
+  std::memcpy(out9, R.m, sizeof(R.m));
 }
 void oracle_tracker_time_surface(void* tv, int cam, uint8_t* out) {
   Tracker* t = (Tracker*)tv;

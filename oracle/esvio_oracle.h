@@ -115,6 +115,21 @@ void oracle_lift_projective(const oracle_camera* cam, double u, double v, double
 int oracle_find_fundamental_ransac(const float* p1, const float* p2, int n, double thr,
                                    double conf, uint8_t* status, double* F9);
 
+/* ------------------------------------------------------------------ motion compensation */
+/* the fields of Motion_correction_value that createSAE_* (5 args) reads
+ * (stereo_event_tracker_node.cpp:192-254, event_detector.cc:102-147) + detector.init's K */
+typedef struct {
+  double t1;          /* event_left.header.stamp (feature_tracker.cpp:622) */
+  double v[3];        /* State_[0..2] (node:215-217) */
+  float v_pre[3];     /* node:220-222 */
+  float accel[3];     /* temp_a (node:230-232): gates the warp at |a| > 5 */
+  float omega[3];     /* IMU angular velocity (node:244-246) */
+  double fx, fy, cx, cy; /* detector.init(COL,ROW,fx,fy,cx,cy) (feature_tracker.cpp:616) */
+} oracle_motion;
+size_t oracle_create_sae_mc(void* d, int cam, const oracle_event* ev, size_t n,
+                            const oracle_event* first_left, const oracle_motion* motion);
+void oracle_matrix_exp3f(const float* a9, float* out9);
+
 /* ------------------------------------------------------------------ tracker */
 typedef struct {
   int32_t n_left;
@@ -136,6 +151,10 @@ void oracle_tracker_destroy(void* t);
 int oracle_track_event(void* t, double cur_time, const oracle_event* left, size_t nL,
                        const oracle_event* right, size_t nR, int pub_this_frame,
                        oracle_tracks* out);
+/* trackEvent overload with Motion_correction_value (feature_tracker.cpp:605-877) */
+int oracle_track_event_mc(void* t, double cur_time, const oracle_event* left, size_t nL,
+                          const oracle_event* right, size_t nR, int pub_this_frame,
+                          const oracle_motion* motion, oracle_tracks* out);
 /* taps */
 void oracle_tracker_time_surface(void* t, int cam, uint8_t* out);
 void* oracle_tracker_detector(void* t);

@@ -42,6 +42,24 @@ class Config(C.Structure):
     ]
 
 
+class Motion(C.Structure):
+    _fields_ = [("t1", C.c_double), ("v", C.c_double * 3), ("v_pre", C.c_float * 3),
+                ("accel", C.c_float * 3), ("omega", C.c_float * 3),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+
+def make_motion(t1, v, v_pre, accel, omega, fx, fy, cx, cy):
+    m = Motion()
+    m.t1 = float(t1)
+    for i in range(3):
+        m.v[i] = float(v[i])
+        m.v_pre[i] = float(v_pre[i])
+        m.accel[i] = float(accel[i])
+        m.omega[i] = float(omega[i])
+    m.fx, m.fy, m.cx, m.cy = float(fx), float(fy), float(cx), float(cy)
+    return m
+
+
 class Tracks(C.Structure):
     _fields_ = [
         ("n_left", C.c_int32), ("n_right", C.c_int32),
@@ -92,6 +110,11 @@ def lib():
         L.oracle_tracker_destroy.argtypes = [vp]
         L.oracle_track_event.restype = i
         L.oracle_track_event.argtypes = [vp, d, vp, sz, vp, sz, i, C.POINTER(Tracks)]
+        L.oracle_track_event_mc.restype = i
+        L.oracle_track_event_mc.argtypes = [vp, d, vp, sz, vp, sz, i, C.POINTER(Motion), C.POINTER(Tracks)]
+        L.oracle_create_sae_mc.restype = sz
+        L.oracle_create_sae_mc.argtypes = [vp, i, vp, sz, vp, C.POINTER(Motion)]
+        L.oracle_matrix_exp3f.argtypes = [vp, vp]
         L.oracle_tracker_time_surface.argtypes = [vp, i, vp]
         L.oracle_tracker_detector.restype = vp
         L.oracle_tracker_detector.argtypes = [vp]
@@ -156,6 +179,12 @@ class Detector:
     def create_sae(self, cam, ev):
         ev = _ev(ev)
         return lib().oracle_create_sae(self.h, cam, _p(ev), ev.shape[0])
+
+    def create_sae_mc(self, cam, ev, first_left, motion):
+        ev = _ev(ev)
+        first_left = _ev(first_left)
+        return lib().oracle_create_sae_mc(self.h, cam, _p(ev), ev.shape[0], _p(first_left),
+                                          C.byref(motion))
 
     def time_surface(self, cam, t_sync):
         out = np.empty((self.H, self.W), np.uint8)
@@ -300,10 +329,15 @@ class Tracker:
             lib().oracle_tracker_destroy(self.h)
             self.h = None
 
-    def track_event(self, cur_time, left, right, pub_this_frame=True):
+    def track_event(self, cur_time, left, right, pub_this_frame=True, motion=None):
         left, right = _ev(left), _ev(right)
-        rc = lib().oracle_track_event(self.h, float(cur_time), _p(left), left.shape[0], _p(right),
-                                      right.shape[0], int(pub_this_frame), C.byref(self._tr))
+        if motion is None:
+            rc = lib().oracle_track_event(self.h, float(cur_time), _p(left), left.shape[0], _p(right),
+                                          right.shape[0], int(pub_this_frame), C.byref(self._tr))
+        else:
+            rc = lib().oracle_track_event_mc(self.h, float(cur_time), _p(left), left.shape[0],
+                                             _p(right), right.shape[0], int(pub_this_frame),
+                                             C.byref(motion), C.byref(self._tr))
         if rc:
             raise RuntimeError("oracle_track_event rc=%d" % rc)
         r = TrackResult()

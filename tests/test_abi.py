@@ -53,7 +53,7 @@ def test_create_fails_loudly_without_gpu(has_gpu):
 def test_create_rejects_bad_config():
     L = FE.load_library()
     h = C.c_void_p()
-    for kw, rc_expected in ((dict(min_dist=2), -1), (dict(equalize=1), -4),
+    for kw, rc_expected in ((dict(min_dist=2), -1), (dict(equalize=2), -1),
                             (dict(median_blur_kernel_size=1), -4), (dict(decay_ms=0.0), -1),
                             (dict(max_cnt=0), -1)):
         cfg = FE.make_config(640, 480, **kw)

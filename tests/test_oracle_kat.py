@@ -439,3 +439,49 @@ def test_clahe_hand_cases(oracle):
     # sizes not divisible by 8 take the REFLECT_101 extension path and keep the shape
     odd = rng.integers(0, 256, (260, 346), dtype=np.uint8)
     assert oracle.clahe(odd).shape == (260, 346)
+
+
+# ------------------------------------------------------------------ IMU motion compensation
+def test_matrix_exp_and_warp_known_answers(oracle):
+    """Matrix3f::exp() restatement against scipy's expm (all three Pade branches), and
+    motioncorrection (event_detector.cc:547-591) against a float64 re-derivation: pure rotation about
+    the optical axis by omega_z*dt moves a pixel on a circle around the principal point."""
+    import ctypes as C
+    from scipy.linalg import expm
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    for scale in (0.01, 0.3, 0.6, 1.5, 3.0, 8.0):
+        w = rng.normal(0, 1, 3)
+        w = w / np.linalg.norm(w) * scale
+        S = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], np.float32)
+        out = np.zeros((3, 3), np.float32)
+        L.oracle_matrix_exp3f(S.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert np.abs(out - expm(S.astype(np.float64))).max() < 2e-6 * max(1.0, scale)
+    # warp: one event late in the batch, rotation about z only, no translation
+    W, H = 640, 480
+    fx = fy = 500.0
+    cx, cy = 320.0, 240.0
+    t0_us, te_us = 10_000_000, 10_020_000          # dt_e = 20 ms
+    ev = _ev([100, 420], [100, 300], [t0_us, te_us], [1, 1])
+    wz = 2.0
+    m = oracle.make_motion(t1=10.03, v=(0, 0, 0), v_pre=(0, 0, 0), accel=(0, 0, 9.0), omega=(0, 0, wz),
+                           fx=fx, fy=fy, cx=cx, cy=cy)
+    d = oracle.Detector(W, H)
+    d.create_sae_mc(0, ev, ev[:1], m)
+    S1 = d.get_sae(0)[3]
+    ys, xs = np.nonzero(S1)
+    # expected: p' = K R^T K^-1 p with R = Rz(wz*dt)  (event warped back to t0)
+    a = wz * 0.02
+    Rt = np.array([[np.cos(a), np.sin(a), 0], [-np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    p = K @ Rt @ np.linalg.inv(K) @ np.array([420.0, 300.0, 1.0])
+    exp_xy = (int(np.floor(p[0] / p[2])), int(np.floor(p[1] / p[2])))
+    got = sorted(zip(xs.tolist(), ys.tolist()))
+    assert (100, 100) in got                      # dt_e = 0 for the first event: identity warp
+    assert exp_xy in got and exp_xy != (420, 300)
+    # |accel| <= 5: no warp at all
+    m2 = oracle.make_motion(t1=10.03, v=(0, 0, 0), v_pre=(0, 0, 0), accel=(0, 0, 4.9), omega=(0, 0, wz),
+                            fx=fx, fy=fy, cx=cx, cy=cy)
+    d2 = oracle.Detector(W, H)
+    d2.create_sae_mc(0, ev, ev[:1], m2)
+    assert d2.get_sae(0)[3][300, 420] > 0

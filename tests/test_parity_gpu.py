@@ -344,3 +344,62 @@ def test_selection_large_radius(oracle):
             assert np.array_equal(idx_g, idx_c) and np.array_equal(xy_g, xy_c)
             assert len(idx_g) >= 3
     ft.close()
+
+
+def _motion(mod, L, accel=(4.0, 5.0, 3.0), omega=(0.9, -1.4, 2.1), W=640, H=480, dt_frac=0.8):
+    """a Motion_correction_value as handle_stereo_event builds it (node:192-254); t1 (header stamp)
+    is placed inside the batch so that both the compensated and the plain branch are exercised"""
+    t = event_times(L)
+    t1 = t[0] + dt_frac * (t[-1] - t[0])
+    return mod.make_motion(t1, v=(0.8, -0.3, 0.2), v_pre=(0.7, -0.25, 0.15), accel=accel, omega=omega,
+                           fx=0.9 * W, fy=0.9 * W, cx=W / 2.0 + 3.5, cy=H / 2.0 - 2.25)
+
+
+def test_motion_compensated_sae(oracle):
+    """createSAE_left/right with Motion_correction_value (event_detector.cc:102-147,168-210) under
+    trackEvent's per-event gate (feature_tracker.cpp:627-641): planes bit-exact, incl. |a| <= 5
+    (no warp), large rotations (Pade-5 / Pade-7 branches of Matrix3f::exp) and border pixels."""
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=2e6, seed=31)
+    cases = [dict(), dict(accel=(1.0, 2.0, 3.0)), dict(omega=(9.0, -14.0, 21.0)),
+             dict(omega=(40.0, 35.0, -60.0)), dict(dt_frac=1.5), dict(dt_frac=-0.5)]
+    for ci, kw in enumerate(cases):
+        ft = _mk(W, H)
+        det = oracle.Detector(W, H)
+        plain = oracle.Detector(W, H)
+        moved = 0
+        for b in range(2):
+            L, R, _ = s.next_batch()
+            L["x"][:200] = np.arange(200) % 14            # border band: kBorder = 6
+            L["y"][200:400] = H - 1 - (np.arange(200) % 14)
+            mg, mo = _motion(FE, L, **kw), _motion(oracle, L, **kw)
+            assert ft.detector.createSAE_stereo_mc(L, R, mg) == 0
+            det.create_sae_mc(0, L, L[:1], mo)
+            det.create_sae_mc(1, R, L[:1], mo)
+            for cam in (0, 1):
+                _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+            plain.create_sae(0, L)
+            moved += int((plain.get_sae(0)[1] != det.get_sae(0)[1]).sum())
+        if ci in (0, 2, 3):
+            assert moved > 1000, (ci, moved)   # the warp really moves events
+        if ci in (1, 5):
+            assert moved == 0, (ci, moved)     # |a| <= 5 or dt <= 0: identical to the plain rule
+        ft.close()
+
+
+def test_track_event_motion_compensated_end_to_end(oracle):
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=5e6, seed=5)
+    ft = FE.FeatureTracker(FE.make_config(W, H))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1))
+    for f in range(6):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        om = (0.5 + 0.1 * f, -0.8, 1.2)
+        ft.trackEvent(t, L, R, f % 3 != 2, measurements=_motion(FE, L, omega=om))
+        r = tr.track_event(t, L, R, f % 3 != 2, motion=_motion(oracle, L, omega=om))
+        assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+        assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1))
+        _compare_tracks(ft, r, ("mc", f))
+    assert len(ft.ids) > 100
+    ft.close()
