@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=40, help="oracle frames for cpu_baseline (0=skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not announce the next batch (esvio_fe_set_next_batch): strictly one "
+                         "batch in flight, like the reference's depth-1 queues")
     ap.add_argument("--split", choices=["rigs", "camera"], default="rigs",
                     help="N>1 sharding: one independent stereo rig per GPU (weak scaling, default) or "
                          "BASELINE C4: left/right cameras of ONE rig on 2 GPUs")
@@ -132,6 +135,7 @@ def main():
             if world > 1 else None)
 
     rig = CameraSplitRig(ft, rank, dist, device=xdev) if cam_split else None
+    pipeline = not args.no_pipeline and not cam_split
 
     def step(i, exchange=True):
         tl, tr, nl, nr, t_last = dev_batches[i]
@@ -143,6 +147,9 @@ def main():
                 if exchange:
                     exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
             return nl if rank == 0 else nr
+        if pipeline and i + 1 < len(dev_batches):  # replay mode: the next batch is already in HBM
+            tl2, tr2, nl2, nr2, t2 = dev_batches[i + 1]
+            ft.set_next_batch(t2, (tl2.data_ptr(), nl2), (tr2.data_ptr(), nr2))
         ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
         if pub:
             fc.published()
@@ -262,6 +269,7 @@ def main():
                 "parallelism": ("left/right camera split, 1 rig on 2 GPUs" if cam_split else
                                 "1 rig per GPU") if world > 1 else "single GPU",
                 "tracks_last_frame": n_tracks,
+                "pipelined_next_batch": bool(pipeline),
             },
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -31,6 +31,31 @@ struct P2f {
   float x, y;
 };
 
+// std::map<int, cv::Point2f> as ptsVelocity uses it (insert-if-absent, find, empty, clear), kept as a
+// sorted flat vector: same semantics, no node allocations per frame
+struct IdMap {
+  std::vector<std::pair<int, P2f>> v;
+  bool empty() const { return v.empty(); }
+  void clear() { v.clear(); }
+  void swap(IdMap& o) { v.swap(o.v); }
+  void build(const std::vector<int>& ids, const std::vector<P2f>& pts) {
+    v.clear();
+    v.reserve(ids.size());
+    for (size_t i = 0; i < ids.size(); i++) v.emplace_back(ids[i], pts[i]);
+    std::stable_sort(v.begin(), v.end(),
+                     [](const std::pair<int, P2f>& a, const std::pair<int, P2f>& b) { return a.first < b.first; });
+    // map::insert keeps the first element of equal keys
+    v.erase(std::unique(v.begin(), v.end(),
+                        [](const std::pair<int, P2f>& a, const std::pair<int, P2f>& b) { return a.first == b.first; }),
+            v.end());
+  }
+  const P2f* find(int id) const {
+    auto it = std::lower_bound(v.begin(), v.end(), id,
+                               [](const std::pair<int, P2f>& a, int k) { return a.first < k; });
+    return (it != v.end() && it->first == id) ? &it->second : nullptr;
+  }
+};
+
 const char* const kKernelNames[K_COUNT] = {
     "k_sae_keys", "k_radix_pass", "k_sae_apply",
     "k_time_surface", "k_clahe", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select"};
@@ -70,7 +95,10 @@ struct PyrStore {
 struct esvio_fe_ctx {
   esvio_fe_config cfg{};
   int dev = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // main stream
+  hipStream_t stream2 = nullptr;  // prefetch stream (next batch's SAE update / images)
+  hipStream_t cur = nullptr;      // the stream the helpers currently enqueue on
+  hipEvent_t ev_planes_free = nullptr, ev_prefetch_done = nullptr;
   std::string err;
   int W = 0, H = 0;
   uint32_t P = 0;
@@ -86,13 +114,29 @@ struct esvio_fe_ctx {
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr;
   size_t sort_cap = 0, hist_cap = 0;
   unsigned long long* d_rejected = nullptr;
-  PyrStore pyr[3];  // two left slots (prev/cur alternate) + right
-  int slot_prevL = 0, slot_curL = 0;
+  PyrStore pyr[5];  // left: slots 0..2 rotate (prev, cur, being-prefetched); right: slots 3,4
+  int slot_prevL = 0, slot_curL = 0, slot_curR = 3;
   bool have_img = false;
   bool ext_right_pending = false;  // esvio_fe_import_image(cam=1) done for the next frame
+  // ---- next-batch prefetch (esvio_fe_set_next_batch)
+  bool nb_set = false, pf_valid = false;
+  const esvio_fe_event *nb_left = nullptr, *nb_right = nullptr;
+  size_t nb_nL = 0, nb_nR = 0;
+  int nb_space = 0;
+  double nb_time = 0;
+  int pf_slotL = 0, pf_slotR = 3, pf_raw = 0;
+  // identity of the batch whose SAE update / images were prefetched
+  const esvio_fe_event *pf_left = nullptr, *pf_right = nullptr;
+  size_t pf_nL = 0, pf_nR = 0;
+  int pf_space = 0;
+  double pf_time = 0;
+  EventRec* d_ev2 = nullptr;
+  size_t ev2_cap = 0;
+  const EventRec *pf_dL = nullptr, *pf_dR = nullptr;
   PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images
   // equalize: raw time surfaces (single padded level each, left/right) + CLAHE scratch
-  PyrStore raw[2];
+  PyrStore raw[2][2];  // [buffer][cam], double-buffered like the pyramids
+  int raw_cur = 0;
   uint8_t* d_lut = nullptr;
   int* d_minmax = nullptr;
   // LK point buffers (device), each max_cnt
@@ -125,7 +169,7 @@ struct esvio_fe_ctx {
   std::vector<P2f> cur_un_pts, cur_un_right_pts, pts_velocity, right_pts_velocity;
   std::vector<int> ids, ids_right, track_cnt, track_cnt_right;
   std::vector<int> src_idx;  // per cur_pts entry: index into the speculative stereo-LK results
-  std::map<int, P2f> cur_un_pts_map, prev_un_pts_map, cur_un_right_pts_map, prev_un_right_pts_map;
+  IdMap cur_un_pts_map, prev_un_pts_map, cur_un_right_pts_map, prev_un_right_pts_map;
   host::BitMask mask_event;
 
   // ---- host phase trace (ESVIO_FE_TRACE=1): stage, sae+ts enqueue, sync A, host A, enqueue B,
@@ -184,21 +228,27 @@ struct ScopedKernel {  // brackets one launch with HIP events on the handle's st
     if (c->prof_on) {
       a = get_event(c);
       b = get_event(c);
-      (void)hipEventRecord(a, c->stream);
+      (void)hipEventRecord(a, c->cur);
     }
   }
   ~ScopedKernel() {
     if (c->prof_on) {
-      (void)hipEventRecord(b, c->stream);
+      (void)hipEventRecord(b, c->cur);
       c->pending.push_back(ProfRec{id, a, b, bytes});
     }
   }
 };
 
-void resolve_profile(esvio_fe_ctx* c) {  // caller guarantees the stream is idle
+void resolve_profile(esvio_fe_ctx* c) {  // main stream idle; prefetch-stream records may be pending
+  std::vector<ProfRec> keep;
   for (auto& r : c->pending) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+    const hipError_t e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e == hipErrorNotReady) {
+      keep.push_back(r);
+      continue;
+    }
+    if (e == hipSuccess) {
       c->stats[r.id].ms += ms;
       c->stats[r.id].launches++;
       c->stats[r.id].bytes += r.bytes;
@@ -206,7 +256,8 @@ void resolve_profile(esvio_fe_ctx* c) {  // caller guarantees the stream is idle
     c->ev_pool.push_back(r.a);
     c->ev_pool.push_back(r.b);
   }
-  c->pending.clear();
+  c->pending.swap(keep);
+  (void)hipGetLastError();
 }
 
 // ---------------------------------------------------------------- memory
@@ -250,7 +301,7 @@ int ensure_sort_capacity(esvio_fe_ctx* c, size_t n) {
     c->hist = nullptr;
     c->hist_cap = 0;
     if (int rc = dev_alloc(c, &c->hist, hneed)) return rc;
-    HIPCHK(c, hipMemsetAsync(c->hist, 0, hneed * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->hist, 0, hneed * 4, c->cur));
     c->hist_cap = hneed;
   }
   return 0;
@@ -296,7 +347,7 @@ int pyr_alloc(esvio_fe_ctx* c, PyrStore& ps, int w, int h, int max_level) {
     lh = (lh + 1) / 2;
   }
   HIPCHK(c, hipMalloc(&ps.mem, off));
-  HIPCHK(c, hipMemsetAsync(ps.mem, 0, off, c->stream));  // derivative borders stay 0 forever
+  HIPCHK(c, hipMemsetAsync(ps.mem, 0, off, c->cur));  // derivative borders stay 0 forever
   for (int l = 0; l <= levels; l++) {
     ps.d.img[l] = (uint8_t*)ps.mem + img_off[l];
     ps.d.deriv[l] = (int16_t*)((uint8_t*)ps.mem + der_off[l]);
@@ -322,17 +373,17 @@ void pyr_build(esvio_fe_ctx* c, const PyrDesc* p, int nimg) {
   for (int l = 0; l < p[0].levels; l++) {
     uint64_t src = (uint64_t)p[0].w[l] * p[0].h[l], dst = (uint64_t)p[0].w[l + 1] * p[0].h[l + 1];
     ScopedKernel k(c, K_PYR_DOWN, (src + dst) * nimg);
-    launch_pyr_down(c->stream, p, nimg, l);
+    launch_pyr_down(c->cur, p, nimg, l);
   }
   {
     ScopedKernel k(c, K_PYR_PAD, 0);
-    launch_pyr_pad(c->stream, p, nimg);
+    launch_pyr_pad(c->cur, p, nimg);
   }
   {
     uint64_t all = 0;
     for (int l = 0; l <= p[0].levels; l++) all += (uint64_t)p[0].w[l] * p[0].h[l];
     ScopedKernel k(c, K_SCHARR, all * 5 * nimg);  // 1 B read + 4 B written per pixel
-    launch_scharr(c->stream, p, nimg);
+    launch_scharr(c->cur, p, nimg);
   }
   (void)px0;
 }
@@ -388,20 +439,20 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
   const uint32_t lb_words = (uint32_t)passes * (nblk << bits);
   {
     ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);
-    launch_sae_keys(c->stream, evL, nL, evR, nR, c->W, c->H, c->keys[0], c->vals[0], c->invalid_key,
+    launch_sae_keys(c->cur, evL, nL, evR, nR, c->W, c->H, c->keys[0], c->vals[0], c->invalid_key,
                     c->d_rejected, passes, bits, ghist, lookback, lb_words, mc);
   }
   int cur = 0;
   for (int p = 0; p < passes; p++) {
     ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 16);
-    launch_radix_pass(c->stream, c->keys[cur], c->vals[cur], n, p * bits, bits, ghist + ((size_t)p << bits),
+    launch_radix_pass(c->cur, c->keys[cur], c->vals[cur], n, p * bits, bits, ghist + ((size_t)p << bits),
                       lookback + (size_t)p * (nblk << bits), tickets + p, c->keys[cur ^ 1],
                       c->vals[cur ^ 1], c->d_counts + 3);
     cur ^= 1;
   }
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
-    launch_sae_apply(c->stream, c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
+    launch_sae_apply(c->cur, c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
                      c->cfg.feature_filter_threshold, c->invalid_key, c->hist, head);
   }
   return 0;
@@ -410,26 +461,34 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
 // stage host events into the handle's device buffer; returns device pointers
 int stage_events(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL,
                  const esvio_fe_event* right, size_t nR, int space, const EventRec** dL,
-                 const EventRec** dR) {
+                 const EventRec** dR, bool second_buffer = false) {
   if (space == ESVIO_FE_DEVICE) {
     *dL = (const EventRec*)left;
     *dR = (const EventRec*)right;
     return 0;
   }
   if (space != ESVIO_FE_HOST) return fail(c, ESVIO_FE_EINVAL, "bad memory space %d", space);
-  if (int rc = ensure_event_capacity(c, nL + nR)) return rc;
-  if (nL) HIPCHK(c, hipMemcpyAsync(c->d_ev, left, nL * 16, hipMemcpyHostToDevice, c->stream));
-  if (nR)
-    HIPCHK(c, hipMemcpyAsync(c->d_ev + nL, right, nR * 16, hipMemcpyHostToDevice, c->stream));
-  *dL = c->d_ev;
-  *dR = c->d_ev + nL;
+  EventRec** buf = second_buffer ? &c->d_ev2 : &c->d_ev;
+  size_t* cap = second_buffer ? &c->ev2_cap : &c->ev_cap;
+  if (nL + nR > *cap) {
+    const size_t ncap = std::max<size_t>(nL + nR + (nL + nR) / 4, 1 << 16);
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    if (int rc = dev_alloc(c, buf, ncap)) return rc;
+    *cap = ncap;
+  }
+  if (nL) HIPCHK(c, hipMemcpyAsync(*buf, left, nL * 16, hipMemcpyHostToDevice, c->cur));
+  if (nR) HIPCHK(c, hipMemcpyAsync(*buf + nL, right, nR * 16, hipMemcpyHostToDevice, c->cur));
+  *dL = *buf;
+  *dR = *buf + nL;
   return 0;
 }
 
 void render_ts(esvio_fe_ctx* c, double t_sync, uint8_t* dst0, uint8_t* dst1, int ncam,
                const double2* S2) {
   ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * ncam);
-  launch_time_surface(c->stream, S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
+  launch_time_surface(c->cur, S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
                       c->cfg.ignore_polarity, dst0, dst1, c->pyr[0].d.stride[0], ncam);
 }
 
@@ -438,17 +497,17 @@ inline uint8_t* px00(const PyrDesc& d) { return d.img[0] + (size_t)kPad * d.stri
 // the image trackEvent feeds to LK: the raw time surface, or CLAHE + normalize of it when
 // `equalize` (feature_tracker.cpp:375-387).  cams: bit 0 left, bit 1 right.  Raw surfaces stay
 // available for the TS_LK_THRESHOLD test and gettimesurface().
-void render_lk_images(esvio_fe_ctx* c, double t_sync, int cams) {
-  const PyrDesc& L = c->pyr[c->slot_curL].d;
-  const PyrDesc& R = c->pyr[2].d;
+void render_lk_images(esvio_fe_ctx* c, double t_sync, int cams, int slotL, int slotR, int rawbuf) {
+  const PyrDesc& L = c->pyr[slotL].d;
+  const PyrDesc& R = c->pyr[slotR].d;
   if (!c->cfg.equalize) {
     if (cams == 3) render_ts(c, t_sync, L.img[0], R.img[0], 2, c->S2);
     else if (cams == 1) render_ts(c, t_sync, L.img[0], L.img[0], 1, c->S2);
     else if (cams == 2) render_ts(c, t_sync, R.img[0], R.img[0], 1, c->S2 + c->P);
     return;
   }
-  const PyrDesc& rl = c->raw[0].d;
-  const PyrDesc& rr = c->raw[1].d;
+  const PyrDesc& rl = c->raw[rawbuf][0].d;
+  const PyrDesc& rr = c->raw[rawbuf][1].d;
   int nimg;
   const uint8_t *s0, *s1;
   uint8_t *d0, *d1;
@@ -464,14 +523,14 @@ void render_lk_images(esvio_fe_ctx* c, double t_sync, int cams) {
   }
   for (int stage = 0; stage < 3; stage++) {
     ScopedKernel k(c, K_CLAHE, stage == 0 ? (uint64_t)c->P * nimg : (uint64_t)c->P * 2 * nimg);
-    launch_clahe(c->stream, s0, s1, rl.stride[0], d0, d1, L.stride[0], c->W, c->H, c->d_lut,
+    launch_clahe(c->cur, s0, s1, rl.stride[0], d0, d1, L.stride[0], c->W, c->H, c->d_lut,
                  c->d_minmax, nimg, stage);
   }
 }
 
 const PyrDesc& raw_ts_desc(const esvio_fe_ctx* c, int cam) {
-  if (c->cfg.equalize) return c->raw[cam].d;
-  return cam ? c->pyr[2].d : c->pyr[c->slot_curL].d;
+  if (c->cfg.equalize) return c->raw[c->raw_cur][cam].d;
+  return cam ? c->pyr[c->slot_curR].d : c->pyr[c->slot_curL].d;
 }
 
 LkArgs make_lk(const PyrDesc& P, const PyrDesc& N, const float2* prev, const float2* init,
@@ -501,21 +560,21 @@ void run_lk(esvio_fe_ctx* c, const LkArgs& f, const LkArgs* b, float2* back_pts,
   uint64_t bytes = (uint64_t)f.n_max * (f.max_level + 1) * kLkWin * kLkWin * 5;
   if (b) bytes += (uint64_t)f.n_max * (b->max_level + 1) * kLkWin * kLkWin * 5;
   ScopedKernel k(c, K_LK, bytes);
-  launch_lk(c->stream, f, b, back_pts, back_status);
+  launch_lk(c->cur, f, b, back_pts, back_status);
 }
 
 int copy_level0_out(esvio_fe_ctx* c, const PyrDesc& d, uint8_t* out) {
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(out, d.w[0], d.img[0] + (size_t)kPad * stride + kPad, stride, d.w[0],
-                             d.h[0], hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+                             d.h[0], hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   return 0;
 }
 
 int copy_level0_in(esvio_fe_ctx* c, const PyrDesc& d, const uint8_t* in) {
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, in, d.w[0], d.w[0],
-                             d.h[0], hipMemcpyHostToDevice, c->stream));
+                             d.h[0], hipMemcpyHostToDevice, c->cur));
   return 0;
 }
 
@@ -585,22 +644,18 @@ std::vector<P2f> undistorted_pts(const std::vector<P2f>& pts, const esvio_fe_cam
 // ptsVelocity (:1004-1045) incl. its quirk: with no previous map the result is sized by the LEFT
 // cur_pts whichever camera it is called for.
 std::vector<P2f> pts_velocity_fn(esvio_fe_ctx* c, std::vector<int>& ids, std::vector<P2f>& pts,
-                                 std::map<int, P2f>& cur_id_pts, std::map<int, P2f>& prev_id_pts) {
+                                 IdMap& cur_id_pts, IdMap& prev_id_pts) {
   std::vector<P2f> vel;
-  cur_id_pts.clear();
-  for (unsigned int i = 0; i < ids.size(); i++) cur_id_pts.insert(std::make_pair(ids[i], pts[i]));
+  cur_id_pts.build(ids, pts);
   if (!prev_id_pts.empty()) {
     const double dt = c->cur_time - c->prev_time;
+    vel.reserve(pts.size());
     for (unsigned int i = 0; i < pts.size(); i++) {
-      if (ids[i] != -1) {
-        auto it = prev_id_pts.find(ids[i]);
-        if (it != prev_id_pts.end()) {
-          const double v_x = (pts[i].x - it->second.x) / dt;
-          const double v_y = (pts[i].y - it->second.y) / dt;
-          vel.push_back(P2f{(float)v_x, (float)v_y});
-        } else {
-          vel.push_back(P2f{0, 0});
-        }
+      const P2f* prev = ids[i] != -1 ? prev_id_pts.find(ids[i]) : nullptr;
+      if (prev) {
+        const double v_x = (pts[i].x - prev->x) / dt;
+        const double v_y = (pts[i].y - prev->y) / dt;
+        vel.push_back(P2f{(float)v_x, (float)v_y});
       } else {
         vel.push_back(P2f{0, 0});
       }
@@ -721,6 +776,8 @@ void clear_tracker_state(esvio_fe_ctx* c) {
   c->prev_un_right_pts_map.clear();
   c->have_img = false;
   c->slot_prevL = c->slot_curL = 0;
+  c->slot_curR = 3;
+  c->ext_right_pending = false;
   c->cur_time = c->prev_time = 0;
 }
 
@@ -754,12 +811,12 @@ void run_select(esvio_fe_ctx* c, uint32_t n_events, int max_corners, float2* out
   const uint32_t nblk = (n_events + kArcBlock - 1) / kArcBlock;
   {
     ScopedKernel k(c, K_COMPACT, 0);
-    launch_compact(c->stream, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, nblk, c->d_comp_xy,
+    launch_compact(c->cur, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, nblk, c->d_comp_xy,
                    c->d_comp_idx, (uint32_t*)(c->d_counts + 2));
   }
   SelectArgs s = make_select_args(c, max_corners, out_pts, out_base, out_idx);
   ScopedKernel k(c, K_SELECT, 0);
-  launch_select(c->stream, s, select_lds_bytes(c));
+  launch_select(c->cur, s, select_lds_bytes(c));
 }
 
 // Arc* flags (+ ordered per-block candidate lists) for the left events
@@ -784,7 +841,50 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool 
   a.cand_idx = want_cand ? c->d_cand_idx : nullptr;
   a.cand_cnt = want_cand ? c->d_cand_cnt : nullptr;
   ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
-  launch_arc(c->stream, a);
+  launch_arc(c->cur, a);
+}
+
+// ---------------------------------------------------------------- next-batch prefetch
+// Enqueue the SAE update, time surfaces and pyramids of the batch announced with
+// esvio_fe_set_next_batch on the second stream; they overlap the rest of the current frame (stereo
+// LK, selection) and the host work between calls.  Waits for ev_planes_free (recorded on the main
+// stream once the current frame has finished reading the SAE planes).
+int prefetch_next(esvio_fe_ctx* c) {
+  if (!c->nb_set || c->pf_valid) return 0;
+  int sl = 0;
+  while (sl == c->slot_prevL || sl == c->slot_curL) sl++;
+  c->pf_slotL = sl;
+  c->pf_slotR = c->slot_curR == 3 ? 4 : 3;
+  c->pf_raw = c->raw_cur ^ 1;
+  c->cur = c->stream2;
+  int rc = 0;
+  do {
+    if (hipStreamWaitEvent(c->stream2, c->ev_planes_free, 0) != hipSuccess) {
+      rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
+      break;
+    }
+    if ((rc = stage_events(c, c->nb_left, c->nb_nL, c->nb_right, c->nb_nR, c->nb_space, &c->pf_dL,
+                           &c->pf_dR, true)))
+      break;
+    if ((rc = sae_update(c, c->pf_dL, (uint32_t)c->nb_nL, c->pf_dR, (uint32_t)c->nb_nR))) break;
+    render_lk_images(c, c->nb_time, 3, c->pf_slotL, c->pf_slotR, c->pf_raw);
+    PyrDesc nxt[2] = {c->pyr[c->pf_slotL].d, c->pyr[c->pf_slotR].d};
+    pyr_build(c, nxt, 2);
+    if (hipEventRecord(c->ev_prefetch_done, c->stream2) != hipSuccess) {
+      rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
+      break;
+    }
+    c->pf_valid = true;
+    c->pf_left = c->nb_left;
+    c->pf_right = c->nb_right;
+    c->pf_nL = c->nb_nL;
+    c->pf_nR = c->nb_nR;
+    c->pf_space = c->nb_space;
+    c->pf_time = c->nb_time;
+    c->nb_set = false;
+  } while (0);
+  c->cur = c->stream;
+  return rc;
 }
 
 // ---------------------------------------------------------------- trackEvent
@@ -805,31 +905,59 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   };
 
   const EventRec *dL = nullptr, *dR = nullptr;
-  if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
-  // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
-  if (motion) {
-    esvio_fe_event first;
-    if (int rc = first_event_host(c, left, space, &first)) return rc;
-    const McParams mc = make_mc_params(motion, first);
-    if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
-  } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) {
-    return rc;
-  }
-
-  // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; prev/cur slot rotation
-  // replaces the cv::Mat header swaps of :390-403,:585.
   const bool first = !c->have_img;
-  c->slot_curL = first ? 0 : (c->slot_prevL ^ 1);
-  if (first) c->slot_prevL = 0;  // prev_img_left = cur_img_left = img_left (:391)
-  PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[2].d};
-  // camera split: the right image was imported from the GPU that owns the right camera
-  render_lk_images(c, c->cur_time, c->ext_right_pending ? 1 : 3);
-  c->ext_right_pending = false;
-  pyr_build(c, cur2, 2);
+  if (c->pf_valid) {
+    // this batch was announced with esvio_fe_set_next_batch and its SAE update, images and
+    // pyramids were enqueued on the prefetch stream during the previous call
+    if (left != c->pf_left || nL != c->pf_nL || right != c->pf_right || nR != c->pf_nR ||
+        space != c->pf_space || _cur_time != c->pf_time || motion)
+      return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
+    c->pf_valid = false;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prefetch_done, 0));
+    dL = c->pf_dL;
+    dR = c->pf_dR;
+    c->slot_curL = c->pf_slotL;
+    c->slot_curR = c->pf_slotR;
+    c->raw_cur = c->pf_raw;
+  } else {
+    if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
+    // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
+    if (motion) {
+      esvio_fe_event first_ev;
+      if (int rc = first_event_host(c, left, space, &first_ev)) return rc;
+      const McParams mc = make_mc_params(motion, first_ev);
+      if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
+    } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) {
+      return rc;
+    }
+    // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; slot rotation replaces the
+    // cv::Mat header swaps of :390-403,:585.  Left slots 0..2: {prev, cur, free}.
+    int sl = 0;
+    while (!first && (sl == c->slot_prevL || sl == c->slot_curL)) sl++;
+    c->slot_curL = sl;
+    // camera split: the right image was imported into slot_curR by esvio_fe_import_image
+    if (!c->ext_right_pending) c->slot_curR = c->slot_curR == 3 ? 4 : 3;
+    c->raw_cur ^= 1;
+    render_lk_images(c, c->cur_time, c->ext_right_pending ? 1 : 3, c->slot_curL, c->slot_curR,
+                     c->raw_cur);
+    c->ext_right_pending = false;
+    PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[c->slot_curR].d};
+    pyr_build(c, cur2, 2);
+  }
+  if (first) c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left = img_left (:391)
   c->have_img = true;
   const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
   const PyrDesc& curL = c->pyr[c->slot_curL].d;
-  const PyrDesc& curR = c->pyr[2].d;
+  const PyrDesc& curR = c->pyr[c->slot_curR].d;
+  bool planes_event_recorded = false;
+  // after this point of the main stream nothing of THIS frame reads the SAE planes or the raw
+  // time surfaces any more, so the next batch's update may start on the prefetch stream
+  auto planes_free = [&]() -> int {
+    if (planes_event_recorded || !c->nb_set) return 0;
+    planes_event_recorded = true;
+    HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
+    return 0;
+  };
 
   c->cur_pts.clear();
   c->cur_right_pts.clear();
@@ -838,7 +966,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   if (c->prev_pts.size() > 0) {  // :405-437
     const int n = (int)c->prev_pts.size();
     std::memcpy(pin.ptsA, c->prev_pts.data(), (size_t)n * 8);
-    HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, c->cur));
     // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
     // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
     LkArgs f = make_lk(prevL, curL, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n, 3, 30, 0.01, 0);
@@ -846,9 +974,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                        ESVIO_FE_LK_USE_INITIAL_FLOW);
     run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_temporal_bytes, hipMemcpyDeviceToHost,
-                             c->stream));
+                             c->cur));
     lap(1);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->cur));
     lap(2);
     std::vector<uint8_t> status(pin.stA, pin.stA + n);
     c->cur_pts.resize(n);
@@ -883,13 +1011,17 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   if (n_surv) {
     std::memcpy(pin.ptsA, c->cur_pts.data(), (size_t)n_surv * 8);
     HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n_surv * 8, hipMemcpyHostToDevice,
-                             c->stream));
+                             c->cur));
     LkArgs f = make_lk(curL, curR, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n_surv, 3, 30,
                        0.01, 0);
     LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
     run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
   }
 
+  if (!PUB_THIS_FRAME) {
+    if (int rc = planes_free()) return rc;
+    if (int rc = prefetch_next(c)) return rc;
+  }
   bool detect = false;
   int n_kept = n_surv;
   if (PUB_THIS_FRAME) {  // :442-469
@@ -903,8 +1035,10 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       if (int rc = ensure_arc_capacity(c, nL)) return rc;
       std::memcpy(pin.mask, c->mask_event.bits.data(), c->mask_event.bits.size() * 4);
       HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
-                               hipMemcpyHostToDevice, c->stream));
+                               hipMemcpyHostToDevice, c->cur));
       run_arc(c, dL, (uint32_t)nL, true, true, false, true);
+      if (int rc = planes_free()) return rc;
+      if (int rc = prefetch_next(c)) return rc;
       run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, 0, nullptr);
       // stereo LK of the new corners only (count known on the device)
       LkArgs f = make_lk(curL, curR, c->d_new, nullptr, c->d_ptsB2, c->d_stA2, c->d_counts, n_max_cnt,
@@ -914,10 +1048,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC2, c->d_stB2);
     }
   }
+  if (PUB_THIS_FRAME && !detect) {
+    if (int rc = planes_free()) return rc;
+    if (int rc = prefetch_next(c)) return rc;
+  }
   if (n_surv || detect)
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->cur));
   lap(5);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   lap(6);
   if ((n_surv || detect) && pin.counts[3] != 0)
     return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
@@ -1016,6 +1154,7 @@ const char* esvio_fe_last_error(esvio_fe_handle h) { return h ? h->err.c_str() :
 int esvio_fe_destroy(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   (void)hipSetDevice(c->dev);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->trace && c->phase_frames) {
     static const char* nm[8] = {"enqueue sae+ts+pyr", "enqueue temporal LK", "sync A", "host filter",
@@ -1030,8 +1169,9 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy,
                   c->d_comp_idx, c->d_mask_bits, c->d_sel_idx, c->pyr[0].mem, c->pyr[1].mem,
-                  c->pyr[2].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->raw[0].mem, c->raw[1].mem,
-                  c->d_lut, c->d_minmax};
+                  c->pyr[2].mem, c->pyr[3].mem, c->pyr[4].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem,
+                  c->raw[0][0].mem, c->raw[0][1].mem, c->raw[1][0].mem, c->raw[1][1].mem, c->d_lut,
+                  c->d_minmax, c->d_ev2};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -1040,6 +1180,12 @@ int esvio_fe_destroy(esvio_fe_handle c) {
     (void)hipEventDestroy(r.b);
   }
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->stream2) {
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamDestroy(c->stream2);
+  }
+  if (c->ev_planes_free) (void)hipEventDestroy(c->ev_planes_free);
+  if (c->ev_prefetch_done) (void)hipEventDestroy(c->ev_prefetch_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -1082,8 +1228,12 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     esvio_fe_destroy(c);
     return rc;
   };
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_prefetch_done, hipEventDisableTiming) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
+  c->cur = c->stream;
   const size_t M = cfg->max_cnt;
   int rc = 0;
   if ((rc = dev_alloc(c, &c->L2, (size_t)2 * c->P))) return bail(rc);
@@ -1109,22 +1259,22 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_sel_idx, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_mask_bits, (size_t)c->H * ((c->W + 31) / 32)))) return bail(rc);
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < 5; i++)
     if ((rc = pyr_alloc(c, c->pyr[i], c->W, c->H, 3))) return bail(rc);
   if (cfg->equalize) {
-    for (int i = 0; i < 2; i++)
-      if ((rc = pyr_alloc(c, c->raw[i], c->W, c->H, 0))) return bail(rc);
+    for (int i = 0; i < 4; i++)
+      if ((rc = pyr_alloc(c, c->raw[i / 2][i % 2], c->W, c->H, 0))) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_lut, (size_t)2 * 64 * 256))) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_minmax, 4))) return bail(rc);
   }
   c->h_pin_bytes = pin_bytes(*cfg);
   if (hipHostMalloc((void**)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
-  if (hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->stream) != hipSuccess ||
-      hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->stream) != hipSuccess ||
-      hipMemsetAsync(c->d_rejected, 0, 8, c->stream) != hipSuccess ||
-      hipMemsetAsync(c->d_counts, 0, 64, c->stream) != hipSuccess ||
-      hipStreamSynchronize(c->stream) != hipSuccess)
+  if (hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->cur) != hipSuccess ||
+      hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->cur) != hipSuccess ||
+      hipMemsetAsync(c->d_rejected, 0, 8, c->cur) != hipSuccess ||
+      hipMemsetAsync(c->d_counts, 0, 64, c->cur) != hipSuccess ||
+      hipStreamSynchronize(c->cur) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
   size_t lds = select_lds_bytes(c);
   if (lds > 160 * 1024) return bail(ESVIO_FE_EINVAL);
@@ -1135,9 +1285,11 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
 int esvio_fe_reset(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  c->nb_set = c->pf_valid = false;
+  HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->cur));
+  HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   clear_tracker_state(c);
   return 0;
 }
@@ -1147,16 +1299,17 @@ int esvio_fe_create_sae_stereo(esvio_fe_handle c, const esvio_fe_event* left, si
                                uint64_t* n_rejected) {
   if (!c || (nL && !left) || (nR && !right)) return ESVIO_FE_EINVAL;
   if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  if (c->pf_valid) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
   HIPCHK(c, hipSetDevice(c->dev));
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
-  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->cur));
   if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) return rc;
   unsigned long long rej = 0;
   int sort_err = 0;
-  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&sort_err, c->d_counts + 3, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipMemcpyAsync(&sort_err, c->d_counts + 3, 4, hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   if (sort_err) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
   if (n_rejected) *n_rejected = rej;
   if (c->prof_on) resolve_profile(c);
@@ -1174,11 +1327,11 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle c, const esvio_fe_event* left,
   const McParams mc = make_mc_params(motion, first);
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
-  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->cur));
   if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
   unsigned long long rej = 0;
-  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   if (n_rejected) *n_rejected = rej;
   return 0;
 }
@@ -1193,9 +1346,10 @@ int esvio_fe_create_sae(esvio_fe_handle c, int cam, const esvio_fe_event* ev, si
 int esvio_fe_sae_to_time_surface(esvio_fe_handle c, int cam, double t_sync, uint8_t* out) {
   if (!c || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  render_lk_images(c, t_sync, cam ? 2 : 1);
+  if (c->pf_valid) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
+  render_lk_images(c, t_sync, cam ? 2 : 1, c->slot_curL, c->slot_curR, c->raw_cur);
   if (out) return copy_level0_out(c, raw_ts_desc(c, cam), out);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -1210,12 +1364,12 @@ int esvio_fe_export_image(esvio_fe_handle c, int cam, uint8_t* dst, int space) {
   if (!c || !dst || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
   if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  const PyrDesc& d = cam ? c->pyr[2].d : c->pyr[c->slot_curL].d;
+  const PyrDesc& d = cam ? c->pyr[c->slot_curR].d : c->pyr[c->slot_curL].d;
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(dst, c->W, d.img[0] + (size_t)kPad * stride + kPad, stride, c->W, c->H,
                              space == ESVIO_FE_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
-                             c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+                             c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   return 0;
 }
 
@@ -1224,12 +1378,15 @@ int esvio_fe_import_image(esvio_fe_handle c, int cam, const uint8_t* src, int sp
   if (cam != 1) return fail(c, ESVIO_FE_EINVAL, "only the right camera's image can be imported");
   if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  const PyrDesc& d = c->pyr[2].d;
+  if (c->nb_set || c->pf_valid)
+    return fail(c, ESVIO_FE_EINVAL, "import_image cannot be combined with set_next_batch");
+  c->slot_curR = c->slot_curR == 3 ? 4 : 3;  // the slot the next trackEvent will use as curR
+  const PyrDesc& d = c->pyr[c->slot_curR].d;
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, src, c->W, c->W, c->H,
                              space == ESVIO_FE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                             c->stream));
-  if (space == ESVIO_FE_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse src
+                             c->cur));
+  if (space == ESVIO_FE_HOST) HIPCHK(c, hipStreamSynchronize(c->cur));  // caller may reuse src
   c->ext_right_pending = true;
   return 0;
 }
@@ -1243,8 +1400,8 @@ int esvio_fe_is_corner(esvio_fe_handle c, const esvio_fe_event* ev, size_t n, in
   if (int rc = stage_events(c, ev, n, nullptr, 0, space, &dL, &dR)) return rc;
   if (int rc = ensure_arc_capacity(c, n)) return rc;
   run_arc(c, dL, (uint32_t)n, false, false, true, false);
-  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, n, hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -1267,11 +1424,11 @@ int esvio_fe_features_to_track(esvio_fe_handle c, const esvio_fe_event* ev, size
   if (mask) bm.from_bytes(mask);
   std::memcpy(pin.mask, bm.bits.data(), bm.bits.size() * 4);
   HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, bm.bits.size() * 4, hipMemcpyHostToDevice,
-                           c->stream));
+                           c->cur));
   run_arc(c, dL, (uint32_t)n, true, true, false, true);
   run_select(c, (uint32_t)n, max_corners, c->d_ptsD, 0, c->d_sel_idx);
-  HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   const int k = pin.counts[0];
   if (k > 0) {
     HIPCHK(c, hipMemcpy(out_xy, c->d_ptsD, (size_t)k * 8, hipMemcpyDeviceToHost));
@@ -1298,7 +1455,7 @@ static int planes_io(esvio_fe_handle c, int cam, double* L0, double* L1, double*
     HIPCHK(c, hipMemcpy(c->L2 + (size_t)cam * c->P, l.data(), (size_t)c->P * 16, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->S2 + (size_t)cam * c->P, s.data(), (size_t)c->P * 16, hipMemcpyHostToDevice));
   } else {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->cur));
     HIPCHK(c, hipMemcpy(l.data(), c->L2 + (size_t)cam * c->P, (size_t)c->P * 16, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(s.data(), c->S2 + (size_t)cam * c->P, (size_t)c->P * 16, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < c->P; i++) {
@@ -1342,15 +1499,15 @@ int esvio_fe_calc_optical_flow_pyr_lk(esvio_fe_handle c, const uint8_t* prev_img
   if (int rc = prep_tmp_pyr(c, 1, next_img, w, hgt, max_level)) return rc;
   PyrDesc two[2] = {c->tmp_pyr[0].d, c->tmp_pyr[1].d};
   pyr_build(c, two, 2);
-  HIPCHK(c, hipMemcpyAsync(c->d_ptsA, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ptsA, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->cur));
   if (flags & ESVIO_FE_LK_USE_INITIAL_FLOW)
-    HIPCHK(c, hipMemcpyAsync(c->d_ptsB, next_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ptsB, next_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->cur));
   LkArgs f = make_lk(two[0], two[1], c->d_ptsA, c->d_ptsB, c->d_ptsB, c->d_stA, nullptr, n, max_level,
                      max_count, eps, flags);
   run_lk(c, f, nullptr, nullptr, nullptr);
-  HIPCHK(c, hipMemcpyAsync(next_pts, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(status, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(next_pts, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipMemcpyAsync(status, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -1366,7 +1523,7 @@ int esvio_fe_build_pyramid(esvio_fe_handle c, const uint8_t* img, int w, int hgt
   pyr_build(c, &d, 1);
   if (n_levels) *n_levels = d.levels + 1;
   if (level < 0 || level > d.levels) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->cur));
     return level < 0 ? 0 : ESVIO_FE_EINVAL;
   }
   if (lw) *lw = d.w[level];
@@ -1374,12 +1531,12 @@ int esvio_fe_build_pyramid(esvio_fe_handle c, const uint8_t* img, int w, int hgt
   const int stride = d.stride[level];
   if (out_img)
     HIPCHK(c, hipMemcpy2DAsync(out_img, d.w[level], d.img[level] + (size_t)kPad * stride + kPad,
-                               stride, d.w[level], d.h[level], hipMemcpyDeviceToHost, c->stream));
+                               stride, d.w[level], d.h[level], hipMemcpyDeviceToHost, c->cur));
   if (out_deriv)
     HIPCHK(c, hipMemcpy2DAsync(out_deriv, (size_t)d.w[level] * 4,
                                d.deriv[level] + ((size_t)kPad * stride + kPad) * 2, (size_t)stride * 4,
-                               (size_t)d.w[level] * 4, d.h[level], hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+                               (size_t)d.w[level] * 4, d.h[level], hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -1441,10 +1598,26 @@ int esvio_fe_track_event_mc(esvio_fe_handle c, double cur_time, const esvio_fe_e
   return track_event_entry(c, cur_time, left, nL, right, nR, space, pub_this_frame, motion, out);
 }
 
+int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio_fe_event* left,
+                            size_t nL, const esvio_fe_event* right, size_t nR, int space) {
+  if (!c) return ESVIO_FE_EINVAL;
+  if (nL == 0 || !left || (nR && !right)) return fail(c, ESVIO_FE_EINVAL, "bad next batch");
+  if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
+  if (c->ext_right_pending) return fail(c, ESVIO_FE_EINVAL, "not with an imported right image");
+  c->nb_set = true;  // may be called while an earlier announced batch is still pending as prefetched
+  c->nb_time = next_cur_time;
+  c->nb_left = left;
+  c->nb_nL = nL;
+  c->nb_right = right;
+  c->nb_nR = nR;
+  c->nb_space = space;
+  return 0;
+}
+
 int esvio_fe_set_profiling(esvio_fe_handle c, int on) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   resolve_profile(c);
   c->prof_on = on != 0;
   return 0;
@@ -1455,7 +1628,8 @@ int esvio_fe_get_kernel_stats(esvio_fe_handle c, int id, double* total_ms, uint6
                               uint64_t* alg_bytes) {
   if (!c || id < 0 || id >= K_COUNT) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   resolve_profile(c);
   if (total_ms) *total_ms = c->stats[id].ms;
   if (launches) *launches = c->stats[id].launches;
@@ -1464,11 +1638,11 @@ int esvio_fe_get_kernel_stats(esvio_fe_handle c, int id, double* total_ms, uint6
 }
 int esvio_fe_reset_kernel_stats(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->cur));
   resolve_profile(c);
   for (auto& s : c->stats) s = KStat();
   return 0;
 }
-void* esvio_fe_stream(esvio_fe_handle c) { return c ? (void*)c->stream : nullptr; }
+void* esvio_fe_stream(esvio_fe_handle c) { return c ? (void*)c->cur : nullptr; }
 
 }  // extern "C"

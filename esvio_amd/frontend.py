@@ -79,7 +79,7 @@ ABI_SYMBOLS = [
     "esvio_fe_get_sae", "esvio_fe_set_sae", "esvio_fe_calc_optical_flow_pyr_lk",
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
-    "esvio_fe_get_time_surface", "esvio_fe_export_image",
+    "esvio_fe_set_next_batch", "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
     "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
@@ -127,6 +127,7 @@ def load_library(build_if_missing=True):
                                           C.POINTER(Tracks)]
     L.esvio_fe_create_sae_stereo_mc.argtypes = [vp, vp, sz, vp, sz, i, C.POINTER(Motion),
                                                 C.POINTER(C.c_uint64)]
+    L.esvio_fe_set_next_batch.argtypes = [vp, d, vp, sz, vp, sz, i]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
     L.esvio_fe_export_image.argtypes = [vp, i, vp, i]
     L.esvio_fe_import_image.argtypes = [vp, i, vp, i]
@@ -325,6 +326,15 @@ class FeatureTracker:
             v = self._bufs[k][:nr_]
             setattr(self, k, v.copy() if copy else v)
         return self
+
+    def set_next_batch(self, next_cur_time, event_left, event_right):
+        """announce the batch of the FOLLOWING trackEvent call (throughput / replay mode)"""
+        pl, nl, sl, k1 = _events_arg(event_left)
+        pr, nr, sr, k2 = _events_arg(event_right)
+        assert sl == sr
+        self._next_keep = (k1, k2)  # host arrays must outlive the prefetch
+        self._hd.check(self._hd.L.esvio_fe_set_next_batch(self._hd.h, float(next_cur_time), pl, nl,
+                                                          pr, nr, sl))
 
     def reset(self):
         self._hd.check(self._hd.L.esvio_fe_reset(self._hd.h))

@@ -403,3 +403,32 @@ def test_track_event_motion_compensated_end_to_end(oracle):
         _compare_tracks(ft, r, ("mc", f))
     assert len(ft.ids) > 100
     ft.close()
+
+
+@pytest.mark.parametrize("equalize", [0, 1])
+def test_next_batch_prefetch_is_transparent(oracle, equalize):
+    """esvio_fe_set_next_batch (replay mode: the next batch's SAE update / images run on a second
+    stream under the current frame's LK) must not change a single result bit; also a mismatching
+    follow-up call is refused."""
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=5e6, seed=6)
+    batches = [s.next_batch() for _ in range(9)]
+    kw = dict(f_ransac=1, equalize=equalize)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f, (L, R, _) in enumerate(batches):
+        pub = (f % 3) != 1
+        t = event_times(L)[-1]
+        if f + 1 < len(batches) and f != 4:      # frame 4 -> 5 is not prefetched (mixing is legal)
+            Ln, Rn, _ = batches[f + 1]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn)
+        ft.trackEvent(t, L, R, pub)
+        _compare_tracks(ft, tr.track_event(t, L, R, pub), ("prefetch", f))
+    assert len(ft.ids) > 100
+    # a call that does not match the announced batch is an error, not silent corruption
+    L, R, _ = batches[0]
+    ft.set_next_batch(1.0, L, R)
+    ft.trackEvent(event_times(batches[1][0])[-1] + 1.0, batches[1][0], batches[1][1], False)
+    with pytest.raises(FE.FrontendError):
+        ft.trackEvent(2.0, batches[2][0], batches[2][1], False)
+    ft.close()
