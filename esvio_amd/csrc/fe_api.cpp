@@ -802,7 +802,7 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int max_corners, float2* out_pts, i
 }
 
 size_t select_lds_bytes(const esvio_fe_ctx* c) {
-  return ((size_t)c->H * ((c->W + 31) / 32) + 32) * 4;
+  return ((size_t)c->H * ((c->W + 31) / 32) + 4 + 64) * 4;  // bitmap + half-width table
 }
 
 // ordered compaction of the Arc* candidates, then the sequential greedy (Event_FeaturesToTrack)
@@ -842,6 +842,17 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool 
   a.cand_cnt = want_cand ? c->d_cand_cnt : nullptr;
   ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
   launch_arc(c->cur, a);
+}
+
+// wait for the main stream with a short busy poll first: the two per-frame host syncs are on the
+// critical path and an interrupt-driven hipStreamSynchronize wakes up tens of microseconds late
+hipError_t sync_main(esvio_fe_ctx* c) {
+  for (int i = 0; i < 20000; i++) {
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) return hipSuccess;
+    if (e != hipErrorNotReady) return e;
+  }
+  return hipStreamSynchronize(c->stream);
 }
 
 // ---------------------------------------------------------------- next-batch prefetch
@@ -963,6 +974,19 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->cur_right_pts.clear();
   lap(0);
 
+  // Arc* for every left event does not depend on the tracks: on published frames it is enqueued
+  // now (behind the temporal LK) without the blocked-pixel mask, so it runs under the host-side
+  // filtering / RANSAC / Event_setMask; k_maskfilter applies the mask afterwards.
+  bool arc_done = false;
+  auto early_arc = [&]() -> int {
+    if (!PUB_THIS_FRAME || arc_done) return 0;
+    if (int rc = ensure_arc_capacity(c, nL)) return rc;
+    run_arc(c, dL, (uint32_t)nL, true, false, false, true);
+    arc_done = true;
+    if (int rc = planes_free()) return rc;
+    return prefetch_next(c);
+  };
+
   if (c->prev_pts.size() > 0) {  // :405-437
     const int n = (int)c->prev_pts.size();
     std::memcpy(pin.ptsA, c->prev_pts.data(), (size_t)n * 8);
@@ -975,8 +999,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_temporal_bytes, hipMemcpyDeviceToHost,
                              c->cur));
+    if (int rc = early_arc()) return rc;
     lap(1);
-    HIPCHK(c, hipStreamSynchronize(c->cur));
+    HIPCHK(c, sync_main(c));
     lap(2);
     std::vector<uint8_t> status(pin.stA, pin.stA + n);
     c->cur_pts.resize(n);
@@ -998,6 +1023,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     reduce_vector(c->track_cnt, status);
   }
 
+  if (int rc = early_arc()) return rc;  // (no previous points: nothing was synchronised above)
   for (auto& n : c->track_cnt) n++;  // :439-440
 
   // ---- speculative stereo LK of every temporal survivor (a superset of the points that survive
@@ -1032,13 +1058,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     const int n_max_cnt = M - n_kept;
     if (n_max_cnt > 0) {
       detect = true;
-      if (int rc = ensure_arc_capacity(c, nL)) return rc;
       std::memcpy(pin.mask, c->mask_event.bits.data(), c->mask_event.bits.size() * 4);
       HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
                                hipMemcpyHostToDevice, c->cur));
-      run_arc(c, dL, (uint32_t)nL, true, true, false, true);
-      if (int rc = planes_free()) return rc;
-      if (int rc = prefetch_next(c)) return rc;
+      {
+        ScopedKernel k(c, K_COMPACT, 0);
+        launch_maskfilter(c->cur, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt,
+                          (uint32_t)((nL + kArcBlock - 1) / kArcBlock), c->d_mask_bits, (c->W + 31) / 32);
+      }
       run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, 0, nullptr);
       // stereo LK of the new corners only (count known on the device)
       LkArgs f = make_lk(curL, curR, c->d_new, nullptr, c->d_ptsB2, c->d_stA2, c->d_counts, n_max_cnt,
@@ -1055,7 +1082,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   if (n_surv || detect)
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->cur));
   lap(5);
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, sync_main(c));
   lap(6);
   if ((n_surv || detect) && pin.counts[3] != 0)
     return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");

@@ -1129,6 +1129,51 @@ void launch_arc(hipStream_t s, const ArcArgs& a) {
 // max_corners.  k_compact turns the per-block candidate lists into one ordered list (parallel),
 // k_select is the inherently sequential greedy: ONE wave, blocked-bitmap of new discs in LDS,
 // 64 candidates tested per step, ballot picks the first alive one.
+// Drop the candidates that fall on an already blocked pixel (Event_setMask's discs), keeping the
+// order, in place, one block per Arc* block.  Lets k_arc run before the mask exists (it overlaps
+// the host-side RANSAC / Event_setMask) — the mask test of feature_tracker.cpp:25 commutes with
+// the corner test.
+__global__ __launch_bounds__(kArcBlock) void k_maskfilter(uint32_t* __restrict__ cand_xy,
+                                                          uint32_t* __restrict__ cand_idx,
+                                                          uint32_t* __restrict__ cand_cnt,
+                                                          const uint32_t* __restrict__ mask_bits,
+                                                          int wpr) {
+  __shared__ uint32_t wave_cnt[kArcBlock / 64];
+  const uint32_t b = blockIdx.x;
+  const uint32_t c = cand_cnt[b];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  uint32_t xy = 0, ci = 0;
+  bool keep = false;
+  if (threadIdx.x < c) {
+    xy = cand_xy[(size_t)b * kArcBlock + threadIdx.x];
+    ci = cand_idx[(size_t)b * kArcBlock + threadIdx.x];
+    const uint32_t x = xy & 0xffffu, y = xy >> 16;
+    keep = !((mask_bits[y * wpr + (x >> 5)] >> (x & 31)) & 1u);
+  }
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) wave_cnt[wave] = __popcll(m);
+  __syncthreads();  // also: every thread has read its candidate before anyone overwrites
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++) base += wave_cnt[w];
+  if (keep) {
+    const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    cand_xy[(size_t)b * kArcBlock + pos] = xy;
+    cand_idx[(size_t)b * kArcBlock + pos] = ci;
+  }
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kArcBlock / 64; w++) t += wave_cnt[w];
+    cand_cnt[b] = t;
+  }
+}
+
+void launch_maskfilter(hipStream_t s, uint32_t* cand_xy, uint32_t* cand_idx, uint32_t* cand_cnt,
+                       uint32_t nblk, const uint32_t* mask_bits, int wpr) {
+  if (!nblk) return;
+  hipLaunchKernelGGL(k_maskfilter, dim3(nblk), dim3(kArcBlock), 0, s, cand_xy, cand_idx, cand_cnt,
+                     mask_bits, wpr);
+}
+
 __global__ __launch_bounds__(kArcBlock) void k_compact(const uint32_t* __restrict__ cand_xy,
                                                        const uint32_t* __restrict__ cand_idx,
                                                        const uint32_t* __restrict__ cand_cnt,
@@ -1162,11 +1207,39 @@ void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand
                      comp_xy, comp_idx, total);
 }
 
+// OR the bits of columns [xa,xb] that fall into word (w0+k) of row yy; rows/words outside the
+// image contribute 0 to a clamped (valid) address, so there is no branch
+__device__ __forceinline__ void stamp_words(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
+                                            int hw, int k0, int k1) {
+  const bool valid = hw >= 0 && (unsigned)yy < (unsigned)H;
+  const int xa = valid ? max(ax - hw, 0) : 1;
+  const int xb = valid ? min(ax + hw, W - 1) : 0;
+  const int w0 = xa >> 5;
+  const int rowbase = min(max(yy, 0), H - 1) * wpr;
+#pragma unroll
+  for (int k = k0; k < k1; k++) {
+    const int w = w0 + k;
+    const int lo = max(xa - (w << 5), 0), hi = min(xb - (w << 5), 31);
+    const uint32_t bits = hi >= lo ? (((2u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+    __hip_atomic_fetch_or(lds + rowbase + min(w, wpr - 1), bits, __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+}
+__device__ __forceinline__ void stamp_row(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
+                                          int hw) {
+  stamp_words(lds, wpr, W, H, ax, yy, hw, 0, 3);  // 2*31+1 = 63 px -> at most 3 words
+}
+__device__ __forceinline__ void stamp_row_tail(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
+                                               int hw) {
+  stamp_words(lds, wpr, W, H, ax, yy, hw, 3, 5);  // r <= 63: 127 px -> at most 5 words
+}
+
 __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* const bitmap = lds;  // H * wpr words, bit set = inside a disc stamped by this call
   const int lane = lane_id();
   const int nwords = a.H * a.wpr;
+  int* const hwtab = (int*)(lds + ((nwords + 3) & ~3));  // cv::circle half-widths by |dy|, -1 beyond r
   for (int i = lane * 4; i < nwords; i += 256) {
     if (i + 3 < nwords) {
       *(uint4*)(lds + i) = make_uint4(0, 0, 0, 0);
@@ -1174,12 +1247,12 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
       for (int k = i; k < nwords; k++) lds[k] = 0;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const int r = a.radius;
+  hwtab[lane] = lane <= r ? (int)a.hw[lane] : -1;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
   const uint32_t total = *a.total;
   int accepted = 0;
-  const int r = a.radius;
-  // this lane's disc rows (row index lane and lane+64) and their half-widths, kept in registers so
-  // an accept never touches memory for the table
+  // this lane's disc rows (row index lane and lane+64) and their half-widths
   const int row_a = lane, row_b = lane + 64;
   const int hw_a = row_a < 2 * r + 1 ? a.hw[row_a < r ? r - row_a : row_a - r] : -1;
   const int hw_b = row_b < 2 * r + 1 ? a.hw[row_b < r ? r - row_b : row_b - r] : -1;
@@ -1187,11 +1260,13 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   // before the current one is processed so the serial loop never waits on HBM/L2 latency
   constexpr int SUB = 4;
   uint32_t nxy[SUB], nci[SUB];
+  // loads are unconditional (clamped index) so the compiler never has to wait for them right away
+  const uint32_t last = total ? total - 1 : 0;
 #pragma unroll
   for (int j = 0; j < SUB; j++) {
-    const uint32_t i = j * 64 + lane;
-    nxy[j] = i < total ? a.comp_xy[i] : 0u;
-    nci[j] = i < total ? a.comp_idx[i] : 0u;
+    const uint32_t i = min(j * 64 + lane, last);
+    nxy[j] = a.comp_xy[i];
+    nci[j] = a.comp_idx[i];
   }
   for (uint32_t base = 0; base < total && accepted < a.max_corners; base += 64 * SUB) {
     uint32_t cxy[SUB], cci[SUB];
@@ -1199,15 +1274,28 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     for (int j = 0; j < SUB; j++) {
       cxy[j] = nxy[j];
       cci[j] = nci[j];
-      const uint32_t i = base + 64 * SUB + j * 64 + lane;
-      nxy[j] = i < total ? a.comp_xy[i] : 0u;
-      nci[j] = i < total ? a.comp_idx[i] : 0u;
+      const uint32_t i = min(base + 64 * SUB + j * 64 + lane, last);
+      nxy[j] = a.comp_xy[i];
+      nci[j] = a.comp_idx[i];
+    }
+    {  // fast path: all 256 candidates of this step already blocked -> next step
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < SUB; j++) {
+        const int x = cxy[j] & 0xffff, y = cxy[j] >> 16;
+        any = any || ((base + j * 64 + lane < total) &&
+                      !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u));
+      }
+      if (!__ballot(any)) continue;
     }
 #pragma unroll
     for (int j = 0; j < SUB; j++) {
       const uint32_t i = base + j * 64 + lane;
       const bool have = i < total;
       const int x = cxy[j] & 0xffff, y = cxy[j] >> 16;
+      // discs stamped while earlier sub-chunks were processed are visible through the bitmap
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
       bool alive = have && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
       while (accepted < a.max_corners) {
         const unsigned long long m = __ballot(alive);
@@ -1221,26 +1309,19 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
           if (a.out_idx) a.out_idx[accepted] = ai;
         }
         accepted++;
-        // stamp the disc: one lane per row (two rows per lane when r > 31), LDS atomic OR
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int hw = h ? hw_b : hw_a;
-          const int yy = ay - r + (h ? row_b : row_a);
-          if (hw < 0 || yy < 0 || yy >= a.H) continue;
-          const int xa = max(ax - hw, 0), xb = min(ax + hw, a.W - 1);
-          if (xb < xa) continue;
-          for (int w = xa >> 5; w <= (xb >> 5); w++) {
-            const int lo = max(xa - (w << 5), 0), hi = min(xb - (w << 5), 31);
-            const uint32_t bits =
-                (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-            __hip_atomic_fetch_or(lds + yy * a.wpr + w, bits, __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
+        // stamp the disc for the LATER sub-chunks (LDS atomic OR, not waited for here): one lane
+        // per row, branch-free: the row's span [xa,xb] touches at most 3 words for r <= 31
+        stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+        if (r > 31) {  // wave-uniform: rows 64.. of a large disc
+          stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
+          stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+          stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
         }
-        // order the LDS stamps before the re-test (LDS only: the global stores above must not be
-        // waited for — a full fence here costs a memory round trip per accepted corner)
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-        alive = alive && lane > first && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+        // ... and kill this sub-chunk's remaining candidates geometrically: inside the disc iff
+        // |dx| <= hw[|dy|] (the same table the stamp uses), so no LDS round trip per accept
+        const int dy = y > ay ? y - ay : ay - y, dx = x > ax ? x - ax : ax - x;
+        const int hwd = hwtab[min(dy, 63)];
+        alive = alive && lane > first && !(dy <= r && dx <= hwd);
       }
       if (accepted >= a.max_corners) break;
     }

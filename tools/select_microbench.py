@@ -1,0 +1,30 @@
+"""k_select micro-benchmark: time vs number of accepted corners / candidates scanned."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from esvio_amd import frontend as FE
+from esvio_amd.events import event_times
+from esvio_amd.synth import SceneStream
+
+W, H = 640, 480
+s = SceneStream(W, H, rate=5e6, seed=12345)
+ft = FE.FeatureTracker(FE.make_config(W, H))
+for _ in range(3):
+    L, R, _ = s.next_batch()
+    ft.detector.createSAE_stereo(L, R)
+ft.detector.SAEtoTimeSurface_left(event_times(L)[-1])
+ft.set_profiling(True)
+for mask_frac in (0.0, 0.5):
+    mask = np.zeros((H, W), np.uint8)
+    if mask_frac:
+        mask[:, : int(W * mask_frac)] = 255
+    for maxc in (1, 25, 50, 100, 200, 300):
+        ft.reset_kernel_stats()
+        for _ in range(5):
+            xy, idx = ft.Event_FeaturesToTrack(L, maxc, mask)
+        st = ft.kernel_stats()
+        print("mask %.1f maxc %3d -> accepted %3d last_idx %6d | k_select %.1f us  k_arc %.1f  k_compact %.1f" % (
+            mask_frac, maxc, len(idx), idx[-1] if len(idx) else -1,
+            st["k_select"]["ms"] / st["k_select"]["launches"] * 1e3,
+            st["k_arc"]["ms"] / st["k_arc"]["launches"] * 1e3,
+            st["k_compact"]["ms"] / st["k_compact"]["launches"] * 1e3))
