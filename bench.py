@@ -147,12 +147,13 @@ def main():
                 if exchange:
                     exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
             return nl if rank == 0 else nr
-        if pipeline and i + 1 < len(dev_batches):  # replay mode: the next batch is already in HBM
-            tl2, tr2, nl2, nr2, t2 = dev_batches[i + 1]
-            ft.set_next_batch(t2, (tl2.data_ptr(), nl2), (tr2.data_ptr(), nr2))
-        ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
         if pub:
             fc.published()
+        if pipeline and i + 1 < len(dev_batches):  # replay mode: the next batch is already in HBM
+            tl2, tr2, nl2, nr2, t2 = dev_batches[i + 1]
+            ft.set_next_batch(t2, (tl2.data_ptr(), nl2), (tr2.data_ptr(), nr2), fc.peek(t2))
+        ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
+        if pub:
             if exch is not None and exchange:  # merge all rigs' tracked corners (async)
                 exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
         return nl + nr

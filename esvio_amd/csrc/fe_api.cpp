@@ -98,7 +98,7 @@ struct esvio_fe_ctx {
   hipStream_t stream = nullptr;   // main stream
   hipStream_t stream2 = nullptr;  // prefetch stream (next batch's SAE update / images)
   hipStream_t cur = nullptr;      // the stream the helpers currently enqueue on
-  hipEvent_t ev_planes_free = nullptr, ev_prefetch_done = nullptr;
+  hipEvent_t ev_planes_free = nullptr, ev_prefetch_done = nullptr, ev_arc_done = nullptr;
   std::string err;
   int W = 0, H = 0;
   uint32_t P = 0;
@@ -124,7 +124,10 @@ struct esvio_fe_ctx {
   size_t nb_nL = 0, nb_nR = 0;
   int nb_space = 0;
   double nb_time = 0;
+  int nb_pub = 0;  // caller's PUB_THIS_FRAME hint for the announced batch
   int pf_slotL = 0, pf_slotR = 3, pf_raw = 0;
+  bool pf_arc_done = false;  // Arc* of the prefetched batch already ran on the prefetch stream
+  bool cur_prefetched = false;  // the frame being processed came from the prefetch stream
   // identity of the batch whose SAE update / images were prefetched
   const esvio_fe_event *pf_left = nullptr, *pf_right = nullptr;
   size_t pf_nL = 0, pf_nR = 0;
@@ -153,7 +156,13 @@ struct esvio_fe_ctx {
   int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total [2]=#candidates
   // arc / select
   uint8_t* d_flags = nullptr;
-  uint32_t *d_cand_xy = nullptr, *d_cand_idx = nullptr, *d_cand_cnt = nullptr;
+  // per-block ordered candidate lists written by k_arc; two sets so that the Arc* of a prefetched
+  // batch (prefetch stream) never overwrites the set the current frame's selection still reads
+  struct CandSet {
+    uint32_t *xy = nullptr, *idx = nullptr, *cnt = nullptr;
+    size_t cap = 0;
+  } cand[2];
+  int cand_cur = 0;
   uint32_t *d_comp_xy = nullptr, *d_comp_idx = nullptr;
   size_t arc_cap = 0;
   uint32_t* d_mask_bits = nullptr;
@@ -307,20 +316,35 @@ int ensure_sort_capacity(esvio_fe_ctx* c, size_t n) {
   return 0;
 }
 
-int ensure_arc_capacity(esvio_fe_ctx* c, size_t n) {
+int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n) {
+  esvio_fe_ctx::CandSet& s = c->cand[set];
+  if (n <= s.cap) return 0;
+  size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
+  cap = (cap + kArcBlock - 1) / kArcBlock * kArcBlock;
+  void* ptrs[] = {s.xy, s.idx, s.cnt};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  s = esvio_fe_ctx::CandSet();
+  if (int rc = dev_alloc(c, &s.xy, cap)) return rc;
+  if (int rc = dev_alloc(c, &s.idx, cap)) return rc;
+  if (int rc = dev_alloc(c, &s.cnt, cap / kArcBlock)) return rc;
+  s.cap = cap;
+  return 0;
+}
+
+// flags + compacted candidate stream (main stream only) and candidate set `set`
+int ensure_arc_capacity(esvio_fe_ctx* c, size_t n, int set) {
+  if (int rc = ensure_cand_capacity(c, set, n)) return rc;
   if (n <= c->arc_cap) return 0;
   size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
   cap = (cap + kArcBlock - 1) / kArcBlock * kArcBlock;
-  void* ptrs[] = {c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy, c->d_comp_idx};
+  void* ptrs[] = {c->d_flags, c->d_comp_xy, c->d_comp_idx};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   c->d_flags = nullptr;
-  c->d_cand_xy = c->d_cand_idx = c->d_cand_cnt = c->d_comp_xy = c->d_comp_idx = nullptr;
+  c->d_comp_xy = c->d_comp_idx = nullptr;
   c->arc_cap = 0;
   if (int rc = dev_alloc(c, &c->d_flags, cap)) return rc;
-  if (int rc = dev_alloc(c, &c->d_cand_xy, cap)) return rc;
-  if (int rc = dev_alloc(c, &c->d_cand_idx, cap)) return rc;
-  if (int rc = dev_alloc(c, &c->d_cand_cnt, cap / kArcBlock)) return rc;
   if (int rc = dev_alloc(c, &c->d_comp_xy, cap)) return rc;
   if (int rc = dev_alloc(c, &c->d_comp_idx, cap)) return rc;
   c->arc_cap = cap;
@@ -811,17 +835,19 @@ void run_select(esvio_fe_ctx* c, uint32_t n_events, int max_corners, float2* out
   const uint32_t nblk = (n_events + kArcBlock - 1) / kArcBlock;
   {
     ScopedKernel k(c, K_COMPACT, 0);
-    launch_compact(c->cur, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, nblk, c->d_comp_xy,
-                   c->d_comp_idx, (uint32_t*)(c->d_counts + 2));
+    const esvio_fe_ctx::CandSet& cs = c->cand[c->cand_cur];
+    launch_compact(c->cur, cs.xy, cs.idx, cs.cnt, nblk, c->d_comp_xy, c->d_comp_idx,
+                   (uint32_t*)(c->d_counts + 2));
   }
   SelectArgs s = make_select_args(c, max_corners, out_pts, out_base, out_idx);
   ScopedKernel k(c, K_SELECT, 0);
   launch_select(c->cur, s, select_lds_bytes(c));
 }
 
-// Arc* flags (+ ordered per-block candidate lists) for the left events
-void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool use_mask,
-             bool want_flags, bool want_cand) {
+// Arc* flags (+ ordered per-block candidate lists into set `set`) for the left events; `ts` is the
+// RAW left time surface the TS_LK_THRESHOLD test reads (null: no test)
+void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts, bool use_mask,
+             bool want_flags, bool want_cand, int set) {
   ArcArgs a{};
   a.ev = ev;
   a.n = n;
@@ -831,15 +857,15 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, bool use_ts, bool 
   a.H = c->H;
   a.filter_threshold = c->cfg.feature_filter_threshold;
   a.border = c->cfg.min_dist + 1;
-  a.ts = use_ts ? raw_ts_desc(c, 0).img[0] : nullptr;  // RAW left time surface (:26)
-  a.ts_stride = raw_ts_desc(c, 0).stride[0];
+  a.ts = ts ? ts->img[0] : nullptr;  // RAW left time surface (:26)
+  a.ts_stride = ts ? ts->stride[0] : 0;
   a.ts_lk_threshold = c->cfg.ts_lk_threshold;
   a.mask_bits = use_mask ? c->d_mask_bits : nullptr;
   a.wpr = (c->W + 31) / 32;
   a.flags = want_flags ? c->d_flags : nullptr;
-  a.cand_xy = want_cand ? c->d_cand_xy : nullptr;
-  a.cand_idx = want_cand ? c->d_cand_idx : nullptr;
-  a.cand_cnt = want_cand ? c->d_cand_cnt : nullptr;
+  a.cand_xy = want_cand ? c->cand[set].xy : nullptr;
+  a.cand_idx = want_cand ? c->cand[set].idx : nullptr;
+  a.cand_cnt = want_cand ? c->cand[set].cnt : nullptr;
   ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
   launch_arc(c->cur, a);
 }
@@ -859,8 +885,12 @@ hipError_t sync_main(esvio_fe_ctx* c) {
 // Enqueue the SAE update, time surfaces and pyramids of the batch announced with
 // esvio_fe_set_next_batch on the second stream; they overlap the rest of the current frame (stereo
 // LK, selection) and the host work between calls.  Waits for ev_planes_free (recorded on the main
-// stream once the current frame has finished reading the SAE planes).
-int prefetch_next(esvio_fe_ctx* c) {
+// stream once the current frame has finished reading the SAE planes) when `wait_planes`; a frame
+// that itself came from the prefetch stream and runs no Arc* on the main stream reads neither the
+// planes nor the raw surfaces there, so the next prefetch only has to follow its own stream.
+// With the caller's PUB hint the Arc* pass of the batch runs here too (into the other candidate
+// set), which takes it off the main stream's per-frame chain.
+int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
   if (!c->nb_set || c->pf_valid) return 0;
   int sl = 0;
   while (sl == c->slot_prevL || sl == c->slot_curL) sl++;
@@ -870,7 +900,7 @@ int prefetch_next(esvio_fe_ctx* c) {
   c->cur = c->stream2;
   int rc = 0;
   do {
-    if (hipStreamWaitEvent(c->stream2, c->ev_planes_free, 0) != hipSuccess) {
+    if (wait_planes && hipStreamWaitEvent(c->stream2, c->ev_planes_free, 0) != hipSuccess) {
       rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
       break;
     }
@@ -884,6 +914,18 @@ int prefetch_next(esvio_fe_ctx* c) {
     if (hipEventRecord(c->ev_prefetch_done, c->stream2) != hipSuccess) {
       rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
       break;
+    }
+    c->pf_arc_done = false;
+    if (c->nb_pub && c->nb_nL) {
+      const int set = c->cand_cur ^ 1;
+      if ((rc = ensure_cand_capacity(c, set, c->nb_nL))) break;
+      const PyrDesc& ts = c->cfg.equalize ? c->raw[c->pf_raw][0].d : c->pyr[c->pf_slotL].d;
+      run_arc(c, c->pf_dL, (uint32_t)c->nb_nL, &ts, false, false, true, set);
+      if (hipEventRecord(c->ev_arc_done, c->stream2) != hipSuccess) {
+        rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
+        break;
+      }
+      c->pf_arc_done = true;
     }
     c->pf_valid = true;
     c->pf_left = c->nb_left;
@@ -917,6 +959,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
 
   const EventRec *dL = nullptr, *dR = nullptr;
   const bool first = !c->have_img;
+  bool arc_done = false, arc_prefetched = false;
   if (c->pf_valid) {
     // this batch was announced with esvio_fe_set_next_batch and its SAE update, images and
     // pyramids were enqueued on the prefetch stream during the previous call
@@ -930,7 +973,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     c->slot_curL = c->pf_slotL;
     c->slot_curR = c->pf_slotR;
     c->raw_cur = c->pf_raw;
+    c->cur_prefetched = true;
+    if (c->pf_arc_done) {  // candidates of this batch are in the other set
+      c->cand_cur ^= 1;
+      arc_done = arc_prefetched = true;
+      c->pf_arc_done = false;
+    }
   } else {
+    c->cur_prefetched = false;
     if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
     // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
     if (motion) {
@@ -960,15 +1010,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
   const PyrDesc& curL = c->pyr[c->slot_curL].d;
   const PyrDesc& curR = c->pyr[c->slot_curR].d;
-  bool planes_event_recorded = false;
-  // after this point of the main stream nothing of THIS frame reads the SAE planes or the raw
-  // time surfaces any more, so the next batch's update may start on the prefetch stream
-  auto planes_free = [&]() -> int {
-    if (planes_event_recorded || !c->nb_set) return 0;
-    planes_event_recorded = true;
-    HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
-    return 0;
-  };
+  // what THIS frame enqueues on the main stream that reads the SAE planes / raw time surfaces:
+  // its own SAE update + rendering unless prefetched, and Arc* unless that ran with the prefetch
+  bool main_reads_planes = !c->cur_prefetched;
 
   c->cur_pts.clear();
   c->cur_right_pts.clear();
@@ -976,15 +1020,23 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
 
   // Arc* for every left event does not depend on the tracks: on published frames it is enqueued
   // now (behind the temporal LK) without the blocked-pixel mask, so it runs under the host-side
-  // filtering / RANSAC / Event_setMask; k_maskfilter applies the mask afterwards.
-  bool arc_done = false;
-  auto early_arc = [&]() -> int {
-    if (!PUB_THIS_FRAME || arc_done) return 0;
-    if (int rc = ensure_arc_capacity(c, nL)) return rc;
-    run_arc(c, dL, (uint32_t)nL, true, false, false, true);
-    arc_done = true;
-    if (int rc = planes_free()) return rc;
-    return prefetch_next(c);
+  // filtering / RANSAC / Event_setMask; k_maskfilter applies the mask afterwards.  After it
+  // nothing of this frame reads the planes on the main stream, so the announced next batch is
+  // started on the prefetch stream.
+  bool early_done = false;
+  auto early_work = [&]() -> int {
+    if (early_done) return 0;
+    early_done = true;
+    if (PUB_THIS_FRAME && !arc_done) {
+      if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
+      const PyrDesc ts = raw_ts_desc(c, 0);
+      run_arc(c, dL, (uint32_t)nL, &ts, false, false, true, c->cand_cur);
+      arc_done = true;
+      main_reads_planes = true;
+    }
+    if (!c->nb_set) return 0;
+    if (main_reads_planes) HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
+    return prefetch_next(c, main_reads_planes);
   };
 
   if (c->prev_pts.size() > 0) {  // :405-437
@@ -999,7 +1051,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_temporal_bytes, hipMemcpyDeviceToHost,
                              c->cur));
-    if (int rc = early_arc()) return rc;
+    if (int rc = early_work()) return rc;
     lap(1);
     HIPCHK(c, sync_main(c));
     lap(2);
@@ -1023,7 +1075,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     reduce_vector(c->track_cnt, status);
   }
 
-  if (int rc = early_arc()) return rc;  // (no previous points: nothing was synchronised above)
+  if (int rc = early_work()) return rc;  // (no previous points: nothing was synchronised above)
   for (auto& n : c->track_cnt) n++;  // :439-440
 
   // ---- speculative stereo LK of every temporal survivor (a superset of the points that survive
@@ -1044,10 +1096,6 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
   }
 
-  if (!PUB_THIS_FRAME) {
-    if (int rc = planes_free()) return rc;
-    if (int rc = prefetch_next(c)) return rc;
-  }
   bool detect = false;
   int n_kept = n_surv;
   if (PUB_THIS_FRAME) {  // :442-469
@@ -1061,10 +1109,13 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       std::memcpy(pin.mask, c->mask_event.bits.data(), c->mask_event.bits.size() * 4);
       HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
                                hipMemcpyHostToDevice, c->cur));
+      if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
+      if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_arc_done, 0));
       {
         ScopedKernel k(c, K_COMPACT, 0);
-        launch_maskfilter(c->cur, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt,
-                          (uint32_t)((nL + kArcBlock - 1) / kArcBlock), c->d_mask_bits, (c->W + 31) / 32);
+        const esvio_fe_ctx::CandSet& cs = c->cand[c->cand_cur];
+        launch_maskfilter(c->cur, cs.xy, cs.idx, cs.cnt, (uint32_t)((nL + kArcBlock - 1) / kArcBlock),
+                          c->d_mask_bits, (c->W + 31) / 32);
       }
       run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, 0, nullptr);
       // stereo LK of the new corners only (count known on the device)
@@ -1074,10 +1125,6 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                          0.01, 0);
       run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC2, c->d_stB2);
     }
-  }
-  if (PUB_THIS_FRAME && !detect) {
-    if (int rc = planes_free()) return rc;
-    if (int rc = prefetch_next(c)) return rc;
   }
   if (n_surv || detect)
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->cur));
@@ -1194,7 +1241,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
-                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_cand_xy, c->d_cand_idx, c->d_cand_cnt, c->d_comp_xy,
+                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->cand[0].xy, c->cand[0].idx,
+                  c->cand[0].cnt, c->cand[1].xy, c->cand[1].idx, c->cand[1].cnt, c->d_comp_xy,
                   c->d_comp_idx, c->d_mask_bits, c->d_sel_idx, c->pyr[0].mem, c->pyr[1].mem,
                   c->pyr[2].mem, c->pyr[3].mem, c->pyr[4].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem,
                   c->raw[0][0].mem, c->raw[0][1].mem, c->raw[1][0].mem, c->raw[1][1].mem, c->d_lut,
@@ -1213,6 +1261,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   }
   if (c->ev_planes_free) (void)hipEventDestroy(c->ev_planes_free);
   if (c->ev_prefetch_done) (void)hipEventDestroy(c->ev_prefetch_done);
+  if (c->ev_arc_done) (void)hipEventDestroy(c->ev_arc_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -1258,7 +1307,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_prefetch_done, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&c->ev_prefetch_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_arc_done, hipEventDisableTiming) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
   c->cur = c->stream;
   const size_t M = cfg->max_cnt;
@@ -1425,8 +1475,8 @@ int esvio_fe_is_corner(esvio_fe_handle c, const esvio_fe_event* ev, size_t n, in
   HIPCHK(c, hipSetDevice(c->dev));
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, ev, n, nullptr, 0, space, &dL, &dR)) return rc;
-  if (int rc = ensure_arc_capacity(c, n)) return rc;
-  run_arc(c, dL, (uint32_t)n, false, false, true, false);
+  if (int rc = ensure_arc_capacity(c, n, c->cand_cur)) return rc;
+  run_arc(c, dL, (uint32_t)n, nullptr, false, true, false, c->cand_cur);
   HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, n, hipMemcpyDeviceToHost, c->cur));
   HIPCHK(c, hipStreamSynchronize(c->cur));
   if (c->prof_on) resolve_profile(c);
@@ -1444,7 +1494,7 @@ int esvio_fe_features_to_track(esvio_fe_handle c, const esvio_fe_event* ev, size
   HIPCHK(c, hipSetDevice(c->dev));
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, ev, n, nullptr, 0, space, &dL, &dR)) return rc;
-  if (int rc = ensure_arc_capacity(c, n)) return rc;
+  if (int rc = ensure_arc_capacity(c, n, c->cand_cur)) return rc;
   Pin pin = pin_of(c);
   host::BitMask bm;
   bm.reset(c->W, c->H);
@@ -1452,7 +1502,8 @@ int esvio_fe_features_to_track(esvio_fe_handle c, const esvio_fe_event* ev, size
   std::memcpy(pin.mask, bm.bits.data(), bm.bits.size() * 4);
   HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, bm.bits.size() * 4, hipMemcpyHostToDevice,
                            c->cur));
-  run_arc(c, dL, (uint32_t)n, true, true, false, true);
+  const PyrDesc ts = raw_ts_desc(c, 0);
+  run_arc(c, dL, (uint32_t)n, &ts, true, false, true, c->cand_cur);
   run_select(c, (uint32_t)n, max_corners, c->d_ptsD, 0, c->d_sel_idx);
   HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->cur));
   HIPCHK(c, hipStreamSynchronize(c->cur));
@@ -1626,7 +1677,8 @@ int esvio_fe_track_event_mc(esvio_fe_handle c, double cur_time, const esvio_fe_e
 }
 
 int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio_fe_event* left,
-                            size_t nL, const esvio_fe_event* right, size_t nR, int space) {
+                            size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                            int pub_hint) {
   if (!c) return ESVIO_FE_EINVAL;
   if (nL == 0 || !left || (nR && !right)) return fail(c, ESVIO_FE_EINVAL, "bad next batch");
   if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
@@ -1638,6 +1690,7 @@ int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio
   c->nb_right = right;
   c->nb_nR = nR;
   c->nb_space = space;
+  c->nb_pub = pub_hint != 0;
   return 0;
 }
 

@@ -127,7 +127,7 @@ def load_library(build_if_missing=True):
                                           C.POINTER(Tracks)]
     L.esvio_fe_create_sae_stereo_mc.argtypes = [vp, vp, sz, vp, sz, i, C.POINTER(Motion),
                                                 C.POINTER(C.c_uint64)]
-    L.esvio_fe_set_next_batch.argtypes = [vp, d, vp, sz, vp, sz, i]
+    L.esvio_fe_set_next_batch.argtypes = [vp, d, vp, sz, vp, sz, i, i]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
     L.esvio_fe_export_image.argtypes = [vp, i, vp, i]
     L.esvio_fe_import_image.argtypes = [vp, i, vp, i]
@@ -327,14 +327,15 @@ class FeatureTracker:
             setattr(self, k, v.copy() if copy else v)
         return self
 
-    def set_next_batch(self, next_cur_time, event_left, event_right):
-        """announce the batch of the FOLLOWING trackEvent call (throughput / replay mode)"""
+    def set_next_batch(self, next_cur_time, event_left, event_right, PUB_NEXT_FRAME=False):
+        """announce the batch of the FOLLOWING trackEvent call (throughput / replay mode);
+        PUB_NEXT_FRAME is the PUB_THIS_FRAME that call is expected to carry (a hint)"""
         pl, nl, sl, k1 = _events_arg(event_left)
         pr, nr, sr, k2 = _events_arg(event_right)
         assert sl == sr
         self._next_keep = (k1, k2)  # host arrays must outlive the prefetch
         self._hd.check(self._hd.L.esvio_fe_set_next_batch(self._hd.h, float(next_cur_time), pl, nl,
-                                                          pr, nr, sl))
+                                                          pr, nr, sl, int(bool(PUB_NEXT_FRAME))))
 
     def reset(self):
         self._hd.check(self._hd.L.esvio_fe_reset(self._hd.h))

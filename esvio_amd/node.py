@@ -39,6 +39,16 @@ class FreqControl:
     def published(self):
         self.pub_count += 1
 
+    def peek(self, msg_timestamp):
+        """the decision pub_this_frame(msg_timestamp) would take, without taking it (the rule reads
+        timestamps only, so a replaying caller can hint the next frame's PUB_THIS_FRAME)"""
+        if self.first_image_time is None:
+            return False
+        dt = msg_timestamp - self.first_image_time
+        if dt <= 0:
+            return False
+        return round(1.0 * self.pub_count / dt) <= self.FREQ
+
 
 def pack_point_cloud(ft):
     """sensor_msgs/PointCloud equivalent (node:273-329): rows of

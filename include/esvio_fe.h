@@ -191,13 +191,17 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle h, const esvio_fe_event* left,
 /* Throughput (replay) mode: announce the batch the FOLLOWING esvio_fe_track_event call will be
  * given.  The current call then enqueues that batch's SAE update, time surfaces and pyramids on a
  * second HIP stream as soon as the current frame has finished reading the SAE planes, so they overlap
- * the current frame's stereo LK / selection and the host work between calls.  The following call must
+ * the current frame's LK / selection and the host work between calls.  `pub_hint` is the
+ * PUB_THIS_FRAME the caller expects to pass with that batch (the node's frequency control depends
+ * on timestamps only, stereo_event_tracker_node.cpp:177-188): when non-zero the batch's Arc* pass
+ * is prefetched as well; a wrong hint costs time, never correctness.  The following call must
  * pass exactly these pointers, sizes, space and cur_time (else ESVIO_FE_EINVAL) and the event memory
  * must stay valid until then.  Results are identical to the non-pipelined sequence.  After a call
  * that prefetched, the get_sae / time-surface taps already reflect the NEXT batch.  The reference
  * has no counterpart: it processes one batch at a time (depth-1 queues, node:128-142). */
 int esvio_fe_set_next_batch(esvio_fe_handle h, double next_cur_time, const esvio_fe_event* left,
-                            size_t nL, const esvio_fe_event* right, size_t nR, int space);
+                            size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                            int pub_hint);
 
 /* FeatureTracker::gettimesurface() tap (feature_tracker.cpp:894): current left/right image */
 int esvio_fe_get_time_surface(esvio_fe_handle h, int cam, uint8_t* out);

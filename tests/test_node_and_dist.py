@@ -149,3 +149,23 @@ def test_track_exchange_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_freq_control_peek_predicts_next_decision():
+    """FreqControl.peek (the PUB hint for esvio_fe_set_next_batch) equals the decision
+    pub_this_frame takes afterwards, for regular and jittered batch timestamps."""
+    from esvio_amd.node import FreqControl
+    rng = np.random.default_rng(3)
+    for freq, hz in [(15, 30.0), (20, 30.0), (30, 30.0), (10, 25.0)]:
+        fc = FreqControl(freq)
+        t = 0.5
+        n_pub = 0
+        for i in range(200):
+            t += (1.0 / hz) * (1.0 + 0.2 * rng.uniform(-1, 1))
+            guess = fc.peek(t)
+            pub = fc.pub_this_frame(t)
+            assert guess == pub, (freq, hz, i)
+            if pub:
+                fc.published()
+                n_pub += 1
+        assert n_pub > 20

@@ -405,25 +405,30 @@ def test_track_event_motion_compensated_end_to_end(oracle):
     ft.close()
 
 
-@pytest.mark.parametrize("equalize", [0, 1])
-def test_next_batch_prefetch_is_transparent(oracle, equalize):
-    """esvio_fe_set_next_batch (replay mode: the next batch's SAE update / images run on a second
-    stream under the current frame's LK) must not change a single result bit; also a mismatching
-    follow-up call is refused."""
+@pytest.mark.parametrize("equalize,hint", [(0, "none"), (0, "right"), (0, "wrong"), (1, "right"),
+                                           (1, "none")])
+def test_next_batch_prefetch_is_transparent(oracle, equalize, hint):
+    """esvio_fe_set_next_batch (replay mode: the next batch's SAE update / images — and, with the
+    PUB hint, its Arc* pass — run on a second stream under the current frame's LK) must not change
+    a single result bit, whether the hint is absent, right or wrong; also a mismatching follow-up
+    call is refused."""
     W, H = 640, 480
     s = SceneStream(W, H, rate=5e6, seed=6)
-    batches = [s.next_batch() for _ in range(9)]
+    batches = [s.next_batch() for _ in range(11)]
     kw = dict(f_ransac=1, equalize=equalize)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    pubs = [(f % 3) != 1 for f in range(len(batches))]
     for f, (L, R, _) in enumerate(batches):
-        pub = (f % 3) != 1
         t = event_times(L)[-1]
         if f + 1 < len(batches) and f != 4:      # frame 4 -> 5 is not prefetched (mixing is legal)
             Ln, Rn, _ = batches[f + 1]
-            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn)
-        ft.trackEvent(t, L, R, pub)
-        _compare_tracks(ft, tr.track_event(t, L, R, pub), ("prefetch", f))
+            h = {"none": False, "right": pubs[f + 1], "wrong": not pubs[f + 1]}[hint]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, h)
+        ft.trackEvent(t, L, R, pubs[f])
+        _compare_tracks(ft, tr.track_event(t, L, R, pubs[f]), ("prefetch", hint, f))
+        if f == 4:  # nothing pending: the taps show this very frame
+            assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
     assert len(ft.ids) > 100
     # a call that does not match the announced batch is an error, not silent corruption
     L, R, _ = batches[0]
