@@ -661,29 +661,53 @@ __device__ __forceinline__ int xor32_add(int v) {
   auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
   return (int)r[0] + (int)r[1];
 }
-__device__ __forceinline__ void wave_sum2_exact(int a, int b, float& fa, float& fb) {
+// Per-lane constants of the packed reduction below: after the 8-lane butterflies every lane of a
+// quad keeps ONE of the four pieces {a.lo12, a.hi20, b.lo12, b.hi20} (piece = lane & 3).
+struct RedLane {
+  bool take_b;       // piece belongs to b
+  uint32_t off, wid; // bit field of the biased 8-lane sum
+  float scale, corr; // piece -> its exact contribution to sum * 2^-20
+};
+__device__ __forceinline__ RedLane red_lane(int lane) {
+  RedLane r;
+  r.take_b = (lane & 2) != 0;
+  const bool hi = (lane & 1) != 0;
+  r.off = hi ? 12u : 0u;
+  r.wid = hi ? 20u : 12u;
+  r.scale = hi ? 0x1p-8f : 0x1p-20f;          // hi piece counts 4096 * 2^-20
+  r.corr = hi ? -(float)(1 << 22) * 0x1p-8f : 0.f;  // eight biases of 2^31 = 2^22 * 4096
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// Exact wave64 sums Sa, Sb of two per-lane integers (|v| < 2^28); returns RN(Sa * 2^-20) and
+// RN(Sb * 2^-20) (= (float)(int64 sum) * 2^-20, one rounding) in EVERY lane, VALU only:
+//   3 DPP butterflies in int32 (8-lane sums < 2^31); bias by 2^31 and keep one 12/20-bit piece per
+//   lane, so the xor-8/16/32 steps (row_ror:8, v_permlane16_swap, v_permlane32_swap) run on a single
+//   register; each piece total (< 2^23) converts to fp32 exactly, is scaled exactly, and lo + hi is
+//   ONE fp32 addition of two exact terms, i.e. the correctly rounded sum.
+__device__ __forceinline__ void wave_sum2_exact(int a, int b, const RedLane& rl, float& fa, float& fb) {
   a = xor_add_dpp(a, 0xB1);  // quad_perm [1,0,3,2]
   b = xor_add_dpp(b, 0xB1);
   a = xor_add_dpp(a, 0x4E);  // quad_perm [2,3,0,1]
   b = xor_add_dpp(b, 0x4E);
   a = xor_add_dpp(a, 0x141);  // row_half_mirror -> 8-lane sums
   b = xor_add_dpp(b, 0x141);
-  int alo = a & 0xfff, ahi = a >> 12, blo = b & 0xfff, bhi = b >> 12;
-  alo = xor_add_dpp(alo, 0x140);  // row_mirror -> 16-lane sums
-  ahi = xor_add_dpp(ahi, 0x140);
-  blo = xor_add_dpp(blo, 0x140);
-  bhi = xor_add_dpp(bhi, 0x140);
-  alo = xor16_add(alo);
-  ahi = xor16_add(ahi);
-  blo = xor16_add(blo);
-  bhi = xor16_add(bhi);
-  alo = xor32_add(alo);
-  ahi = xor32_add(ahi);
-  blo = xor32_add(blo);
-  bhi = xor32_add(bhi);
-  fa = (float)__dadd_rn(__dmul_rn((double)ahi, 4096.0), (double)alo);
-  fb = (float)__dadd_rn(__dmul_rn((double)bhi, 4096.0), (double)blo);
+  const uint32_t v = (uint32_t)(rl.take_b ? b : a) ^ 0x80000000u;
+  int x = (int)__builtin_amdgcn_ubfe(v, rl.off, rl.wid);
+  x = xor_add_dpp(x, 0x128);  // row_ror:8 -> 16-lane sums (lane & 3 preserved)
+  x = xor16_add(x);
+  x = xor32_add(x);
+  const float t = __fmaf_rn((float)x, rl.scale, rl.corr);  // exact
+  fa = quad_bcast<0x55>(t) + quad_bcast<0x00>(t);
+  fb = quad_bcast<0xFF>(t) + quad_bcast<0xAA>(t);
 }
+
+// every lane of the wave holds the same point state, so loop exits are uniform: turning the
+// condition into a ballot makes the compiler emit scalar branches instead of exec-mask bookkeeping
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
 
 struct LkCall {
   PyrDesc P;  // prev pyramid (+ derivatives)
@@ -731,7 +755,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   constexpr int WIN = kLkWin, NP = 7, NL = kMaxLevels;
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
-  const float FLT_SCALE = 1.f / (1 << 20);
+  const RedLane rl = red_lane(lane);
   const bool on = lane < 63;
   const int row = on ? lane / 3 : 0;
   const int x0 = on ? (lane - row * 3) * NP : 0;
@@ -799,12 +823,9 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         sA12 += __mul24(pIx[L][k], pIy[L][k]);
         sA22 += __mul24(pIy[L][k], pIy[L][k]);
       }
-      float f11, f12, f22, fdummy;
-      wave_sum2_exact(sA11, sA12, f11, f12);
-      wave_sum2_exact(sA22, 0, f22, fdummy);
-      A11[L] = f11 * FLT_SCALE;
-      A12[L] = f12 * FLT_SCALE;
-      A22[L] = f22 * FLT_SCALE;
+      float fdummy;
+      wave_sum2_exact(sA11, sA12, rl, A11[L], A12[L]);  // already scaled by FLT_SCALE = 2^-20
+      wave_sum2_exact(sA22, 0, rl, A22[L], fdummy);
       const float D = A11[L] * A22[L] - A12[L] * A12[L];
       const float minEig =
           (A22[L] + A11[L] - sqrtf((A11[L] - A22[L]) * (A11[L] - A22[L]) + 4.f * A12[L] * A12[L])) /
@@ -838,7 +859,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       nextY = np.y * 2.f;
     }
     np = make_float2(nextX, nextY);
-    if (!win_ok[L] || !eig_ok[L]) {
+    if (wave_any(!win_ok[L] || !eig_ok[L])) {
       if (L == 0) st = 0;
       continue;
     }
@@ -855,13 +876,13 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
     for (int j = 0; j < c.max_count; j++) {
       const float flX = floorf(nextX), flY = floorf(nextY);
       const int inextX = (int)flX, inextY = (int)flY;
-      if (inextX < -WIN || inextX >= cols || inextY < -WIN || inextY >= rows) {
+      if (wave_any((inextX < -WIN) | (inextX >= cols) | (inextY < -WIN) | (inextY >= rows))) {
         if (L == 0) st = 0;
         break;
       }
       int offx = inextX - rx0, offy = inextY - ry0;
-      if ((unsigned)offx > (unsigned)(kLkRegW - (WIN + 1)) ||
-          (unsigned)offy > (unsigned)(kLkRegH - (WIN + 1))) {
+      if (wave_any(((unsigned)offx > (unsigned)(kLkRegW - (WIN + 1))) |
+                   ((unsigned)offy > (unsigned)(kLkRegH - (WIN + 1))))) {
         uint32_t reg[(kLkRegDw + 63) / 64];  // the window drifted out of the staged region
         lk_region_load(J, stride, rows, inextX, inextY, lane, rx0, ry0, reg);
         lk_region_store(regJ, lane, reg);
@@ -897,18 +918,20 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         sb2 += __mul24(diff, pIy[L][k]);
       }
       float b1, b2;
-      wave_sum2_exact(sb1, sb2, b1, b2);
-      b1 *= FLT_SCALE;
-      b2 *= FLT_SCALE;
+      wave_sum2_exact(sb1, sb2, rl, b1, b2);  // already scaled by FLT_SCALE
       const float dx = (A12[L] * b2 - A22[L] * b1) * Dinv[L];
       const float dy = (A12[L] * b1 - A11[L] * b2) * Dinv[L];
       nextX += dx;
       nextY += dy;
       np = make_float2(nextX + halfWin, nextY + halfWin);
-      if ((double)dx * (double)dx + (double)dy * (double)dy <= c.eps2) break;
-      if (j > 0 && (double)fabsf(dx + prevDx) < 0.01 && (double)fabsf(dy + prevDy) < 0.01) {
-        np.x -= dx * 0.5f;
-        np.y -= dy * 0.5f;
+      const bool conv = (double)dx * (double)dx + (double)dy * (double)dy <= c.eps2;
+      // (double)|x| < 0.01  <=>  |x| <= 0.01f: 0.01f is the largest float below the real 0.01
+      const bool osc = (j > 0) & (fabsf(dx + prevDx) <= 0.01f) & (fabsf(dy + prevDy) <= 0.01f);
+      if (wave_any(conv | osc)) {
+        if (!conv) {
+          np.x -= dx * 0.5f;
+          np.y -= dy * 0.5f;
+        }
         break;
       }
       prevDx = dx;
