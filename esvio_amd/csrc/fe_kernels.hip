@@ -682,12 +682,14 @@ template <int CTRL>
 __device__ __forceinline__ float quad_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
-// Exact wave64 sums Sa, Sb of two per-lane integers (|v| < 2^28); returns RN(Sa * 2^-20) and
+// Exact wave64 sums Sa, Sb of two per-lane integers (|v| < 2^28), each passed in with kRedSeed
+// (2^28) added so that the 8-lane sums carry a bias of 2^31; returns RN(Sa * 2^-20) and
 // RN(Sb * 2^-20) (= (float)(int64 sum) * 2^-20, one rounding) in EVERY lane, VALU only:
-//   3 DPP butterflies in int32 (8-lane sums < 2^31); bias by 2^31 and keep one 12/20-bit piece per
+//   3 DPP butterflies in uint32 (biased 8-lane sums in (0, 2^32)); keep one 12/20-bit piece per
 //   lane, so the xor-8/16/32 steps (row_ror:8, v_permlane16_swap, v_permlane32_swap) run on a single
 //   register; each piece total (< 2^23) converts to fp32 exactly, is scaled exactly, and lo + hi is
 //   ONE fp32 addition of two exact terms, i.e. the correctly rounded sum.
+constexpr int kRedSeed = 1 << 28;
 __device__ __forceinline__ void wave_sum2_exact(int a, int b, const RedLane& rl, float& fa, float& fb) {
   a = xor_add_dpp(a, 0xB1);  // quad_perm [1,0,3,2]
   b = xor_add_dpp(b, 0xB1);
@@ -695,7 +697,7 @@ __device__ __forceinline__ void wave_sum2_exact(int a, int b, const RedLane& rl,
   b = xor_add_dpp(b, 0x4E);
   a = xor_add_dpp(a, 0x141);  // row_half_mirror -> 8-lane sums
   b = xor_add_dpp(b, 0x141);
-  const uint32_t v = (uint32_t)(rl.take_b ? b : a) ^ 0x80000000u;
+  const uint32_t v = (uint32_t)(rl.take_b ? b : a);
   int x = (int)__builtin_amdgcn_ubfe(v, rl.off, rl.wid);
   x = xor_add_dpp(x, 0x128);  // row_ror:8 -> 16-lane sums (lane & 3 preserved)
   x = xor16_add(x);
@@ -705,9 +707,21 @@ __device__ __forceinline__ void wave_sum2_exact(int a, int b, const RedLane& rl,
   fb = quad_bcast<0xFF>(t) + quad_bcast<0xAA>(t);
 }
 
+typedef short ss2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) {  // {(int16)lo, (int16)hi}
+  return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {  // v_dot2_i32_i16
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b), c, false);
+}
+
 // every lane of the wave holds the same point state, so loop exits are uniform: turning the
 // condition into a ballot makes the compiler emit scalar branches instead of exec-mask bookkeeping
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+// ... and combining several tests as ballot masks keeps the combination on the scalar unit
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ lanemask_t bal(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 
 struct LkCall {
   PyrDesc P;  // prev pyramid (+ derivatives)
@@ -752,18 +766,21 @@ __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
 // one calcOpticalFlowPyrLK call for one point; returns nextPts[pt] and status
 __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, const float2 init,
                                          uint32_t* regJ, int lane, float2& np_out, int& st_out) {
-  constexpr int WIN = kLkWin, NP = 7, NL = kMaxLevels;
+  constexpr int WIN = kLkWin, NP = 7, NPP = (NP + 1) / 2, NL = kMaxLevels;
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
   const RedLane rl = red_lane(lane);
   const bool on = lane < 63;
   const int row = on ? lane / 3 : 0;
   const int x0 = on ? (lane - row * 3) * NP : 0;
+  const int lane_bo = row * kLkRegW + x0;  // this lane's byte offset inside a staged window
 
   // ---- phase A: the previous-image side of EVERY level depends only on prevPts, so all
   // levels' patches (I, Ix, Iy in registers) and 2x2 matrices are built up front with the
   // global loads of all levels in flight together (one memory round trip instead of one per level)
-  int pI[NL][NP], pIx[NL][NP], pIy[NL][NP];
+  // the patch is kept as packed int16 pairs {px 2m, px 2m+1} (the 8th half is zero), the form the
+  // v_dot2 / v_pk iteration below consumes
+  uint32_t pIp[NL][NPP], pIxp[NL][NPP], pIyp[NL][NPP];
   bool win_ok[NL], eig_ok[NL];
   float A11[NL], A12[NL], A22[NL], Dinv[NL];
   {
@@ -803,7 +820,9 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
 #pragma unroll
     for (int L = 0; L < NL; L++) {
       if (L > c.max_level) continue;
-      int sA11 = 0, sA12 = 0, sA22 = 0;  // 7 terms <= 2^24 each
+      int sA11 = kRedSeed, sA12 = kRedSeed, sA22 = kRedSeed;  // + 7 terms <= 2^24 each
+      int pI[NP + 1], pIx[NP + 1], pIy[NP + 1];
+      pI[NP] = pIx[NP] = pIy[NP] = 0;
 #pragma unroll
       for (int k = 0; k < NP; k++) {
         const int ival = CV_DESCALE(__mul24(t0[L][k], w00[L]) + __mul24(t0[L][k + 1], w01[L]) +
@@ -816,16 +835,22 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         const int iyval = CV_DESCALE(__mul24(g0[L][k] >> 16, w00[L]) + __mul24(g0[L][k + 1] >> 16, w01[L]) +
                                          __mul24(g1[L][k] >> 16, w10[L]) + __mul24(g1[L][k + 1] >> 16, w11[L]),
                                      W_BITS);
-        pI[L][k] = (int)(int16_t)ival;
-        pIx[L][k] = on ? (int)(int16_t)ixval : 0;
-        pIy[L][k] = on ? (int)(int16_t)iyval : 0;
-        sA11 += __mul24(pIx[L][k], pIx[L][k]);
-        sA12 += __mul24(pIx[L][k], pIy[L][k]);
-        sA22 += __mul24(pIy[L][k], pIy[L][k]);
+        pI[k] = (int)(int16_t)ival;
+        pIx[k] = on ? (int)(int16_t)ixval : 0;
+        pIy[k] = on ? (int)(int16_t)iyval : 0;
+        sA11 += __mul24(pIx[k], pIx[k]);
+        sA12 += __mul24(pIx[k], pIy[k]);
+        sA22 += __mul24(pIy[k], pIy[k]);
+      }
+#pragma unroll
+      for (int m = 0; m < NPP; m++) {
+        pIp[L][m] = pack16(pI[2 * m], pI[2 * m + 1]);
+        pIxp[L][m] = pack16(pIx[2 * m], pIx[2 * m + 1]);
+        pIyp[L][m] = pack16(pIy[2 * m], pIy[2 * m + 1]);
       }
       float fdummy;
       wave_sum2_exact(sA11, sA12, rl, A11[L], A12[L]);  // already scaled by FLT_SCALE = 2^-20
-      wave_sum2_exact(sA22, 0, rl, A22[L], fdummy);
+      wave_sum2_exact(sA22, kRedSeed, rl, A22[L], fdummy);
       const float D = A11[L] * A22[L] - A12[L] * A12[L];
       const float minEig =
           (A22[L] + A11[L] - sqrtf((A11[L] - A22[L]) * (A11[L] - A22[L]) + 4.f * A12[L] * A12[L])) /
@@ -836,6 +861,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   }
 
   // ---- phase B: coarse-to-fine iterations
+  const float eps_lo = (float)(c.eps2 * (1.0 - 0x1p-20)), eps_hi = (float)(c.eps2 * (1.0 + 0x1p-20));
   float2 np = (c.flags & 4) ? init : make_float2(0.f, 0.f);  // nextPts[ptidx]
   int st = 1;
 #pragma unroll
@@ -872,50 +898,67 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       lk_region_load(J, stride, rows, (int)floorf(nextX), (int)floorf(nextY), lane, rx0, ry0, reg);
       lk_region_store(regJ, lane, reg);
     }
+    int cbo = lane_bo - rx0 - ry0 * kLkRegW;  // window origin (x,y) -> this lane's byte in regJ
     float prevDx = 0.f, prevDy = 0.f;
     for (int j = 0; j < c.max_count; j++) {
       const float flX = floorf(nextX), flY = floorf(nextY);
       const int inextX = (int)flX, inextY = (int)flY;
-      if (wave_any((inextX < -WIN) | (inextX >= cols) | (inextY < -WIN) | (inextY >= rows))) {
-        if (L == 0) st = 0;
-        break;
-      }
-      int offx = inextX - rx0, offy = inextY - ry0;
-      if (wave_any(((unsigned)offx > (unsigned)(kLkRegW - (WIN + 1))) |
-                   ((unsigned)offy > (unsigned)(kLkRegH - (WIN + 1))))) {
+      const int offx = inextX - rx0, offy = inextY - ry0;
+      const lanemask_t outside = bal((unsigned)(inextX + WIN) >= (unsigned)(cols + WIN)) |
+                                 bal((unsigned)(inextY + WIN) >= (unsigned)(rows + WIN));
+      const lanemask_t drifted = bal((unsigned)offx > (unsigned)(kLkRegW - (WIN + 1))) |
+                                 bal((unsigned)offy > (unsigned)(kLkRegH - (WIN + 1)));
+      if (__builtin_expect((outside | drifted) != 0, 0)) {  // one rarely taken branch for both
+        if (outside) {
+          if (L == 0) st = 0;
+          break;
+        }
         uint32_t reg[(kLkRegDw + 63) / 64];  // the window drifted out of the staged region
         lk_region_load(J, stride, rows, inextX, inextY, lane, rx0, ry0, reg);
         lk_region_store(regJ, lane, reg);
-        offx = inextX - rx0;
-        offy = inextY - ry0;
+        cbo = lane_bo - rx0 - ry0 * kLkRegW;
       }
-      const float fa = nextX - flX, fb = nextY - flY;
-      const int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-      const int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
-      const int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
-      const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-      // 8 bytes of two consecutive staged rows: 3 aligned dwords per row + funnel shift
-      const int bo = (row + offy) * kLkRegW + offx + x0;
+      // bilinear weights: rint(w * 2^14) for w in [0,1] is the low half of the bit pattern of
+      // fma(w, 2^14, 2^23) (one RNE rounding to an integer), which v_perm packs straight into
+      // the int16 pairs {iw00,iw01} {iw10,iw11}
+      const float fa = nextX - flX, fb = nextY - flY, ofa = 1.f - fa, ofb = 1.f - fb;
+      const float kMagic = 8388608.f, kW = (float)(1 << W_BITS);
+      const uint32_t b00 = __float_as_uint(__fmaf_rn(ofa * ofb, kW, kMagic));
+      const uint32_t b01 = __float_as_uint(__fmaf_rn(fa * ofb, kW, kMagic));
+      const uint32_t b10 = __float_as_uint(__fmaf_rn(ofa * fb, kW, kMagic));
+      const uint32_t iw11 = ((1u << W_BITS) + 3u * 0x4B000000u) - (b00 + b01 + b10);
+      const uint32_t W0 = __builtin_amdgcn_perm(b01, b00, 0x05040100u);
+      const uint32_t W1 = __builtin_amdgcn_perm(iw11, b10, 0x05040100u);
+      // 8 bytes of two consecutive staged rows: 3 aligned dwords per row + funnel shift (unaligned
+      // ds_read_b64 would do it in one instruction, but measured slower)
+      const int bo = __mul24(inextY, kLkRegW) + (inextX + cbo);
       const uint32_t* rp = regJ + (bo >> 2);
       const uint32_t sh = (uint32_t)bo & 3u;
       const uint32_t a0 = rp[0], a1 = rp[1], a2 = rp[2];
       const uint32_t c0 = rp[kLkRegW / 4], c1 = rp[kLkRegW / 4 + 1], c2 = rp[kLkRegW / 4 + 2];
       const uint32_t w0[2] = {__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh)};
       const uint32_t w1[2] = {__builtin_amdgcn_alignbyte(c1, c0, sh), __builtin_amdgcn_alignbyte(c2, c1, sh)};
-      int q0[NP + 1], q1[NP + 1];
-#pragma unroll
-      for (int k = 0; k <= NP; k++) {
-        q0[k] = (int)((w0[k >> 2] >> (8 * (k & 3))) & 0xffu);
-        q1[k] = (int)((w1[k >> 2] >> (8 * (k & 3))) & 0xffu);
-      }
-      int sb1 = 0, sb2 = 0;  // 7 terms of <= 2^25 each
+      // per pixel: the two horizontally adjacent bytes of each row as an int16 pair (v_perm_b32)
+      // against the packed weight pairs (v_dot2_i32_i16), rounding constant as the accumulator seed
+      uint32_t t[NP + 1];
 #pragma unroll
       for (int k = 0; k < NP; k++) {
-        const int t = __mul24(q0[k], iw00) + __mul24(q0[k + 1], iw01) + __mul24(q1[k], iw10) +
-                      __mul24(q1[k + 1], iw11);
-        const int diff = CV_DESCALE(t, W_BITS - 5) - pI[L][k];
-        sb1 += __mul24(diff, pIx[L][k]);
-        sb2 += __mul24(diff, pIy[L][k]);
+        const uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
+        const uint32_t p0 = __builtin_amdgcn_perm(w0[1], w0[0], sel);
+        const uint32_t p1 = __builtin_amdgcn_perm(w1[1], w1[0], sel);
+        t[k] = (uint32_t)sdot2(p1, W1, sdot2(p0, W0, 1 << (W_BITS - 5 - 1)));  // in [1, 2^22]
+      }
+      t[NP] = 0;
+      // CV_DESCALE(.., 9) of two pixels at once: bytes 1..2 of each sum, packed shift by one more
+      // bit, packed subtract of the patch, dot with the packed derivatives
+      int sb1 = kRedSeed, sb2 = kRedSeed;  // + 7 terms of <= 2^25 each
+#pragma unroll
+      for (int m = 0; m < NPP; m++) {
+        const uint32_t hi8 = __builtin_amdgcn_perm(t[2 * m + 1], t[2 * m], 0x06050201u);
+        const us2 val = __builtin_bit_cast(us2, hi8) >> (unsigned short)1;
+        const ss2 diff = __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]);
+        sb1 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, pIxp[L][m]), sb1, false);
+        sb2 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, pIyp[L][m]), sb2, false);
       }
       float b1, b2;
       wave_sum2_exact(sb1, sb2, rl, b1, b2);  // already scaled by FLT_SCALE
@@ -924,10 +967,18 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       nextX += dx;
       nextY += dy;
       np = make_float2(nextX + halfWin, nextY + halfWin);
-      const bool conv = (double)dx * (double)dx + (double)dy * (double)dy <= c.eps2;
+      // |delta|^2 <= eps^2 is decided in fp64 by OpenCV; an fp32 evaluation (relative error
+      // < 2^-22) settles it unless it lands within 2^-20 of the threshold
+      const float d2 = __fmaf_rn(dx, dx, dy * dy);
+      lanemask_t conv = bal(d2 <= eps_lo);
+      if (__builtin_expect((bal(d2 > eps_lo) & bal(d2 < eps_hi)) != 0, 0)) {
+        asm volatile("; fp64 tie-break" ::: "memory");  // keep this a branch, not a select
+        conv = bal((double)dx * (double)dx + (double)dy * (double)dy <= c.eps2);
+      }
       // (double)|x| < 0.01  <=>  |x| <= 0.01f: 0.01f is the largest float below the real 0.01
-      const bool osc = (j > 0) & (fabsf(dx + prevDx) <= 0.01f) & (fabsf(dy + prevDy) <= 0.01f);
-      if (wave_any(conv | osc)) {
+      const lanemask_t osc =
+          j > 0 ? bal(fabsf(dx + prevDx) <= 0.01f) & bal(fabsf(dy + prevDy) <= 0.01f) : 0;
+      if (conv | osc) {
         if (!conv) {
           np.x -= dx * 0.5f;
           np.y -= dy * 0.5f;
