@@ -97,8 +97,10 @@ struct esvio_fe_ctx {
   int dev = 0;
   hipStream_t stream = nullptr;   // main stream
   hipStream_t stream2 = nullptr;  // prefetch stream (next batch's SAE update / images)
+  hipStream_t stream3 = nullptr;  // speculative temporal LK of the next frame
   hipStream_t cur = nullptr;      // the stream the helpers currently enqueue on
   hipEvent_t ev_planes_free = nullptr, ev_prefetch_done = nullptr, ev_arc_done = nullptr;
+  hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr;
   std::string err;
   int W = 0, H = 0;
   uint32_t P = 0;
@@ -151,9 +153,17 @@ struct esvio_fe_ctx {
   uint8_t *d_stA = nullptr, *d_stB = nullptr;
   // second LK result set + newly selected corners (stereo LK of the new corners runs as its own
   // launch after the speculative stereo LK of the temporal survivors)
-  float2 *d_new = nullptr, *d_ptsB2 = nullptr, *d_ptsC2 = nullptr;
+  float2 *d_new = nullptr, *d_ptsB2 = nullptr, *d_ptsC2 = nullptr;  // d_new: [kept | new corners]
   uint8_t *d_stA2 = nullptr, *d_stB2 = nullptr;
   int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total [2]=#candidates
+  // ---- speculative temporal LK of the next frame (replay mode): once this frame's kept points
+  // and new corners are final, next frame's calcOpticalFlowPyrLK(cur -> next) pair is launched on
+  // stream3 against the prefetched pyramids, so it overlaps this frame's stereo LK and host tail
+  uint8_t* d_spec = nullptr;  // [ptsB | ptsC | stA | stB] of that launch
+  uint8_t* h_spec = nullptr;  // pinned mirror
+  size_t spec_bytes = 0;
+  bool spec_valid = false;
+  int spec_n = 0;             // number of points of that launch (= the next frame's prev_pts.size())
   // arc / select
   uint8_t* d_flags = nullptr;
   // per-block ordered candidate lists written by k_arc; two sets so that the Arc* of a prefetched
@@ -745,10 +755,11 @@ struct Pin {
   float2 *ptsB, *ptsC;    // set 1
   uint8_t *stA, *stB;
   int* counts;            // [16]
-  float2* news;           // newly selected corners
+  float2* news;           // [kept points (as uploaded) | newly selected corners]
   float2 *ptsB2, *ptsC2;  // set 2
   uint8_t *stA2, *stB2;
   float2* ptsA;           // H2D prev_pts / survivors
+  float2* kept;           // H2D kept points for the speculative next-frame LK
   uint32_t* mask;         // H2D H*wpr words
 };
 
@@ -770,6 +781,8 @@ Pin pin_of(esvio_fe_ctx* c) {
   b += (L.total + 255) / 256 * 256;
   p.ptsA = (float2*)b;
   b += (M * 8 + 255) / 256 * 256;
+  p.kept = (float2*)b;
+  b += (M * 8 + 255) / 256 * 256;
   p.mask = (uint32_t*)b;
   return p;
 }
@@ -777,7 +790,7 @@ Pin pin_of(esvio_fe_ctx* c) {
 size_t pin_bytes(const esvio_fe_config& cfg) {
   const size_t M = std::max(cfg.max_cnt, 1);
   const ResLayout L = res_layout(M);
-  return (L.total + 255) / 256 * 256 + (M * 8 + 255) / 256 * 256 +
+  return (L.total + 255) / 256 * 256 + 2 * ((M * 8 + 255) / 256 * 256) +
          (size_t)cfg.height * ((cfg.width + 31) / 32) * 4 + 256;
 }
 
@@ -881,6 +894,15 @@ hipError_t sync_main(esvio_fe_ctx* c) {
   return hipStreamSynchronize(c->stream);
 }
 
+hipError_t sync_event(hipEvent_t ev) {
+  for (int i = 0; i < 20000; i++) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return hipSuccess;
+    if (e != hipErrorNotReady) return e;
+  }
+  return hipEventSynchronize(ev);
+}
+
 // ---------------------------------------------------------------- next-batch prefetch
 // Enqueue the SAE update, time surfaces and pyramids of the batch announced with
 // esvio_fe_set_next_batch on the second stream; they overlap the rest of the current frame (stereo
@@ -938,6 +960,36 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
   } while (0);
   c->cur = c->stream;
   return rc;
+}
+
+// Launch the NEXT frame's temporal forward/backward LK (feature_tracker.cpp:410,417 of the next
+// call) now: its inputs are final once this frame's kept points (uploaded to d_new[0..n_kept)) and
+// new corners (written by k_select behind them, total count in d_counts[1]) are known, and the next
+// frame's pyramids are already being built on the prefetch stream.
+int enqueue_spec_temporal(esvio_fe_ctx* c, int n_kept, bool with_new) {
+  const size_t M = std::max(c->cfg.max_cnt, 1);
+  const size_t stM = (M + 63) / 64 * 64;
+  HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_pts_ready, 0));
+  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_prefetch_done, 0));
+  float2* B = (float2*)c->d_spec;
+  float2* Cb = B + M;
+  uint8_t* sA = c->d_spec + M * 16;
+  uint8_t* sB = sA + stM;
+  const PyrDesc& P = c->pyr[c->slot_curL].d;
+  const PyrDesc& N = c->pyr[c->pf_slotL].d;
+  const int* n_ptr = with_new ? c->d_counts + 1 : nullptr;
+  const int n_max = with_new ? (int)M : n_kept;
+  LkArgs f = make_lk(P, N, c->d_new, nullptr, B, sA, n_ptr, n_max, 3, 30, 0.01, 0);
+  LkArgs b = make_lk(N, P, nullptr, nullptr, nullptr, nullptr, n_ptr, n_max, 1, 30, 0.01,
+                     ESVIO_FE_LK_USE_INITIAL_FLOW);
+  c->cur = c->stream3;
+  run_lk(c, f, c->cfg.flow_back ? &b : nullptr, Cb, sB);
+  c->cur = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->h_spec, c->d_spec, c->spec_bytes, hipMemcpyDeviceToHost, c->stream3));
+  HIPCHK(c, hipEventRecord(c->ev_spec_done, c->stream3));
+  c->spec_valid = true;
+  return 0;
 }
 
 // ---------------------------------------------------------------- trackEvent
@@ -1039,29 +1091,54 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     return prefetch_next(c, main_reads_planes);
   };
 
+  // a speculative launch of this very temporal LK may have been made by the previous call
+  bool use_spec = false;
+  if (c->spec_valid) {
+    c->spec_valid = false;
+    use_spec = c->cur_prefetched && (int)c->prev_pts.size() == c->spec_n;
+    if (!use_spec) HIPCHK(c, hipStreamSynchronize(c->stream3));
+  }
   if (c->prev_pts.size() > 0) {  // :405-437
     const int n = (int)c->prev_pts.size();
-    std::memcpy(pin.ptsA, c->prev_pts.data(), (size_t)n * 8);
-    HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, c->cur));
-    // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
-    // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
-    LkArgs f = make_lk(prevL, curL, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n, 3, 30, 0.01, 0);
-    LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
-                       ESVIO_FE_LK_USE_INITIAL_FLOW);
-    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_temporal_bytes, hipMemcpyDeviceToHost,
-                             c->cur));
-    if (int rc = early_work()) return rc;
-    lap(1);
-    HIPCHK(c, sync_main(c));
-    lap(2);
-    std::vector<uint8_t> status(pin.stA, pin.stA + n);
+    const uint8_t *t_stA, *t_stB;
+    const P2f *t_ptsB, *t_ptsC;
+    if (use_spec) {
+      if (int rc = early_work()) return rc;
+      lap(1);
+      HIPCHK(c, sync_event(c->ev_spec_done));
+      lap(2);
+      const size_t stM = ((size_t)std::max(M, 1) + 63) / 64 * 64;
+      t_ptsB = (const P2f*)c->h_spec;
+      t_ptsC = (const P2f*)(c->h_spec + (size_t)std::max(M, 1) * 8);
+      t_stA = c->h_spec + (size_t)std::max(M, 1) * 16;
+      t_stB = t_stA + stM;
+    } else {
+      std::memcpy(pin.ptsA, c->prev_pts.data(), (size_t)n * 8);
+      HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, c->cur));
+      // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
+      // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
+      LkArgs f = make_lk(prevL, curL, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n, 3, 30, 0.01, 0);
+      LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
+                         ESVIO_FE_LK_USE_INITIAL_FLOW);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
+      HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_temporal_bytes, hipMemcpyDeviceToHost,
+                               c->cur));
+      if (int rc = early_work()) return rc;
+      lap(1);
+      HIPCHK(c, sync_main(c));
+      lap(2);
+      t_ptsB = (const P2f*)pin.ptsB;
+      t_ptsC = (const P2f*)pin.ptsC;
+      t_stA = pin.stA;
+      t_stB = pin.stB;
+    }
+    std::vector<uint8_t> status(t_stA, t_stA + n);
     c->cur_pts.resize(n);
-    std::memcpy(c->cur_pts.data(), pin.ptsB, (size_t)n * 8);
+    std::memcpy(c->cur_pts.data(), t_ptsB, (size_t)n * 8);
     if (cfg.flow_back) {
-      const P2f* reverse_pts = (const P2f*)pin.ptsC;
+      const P2f* reverse_pts = t_ptsC;
       for (int i = 0; i < n; i++) {
-        if (status[i] && pin.stB[i] && pt_distance(c->prev_pts[i], reverse_pts[i]) <= 0.5)
+        if (status[i] && t_stB[i] && pt_distance(c->prev_pts[i], reverse_pts[i]) <= 0.5)
           status[i] = 1;
         else
           status[i] = 0;
@@ -1086,6 +1163,22 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->src_idx.resize(n_surv);
   for (int i = 0; i < n_surv; i++) c->src_idx[i] = i;
   lap(3);
+  bool detect = false;
+  int n_kept = n_surv;
+  // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
+  // launched as soon as this frame's points are final
+  const bool will_spec = c->pf_valid;
+  auto upload_kept = [&]() -> int {
+    if (!will_spec || !n_kept) return 0;
+    std::memcpy(pin.kept, c->cur_pts.data(), (size_t)n_kept * 8);
+    HIPCHK(c, hipMemcpyAsync(c->d_new, pin.kept, (size_t)n_kept * 8, hipMemcpyHostToDevice, c->cur));
+    return 0;
+  };
+  if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
+    if (int rc = upload_kept()) return rc;
+    if (will_spec && n_kept)
+      if (int rc = enqueue_spec_temporal(c, n_kept, false)) return rc;
+  }
   if (n_surv) {
     std::memcpy(pin.ptsA, c->cur_pts.data(), (size_t)n_surv * 8);
     HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n_surv * 8, hipMemcpyHostToDevice,
@@ -1096,14 +1189,15 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
   }
 
-  bool detect = false;
-  int n_kept = n_surv;
   if (PUB_THIS_FRAME) {  // :442-469
     if (cfg.f_ransac) reject_with_f_event(c);
     lap(4);
     event_set_mask(c);
     n_kept = (int)c->cur_pts.size();
     const int n_max_cnt = M - n_kept;
+    if (int rc = upload_kept()) return rc;
+    if (n_max_cnt <= 0 && will_spec && n_kept)
+      if (int rc = enqueue_spec_temporal(c, n_kept, false)) return rc;
     if (n_max_cnt > 0) {
       detect = true;
       std::memcpy(pin.mask, c->mask_event.bits.data(), c->mask_event.bits.size() * 4);
@@ -1117,10 +1211,13 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
         launch_maskfilter(c->cur, cs.xy, cs.idx, cs.cnt, (uint32_t)((nL + kArcBlock - 1) / kArcBlock),
                           c->d_mask_bits, (c->W + 31) / 32);
       }
-      run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, 0, nullptr);
+      // new corners go behind the kept points: d_new = next frame's prev_pts
+      run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, n_kept, nullptr);
+      if (will_spec)
+        if (int rc = enqueue_spec_temporal(c, n_kept, true)) return rc;
       // stereo LK of the new corners only (count known on the device)
-      LkArgs f = make_lk(curL, curR, c->d_new, nullptr, c->d_ptsB2, c->d_stA2, c->d_counts, n_max_cnt,
-                         3, 30, 0.01, 0);
+      LkArgs f = make_lk(curL, curR, c->d_new + n_kept, nullptr, c->d_ptsB2, c->d_stA2, c->d_counts,
+                         n_max_cnt, 3, 30, 0.01, 0);
       LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, c->d_counts, n_max_cnt, 3, 30,
                          0.01, 0);
       run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC2, c->d_stB2);
@@ -1142,7 +1239,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       c->tr_cand += (uint64_t)pin.counts[2];
       c->tr_new += (uint64_t)n_new;
       c->tr_detect++;
-      const P2f* np = (const P2f*)pin.news;
+      const P2f* np = (const P2f*)pin.news + n_kept;
       for (int i = 0; i < n_new; i++) c->n_pts.push_back(np[i]);
     }
     for (auto& p : c->n_pts) {  // :463-468
@@ -1209,6 +1306,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->prev_pts = c->cur_pts;
   c->prev_un_pts_map.swap(c->cur_un_pts_map);
   c->prev_time = c->cur_time;
+  c->spec_n = (int)c->prev_pts.size();
   lap(7);
   c->phase_frames++;
   c->tr_surv += (uint64_t)n_surv;
@@ -1228,6 +1326,7 @@ const char* esvio_fe_last_error(esvio_fe_handle h) { return h ? h->err.c_str() :
 int esvio_fe_destroy(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   (void)hipSetDevice(c->dev);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->trace && c->phase_frames) {
@@ -1246,10 +1345,12 @@ int esvio_fe_destroy(esvio_fe_handle c) {
                   c->d_comp_idx, c->d_mask_bits, c->d_sel_idx, c->pyr[0].mem, c->pyr[1].mem,
                   c->pyr[2].mem, c->pyr[3].mem, c->pyr[4].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem,
                   c->raw[0][0].mem, c->raw[0][1].mem, c->raw[1][0].mem, c->raw[1][1].mem, c->d_lut,
-                  c->d_minmax, c->d_ev2};
+                  c->d_minmax, c->d_ev2, c->d_spec};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->h_spec) (void)hipHostFree(c->h_spec);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   for (auto& r : c->pending) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
@@ -1262,6 +1363,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->ev_planes_free) (void)hipEventDestroy(c->ev_planes_free);
   if (c->ev_prefetch_done) (void)hipEventDestroy(c->ev_prefetch_done);
   if (c->ev_arc_done) (void)hipEventDestroy(c->ev_arc_done);
+  if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
+  if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -1306,6 +1409,9 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_prefetch_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_arc_done, hipEventDisableTiming) != hipSuccess)
@@ -1332,6 +1438,13 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     c->d_ptsC2 = (float2*)(c->d_res + L.C2);
     c->d_stA2 = c->d_res + L.SA2;
     c->d_stB2 = c->d_res + L.SB2;
+  }
+  {
+    const size_t stM = (std::max<size_t>(M, 1) + 63) / 64 * 64;
+    c->spec_bytes = std::max<size_t>(M, 1) * 16 + 2 * stM;
+    if ((rc = dev_alloc(c, &c->d_spec, c->spec_bytes))) return bail(rc);
+    if (hipHostMalloc((void**)&c->h_spec, c->spec_bytes, hipHostMallocDefault) != hipSuccess)
+      return bail(ESVIO_FE_EHIP);
   }
   if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_sel_idx, M))) return bail(rc);
@@ -1362,8 +1475,9 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
 int esvio_fe_reset(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
-  c->nb_set = c->pf_valid = false;
+  c->nb_set = c->pf_valid = c->spec_valid = false;
   HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->cur));
   HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->cur));
   HIPCHK(c, hipStreamSynchronize(c->cur));
