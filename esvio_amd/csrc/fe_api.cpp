@@ -100,7 +100,7 @@ struct esvio_fe_ctx {
   hipStream_t stream3 = nullptr;  // speculative temporal LK of the next frame
   hipStream_t cur = nullptr;      // the stream the helpers currently enqueue on
   hipEvent_t ev_planes_free = nullptr, ev_prefetch_done = nullptr, ev_arc_done = nullptr;
-  hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr;
+  hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr, ev_sel_host = nullptr;
   std::string err;
   int W = 0, H = 0;
   uint32_t P = 0;
@@ -665,13 +665,12 @@ void event_set_mask(esvio_fe_ctx* c) {
 }
 
 std::vector<P2f> undistorted_pts(const std::vector<P2f>& pts, const esvio_fe_camera& cam) {  // :991
-  std::vector<P2f> un;
-  un.reserve(pts.size());
-  for (const P2f& p : pts) {
-    double b[3];
-    host::lift_projective(cam, (double)p.x, (double)p.y, b);
-    un.push_back(P2f{(float)(b[0] / b[2]), (float)(b[1] / b[2])});
-  }
+  const size_t n = pts.size();
+  std::vector<P2f> un(n);
+  if (!n) return un;
+  std::vector<double> lx(n), ly(n);
+  host::lift_projective_batch(cam, &pts[0].x, (int)n, lx.data(), ly.data());
+  for (size_t i = 0; i < n; i++) un[i] = P2f{(float)lx[i], (float)ly[i]};  // b[2] == 1.0
   return un;
 }
 
@@ -704,15 +703,19 @@ void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
   if (c->cur_pts.size() >= 8) {
     const esvio_fe_camera& cam = c->cfg.cam[0];
     const double FOCAL = c->cfg.focal_length;
-    std::vector<float> un_cur(c->cur_pts.size() * 2), un_prev(c->prev_pts.size() * 2);
-    for (unsigned int i = 0; i < c->prev_pts.size(); i++) {
-      double p[3];
-      host::lift_projective(cam, c->prev_pts[i].x, c->prev_pts[i].y, p);
-      un_prev[2 * i] = (float)(FOCAL * p[0] / p[2] + c->W / 2.0);
-      un_prev[2 * i + 1] = (float)(FOCAL * p[1] / p[2] + c->H / 2.0);
-      host::lift_projective(cam, c->cur_pts[i].x, c->cur_pts[i].y, p);
-      un_cur[2 * i] = (float)(FOCAL * p[0] / p[2] + c->W / 2.0);
-      un_cur[2 * i + 1] = (float)(FOCAL * p[1] / p[2] + c->H / 2.0);
+    const size_t n = c->prev_pts.size();
+    std::vector<float> un_cur(n * 2), un_prev(n * 2);
+    std::vector<double> lx(n), ly(n);
+    const double cx = c->W / 2.0, cy = c->H / 2.0;
+    host::lift_projective_batch(cam, &c->prev_pts[0].x, (int)n, lx.data(), ly.data());
+    for (size_t i = 0; i < n; i++) {  // p[2] == 1.0: x / 1.0 is exact
+      un_prev[2 * i] = (float)(FOCAL * lx[i] / 1.0 + cx);
+      un_prev[2 * i + 1] = (float)(FOCAL * ly[i] / 1.0 + cy);
+    }
+    host::lift_projective_batch(cam, &c->cur_pts[0].x, (int)n, lx.data(), ly.data());
+    for (size_t i = 0; i < n; i++) {
+      un_cur[2 * i] = (float)(FOCAL * lx[i] / 1.0 + cx);
+      un_cur[2 * i + 1] = (float)(FOCAL * ly[i] / 1.0 + cy);
     }
     std::vector<uint8_t> status(c->cur_pts.size());
     host::find_fundamental_mat(un_prev.data(), un_cur.data(), (int)c->cur_pts.size(),
@@ -966,10 +969,10 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
 // call) now: its inputs are final once this frame's kept points (uploaded to d_new[0..n_kept)) and
 // new corners (written by k_select behind them, total count in d_counts[1]) are known, and the next
 // frame's pyramids are already being built on the prefetch stream.
-int enqueue_spec_temporal(esvio_fe_ctx* c, int n_kept, bool with_new) {
+int enqueue_spec_temporal(esvio_fe_ctx* c, int n_kept, bool with_new, bool record_pts_ready = true) {
   const size_t M = std::max(c->cfg.max_cnt, 1);
   const size_t stM = (M + 63) / 64 * 64;
-  HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
+  if (record_pts_ready) HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_pts_ready, 0));
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_prefetch_done, 0));
   float2* B = (float2*)c->d_spec;
@@ -1098,12 +1101,16 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     use_spec = c->cur_prefetched && (int)c->prev_pts.size() == c->spec_n;
     if (!use_spec) HIPCHK(c, hipStreamSynchronize(c->stream3));
   }
+  // on a frame that publishes nothing the host has little to do: the ~12 launches of the next
+  // batch's prefetch are then enqueued after the stereo LK, in its shadow
+  const bool defer_early = use_spec && !PUB_THIS_FRAME;
   if (c->prev_pts.size() > 0) {  // :405-437
     const int n = (int)c->prev_pts.size();
     const uint8_t *t_stA, *t_stB;
     const P2f *t_ptsB, *t_ptsC;
     if (use_spec) {
-      if (int rc = early_work()) return rc;
+      if (!defer_early)
+        if (int rc = early_work()) return rc;
       lap(1);
       HIPCHK(c, sync_event(c->ev_spec_done));
       lap(2);
@@ -1152,7 +1159,8 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     reduce_vector(c->track_cnt, status);
   }
 
-  if (int rc = early_work()) return rc;  // (no previous points: nothing was synchronised above)
+  if (!defer_early)
+    if (int rc = early_work()) return rc;  // (no previous points: nothing was synchronised above)
   for (auto& n : c->track_cnt) n++;  // :439-440
 
   // ---- speculative stereo LK of every temporal survivor (a superset of the points that survive
@@ -1167,7 +1175,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   int n_kept = n_surv;
   // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
   // launched as soon as this frame's points are final
-  const bool will_spec = c->pf_valid;
+  const bool will_spec = c->pf_valid || (defer_early && c->nb_set);
   auto upload_kept = [&]() -> int {
     if (!will_spec || !n_kept) return 0;
     std::memcpy(pin.kept, c->cur_pts.data(), (size_t)n_kept * 8);
@@ -1176,8 +1184,12 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   };
   if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
     if (int rc = upload_kept()) return rc;
-    if (will_spec && n_kept)
-      if (int rc = enqueue_spec_temporal(c, n_kept, false)) return rc;
+    if (will_spec && n_kept) {
+      if (defer_early)
+        HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
+      else if (int rc = enqueue_spec_temporal(c, n_kept, false))
+        return rc;
+    }
   }
   if (n_surv) {
     std::memcpy(pin.ptsA, c->cur_pts.data(), (size_t)n_surv * 8);
@@ -1187,6 +1199,11 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                        0.01, 0);
     LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
     run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
+  }
+  if (defer_early) {
+    if (int rc = early_work()) return rc;
+    if (c->pf_valid && n_kept)
+      if (int rc = enqueue_spec_temporal(c, n_kept, false, false)) return rc;
   }
 
   if (PUB_THIS_FRAME) {  // :442-469
@@ -1215,6 +1232,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, n_kept, nullptr);
       if (will_spec)
         if (int rc = enqueue_spec_temporal(c, n_kept, true)) return rc;
+      // the selection result goes to the host right away (counts .. new corners of the result
+      // block), so that the left-camera bookkeeping below runs under the stereo LK of the new corners
+      {
+        const ResLayout RL = res_layout((size_t)std::max(M, 1));
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + RL.CNT, c->d_res + RL.CNT, RL.B2 - RL.CNT,
+                                 hipMemcpyDeviceToHost, c->cur));
+        HIPCHK(c, hipEventRecord(c->ev_sel_host, c->cur));
+      }
       // stereo LK of the new corners only (count known on the device)
       LkArgs f = make_lk(curL, curR, c->d_new + n_kept, nullptr, c->d_ptsB2, c->d_stA2, c->d_counts,
                          n_max_cnt, 3, 30, 0.01, 0);
@@ -1226,10 +1251,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   if (n_surv || detect)
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->cur));
   lap(5);
-  HIPCHK(c, sync_main(c));
-  lap(6);
-  if ((n_surv || detect) && pin.counts[3] != 0)
-    return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
+  if (detect) HIPCHK(c, sync_event(c->ev_sel_host));
 
   int n_new = 0;
   if (PUB_THIS_FRAME) {
@@ -1250,6 +1272,11 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   }
   c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);  // :470-473
   c->pts_velocity = pts_velocity_fn(c, c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map);
+  lap(7);
+  HIPCHK(c, sync_main(c));  // stereo LK results
+  lap(6);
+  if ((n_surv || detect) && pin.counts[3] != 0)
+    return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
 
   {  // :475-575
     c->ids_right.clear();
@@ -1365,6 +1392,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->ev_arc_done) (void)hipEventDestroy(c->ev_arc_done);
   if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
   if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
+  if (c->ev_sel_host) (void)hipEventDestroy(c->ev_sel_host);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -1412,6 +1440,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_sel_host, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_prefetch_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_arc_done, hipEventDisableTiming) != hipSuccess)

@@ -8,6 +8,16 @@
 #include <cmath>
 #include <cstring>
 
+// The per-point loops below are written over plain arrays so that the compiler vectorises them;
+// an AVX2 clone is selected at load time where the CPU has it.  Every element still goes through
+// the same IEEE operations in the same order (no contraction, no reassociation), so results do not
+// depend on the vector width.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ESVIO_SIMD_CLONES
+#else
+#define ESVIO_SIMD_CLONES __attribute__((target_clones("avx2", "default")))
+#endif
+
 namespace esvio {
 namespace host {
 
@@ -55,6 +65,44 @@ void lift_projective(const esvio_fe_camera& c, double u, double v, double out[3]
   out[0] = xu;
   out[1] = yu;
   out[2] = 1.0;
+}
+
+// liftProjective of n points (uv interleaved float pairs) -> xu[], yu[] (z = 1): the 8 fixed-point
+// iterations run over all points together
+ESVIO_SIMD_CLONES
+void lift_projective_batch(const esvio_fe_camera& c, const float* uv, int n, double* __restrict xu,
+                           double* __restrict yu) {
+  const double ifx = 1.0 / c.fx, ify = 1.0 / c.fy, ox = -c.cx / c.fx, oy = -c.cy / c.fy;
+  const double k1 = c.k1, k2 = c.k2, p1 = c.p1, p2 = c.p2;
+  const bool no_distortion = k1 == 0.0 && k2 == 0.0 && p1 == 0.0 && p2 == 0.0;
+  constexpr int B = 64;
+  double xd[B], yd[B], x[B], y[B];
+  for (int i0 = 0; i0 < n; i0 += B) {
+    const int m = std::min(B, n - i0);
+    for (int i = 0; i < m; i++) {
+      xd[i] = ifx * (double)uv[2 * (i0 + i)] + ox;
+      yd[i] = ify * (double)uv[2 * (i0 + i) + 1] + oy;
+      x[i] = xd[i];
+      y[i] = yd[i];
+    }
+    if (!no_distortion) {
+      for (int it = 0; it < 8; ++it) {
+        for (int i = 0; i < m; i++) {
+          const double x2 = x[i] * x[i], y2 = y[i] * y[i], xy = x[i] * y[i];
+          const double rho2 = x2 + y2;
+          const double rad = k1 * rho2 + k2 * rho2 * rho2;
+          const double dx = x[i] * rad + 2.0 * p1 * xy + p2 * (rho2 + 2.0 * x2);
+          const double dy = y[i] * rad + 2.0 * p2 * xy + p1 * (rho2 + 2.0 * y2);
+          x[i] = xd[i] - dx;
+          y[i] = yd[i] - dy;
+        }
+      }
+    }
+    for (int i = 0; i < m; i++) {
+      xu[i0 + i] = x[i];
+      yu[i0 + i] = y[i];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------- disc / bitmap
@@ -122,12 +170,19 @@ struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-
 // rank-7 system that is the same plane, so the cubic below has the same F solutions.]  The
 // operation order matches the oracle's restatement exactly, so both produce identical bits (two
 // different null-space bases differ by rounding and can flip a knife-edge inlier decision).
+//
+// Same arithmetic as the straightforward triple loop (per matrix entry: the same products added in
+// the same order), arranged for the vector units: the reflector is applied to all columns of R / all
+// rows of Q at once (Q is kept transposed), and the columns of R left of the current one — which
+// nothing reads any more — are not updated.
+ESVIO_SIMD_CLONES
 void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
-  constexpr int M = 9, N = 7;
-  double R[M][N], Q[M][M];
+  constexpr int M = 9, N = 7, NP = 8, MP = 12;
+  alignas(32) double R[M][NP], QT[M][MP];  // QT[i][j] = Q[j][i]
   for (int i = 0; i < M; i++) {
     for (int j = 0; j < N; j++) R[i][j] = A[j][i];
-    for (int j = 0; j < M; j++) Q[i][j] = (i == j);
+    R[i][N] = 0;
+    for (int j = 0; j < MP; j++) QT[i][j] = (i == j);
   }
   for (int k = 0; k < N; k++) {
     double norm = 0;
@@ -141,22 +196,26 @@ void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
     double vn = 0;
     for (int i = k; i < M; i++) vn += v[i] * v[i];
     if (vn == 0) continue;
-    for (int j = 0; j < N; j++) {  // R <- H R
-      double t = 0;
-      for (int i = k; i < M; i++) t += v[i] * R[i][j];
-      t = 2 * t / vn;
-      for (int i = k; i < M; i++) R[i][j] -= t * v[i];
+    if (k + 1 < N) {  // R <- H R, columns right of k (column j is only ever read for step j)
+      alignas(32) double t[NP] = {0};
+      for (int i = k; i < M; i++)
+        for (int j = 0; j < NP; j++) t[j] += v[i] * R[i][j];
+      for (int j = 0; j < NP; j++) t[j] = 2 * t[j] / vn;
+      for (int i = k; i < M; i++)
+        for (int j = 0; j < NP; j++) R[i][j] -= t[j] * v[i];
     }
-    for (int j = 0; j < M; j++) {  // Q <- Q H
-      double t = 0;
-      for (int i = k; i < M; i++) t += Q[j][i] * v[i];
-      t = 2 * t / vn;
-      for (int i = k; i < M; i++) Q[j][i] -= t * v[i];
+    {  // Q <- Q H
+      alignas(32) double t[MP] = {0};
+      for (int i = k; i < M; i++)
+        for (int j = 0; j < MP; j++) t[j] += QT[i][j] * v[i];
+      for (int j = 0; j < MP; j++) t[j] = 2 * t[j] / vn;
+      for (int i = k; i < M; i++)
+        for (int j = 0; j < MP; j++) QT[i][j] -= t[j] * v[i];
     }
   }
   for (int i = 0; i < M; i++) {
-    f1[i] = Q[i][7];
-    f2[i] = Q[i][8];
+    f1[i] = QT[7][i];
+    f2[i] = QT[8][i];
   }
 }
 
@@ -358,6 +417,51 @@ int mark_inliers(const float* m1, const float* m2, int n, const double* F, std::
   return good;
 }
 
+// RANSAC scoring of one model over points held as double arrays: inlier flags + count for the
+// points [i0, i1) (FMEstimatorCallback::computeError + findInliers, element for element)
+ESVIO_SIMD_CLONES
+int score_block(const double* __restrict x1, const double* __restrict y1, const double* __restrict x2,
+                const double* __restrict y2, int i0, int i1, const double* F, float t,
+                uint8_t* __restrict mask) {
+  const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7],
+               F8 = F[8];
+  int good = 0;
+  for (int i = i0; i < i1; i++) {
+    double a = F0 * x1[i] + F1 * y1[i] + F2;
+    double b = F3 * x1[i] + F4 * y1[i] + F5;
+    double c = F6 * x1[i] + F7 * y1[i] + F8;
+    const double s2 = 1. / (a * a + b * b);
+    const double d2 = x2[i] * a + y2[i] * b + c;
+    a = F0 * x2[i] + F3 * y2[i] + F6;
+    b = F1 * x2[i] + F4 * y2[i] + F7;
+    c = F2 * x2[i] + F5 * y2[i] + F8;
+    const double s1 = 1. / (a * a + b * b);
+    const double d1 = x1[i] * a + y1[i] * b + c;
+    const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    const float err = (float)(e1 < e2 ? e2 : e1);  // std::max(e1, e2)
+    const int f = err <= t;
+    mask[i] = (uint8_t)f;
+    good += f;
+  }
+  return good;
+}
+
+// Inlier count of a model if it can still beat `need` (> need wins), else a value <= need: the
+// RANSAC loop only looks at the flags of a model that improves on the best one, so scoring stops
+// as soon as that has become impossible.
+int mark_inliers_bounded(const double* x1, const double* y1, const double* x2, const double* y2, int n,
+                         const double* F, uint8_t* mask, double thresh, int need) {
+  const float t = (float)(thresh * thresh);
+  constexpr int kBlock = 32;
+  int good = 0;
+  for (int i0 = 0; i0 < n; i0 += kBlock) {
+    const int i1 = std::min(n, i0 + kBlock);
+    good += score_block(x1, y1, x2, y2, i0, i1, F, t, mask);
+    if (good + (n - i1) <= need) return good;  // cannot exceed `need` any more
+  }
+  return good;
+}
+
 }  // namespace
 
 int find_fundamental_mat(const float* m1, const float* m2, int count, double thr, double conf,
@@ -378,6 +482,14 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
     return n > 0 ? count : 0;
   }
   if (count >= 15) {  // RANSAC
+    std::vector<double> xy((size_t)4 * count);
+    double *x1 = xy.data(), *y1 = x1 + count, *x2 = y1 + count, *y2 = x2 + count;
+    for (int i = 0; i < count; i++) {
+      x1[i] = m1[2 * i];
+      y1[i] = m1[2 * i + 1];
+      x2[i] = m2[2 * i];
+      y2[i] = m2[2 * i + 1];
+    }
     int niters = kMaxIters, best_good = 0;
     for (int iter = 0; iter < niters; iter++) {
       if (!draw_subset(m1, m2, count, s1, s2, rng, 10000)) {
@@ -387,7 +499,8 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
       const int nm = seven_point(s1, s2, models);
       if (nm <= 0) continue;
       for (int k = 0; k < nm; k++) {
-        const int good = mark_inliers(m1, m2, count, models + 9 * k, err, mask.data(), thr);
+        const int good = mark_inliers_bounded(x1, y1, x2, y2, count, models + 9 * k, mask.data(), thr,
+                                              std::max(best_good, kModelPoints - 1));
         if (good > std::max(best_good, kModelPoints - 1)) {
           std::memcpy(status, mask.data(), count);
           best_good = good;

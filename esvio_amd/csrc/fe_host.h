@@ -16,6 +16,8 @@ int cv_floor(float v);
 
 // camodocal PinholeCamera::liftProjective (camera_model/src/camera_models/PinholeCamera.cc:450-510)
 void lift_projective(const esvio_fe_camera& cam, double u, double v, double out[3]);
+// the same for n points (uv = interleaved float pairs), results xu[i], yu[i] with z = 1
+void lift_projective_batch(const esvio_fe_camera& cam, const float* uv, int n, double* xu, double* yu);
 
 // half-width per |dy| of cv::circle(img, c, r, color, -1) [OpenCV imgproc/drawing.cpp Circle()]
 std::vector<int> disc_halfwidths(int r);
