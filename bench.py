@@ -129,7 +129,16 @@ def main():
 
     cfg = FE.make_config(W, H, device=dev_index, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1)
     ft = FE.FeatureTracker(cfg)
+    # PUB_THIS_FRAME depends on the batch timestamps only (node:155-188), so the whole plan is known
+    # up front; replay mode hands it to esvio_fe_set_next_batch as the PUB hint
     fc = FreqControl(args.freq)
+    pub_flags = []
+    for b in dev_batches:
+        pub_flags.append(fc.pub_this_frame(b[4]))
+        if pub_flags[-1]:
+            fc.published()
+    pub_plan = lambda k: pub_flags[k]
+    announced = [0]
     exch = (TrackExchange(cfg.max_cnt, world, device=xdev, dist=dist,
                           stream=torch.cuda.Stream() if xdev == "cuda" else None)
             if world > 1 else None)
@@ -139,19 +148,17 @@ def main():
 
     def step(i, exchange=True):
         tl, tr, nl, nr, t_last = dev_batches[i]
-        pub = fc.pub_this_frame(t_last)
+        pub = pub_flags[i]
         if rig is not None:  # C4: rank 0 = left camera + tracking, rank 1 = right camera
             rig.track(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub)
-            if pub:
-                fc.published()
-                if exchange:
-                    exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
+            if pub and exchange:
+                exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
             return nl if rank == 0 else nr
-        if pub:
-            fc.published()
-        if pipeline and i + 1 < len(dev_batches):  # replay mode: the next batch is already in HBM
-            tl2, tr2, nl2, nr2, t2 = dev_batches[i + 1]
-            ft.set_next_batch(t2, (tl2.data_ptr(), nl2), (tr2.data_ptr(), nr2), fc.peek(t2))
+        if pipeline:  # replay mode: the next batches are already in HBM; announce two ahead
+            while announced[0] < min(i + 2, len(dev_batches) - 1):
+                k = announced[0] = announced[0] + 1
+                tl2, tr2, nl2, nr2, t2 = dev_batches[k]
+                ft.set_next_batch(t2, (tl2.data_ptr(), nl2), (tr2.data_ptr(), nr2), pub_plan(k))
         ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
         if pub:
             if exch is not None and exchange:  # merge all rigs' tracked corners (async)

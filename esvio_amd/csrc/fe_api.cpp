@@ -16,6 +16,7 @@
 #include <map>
 #include <string>
 #include <utility>
+#include <deque>
 #include <vector>
 
 #include "../../include/esvio_fe.h"
@@ -83,6 +84,26 @@ int pyr_levels(int w, int h, int win, int max_level) {
   return max_level;
 }
 
+// esvio_fe_set_next_batch: a batch announced ahead of its trackEvent call ...
+struct Batch {
+  const esvio_fe_event *left = nullptr, *right = nullptr;
+  size_t nL = 0, nR = 0;
+  int space = 0;
+  double time = 0;
+  int pub = 0;  // caller's PUB_THIS_FRAME hint
+};
+// ... and, once its SAE update / images / pyramids (/ Arc*) are enqueued on the prefetch stream,
+// the resources they were given
+struct Inflight : Batch {
+  int lane = 0;  // staging buffer + event pair
+  int slotL = 0, slotR = 0, raw = 0, cand = 0;
+  const EventRec *dL = nullptr, *dR = nullptr;
+  bool arc_done = false;
+};
+constexpr int kPrefetchDepth = 2;
+constexpr int kLeftSlots = 2 + kPrefetchDepth;   // prev, cur, prefetched...
+constexpr int kRightSlots = 1 + kPrefetchDepth;  // cur, prefetched...
+
 struct PyrStore {
   PyrDesc d{};
   void* mem = nullptr;
@@ -99,7 +120,7 @@ struct esvio_fe_ctx {
   hipStream_t stream2 = nullptr;  // prefetch stream (next batch's SAE update / images)
   hipStream_t stream3 = nullptr;  // speculative temporal LK of the next frame
   hipStream_t cur = nullptr;      // the stream the helpers currently enqueue on
-  hipEvent_t ev_planes_free = nullptr, ev_prefetch_done = nullptr, ev_arc_done = nullptr;
+  hipEvent_t ev_planes_free = nullptr;
   hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr, ev_sel_host = nullptr;
   std::string err;
   int W = 0, H = 0;
@@ -116,31 +137,22 @@ struct esvio_fe_ctx {
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr;
   size_t sort_cap = 0, hist_cap = 0;
   unsigned long long* d_rejected = nullptr;
-  PyrStore pyr[5];  // left: slots 0..2 rotate (prev, cur, being-prefetched); right: slots 3,4
-  int slot_prevL = 0, slot_curL = 0, slot_curR = 3;
+  // left: slots 0..kLeftSlots-1 rotate (prev, cur, up to kPrefetchDepth being prefetched);
+  // right: the kRightSlots after them (cur + prefetched)
+  PyrStore pyr[kLeftSlots + kRightSlots];
+  int slot_prevL = 0, slot_curL = 0, slot_curR = kLeftSlots;
   bool have_img = false;
   bool ext_right_pending = false;  // esvio_fe_import_image(cam=1) done for the next frame
   // ---- next-batch prefetch (esvio_fe_set_next_batch)
-  bool nb_set = false, pf_valid = false;
-  const esvio_fe_event *nb_left = nullptr, *nb_right = nullptr;
-  size_t nb_nL = 0, nb_nR = 0;
-  int nb_space = 0;
-  double nb_time = 0;
-  int nb_pub = 0;  // caller's PUB_THIS_FRAME hint for the announced batch
-  int pf_slotL = 0, pf_slotR = 3, pf_raw = 0;
-  bool pf_arc_done = false;  // Arc* of the prefetched batch already ran on the prefetch stream
-  bool cur_prefetched = false;  // the frame being processed came from the prefetch stream
-  // identity of the batch whose SAE update / images were prefetched
-  const esvio_fe_event *pf_left = nullptr, *pf_right = nullptr;
-  size_t pf_nL = 0, pf_nR = 0;
-  int pf_space = 0;
-  double pf_time = 0;
-  EventRec* d_ev2 = nullptr;
-  size_t ev2_cap = 0;
-  const EventRec *pf_dL = nullptr, *pf_dR = nullptr;
+  std::deque<Batch> announced;     // announced, nothing enqueued yet (<= kPrefetchDepth)
+  std::deque<Inflight> inflight;   // SAE update / images / pyramids enqueued on the prefetch stream
+  bool cur_prefetched = false;     // the frame being processed came from the prefetch stream
+  EventRec* d_evp[kPrefetchDepth] = {};  // host-event staging, one per prefetch lane
+  size_t evp_cap[kPrefetchDepth] = {};
+  hipEvent_t ev_lane_done[kPrefetchDepth] = {}, ev_lane_arc[kPrefetchDepth] = {};
   PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images
   // equalize: raw time surfaces (single padded level each, left/right) + CLAHE scratch
-  PyrStore raw[2][2];  // [buffer][cam], double-buffered like the pyramids
+  PyrStore raw[kRightSlots][2];  // [buffer][cam], rotating like the right pyramids
   int raw_cur = 0;
   uint8_t* d_lut = nullptr;
   int* d_minmax = nullptr;
@@ -171,7 +183,7 @@ struct esvio_fe_ctx {
   struct CandSet {
     uint32_t *xy = nullptr, *idx = nullptr, *cnt = nullptr;
     size_t cap = 0;
-  } cand[2];
+  } cand[kRightSlots];
   int cand_cur = 0;
   uint32_t *d_comp_xy = nullptr, *d_comp_idx = nullptr;
   size_t arc_cap = 0;
@@ -495,15 +507,15 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
 // stage host events into the handle's device buffer; returns device pointers
 int stage_events(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL,
                  const esvio_fe_event* right, size_t nR, int space, const EventRec** dL,
-                 const EventRec** dR, bool second_buffer = false) {
+                 const EventRec** dR, int lane = -1) {
   if (space == ESVIO_FE_DEVICE) {
     *dL = (const EventRec*)left;
     *dR = (const EventRec*)right;
     return 0;
   }
   if (space != ESVIO_FE_HOST) return fail(c, ESVIO_FE_EINVAL, "bad memory space %d", space);
-  EventRec** buf = second_buffer ? &c->d_ev2 : &c->d_ev;
-  size_t* cap = second_buffer ? &c->ev2_cap : &c->ev_cap;
+  EventRec** buf = lane >= 0 ? &c->d_evp[lane] : &c->d_ev;
+  size_t* cap = lane >= 0 ? &c->evp_cap[lane] : &c->ev_cap;
   if (nL + nR > *cap) {
     const size_t ncap = std::max<size_t>(nL + nR + (nL + nR) / 4, 1 << 16);
     if (*buf) (void)hipFree(*buf);
@@ -816,7 +828,7 @@ void clear_tracker_state(esvio_fe_ctx* c) {
   c->prev_un_right_pts_map.clear();
   c->have_img = false;
   c->slot_prevL = c->slot_curL = 0;
-  c->slot_curR = 3;
+  c->slot_curR = kLeftSlots;
   c->ext_right_pending = false;
   c->cur_time = c->prev_time = 0;
 }
@@ -916,51 +928,58 @@ hipError_t sync_event(hipEvent_t ev) {
 // With the caller's PUB hint the Arc* pass of the batch runs here too (into the other candidate
 // set), which takes it off the main stream's per-frame chain.
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
-  if (!c->nb_set || c->pf_valid) return 0;
-  int sl = 0;
-  while (sl == c->slot_prevL || sl == c->slot_curL) sl++;
-  c->pf_slotL = sl;
-  c->pf_slotR = c->slot_curR == 3 ? 4 : 3;
-  c->pf_raw = c->raw_cur ^ 1;
-  c->cur = c->stream2;
   int rc = 0;
-  do {
-    if (wait_planes && hipStreamWaitEvent(c->stream2, c->ev_planes_free, 0) != hipSuccess) {
-      rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
-      break;
-    }
-    if ((rc = stage_events(c, c->nb_left, c->nb_nL, c->nb_right, c->nb_nR, c->nb_space, &c->pf_dL,
-                           &c->pf_dR, true)))
-      break;
-    if ((rc = sae_update(c, c->pf_dL, (uint32_t)c->nb_nL, c->pf_dR, (uint32_t)c->nb_nR))) break;
-    render_lk_images(c, c->nb_time, 3, c->pf_slotL, c->pf_slotR, c->pf_raw);
-    PyrDesc nxt[2] = {c->pyr[c->pf_slotL].d, c->pyr[c->pf_slotR].d};
-    pyr_build(c, nxt, 2);
-    if (hipEventRecord(c->ev_prefetch_done, c->stream2) != hipSuccess) {
-      rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
-      break;
-    }
-    c->pf_arc_done = false;
-    if (c->nb_pub && c->nb_nL) {
-      const int set = c->cand_cur ^ 1;
-      if ((rc = ensure_cand_capacity(c, set, c->nb_nL))) break;
-      const PyrDesc& ts = c->cfg.equalize ? c->raw[c->pf_raw][0].d : c->pyr[c->pf_slotL].d;
-      run_arc(c, c->pf_dL, (uint32_t)c->nb_nL, &ts, false, false, true, set);
-      if (hipEventRecord(c->ev_arc_done, c->stream2) != hipSuccess) {
+  c->cur = c->stream2;
+  while (!rc && !c->announced.empty() && (int)c->inflight.size() < kPrefetchDepth) {
+    Inflight b;
+    static_cast<Batch&>(b) = c->announced.front();
+    // resources nobody is using: not the current frame's, not another prefetched batch's
+    auto taken = [&](int Inflight::*m, int v) {
+      for (const Inflight& o : c->inflight)
+        if (o.*m == v) return true;
+      return false;
+    };
+    b.lane = 0;
+    while (taken(&Inflight::lane, b.lane)) b.lane++;
+    b.slotL = 0;
+    while (b.slotL == c->slot_prevL || b.slotL == c->slot_curL || taken(&Inflight::slotL, b.slotL))
+      b.slotL++;
+    b.slotR = kLeftSlots;
+    while (b.slotR == c->slot_curR || taken(&Inflight::slotR, b.slotR)) b.slotR++;
+    b.raw = 0;
+    while (b.raw == c->raw_cur || taken(&Inflight::raw, b.raw)) b.raw++;
+    b.cand = 0;
+    while (b.cand == c->cand_cur || taken(&Inflight::cand, b.cand)) b.cand++;
+    do {
+      if (wait_planes && hipStreamWaitEvent(c->stream2, c->ev_planes_free, 0) != hipSuccess) {
+        rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
+        break;
+      }
+      wait_planes = false;  // later batches simply follow on the same stream
+      if ((rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &b.dL, &b.dR, b.lane))) break;
+      if ((rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR))) break;
+      render_lk_images(c, b.time, 3, b.slotL, b.slotR, b.raw);
+      PyrDesc nxt[2] = {c->pyr[b.slotL].d, c->pyr[b.slotR].d};
+      pyr_build(c, nxt, 2);
+      if (hipEventRecord(c->ev_lane_done[b.lane], c->stream2) != hipSuccess) {
         rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
         break;
       }
-      c->pf_arc_done = true;
-    }
-    c->pf_valid = true;
-    c->pf_left = c->nb_left;
-    c->pf_right = c->nb_right;
-    c->pf_nL = c->nb_nL;
-    c->pf_nR = c->nb_nR;
-    c->pf_space = c->nb_space;
-    c->pf_time = c->nb_time;
-    c->nb_set = false;
-  } while (0);
+      b.arc_done = false;
+      if (b.pub && b.nL) {
+        if ((rc = ensure_cand_capacity(c, b.cand, b.nL))) break;
+        const PyrDesc& ts = c->cfg.equalize ? c->raw[b.raw][0].d : c->pyr[b.slotL].d;
+        run_arc(c, b.dL, (uint32_t)b.nL, &ts, false, false, true, b.cand);
+        if (hipEventRecord(c->ev_lane_arc[b.lane], c->stream2) != hipSuccess) {
+          rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
+          break;
+        }
+        b.arc_done = true;
+      }
+      c->inflight.push_back(b);
+      c->announced.pop_front();
+    } while (0);
+  }
   c->cur = c->stream;
   return rc;
 }
@@ -972,15 +991,16 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
 int enqueue_spec_temporal(esvio_fe_ctx* c, int n_kept, bool with_new, bool record_pts_ready = true) {
   const size_t M = std::max(c->cfg.max_cnt, 1);
   const size_t stM = (M + 63) / 64 * 64;
+  const Inflight& nxt = c->inflight.front();  // the next frame's batch
   if (record_pts_ready) HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_pts_ready, 0));
-  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_prefetch_done, 0));
+  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_lane_done[nxt.lane], 0));
   float2* B = (float2*)c->d_spec;
   float2* Cb = B + M;
   uint8_t* sA = c->d_spec + M * 16;
   uint8_t* sB = sA + stM;
   const PyrDesc& P = c->pyr[c->slot_curL].d;
-  const PyrDesc& N = c->pyr[c->pf_slotL].d;
+  const PyrDesc& N = c->pyr[nxt.slotL].d;
   const int* n_ptr = with_new ? c->d_counts + 1 : nullptr;
   const int n_max = with_new ? (int)M : n_kept;
   LkArgs f = make_lk(P, N, c->d_new, nullptr, B, sA, n_ptr, n_max, 3, 30, 0.01, 0);
@@ -1015,24 +1035,30 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   const EventRec *dL = nullptr, *dR = nullptr;
   const bool first = !c->have_img;
   bool arc_done = false, arc_prefetched = false;
-  if (c->pf_valid) {
+  int arc_lane = 0;
+  if (!c->inflight.empty()) {
     // this batch was announced with esvio_fe_set_next_batch and its SAE update, images and
-    // pyramids were enqueued on the prefetch stream during the previous call
-    if (left != c->pf_left || nL != c->pf_nL || right != c->pf_right || nR != c->pf_nR ||
-        space != c->pf_space || _cur_time != c->pf_time || motion)
+    // pyramids were enqueued on the prefetch stream during an earlier call
+    const Inflight b = c->inflight.front();
+    if (left != b.left || nL != b.nL || right != b.right || nR != b.nR || space != b.space ||
+        _cur_time != b.time || motion)
       return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
-    c->pf_valid = false;
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prefetch_done, 0));
-    dL = c->pf_dL;
-    dR = c->pf_dR;
-    c->slot_curL = c->pf_slotL;
-    c->slot_curR = c->pf_slotR;
-    c->raw_cur = c->pf_raw;
+    if (PUB_THIS_FRAME && !b.arc_done && c->inflight.size() > 1)
+      return fail(c, ESVIO_FE_EINVAL,
+                  "PUB hint was 0 for a published frame and a later batch is already applied to "
+                  "the SAE: with more than one batch announced the hint must be exact");
+    c->inflight.pop_front();
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_done[b.lane], 0));
+    dL = b.dL;
+    dR = b.dR;
+    c->slot_curL = b.slotL;
+    c->slot_curR = b.slotR;
+    c->raw_cur = b.raw;
     c->cur_prefetched = true;
-    if (c->pf_arc_done) {  // candidates of this batch are in the other set
-      c->cand_cur ^= 1;
+    if (b.arc_done) {  // candidates of this batch are in its own set
+      c->cand_cur = b.cand;
+      arc_lane = b.lane;
       arc_done = arc_prefetched = true;
-      c->pf_arc_done = false;
     }
   } else {
     c->cur_prefetched = false;
@@ -1052,8 +1078,8 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     while (!first && (sl == c->slot_prevL || sl == c->slot_curL)) sl++;
     c->slot_curL = sl;
     // camera split: the right image was imported into slot_curR by esvio_fe_import_image
-    if (!c->ext_right_pending) c->slot_curR = c->slot_curR == 3 ? 4 : 3;
-    c->raw_cur ^= 1;
+    if (!c->ext_right_pending) c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;
+    c->raw_cur = (c->raw_cur + 1) % kRightSlots;
     render_lk_images(c, c->cur_time, c->ext_right_pending ? 1 : 3, c->slot_curL, c->slot_curR,
                      c->raw_cur);
     c->ext_right_pending = false;
@@ -1089,7 +1115,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       arc_done = true;
       main_reads_planes = true;
     }
-    if (!c->nb_set) return 0;
+    if (c->announced.empty()) return 0;
     if (main_reads_planes) HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
     return prefetch_next(c, main_reads_planes);
   };
@@ -1175,7 +1201,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   int n_kept = n_surv;
   // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
   // launched as soon as this frame's points are final
-  const bool will_spec = c->pf_valid || (defer_early && c->nb_set);
+  const bool will_spec = !c->inflight.empty() || (defer_early && !c->announced.empty());
   auto upload_kept = [&]() -> int {
     if (!will_spec || !n_kept) return 0;
     std::memcpy(pin.kept, c->cur_pts.data(), (size_t)n_kept * 8);
@@ -1202,7 +1228,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   }
   if (defer_early) {
     if (int rc = early_work()) return rc;
-    if (c->pf_valid && n_kept)
+    if (!c->inflight.empty() && n_kept)
       if (int rc = enqueue_spec_temporal(c, n_kept, false, false)) return rc;
   }
 
@@ -1221,7 +1247,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
                                hipMemcpyHostToDevice, c->cur));
       if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
-      if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_arc_done, 0));
+      if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
       {
         ScopedKernel k(c, K_COMPACT, 0);
         const esvio_fe_ctx::CandSet& cs = c->cand[c->cand_cur];
@@ -1369,12 +1395,20 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->cand[0].xy, c->cand[0].idx,
                   c->cand[0].cnt, c->cand[1].xy, c->cand[1].idx, c->cand[1].cnt, c->d_comp_xy,
-                  c->d_comp_idx, c->d_mask_bits, c->d_sel_idx, c->pyr[0].mem, c->pyr[1].mem,
-                  c->pyr[2].mem, c->pyr[3].mem, c->pyr[4].mem, c->tmp_pyr[0].mem, c->tmp_pyr[1].mem,
-                  c->raw[0][0].mem, c->raw[0][1].mem, c->raw[1][0].mem, c->raw[1][1].mem, c->d_lut,
-                  c->d_minmax, c->d_ev2, c->d_spec};
+                  c->d_comp_idx, c->d_mask_bits, c->d_sel_idx,
+                  c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->d_lut, c->d_minmax, c->d_spec};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (PyrStore& ps : c->pyr)
+    if (ps.mem) (void)hipFree(ps.mem);
+  for (auto& rb : c->raw)
+    for (PyrStore& ps : rb)
+      if (ps.mem) (void)hipFree(ps.mem);
+  for (int i = 0; i < kPrefetchDepth; i++) {
+    if (c->d_evp[i]) (void)hipFree(c->d_evp[i]);
+    if (c->ev_lane_done[i]) (void)hipEventDestroy(c->ev_lane_done[i]);
+    if (c->ev_lane_arc[i]) (void)hipEventDestroy(c->ev_lane_arc[i]);
+  }
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_spec) (void)hipHostFree(c->h_spec);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -1388,8 +1422,6 @@ int esvio_fe_destroy(esvio_fe_handle c) {
     (void)hipStreamDestroy(c->stream2);
   }
   if (c->ev_planes_free) (void)hipEventDestroy(c->ev_planes_free);
-  if (c->ev_prefetch_done) (void)hipEventDestroy(c->ev_prefetch_done);
-  if (c->ev_arc_done) (void)hipEventDestroy(c->ev_arc_done);
   if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
   if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
   if (c->ev_sel_host) (void)hipEventDestroy(c->ev_sel_host);
@@ -1441,10 +1473,12 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_sel_host, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_prefetch_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_arc_done, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
+  for (int i = 0; i < kPrefetchDepth; i++)
+    if (hipEventCreateWithFlags(&c->ev_lane_done[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_lane_arc[i], hipEventDisableTiming) != hipSuccess)
+      return bail(ESVIO_FE_EHIP);
   c->cur = c->stream;
   const size_t M = cfg->max_cnt;
   int rc = 0;
@@ -1478,11 +1512,12 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_sel_idx, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_mask_bits, (size_t)c->H * ((c->W + 31) / 32)))) return bail(rc);
-  for (int i = 0; i < 5; i++)
-    if ((rc = pyr_alloc(c, c->pyr[i], c->W, c->H, 3))) return bail(rc);
+  for (PyrStore& ps : c->pyr)
+    if ((rc = pyr_alloc(c, ps, c->W, c->H, 3))) return bail(rc);
   if (cfg->equalize) {
-    for (int i = 0; i < 4; i++)
-      if ((rc = pyr_alloc(c, c->raw[i / 2][i % 2], c->W, c->H, 0))) return bail(rc);
+    for (auto& rb : c->raw)
+      for (PyrStore& ps : rb)
+        if ((rc = pyr_alloc(c, ps, c->W, c->H, 0))) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_lut, (size_t)2 * 64 * 256))) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_minmax, 4))) return bail(rc);
   }
@@ -1506,7 +1541,9 @@ int esvio_fe_reset(esvio_fe_handle c) {
   HIPCHK(c, hipSetDevice(c->dev));
   HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
-  c->nb_set = c->pf_valid = c->spec_valid = false;
+  c->announced.clear();
+  c->inflight.clear();
+  c->spec_valid = false;
   HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->cur));
   HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->cur));
   HIPCHK(c, hipStreamSynchronize(c->cur));
@@ -1519,7 +1556,7 @@ int esvio_fe_create_sae_stereo(esvio_fe_handle c, const esvio_fe_event* left, si
                                uint64_t* n_rejected) {
   if (!c || (nL && !left) || (nR && !right)) return ESVIO_FE_EINVAL;
   if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
-  if (c->pf_valid) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
+  if (!c->inflight.empty()) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
   HIPCHK(c, hipSetDevice(c->dev));
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
@@ -1566,7 +1603,7 @@ int esvio_fe_create_sae(esvio_fe_handle c, int cam, const esvio_fe_event* ev, si
 int esvio_fe_sae_to_time_surface(esvio_fe_handle c, int cam, double t_sync, uint8_t* out) {
   if (!c || (cam != 0 && cam != 1)) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  if (c->pf_valid) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
+  if (!c->inflight.empty()) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
   render_lk_images(c, t_sync, cam ? 2 : 1, c->slot_curL, c->slot_curR, c->raw_cur);
   if (out) return copy_level0_out(c, raw_ts_desc(c, cam), out);
   HIPCHK(c, hipStreamSynchronize(c->cur));
@@ -1598,9 +1635,9 @@ int esvio_fe_import_image(esvio_fe_handle c, int cam, const uint8_t* src, int sp
   if (cam != 1) return fail(c, ESVIO_FE_EINVAL, "only the right camera's image can be imported");
   if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  if (c->nb_set || c->pf_valid)
+  if (!c->announced.empty() || !c->inflight.empty())
     return fail(c, ESVIO_FE_EINVAL, "import_image cannot be combined with set_next_batch");
-  c->slot_curR = c->slot_curR == 3 ? 4 : 3;  // the slot the next trackEvent will use as curR
+  c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;  // next trackEvent's curR
   const PyrDesc& d = c->pyr[c->slot_curR].d;
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, src, c->W, c->W, c->H,
@@ -1826,14 +1863,17 @@ int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio
   if (nL == 0 || !left || (nR && !right)) return fail(c, ESVIO_FE_EINVAL, "bad next batch");
   if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
   if (c->ext_right_pending) return fail(c, ESVIO_FE_EINVAL, "not with an imported right image");
-  c->nb_set = true;  // may be called while an earlier announced batch is still pending as prefetched
-  c->nb_time = next_cur_time;
-  c->nb_left = left;
-  c->nb_nL = nL;
-  c->nb_right = right;
-  c->nb_nR = nR;
-  c->nb_space = space;
-  c->nb_pub = pub_hint != 0;
+  if ((int)c->announced.size() >= kPrefetchDepth)
+    return fail(c, ESVIO_FE_EINVAL, "at most %d batches can be announced ahead", kPrefetchDepth);
+  Batch b;
+  b.time = next_cur_time;
+  b.left = left;
+  b.nL = nL;
+  b.right = right;
+  b.nR = nR;
+  b.space = space;
+  b.pub = pub_hint != 0;
+  c->announced.push_back(b);
   return 0;
 }
 

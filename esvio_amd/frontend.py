@@ -333,7 +333,8 @@ class FeatureTracker:
         pl, nl, sl, k1 = _events_arg(event_left)
         pr, nr, sr, k2 = _events_arg(event_right)
         assert sl == sr
-        self._next_keep = (k1, k2)  # host arrays must outlive the prefetch
+        # host arrays must outlive the prefetch (up to two announced + the one being tracked)
+        self._next_keep = (getattr(self, "_next_keep", []) + [(k1, k2)])[-4:]
         self._hd.check(self._hd.L.esvio_fe_set_next_batch(self._hd.h, float(next_cur_time), pl, nl,
                                                           pr, nr, sl, int(bool(PUB_NEXT_FRAME))))
 

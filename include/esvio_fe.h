@@ -197,8 +197,13 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle h, const esvio_fe_event* left,
  * is prefetched as well; a wrong hint costs time, never correctness.  The following call must
  * pass exactly these pointers, sizes, space and cur_time (else ESVIO_FE_EINVAL) and the event memory
  * must stay valid until then.  Results are identical to the non-pipelined sequence.  After a call
- * that prefetched, the get_sae / time-surface taps already reflect the NEXT batch.  The reference
- * has no counterpart: it processes one batch at a time (depth-1 queues, node:128-142). */
+ * that prefetched, the get_sae / time-surface taps already reflect the latest prefetched batch.
+ * Up to two batches may be announced ahead (call this twice before a track call; the calls that
+ * follow must come in the announced order): the second one's SAE update then runs a whole frame
+ * early.  With two batches in flight the hint of a published frame must be exact (the SAE has
+ * moved on by the time it is tracked): a published frame whose hint was 0 is refused with
+ * ESVIO_FE_EINVAL.  The reference has no counterpart: it processes one batch at a time (depth-1
+ * queues, node:128-142). */
 int esvio_fe_set_next_batch(esvio_fe_handle h, double next_cur_time, const esvio_fe_event* left,
                             size_t nL, const esvio_fe_event* right, size_t nR, int space,
                             int pub_hint);

@@ -405,28 +405,37 @@ def test_track_event_motion_compensated_end_to_end(oracle):
     ft.close()
 
 
-@pytest.mark.parametrize("equalize,hint", [(0, "none"), (0, "right"), (0, "wrong"), (1, "right"),
-                                           (1, "none")])
-def test_next_batch_prefetch_is_transparent(oracle, equalize, hint):
-    """esvio_fe_set_next_batch (replay mode: the next batch's SAE update / images — and, with the
-    PUB hint, its Arc* pass — run on a second stream under the current frame's LK) must not change
-    a single result bit, whether the hint is absent, right or wrong; also a mismatching follow-up
-    call is refused."""
+@pytest.mark.parametrize("equalize,hint,depth", [(0, "none", 1), (0, "right", 1), (0, "wrong", 1),
+                                                 (1, "right", 1), (1, "none", 1), (0, "right", 2),
+                                                 (1, "right", 2)])
+def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth):
+    """esvio_fe_set_next_batch (replay mode: the next one or two batches' SAE update / images — and,
+    with the PUB hint, their Arc* pass — run on a second stream, and the next frame's temporal LK
+    is launched speculatively on a third) must not change a single result bit, whether the hint is
+    absent, right or wrong; also a mismatching follow-up call is refused."""
     W, H = 640, 480
     s = SceneStream(W, H, rate=5e6, seed=6)
-    batches = [s.next_batch() for _ in range(11)]
+    batches = [s.next_batch() for _ in range(12)]
     kw = dict(f_ransac=1, equalize=equalize)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
     pubs = [(f % 3) != 1 for f in range(len(batches))]
+    announced = 0
     for f, (L, R, _) in enumerate(batches):
         t = event_times(L)[-1]
-        if f + 1 < len(batches) and f != 4:      # frame 4 -> 5 is not prefetched (mixing is legal)
-            Ln, Rn, _ = batches[f + 1]
-            h = {"none": False, "right": pubs[f + 1], "wrong": not pubs[f + 1]}[hint]
+        # batch 5 is never announced (mixing prefetched and plain calls is legal)
+        if f == 5:
+            announced = 5
+        hi = min(f + depth, len(batches) - 1)
+        if f <= 4:
+            hi = min(hi, 4)
+        while announced < hi:
+            announced += 1
+            Ln, Rn, _ = batches[announced]
+            h = {"none": False, "right": pubs[announced], "wrong": not pubs[announced]}[hint]
             ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, h)
         ft.trackEvent(t, L, R, pubs[f])
-        _compare_tracks(ft, tr.track_event(t, L, R, pubs[f]), ("prefetch", hint, f))
+        _compare_tracks(ft, tr.track_event(t, L, R, pubs[f]), ("prefetch", hint, depth, f))
         if f == 4:  # nothing pending: the taps show this very frame
             assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
     assert len(ft.ids) > 100
@@ -436,4 +445,26 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint):
     ft.trackEvent(event_times(batches[1][0])[-1] + 1.0, batches[1][0], batches[1][1], False)
     with pytest.raises(FE.FrontendError):
         ft.trackEvent(2.0, batches[2][0], batches[2][1], False)
+    ft.close()
+
+
+def test_two_batches_ahead_need_an_exact_pub_hint():
+    """with two batches in flight the SAE has moved past a frame by the time it is tracked, so a
+    published frame whose hint was 0 (no prefetched Arc* pass) is refused instead of detecting on
+    the wrong surface; a third announcement is refused too"""
+    W, H = 346, 260
+    s = SceneStream(W, H, rate=2e6, seed=2)
+    b = [s.next_batch() for _ in range(4)]
+    t = [event_times(x[0])[-1] for x in b]
+    ft = FE.FeatureTracker(FE.make_config(W, H))
+    ft.set_next_batch(t[1], b[1][0], b[1][1], False)
+    ft.set_next_batch(t[2], b[2][0], b[2][1], False)
+    with pytest.raises(FE.FrontendError):
+        ft.set_next_batch(t[3], b[3][0], b[3][1], False)
+    ft.trackEvent(t[0], b[0][0], b[0][1], True)       # enqueues the prefetch of frames 1 and 2
+    with pytest.raises(FE.FrontendError):
+        ft.trackEvent(t[1], b[1][0], b[1][1], True)   # hint said "not published"
+    ft.reset()
+    ft.trackEvent(t[0], b[0][0], b[0][1], True)       # usable again after reset
+    assert len(ft.ids) > 0
     ft.close()
