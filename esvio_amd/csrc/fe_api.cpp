@@ -206,7 +206,8 @@ struct esvio_fe_ctx {
   // ---- host phase trace (ESVIO_FE_TRACE=1): stage, sae+ts enqueue, sync A, host A, enqueue B,
   // sync B, host B
   bool trace = false;
-  double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double phase_ms[2][8] = {};  // [published?][phase]
+  uint64_t phase_count[2] = {0, 0};
   uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
 
   // ---- profiling
@@ -650,15 +651,19 @@ double pt_distance(const P2f& a, const P2f& b) {  // :1314-1319
 // the (unstable) permutation of equal track counts is inherited from libstdc++.
 void event_set_mask(esvio_fe_ctx* c) {
   c->mask_event.reset(c->W, c->H);
-  std::vector<std::pair<int, std::pair<P2f, int>>> cnt_pts_id;
+  // (the sort only ever compares .first, so carrying src_idx along as payload leaves the
+  // permutation — std::sort is not stable — exactly what it is for the reference's pair type)
+  struct Item {
+    int first;
+    std::pair<P2f, int> second;
+    int src;
+  };
+  std::vector<Item> cnt_pts_id;
+  cnt_pts_id.reserve(c->cur_pts.size());
   for (unsigned int i = 0; i < c->cur_pts.size(); i++)
-    cnt_pts_id.push_back(std::make_pair(c->track_cnt[i], std::make_pair(c->cur_pts[i], c->ids[i])));
+    cnt_pts_id.push_back(Item{c->track_cnt[i], std::make_pair(c->cur_pts[i], c->ids[i]), c->src_idx[i]});
   std::sort(cnt_pts_id.begin(), cnt_pts_id.end(),
-            [](const std::pair<int, std::pair<P2f, int>>& a,
-               const std::pair<int, std::pair<P2f, int>>& b) { return a.first > b.first; });
-  // ids are unique, so the permutation can be recovered afterwards for src_idx
-  std::map<int, int> src_of_id;
-  for (unsigned int i = 0; i < c->ids.size(); i++) src_of_id[c->ids[i]] = c->src_idx[i];
+            [](const Item& a, const Item& b) { return a.first > b.first; });
   c->cur_pts.clear();
   c->ids.clear();
   c->track_cnt.clear();
@@ -670,7 +675,7 @@ void event_set_mask(esvio_fe_ctx* c) {
       c->cur_pts.push_back(it.second.first);
       c->ids.push_back(it.second.second);
       c->track_cnt.push_back(it.first);
-      c->src_idx.push_back(src_of_id[it.second.second]);
+      c->src_idx.push_back(it.src);
       c->mask_event.stamp_disc(px, py, c->cfg.min_dist, c->hw);
     }
   }
@@ -1028,7 +1033,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   auto lap = [&](int i) {
     if (!c->trace) return;
     auto now = clk::now();
-    c->phase_ms[i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    c->phase_ms[PUB_THIS_FRAME ? 1 : 0][i] += std::chrono::duration<double, std::milli>(now - tp).count();
     tp = now;
   };
 
@@ -1127,15 +1132,19 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     use_spec = c->cur_prefetched && (int)c->prev_pts.size() == c->spec_n;
     if (!use_spec) HIPCHK(c, hipStreamSynchronize(c->stream3));
   }
-  // on a frame that publishes nothing the host has little to do: the ~12 launches of the next
-  // batch's prefetch are then enqueued after the stereo LK, in its shadow
-  const bool defer_early = use_spec && !PUB_THIS_FRAME;
+  // When to enqueue the ~12 launches of the announced batch's prefetch (early_work):
+  //  * late — the next frame's batch is already in flight (two announced ahead), so the one to
+  //    enqueue is not urgent: after everything else of this frame, where the host would only wait;
+  //  * mid — on a frame that publishes nothing, after the stereo LK, in its shadow;
+  //  * else right away (Arc* still has to run on the main stream, or nothing to overlap with).
+  const bool defer_late = !(PUB_THIS_FRAME && !arc_done) && !c->inflight.empty();
+  const bool defer_early = !defer_late && use_spec && !PUB_THIS_FRAME;
   if (c->prev_pts.size() > 0) {  // :405-437
     const int n = (int)c->prev_pts.size();
     const uint8_t *t_stA, *t_stB;
     const P2f *t_ptsB, *t_ptsC;
     if (use_spec) {
-      if (!defer_early)
+      if (!defer_early && !defer_late)
         if (int rc = early_work()) return rc;
       lap(1);
       HIPCHK(c, sync_event(c->ev_spec_done));
@@ -1185,7 +1194,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     reduce_vector(c->track_cnt, status);
   }
 
-  if (!defer_early)
+  if (!defer_early && !defer_late)
     if (int rc = early_work()) return rc;  // (no previous points: nothing was synchronised above)
   for (auto& n : c->track_cnt) n++;  // :439-440
 
@@ -1276,6 +1285,8 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   }
   if (n_surv || detect)
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->cur));
+  if (defer_late)
+    if (int rc = early_work()) return rc;
   lap(5);
   if (detect) HIPCHK(c, sync_event(c->ev_sel_host));
 
@@ -1362,6 +1373,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->spec_n = (int)c->prev_pts.size();
   lap(7);
   c->phase_frames++;
+  c->phase_count[PUB_THIS_FRAME ? 1 : 0]++;
   c->tr_surv += (uint64_t)n_surv;
   if (c->prof_on) resolve_profile(c);
   return 0;
@@ -1385,8 +1397,18 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->trace && c->phase_frames) {
     static const char* nm[8] = {"enqueue sae+ts+pyr", "enqueue temporal LK", "sync A", "host filter",
                                 "host ransac", "host mask + enqueue detect/stereo", "sync B", "host tail"};
-    fprintf(stderr, "[esvio_fe trace] %llu frames, ms/frame:", (unsigned long long)c->phase_frames);
-    for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.3f", nm[i], c->phase_ms[i] / c->phase_frames);
+    for (int pub = 0; pub < 2; pub++) {
+      if (!c->phase_count[pub]) continue;
+      double tot = 0;
+      fprintf(stderr, "[esvio_fe trace] %llu %s frames, ms/frame:", (unsigned long long)c->phase_count[pub],
+              pub ? "published" : "unpublished");
+      for (int i = 0; i < 8; i++) {
+        fprintf(stderr, " %s=%.3f", nm[i], c->phase_ms[pub][i] / c->phase_count[pub]);
+        tot += c->phase_ms[pub][i] / c->phase_count[pub];
+      }
+      fprintf(stderr, " | total=%.3f\n", tot);
+    }
+    fprintf(stderr, "[esvio_fe trace]");
     fprintf(stderr, "\n[esvio_fe trace] survivors/frame=%.1f; detect frames=%llu: candidates/frame=%.0f new/frame=%.1f\n",
             (double)c->tr_surv / c->phase_frames, (unsigned long long)c->tr_detect,
             c->tr_detect ? (double)c->tr_cand / c->tr_detect : 0.0,
