@@ -119,7 +119,6 @@ struct esvio_fe_ctx {
   hipStream_t stream = nullptr;   // main stream
   hipStream_t stream2 = nullptr;  // prefetch stream (next batch's SAE update / images)
   hipStream_t stream3 = nullptr;  // speculative temporal LK of the next frame
-  hipStream_t cur = nullptr;      // the stream the helpers currently enqueue on
   hipEvent_t ev_planes_free = nullptr;
   hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr, ev_sel_host = nullptr;
   std::string err;
@@ -219,6 +218,18 @@ struct esvio_fe_ctx {
 
 namespace {
 
+// The stream the helpers enqueue on: the main stream unless the calling thread has switched to
+// another one (prefetch -> stream2, speculative LK -> stream3).
+thread_local hipStream_t t_stream_override = nullptr;
+inline hipStream_t cur_stream(const esvio_fe_ctx* c) {
+  return t_stream_override ? t_stream_override : c->stream;
+}
+struct StreamScope {
+  hipStream_t saved;
+  explicit StreamScope(hipStream_t s) : saved(t_stream_override) { t_stream_override = s; }
+  ~StreamScope() { t_stream_override = saved; }
+};
+
 int fail(esvio_fe_ctx* c, int code, const char* fmt, ...) {
   if (c) {
     char buf[512];
@@ -260,12 +271,12 @@ struct ScopedKernel {  // brackets one launch with HIP events on the handle's st
     if (c->prof_on) {
       a = get_event(c);
       b = get_event(c);
-      (void)hipEventRecord(a, c->cur);
+      (void)hipEventRecord(a, cur_stream(c));
     }
   }
   ~ScopedKernel() {
-    if (c->prof_on) {
-      (void)hipEventRecord(b, c->cur);
+    if (a) {
+      (void)hipEventRecord(b, cur_stream(c));
       c->pending.push_back(ProfRec{id, a, b, bytes});
     }
   }
@@ -333,7 +344,7 @@ int ensure_sort_capacity(esvio_fe_ctx* c, size_t n) {
     c->hist = nullptr;
     c->hist_cap = 0;
     if (int rc = dev_alloc(c, &c->hist, hneed)) return rc;
-    HIPCHK(c, hipMemsetAsync(c->hist, 0, hneed * 4, c->cur));
+    HIPCHK(c, hipMemsetAsync(c->hist, 0, hneed * 4, cur_stream(c)));
     c->hist_cap = hneed;
   }
   return 0;
@@ -394,7 +405,7 @@ int pyr_alloc(esvio_fe_ctx* c, PyrStore& ps, int w, int h, int max_level) {
     lh = (lh + 1) / 2;
   }
   HIPCHK(c, hipMalloc(&ps.mem, off));
-  HIPCHK(c, hipMemsetAsync(ps.mem, 0, off, c->cur));  // derivative borders stay 0 forever
+  HIPCHK(c, hipMemsetAsync(ps.mem, 0, off, cur_stream(c)));  // derivative borders stay 0 forever
   for (int l = 0; l <= levels; l++) {
     ps.d.img[l] = (uint8_t*)ps.mem + img_off[l];
     ps.d.deriv[l] = (int16_t*)((uint8_t*)ps.mem + der_off[l]);
@@ -420,17 +431,17 @@ void pyr_build(esvio_fe_ctx* c, const PyrDesc* p, int nimg) {
   for (int l = 0; l < p[0].levels; l++) {
     uint64_t src = (uint64_t)p[0].w[l] * p[0].h[l], dst = (uint64_t)p[0].w[l + 1] * p[0].h[l + 1];
     ScopedKernel k(c, K_PYR_DOWN, (src + dst) * nimg);
-    launch_pyr_down(c->cur, p, nimg, l);
+    launch_pyr_down(cur_stream(c), p, nimg, l);
   }
   {
     ScopedKernel k(c, K_PYR_PAD, 0);
-    launch_pyr_pad(c->cur, p, nimg);
+    launch_pyr_pad(cur_stream(c), p, nimg);
   }
   {
     uint64_t all = 0;
     for (int l = 0; l <= p[0].levels; l++) all += (uint64_t)p[0].w[l] * p[0].h[l];
     ScopedKernel k(c, K_SCHARR, all * 5 * nimg);  // 1 B read + 4 B written per pixel
-    launch_scharr(c->cur, p, nimg);
+    launch_scharr(cur_stream(c), p, nimg);
   }
   (void)px0;
 }
@@ -486,20 +497,20 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
   const uint32_t lb_words = (uint32_t)passes * (nblk << bits);
   {
     ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);
-    launch_sae_keys(c->cur, evL, nL, evR, nR, c->W, c->H, c->keys[0], c->vals[0], c->invalid_key,
+    launch_sae_keys(cur_stream(c), evL, nL, evR, nR, c->W, c->H, c->keys[0], c->vals[0], c->invalid_key,
                     c->d_rejected, passes, bits, ghist, lookback, lb_words, mc);
   }
   int cur = 0;
   for (int p = 0; p < passes; p++) {
     ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 16);
-    launch_radix_pass(c->cur, c->keys[cur], c->vals[cur], n, p * bits, bits, ghist + ((size_t)p << bits),
+    launch_radix_pass(cur_stream(c), c->keys[cur], c->vals[cur], n, p * bits, bits, ghist + ((size_t)p << bits),
                       lookback + (size_t)p * (nblk << bits), tickets + p, c->keys[cur ^ 1],
                       c->vals[cur ^ 1], c->d_counts + 3);
     cur ^= 1;
   }
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
-    launch_sae_apply(c->cur, c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
+    launch_sae_apply(cur_stream(c), c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
                      c->cfg.feature_filter_threshold, c->invalid_key, c->hist, head);
   }
   return 0;
@@ -525,8 +536,8 @@ int stage_events(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL,
     if (int rc = dev_alloc(c, buf, ncap)) return rc;
     *cap = ncap;
   }
-  if (nL) HIPCHK(c, hipMemcpyAsync(*buf, left, nL * 16, hipMemcpyHostToDevice, c->cur));
-  if (nR) HIPCHK(c, hipMemcpyAsync(*buf + nL, right, nR * 16, hipMemcpyHostToDevice, c->cur));
+  if (nL) HIPCHK(c, hipMemcpyAsync(*buf, left, nL * 16, hipMemcpyHostToDevice, cur_stream(c)));
+  if (nR) HIPCHK(c, hipMemcpyAsync(*buf + nL, right, nR * 16, hipMemcpyHostToDevice, cur_stream(c)));
   *dL = *buf;
   *dR = *buf + nL;
   return 0;
@@ -535,7 +546,7 @@ int stage_events(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL,
 void render_ts(esvio_fe_ctx* c, double t_sync, uint8_t* dst0, uint8_t* dst1, int ncam,
                const double2* S2) {
   ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * ncam);
-  launch_time_surface(c->cur, S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
+  launch_time_surface(cur_stream(c), S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
                       c->cfg.ignore_polarity, dst0, dst1, c->pyr[0].d.stride[0], ncam);
 }
 
@@ -570,7 +581,7 @@ void render_lk_images(esvio_fe_ctx* c, double t_sync, int cams, int slotL, int s
   }
   for (int stage = 0; stage < 3; stage++) {
     ScopedKernel k(c, K_CLAHE, stage == 0 ? (uint64_t)c->P * nimg : (uint64_t)c->P * 2 * nimg);
-    launch_clahe(c->cur, s0, s1, rl.stride[0], d0, d1, L.stride[0], c->W, c->H, c->d_lut,
+    launch_clahe(cur_stream(c), s0, s1, rl.stride[0], d0, d1, L.stride[0], c->W, c->H, c->d_lut,
                  c->d_minmax, nimg, stage);
   }
 }
@@ -607,21 +618,21 @@ void run_lk(esvio_fe_ctx* c, const LkArgs& f, const LkArgs* b, float2* back_pts,
   uint64_t bytes = (uint64_t)f.n_max * (f.max_level + 1) * kLkWin * kLkWin * 5;
   if (b) bytes += (uint64_t)f.n_max * (b->max_level + 1) * kLkWin * kLkWin * 5;
   ScopedKernel k(c, K_LK, bytes);
-  launch_lk(c->cur, f, b, back_pts, back_status);
+  launch_lk(cur_stream(c), f, b, back_pts, back_status);
 }
 
 int copy_level0_out(esvio_fe_ctx* c, const PyrDesc& d, uint8_t* out) {
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(out, d.w[0], d.img[0] + (size_t)kPad * stride + kPad, stride, d.w[0],
-                             d.h[0], hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+                             d.h[0], hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   return 0;
 }
 
 int copy_level0_in(esvio_fe_ctx* c, const PyrDesc& d, const uint8_t* in) {
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, in, d.w[0], d.w[0],
-                             d.h[0], hipMemcpyHostToDevice, c->cur));
+                             d.h[0], hipMemcpyHostToDevice, cur_stream(c)));
   return 0;
 }
 
@@ -869,12 +880,12 @@ void run_select(esvio_fe_ctx* c, uint32_t n_events, int max_corners, float2* out
   {
     ScopedKernel k(c, K_COMPACT, 0);
     const esvio_fe_ctx::CandSet& cs = c->cand[c->cand_cur];
-    launch_compact(c->cur, cs.xy, cs.idx, cs.cnt, nblk, c->d_comp_xy, c->d_comp_idx,
+    launch_compact(cur_stream(c), cs.xy, cs.idx, cs.cnt, nblk, c->d_comp_xy, c->d_comp_idx,
                    (uint32_t*)(c->d_counts + 2));
   }
   SelectArgs s = make_select_args(c, max_corners, out_pts, out_base, out_idx);
   ScopedKernel k(c, K_SELECT, 0);
-  launch_select(c->cur, s, select_lds_bytes(c));
+  launch_select(cur_stream(c), s, select_lds_bytes(c));
 }
 
 // Arc* flags (+ ordered per-block candidate lists into set `set`) for the left events; `ts` is the
@@ -900,7 +911,7 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
   a.cand_idx = want_cand ? c->cand[set].idx : nullptr;
   a.cand_cnt = want_cand ? c->cand[set].cnt : nullptr;
   ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
-  launch_arc(c->cur, a);
+  launch_arc(cur_stream(c), a);
 }
 
 // wait for the main stream with a short busy poll first: the two per-frame host syncs are on the
@@ -934,7 +945,7 @@ hipError_t sync_event(hipEvent_t ev) {
 // set), which takes it off the main stream's per-frame chain.
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
   int rc = 0;
-  c->cur = c->stream2;
+  StreamScope on_prefetch_stream(c->stream2);
   while (!rc && !c->announced.empty() && (int)c->inflight.size() < kPrefetchDepth) {
     Inflight b;
     static_cast<Batch&>(b) = c->announced.front();
@@ -985,7 +996,6 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
       c->announced.pop_front();
     } while (0);
   }
-  c->cur = c->stream;
   return rc;
 }
 
@@ -993,10 +1003,10 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
 // call) now: its inputs are final once this frame's kept points (uploaded to d_new[0..n_kept)) and
 // new corners (written by k_select behind them, total count in d_counts[1]) are known, and the next
 // frame's pyramids are already being built on the prefetch stream.
-int enqueue_spec_temporal(esvio_fe_ctx* c, int n_kept, bool with_new, bool record_pts_ready = true) {
+int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame's batch */,
+                          int n_kept, bool with_new, bool record_pts_ready = true) {
   const size_t M = std::max(c->cfg.max_cnt, 1);
   const size_t stM = (M + 63) / 64 * 64;
-  const Inflight& nxt = c->inflight.front();  // the next frame's batch
   if (record_pts_ready) HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_pts_ready, 0));
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_lane_done[nxt.lane], 0));
@@ -1011,9 +1021,10 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, int n_kept, bool with_new, bool recor
   LkArgs f = make_lk(P, N, c->d_new, nullptr, B, sA, n_ptr, n_max, 3, 30, 0.01, 0);
   LkArgs b = make_lk(N, P, nullptr, nullptr, nullptr, nullptr, n_ptr, n_max, 1, 30, 0.01,
                      ESVIO_FE_LK_USE_INITIAL_FLOW);
-  c->cur = c->stream3;
-  run_lk(c, f, c->cfg.flow_back ? &b : nullptr, Cb, sB);
-  c->cur = c->stream;
+  {
+    StreamScope on_spec_stream(c->stream3);
+    run_lk(c, f, c->cfg.flow_back ? &b : nullptr, Cb, sB);
+  }
   HIPCHK(c, hipMemcpyAsync(c->h_spec, c->d_spec, c->spec_bytes, hipMemcpyDeviceToHost, c->stream3));
   HIPCHK(c, hipEventRecord(c->ev_spec_done, c->stream3));
   c->spec_valid = true;
@@ -1091,6 +1102,20 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[c->slot_curR].d};
     pyr_build(c, cur2, 2);
   }
+  // the next frame's batch, if it is already in flight (two announced ahead), else once this
+  // frame's early_work has put it there
+  bool have_next = !c->inflight.empty();
+  Inflight next_b = have_next ? c->inflight.front() : Inflight();
+  const bool had_announced = !c->announced.empty();
+  auto next_batch = [&]() -> const Inflight* {
+    if (!have_next && had_announced) {
+      if (!c->inflight.empty()) {
+        next_b = c->inflight.front();
+        have_next = true;
+      }
+    }
+    return have_next ? &next_b : nullptr;
+  };
   if (first) c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left = img_left (:391)
   c->have_img = true;
   const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
@@ -1120,7 +1145,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       arc_done = true;
       main_reads_planes = true;
     }
-    if (c->announced.empty()) return 0;
+    if (!had_announced) return 0;
     if (main_reads_planes) HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
     return prefetch_next(c, main_reads_planes);
   };
@@ -1137,7 +1162,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   //    enqueue is not urgent: after everything else of this frame, where the host would only wait;
   //  * mid — on a frame that publishes nothing, after the stereo LK, in its shadow;
   //  * else right away (Arc* still has to run on the main stream, or nothing to overlap with).
-  const bool defer_late = !(PUB_THIS_FRAME && !arc_done) && !c->inflight.empty();
+  // (Handing them to a second host thread was tried: the two threads' launches serialise inside
+  // the runtime and the frame got slower, so everything stays on the calling thread.)
+  const bool defer_late = !(PUB_THIS_FRAME && !arc_done) && have_next;
   const bool defer_early = !defer_late && use_spec && !PUB_THIS_FRAME;
   if (c->prev_pts.size() > 0) {  // :405-437
     const int n = (int)c->prev_pts.size();
@@ -1156,7 +1183,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       t_stB = t_stA + stM;
     } else {
       std::memcpy(pin.ptsA, c->prev_pts.data(), (size_t)n * 8);
-      HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, c->cur));
+      HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, cur_stream(c)));
       // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
       // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
       LkArgs f = make_lk(prevL, curL, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n, 3, 30, 0.01, 0);
@@ -1164,7 +1191,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                          ESVIO_FE_LK_USE_INITIAL_FLOW);
       run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
       HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_temporal_bytes, hipMemcpyDeviceToHost,
-                               c->cur));
+                               cur_stream(c)));
       if (int rc = early_work()) return rc;
       lap(1);
       HIPCHK(c, sync_main(c));
@@ -1210,11 +1237,11 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   int n_kept = n_surv;
   // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
   // launched as soon as this frame's points are final
-  const bool will_spec = !c->inflight.empty() || (defer_early && !c->announced.empty());
+  const bool will_spec = have_next || had_announced;
   auto upload_kept = [&]() -> int {
     if (!will_spec || !n_kept) return 0;
     std::memcpy(pin.kept, c->cur_pts.data(), (size_t)n_kept * 8);
-    HIPCHK(c, hipMemcpyAsync(c->d_new, pin.kept, (size_t)n_kept * 8, hipMemcpyHostToDevice, c->cur));
+    HIPCHK(c, hipMemcpyAsync(c->d_new, pin.kept, (size_t)n_kept * 8, hipMemcpyHostToDevice, cur_stream(c)));
     return 0;
   };
   if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
@@ -1222,14 +1249,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     if (will_spec && n_kept) {
       if (defer_early)
         HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
-      else if (int rc = enqueue_spec_temporal(c, n_kept, false))
-        return rc;
+      else if (const Inflight* nb = next_batch())
+        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
     }
   }
   if (n_surv) {
     std::memcpy(pin.ptsA, c->cur_pts.data(), (size_t)n_surv * 8);
     HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n_surv * 8, hipMemcpyHostToDevice,
-                             c->cur));
+                             cur_stream(c)));
     LkArgs f = make_lk(curL, curR, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n_surv, 3, 30,
                        0.01, 0);
     LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
@@ -1237,8 +1264,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   }
   if (defer_early) {
     if (int rc = early_work()) return rc;
-    if (!c->inflight.empty() && n_kept)
-      if (int rc = enqueue_spec_temporal(c, n_kept, false, false)) return rc;
+    if (n_kept)
+      if (const Inflight* nb = next_batch())
+        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false, false)) return rc;
   }
 
   if (PUB_THIS_FRAME) {  // :442-469
@@ -1249,31 +1277,33 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     const int n_max_cnt = M - n_kept;
     if (int rc = upload_kept()) return rc;
     if (n_max_cnt <= 0 && will_spec && n_kept)
-      if (int rc = enqueue_spec_temporal(c, n_kept, false)) return rc;
+      if (const Inflight* nb = next_batch())
+        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
     if (n_max_cnt > 0) {
       detect = true;
       std::memcpy(pin.mask, c->mask_event.bits.data(), c->mask_event.bits.size() * 4);
       HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
-                               hipMemcpyHostToDevice, c->cur));
+                               hipMemcpyHostToDevice, cur_stream(c)));
       if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
       if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
       {
         ScopedKernel k(c, K_COMPACT, 0);
         const esvio_fe_ctx::CandSet& cs = c->cand[c->cand_cur];
-        launch_maskfilter(c->cur, cs.xy, cs.idx, cs.cnt, (uint32_t)((nL + kArcBlock - 1) / kArcBlock),
+        launch_maskfilter(cur_stream(c), cs.xy, cs.idx, cs.cnt, (uint32_t)((nL + kArcBlock - 1) / kArcBlock),
                           c->d_mask_bits, (c->W + 31) / 32);
       }
       // new corners go behind the kept points: d_new = next frame's prev_pts
       run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, n_kept, nullptr);
       if (will_spec)
-        if (int rc = enqueue_spec_temporal(c, n_kept, true)) return rc;
+        if (const Inflight* nb = next_batch())
+          if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
       // the selection result goes to the host right away (counts .. new corners of the result
       // block), so that the left-camera bookkeeping below runs under the stereo LK of the new corners
       {
         const ResLayout RL = res_layout((size_t)std::max(M, 1));
         HIPCHK(c, hipMemcpyAsync(c->h_pin + RL.CNT, c->d_res + RL.CNT, RL.B2 - RL.CNT,
-                                 hipMemcpyDeviceToHost, c->cur));
-        HIPCHK(c, hipEventRecord(c->ev_sel_host, c->cur));
+                                 hipMemcpyDeviceToHost, cur_stream(c)));
+        HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
       }
       // stereo LK of the new corners only (count known on the device)
       LkArgs f = make_lk(curL, curR, c->d_new + n_kept, nullptr, c->d_ptsB2, c->d_stA2, c->d_counts,
@@ -1284,7 +1314,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     }
   }
   if (n_surv || detect)
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, c->cur));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, cur_stream(c)));
   if (defer_late)
     if (int rc = early_work()) return rc;
   lap(5);
@@ -1489,9 +1519,15 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     esvio_fe_destroy(c);
     return rc;
   };
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
+  // the frame's own chain (LK, selection: few, latency-bound waves) outranks the prefetch stream's
+  // wide kernels, which have a whole frame of slack
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  const bool streams_ok =
+      hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
+      hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+  if (!streams_ok ||
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_sel_host, hipEventDisableTiming) != hipSuccess ||
@@ -1501,7 +1537,6 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     if (hipEventCreateWithFlags(&c->ev_lane_done[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_lane_arc[i], hipEventDisableTiming) != hipSuccess)
       return bail(ESVIO_FE_EHIP);
-  c->cur = c->stream;
   const size_t M = cfg->max_cnt;
   int rc = 0;
   if ((rc = dev_alloc(c, &c->L2, (size_t)2 * c->P))) return bail(rc);
@@ -1546,11 +1581,11 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->h_pin_bytes = pin_bytes(*cfg);
   if (hipHostMalloc((void**)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
-  if (hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->cur) != hipSuccess ||
-      hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->cur) != hipSuccess ||
-      hipMemsetAsync(c->d_rejected, 0, 8, c->cur) != hipSuccess ||
-      hipMemsetAsync(c->d_counts, 0, 64, c->cur) != hipSuccess ||
-      hipStreamSynchronize(c->cur) != hipSuccess)
+  if (hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, cur_stream(c)) != hipSuccess ||
+      hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, cur_stream(c)) != hipSuccess ||
+      hipMemsetAsync(c->d_rejected, 0, 8, cur_stream(c)) != hipSuccess ||
+      hipMemsetAsync(c->d_counts, 0, 64, cur_stream(c)) != hipSuccess ||
+      hipStreamSynchronize(cur_stream(c)) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
   size_t lds = select_lds_bytes(c);
   if (lds > 160 * 1024) return bail(ESVIO_FE_EINVAL);
@@ -1566,9 +1601,9 @@ int esvio_fe_reset(esvio_fe_handle c) {
   c->announced.clear();
   c->inflight.clear();
   c->spec_valid = false;
-  HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, c->cur));
-  HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, cur_stream(c)));
+  HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   clear_tracker_state(c);
   return 0;
 }
@@ -1582,13 +1617,13 @@ int esvio_fe_create_sae_stereo(esvio_fe_handle c, const esvio_fe_event* left, si
   HIPCHK(c, hipSetDevice(c->dev));
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
-  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->cur));
+  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, cur_stream(c)));
   if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) return rc;
   unsigned long long rej = 0;
   int sort_err = 0;
-  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipMemcpyAsync(&sort_err, c->d_counts + 3, 4, hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipMemcpyAsync(&sort_err, c->d_counts + 3, 4, hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   if (sort_err) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
   if (n_rejected) *n_rejected = rej;
   if (c->prof_on) resolve_profile(c);
@@ -1606,11 +1641,11 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle c, const esvio_fe_event* left,
   const McParams mc = make_mc_params(motion, first);
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
-  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, c->cur));
+  HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, cur_stream(c)));
   if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
   unsigned long long rej = 0;
-  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   if (n_rejected) *n_rejected = rej;
   return 0;
 }
@@ -1628,7 +1663,7 @@ int esvio_fe_sae_to_time_surface(esvio_fe_handle c, int cam, double t_sync, uint
   if (!c->inflight.empty()) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
   render_lk_images(c, t_sync, cam ? 2 : 1, c->slot_curL, c->slot_curR, c->raw_cur);
   if (out) return copy_level0_out(c, raw_ts_desc(c, cam), out);
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -1647,8 +1682,8 @@ int esvio_fe_export_image(esvio_fe_handle c, int cam, uint8_t* dst, int space) {
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(dst, c->W, d.img[0] + (size_t)kPad * stride + kPad, stride, c->W, c->H,
                              space == ESVIO_FE_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
-                             c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+                             cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   return 0;
 }
 
@@ -1664,8 +1699,8 @@ int esvio_fe_import_image(esvio_fe_handle c, int cam, const uint8_t* src, int sp
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, src, c->W, c->W, c->H,
                              space == ESVIO_FE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                             c->cur));
-  if (space == ESVIO_FE_HOST) HIPCHK(c, hipStreamSynchronize(c->cur));  // caller may reuse src
+                             cur_stream(c)));
+  if (space == ESVIO_FE_HOST) HIPCHK(c, hipStreamSynchronize(cur_stream(c)));  // caller may reuse src
   c->ext_right_pending = true;
   return 0;
 }
@@ -1679,8 +1714,8 @@ int esvio_fe_is_corner(esvio_fe_handle c, const esvio_fe_event* ev, size_t n, in
   if (int rc = stage_events(c, ev, n, nullptr, 0, space, &dL, &dR)) return rc;
   if (int rc = ensure_arc_capacity(c, n, c->cand_cur)) return rc;
   run_arc(c, dL, (uint32_t)n, nullptr, false, true, false, c->cand_cur);
-  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, n, hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, n, hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -1703,12 +1738,12 @@ int esvio_fe_features_to_track(esvio_fe_handle c, const esvio_fe_event* ev, size
   if (mask) bm.from_bytes(mask);
   std::memcpy(pin.mask, bm.bits.data(), bm.bits.size() * 4);
   HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, bm.bits.size() * 4, hipMemcpyHostToDevice,
-                           c->cur));
+                           cur_stream(c)));
   const PyrDesc ts = raw_ts_desc(c, 0);
   run_arc(c, dL, (uint32_t)n, &ts, true, false, true, c->cand_cur);
   run_select(c, (uint32_t)n, max_corners, c->d_ptsD, 0, c->d_sel_idx);
-  HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   const int k = pin.counts[0];
   if (k > 0) {
     HIPCHK(c, hipMemcpy(out_xy, c->d_ptsD, (size_t)k * 8, hipMemcpyDeviceToHost));
@@ -1735,7 +1770,7 @@ static int planes_io(esvio_fe_handle c, int cam, double* L0, double* L1, double*
     HIPCHK(c, hipMemcpy(c->L2 + (size_t)cam * c->P, l.data(), (size_t)c->P * 16, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->S2 + (size_t)cam * c->P, s.data(), (size_t)c->P * 16, hipMemcpyHostToDevice));
   } else {
-    HIPCHK(c, hipStreamSynchronize(c->cur));
+    HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
     HIPCHK(c, hipMemcpy(l.data(), c->L2 + (size_t)cam * c->P, (size_t)c->P * 16, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(s.data(), c->S2 + (size_t)cam * c->P, (size_t)c->P * 16, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < c->P; i++) {
@@ -1779,15 +1814,15 @@ int esvio_fe_calc_optical_flow_pyr_lk(esvio_fe_handle c, const uint8_t* prev_img
   if (int rc = prep_tmp_pyr(c, 1, next_img, w, hgt, max_level)) return rc;
   PyrDesc two[2] = {c->tmp_pyr[0].d, c->tmp_pyr[1].d};
   pyr_build(c, two, 2);
-  HIPCHK(c, hipMemcpyAsync(c->d_ptsA, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->cur));
+  HIPCHK(c, hipMemcpyAsync(c->d_ptsA, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, cur_stream(c)));
   if (flags & ESVIO_FE_LK_USE_INITIAL_FLOW)
-    HIPCHK(c, hipMemcpyAsync(c->d_ptsB, next_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->cur));
+    HIPCHK(c, hipMemcpyAsync(c->d_ptsB, next_pts, (size_t)n * 8, hipMemcpyHostToDevice, cur_stream(c)));
   LkArgs f = make_lk(two[0], two[1], c->d_ptsA, c->d_ptsB, c->d_ptsB, c->d_stA, nullptr, n, max_level,
                      max_count, eps, flags);
   run_lk(c, f, nullptr, nullptr, nullptr);
-  HIPCHK(c, hipMemcpyAsync(next_pts, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipMemcpyAsync(status, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipMemcpyAsync(next_pts, c->d_ptsB, (size_t)n * 8, hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipMemcpyAsync(status, c->d_stA, (size_t)n, hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -1803,7 +1838,7 @@ int esvio_fe_build_pyramid(esvio_fe_handle c, const uint8_t* img, int w, int hgt
   pyr_build(c, &d, 1);
   if (n_levels) *n_levels = d.levels + 1;
   if (level < 0 || level > d.levels) {
-    HIPCHK(c, hipStreamSynchronize(c->cur));
+    HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
     return level < 0 ? 0 : ESVIO_FE_EINVAL;
   }
   if (lw) *lw = d.w[level];
@@ -1811,12 +1846,12 @@ int esvio_fe_build_pyramid(esvio_fe_handle c, const uint8_t* img, int w, int hgt
   const int stride = d.stride[level];
   if (out_img)
     HIPCHK(c, hipMemcpy2DAsync(out_img, d.w[level], d.img[level] + (size_t)kPad * stride + kPad,
-                               stride, d.w[level], d.h[level], hipMemcpyDeviceToHost, c->cur));
+                               stride, d.w[level], d.h[level], hipMemcpyDeviceToHost, cur_stream(c)));
   if (out_deriv)
     HIPCHK(c, hipMemcpy2DAsync(out_deriv, (size_t)d.w[level] * 4,
                                d.deriv[level] + ((size_t)kPad * stride + kPad) * 2, (size_t)stride * 4,
-                               (size_t)d.w[level] * 4, d.h[level], hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+                               (size_t)d.w[level] * 4, d.h[level], hipMemcpyDeviceToHost, cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   if (c->prof_on) resolve_profile(c);
   return 0;
 }
@@ -1902,7 +1937,7 @@ int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio
 int esvio_fe_set_profiling(esvio_fe_handle c, int on) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   resolve_profile(c);
   c->prof_on = on != 0;
   return 0;
@@ -1914,7 +1949,7 @@ int esvio_fe_get_kernel_stats(esvio_fe_handle c, int id, double* total_ms, uint6
   if (!c || id < 0 || id >= K_COUNT) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   resolve_profile(c);
   if (total_ms) *total_ms = c->stats[id].ms;
   if (launches) *launches = c->stats[id].launches;
@@ -1923,11 +1958,11 @@ int esvio_fe_get_kernel_stats(esvio_fe_handle c, int id, double* total_ms, uint6
 }
 int esvio_fe_reset_kernel_stats(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
-  HIPCHK(c, hipStreamSynchronize(c->cur));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   resolve_profile(c);
   for (auto& s : c->stats) s = KStat();
   return 0;
 }
-void* esvio_fe_stream(esvio_fe_handle c) { return c ? (void*)c->cur : nullptr; }
+void* esvio_fe_stream(esvio_fe_handle c) { return c ? (void*)cur_stream(c) : nullptr; }
 
 }  // extern "C"
