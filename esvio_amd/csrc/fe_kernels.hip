@@ -1303,10 +1303,27 @@ __device__ __forceinline__ void stamp_row(uint32_t* lds, int wpr, int W, int H, 
                                           int hw) {
   stamp_words(lds, wpr, W, H, ax, yy, hw, 0, 3);  // 2*31+1 = 63 px -> at most 3 words
 }
+// radius <= 15: the row's span is at most 31 px, i.e. one 64-bit shifted mask = two words (the
+// second OR is 0 when the span stays inside one word; the bitmap is followed by spare words)
+__device__ __forceinline__ void stamp_row_small(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
+                                                int hw) {
+  const bool valid = hw >= 0 && (unsigned)yy < (unsigned)H;
+  const int xa = max(ax - hw, 0), xb = min(ax + hw, W - 1);
+  const int len = valid ? xb - xa + 1 : 0;  // <= 31
+  const unsigned long long mm = (unsigned long long)((1u << len) - 1u) << (xa & 31);
+  uint32_t* wp = lds + (min(max(yy, 0), H - 1) * wpr + (xa >> 5));
+  __hip_atomic_fetch_or(wp, (uint32_t)mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __hip_atomic_fetch_or(wp + 1, (uint32_t)(mm >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 __device__ __forceinline__ void stamp_row_tail(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
                                                int hw) {
   stamp_words(lds, wpr, W, H, ax, yy, hw, 3, 5);  // r <= 63: 127 px -> at most 5 words
 }
+
+// sub-chunks with more live candidates than this are resolved as a batch (see k_select)
+constexpr int kSelectBatchMin = 4;
+constexpr int kSelectGroup = 8;
+constexpr int kSelectLaneStampMin = 12;  // accepted discs per sub-chunk above which each lane stamps its own
 
 __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1371,6 +1388,78 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
       // discs stamped while earlier sub-chunks were processed are visible through the bitmap
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
       bool alive = have && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+      const unsigned long long m_alive = __ballot(alive);
+      if (__builtin_popcountll(m_alive) > kSelectBatchMin) {
+        // Many live candidates in this sub-chunk (the usual case while the image is still empty):
+        // resolve the whole sub-chunk at once.  B_j = lanes whose pixel lies inside candidate j's
+        // disc (one readlane + a handful of VALU ops + a compare per j, independent across j);
+        // the greedy itself then runs on the scalar unit over 64-bit lane masks, in stream order.
+        unsigned long long dead = ~m_alive, acc = 0;
+        unsigned long long rem = m_alive;  // live candidates not yet looked at, in stream order
+        const int room = a.max_corners - accepted;
+        while (rem && __builtin_popcountll(acc) < room) {
+          // a group of live candidates, staged so that the table look-ups are in flight together
+          unsigned long long bit[kSelectGroup], Bdy[kSelectGroup];
+          int dxs[kSelectGroup], hws[kSelectGroup];
+#pragma unroll
+          for (int g = 0; g < kSelectGroup; g++) {
+            const int q = rem ? __builtin_ctzll(rem) : 0;
+            bit[g] = rem & (0ull - rem);  // lowest live candidate (0 when none is left)
+            rem &= rem - 1ull;            // (0 stays 0)
+            const int ax = __builtin_amdgcn_readlane(x, q), ay = __builtin_amdgcn_readlane(y, q);
+            const int dy = (int)__builtin_amdgcn_sad_u16((unsigned)y, (unsigned)ay, 0u);
+            dxs[g] = (int)__builtin_amdgcn_sad_u16((unsigned)x, (unsigned)ax, 0u);
+            Bdy[g] = bal(dy <= r);
+            hws[g] = hwtab[min(dy, 63)];
+          }
+#pragma unroll
+          for (int g = 0; g < kSelectGroup; g++) {
+            const unsigned long long B = Bdy[g] & bal(dxs[g] <= hws[g]);  // lanes inside this disc
+            const unsigned long long t = bit[g] & ~dead;                  // candidate still free?
+            acc |= t;
+            dead |= t ? B : 0ull;
+          }
+        }
+        // only the first (max_corners - accepted) of them count
+        const int before = __builtin_popcountll(acc & ((1ull << lane) - 1ull));
+        const bool mine = ((acc >> lane) & 1ull) && before < room;
+        if (mine) {
+          a.out_pts[a.out_base + accepted + before] = make_float2((float)x, (float)y);
+          if (a.out_idx) a.out_idx[accepted + before] = (int)cci[j];
+        }
+        accepted += min(__builtin_popcountll(acc), room);
+        if (accepted >= a.max_corners) break;
+        // stamp the accepted discs for the later sub-chunks
+        if (__builtin_popcountll(acc) > kSelectLaneStampMin) {
+          // many: one lane per disc, rows in a uniform loop
+          for (int row = 0; row <= 2 * r; row++) {
+            const int hwr = mine ? (int)a.hw[row < r ? r - row : row - r] : -1;
+            if (r <= 15) {
+              stamp_row_small(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+            } else {
+              stamp_row(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+              if (r > 31) stamp_row_tail(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+            }
+          }
+        } else {
+          // few: one disc at a time, one lane per row
+          for (unsigned long long todo = acc; todo; todo &= todo - 1ull) {
+            const int q = __builtin_ctzll(todo);
+            const int ax = __builtin_amdgcn_readlane(x, q), ay = __builtin_amdgcn_readlane(y, q);
+            if (r <= 15) {
+              stamp_row_small(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+              continue;
+            }
+            stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+            if (r > 31) {
+              stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
+              stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+              stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
+            }
+          }
+        }
+        continue;
+      }
       while (accepted < a.max_corners) {
         const unsigned long long m = __ballot(alive);
         if (!m) break;
@@ -1385,7 +1474,11 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         accepted++;
         // stamp the disc for the LATER sub-chunks (LDS atomic OR, not waited for here): one lane
         // per row, branch-free: the row's span [xa,xb] touches at most 3 words for r <= 31
-        stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+        if (r <= 15) {
+          stamp_row_small(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+        } else {
+          stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+        }
         if (r > 31) {  // wave-uniform: rows 64.. of a large disc
           stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
           stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
