@@ -167,11 +167,19 @@ struct esvio_fe_ctx {
   float2 *d_new = nullptr, *d_ptsB2 = nullptr, *d_ptsC2 = nullptr;  // d_new: [kept | new corners]
   uint8_t *d_stA2 = nullptr, *d_stB2 = nullptr;
   int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total [2]=#candidates
+  // The per-frame path works on the pinned host block itself (device-visible): the LK kernels read
+  // their points from it and write results into it, k_select mirrors its counters into it — no
+  // H2D / D2H copy calls on the frame's critical path (each costs more host time than the few
+  // hundred bytes take over PCIe).  z_* = device-side addresses of the h_pin / h_spec regions.
+  uint8_t *z_res = nullptr, *z_spec = nullptr;
+  float2 *z_ptsA = nullptr, *z_ptsB = nullptr, *z_ptsC = nullptr, *z_new = nullptr, *z_ptsB2 = nullptr,
+         *z_ptsC2 = nullptr;
+  uint8_t *z_stA = nullptr, *z_stB = nullptr, *z_stA2 = nullptr, *z_stB2 = nullptr;
+  int* z_counts = nullptr;
   // ---- speculative temporal LK of the next frame (replay mode): once this frame's kept points
   // and new corners are final, next frame's calcOpticalFlowPyrLK(cur -> next) pair is launched on
   // stream3 against the prefetched pyramids, so it overlaps this frame's stereo LK and host tail
-  uint8_t* d_spec = nullptr;  // [ptsB | ptsC | stA | stB] of that launch
-  uint8_t* h_spec = nullptr;  // pinned mirror
+  uint8_t* h_spec = nullptr;  // pinned, device-visible: [ptsB | ptsC | stA | stB] of that launch
   size_t spec_bytes = 0;
   bool spec_valid = false;
   int spec_n = 0;             // number of points of that launch (= the next frame's prev_pts.size())
@@ -505,7 +513,7 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
     ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 16);
     launch_radix_pass(cur_stream(c), c->keys[cur], c->vals[cur], n, p * bits, bits, ghist + ((size_t)p << bits),
                       lookback + (size_t)p * (nblk << bits), tickets + p, c->keys[cur ^ 1],
-                      c->vals[cur ^ 1], c->d_counts + 3);
+                      c->vals[cur ^ 1], c->z_counts + 3);
     cur ^= 1;
   }
   {
@@ -789,8 +797,9 @@ struct Pin {
   float2* news;           // [kept points (as uploaded) | newly selected corners]
   float2 *ptsB2, *ptsC2;  // set 2
   uint8_t *stA2, *stB2;
-  float2* ptsA;           // H2D prev_pts / survivors
-  float2* kept;           // H2D kept points for the speculative next-frame LK
+  float2* A;              // LK input points (read by the kernels in place)
+  float2* ptsA;           // staging for the standalone entry points' H2D copies
+  float2* kept;           // (spare)
   uint32_t* mask;         // H2D H*wpr words
 };
 
@@ -805,6 +814,7 @@ Pin pin_of(esvio_fe_ctx* c) {
   p.stB = b + L.SB1;
   p.counts = (int*)(b + L.CNT);
   p.news = (float2*)(b + L.NEW);
+  p.A = (float2*)(b + L.A);
   p.ptsB2 = (float2*)(b + L.B2);
   p.ptsC2 = (float2*)(b + L.C2);
   p.stA2 = b + L.SA2;
@@ -866,6 +876,7 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int max_corners, float2* out_pts, i
   s.out_base = out_base;
   s.n_out = c->d_counts;
   s.n_total = c->d_counts + 1;
+  s.host_counts = nullptr;
   return s;
 }
 
@@ -875,7 +886,7 @@ size_t select_lds_bytes(const esvio_fe_ctx* c) {
 
 // ordered compaction of the Arc* candidates, then the sequential greedy (Event_FeaturesToTrack)
 void run_select(esvio_fe_ctx* c, uint32_t n_events, int max_corners, float2* out_pts, int out_base,
-                int32_t* out_idx) {
+                int32_t* out_idx, int* host_counts = nullptr) {
   const uint32_t nblk = (n_events + kArcBlock - 1) / kArcBlock;
   {
     ScopedKernel k(c, K_COMPACT, 0);
@@ -884,6 +895,7 @@ void run_select(esvio_fe_ctx* c, uint32_t n_events, int max_corners, float2* out
                    (uint32_t*)(c->d_counts + 2));
   }
   SelectArgs s = make_select_args(c, max_corners, out_pts, out_base, out_idx);
+  s.host_counts = host_counts;
   ScopedKernel k(c, K_SELECT, 0);
   launch_select(cur_stream(c), s, select_lds_bytes(c));
 }
@@ -1004,28 +1016,29 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
 // new corners (written by k_select behind them, total count in d_counts[1]) are known, and the next
 // frame's pyramids are already being built on the prefetch stream.
 int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame's batch */,
-                          int n_kept, bool with_new, bool record_pts_ready = true) {
+                          int n_kept, bool with_new) {
   const size_t M = std::max(c->cfg.max_cnt, 1);
   const size_t stM = (M + 63) / 64 * 64;
-  if (record_pts_ready) HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_pts_ready, 0));
+  if (with_new) {  // the new corners come from k_select on the main stream (kept ones: host memory)
+    HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_pts_ready, 0));
+  }
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_lane_done[nxt.lane], 0));
-  float2* B = (float2*)c->d_spec;
+  float2* B = (float2*)c->z_spec;  // results land in the pinned block itself
   float2* Cb = B + M;
-  uint8_t* sA = c->d_spec + M * 16;
+  uint8_t* sA = c->z_spec + M * 16;
   uint8_t* sB = sA + stM;
   const PyrDesc& P = c->pyr[c->slot_curL].d;
   const PyrDesc& N = c->pyr[nxt.slotL].d;
   const int* n_ptr = with_new ? c->d_counts + 1 : nullptr;
   const int n_max = with_new ? (int)M : n_kept;
-  LkArgs f = make_lk(P, N, c->d_new, nullptr, B, sA, n_ptr, n_max, 3, 30, 0.01, 0);
+  LkArgs f = make_lk(P, N, c->z_new, nullptr, B, sA, n_ptr, n_max, 3, 30, 0.01, 0);
   LkArgs b = make_lk(N, P, nullptr, nullptr, nullptr, nullptr, n_ptr, n_max, 1, 30, 0.01,
                      ESVIO_FE_LK_USE_INITIAL_FLOW);
   {
     StreamScope on_spec_stream(c->stream3);
     run_lk(c, f, c->cfg.flow_back ? &b : nullptr, Cb, sB);
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_spec, c->d_spec, c->spec_bytes, hipMemcpyDeviceToHost, c->stream3));
   HIPCHK(c, hipEventRecord(c->ev_spec_done, c->stream3));
   c->spec_valid = true;
   return 0;
@@ -1182,16 +1195,13 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       t_stA = c->h_spec + (size_t)std::max(M, 1) * 16;
       t_stB = t_stA + stM;
     } else {
-      std::memcpy(pin.ptsA, c->prev_pts.data(), (size_t)n * 8);
-      HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n * 8, hipMemcpyHostToDevice, cur_stream(c)));
+      std::memcpy(pin.A, c->prev_pts.data(), (size_t)n * 8);
       // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
       // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
-      LkArgs f = make_lk(prevL, curL, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n, 3, 30, 0.01, 0);
+      LkArgs f = make_lk(prevL, curL, c->z_ptsA, nullptr, c->z_ptsB, c->z_stA, nullptr, n, 3, 30, 0.01, 0);
       LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
                          ESVIO_FE_LK_USE_INITIAL_FLOW);
-      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
-      HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_temporal_bytes, hipMemcpyDeviceToHost,
-                               cur_stream(c)));
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC, c->z_stB);
       if (int rc = early_work()) return rc;
       lap(1);
       HIPCHK(c, sync_main(c));
@@ -1240,33 +1250,27 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   const bool will_spec = have_next || had_announced;
   auto upload_kept = [&]() -> int {
     if (!will_spec || !n_kept) return 0;
-    std::memcpy(pin.kept, c->cur_pts.data(), (size_t)n_kept * 8);
-    HIPCHK(c, hipMemcpyAsync(c->d_new, pin.kept, (size_t)n_kept * 8, hipMemcpyHostToDevice, cur_stream(c)));
+    std::memcpy(pin.news, c->cur_pts.data(), (size_t)n_kept * 8);  // read in place by the LK
     return 0;
   };
   if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
     if (int rc = upload_kept()) return rc;
-    if (will_spec && n_kept) {
-      if (defer_early)
-        HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
-      else if (const Inflight* nb = next_batch())
+    if (will_spec && n_kept && !defer_early)
+      if (const Inflight* nb = next_batch())
         if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
-    }
   }
   if (n_surv) {
-    std::memcpy(pin.ptsA, c->cur_pts.data(), (size_t)n_surv * 8);
-    HIPCHK(c, hipMemcpyAsync(c->d_ptsA, pin.ptsA, (size_t)n_surv * 8, hipMemcpyHostToDevice,
-                             cur_stream(c)));
-    LkArgs f = make_lk(curL, curR, c->d_ptsA, nullptr, c->d_ptsB, c->d_stA, nullptr, n_surv, 3, 30,
+    std::memcpy(pin.A, c->cur_pts.data(), (size_t)n_surv * 8);
+    LkArgs f = make_lk(curL, curR, c->z_ptsA, nullptr, c->z_ptsB, c->z_stA, nullptr, n_surv, 3, 30,
                        0.01, 0);
     LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
-    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC, c->d_stB);
+    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC, c->z_stB);
   }
   if (defer_early) {
     if (int rc = early_work()) return rc;
     if (n_kept)
       if (const Inflight* nb = next_batch())
-        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false, false)) return rc;
+        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
   }
 
   if (PUB_THIS_FRAME) {  // :442-469
@@ -1293,28 +1297,21 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                           c->d_mask_bits, (c->W + 31) / 32);
       }
       // new corners go behind the kept points: d_new = next frame's prev_pts
-      run_select(c, (uint32_t)nL, n_max_cnt, c->d_new, n_kept, nullptr);
+      run_select(c, (uint32_t)nL, n_max_cnt, c->z_new, n_kept, nullptr, c->z_counts);
       if (will_spec)
         if (const Inflight* nb = next_batch())
           if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
-      // the selection result goes to the host right away (counts .. new corners of the result
-      // block), so that the left-camera bookkeeping below runs under the stereo LK of the new corners
-      {
-        const ResLayout RL = res_layout((size_t)std::max(M, 1));
-        HIPCHK(c, hipMemcpyAsync(c->h_pin + RL.CNT, c->d_res + RL.CNT, RL.B2 - RL.CNT,
-                                 hipMemcpyDeviceToHost, cur_stream(c)));
-        HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
-      }
+      // the selection result is in host memory once k_select is done: an event right behind it lets
+      // the left-camera bookkeeping below run under the stereo LK of the new corners
+      HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
       // stereo LK of the new corners only (count known on the device)
-      LkArgs f = make_lk(curL, curR, c->d_new + n_kept, nullptr, c->d_ptsB2, c->d_stA2, c->d_counts,
+      LkArgs f = make_lk(curL, curR, c->z_new + n_kept, nullptr, c->z_ptsB2, c->z_stA2, c->d_counts,
                          n_max_cnt, 3, 30, 0.01, 0);
       LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, c->d_counts, n_max_cnt, 3, 30,
                          0.01, 0);
-      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->d_ptsC2, c->d_stB2);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC2, c->z_stB2);
     }
   }
-  if (n_surv || detect)
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->d_res, c->res_bytes, hipMemcpyDeviceToHost, cur_stream(c)));
   if (defer_late)
     if (int rc = early_work()) return rc;
   lap(5);
@@ -1448,7 +1445,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->cand[0].xy, c->cand[0].idx,
                   c->cand[0].cnt, c->cand[1].xy, c->cand[1].idx, c->cand[1].cnt, c->d_comp_xy,
                   c->d_comp_idx, c->d_mask_bits, c->d_sel_idx,
-                  c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->d_lut, c->d_minmax, c->d_spec};
+                  c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->d_lut, c->d_minmax};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (PyrStore& ps : c->pyr)
@@ -1562,9 +1559,10 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   {
     const size_t stM = (std::max<size_t>(M, 1) + 63) / 64 * 64;
     c->spec_bytes = std::max<size_t>(M, 1) * 16 + 2 * stM;
-    if ((rc = dev_alloc(c, &c->d_spec, c->spec_bytes))) return bail(rc);
-    if (hipHostMalloc((void**)&c->h_spec, c->spec_bytes, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc((void**)&c->h_spec, c->spec_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->z_spec, c->h_spec, 0) != hipSuccess)
       return bail(ESVIO_FE_EHIP);
+    std::memset(c->h_spec, 0, c->spec_bytes);
   }
   if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_sel_idx, M))) return bail(rc);
@@ -1579,8 +1577,24 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     if ((rc = dev_alloc(c, &c->d_minmax, 4))) return bail(rc);
   }
   c->h_pin_bytes = pin_bytes(*cfg);
-  if (hipHostMalloc((void**)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess)
+  if (hipHostMalloc((void**)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->z_res, c->h_pin, 0) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
+  std::memset(c->h_pin, 0, c->h_pin_bytes);
+  {
+    const ResLayout L = res_layout(std::max<size_t>(M, 1));
+    c->z_ptsB = (float2*)(c->z_res + L.B1);
+    c->z_ptsC = (float2*)(c->z_res + L.C1);
+    c->z_stA = c->z_res + L.SA1;
+    c->z_stB = c->z_res + L.SB1;
+    c->z_counts = (int*)(c->z_res + L.CNT);
+    c->z_ptsA = (float2*)(c->z_res + L.A);
+    c->z_new = (float2*)(c->z_res + L.NEW);
+    c->z_ptsB2 = (float2*)(c->z_res + L.B2);
+    c->z_ptsC2 = (float2*)(c->z_res + L.C2);
+    c->z_stA2 = c->z_res + L.SA2;
+    c->z_stB2 = c->z_res + L.SB2;
+  }
   if (hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, cur_stream(c)) != hipSuccess ||
       hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, cur_stream(c)) != hipSuccess ||
       hipMemsetAsync(c->d_rejected, 0, 8, cur_stream(c)) != hipSuccess ||
@@ -1620,11 +1634,9 @@ int esvio_fe_create_sae_stereo(esvio_fe_handle c, const esvio_fe_event* left, si
   HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, cur_stream(c)));
   if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) return rc;
   unsigned long long rej = 0;
-  int sort_err = 0;
   HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, cur_stream(c)));
-  HIPCHK(c, hipMemcpyAsync(&sort_err, c->d_counts + 3, 4, hipMemcpyDeviceToHost, cur_stream(c)));
   HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
-  if (sort_err) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
+  if (pin_of(c).counts[3]) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
   if (n_rejected) *n_rejected = rej;
   if (c->prof_on) resolve_profile(c);
   return 0;

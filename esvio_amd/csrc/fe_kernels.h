@@ -154,6 +154,7 @@ struct SelectArgs {
   int out_base;
   int* n_out;                // number accepted
   int* n_total;              // out_base + accepted (feeds the LK kernels' n_ptr), may be NULL
+  int* host_counts;          // optional host-mapped mirror: {accepted, out_base + accepted, total}
 };
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes);
 

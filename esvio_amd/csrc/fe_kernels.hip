@@ -1496,6 +1496,11 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   if (lane == 0) {
     *a.n_out = accepted;
     if (a.n_total) *a.n_total = a.out_base + accepted;
+    if (a.host_counts) {
+      a.host_counts[0] = accepted;
+      a.host_counts[1] = a.out_base + accepted;
+      a.host_counts[2] = (int)total;
+    }
   }
 }
 
