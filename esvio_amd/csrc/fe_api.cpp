@@ -189,10 +189,11 @@ struct esvio_fe_ctx {
   // batch (prefetch stream) never overwrites the set the current frame's selection still reads
   struct CandSet {
     uint32_t *xy = nullptr, *idx = nullptr, *cnt = nullptr;
+    // ... and their ordered compaction into one stream (k_compact, launched right behind k_arc)
+    uint32_t *comp_xy = nullptr, *comp_idx = nullptr, *total = nullptr;
     size_t cap = 0;
   } cand[kRightSlots];
   int cand_cur = 0;
-  uint32_t *d_comp_xy = nullptr, *d_comp_idx = nullptr;
   size_t arc_cap = 0;
   uint32_t* d_mask_bits = nullptr;
   int32_t* d_sel_idx = nullptr;
@@ -363,32 +364,30 @@ int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n) {
   if (n <= s.cap) return 0;
   size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
   cap = (cap + kArcBlock - 1) / kArcBlock * kArcBlock;
-  void* ptrs[] = {s.xy, s.idx, s.cnt};
+  void* ptrs[] = {s.xy, s.idx, s.cnt, s.comp_xy, s.comp_idx, s.total};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   s = esvio_fe_ctx::CandSet();
   if (int rc = dev_alloc(c, &s.xy, cap)) return rc;
   if (int rc = dev_alloc(c, &s.idx, cap)) return rc;
   if (int rc = dev_alloc(c, &s.cnt, cap / kArcBlock)) return rc;
+  if (int rc = dev_alloc(c, &s.comp_xy, cap)) return rc;
+  if (int rc = dev_alloc(c, &s.comp_idx, cap)) return rc;
+  if (int rc = dev_alloc(c, &s.total, 1)) return rc;
   s.cap = cap;
   return 0;
 }
 
-// flags + compacted candidate stream (main stream only) and candidate set `set`
+// per-event flags (standalone isCorner) and candidate set `set`
 int ensure_arc_capacity(esvio_fe_ctx* c, size_t n, int set) {
   if (int rc = ensure_cand_capacity(c, set, n)) return rc;
   if (n <= c->arc_cap) return 0;
   size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
   cap = (cap + kArcBlock - 1) / kArcBlock * kArcBlock;
-  void* ptrs[] = {c->d_flags, c->d_comp_xy, c->d_comp_idx};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  if (c->d_flags) (void)hipFree(c->d_flags);
   c->d_flags = nullptr;
-  c->d_comp_xy = c->d_comp_idx = nullptr;
   c->arc_cap = 0;
   if (int rc = dev_alloc(c, &c->d_flags, cap)) return rc;
-  if (int rc = dev_alloc(c, &c->d_comp_xy, cap)) return rc;
-  if (int rc = dev_alloc(c, &c->d_comp_idx, cap)) return rc;
   c->arc_cap = cap;
   return 0;
 }
@@ -859,12 +858,12 @@ void clear_tracker_state(esvio_fe_ctx* c) {
   c->cur_time = c->prev_time = 0;
 }
 
-SelectArgs make_select_args(esvio_fe_ctx* c, int max_corners, float2* out_pts, int out_base,
+SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int out_base,
                             int32_t* out_idx) {
   SelectArgs s{};
-  s.comp_xy = c->d_comp_xy;
-  s.comp_idx = c->d_comp_idx;
-  s.total = (const uint32_t*)(c->d_counts + 2);
+  s.comp_xy = c->cand[set].comp_xy;
+  s.comp_idx = c->cand[set].comp_idx;
+  s.total = c->cand[set].total;
   s.W = c->W;
   s.H = c->H;
   s.wpr = (c->W + 31) / 32;
@@ -877,6 +876,7 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int max_corners, float2* out_pts, i
   s.n_out = c->d_counts;
   s.n_total = c->d_counts + 1;
   s.host_counts = nullptr;
+  s.init_bits = nullptr;
   return s;
 }
 
@@ -884,18 +884,21 @@ size_t select_lds_bytes(const esvio_fe_ctx* c) {
   return ((size_t)c->H * ((c->W + 31) / 32) + 4 + 64) * 4;  // bitmap + half-width table
 }
 
-// ordered compaction of the Arc* candidates, then the sequential greedy (Event_FeaturesToTrack)
-void run_select(esvio_fe_ctx* c, uint32_t n_events, int max_corners, float2* out_pts, int out_base,
-                int32_t* out_idx, int* host_counts = nullptr) {
+// ordered compaction of candidate set `set` (right behind the k_arc that filled it)
+void run_compact(esvio_fe_ctx* c, uint32_t n_events, int set) {
   const uint32_t nblk = (n_events + kArcBlock - 1) / kArcBlock;
-  {
-    ScopedKernel k(c, K_COMPACT, 0);
-    const esvio_fe_ctx::CandSet& cs = c->cand[c->cand_cur];
-    launch_compact(cur_stream(c), cs.xy, cs.idx, cs.cnt, nblk, c->d_comp_xy, c->d_comp_idx,
-                   (uint32_t*)(c->d_counts + 2));
-  }
-  SelectArgs s = make_select_args(c, max_corners, out_pts, out_base, out_idx);
+  const esvio_fe_ctx::CandSet& cs = c->cand[set];
+  ScopedKernel k(c, K_COMPACT, 0);
+  launch_compact(cur_stream(c), cs.xy, cs.idx, cs.cnt, nblk, cs.comp_xy, cs.comp_idx, cs.total);
+}
+
+// the sequential greedy (Event_FeaturesToTrack) over the compacted candidates of set `set`;
+// `mask_bits`: blocked pixels the disc bitmap starts from (null: none, or already applied by k_arc)
+void run_select(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int out_base,
+                int32_t* out_idx, const uint32_t* mask_bits = nullptr, int* host_counts = nullptr) {
+  SelectArgs s = make_select_args(c, set, max_corners, out_pts, out_base, out_idx);
   s.host_counts = host_counts;
+  s.init_bits = mask_bits;
   ScopedKernel k(c, K_SELECT, 0);
   launch_select(cur_stream(c), s, select_lds_bytes(c));
 }
@@ -998,6 +1001,7 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
         if ((rc = ensure_cand_capacity(c, b.cand, b.nL))) break;
         const PyrDesc& ts = c->cfg.equalize ? c->raw[b.raw][0].d : c->pyr[b.slotL].d;
         run_arc(c, b.dL, (uint32_t)b.nL, &ts, false, false, true, b.cand);
+        run_compact(c, (uint32_t)b.nL, b.cand);
         if (hipEventRecord(c->ev_lane_arc[b.lane], c->stream2) != hipSuccess) {
           rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
           break;
@@ -1144,7 +1148,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
 
   // Arc* for every left event does not depend on the tracks: on published frames it is enqueued
   // now (behind the temporal LK) without the blocked-pixel mask, so it runs under the host-side
-  // filtering / RANSAC / Event_setMask; k_maskfilter applies the mask afterwards.  After it
+  // filtering / RANSAC / Event_setMask; the mask becomes k_select's initial bitmap.  After it
   // nothing of this frame reads the planes on the main stream, so the announced next batch is
   // started on the prefetch stream.
   bool early_done = false;
@@ -1155,6 +1159,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
       const PyrDesc ts = raw_ts_desc(c, 0);
       run_arc(c, dL, (uint32_t)nL, &ts, false, false, true, c->cand_cur);
+      run_compact(c, (uint32_t)nL, c->cand_cur);
       arc_done = true;
       main_reads_planes = true;
     }
@@ -1288,16 +1293,10 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       std::memcpy(pin.mask, c->mask_event.bits.data(), c->mask_event.bits.size() * 4);
       HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
                                hipMemcpyHostToDevice, cur_stream(c)));
-      if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
       if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
-      {
-        ScopedKernel k(c, K_COMPACT, 0);
-        const esvio_fe_ctx::CandSet& cs = c->cand[c->cand_cur];
-        launch_maskfilter(cur_stream(c), cs.xy, cs.idx, cs.cnt, (uint32_t)((nL + kArcBlock - 1) / kArcBlock),
-                          c->d_mask_bits, (c->W + 31) / 32);
-      }
       // new corners go behind the kept points: d_new = next frame's prev_pts
-      run_select(c, (uint32_t)nL, n_max_cnt, c->z_new, n_kept, nullptr, c->z_counts);
+      // (the blocked pixels are the greedy's initial bitmap: candidates on them are skipped there)
+      run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, c->d_mask_bits, c->z_counts);
       if (will_spec)
         if (const Inflight* nb = next_batch())
           if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
@@ -1442,12 +1441,15 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
-                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->cand[0].xy, c->cand[0].idx,
-                  c->cand[0].cnt, c->cand[1].xy, c->cand[1].idx, c->cand[1].cnt, c->d_comp_xy,
-                  c->d_comp_idx, c->d_mask_bits, c->d_sel_idx,
+                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags,
+                  c->d_mask_bits, c->d_sel_idx,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->d_lut, c->d_minmax};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto& cs : c->cand)
+    for (void* p : {(void*)cs.xy, (void*)cs.idx, (void*)cs.cnt, (void*)cs.comp_xy, (void*)cs.comp_idx,
+                    (void*)cs.total})
+      if (p) (void)hipFree(p);
   for (PyrStore& ps : c->pyr)
     if (ps.mem) (void)hipFree(ps.mem);
   for (auto& rb : c->raw)
@@ -1753,7 +1755,8 @@ int esvio_fe_features_to_track(esvio_fe_handle c, const esvio_fe_event* ev, size
                            cur_stream(c)));
   const PyrDesc ts = raw_ts_desc(c, 0);
   run_arc(c, dL, (uint32_t)n, &ts, true, false, true, c->cand_cur);
-  run_select(c, (uint32_t)n, max_corners, c->d_ptsD, 0, c->d_sel_idx);
+  run_compact(c, (uint32_t)n, c->cand_cur);
+  run_select(c, c->cand_cur, max_corners, c->d_ptsD, 0, c->d_sel_idx);
   HIPCHK(c, hipMemcpyAsync(pin.counts, c->d_counts, 8, hipMemcpyDeviceToHost, cur_stream(c)));
   HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   const int k = pin.counts[0];

@@ -133,9 +133,6 @@ struct ArcArgs {
 };
 void launch_arc(hipStream_t s, const ArcArgs& a);
 
-// drop candidates on blocked pixels, in place, order kept (one block per Arc* block)
-void launch_maskfilter(hipStream_t s, uint32_t* cand_xy, uint32_t* cand_idx, uint32_t* cand_cnt,
-                       uint32_t nblk, const uint32_t* mask_bits, int wpr);
 // ordered compaction of the per-block candidate lists (parallel; one block per Arc* block)
 void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand_idx,
                     const uint32_t* cand_cnt, uint32_t nblk, uint32_t* comp_xy, uint32_t* comp_idx,
@@ -155,6 +152,7 @@ struct SelectArgs {
   int* n_out;                // number accepted
   int* n_total;              // out_base + accepted (feeds the LK kernels' n_ptr), may be NULL
   int* host_counts;          // optional host-mapped mirror: {accepted, out_base + accepted, total}
+  const uint32_t* init_bits; // optional H*wpr words the disc bitmap starts from (blocked pixels)
 };
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes);
 

@@ -1201,53 +1201,9 @@ void launch_arc(hipStream_t s, const ArcArgs& a) {
 // Event_FeaturesToTrack (feature_tracker.cpp:13-38): candidates in stream order; accept iff the
 // pixel is not blocked; stamp cv::circle(r = MIN_DIST, filled) [OpenCV midpoint disc]; stop at
 // max_corners.  k_compact turns the per-block candidate lists into one ordered list (parallel),
-// k_select is the inherently sequential greedy: ONE wave, blocked-bitmap of new discs in LDS,
-// 64 candidates tested per step, ballot picks the first alive one.
-// Drop the candidates that fall on an already blocked pixel (Event_setMask's discs), keeping the
-// order, in place, one block per Arc* block.  Lets k_arc run before the mask exists (it overlaps
-// the host-side RANSAC / Event_setMask) — the mask test of feature_tracker.cpp:25 commutes with
-// the corner test.
-__global__ __launch_bounds__(kArcBlock) void k_maskfilter(uint32_t* __restrict__ cand_xy,
-                                                          uint32_t* __restrict__ cand_idx,
-                                                          uint32_t* __restrict__ cand_cnt,
-                                                          const uint32_t* __restrict__ mask_bits,
-                                                          int wpr) {
-  __shared__ uint32_t wave_cnt[kArcBlock / 64];
-  const uint32_t b = blockIdx.x;
-  const uint32_t c = cand_cnt[b];
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  uint32_t xy = 0, ci = 0;
-  bool keep = false;
-  if (threadIdx.x < c) {
-    xy = cand_xy[(size_t)b * kArcBlock + threadIdx.x];
-    ci = cand_idx[(size_t)b * kArcBlock + threadIdx.x];
-    const uint32_t x = xy & 0xffffu, y = xy >> 16;
-    keep = !((mask_bits[y * wpr + (x >> 5)] >> (x & 31)) & 1u);
-  }
-  const unsigned long long m = __ballot(keep);
-  if (lane == 0) wave_cnt[wave] = __popcll(m);
-  __syncthreads();  // also: every thread has read its candidate before anyone overwrites
-  uint32_t base = 0;
-  for (int w = 0; w < wave; w++) base += wave_cnt[w];
-  if (keep) {
-    const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-    cand_xy[(size_t)b * kArcBlock + pos] = xy;
-    cand_idx[(size_t)b * kArcBlock + pos] = ci;
-  }
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int w = 0; w < kArcBlock / 64; w++) t += wave_cnt[w];
-    cand_cnt[b] = t;
-  }
-}
-
-void launch_maskfilter(hipStream_t s, uint32_t* cand_xy, uint32_t* cand_idx, uint32_t* cand_cnt,
-                       uint32_t nblk, const uint32_t* mask_bits, int wpr) {
-  if (!nblk) return;
-  hipLaunchKernelGGL(k_maskfilter, dim3(nblk), dim3(kArcBlock), 0, s, cand_xy, cand_idx, cand_cnt,
-                     mask_bits, wpr);
-}
-
+// k_select is the inherently sequential greedy: ONE wave, bitmap of blocked pixels + new discs in
+// LDS (seeded with Event_setMask's bitmap, so k_arc can run before that mask exists — the mask
+// test of feature_tracker.cpp:25 commutes with the corner test), 64 candidates per sub-chunk.
 __global__ __launch_bounds__(kArcBlock) void k_compact(const uint32_t* __restrict__ cand_xy,
                                                        const uint32_t* __restrict__ cand_idx,
                                                        const uint32_t* __restrict__ cand_cnt,
@@ -1331,11 +1287,31 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   const int lane = lane_id();
   const int nwords = a.H * a.wpr;
   int* const hwtab = (int*)(lds + ((nwords + 3) & ~3));  // cv::circle half-widths by |dy|, -1 beyond r
-  for (int i = lane * 4; i < nwords; i += 256) {
-    if (i + 3 < nwords) {
-      *(uint4*)(lds + i) = make_uint4(0, 0, 0, 0);
-    } else {
-      for (int k = i; k < nwords; k++) lds[k] = 0;
+  // the bitmap starts empty, or from the caller's blocked-pixel bitmap (Event_setMask): a candidate
+  // on a blocked pixel is then skipped exactly like one inside an already stamped disc
+  if (a.init_bits) {
+    constexpr int kInFlight = 8;  // 8 x 16 B loads per lane in flight: the copy is latency-bound
+    for (int i0 = lane * 4; i0 < nwords; i0 += 256 * kInFlight) {
+      uint4 v[kInFlight];
+#pragma unroll
+      for (int k = 0; k < kInFlight; k++) {
+        const int i = i0 + 256 * k;
+        v[k] = i + 3 < nwords ? *(const uint4*)(a.init_bits + i) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < kInFlight; k++) {
+        const int i = i0 + 256 * k;
+        if (i + 3 < nwords) *(uint4*)(lds + i) = v[k];
+      }
+    }
+    for (int k = (nwords & ~3) + lane; k < nwords; k += 64) lds[k] = a.init_bits[k];
+  } else {
+    for (int i = lane * 4; i < nwords; i += 256) {
+      if (i + 3 < nwords) {
+        *(uint4*)(lds + i) = make_uint4(0, 0, 0, 0);
+      } else {
+        for (int k = i; k < nwords; k++) lds[k] = 0;
+      }
     }
   }
   const int r = a.radius;
