@@ -45,10 +45,10 @@ def pmc_traffic(kernel):
         d = json.load(open(files[-1]))
         f = w = None
         for name, v in d["pmc"].get("FETCH_SIZE", {}).items():
-            if ("::" + kernel + "(") in name or name.startswith(kernel):
+            if ("::" + kernel + "(") in name or name.startswith(kernel) or ("::" + kernel + "<") in name:
                 f = v["avg"]
         for name, v in d["pmc"].get("WRITE_SIZE", {}).items():
-            if ("::" + kernel + "(") in name or name.startswith(kernel):
+            if ("::" + kernel + "(") in name or name.startswith(kernel) or ("::" + kernel + "<") in name:
                 w = v["avg"]
         if f is None or w is None:
             return None, None
@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--batch-hz", type=float, default=30.0)
     ap.add_argument("--freq", type=int, default=15, help="publish rate (config freq)")
     ap.add_argument("--cpu-frames", type=int, default=40, help="oracle frames for cpu_baseline (0=skip)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="processes for the all-cores CPU figure (-1 = os.cpu_count(), 0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-pipeline", action="store_true",
@@ -79,6 +81,50 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the N>1 path)")
     return ap.parse_args()
+
+
+def cpu_all_cores(batches, args, W, H):
+    """besides the like-for-like single-core figure, one independent oracle tracker per
+    host core over the same batches, all started together; value = all events / slowest process."""
+    import shutil
+    import subprocess
+    import tempfile
+    nproc = os.cpu_count() if args.cpu_procs < 0 else args.cpu_procs
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = tempfile.mkdtemp(prefix="esvio_cpu_", dir=base)
+    try:
+        arrs = {}
+        for i, (L, R) in enumerate(batches):
+            arrs["L%d" % i] = L.view(np.uint8).reshape(-1, 16)
+            arrs["R%d" % i] = R.view(np.uint8).reshape(-1, 16)
+        path = os.path.join(d, "batches.npz")
+        np.savez(path, **arrs)
+        go = os.path.join(d, "go")
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "cpu_worker.py")
+        procs = []
+        for k in range(nproc):
+            procs.append(subprocess.Popen(
+                [sys.executable, worker, path, str(len(batches)), str(args.freq), str(W), str(H),
+                 os.path.join(d, "ready%d" % k), go], stdout=subprocess.PIPE, text=True))
+        t_wait = time.time()
+        while sum(os.path.exists(os.path.join(d, "ready%d" % k)) for k in range(nproc)) < nproc:
+            if time.time() - t_wait > 120 or any(p.poll() not in (None, 0) for p in procs):
+                for p in procs:
+                    p.kill()
+                return dict(error="workers did not start")
+            time.sleep(0.01)
+        open(go, "w").close()
+        ev, worst = 0, 0.0
+        for p in procs:
+            out, _ = p.communicate(timeout=600)
+            e, t = out.split()
+            ev += int(e)
+            worst = max(worst, float(t))
+        return dict(value=round(ev / worst / 1e6, 3), unit="Mevents/s", cores=nproc,
+                    sample="%d processes x %d stereo batches each (the same batches), one oracle tracker "
+                           "per process, started together; all events / slowest process" % (nproc, len(batches)))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -215,6 +261,8 @@ def main():
                                   avg_us=round(avg_us, 3),
                                   alg_bytes_per_launch=s["alg_bytes"] // s["launches"],
                                   achieved_GBs=round(gbs, 2))
+        for k in kernels:  # PMC-measured HBM bytes per launch beside the algorithmic ones
+            kernels[k]["hbm_bytes_per_launch_pmc"] = pmc_traffic(k)[0]
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
         if dom:
             d = kernels[dom]
@@ -253,6 +301,8 @@ def main():
                    ms_per_step=round(tc / nfr * 1e3, 3),
                    stage_ms_per_step={k: round(v / nfr * 1e3, 3) for k, v in st.items()},
                    host_cpus=os.cpu_count())
+        if args.cpu_procs != 0:
+            cpu["all_cores"] = cpu_all_cores(host_batches[:nfr], args, W, H)
 
     if rank == 0:
         out = {

@@ -15,7 +15,7 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ESVIO_SIMD_CLONES
 #else
-#define ESVIO_SIMD_CLONES __attribute__((target_clones("avx2", "default")))
+#define ESVIO_SIMD_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
 #endif
 
 namespace esvio {

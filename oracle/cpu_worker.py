@@ -1,0 +1,45 @@
+"""All-cores leg of bench.py's cpu_baseline: one independent oracle tracker per process over the
+same stereo batches (test infrastructure, like everything under oracle/).
+
+    python oracle/cpu_worker.py <batches.npz> <n_frames> <freq> <W> <H> <ready_file> <go_file>
+
+Loads the batches, signals ready, waits for the go file, runs the frames, prints
+"<events> <seconds>" on stdout."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from esvio_amd.events import EVENT_DTYPE, event_times  # noqa: E402
+from esvio_amd.node import FreqControl  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    path, nfr, freq, W, H, ready, go = sys.argv[1:8]
+    nfr, freq, W, H = int(nfr), int(freq), int(W), int(H)
+    z = np.load(path, mmap_mode="r")
+    batches = [(np.asarray(z["L%d" % i]).view(EVENT_DTYPE).reshape(-1),
+                np.asarray(z["R%d" % i]).view(EVENT_DTYPE).reshape(-1)) for i in range(nfr)]
+    tr = O.Tracker(O.make_config(W, H, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1, lk_accum=1))
+    fc = FreqControl(freq)
+    open(ready, "w").close()
+    while not os.path.exists(go):
+        time.sleep(0.001)
+    ev = 0
+    t0 = time.perf_counter()
+    for L, R in batches:
+        t_last = event_times(L)[-1]
+        pub = fc.pub_this_frame(t_last)
+        tr.track_event(t_last, L, R, pub)
+        if pub:
+            fc.published()
+        ev += len(L) + len(R)
+    print(ev, time.perf_counter() - t0)
+
+
+if __name__ == "__main__":
+    main()
