@@ -83,13 +83,31 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """host threads this process may actually use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_all_cores(batches, args, W, H):
     """besides the like-for-like single-core figure, one independent oracle tracker per
     host core over the same batches, all started together; value = all events / slowest process."""
     import shutil
     import subprocess
     import tempfile
-    nproc = os.cpu_count() if args.cpu_procs < 0 else args.cpu_procs
+    nproc = usable_cpus() if args.cpu_procs < 0 else args.cpu_procs
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     d = tempfile.mkdtemp(prefix="esvio_cpu_", dir=base)
     try:
@@ -300,7 +318,7 @@ def main():
                           % (nfr, ev),
                    ms_per_step=round(tc / nfr * 1e3, 3),
                    stage_ms_per_step={k: round(v / nfr * 1e3, 3) for k, v in st.items()},
-                   host_cpus=os.cpu_count())
+                   host_cpus=os.cpu_count(), usable_cpus=usable_cpus())
         if args.cpu_procs != 0:
             cpu["all_cores"] = cpu_all_cores(host_batches[:nfr], args, W, H)
 
