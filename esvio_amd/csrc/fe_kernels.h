@@ -138,6 +138,39 @@ void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand
                     const uint32_t* cand_cnt, uint32_t nblk, uint32_t* comp_xy, uint32_t* comp_idx,
                     uint32_t* total);
 
+// ---- goodFeaturesToTrack (image front-end) ----------------------------------
+// cv::goodFeaturesToTrack(img, n, quality, minDistance, mask) with blockSize 3 / gradientSize 3 /
+// Shi-Tomasi, as FeatureTracker::trackImage calls it (feature_tracker.cpp:228) [OpenCV, restated]:
+//   k_gftt_cov      Sobel (float, scale 1/3060) -> (Dx*Dx, Dx*Dy, Dy*Dy) per pixel
+//   k_gftt_rowsum   box filter rows: (c[x-1] + c[x]) + c[x+1]
+//   k_gftt_eig      box filter columns as OpenCV's running sum (one thread per column, rows in
+//                   order: float addition order matters), min eigenvalue, masked maximum
+//   k_gftt_collect  threshold at quality*max, 3x3 local maximum, mask -> per-block ordered lists
+//   (k_compact), k_gftt_sortprep + 4 x k_radix_pass: by value then address, both descending
+//   k_select with the open Euclidean disc: the minDistance greedy
+struct GfttArgs {
+  const uint8_t* img;  // level-0 pixel (0,0) inside its reflect-101 padded buffer
+  int stride;
+  int W, H;
+  float4* cov;         // [W*H] scratch
+  float4* rowsum;      // [W*H] scratch
+  float* eig;          // [W*H] cornerMinEigenVal
+  const uint32_t* mask_bits;  // blocked pixels (1 = not allowed), may be NULL
+  int wpr;
+  uint32_t* max_key;   // [1] order-preserving key of the masked maximum (cleared by k_gftt_cov)
+  double quality;
+  uint32_t* cand_xy;   // [nblk*kArcBlock] per-block ordered candidates: x | y<<16 ...
+  uint32_t* cand_val;  // ... and the response bits
+  uint32_t* cand_cnt;  // [nblk]
+};
+void launch_gftt_response(hipStream_t s, const GfttArgs& a);  // cov, rowsum, eig
+void launch_gftt_collect(hipStream_t s, const GfttArgs& a);
+// keys = ~value bits, vals = xy, read back to front (so that the stable sort leaves equal values
+// in descending address order); accumulates the 4 x 8-bit digit histograms, clears the look-back
+void launch_gftt_sortprep(hipStream_t s, const uint32_t* comp_xy, const uint32_t* comp_val, uint32_t n,
+                          uint32_t* keys, uint32_t* vals, uint32_t* ghist, uint32_t* lookback,
+                          uint32_t lookback_words);
+
 struct SelectArgs {
   const uint32_t* comp_xy;   // compacted candidates in stream order
   const uint32_t* comp_idx;

@@ -1197,6 +1197,179 @@ void launch_arc(hipStream_t s, const ArcArgs& a) {
   hipLaunchKernelGGL(k_arc, dim3((a.n + kArcBlock - 1) / kArcBlock), dim3(kArcBlock), 0, s, a);
 }
 
+// ============================================================================ goodFeaturesToTrack
+// (see fe_kernels.h; every float operation in the order of the oracle's restatement)
+__device__ __forceinline__ uint32_t f32_order_key(float v) {  // monotonic float -> uint
+  const uint32_t b = __float_as_uint(v);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(uint32_t k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+__global__ __launch_bounds__(256) void k_gftt_cov(GfttArgs a) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.max_key = 0u;
+  if (x >= a.W || y >= a.H) return;
+  double scale = (double)(1 << (3 - 1)) * 3;
+  scale *= 255.0;
+  scale = 1.0 / scale;
+  const float fs = (float)scale, k0 = 2.f * fs, k1 = 1.f * fs;
+  const uint8_t* p = a.img + (ptrdiff_t)y * a.stride + x;  // borders are materialised (reflect-101)
+  const int s = a.stride;
+  const int a00 = p[-s - 1], a01 = p[-s], a02 = p[-s + 1];
+  const int a10 = p[-1], a12 = p[1];
+  const int a20 = p[s - 1], a21 = p[s], a22 = p[s + 1];
+  const int r0 = a02 - a00, r1 = a12 - a10, r2 = a22 - a20;
+  const float dx = __fadd_rn(__fmul_rn((float)(r0 + r2), k1), __fmul_rn((float)r1, k0));
+  const float R0 = __fadd_rn(__fmul_rn((float)(a00 + a02), k1), __fmul_rn((float)a01, k0));
+  const float R2 = __fadd_rn(__fmul_rn((float)(a20 + a22), k1), __fmul_rn((float)a21, k0));
+  const float dy = __fsub_rn(R2, R0);
+  a.cov[(size_t)y * a.W + x] = make_float4(__fmul_rn(dx, dx), __fmul_rn(dx, dy), __fmul_rn(dy, dy), 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_gftt_rowsum(GfttArgs a) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= a.W || y >= a.H) return;
+  const float4* r = a.cov + (size_t)y * a.W;
+  const float4 l = r[reflect101(x - 1, a.W)], c = r[x], rr = r[reflect101(x + 1, a.W)];
+  a.rowsum[(size_t)y * a.W + x] =
+      make_float4(__fadd_rn(__fadd_rn(l.x, c.x), rr.x), __fadd_rn(__fadd_rn(l.y, c.y), rr.y),
+                  __fadd_rn(__fadd_rn(l.z, c.z), rr.z), 0.f);
+}
+
+// one thread per column; the running column sum of OpenCV's ColumnSum, rows -1 .. H in order
+__global__ __launch_bounds__(64) void k_gftt_eig(GfttArgs a) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  if (x >= a.W) return;
+  const int W = a.W, H = a.H;
+  auto row = [&](int y) { return a.rowsum[(size_t)reflect101(y, H) * W + x]; };
+  float4 prev = row(-1), cur = row(0);
+  float s0 = __fadd_rn(__fadd_rn(0.f, prev.x), cur.x), s1 = __fadd_rn(__fadd_rn(0.f, prev.y), cur.y),
+        s2 = __fadd_rn(__fadd_rn(0.f, prev.z), cur.z);
+  uint32_t best = 0u;
+  constexpr int kAhead = 8;
+  for (int y0 = 0; y0 < H; y0 += kAhead) {
+    float4 nx[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) nx[k] = row(min(y0 + k, H - 1) + 1);
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) {
+      const int y = y0 + k;
+      if (y >= H) break;
+      const float c0 = __fadd_rn(s0, nx[k].x), c1 = __fadd_rn(s1, nx[k].y), c2 = __fadd_rn(s2, nx[k].z);
+      s0 = __fsub_rn(c0, prev.x);
+      s1 = __fsub_rn(c1, prev.y);
+      s2 = __fsub_rn(c2, prev.z);
+      prev = cur;
+      cur = nx[k];
+      const float aa = __fmul_rn(c0, 0.5f), bb = c1, cc = __fmul_rn(c2, 0.5f);
+      const float d = __fsub_rn(aa, cc);
+      const float e = __fsub_rn(__fadd_rn(aa, cc), sqrtf(__fadd_rn(__fmul_rn(d, d), __fmul_rn(bb, bb))));
+      a.eig[(size_t)y * W + x] = e;
+      const bool allowed = !a.mask_bits || !((a.mask_bits[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+      if (allowed) best = max(best, f32_order_key(e));
+    }
+  }
+  // wave maximum, one atomic per wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o));
+  if (threadIdx.x == 0 && best) atomicMax(a.max_key, best);
+}
+
+void launch_gftt_response(hipStream_t s, const GfttArgs& a) {
+  const dim3 grid((a.W + 63) / 64, (a.H + 3) / 4);
+  hipLaunchKernelGGL(k_gftt_cov, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_gftt_rowsum, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_gftt_eig, dim3((a.W + 63) / 64), dim3(64), 0, s, a);
+}
+
+// threshold + 3x3 local maximum + mask; block b owns pixels [b*kArcBlock, (b+1)*kArcBlock) in
+// row-major order and leaves its candidates in that order
+__global__ __launch_bounds__(kArcBlock) void k_gftt_collect(GfttArgs a) {
+  __shared__ uint32_t wave_cnt[kArcBlock / 64];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const uint32_t i = blockIdx.x * kArcBlock + threadIdx.x;
+  const int W = a.W, H = a.H;
+  const uint32_t mk = *a.max_key;
+  bool take = false;
+  float val = 0.f;
+  int x = 0, y = 0;
+  if (mk && i < (uint32_t)W * (uint32_t)H) {
+    y = (int)(i / (uint32_t)W);
+    x = (int)(i - (uint32_t)y * (uint32_t)W);
+    const float thr = (float)__dmul_rn((double)f32_from_order_key(mk), a.quality);
+    if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1) {
+      const float* e = a.eig + (size_t)y * W + x;
+      auto th = [&](float v) { return v > thr ? v : 0.f; };
+      val = th(e[0]);
+      if (val != 0.f) {
+        float m = val;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+          for (int dx = -1; dx <= 1; dx++) m = fmaxf(m, th(e[dy * W + dx]));
+        const bool allowed = !a.mask_bits || !((a.mask_bits[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+        take = val == m && allowed;
+      }
+    }
+  }
+  const unsigned long long mb = __ballot(take);
+  if (lane == 0) wave_cnt[wave] = __popcll(mb);
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++) base += wave_cnt[w];
+  if (take) {
+    const uint32_t pos = base + __popcll(mb & ((1ull << lane) - 1ull));
+    a.cand_xy[(size_t)blockIdx.x * kArcBlock + pos] = (uint32_t)x | ((uint32_t)y << 16);
+    a.cand_val[(size_t)blockIdx.x * kArcBlock + pos] = __float_as_uint(val);
+  }
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kArcBlock / 64; w++) t += wave_cnt[w];
+    a.cand_cnt[blockIdx.x] = t;
+  }
+}
+
+void launch_gftt_collect(hipStream_t s, const GfttArgs& a) {
+  const uint32_t nblk = ((uint32_t)a.W * a.H + kArcBlock - 1) / kArcBlock;
+  hipLaunchKernelGGL(k_gftt_collect, dim3(nblk), dim3(kArcBlock), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void k_gftt_sortprep(const uint32_t* __restrict__ comp_xy,
+                                                       const uint32_t* __restrict__ comp_val, uint32_t n,
+                                                       uint32_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ ghist,
+                                                       uint32_t* __restrict__ lookback,
+                                                       uint32_t lookback_words) {
+  __shared__ uint32_t h[4 << 8];
+  for (int i = threadIdx.x; i < (4 << 8); i += 256) h[i] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t src = n - 1u - i;
+    const uint32_t key = ~comp_val[src];  // positive floats: larger value -> smaller key
+    keys[i] = key;
+    vals[i] = comp_xy[src];
+    for (int p = 0; p < 4; p++) atomicAdd(&h[(p << 8) + ((key >> (8 * p)) & 255u)], 1u);
+  }
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < lookback_words;
+       i += gridDim.x * blockDim.x)
+    lookback[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < (4 << 8); i += 256)
+    if (h[i]) atomicAdd(&ghist[i], h[i]);
+}
+
+void launch_gftt_sortprep(hipStream_t s, const uint32_t* comp_xy, const uint32_t* comp_val, uint32_t n,
+                          uint32_t* keys, uint32_t* vals, uint32_t* ghist, uint32_t* lookback,
+                          uint32_t lookback_words) {
+  uint32_t grid = (n + 1023) / 1024;
+  grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
+  hipLaunchKernelGGL(k_gftt_sortprep, dim3(grid), dim3(256), 0, s, comp_xy, comp_val, n, keys, vals,
+                     ghist, lookback, lookback_words);
+}
+
 // ============================================================================ greedy selection
 // Event_FeaturesToTrack (feature_tracker.cpp:13-38): candidates in stream order; accept iff the
 // pixel is not blocked; stamp cv::circle(r = MIN_DIST, filled) [OpenCV midpoint disc]; stop at

@@ -79,7 +79,8 @@ ABI_SYMBOLS = [
     "esvio_fe_get_sae", "esvio_fe_set_sae", "esvio_fe_calc_optical_flow_pyr_lk",
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
-    "esvio_fe_set_next_batch", "esvio_fe_get_time_surface", "esvio_fe_export_image",
+    "esvio_fe_set_next_batch", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
+    "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
     "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
@@ -128,6 +129,8 @@ def load_library(build_if_missing=True):
     L.esvio_fe_create_sae_stereo_mc.argtypes = [vp, vp, sz, vp, sz, i, C.POINTER(Motion),
                                                 C.POINTER(C.c_uint64)]
     L.esvio_fe_set_next_batch.argtypes = [vp, d, vp, sz, vp, sz, i, i]
+    L.esvio_fe_good_features_to_track.argtypes = [vp, vp, i, d, d, vp, vp, vp, vp]
+    L.esvio_fe_track_image.argtypes = [vp, d, vp, vp, i, vp]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
     L.esvio_fe_export_image.argtypes = [vp, i, vp, i]
     L.esvio_fe_import_image.argtypes = [vp, i, vp, i]
@@ -318,6 +321,9 @@ class FeatureTracker:
             self._hd.check(self._hd.L.esvio_fe_track_event_mc(
                 self._hd.h, float(cur_time), pl, nl, pr, nr, sl, int(PUB_THIS_FRAME),
                 C.byref(measurements), C.byref(self._tr)))
+        return self._take(copy)
+
+    def _take(self, copy):
         nl_, nr_ = self._tr.n_left, self._tr.n_right
         for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"):
             v = self._bufs[k][:nl_]
@@ -326,6 +332,35 @@ class FeatureTracker:
             v = self._bufs[k][:nr_]
             setattr(self, k, v.copy() if copy else v)
         return self
+
+    def trackImage(self, cur_time, img_left, img_right, PUB_THIS_FRAME=True, copy=True):
+        """FeatureTracker::trackImage (feature_tracker.cpp:164-338); the handle's width/height/
+        max_cnt/min_dist are the image camera's COL/ROW/MAX_CNT_IMG/MIN_DIST_IMG"""
+        il = np.ascontiguousarray(img_left, np.uint8)
+        assert il.shape == (self.cfg.height, self.cfg.width)
+        ir = None
+        if img_right is not None:
+            ir = np.ascontiguousarray(img_right, np.uint8)
+            assert ir.shape == il.shape
+        self._hd.check(self._hd.L.esvio_fe_track_image(
+            self._hd.h, float(cur_time), _p(il), None if ir is None else _p(ir), int(PUB_THIS_FRAME),
+            C.byref(self._tr)))
+        return self._take(copy)
+
+    def goodFeaturesToTrack(self, image, maxCorners, qualityLevel=0.01, minDistance=30, mask=None,
+                            want_eig=False):
+        """cv::goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask) with
+        trackImage's defaults (feature_tracker.cpp:228)"""
+        img = np.ascontiguousarray(image, np.uint8)
+        assert img.shape == (self.cfg.height, self.cfg.width)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        out = np.zeros((max(int(maxCorners), 1), 2), np.float32)
+        eig = np.zeros(img.shape, np.float32) if want_eig else None
+        n = C.c_int32()
+        self._hd.check(self._hd.L.esvio_fe_good_features_to_track(
+            self._hd.h, _p(img), int(maxCorners), float(qualityLevel), float(minDistance),
+            None if m is None else _p(m), _p(out), C.byref(n), None if eig is None else _p(eig)))
+        return (out[:n.value].copy(), eig) if want_eig else out[:n.value].copy()
 
     def set_next_batch(self, next_cur_time, event_left, event_right, PUB_NEXT_FRAME=False):
         """announce the batch of the FOLLOWING trackEvent call (throughput / replay mode);

@@ -133,3 +133,52 @@ class StereoEventTrackerNode:
             self.init_pub = True
             return None
         return pc
+
+
+class StereoImageTrackerNode:
+    """handle_stereo_image (stereo_image_tracker_node.cpp:54-183): same first-frame / discontinuity
+    / publish-rate logic as the event node, `trackImage` instead of `trackEvent` (the tracker's own
+    `equalize` setting stands for the node's CLAHE, :92-96).  A discontinuity only re-arms the node
+    (:68-78: the restart flag is published, the tracker is not reset).  ``handle(img_left,
+    img_right, msg_timestamp)`` returns the published PointCloud rows or None."""
+
+    def __init__(self, tracker, freq):
+        self.trackerData = tracker
+        self.first_image_flag = True
+        self.first_image_time = 0.0
+        self.last_image_time = 0.0
+        self.pub_count = 1
+        self.init_pub = False
+        self.restart_count = 0
+        self.FREQ = freq if freq != 0 else 100
+
+    def handle(self, img_left, img_right, msg_timestamp):
+        if self.first_image_flag:  # :58-64
+            self.first_image_flag = False
+            self.first_image_time = msg_timestamp
+            self.last_image_time = msg_timestamp
+            return None
+        if msg_timestamp - self.last_image_time > 1.0 or msg_timestamp < self.last_image_time:
+            self.first_image_flag = True  # :66-78
+            self.last_image_time = 0
+            self.pub_count = 1
+            self.restart_count += 1
+            return None
+        self.last_image_time = msg_timestamp
+        rate = 1.0 * self.pub_count / (msg_timestamp - self.first_image_time)
+        if round(rate) <= self.FREQ:  # :81-91
+            pub = True
+            if abs(rate - self.FREQ) < 0.01 * self.FREQ:
+                self.first_image_time = msg_timestamp
+                self.pub_count = 0
+        else:
+            pub = False
+        self.trackerData.trackImage(msg_timestamp, img_left, img_right, pub)  # :100
+        if not pub:
+            return None
+        self.pub_count += 1  # :113-115
+        pc = pack_point_cloud(self.trackerData)
+        if not self.init_pub:  # :171-176: the first publishable frame is swallowed
+            self.init_pub = True
+            return None
+        return pc

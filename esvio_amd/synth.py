@@ -163,3 +163,49 @@ class SceneStream:
                     self.v[k, a] = -self.v[k, a]
         self.t_us += self.dur_us
         return out[0], out[1], self.t_us
+
+
+class ImageStream:
+    """Stereo grey-image stream for the image front-end (trackImage): a fixed random texture
+    (smoothed noise + rectangles of random brightness) seen through a window that moves by an
+    integer velocity per frame; the right image is the left one shifted by `disparity` pixels;
+    a little per-frame sensor noise.  ``next_frame()`` -> (left, right, t_seconds)."""
+
+    def __init__(self, W=640, H=480, velocity=(3, 2), disparity=8, noise=2.0, n_rect=60, fps=20.0,
+                 t0=100.0, seed=7):
+        self.W, self.H = W, H
+        self.v = velocity
+        self.disp = disparity
+        self.noise = noise
+        self.dt = 1.0 / fps
+        self.t = t0
+        self.k = 0
+        self.rng = np.random.default_rng(seed)
+        r = self.rng
+        pad = 256
+        TH, TW = H + 2 * pad, W + 2 * pad + disparity
+        tex = r.normal(0, 1, (TH, TW))
+        for _ in range(3):  # cheap separable smoothing
+            tex = (tex + np.roll(tex, 1, 0) + np.roll(tex, -1, 0) + np.roll(tex, 1, 1) + np.roll(tex, -1, 1)) / 5
+        tex = 128 + 60 * tex / tex.std()
+        for _ in range(n_rect * (TH * TW) // (W * H)):
+            w, h = r.integers(12, 70, 2)
+            x, y = r.integers(0, TW - w), r.integers(0, TH - h)
+            tex[y:y + h, x:x + w] = 0.35 * tex[y:y + h, x:x + w] + 0.65 * r.uniform(20, 235)
+        self.tex = tex
+        self.pad = pad
+
+    def next_frame(self):
+        ox = self.pad + (self.v[0] * self.k) % 128
+        oy = self.pad + (self.v[1] * self.k) % 128
+        r = self.rng
+
+        def view(x0):
+            img = self.tex[oy:oy + self.H, x0:x0 + self.W] + r.normal(0, self.noise, (self.H, self.W))
+            return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+        left, right = view(ox + self.disp), view(ox)
+        t = self.t
+        self.t += self.dt
+        self.k += 1
+        return left, right, t

@@ -208,6 +208,25 @@ int esvio_fe_set_next_batch(esvio_fe_handle h, double next_cur_time, const esvio
                             size_t nL, const esvio_fe_event* right, size_t nR, int space,
                             int pub_hint);
 
+/* ---- image front-end: FeatureTracker::trackImage ------------------------ */
+/* For this path the handle is the image tracker's own instance (stereo_image_tracker_node.cpp:31):
+ * width/height = image_width/image_height (parameters.cpp:103-104), max_cnt = max_cnt_img,
+ * min_dist = min_dist_img (:100-102); equalize = the node's CLAHE (node:92-96).
+ *
+ * cv::goodFeaturesToTrack(img, corners, max_corners, quality, min_distance, mask) as trackImage
+ * calls it (feature_tracker.cpp:228: blockSize 3, gradientSize 3, Shi-Tomasi) [OpenCV, restated].
+ * img: width*height bytes (host); mask: width*height bytes, nonzero = allowed, or NULL;
+ * 1 <= max_corners <= max_cnt; out_xy: 2*max_corners floats; eig_out (optional): the
+ * cornerMinEigenVal map, width*height floats. */
+int esvio_fe_good_features_to_track(esvio_fe_handle h, const uint8_t* img, int max_corners,
+                                    double quality, double min_distance, const uint8_t* mask,
+                                    float* out_xy, int32_t* n_out, float* eig_out);
+/* FeatureTracker::trackImage(cur_time, img_left, img_right) (feature_tracker.cpp:164-338), host
+ * images of width*height bytes; img_right may be NULL (the right block is then skipped like the
+ * reference's `!img_right.empty()` test).  Results as esvio_fe_track_event. */
+int esvio_fe_track_image(esvio_fe_handle h, double cur_time, const uint8_t* img_left,
+                         const uint8_t* img_right, int pub_this_frame, esvio_fe_tracks* out);
+
 /* FeatureTracker::gettimesurface() tap (feature_tracker.cpp:894): current left/right image */
 int esvio_fe_get_time_surface(esvio_fe_handle h, int cam, uint8_t* out);
 

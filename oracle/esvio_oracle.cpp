@@ -1572,6 +1572,278 @@ int track_event(Tracker* t, double _cur_time, const oracle_event* left, size_t n
   return 0;
 }
 
+
+// ============================================================================ image front-end
+// FeatureTracker::trackImage (feature_tracker.cpp:164-338) — SURVEY 8(f) N4.
+//
+// cv::goodFeaturesToTrack(image, corners, maxCorners, qualityLevel, minDistance, mask) with the
+// defaults trackImage uses (blockSize 3, gradientSize 3, Shi-Tomasi min-eigenvalue response).
+// [OpenCV imgproc: featureselect.cpp goodFeaturesToTrack, corner.cpp cornerEigenValsVecs /
+//  calcMinEigenVal, deriv.cpp Sobel, filter.cpp SymmRowSmallFilter / SymmColumnSmallFilter,
+//  box_filter.cpp RowSum (ksize 3 branch) / ColumnSum — restated as recalled; OpenCV is not in the
+//  reference tree and its version is unpinned, so this arithmetic is "parity unpinned".]
+//   scale = 1 / (2^(3-1) * blockSize * 255);  smoothing taps {1,2,1} * (float)scale
+//   Dx = Sobel(1,0): row [-1,0,1] (exact integers), column ((r0+r2)*f1 + r1*f0)
+//   Dy = Sobel(0,1): row ((s0+s2)*k1 + s1*k0) in float, column (R2 - R0)
+//   cov = (Dx*Dx, Dx*Dy, Dy*Dy);  3x3 unnormalised box: rows (c0+c1)+c2, columns as the running
+//   sum SUM += next; D = SUM; SUM -= oldest (order matters in float);  BORDER_REFLECT_101 throughout
+//   eig = (a+c) - sqrt((a-c)^2 + b^2), a = cov0*0.5f, b = cov1, c = cov2*0.5f
+void corner_min_eigen_val(const uint8_t* img, int W, int H, std::vector<float>& eig) {
+  double scale = (double)(1 << (3 - 1)) * 3;
+  scale *= 255.0;
+  scale = 1.0 / scale;
+  const float fs = (float)scale;
+  const float k0 = 2.f * fs, k1 = 1.f * fs;  // centre / neighbour smoothing taps
+  auto px = [&](int y, int x) { return (int)img[(size_t)reflect101(y, H) * W + reflect101(x, W)]; };
+  std::vector<float> cov((size_t)W * H * 3);
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      // Dx: differentiate along x (exact), smooth along y
+      const int r0 = px(y - 1, x + 1) - px(y - 1, x - 1);
+      const int r1 = px(y, x + 1) - px(y, x - 1);
+      const int r2 = px(y + 1, x + 1) - px(y + 1, x - 1);
+      const float dx = (float)(r0 + r2) * k1 + (float)r1 * k0;
+      // Dy: smooth along x in float, differentiate along y
+      const float R0 = (float)(px(y - 1, x - 1) + px(y - 1, x + 1)) * k1 + (float)px(y - 1, x) * k0;
+      const float R2 = (float)(px(y + 1, x - 1) + px(y + 1, x + 1)) * k1 + (float)px(y + 1, x) * k0;
+      const float dy = R2 - R0;
+      float* c = &cov[((size_t)y * W + x) * 3];
+      c[0] = dx * dx;
+      c[1] = dx * dy;
+      c[2] = dy * dy;
+    }
+  // RowSum, ksize == 3
+  std::vector<float> rs((size_t)W * H * 3);
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++)
+      for (int k = 0; k < 3; k++) {
+        const float* r = &cov[(size_t)y * W * 3];
+        rs[((size_t)y * W + x) * 3 + k] =
+            (r[reflect101(x - 1, W) * 3 + k] + r[x * 3 + k]) + r[reflect101(x + 1, W) * 3 + k];
+      }
+  // ColumnSum (running sum over the rows -1 .. H), then calcMinEigenVal
+  eig.assign((size_t)W * H, 0.f);
+  std::vector<float> SUM((size_t)W * 3, 0.f);
+  auto row = [&](int y) { return &rs[(size_t)reflect101(y, H) * W * 3]; };
+  for (int y = -1; y <= 0; y++) {
+    const float* Sp = row(y);
+    for (int i = 0; i < W * 3; i++) SUM[i] += Sp[i];
+  }
+  for (int y = 0; y < H; y++) {
+    const float* Sp = row(y + 1);
+    const float* Sm = row(y - 1);
+    for (int x = 0; x < W; x++) {
+      float cv3[3];
+      for (int k = 0; k < 3; k++) {
+        const int i = x * 3 + k;
+        const float s0 = SUM[i] + Sp[i];
+        cv3[k] = s0;
+        SUM[i] = s0 - Sm[i];
+      }
+      const float a = cv3[0] * 0.5f, b = cv3[1], c = cv3[2] * 0.5f;
+      eig[(size_t)y * W + x] = (a + c) - std::sqrt((a - c) * (a - c) + b * b);
+    }
+  }
+}
+
+// half-widths of the open Euclidean disc dx*dx + dy*dy < r*r by |dy| (-1: row not touched)
+void euclid_halfwidths(int r, int* hw /*[r+1]*/) {
+  for (int dy = 0; dy <= r; dy++) {
+    int w = -1;
+    for (int dx = 0; dx <= r; dx++)
+      if (dx * dx + dy * dy < r * r) w = dx;
+    hw[dy] = w;
+  }
+}
+
+int good_features_to_track(const uint8_t* img, int W, int H, int maxCorners, double qualityLevel,
+                           double minDistance, const uint8_t* mask /*nonzero = allowed, or NULL*/,
+                           std::vector<P2f>& corners, std::vector<float>* eig_out) {
+  corners.clear();
+  std::vector<float> eig;
+  corner_min_eigen_val(img, W, H, eig);
+  if (eig_out) *eig_out = eig;
+  // minMaxLoc(eig, 0, &maxVal, 0, 0, mask); threshold(eig, eig, maxVal*qualityLevel, 0, THRESH_TOZERO)
+  double maxVal = 0;
+  bool any = false;
+  for (size_t i = 0; i < eig.size(); i++)
+    if (!mask || mask[i]) {
+      if (!any || (double)eig[i] > maxVal) maxVal = eig[i];
+      any = true;
+    }
+  if (!any) return 0;
+  const float thr = (float)(maxVal * qualityLevel);
+  std::vector<float> th(eig.size());
+  for (size_t i = 0; i < eig.size(); i++) th[i] = eig[i] > thr ? eig[i] : 0.f;
+  // dilate 3x3 + local-maximum test, rows/cols 1 .. size-2
+  std::vector<int> cand;  // pixel offsets
+  for (int y = 1; y < H - 1; y++)
+    for (int x = 1; x < W - 1; x++) {
+      const float val = th[(size_t)y * W + x];
+      if (val == 0) continue;
+      float tmp = val;
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) tmp = std::max(tmp, th[(size_t)(y + dy) * W + (x + dx)]);
+      if (val == tmp && (!mask || mask[(size_t)y * W + x])) cand.push_back(y * W + x);
+    }
+  // std::sort(tmpCorners, greaterThanPtr): by value, ties by address, both descending
+  std::sort(cand.begin(), cand.end(), [&](int a, int b) {
+    return th[a] > th[b] ? true : th[a] < th[b] ? false : a > b;
+  });
+  if (minDistance >= 1) {
+    // the cell grid only accelerates the search; the test is the plain Euclidean one
+    const double md2 = minDistance * minDistance;
+    for (int o : cand) {
+      const int y = o / W, x = o - y * W;
+      bool good = true;
+      for (const P2f& q : corners) {
+        const float dx = (float)x - q.x, dy = (float)y - q.y;
+        if (dx * dx + dy * dy < md2) {
+          good = false;
+          break;
+        }
+      }
+      if (good) {
+        corners.push_back(P2f{(float)x, (float)y});
+        if (maxCorners > 0 && (int)corners.size() == maxCorners) break;
+      }
+    }
+  } else {
+    for (int o : cand) {
+      const int y = o / W, x = o - y * W;
+      corners.push_back(P2f{(float)x, (float)y});
+      if (maxCorners > 0 && (int)corners.size() == maxCorners) break;
+    }
+  }
+  return (int)corners.size();
+}
+
+// FeatureTracker::Image_setMask (feature_tracker.cpp:90-119; FISHEYE = 0): mask_image 255 = free
+void image_set_mask(Tracker* t, std::vector<uint8_t>& mask_image) {
+  const int W = t->cfg.width, H = t->cfg.height;
+  mask_image.assign((size_t)W * H, 255);
+  std::vector<std::pair<int, std::pair<P2f, int>>> cnt_pts_id;
+  for (unsigned int i = 0; i < t->cur_pts.size(); i++)
+    cnt_pts_id.push_back(std::make_pair(t->track_cnt[i], std::make_pair(t->cur_pts[i], t->ids[i])));
+  std::sort(cnt_pts_id.begin(), cnt_pts_id.end(),
+            [](const std::pair<int, std::pair<P2f, int>>& a,
+               const std::pair<int, std::pair<P2f, int>>& b) { return a.first > b.first; });
+  t->cur_pts.clear();
+  t->ids.clear();
+  t->track_cnt.clear();
+  for (auto& it : cnt_pts_id) {
+    // Mat::at<uchar>(Point2f) -> Point(cvRound(x), cvRound(y)); inside the image after inBorder
+    const int px = cv_round_f(it.second.first.x), py = cv_round_f(it.second.first.y);
+    if (px < 0 || px >= W || py < 0 || py >= H) continue;
+    if (mask_image[(size_t)py * W + px] == 255) {
+      t->cur_pts.push_back(it.second.first);
+      t->ids.push_back(it.second.second);
+      t->track_cnt.push_back(it.first);
+      circle_fill(mask_image.data(), W, H, px, py, t->cfg.min_dist, 0);
+    }
+  }
+}
+
+// trackImage: cfg.width/height = COL/ROW, max_cnt = MAX_CNT_IMG, min_dist = MIN_DIST_IMG;
+// cfg.equalize applies the node's CLAHE (stereo_image_tracker_node.cpp:92-96) to both images first.
+// inBorder (feature_tracker.cpp:40-46) == in_border_event with COL/ROW.  The reference's
+// track_cnt_right bookkeeping (:303-311) is not an output and indexes out of range; not restated.
+int track_image(Tracker* t, double _cur_time, const uint8_t* img_left_in, const uint8_t* img_right_in,
+                bool PUB_THIS_FRAME) {
+  const oracle_config& c = t->cfg;
+  const int W = c.width, H = c.height, WIN = 21;
+  t->cur_time = _cur_time;
+  std::vector<uint8_t> img_left(img_left_in, img_left_in + (size_t)W * H), img_right;
+  if (img_right_in) img_right.assign(img_right_in, img_right_in + (size_t)W * H);
+  if (c.equalize) {
+    std::vector<uint8_t> tmp(img_left.size());
+    clahe_apply(img_left.data(), W, H, tmp.data());
+    img_left.swap(tmp);
+    if (!img_right.empty()) {
+      clahe_apply(img_right.data(), W, H, tmp.data());
+      img_right.swap(tmp);
+    }
+  }
+  if (t->cur_img_left.empty())
+    t->prev_img_left = t->cur_img_left = img_left;
+  else
+    t->cur_img_left = img_left;
+  t->cur_pts.clear();
+  if (t->prev_pts.size() > 0) {  // :180-209
+    const int n = (int)t->prev_pts.size();
+    std::vector<uint8_t> status(n);
+    t->cur_pts.resize(n);
+    calc_lk(t->prev_img_left.data(), t->cur_img_left.data(), W, H, &t->prev_pts[0].x,
+            &t->cur_pts[0].x, status.data(), n, WIN, 3, 30, 0.01, 0, c.lk_accum);
+    if (c.flow_back) {
+      std::vector<uint8_t> reverse_status(n);
+      std::vector<P2f> reverse_pts = t->prev_pts;  // (initial values unused: flags 0)
+      calc_lk(t->cur_img_left.data(), t->prev_img_left.data(), W, H, &t->cur_pts[0].x,
+              &reverse_pts[0].x, reverse_status.data(), n, WIN, 3, 30, 0.01, 0, c.lk_accum);
+      for (size_t i = 0; i < status.size(); i++)
+        status[i] = status[i] && reverse_status[i] && pt_distance(t->prev_pts[i], reverse_pts[i]) <= 0.5;
+    }
+    for (int i = 0; i < int(t->cur_pts.size()); i++)
+      if (status[i] && !in_border_event(t, t->cur_pts[i])) status[i] = 0;
+    reduce_vector(t->prev_pts, status);
+    reduce_vector(t->cur_pts, status);
+    reduce_vector(t->ids, status);
+    reduce_vector(t->track_cnt, status);
+  }
+  for (auto& n : t->track_cnt) n++;
+  if (PUB_THIS_FRAME) {  // :214-241
+    std::vector<uint8_t> mask_image;
+    image_set_mask(t, mask_image);
+    const int n_max_cnt = c.max_cnt - static_cast<int>(t->cur_pts.size());
+    if (n_max_cnt > 0)
+      good_features_to_track(t->cur_img_left.data(), W, H, n_max_cnt, 0.01, c.min_dist,
+                             mask_image.data(), t->n_pts, nullptr);
+    else
+      t->n_pts.clear();
+    for (auto& p : t->n_pts) {
+      t->cur_pts.push_back(p);
+      t->ids.push_back(t->n_id++);
+      t->track_cnt.push_back(1);
+    }
+  }
+  t->cur_un_pts = undistorted_pts(t->cur_pts, &c.cam[0]);
+  t->pts_velocity = pts_velocity_fn(t, t->ids, t->cur_un_pts, t->cur_un_pts_map, t->prev_un_pts_map);
+  if (!img_right.empty()) {  // :249-318
+    t->ids_right.clear();
+    t->cur_right_pts.clear();
+    t->cur_un_right_pts.clear();
+    t->right_pts_velocity.clear();
+    t->cur_un_right_pts_map.clear();
+    if (!t->cur_pts.empty()) {
+      const int n = (int)t->cur_pts.size();
+      std::vector<P2f> reverseLeftPts(n);
+      std::vector<uint8_t> status(n), statusRightLeft(n);
+      t->cur_right_pts.resize(n);
+      calc_lk(t->cur_img_left.data(), img_right.data(), W, H, &t->cur_pts[0].x, &t->cur_right_pts[0].x,
+              status.data(), n, WIN, 3, 30, 0.01, 0, c.lk_accum);
+      if (c.flow_back && !t->cur_right_pts.empty()) {
+        calc_lk(img_right.data(), t->cur_img_left.data(), W, H, &t->cur_right_pts[0].x,
+                &reverseLeftPts[0].x, statusRightLeft.data(), n, WIN, 3, 30, 0.01, 0, c.lk_accum);
+        for (size_t i = 0; i < status.size(); i++)
+          status[i] = status[i] && statusRightLeft[i] && in_border_event(t, t->cur_right_pts[i]) &&
+                      pt_distance(t->cur_pts[i], reverseLeftPts[i]) <= 0.5;
+      }
+      t->ids_right = t->ids;
+      reduce_vector(t->cur_right_pts, status);
+      reduce_vector(t->ids_right, status);
+      t->cur_un_right_pts = undistorted_pts(t->cur_right_pts, &c.cam[1]);
+      t->right_pts_velocity = pts_velocity_fn(t, t->ids_right, t->cur_un_right_pts,
+                                              t->cur_un_right_pts_map, t->prev_un_right_pts_map);
+    }
+    t->prev_un_right_pts_map = t->cur_un_right_pts_map;
+  }
+  t->prev_img_left = t->cur_img_left;
+  t->prev_pts = t->cur_pts;
+  t->prev_un_pts_map = t->cur_un_pts_map;
+  t->prev_time = t->cur_time;
+  return 0;
+}
+
 }  // namespace
 
 // ================================================================== C interface
@@ -1763,6 +2035,27 @@ void oracle_tracker_time_surface(void* tv, int cam, uint8_t* out) {
   std::memcpy(out, s.data(), s.size());
 }
 void* oracle_tracker_detector(void* tv) { return &((Tracker*)tv)->det; }
+int oracle_good_features_to_track(const uint8_t* img, int w, int h, int max_corners, double quality,
+                                  double min_distance, const uint8_t* mask, float* out_xy,
+                                  int32_t* n_out, float* eig_out) {
+  std::vector<P2f> corners;
+  std::vector<float> eig;
+  const int n = good_features_to_track(img, w, h, max_corners, quality, min_distance, mask, corners,
+                                       eig_out ? &eig : nullptr);
+  if (out_xy) std::memcpy(out_xy, corners.data(), corners.size() * sizeof(P2f));
+  if (eig_out) std::memcpy(eig_out, eig.data(), eig.size() * sizeof(float));
+  if (n_out) *n_out = n;
+  return n;
+}
+void oracle_euclid_halfwidths(int r, int* hw) { euclid_halfwidths(r, hw); }
+int oracle_track_image(void* tv, double cur_time, const uint8_t* left, const uint8_t* right,
+                       int pub_this_frame, oracle_tracks* out) {
+  Tracker* t = (Tracker*)tv;
+  if (!left) return -1;
+  const int rc = track_image(t, cur_time, left, right, pub_this_frame != 0);
+  if (rc == 0 && out) fill_tracks(t, out);
+  return rc;
+}
 void oracle_lk_iter_stats(unsigned long long* out3, int reset) {
   out3[0] = g_lk_iters;
   out3[1] = g_lk_visits;

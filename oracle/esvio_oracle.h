@@ -155,6 +155,16 @@ int oracle_track_event(void* t, double cur_time, const oracle_event* left, size_
 int oracle_track_event_mc(void* t, double cur_time, const oracle_event* left, size_t nL,
                           const oracle_event* right, size_t nR, int pub_this_frame,
                           const oracle_motion* motion, oracle_tracks* out);
+/* ---- image front-end */
+/* cv::goodFeaturesToTrack(img, maxCorners, quality, minDistance, mask) with blockSize 3,
+ * gradientSize 3, Shi-Tomasi [OpenCV restated]; eig_out (w*h floats, optional) = cornerMinEigenVal */
+int oracle_good_features_to_track(const uint8_t* img, int w, int h, int max_corners, double quality,
+                                  double min_distance, const uint8_t* mask, float* out_xy,
+                                  int32_t* n_out, float* eig_out);
+void oracle_euclid_halfwidths(int r, int* hw /*[r+1]*/);
+/* FeatureTracker::trackImage (feature_tracker.cpp:164-338); right may be NULL */
+int oracle_track_image(void* t, double cur_time, const uint8_t* left, const uint8_t* right,
+                       int pub_this_frame, oracle_tracks* out);
 /* taps */
 void oracle_tracker_time_surface(void* t, int cam, uint8_t* out);
 void* oracle_tracker_detector(void* t);

@@ -119,6 +119,11 @@ def lib():
         L.oracle_tracker_detector.restype = vp
         L.oracle_tracker_detector.argtypes = [vp]
         L.oracle_tracker_stage_seconds.argtypes = [vp, vp]
+        L.oracle_good_features_to_track.restype = i
+        L.oracle_good_features_to_track.argtypes = [vp, i, i, i, d, d, vp, vp, vp, vp]
+        L.oracle_euclid_halfwidths.argtypes = [i, vp]
+        L.oracle_track_image.restype = i
+        L.oracle_track_image.argtypes = [vp, d, vp, vp, i, C.POINTER(Tracks)]
         _lib = L
     return _lib
 
@@ -283,6 +288,27 @@ def normalize_minmax(img):
     return out
 
 
+def good_features_to_track(img, max_corners, quality=0.01, min_distance=30, mask=None, want_eig=False):
+    """cv::goodFeaturesToTrack restatement (blockSize 3, gradientSize 3, Shi-Tomasi);
+    returns corners (n,2) float32 [, cornerMinEigenVal map]"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((max(max_corners, 1) if max_corners > 0 else w * h, 2), np.float32)
+    n = C.c_int32()
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    eig = np.zeros((h, w), np.float32) if want_eig else None
+    lib().oracle_good_features_to_track(_p(img), w, h, int(max_corners), float(quality),
+                                        float(min_distance), None if m is None else _p(m), _p(out),
+                                        C.byref(n), None if eig is None else _p(eig))
+    return (out[:n.value].copy(), eig) if want_eig else out[:n.value].copy()
+
+
+def euclid_halfwidths(r):
+    hw = np.zeros(r + 1, np.int32)
+    lib().oracle_euclid_halfwidths(int(r), _p(hw))
+    return hw
+
+
 def lift_projective(cam, u, v):
     c = Camera(**{k: float(cam[k]) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")})
     out = np.empty(3, np.float64)
@@ -347,6 +373,25 @@ class Tracker:
         for k in ("ids_right", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity"):
             setattr(r, k, self._bufs[k][:nr].copy())
         return r
+
+    def _result(self):
+        r = TrackResult()
+        nl, nr = self._tr.n_left, self._tr.n_right
+        for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"):
+            setattr(r, k, self._bufs[k][:nl].copy())
+        for k in ("ids_right", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity"):
+            setattr(r, k, self._bufs[k][:nr].copy())
+        return r
+
+    def track_image(self, cur_time, img_left, img_right, pub_this_frame=True):
+        """FeatureTracker::trackImage (feature_tracker.cpp:164-338)"""
+        il = np.ascontiguousarray(img_left, np.uint8)
+        ir = None if img_right is None else np.ascontiguousarray(img_right, np.uint8)
+        rc = lib().oracle_track_image(self.h, float(cur_time), _p(il), None if ir is None else _p(ir),
+                                      int(pub_this_frame), C.byref(self._tr))
+        if rc:
+            raise RuntimeError("oracle_track_image rc=%d" % rc)
+        return self._result()
 
     def time_surface(self, cam):
         out = np.empty((self.cfg.height, self.cfg.width), np.uint8)

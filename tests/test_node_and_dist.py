@@ -169,3 +169,32 @@ def test_freq_control_peek_predicts_next_decision():
                 fc.published()
                 n_pub += 1
         assert n_pub > 20
+
+
+def test_handle_stereo_image_flow():
+    """stereo_image_tracker_node.cpp:54-183: first frame swallowed, 30 Hz input at freq 15 tracks
+    every frame and publishes every other one, first publish swallowed, a discontinuity re-arms the
+    node without resetting the tracker"""
+    from esvio_amd.node import StereoImageTrackerNode
+
+    class Stub:
+        def __init__(self):
+            self.calls = []
+            self.__dict__.update(_fake_tracker().__dict__)
+
+        def trackImage(self, t, left, right, pub):
+            self.calls.append((t, pub))
+
+    tr = Stub()
+    node = StereoImageTrackerNode(tr, freq=15)
+    img = np.zeros((4, 4), np.uint8)
+    assert node.handle(img, img, 5.0) is None and not tr.calls
+    assert node.handle(img, img, 5.0 + 1 / 30.0) is None and tr.calls[-1] == (5.0 + 1 / 30.0, False)
+    assert node.handle(img, img, 5.0 + 2 / 30.0) is None and tr.calls[-1][1] is True   # swallowed
+    out = node.handle(img, img, 5.0 + 4 / 30.0)
+    assert tr.calls[-1][1] is True and out is not None and out.shape == (5, 8)
+    n = len(tr.calls)
+    assert node.handle(img, img, 7.5) is None and len(tr.calls) == n and node.restart_count == 1
+    assert node.handle(img, img, 7.53) is None and len(tr.calls) == n      # treated as first frame
+    node.handle(img, img, 7.56)
+    assert len(tr.calls) == n + 1

@@ -485,3 +485,98 @@ def test_matrix_exp_and_warp_known_answers(oracle):
     d2 = oracle.Detector(W, H)
     d2.create_sae_mc(0, ev, ev[:1], m2)
     assert d2.get_sae(0)[3][300, 420] > 0
+
+
+# ------------------------------------------------------------------ image front-end
+# cv::goodFeaturesToTrack as FeatureTracker::trackImage calls it (feature_tracker.cpp:228) [OpenCV]
+def test_gftt_square_gives_its_four_corners(oracle):
+    """a bright rectangle on black: the Shi-Tomasi response has exactly four local maxima above
+    1 % of the peak, on the rectangle's corner pixels; the four are equal by symmetry, so the order
+    is the address-descending tie-break of greaterThanPtr"""
+    img = np.zeros((120, 160), np.uint8)
+    img[40:80, 50:110] = 200
+    c = oracle.good_features_to_track(img, 10, 0.01, 10)
+    assert c.tolist() == [[109.0, 79.0], [50.0, 79.0], [109.0, 40.0], [50.0, 40.0]]
+    # maxCorners cuts the sorted list
+    assert oracle.good_features_to_track(img, 2, 0.01, 10).tolist() == [[109.0, 79.0], [50.0, 79.0]]
+    # a mask (nonzero = allowed) removes corners; it also restricts the pixels the peak is taken over
+    m = np.full(img.shape, 255, np.uint8)
+    m[70:90, 100:120] = 0
+    assert oracle.good_features_to_track(img, 10, 0.01, 10, mask=m).tolist() == [
+        [50.0, 79.0], [109.0, 40.0], [50.0, 40.0]]
+
+
+def test_gftt_straight_edges_and_flat_images_have_no_corners(oracle):
+    """one gradient direction only -> cov has rank 1 -> (a+c) - sqrt((a-c)^2 + b^2) == 0 exactly"""
+    img = np.zeros((60, 80), np.uint8)
+    img[:, 40:] = 180
+    c, e = oracle.good_features_to_track(img, 10, 0.01, 5, want_eig=True)
+    assert len(c) == 0 and np.all(e == 0)
+    c, e = oracle.good_features_to_track(np.full((40, 50), 77, np.uint8), 10, 0.01, 5, want_eig=True)
+    assert len(c) == 0 and np.all(e == 0)
+
+
+def test_gftt_response_matches_a_float64_evaluation_of_the_definition(oracle):
+    """cornerMinEigenVal = smaller eigenvalue of the 3x3-box-summed structure tensor of the
+    Sobel gradients scaled by 1/(4*3*255), BORDER_REFLECT_101 — evaluated independently in float64"""
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    _, e = oracle.good_features_to_track(im, 5, 0.01, 6, want_eig=True)
+    f = im.astype(np.float64)
+    p = np.pad(f, 1, mode="reflect")
+    dx = ((p[:-2, 2:] - p[:-2, :-2]) + 2 * (p[1:-1, 2:] - p[1:-1, :-2]) + (p[2:, 2:] - p[2:, :-2])) / 3060.0
+    dy = ((p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:])) / 3060.0
+
+    def box(a):
+        q = np.pad(a, 1, mode="reflect")
+        return sum(q[i:i + a.shape[0], j:j + a.shape[1]] for i in range(3) for j in range(3))
+
+    a_, b_, c_ = box(dx * dx) * 0.5, box(dx * dy), box(dy * dy) * 0.5
+    ref = (a_ + c_) - np.sqrt((a_ - c_) ** 2 + b_ ** 2)
+    assert np.abs(ref - e).max() <= 2e-6 * ref.max()
+
+
+def test_gftt_order_distance_and_limit(oracle):
+    rng = np.random.default_rng(3)
+    im = rng.integers(0, 256, (96, 128), dtype=np.uint8)
+    for md in (1, 4, 9):
+        c, e = oracle.good_features_to_track(im, 300, 0.01, md, want_eig=True)
+        v = e[c[:, 1].astype(int), c[:, 0].astype(int)]
+        assert np.all(np.diff(v) <= 0), "strongest first"
+        assert v.min() > 0.01 * e.max()
+        d = np.sqrt(((c[:, None, :] - c[None, :, :]) ** 2).sum(-1))
+        d[np.diag_indices(len(c))] = 1e9
+        assert d.min() >= md, "no two corners closer than minDistance (dx^2+dy^2 < md^2 rejects)"
+        assert np.all((c[:, 0] >= 1) & (c[:, 0] <= 126) & (c[:, 1] >= 1) & (c[:, 1] <= 94))
+    assert oracle.euclid_halfwidths(3).tolist() == [2, 2, 2, -1]
+    assert oracle.euclid_halfwidths(5).tolist() == [4, 4, 4, 3, 2, -1]
+
+
+def test_track_image_follows_a_translating_scene(oracle):
+    """trackImage (feature_tracker.cpp:164-338) on a texture moving by (3,2) px/frame with an 8 px
+    stereo disparity: ids persist, track counts grow, tracked points move by the scene velocity,
+    stereo matches sit at the disparity, velocities are displacement / dt in normalised coords"""
+    from esvio_amd.synth import ImageStream
+    W, H = 320, 240
+    s = ImageStream(W, H, velocity=(3, 2), disparity=8, seed=3)
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, max_cnt=80, min_dist=20, flow_back=1))
+    prev = None
+    for f in range(5):
+        L, R, t = s.next_frame()
+        r = tr.track_image(t, L, R, True)
+        assert 60 <= len(r.ids) <= 80 and len(r.ids_right) >= 0.8 * len(r.ids)
+        if prev is not None:
+            common = [i for i in r.ids if i in prev]
+            assert len(common) >= 0.8 * len(prev)
+            mv = np.array([r.cur_pts[list(r.ids).index(i)] - prev[i] for i in common])
+            assert np.abs(np.median(mv, 0) - (-3, -2)).max() < 0.05  # the window moves +v, content -v
+        right = dict(zip(r.ids_right, r.cur_right_pts))
+        dd = np.array([r.cur_pts[k] - right[i] for k, i in enumerate(r.ids) if i in right])
+        assert np.abs(np.median(dd, 0) - (-8, 0)).max() < 0.05
+        prev = dict(zip(r.ids, r.cur_pts))
+    assert r.track_cnt.max() == 5
+    # without a right image the right-camera outputs keep their last values (the block is skipped)
+    L, R, t = s.next_frame()
+    n_right = len(r.ids_right)
+    r2 = tr.track_image(t, L, None, True)
+    assert len(r2.ids_right) == n_right

@@ -468,3 +468,55 @@ def test_two_batches_ahead_need_an_exact_pub_hint():
     ft.trackEvent(t[0], b[0][0], b[0][1], True)       # usable again after reset
     assert len(ft.ids) > 0
     ft.close()
+
+
+# ------------------------------------------------------------------ image front-end
+@pytest.mark.parametrize("W,H,md,use_mask", [(160, 120, 10, False), (346, 260, 20, True),
+                                             (640, 480, 30, True), (640, 480, 1, False)])
+def test_good_features_to_track_matches_oracle(oracle, W, H, md, use_mask):
+    """cv::goodFeaturesToTrack restated (feature_tracker.cpp:228): response map bit-exact (Sobel,
+    structure tensor, OpenCV's running column sum, min eigenvalue), corners identical and in order"""
+    from esvio_amd.synth import ImageStream
+    s = ImageStream(W, H, seed=W + md)
+    ft = _mk(W, H, max_cnt=150, min_dist=10)
+    rng = np.random.default_rng(md)
+    for k in range(2):
+        img = s.next_frame()[0] if k == 0 else rng.integers(0, 256, (H, W), dtype=np.uint8)
+        mask = None
+        if use_mask:
+            mask = np.full((H, W), 255, np.uint8)
+            for _ in range(25):
+                x, y = rng.integers(0, W - 30), rng.integers(0, H - 30)
+                mask[y:y + rng.integers(5, 30), x:x + rng.integers(5, 30)] = 0
+        for maxc in (150, 7):
+            cg, eg = ft.goodFeaturesToTrack(img, maxc, 0.01, md, mask, want_eig=True)
+            co, eo = oracle.good_features_to_track(img, maxc, 0.01, md, mask, want_eig=True)
+            assert np.array_equal(eg.view(np.uint32), eo.view(np.uint32)), "cornerMinEigenVal differs"
+            assert cg.shape == co.shape and np.array_equal(cg, co), (k, maxc)
+            assert len(cg) > 3
+    # degenerate inputs: flat image -> nothing; everything masked -> nothing
+    assert len(ft.goodFeaturesToTrack(np.full((H, W), 9, np.uint8), 10, 0.01, md)) == 0
+    assert len(ft.goodFeaturesToTrack(img, 10, 0.01, md, np.zeros((H, W), np.uint8))) == 0
+    ft.close()
+
+
+@pytest.mark.parametrize("equalize", [0, 1])
+def test_track_image_end_to_end_matches_oracle(oracle, equalize):
+    """FeatureTracker::trackImage (feature_tracker.cpp:164-338), 8 stereo frames 640x480, forward /
+    backward checks on, published and unpublished frames, one frame without a right image:
+    ids, track counts and every float result vector bit-exact"""
+    from esvio_amd.synth import ImageStream
+    W, H = 640, 480
+    s = ImageStream(W, H, velocity=(4, -3), disparity=11, seed=5)
+    kw = dict(max_cnt=150, min_dist=30, flow_back=1, equalize=equalize)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(8):
+        L, R, t = s.next_frame()
+        pub = f % 3 != 1
+        if f == 5:
+            R = None
+        ft.trackImage(t, L, R, pub)
+        _compare_tracks(ft, tr.track_image(t, L, R, pub), ("image", equalize, f))
+    assert len(ft.ids) > 100 and ft.track_cnt.max() >= 6 and len(ft.ids_right) > 80
+    ft.close()
