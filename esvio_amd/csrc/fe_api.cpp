@@ -150,6 +150,7 @@ struct esvio_fe_ctx {
   size_t evp_cap[kPrefetchDepth] = {};
   hipEvent_t ev_lane_done[kPrefetchDepth] = {}, ev_lane_arc[kPrefetchDepth] = {};
   PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images
+  PyrStore med_tmp[2];  // median_blur_kernel_size > 0: the surfaces before cv::medianBlur
   // equalize: raw time surfaces (single padded level each, left/right) + CLAHE scratch
   PyrStore raw[kRightSlots][2];  // [buffer][cam], rotating like the right pyramids
   int raw_cur = 0;
@@ -556,9 +557,20 @@ int stage_events(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL,
 
 void render_ts(esvio_fe_ctx* c, double t_sync, uint8_t* dst0, uint8_t* dst1, int ncam,
                const double2* S2) {
-  ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * ncam);
-  launch_time_surface(cur_stream(c), S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
-                      c->cfg.ignore_polarity, dst0, dst1, c->pyr[0].d.stride[0], ncam);
+  const int stride = c->pyr[0].d.stride[0];
+  const int mk = c->cfg.median_blur_kernel_size;
+  uint8_t* r0 = mk > 0 ? c->med_tmp[0].d.img[0] : dst0;
+  uint8_t* r1 = mk > 0 ? c->med_tmp[ncam == 2 ? 1 : 0].d.img[0] : dst1;
+  {
+    ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * ncam);
+    launch_time_surface(cur_stream(c), S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
+                        c->cfg.ignore_polarity, r0, r1, stride, ncam);
+  }
+  if (mk > 0) {  // cv::medianBlur(2k+1) of the rendered surface (event_detector.cc:262-264)
+    const size_t o = (size_t)kPad * stride + kPad;
+    ScopedKernel k(c, K_TIME_SURFACE, 0);
+    launch_median(cur_stream(c), r0 + o, r1 + o, stride, dst0 + o, dst1 + o, stride, c->W, c->H, mk, ncam);
+  }
 }
 
 inline uint8_t* px00(const PyrDesc& d) { return d.img[0] + (size_t)kPad * d.stride[0] + kPad; }
@@ -1704,7 +1716,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx,
-                  c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->d_lut, c->d_minmax};
+                  c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
+                  c->d_minmax};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& cs : c->cand)
@@ -1750,7 +1763,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if (cfg->max_cnt < 1 || cfg->max_cnt > 65536) return ESVIO_FE_EINVAL;
   if (cfg->min_dist < 3 || cfg->min_dist > kMaxDiscR) return ESVIO_FE_EINVAL;  // Arc* ring r=4
   if (cfg->lk_accum != 1) return ESVIO_FE_EINVAL;
-  if (cfg->median_blur_kernel_size != 0) return ESVIO_FE_ENOTIMPL;
+  if (cfg->median_blur_kernel_size < 0) return ESVIO_FE_EINVAL;
+  if (cfg->median_blur_kernel_size > kMaxMedianK) return ESVIO_FE_ENOTIMPL;  // ksize > 15
   if (cfg->equalize != 0 && cfg->equalize != 1) return ESVIO_FE_EINVAL;
   if (!(cfg->decay_ms > 0)) return ESVIO_FE_EINVAL;
   int ndev = 0;
@@ -1832,6 +1846,9 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if ((rc = dev_alloc(c, &c->d_mask_bits, (size_t)c->H * ((c->W + 31) / 32)))) return bail(rc);
   for (PyrStore& ps : c->pyr)
     if ((rc = pyr_alloc(c, ps, c->W, c->H, 3))) return bail(rc);
+  if (cfg->median_blur_kernel_size > 0)
+    for (PyrStore& ps : c->med_tmp)
+      if ((rc = pyr_alloc(c, ps, c->W, c->H, 0))) return bail(rc);
   if (cfg->equalize) {
     for (auto& rb : c->raw)
       for (PyrStore& ps : rb)

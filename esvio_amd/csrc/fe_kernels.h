@@ -80,6 +80,12 @@ void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double 
                          double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
                          int dst_stride, int ncam);
 
+// ---- cv::medianBlur(ksize = 2k+1) of the rendered time surface (event_detector.cc:262-264) ----
+// src/dst: pixel (0,0) pointers of nimg images with the given strides; BORDER_REPLICATE; k <= 7
+constexpr int kMaxMedianK = 7;
+void launch_median(hipStream_t s, const uint8_t* src0, const uint8_t* src1, int src_stride,
+                   uint8_t* dst0, uint8_t* dst1, int dst_stride, int W, int H, int k, int nimg);
+
 // ---- CLAHE + normalize (equalize: 1) ---------------------------------------------------------
 // stage 0: per-tile LUTs, stage 1: LUT blending + min/max, stage 2: MINMAX normalisation in place
 void launch_clahe(hipStream_t s, const uint8_t* raw0, const uint8_t* raw1, int raw_stride,

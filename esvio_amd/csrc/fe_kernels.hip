@@ -1197,6 +1197,45 @@ void launch_arc(hipStream_t s, const ArcArgs& a) {
   hipLaunchKernelGGL(k_arc, dim3((a.n + kArcBlock - 1) / kArcBlock), dim3(kArcBlock), 0, s, a);
 }
 
+// ============================================================================ median blur
+// exact median of the (2k+1)^2 neighbourhood, replicated borders: tile + halo in LDS, then an
+// 8-step bisection on the value (the median is the smallest v with #(values < v+1) > n/2)
+__global__ __launch_bounds__(256) void k_median(const uint8_t* src0, const uint8_t* src1, int src_stride,
+                                                uint8_t* dst0, uint8_t* dst1, int dst_stride, int W,
+                                                int H, int k) {
+  constexpr int T = 16, MAXW = T + 2 * kMaxMedianK;
+  __shared__ uint8_t tile[MAXW * MAXW];
+  const uint8_t* src = blockIdx.z ? src1 : src0;
+  uint8_t* dst = blockIdx.z ? dst1 : dst0;
+  const int tw = T + 2 * k;
+  const int x0 = blockIdx.x * T - k, y0 = blockIdx.y * T - k;
+  for (int i = threadIdx.x; i < tw * tw; i += 256) {
+    const int ty = i / tw, tx = i - ty * tw;
+    const int yy = min(max(y0 + ty, 0), H - 1), xx = min(max(x0 + tx, 0), W - 1);
+    tile[ty * MAXW + tx] = src[(size_t)yy * src_stride + xx];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int x = blockIdx.x * T + lx, y = blockIdx.y * T + ly;
+  if (x >= W || y >= H) return;
+  const int ks = 2 * k + 1, need = (ks * ks) / 2 + 1;
+  int r = 0;
+  for (int bit = 7; bit >= 0; bit--) {
+    const int t = r | (1 << bit);
+    int cnt = 0;
+    for (int dy = 0; dy < ks; dy++)
+      for (int dx = 0; dx < ks; dx++) cnt += tile[(ly + dy) * MAXW + lx + dx] < t;
+    if (cnt < need) r = t;
+  }
+  dst[(size_t)y * dst_stride + x] = (uint8_t)r;
+}
+
+void launch_median(hipStream_t s, const uint8_t* src0, const uint8_t* src1, int src_stride,
+                   uint8_t* dst0, uint8_t* dst1, int dst_stride, int W, int H, int k, int nimg) {
+  hipLaunchKernelGGL(k_median, dim3((W + 15) / 16, (H + 15) / 16, nimg), dim3(256), 0, s, src0, src1,
+                     src_stride, dst0, dst1, dst_stride, W, H, k);
+}
+
 // ============================================================================ goodFeaturesToTrack
 // (see fe_kernels.h; every float operation in the order of the oracle's restatement)
 __device__ __forceinline__ uint32_t f32_order_key(float v) {  // monotonic float -> uint

@@ -53,7 +53,7 @@ typedef struct esvio_fe_config {
   int32_t width, height;            /* event_width / event_height -> COL_event, ROW_event */
   double decay_ms;                  /* decay_ms */
   int32_t ignore_polarity;          /* ignore_polarity */
-  int32_t median_blur_kernel_size;  /* must be 0 (every shipped config); else ENOTIMPL */
+  int32_t median_blur_kernel_size;  /* k: cv::medianBlur(2k+1) of each surface; 0 in every shipped config; k <= 7 */
   double feature_filter_threshold;  /* feature_filter_threshold [s] */
   double ts_lk_threshold;           /* TS_LK_threshold (128.0) */
   int32_t max_cnt;                  /* max_cnt */

@@ -62,6 +62,7 @@ struct Detector {
   bool ignore_polarity;
   double filter_threshold;
   int min_dist;
+  int median_blur_kernel_size = 0;  // k: cv::medianBlur(ksize 2k+1) on the rendered surface (:262-264)
   // planes indexed x + y*W (Eigen MatrixXd(W,H) col-major indexed (x,y), event_detector.cc:52-63)
   // [cam][pol]; cam 0 = sae_/sae_latest_ (left), cam 1 = sae_right/sae_latest_right
   std::vector<double> sae[2][2];         // S: latest ACCEPTED time
@@ -99,6 +100,25 @@ inline void create_sae_one(Detector* d, int cam, double et, int ex, int ey, bool
 }
 
 // SAEtoTimeSurface_left/right (event_detector.cc:230-305)
+// cv::medianBlur(src, dst, ksize) on CV_8U, BORDER_REPLICATE [OpenCV imgproc/median_blur]: the
+// exact median of the ksize x ksize neighbourhood (OpenCV's sorting networks / histogram variants
+// all return it); in place in the reference, i.e. computed from a copy of the source
+void median_blur_u8(uint8_t* img, int W, int H, int ksize) {
+  const int k = ksize / 2, n = ksize * ksize;
+  std::vector<uint8_t> src(img, img + (size_t)W * H), win(n);
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      int m = 0;
+      for (int dy = -k; dy <= k; dy++)
+        for (int dx = -k; dx <= k; dx++) {
+          const int yy = std::min(std::max(y + dy, 0), H - 1), xx = std::min(std::max(x + dx, 0), W - 1);
+          win[m++] = src[(size_t)yy * W + xx];
+        }
+      std::nth_element(win.begin(), win.begin() + n / 2, win.end());
+      img[(size_t)y * W + x] = win[n / 2];
+    }
+}
+
 void sae_to_ts(const Detector* d, int cam, double external_sync_time, uint8_t* out) {
   const double decay_sec = d->decay_ms / 1000.0;
   const std::vector<double>& s0 = d->sae[cam][0];
@@ -123,6 +143,8 @@ void sae_to_ts(const Detector* d, int cam, double external_sync_time, uint8_t* o
       out[(size_t)y * d->W + x] = saturate_u8(cv_round_d(scaled));
     }
   }
+  if (d->median_blur_kernel_size > 0)  // :262-264
+    median_blur_u8(out, d->W, d->H, 2 * d->median_blur_kernel_size + 1);
 }
 
 // one Arc* ring (event_detector.cc:337-435 small, :438-541 large) — same code, N/min/max differ
@@ -1863,6 +1885,8 @@ void* oracle_detector_create(int W, int H, double decay_ms, int ignore_polarity,
 }
 void oracle_detector_destroy(void* d) { delete (Detector*)d; }
 void oracle_detector_reset(void* d) { ((Detector*)d)->reset(); }
+void oracle_detector_set_median(void* d, int k) { ((Detector*)d)->median_blur_kernel_size = k; }
+void oracle_median_blur(uint8_t* img, int w, int h, int ksize) { median_blur_u8(img, w, h, ksize); }
 
 size_t oracle_create_sae(void* dv, int cam, const oracle_event* ev, size_t n) {
   Detector* d = (Detector*)dv;
@@ -1949,7 +1973,7 @@ int oracle_find_fundamental_ransac(const float* p1, const float* p2, int n, doub
 }
 
 void* oracle_tracker_create(const oracle_config* cfg) {
-  if (cfg->median_blur_kernel_size != 0) return nullptr;
+  if (cfg->median_blur_kernel_size < 0) return nullptr;
   Tracker* t = new Tracker();
   t->cfg = *cfg;
   t->det.W = cfg->width;
@@ -1958,6 +1982,7 @@ void* oracle_tracker_create(const oracle_config* cfg) {
   t->det.ignore_polarity = cfg->ignore_polarity != 0;
   t->det.filter_threshold = cfg->feature_filter_threshold;
   t->det.min_dist = cfg->min_dist;
+  t->det.median_blur_kernel_size = cfg->median_blur_kernel_size;
   t->det.reset();
   return t;
 }

@@ -63,6 +63,9 @@ void* oracle_detector_create(int W, int H, double decay_ms, int ignore_polarity,
                              double filter_threshold, int min_dist);
 void oracle_detector_destroy(void* d);
 void oracle_detector_reset(void* d);
+/* median_blur_kernel_size k (event_detector.cc:262-264): cv::medianBlur(2k+1) on every rendered surface */
+void oracle_detector_set_median(void* d, int k);
+void oracle_median_blur(uint8_t* img, int w, int h, int ksize);
 /* createSAE_left (cam 0) / createSAE_right (cam 1) applied to n events in stream order.
  * returns number of events rejected because x>=W or y>=H (the reference would abort). */
 size_t oracle_create_sae(void* d, int cam, const oracle_event* ev, size_t n);

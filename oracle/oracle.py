@@ -83,6 +83,8 @@ def lib():
         L.oracle_detector_create.argtypes = [i, i, d, i, d, i]
         L.oracle_detector_destroy.argtypes = [vp]
         L.oracle_detector_reset.argtypes = [vp]
+        L.oracle_detector_set_median.argtypes = [vp, i]
+        L.oracle_median_blur.argtypes = [vp, i, i, i]
         L.oracle_create_sae.restype = sz
         L.oracle_create_sae.argtypes = [vp, i, vp, sz]
         L.oracle_sae_to_time_surface.argtypes = [vp, i, d, vp]
@@ -167,11 +169,13 @@ class Detector:
     """esvio::EventDetector restatement (event_detector.cc)."""
 
     def __init__(self, W, H, decay_ms=20.0, ignore_polarity=0, filter_threshold=0.01, min_dist=10,
-                 handle=None):
+                 handle=None, median_blur_kernel_size=0):
         self.W, self.H = W, H
         self._own = handle is None
         self.h = handle if handle is not None else lib().oracle_detector_create(
             W, H, decay_ms, ignore_polarity, filter_threshold, min_dist)
+        if handle is None and median_blur_kernel_size:
+            lib().oracle_detector_set_median(self.h, int(median_blur_kernel_size))
 
     def __del__(self):
         if getattr(self, "_own", False) and self.h:
@@ -274,6 +278,13 @@ def lk(prev, nxt, prev_pts, next_pts=None, win=21, max_level=3, max_count=30, ep
     return next_pts, status
 
 
+def median_blur(img, ksize):
+    """cv::medianBlur(img, ksize) on u8 (BORDER_REPLICATE)"""
+    out = np.ascontiguousarray(img, np.uint8).copy()
+    lib().oracle_median_blur(_p(out), out.shape[1], out.shape[0], int(ksize))
+    return out
+
+
 def clahe(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
@@ -337,7 +348,7 @@ class Tracker:
         self.cfg = cfg
         self.h = lib().oracle_tracker_create(C.byref(cfg))
         if not self.h:
-            raise ValueError("unsupported config (median_blur_kernel_size must be 0)")
+            raise ValueError("unsupported config")
         m = max(cfg.max_cnt, 1)
         self._bufs = dict(
             ids=np.zeros(m, np.int32), track_cnt=np.zeros(m, np.int32),

@@ -54,7 +54,8 @@ def test_create_rejects_bad_config():
     L = FE.load_library()
     h = C.c_void_p()
     for kw, rc_expected in ((dict(min_dist=2), -1), (dict(equalize=2), -1),
-                            (dict(median_blur_kernel_size=1), -4), (dict(decay_ms=0.0), -1),
+                            (dict(median_blur_kernel_size=8), -4), (dict(median_blur_kernel_size=-1), -1),
+                            (dict(decay_ms=0.0), -1),
                             (dict(max_cnt=0), -1)):
         cfg = FE.make_config(640, 480, **kw)
         assert L.esvio_fe_create(C.byref(cfg), C.byref(h)) == rc_expected, kw

@@ -520,3 +520,33 @@ def test_track_image_end_to_end_matches_oracle(oracle, equalize):
         _compare_tracks(ft, tr.track_image(t, L, R, pub), ("image", equalize, f))
     assert len(ft.ids) > 100 and ft.track_cnt.max() >= 6 and len(ft.ids_right) > 80
     ft.close()
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_median_blur_kernel_size(oracle, k):
+    """median_blur_kernel_size k > 0 (event_detector.cc:262-264): cv::medianBlur(2k+1) of each
+    rendered surface — the standalone render, and the whole tracker on top of it"""
+    W, H = 346, 260
+    s = SceneStream(W, H, rate=2e6, seed=17, n_rect=14, size=(30.0, 90.0))
+    kw = dict(max_cnt=100, min_dist=10, f_ransac=1, median_blur_kernel_size=k)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(5):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, f % 2 == 0)
+        r = tr.track_event(t, L, R, f % 2 == 0)
+        assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+        assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1))
+        _compare_tracks(ft, r, ("median", k, f))
+    assert len(ft.ids) > 30
+    # the plain render entry point
+    det = oracle.Detector(W, H, median_blur_kernel_size=k)
+    L, R, _ = s.next_batch()
+    det.create_sae(0, L)
+    ft2 = FE.FeatureTracker(FE.make_config(W, H, median_blur_kernel_size=k))
+    ft2.detector.createSAE_left(L)
+    t = event_times(L)[-1]
+    assert np.array_equal(ft2.detector.SAEtoTimeSurface_left(t), det.time_surface(0, t))
+    ft.close()
+    ft2.close()
