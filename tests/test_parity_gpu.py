@@ -550,3 +550,35 @@ def test_median_blur_kernel_size(oracle, k):
     assert np.array_equal(ft2.detector.SAEtoTimeSurface_left(t), det.time_surface(0, t))
     ft.close()
     ft2.close()
+
+
+def test_replay_mode_soak(oracle):
+    """60 frames with two batches announced ahead, irregular publish pattern, event rate changing
+    from batch to batch (buffers regrow, speculative temporal LK sizes change), an empty right batch
+    now and then: every frame bit-identical to the sequential oracle"""
+    W, H = 346, 260
+    rng = np.random.default_rng(99)
+    s = SceneStream(W, H, rate=2.5e6, seed=41, n_rect=10, size=(25.0, 80.0), t0_us=3_000_000_000)
+    batches = []
+    for f in range(60):
+        L, R, _ = s.next_batch()
+        if rng.integers(0, 2):  # a quarter of the events on some frames
+            L, R = L[::4].copy(), R[::4].copy()
+        if f % 11 == 7:
+            R = R[:0]
+        batches.append((L, R))
+    pubs = [bool(rng.integers(0, 3) != 0) for _ in batches]
+    kw = dict(max_cnt=120, min_dist=10, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        while announced < min(f + 2, len(batches) - 1):
+            announced += 1
+            Ln, Rn = batches[announced]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pubs[f])
+        _compare_tracks(ft, tr.track_event(t, L, R, pubs[f]), ("soak", f))
+    assert len(ft.ids) > 40 and ft.track_cnt.max() >= 3
+    ft.close()
