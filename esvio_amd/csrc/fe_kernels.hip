@@ -257,21 +257,41 @@ __global__ __launch_bounds__(256) void k_sae_apply(const uint32_t* __restrict__ 
   if (i > 0 && keys[i - 1] == k) return;  // not a segment head
   double2 Lv = L2[k], Sv = S2[k];
   double L[2] = {Lv.x, Lv.y}, S[2] = {Sv.x, Sv.y};
-  for (uint32_t j = i; j < n && keys[j] == k; j++) {
-    const uint32_t idx = vals[j];
-    const uint4 e = idx >= nL ? evR[idx - nL] : evL[idx];
-    const double t = ev_time(e.y, e.z);
-    const bool p = (e.w & 0xffu) != 0;
-    const double t_last = p ? L[1] : L[0];
-    const double t_last_inv = p ? L[0] : L[1];
-    const bool pass = (t > __dadd_rn(t_last, thr)) || (t_last_inv > t_last);
-    if (p) {
-      L[1] = t;
-      if (pass) S[1] = t;
-    } else {
-      L[0] = t;
-      if (pass) S[0] = t;
+  // Which events belong to the segment does not depend on the state, only the four values do: the
+  // keys / indices / events of kAhead positions are fetched together (two dependent round trips
+  // per group instead of two per event), then applied in order.
+  constexpr int kAhead = 8;
+  for (uint32_t j0 = i;; j0 += kAhead) {
+    uint32_t kk[kAhead], idx[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) {
+      const uint32_t j = min(j0 + u, n - 1);
+      kk[u] = j0 + u < n ? keys[j] : ~k;
+      idx[u] = vals[j];
     }
+    uint4 e[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) e[u] = idx[u] >= nL ? evR[idx[u] - nL] : evL[idx[u]];
+    bool more = true;
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) {
+      more = more && kk[u] == k;
+      if (more) {
+        const double t = ev_time(e[u].y, e[u].z);
+        const bool p = (e[u].w & 0xffu) != 0;
+        const double t_last = p ? L[1] : L[0];
+        const double t_last_inv = p ? L[0] : L[1];
+        const bool pass = (t > __dadd_rn(t_last, thr)) || (t_last_inv > t_last);
+        if (p) {
+          L[1] = t;
+          if (pass) S[1] = t;
+        } else {
+          L[0] = t;
+          if (pass) S[0] = t;
+        }
+      }
+    }
+    if (!more) break;
   }
   L2[k] = make_double2(L[0], L[1]);
   S2[k] = make_double2(S[0], S[1]);

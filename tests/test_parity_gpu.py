@@ -72,6 +72,44 @@ def test_sae_adversarial_duplicates(oracle):
     ft.close()
 
 
+def test_sae_segment_lengths_around_the_wave_path(oracle):
+    """per-pixel segments of every length around the hand-over to the wave-per-segment kernel (16/17)
+    and around its 64-event step (63..65, 127..129, 200): long same-polarity bursts inside the
+    refractory window, polarity flips, equal stamps and stamps going BACKWARDS inside the batch;
+    two batches so the carried-in state matters"""
+    W, H = 346, 260
+    rng = np.random.default_rng(11)
+    lengths = [1, 2, 15, 16, 17, 18, 31, 63, 64, 65, 66, 127, 128, 129, 200, 513]
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    for batch in range(2):
+        xs, ys, ts, ps = [], [], [], []
+        for i, n in enumerate(lengths * 3):
+            x, y = 3 + 2 * (i % 100), 7 + 5 * (i // 100) + 40 * batch * (i % 2)
+            kind = i % 3
+            if kind == 0:      # bursts of one polarity, 1 ms apart (mostly filtered), rare flips
+                p = (np.cumsum(rng.random(n) < 0.05) + i) % 2
+                t = 6_000_000 + np.arange(n) * 1000
+            elif kind == 1:    # random polarity, many ties, some 20 ms gaps (pass by time)
+                p = rng.integers(0, 2, n)
+                t = 6_000_000 + np.cumsum(rng.choice([0, 0, 500, 20_000], n))
+            else:              # stamps jump backwards now and then
+                p = rng.integers(0, 2, n)
+                t = 6_500_000 + np.cumsum(rng.choice([-3000, 0, 2000, 15_000], n))
+            xs.append(np.full(n, x)); ys.append(np.full(n, y)); ts.append(t + batch * 40_000); ps.append(p)
+        x, y, t, p = (np.concatenate(v) for v in (xs, ys, ts, ps))
+        perm = rng.permutation(len(x))  # interleave the pixels; each pixel's own order ...
+        order = perm[np.argsort(np.concatenate([np.arange(len(v)) for v in xs])[perm], kind="stable")]
+        ev = make_events(x[order], y[order], t[order], p[order])  # ... stays as generated
+        ft.detector.createSAE_left(ev)
+        det.create_sae(0, ev)
+        _planes_equal(ft.detector.get_sae(0), det.get_sae(0))
+        ft.detector.createSAE_right(ev[::-1].copy() if batch else ev)  # right camera: reversed stream
+        det.create_sae(1, ev[::-1].copy() if batch else ev)
+        _planes_equal(ft.detector.get_sae(1), det.get_sae(1))
+    ft.close()
+
+
 def test_time_surface_edge_cases(oracle):
     W, H = 346, 260
     ft = _mk(W, H)
