@@ -413,9 +413,15 @@ def test_ransac_rng_and_inliers(oracle):
     x1 = np.c_[p1[25:], np.ones(n - 25)]
     x2 = np.c_[p2[25:], np.ones(n - 25)]
     assert np.abs(np.einsum("ij,jk,ik->i", x2, F, x1)).max() < 5.0  # x2^T F x1 ~ 0
-    # LMedS branch (8..14 points) and the degenerate sizes
-    cnt, status, _ = oracle.find_fundamental(p1[30:42], p2[30:42], 1.0, 0.99)
-    assert cnt >= 10
+    # LMedS branch (8..14 points).  The median is the (n/2)-th smallest residual: with 14 points
+    # that is one the 7-point sample does not interpolate, so the true model wins and all 14 exact
+    # correspondences fall inside sigma (clamped at 0.001 px).  [With <= 13 points the median is a
+    # sample point's ~0 residual for EVERY candidate and the choice is numerical noise — inherent to
+    # cv::findFundamentalMat's LMedS, which the reference reaches only when fewer than 15 tracks
+    # survive.]
+    for lo in (30, 50, 70, 100):
+        cnt, status, _ = oracle.find_fundamental(p1[lo:lo + 14], p2[lo:lo + 14], 1.0, 0.99)
+        assert cnt == 14 and status.all()
     assert oracle.find_fundamental(p1[:6], p2[:6])[0] == 0
 
 
