@@ -216,7 +216,7 @@ def main():
         if rig is not None:  # C4: rank 0 = left camera + tracking, rank 1 = right camera
             rig.track(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub)
             if pub and exchange:
-                exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
+                exch.submit_tracker(ft, async_op=True)
             return nl if rank == 0 else nr
         if pipeline:  # replay mode: the next batches are already in HBM; announce two ahead
             while announced[0] < min(i + 2, len(dev_batches) - 1):
@@ -226,7 +226,7 @@ def main():
         ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
         if pub:
             if exch is not None and exchange:  # merge all rigs' tracked corners (async)
-                exch.submit(pack_track_records(ft, cfg.max_cnt), async_op=True)
+                exch.submit_tracker(ft, async_op=True)
         return nl + nr
 
     def barrier():

@@ -2264,6 +2264,50 @@ int esvio_fe_track_image(esvio_fe_handle c, double cur_time, const uint8_t* img_
   return fill_tracks(c, out);
 }
 
+// The node's sensor_msgs/PointCloud packing (stereo_event_tracker_node.cpp:273-329) of the current
+// result members, as a fixed-size block: left entries with track_cnt > 1, then right entries whose
+// id is among them; rows (x_un, y_un, 1, id*2+cam as float32, u, v, vx, vy); padding rows id -1.
+int esvio_fe_pack_track_records(esvio_fe_handle c, float* out, int32_t* n_rows) {
+  if (!c || !out) return ESVIO_FE_EINVAL;
+  const int rows = 2 * std::max(c->cfg.max_cnt, 1);
+  int k = 0;
+  std::vector<int> left_ids;
+  left_ids.reserve(c->ids.size());
+  for (size_t j = 0; j < c->ids.size() && k < rows; j++)
+    if (c->track_cnt[j] > 1) {
+      float* r = out + (size_t)k++ * 8;
+      r[0] = c->cur_un_pts[j].x;
+      r[1] = c->cur_un_pts[j].y;
+      r[2] = 1.f;
+      r[3] = (float)(c->ids[j] * 2 + 0);
+      r[4] = c->cur_pts[j].x;
+      r[5] = c->cur_pts[j].y;
+      r[6] = c->pts_velocity[j].x;
+      r[7] = c->pts_velocity[j].y;
+      left_ids.push_back(c->ids[j]);
+    }
+  std::sort(left_ids.begin(), left_ids.end());
+  for (size_t j = 0; j < c->ids_right.size() && k < rows; j++)
+    if (std::binary_search(left_ids.begin(), left_ids.end(), c->ids_right[j])) {
+      float* r = out + (size_t)k++ * 8;
+      r[0] = c->cur_un_right_pts[j].x;
+      r[1] = c->cur_un_right_pts[j].y;
+      r[2] = 1.f;
+      r[3] = (float)(c->ids_right[j] * 2 + 1);
+      r[4] = c->cur_right_pts[j].x;
+      r[5] = c->cur_right_pts[j].y;
+      r[6] = c->right_pts_velocity[j].x;
+      r[7] = c->right_pts_velocity[j].y;
+    }
+  if (n_rows) *n_rows = k;
+  for (; k < rows; k++) {
+    float* r = out + (size_t)k * 8;
+    for (int i = 0; i < 8; i++) r[i] = 0.f;
+    r[3] = -1.f;
+  }
+  return 0;
+}
+
 int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio_fe_event* left,
                             size_t nL, const esvio_fe_event* right, size_t nR, int space,
                             int pub_hint) {

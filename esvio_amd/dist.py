@@ -14,6 +14,14 @@ def shard_units(n_units, world, rank):
     return [u for u in range(n_units) if u % world == rank]
 
 
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class TrackExchange:
     """one (async) all_gather of track records per published frame."""
 
@@ -24,9 +32,18 @@ class TrackExchange:
         self.world = world
         self.rows = 2 * max_cnt
         self.send = torch.zeros((self.rows, 8), dtype=torch.float32, device=device)
-        self.recv = [torch.zeros_like(self.send) for _ in range(world)]
+        # one flat receive buffer (all_gather_into_tensor: no per-rank copies afterwards)
+        self.recv_flat = torch.zeros((world * self.rows, 8), dtype=torch.float32, device=device)
+        self.recv = list(self.recv_flat.view(world, self.rows, 8).unbind(0))
         self.stream = stream
         self.pending = None
+        # pinned staging (two, alternating) so that a tracker can pack straight into them and the
+        # upload is a non-blocking copy on the side stream
+        self.stage = None
+        if str(device).startswith("cuda"):
+            self.stage = [torch.zeros((self.rows, 8), dtype=torch.float32).pin_memory() for _ in range(2)]
+            self.stage_ev = [None, None]
+            self.stage_i = 0
 
     def submit(self, rec, async_op=True):
         """rec: (2*max_cnt, 8) float32 numpy block from node.pack_track_records"""
@@ -35,10 +52,28 @@ class TrackExchange:
         if self.stream is not None:
             with self.torch.cuda.stream(self.stream):
                 self.send.copy_(t)
-                self.pending = self.dist.all_gather(self.recv, self.send, async_op=async_op)
+                self.pending = self.dist.all_gather_into_tensor(self.recv_flat, self.send, async_op=async_op)
         else:
             self.send.copy_(t)
-            self.pending = self.dist.all_gather(self.recv, self.send, async_op=async_op)
+            self.pending = self.dist.all_gather_into_tensor(self.recv_flat, self.send, async_op=async_op)
+        return self.pending
+
+    def submit_tracker(self, ft, async_op=True):
+        """like submit(ft.pack_track_records()), without the detour through pageable memory"""
+        if self.stage is None:
+            return self.submit(ft.pack_track_records(), async_op)
+        self.wait()
+        i = self.stage_i
+        self.stage_i ^= 1
+        if self.stage_ev[i] is not None:
+            self.stage_ev[i].synchronize()  # its previous upload has long finished
+        ft.pack_track_records(self.stage[i].numpy())
+        with self.torch.cuda.stream(self.stream) if self.stream is not None else _null():
+            self.send.copy_(self.stage[i], non_blocking=True)
+            ev = self.torch.cuda.Event()
+            ev.record()
+            self.stage_ev[i] = ev
+            self.pending = self.dist.all_gather_into_tensor(self.recv_flat, self.send, async_op=async_op)
         return self.pending
 
     def wait(self):

@@ -80,6 +80,7 @@ ABI_SYMBOLS = [
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
     "esvio_fe_set_next_batch", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
+    "esvio_fe_pack_track_records",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
@@ -131,6 +132,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_set_next_batch.argtypes = [vp, d, vp, sz, vp, sz, i, i]
     L.esvio_fe_good_features_to_track.argtypes = [vp, vp, i, d, d, vp, vp, vp, vp]
     L.esvio_fe_track_image.argtypes = [vp, d, vp, vp, i, vp]
+    L.esvio_fe_pack_track_records.argtypes = [vp, vp, vp]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
     L.esvio_fe_export_image.argtypes = [vp, i, vp, i]
     L.esvio_fe_import_image.argtypes = [vp, i, vp, i]
@@ -361,6 +363,16 @@ class FeatureTracker:
             self._hd.h, _p(img), int(maxCorners), float(qualityLevel), float(minDistance),
             None if m is None else _p(m), _p(out), C.byref(n), None if eig is None else _p(eig)))
         return (out[:n.value].copy(), eig) if want_eig else out[:n.value].copy()
+
+    def pack_track_records(self, out=None):
+        """node:273-329 packing of the current results into a (2*max_cnt, 8) float32 block
+        (padding rows have id -1); `out` may be a preallocated (e.g. pinned) array"""
+        if out is None:
+            out = np.empty((2 * self.cfg.max_cnt, 8), np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == 16 * self.cfg.max_cnt
+        n = C.c_int32()
+        self._hd.check(self._hd.L.esvio_fe_pack_track_records(self._hd.h, _p(out), C.byref(n)))
+        return out
 
     def set_next_batch(self, next_cur_time, event_left, event_right, PUB_NEXT_FRAME=False):
         """announce the batch of the FOLLOWING trackEvent call (throughput / replay mode);

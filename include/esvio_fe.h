@@ -227,6 +227,12 @@ int esvio_fe_good_features_to_track(esvio_fe_handle h, const uint8_t* img, int m
 int esvio_fe_track_image(esvio_fe_handle h, double cur_time, const uint8_t* img_left,
                          const uint8_t* img_right, int pub_this_frame, esvio_fe_tracks* out);
 
+/* The node's PointCloud packing of the current results (stereo_event_tracker_node.cpp:273-329):
+ * out = 2*max_cnt rows of 8 floats (x_un, y_un, 1, id*2+cam as float32, u, v, vx, vy): left entries
+ * with track_cnt > 1, then right entries whose id is among them, then padding rows with id -1.
+ * This fixed-size block is the unit the multi-GPU all_gather exchanges. */
+int esvio_fe_pack_track_records(esvio_fe_handle h, float* out, int32_t* n_rows);
+
 /* FeatureTracker::gettimesurface() tap (feature_tracker.cpp:894): current left/right image */
 int esvio_fe_get_time_surface(esvio_fe_handle h, int cam, uint8_t* out);
 

@@ -620,3 +620,20 @@ def test_replay_mode_soak(oracle):
         _compare_tracks(ft, tr.track_event(t, L, R, pubs[f]), ("soak", f))
     assert len(ft.ids) > 40 and ft.track_cnt.max() >= 3
     ft.close()
+
+
+def test_pack_track_records_matches_the_node_packing():
+    """esvio_fe_pack_track_records == the PointCloud packing of stereo_event_tracker_node.cpp:273-329
+    (python mirror node.pack_track_records) on live tracker results"""
+    from esvio_amd.node import pack_track_records
+    W, H = 346, 260
+    s = SceneStream(W, H, rate=2e6, seed=5, n_rect=12, size=(30.0, 90.0))
+    ft = FE.FeatureTracker(FE.make_config(W, H, max_cnt=90, min_dist=10))
+    for f in range(5):
+        L, R, _ = s.next_batch()
+        ft.trackEvent(event_times(L)[-1], L, R, True)
+        a = ft.pack_track_records()
+        b = pack_track_records(ft, 90)
+        assert a.shape == b.shape == (180, 8) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), f
+    assert (a[:, 3] >= 0).sum() > 60
+    ft.close()
