@@ -156,18 +156,13 @@ struct esvio_fe_ctx {
   int raw_cur = 0;
   uint8_t* d_lut = nullptr;
   int* d_minmax = nullptr;
-  // LK point buffers (device), each max_cnt
-  // one allocation, laid out [ptsB | ptsC | stA | stB | counts | ptsA] so that each host sync
-  // needs a single D2H copy
+  // device-side point / status buffers of the standalone entry points (LK, featuresToTrack) and the
+  // selection counters; one allocation with the layout of ResLayout
   uint8_t* d_res = nullptr;
-  size_t res_bytes = 0, res_temporal_bytes = 0;
+  size_t res_bytes = 0;
   float2 *d_ptsA = nullptr, *d_ptsB = nullptr, *d_ptsC = nullptr, *d_ptsD = nullptr;
   uint8_t *d_stA = nullptr, *d_stB = nullptr;
-  // second LK result set + newly selected corners (stereo LK of the new corners runs as its own
-  // launch after the speculative stereo LK of the temporal survivors)
-  float2 *d_new = nullptr, *d_ptsB2 = nullptr, *d_ptsC2 = nullptr;  // d_new: [kept | new corners]
-  uint8_t *d_stA2 = nullptr, *d_stB2 = nullptr;
-  int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total [2]=#candidates
+  int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total (kept + new: the LK kernels' n_ptr)
   // The per-frame path works on the pinned host block itself (device-visible): the LK kernels read
   // their points from it and write results into it, k_select mirrors its counters into it — no
   // H2D / D2H copy calls on the frame's critical path (each costs more host time than the few
@@ -813,8 +808,6 @@ struct Pin {
   float2 *ptsB2, *ptsC2;  // set 2
   uint8_t *stA2, *stB2;
   float2* A;              // LK input points (read by the kernels in place)
-  float2* ptsA;           // staging for the standalone entry points' H2D copies
-  float2* kept;           // (spare)
   uint32_t* mask;         // H2D H*wpr words
 };
 
@@ -835,10 +828,6 @@ Pin pin_of(esvio_fe_ctx* c) {
   p.stA2 = b + L.SA2;
   p.stB2 = b + L.SB2;
   b += (L.total + 255) / 256 * 256;
-  p.ptsA = (float2*)b;
-  b += (M * 8 + 255) / 256 * 256;
-  p.kept = (float2*)b;
-  b += (M * 8 + 255) / 256 * 256;
   p.mask = (uint32_t*)b;
   return p;
 }
@@ -846,7 +835,7 @@ Pin pin_of(esvio_fe_ctx* c) {
 size_t pin_bytes(const esvio_fe_config& cfg) {
   const size_t M = std::max(cfg.max_cnt, 1);
   const ResLayout L = res_layout(M);
-  return (L.total + 255) / 256 * 256 + 2 * ((M * 8 + 255) / 256 * 256) +
+  return (L.total + 255) / 256 * 256 +
          (size_t)cfg.height * ((cfg.width + 31) / 32) * 4 + 256;
 }
 
@@ -1032,7 +1021,7 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
 }
 
 // Launch the NEXT frame's temporal forward/backward LK (feature_tracker.cpp:410,417 of the next
-// call) now: its inputs are final once this frame's kept points (uploaded to d_new[0..n_kept)) and
+// call) now: its inputs are final once this frame's kept points (written to z_new[0..n_kept)) and
 // new corners (written by k_select behind them, total count in d_counts[1]) are known, and the next
 // frame's pyramids are already being built on the prefetch stream.
 int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame's batch */,
@@ -1310,7 +1299,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
                                hipMemcpyHostToDevice, cur_stream(c)));
       if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
-      // new corners go behind the kept points: d_new = next frame's prev_pts
+      // new corners go behind the kept points: z_new = next frame's prev_pts
       // (the blocked pixels are the greedy's initial bitmap: candidates on them are skipped there)
       run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, c->d_mask_bits, c->z_counts);
       if (will_spec)
@@ -1819,7 +1808,6 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   {
     const ResLayout L = res_layout(M);
     c->res_bytes = L.total;
-    c->res_temporal_bytes = L.CNT;  // ptsB..stB of set 1
     if ((rc = dev_alloc(c, &c->d_res, c->res_bytes))) return bail(rc);
     c->d_ptsB = (float2*)(c->d_res + L.B1);
     c->d_ptsC = (float2*)(c->d_res + L.C1);
@@ -1827,11 +1815,6 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     c->d_stB = c->d_res + L.SB1;
     c->d_counts = (int*)(c->d_res + L.CNT);
     c->d_ptsA = (float2*)(c->d_res + L.A);
-    c->d_new = (float2*)(c->d_res + L.NEW);
-    c->d_ptsB2 = (float2*)(c->d_res + L.B2);
-    c->d_ptsC2 = (float2*)(c->d_res + L.C2);
-    c->d_stA2 = c->d_res + L.SA2;
-    c->d_stB2 = c->d_res + L.SB2;
   }
   {
     const size_t stM = (std::max<size_t>(M, 1) + 63) / 64 * 64;
