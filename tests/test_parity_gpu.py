@@ -510,7 +510,8 @@ def test_two_batches_ahead_need_an_exact_pub_hint():
 
 # ------------------------------------------------------------------ image front-end
 @pytest.mark.parametrize("W,H,md,use_mask", [(160, 120, 10, False), (346, 260, 20, True),
-                                             (640, 480, 30, True), (640, 480, 1, False)])
+                                             (640, 480, 30, True), (640, 480, 1, False),
+                                             (345, 259, 15, True), (1280, 720, 30, False)])
 def test_good_features_to_track_matches_oracle(oracle, W, H, md, use_mask):
     """cv::goodFeaturesToTrack restated (feature_tracker.cpp:228): response map bit-exact (Sobel,
     structure tensor, OpenCV's running column sum, min eigenvalue), corners identical and in order"""
@@ -636,4 +637,37 @@ def test_pack_track_records_matches_the_node_packing():
         b = pack_track_records(ft, 90)
         assert a.shape == b.shape == (180, 8) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), f
     assert (a[:, 3] >= 0).sum() > 60
+    ft.close()
+
+
+@pytest.mark.parametrize("W,H", [(345, 259), (321, 243), (250, 187)])
+def test_odd_sensor_sizes_end_to_end(oracle, W, H):
+    """sizes that are not multiples of 2/4/32: pyramid levels round up ((n+1)/2), bitmap rows end in
+    a partial word, image rows are not dword multiples — whole tracker + taps against the oracle"""
+    s = SceneStream(W, H, rate=1.5e6, seed=W, n_rect=12, size=(25.0, 80.0))
+    kw = dict(max_cnt=100, min_dist=9, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    batches = [s.next_batch() for _ in range(7)]
+    for f, (L, R, _) in enumerate(batches):
+        t = event_times(L)[-1]
+        if 1 <= f < len(batches) - 1 and f != 3:  # mix prefetched and plain calls
+            Ln, Rn, _ = batches[f + 1]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, (f + 1) % 2 == 0)
+        ft.trackEvent(t, L, R, f % 2 == 0)
+        _compare_tracks(ft, tr.track_event(t, L, R, f % 2 == 0), ("odd", W, H, f))
+        if f in (0, 3):  # nothing pending: the taps show this frame
+            assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+            assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1))
+    assert len(ft.ids) > 30
+    # pyramids and Scharr of an arbitrary image at this size
+    img = np.random.default_rng(W).integers(0, 256, (H, W), dtype=np.uint8)
+    levels = ft.build_pyramid(img, 3)
+    assert len(levels) == oracle.pyr_levels(W, H) + 1
+    cur = img
+    for l, (im, dv) in enumerate(levels):
+        if l > 0:
+            cur = oracle.pyr_down(cur)
+        assert np.array_equal(im, cur), ("level", l)
+        assert np.array_equal(dv, oracle.scharr(cur)), ("scharr", l)
     ft.close()
