@@ -671,3 +671,31 @@ def test_odd_sensor_sizes_end_to_end(oracle, W, H):
         assert np.array_equal(im, cur), ("level", l)
         assert np.array_equal(dv, oracle.scharr(cur)), ("scharr", l)
     ft.close()
+
+
+def test_event_and_image_handles_interleaved(oracle):
+    """ESVIO mode runs both front-ends (two nodes in the reference): an event handle in replay mode
+    and an image handle used alternately in one process do not disturb each other"""
+    from esvio_amd.synth import ImageStream
+    W, H = 346, 260
+    es = SceneStream(W, H, rate=1.5e6, seed=8, n_rect=12, size=(25.0, 80.0))
+    ims = ImageStream(W, H, velocity=(2, 1), disparity=6, seed=8)
+    ekw = dict(max_cnt=90, min_dist=10, f_ransac=1)
+    ikw = dict(max_cnt=70, min_dist=20, flow_back=1)
+    fe, fi = FE.FeatureTracker(FE.make_config(W, H, **ekw)), FE.FeatureTracker(FE.make_config(W, H, **ikw))
+    oe, oi = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **ekw)), oracle.Tracker(
+        oracle.make_config(W, H, lk_accum=1, **ikw))
+    batches = [es.next_batch() for _ in range(6)]
+    for f, (L, R, _) in enumerate(batches):
+        if f + 1 < len(batches):
+            Ln, Rn, _ = batches[f + 1]
+            fe.set_next_batch(event_times(Ln)[-1], Ln, Rn, True)
+        t = event_times(L)[-1]
+        fe.trackEvent(t, L, R, True)
+        IL, IR, ti = ims.next_frame()
+        fi.trackImage(ti, IL, IR, True)
+        _compare_tracks(fe, oe.track_event(t, L, R, True), ("ev", f))
+        _compare_tracks(fi, oi.track_image(ti, IL, IR, True), ("img", f))
+    assert len(fe.ids) > 30 and len(fi.ids) > 40
+    fe.close()
+    fi.close()
