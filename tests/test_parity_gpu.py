@@ -699,3 +699,41 @@ def test_event_and_image_handles_interleaved(oracle):
     assert len(fe.ids) > 30 and len(fi.ids) > 40
     fe.close()
     fi.close()
+
+
+def test_randomized_small_cases(oracle):
+    """40 seeded random cases: sensor sizes from 48x44 up, batch sizes around the sort tile (1, 2,
+    2047..2049, 4097 ...), clustered pixels, tied / reversed stamps, both polarity modes: SAE planes,
+    time surfaces (several sync times) and Arc* flags bit-exact"""
+    rng = np.random.default_rng(2024)
+    sizes = [1, 2, 3, 63, 64, 65, 255, 257, 2047, 2048, 2049, 4097, 6000, 10000]
+    for case in range(40):
+        W, H = int(rng.integers(48, 200)), int(rng.integers(44, 150))
+        ign = int(rng.integers(0, 2))
+        thr = float(rng.choice([0.0, 0.001, 0.01, 0.05]))
+        ft = FE.FeatureTracker(FE.make_config(W, H, ignore_polarity=ign, feature_filter_threshold=thr,
+                                              decay_ms=float(rng.choice([5.0, 20.0, 100.0]))))
+        det = oracle.Detector(W, H, decay_ms=ft.cfg.decay_ms, ignore_polarity=ign, filter_threshold=thr)
+        t0 = 9_000_000
+        for b in range(3):
+            n = int(rng.choice(sizes))
+            if rng.integers(0, 2):  # clustered: few pixels, long per-pixel runs
+                cx, cy = rng.integers(0, W, 6), rng.integers(0, H, 6)
+                k = rng.integers(0, 6, n)
+                x, y = cx[k], cy[k]
+            else:
+                x, y = rng.integers(0, W, n), rng.integers(0, H, n)
+            dt = rng.choice([0, 0, 1, 50, 3000, -200], n)
+            t = t0 + np.maximum(np.cumsum(dt), -t0 + 1)
+            t0 = int(t[-1]) + int(rng.integers(0, 20000))
+            ev = make_events(x, y, t, rng.integers(0, 2, n))
+            cam = int(rng.integers(0, 2))
+            (ft.detector.createSAE_right if cam else ft.detector.createSAE_left)(ev)
+            det.create_sae(cam, ev)
+            _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+            if cam == 0:
+                assert np.array_equal(ft.detector.isCorner(ev), det.corner_flags(ev)), (case, b)
+            for ts in (t[-1] * 1e-6, t[-1] * 1e-6 + 0.013, t[0] * 1e-6 - 0.2):
+                f = ft.detector.SAEtoTimeSurface_right if cam else ft.detector.SAEtoTimeSurface_left
+                assert np.array_equal(f(ts), det.time_surface(cam, ts)), (case, b, ts)
+        ft.close()
