@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not announce the next batch (esvio_fe_set_next_batch): strictly one "
                          "batch in flight, like the reference's depth-1 queues")
+    ap.add_argument("--no-lazy", action="store_true",
+                    help="wait for the stereo LK of newly detected corners inside the call that detects "
+                         "them (default in replay mode: their right-camera entries are completed by "
+                         "the next call; the published PointCloud rows never contain them)")
     ap.add_argument("--split", choices=["rigs", "camera"], default="rigs",
                     help="N>1 sharding: one independent stereo rig per GPU (weak scaling, default) or "
                          "BASELINE C4: left/right cameras of ONE rig on 2 GPUs")
@@ -209,6 +213,9 @@ def main():
 
     rig = CameraSplitRig(ft, rank, dist, device=xdev) if cam_split else None
     pipeline = not args.no_pipeline and not cam_split
+    lazy = pipeline and not args.no_lazy
+    if lazy:
+        ft.set_lazy_new_stereo(True)
 
     def step(i, exchange=True):
         tl, tr, nl, nr, t_last = dev_batches[i]
@@ -241,6 +248,8 @@ def main():
     n_events = 0
     for i in range(args.warmup, n_frames):
         n_events += step(i)
+    if lazy:
+        ft.finish(copy=False)  # the last published frame's deferred right-camera entries
     if exch is not None:
         exch.wait()
     torch.cuda.synchronize()
@@ -346,6 +355,7 @@ def main():
                                 "1 rig per GPU") if world > 1 else "single GPU",
                 "tracks_last_frame": n_tracks,
                 "pipelined_next_batch": bool(pipeline),
+                "lazy_new_corner_stereo": bool(lazy),
             },
             "roofline": roof,
             "cpu_baseline": cpu,

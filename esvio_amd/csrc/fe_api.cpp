@@ -179,6 +179,17 @@ struct esvio_fe_ctx {
   size_t spec_bytes = 0;
   bool spec_valid = false;
   int spec_n = 0;             // number of points of that launch (= the next frame's prev_pts.size())
+  // ---- lazy stereo of new corners (esvio_fe_set_lazy_new_stereo): a published frame returns
+  // without waiting for the stereo LK of the corners it has just detected; their right-camera
+  // entries are appended by the next call (before anything reads them) or by esvio_fe_finish
+  bool lazy_new = false;
+  struct PendingNew {
+    bool active = false;
+    bool prev_map_was_empty = false;
+    std::vector<int> ids;       // the new corners' ids
+    std::vector<P2f> left;      // ... and left positions
+  } pend;
+  hipEvent_t ev_lks_done = nullptr, ev_lknew_done = nullptr;
   // arc / select
   uint8_t* d_flags = nullptr;
   // per-block ordered candidate lists written by k_arc; two sets so that the Arc* of a prefetched
@@ -1053,6 +1064,41 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
   return 0;
 }
 
+// Lazy mode: append the right-camera entries of the corners the previous published frame detected
+// (their stereo LK has run meanwhile).  Equal to what the eager tail would have produced: the new
+// ids are the largest, come last in every vector, are absent from the previous frame's map (zero
+// velocity, feature_tracker.cpp:1026-1040) and extend the (sorted) map the next frame reads.
+int finalize_pending(esvio_fe_ctx* c) {
+  if (!c->pend.active) return 0;
+  c->pend.active = false;
+  HIPCHK(c, sync_event(c->ev_lknew_done));
+  Pin pin = pin_of(c);
+  const esvio_fe_config& cfg = c->cfg;
+  const P2f *B2 = (const P2f*)pin.ptsB2, *C2 = (const P2f*)pin.ptsC2;
+  std::vector<P2f> add;
+  std::vector<int> add_ids;
+  for (size_t j = 0; j < c->pend.ids.size(); j++) {
+    bool ok = pin.stA2[j] != 0;
+    if (cfg.flow_back)
+      ok = ok && pin.stB2[j] && in_border_event(c, B2[j]) && pt_distance(c->pend.left[j], C2[j]) <= 0.5;
+    if (ok) {
+      add.push_back(B2[j]);
+      add_ids.push_back(c->pend.ids[j]);
+    }
+  }
+  if (add.empty()) return 0;
+  const std::vector<P2f> un = undistorted_pts(add, cfg.cam[1]);
+  for (size_t j = 0; j < add.size(); j++) {
+    c->ids_right.push_back(add_ids[j]);
+    c->cur_right_pts.push_back(add[j]);
+    c->cur_un_right_pts.push_back(un[j]);
+    c->track_cnt_right.push_back(1);
+    if (!c->pend.prev_map_was_empty) c->right_pts_velocity.push_back(P2f{0, 0});
+    c->prev_un_right_pts_map.v.emplace_back(add_ids[j], un[j]);  // (already swapped: next frame's prev)
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- trackEvent
 int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* left, size_t nL,
                      const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME,
@@ -1275,6 +1321,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                        0.01, 0);
     LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
     run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC, c->z_stB);
+    if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lks_done, cur_stream(c)));
   }
   if (defer_early) {
     if (int rc = early_work()) return rc;
@@ -1308,12 +1355,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       // the selection result is in host memory once k_select is done: an event right behind it lets
       // the left-camera bookkeeping below run under the stereo LK of the new corners
       HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
+      if (int rc = finalize_pending(c)) return rc;  // (its results live where this launch writes)
       // stereo LK of the new corners only (count known on the device)
       LkArgs f = make_lk(curL, curR, c->z_new + n_kept, nullptr, c->z_ptsB2, c->z_stA2, c->d_counts,
                          n_max_cnt, 3, 30, 0.01, 0);
       LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, c->d_counts, n_max_cnt, 3, 30,
                          0.01, 0);
       run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC2, c->z_stB2);
+      if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lknew_done, cur_stream(c)));
     }
   }
   if (defer_late)
@@ -1341,7 +1390,13 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);  // :470-473
   c->pts_velocity = pts_velocity_fn(c, c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map);
   lap(7);
-  HIPCHK(c, sync_main(c));  // stereo LK results
+  if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners)
+  const bool lazy = c->lazy_new && detect;      // leave this frame's new corners to the next call
+  if (lazy) {
+    if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done));
+  } else {
+    HIPCHK(c, sync_main(c));  // stereo LK results
+  }
   lap(6);
   if ((n_surv || detect) && pin.counts[3] != 0)
     return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
@@ -1353,8 +1408,15 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     c->right_pts_velocity.clear();
     c->cur_un_right_pts_map.clear();
     c->track_cnt_right.clear();
+    const int n_tail = lazy ? n_kept : (int)c->cur_pts.size();
+    if (lazy) {
+      c->pend.active = true;
+      c->pend.prev_map_was_empty = c->prev_un_right_pts_map.empty();
+      c->pend.ids.assign(c->ids.begin() + n_kept, c->ids.end());
+      c->pend.left.assign(c->cur_pts.begin() + n_kept, c->cur_pts.end());
+    }
     if (!c->cur_pts.empty()) {
-      const int n = (int)c->cur_pts.size();
+      const int n = n_tail;
       // gather the stereo results: kept points from set 1 (by survivor index), new ones from set 2
       std::vector<uint8_t> status(n), statusRightLeft(n);
       std::vector<P2f> reverseLeftPts(n);
@@ -1385,7 +1447,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
             status[i] = 0;
         }
       }
-      c->ids_right = c->ids;
+      c->ids_right.assign(c->ids.begin(), c->ids.begin() + n);
       reduce_vector(c->cur_right_pts, status);
       reduce_vector(c->ids_right, status);
       for (size_t i = 0; i < c->cur_right_pts.size(); i++) c->track_cnt_right.push_back(1);
@@ -1739,6 +1801,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
   if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
   if (c->ev_sel_host) (void)hipEventDestroy(c->ev_sel_host);
+  if (c->ev_lks_done) (void)hipEventDestroy(c->ev_lks_done);
+  if (c->ev_lknew_done) (void)hipEventDestroy(c->ev_lknew_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -1794,6 +1858,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_sel_host, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_lks_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_lknew_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
   for (int i = 0; i < kPrefetchDepth; i++)
@@ -1878,6 +1944,7 @@ int esvio_fe_reset(esvio_fe_handle c) {
   c->announced.clear();
   c->inflight.clear();
   c->spec_valid = false;
+  c->pend.active = false;
   HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, cur_stream(c)));
   HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, cur_stream(c)));
   HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
@@ -2289,6 +2356,21 @@ int esvio_fe_pack_track_records(esvio_fe_handle c, float* out, int32_t* n_rows) 
     r[3] = -1.f;
   }
   return 0;
+}
+
+int esvio_fe_set_lazy_new_stereo(esvio_fe_handle c, int on) {
+  if (!c) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = finalize_pending(c)) return rc;
+  c->lazy_new = on != 0;
+  return 0;
+}
+
+int esvio_fe_finish(esvio_fe_handle c, esvio_fe_tracks* out) {
+  if (!c) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = finalize_pending(c)) return rc;
+  return fill_tracks(c, out);
 }
 
 int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio_fe_event* left,

@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
     "esvio_fe_set_next_batch", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
-    "esvio_fe_pack_track_records",
+    "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
@@ -133,6 +133,8 @@ def load_library(build_if_missing=True):
     L.esvio_fe_good_features_to_track.argtypes = [vp, vp, i, d, d, vp, vp, vp, vp]
     L.esvio_fe_track_image.argtypes = [vp, d, vp, vp, i, vp]
     L.esvio_fe_pack_track_records.argtypes = [vp, vp, vp]
+    L.esvio_fe_set_lazy_new_stereo.argtypes = [vp, i]
+    L.esvio_fe_finish.argtypes = [vp, vp]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
     L.esvio_fe_export_image.argtypes = [vp, i, vp, i]
     L.esvio_fe_import_image.argtypes = [vp, i, vp, i]
@@ -363,6 +365,16 @@ class FeatureTracker:
             self._hd.h, _p(img), int(maxCorners), float(qualityLevel), float(minDistance),
             None if m is None else _p(m), _p(out), C.byref(n), None if eig is None else _p(eig)))
         return (out[:n.value].copy(), eig) if want_eig else out[:n.value].copy()
+
+    def set_lazy_new_stereo(self, on=True):
+        """throughput option: published frames do not wait for the stereo LK of the corners they have
+        just detected; finish() (or the next call) completes the right-camera vectors"""
+        self._hd.check(self._hd.L.esvio_fe_set_lazy_new_stereo(self._hd.h, int(bool(on))))
+
+    def finish(self, copy=True):
+        """complete a lazily returned frame and refresh the result members"""
+        self._hd.check(self._hd.L.esvio_fe_finish(self._hd.h, C.byref(self._tr)))
+        return self._take(copy)
 
     def pack_track_records(self, out=None):
         """node:273-329 packing of the current results into a (2*max_cnt, 8) float32 block

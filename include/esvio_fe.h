@@ -233,6 +233,16 @@ int esvio_fe_track_image(esvio_fe_handle h, double cur_time, const uint8_t* img_
  * This fixed-size block is the unit the multi-GPU all_gather exchanges. */
 int esvio_fe_pack_track_records(esvio_fe_handle h, float* out, int32_t* n_rows);
 
+/* Throughput option: with `on`, a published esvio_fe_track_event call returns without waiting for
+ * the stereo LK of the corners it has just detected.  Everything else in its results is complete
+ * (the node's PointCloud never contains corners of track_cnt 1, node:289); the right-camera entries
+ * of those new corners (ids_right / cur_right_pts / cur_un_right_pts / right_pts_velocity tails) are
+ * appended at the start of the next call's right-camera bookkeeping — before they can influence
+ * anything — or by esvio_fe_finish, after which the state is bit-identical to the eager sequence. */
+int esvio_fe_set_lazy_new_stereo(esvio_fe_handle h, int on);
+/* complete a lazily returned frame (no-op otherwise) and copy the result members into `out` */
+int esvio_fe_finish(esvio_fe_handle h, esvio_fe_tracks* out);
+
 /* FeatureTracker::gettimesurface() tap (feature_tracker.cpp:894): current left/right image */
 int esvio_fe_get_time_surface(esvio_fe_handle h, int cam, uint8_t* out);
 

@@ -443,10 +443,10 @@ def test_track_event_motion_compensated_end_to_end(oracle):
     ft.close()
 
 
-@pytest.mark.parametrize("equalize,hint,depth", [(0, "none", 1), (0, "right", 1), (0, "wrong", 1),
-                                                 (1, "right", 1), (1, "none", 1), (0, "right", 2),
-                                                 (1, "right", 2)])
-def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth):
+@pytest.mark.parametrize("equalize,hint,depth,lazy", [
+    (0, "none", 1, 0), (0, "right", 1, 0), (0, "wrong", 1, 0), (1, "right", 1, 0), (1, "none", 1, 0),
+    (0, "right", 2, 0), (1, "right", 2, 0), (0, "right", 2, 1), (0, "none", 1, 1), (1, "right", 2, 1)])
+def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy):
     """esvio_fe_set_next_batch (replay mode: the next one or two batches' SAE update / images — and,
     with the PUB hint, their Arc* pass — run on a second stream, and the next frame's temporal LK
     is launched speculatively on a third) must not change a single result bit, whether the hint is
@@ -456,6 +456,7 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth):
     batches = [s.next_batch() for _ in range(12)]
     kw = dict(f_ransac=1, equalize=equalize)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(bool(lazy))
     tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
     pubs = [(f % 3) != 1 for f in range(len(batches))]
     announced = 0
@@ -473,7 +474,16 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth):
             h = {"none": False, "right": pubs[announced], "wrong": not pubs[announced]}[hint]
             ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, h)
         ft.trackEvent(t, L, R, pubs[f])
-        _compare_tracks(ft, tr.track_event(t, L, R, pubs[f]), ("prefetch", hint, depth, f))
+        r = tr.track_event(t, L, R, pubs[f])
+        if lazy:
+            # what a lazily returned frame already guarantees: the left side and the PointCloud rows
+            for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"):
+                assert np.array_equal(getattr(ft, k), getattr(r, k)), (k, f)
+            if f % 2:   # ... and after finish() everything (odd frames only: the next call must
+                ft.finish()   # complete a pending frame by itself as well)
+                _compare_tracks(ft, r, ("lazy+finish", hint, depth, f))
+        else:
+            _compare_tracks(ft, r, ("prefetch", hint, depth, f))
         if f == 4:  # nothing pending: the taps show this very frame
             assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
     assert len(ft.ids) > 100
@@ -591,7 +601,8 @@ def test_median_blur_kernel_size(oracle, k):
     ft2.close()
 
 
-def test_replay_mode_soak(oracle):
+@pytest.mark.parametrize("lazy", [0, 1])
+def test_replay_mode_soak(oracle, lazy):
     """60 frames with two batches announced ahead, irregular publish pattern, event rate changing
     from batch to batch (buffers regrow, speculative temporal LK sizes change), an empty right batch
     now and then: every frame bit-identical to the sequential oracle"""
@@ -609,7 +620,9 @@ def test_replay_mode_soak(oracle):
     pubs = [bool(rng.integers(0, 3) != 0) for _ in batches]
     kw = dict(max_cnt=120, min_dist=10, f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(bool(lazy))
     tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    from esvio_amd.node import pack_track_records
     announced = 0
     for f, (L, R) in enumerate(batches):
         while announced < min(f + 2, len(batches) - 1):
@@ -618,7 +631,15 @@ def test_replay_mode_soak(oracle):
             ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
         t = event_times(L)[-1]
         ft.trackEvent(t, L, R, pubs[f])
-        _compare_tracks(ft, tr.track_event(t, L, R, pubs[f]), ("soak", f))
+        r = tr.track_event(t, L, R, pubs[f])
+        if lazy:  # the published rows are complete even before the frame is finished
+            rows = ft.pack_track_records()
+            if rng.integers(0, 3) == 0:
+                ft.finish()
+                _compare_tracks(ft, r, ("soak lazy", f))
+                assert np.array_equal(rows.view(np.uint32), pack_track_records(ft, 120).view(np.uint32))
+        else:
+            _compare_tracks(ft, r, ("soak", f))
     assert len(ft.ids) > 40 and ft.track_cnt.max() >= 3
     ft.close()
 
