@@ -179,6 +179,10 @@ struct esvio_fe_ctx {
   size_t spec_bytes = 0;
   bool spec_valid = false;
   int spec_n = 0;             // number of points of that launch (= the next frame's prev_pts.size())
+  // k_select publishes each new corner as it accepts it; the speculative launch, already resident,
+  // picks them up one by one instead of starting after the whole selection
+  unsigned long long *d_pub_slots = nullptr, *d_pub_done = nullptr;
+  uint32_t pub_seq = 0;
   // ---- lazy stereo of new corners (esvio_fe_set_lazy_new_stereo): a published frame returns
   // without waiting for the stereo LK of the corners it has just detected; their right-camera
   // entries are appended by the next call (before anything reads them) or by esvio_fe_finish
@@ -893,6 +897,9 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* o
   s.n_total = c->d_counts + 1;
   s.host_counts = nullptr;
   s.init_bits = nullptr;
+  s.pub_slots = nullptr;
+  s.pub_done = nullptr;
+  s.pub_seq = 0;
   return s;
 }
 
@@ -911,10 +918,16 @@ void run_compact(esvio_fe_ctx* c, uint32_t n_events, int set) {
 // the sequential greedy (Event_FeaturesToTrack) over the compacted candidates of set `set`;
 // `mask_bits`: blocked pixels the disc bitmap starts from (null: none, or already applied by k_arc)
 void run_select(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int out_base,
-                int32_t* out_idx, const uint32_t* mask_bits = nullptr, int* host_counts = nullptr) {
+                int32_t* out_idx, const uint32_t* mask_bits = nullptr, int* host_counts = nullptr,
+                bool publish = false) {
   SelectArgs s = make_select_args(c, set, max_corners, out_pts, out_base, out_idx);
   s.host_counts = host_counts;
   s.init_bits = mask_bits;
+  if (publish) {
+    s.pub_slots = c->d_pub_slots;
+    s.pub_done = c->d_pub_done;
+    s.pub_seq = c->pub_seq;
+  }
   ScopedKernel k(c, K_SELECT, 0);
   launch_select(cur_stream(c), s, select_lds_bytes(c));
 }
@@ -1039,10 +1052,8 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
                           int n_kept, bool with_new) {
   const size_t M = std::max(c->cfg.max_cnt, 1);
   const size_t stM = (M + 63) / 64 * 64;
-  if (with_new) {  // the new corners come from k_select on the main stream (kept ones: host memory)
-    HIPCHK(c, hipEventRecord(c->ev_pts_ready, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_pts_ready, 0));
-  }
+  // (kept points: already in host memory; new corners: published one by one by the k_select that
+  // has just been launched — the waves of points >= n_kept wait for their slot)
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_lane_done[nxt.lane], 0));
   float2* B = (float2*)c->z_spec;  // results land in the pinned block itself
   float2* Cb = B + M;
@@ -1050,11 +1061,17 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
   uint8_t* sB = sA + stM;
   const PyrDesc& P = c->pyr[c->slot_curL].d;
   const PyrDesc& N = c->pyr[nxt.slotL].d;
-  const int* n_ptr = with_new ? c->d_counts + 1 : nullptr;
   const int n_max = with_new ? (int)M : n_kept;
-  LkArgs f = make_lk(P, N, c->z_new, nullptr, B, sA, n_ptr, n_max, 3, 30, 0.01, 0);
-  LkArgs b = make_lk(N, P, nullptr, nullptr, nullptr, nullptr, n_ptr, n_max, 1, 30, 0.01,
+  LkArgs f = make_lk(P, N, c->z_new, nullptr, B, sA, nullptr, n_max, 3, 30, 0.01, 0);
+  LkArgs b = make_lk(N, P, nullptr, nullptr, nullptr, nullptr, nullptr, n_max, 1, 30, 0.01,
                      ESVIO_FE_LK_USE_INITIAL_FLOW);
+  if (with_new) {
+    f.poll_slots = c->d_pub_slots;
+    f.poll_done = c->d_pub_done;
+    f.poll_seq = c->pub_seq;
+    f.poll_from = n_kept;
+    f.poll_err = (int*)(c->z_spec + M * 16 + 2 * stM);
+  }
   {
     StreamScope on_spec_stream(c->stream3);
     run_lk(c, f, c->cfg.flow_back ? &b : nullptr, Cb, sB);
@@ -1239,6 +1256,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     const int n = (int)c->prev_pts.size();
     const uint8_t *t_stA, *t_stB;
     const P2f *t_ptsB, *t_ptsC;
+    bool spec_ok = false;
     if (use_spec) {
       if (!defer_early && !defer_late)
         if (int rc = early_work()) return rc;
@@ -1250,7 +1268,11 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       t_ptsC = (const P2f*)(c->h_spec + (size_t)std::max(M, 1) * 8);
       t_stA = c->h_spec + (size_t)std::max(M, 1) * 16;
       t_stB = t_stA + stM;
-    } else {
+      int* wait_expired = (int*)(c->h_spec + (size_t)std::max(M, 1) * 16 + 2 * stM);
+      spec_ok = *wait_expired == 0;  // (a wave gave up waiting for k_select: redo the launch below)
+      *wait_expired = 0;
+    }
+    if (!spec_ok) {
       std::memcpy(pin.A, c->prev_pts.data(), (size_t)n * 8);
       // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
       // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
@@ -1348,7 +1370,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
       // new corners go behind the kept points: z_new = next frame's prev_pts
       // (the blocked pixels are the greedy's initial bitmap: candidates on them are skipped there)
-      run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, c->d_mask_bits, c->z_counts);
+      c->pub_seq++;
+      run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, c->d_mask_bits, c->z_counts,
+                 will_spec);
       if (will_spec)
         if (const Inflight* nb = next_batch())
           if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
@@ -1562,6 +1586,9 @@ int gftt_run(esvio_fe_ctx* c, const PyrDesc& d, int max_corners, double quality,
   sa.n_total = c->d_counts + 1;
   sa.host_counts = host_counts;
   sa.init_bits = nullptr;
+  sa.pub_slots = nullptr;
+  sa.pub_done = nullptr;
+  sa.pub_seq = 0;
   ScopedKernel k(c, K_SELECT, 0);
   launch_select(cur_stream(c), sa, select_lds_bytes(c));
   return 0;
@@ -1765,7 +1792,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
-                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
+                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
                   c->d_minmax};
@@ -1884,12 +1911,17 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   }
   {
     const size_t stM = (std::max<size_t>(M, 1) + 63) / 64 * 64;
-    c->spec_bytes = std::max<size_t>(M, 1) * 16 + 2 * stM;
+    c->spec_bytes = std::max<size_t>(M, 1) * 16 + 2 * stM + 64;  // results + the wait-expired flag
     if (hipHostMalloc((void**)&c->h_spec, c->spec_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->z_spec, c->h_spec, 0) != hipSuccess)
       return bail(ESVIO_FE_EHIP);
     std::memset(c->h_spec, 0, c->spec_bytes);
   }
+  if ((rc = dev_alloc(c, &c->d_pub_slots, std::max<size_t>(M, 1)))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_pub_done, 1))) return bail(rc);
+  if (hipMemsetAsync(c->d_pub_slots, 0, std::max<size_t>(M, 1) * 8, cur_stream(c)) != hipSuccess ||
+      hipMemsetAsync(c->d_pub_done, 0, 8, cur_stream(c)) != hipSuccess)
+    return bail(ESVIO_FE_EHIP);
   if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_sel_idx, M))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_mask_bits, (size_t)c->H * ((c->W + 31) / 32)))) return bail(rc);

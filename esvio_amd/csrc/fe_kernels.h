@@ -107,6 +107,13 @@ struct LkArgs {
   uint8_t* status;
   const int* n_ptr;  // device count (may be NULL -> n_max)
   int n_max;
+  // optional: points with index >= poll_from are not in prev_pts yet; their wave waits (bounded)
+  // for k_select to publish them (SelectArgs::pub_*) or to announce a total below their index
+  const unsigned long long* poll_slots = nullptr;
+  const unsigned long long* poll_done = nullptr;
+  uint32_t poll_seq = 0;
+  int poll_from = 0;
+  int* poll_err = nullptr;  // set to 1 if a wait expired (host-visible)
   int max_level;
   int max_count;
   double eps2;
@@ -192,6 +199,13 @@ struct SelectArgs {
   int* n_total;              // out_base + accepted (feeds the LK kernels' n_ptr), may be NULL
   int* host_counts;          // optional host-mapped mirror: {accepted, out_base + accepted, total}
   const uint32_t* init_bits; // optional H*wpr words the disc bitmap starts from (blocked pixels)
+  // optional publication of each accepted corner the moment it is accepted, for an LK launch that
+  // is already waiting (LkArgs::poll_*): slot[out_base + k] = seq<<32 | y<<16 | x, and at the end
+  // *done = seq<<32 | (out_base + accepted).  Device memory, relaxed agent-scope atomics; the data
+  // travels in the flag word itself, so no fence is needed.
+  unsigned long long* pub_slots;
+  unsigned long long* pub_done;
+  uint32_t pub_seq;
 };
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes);
 

@@ -1030,6 +1030,11 @@ struct LkKernelArgs {
   uint8_t* back_status;
   const int* n_ptr;        // device count (may be NULL -> n_max)
   int n_max;
+  const unsigned long long* poll_slots;  // see LkArgs::poll_*
+  const unsigned long long* poll_done;
+  uint32_t poll_seq;
+  int poll_from;
+  int* poll_err;
 };
 
 __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
@@ -1038,7 +1043,27 @@ __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
   const int pt = blockIdx.x * 4 + wave;
   const int n = a.n_ptr ? *a.n_ptr : a.n_max;
   if (pt >= n || pt >= a.n_max) return;
-  const float2 prev0 = a.prev_pts[pt];
+  float2 prev0;
+  if (a.poll_slots && pt >= a.poll_from) {
+    // this point is a corner k_select may still be about to accept: wait for its slot (or for the
+    // final count to rule it out).  wall_clock64 ticks at 100 MHz: give up after 20 ms.
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long v;
+    for (;;) {
+      v = __hip_atomic_load(&a.poll_slots[pt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(v >> 32) == a.poll_seq) break;
+      const unsigned long long d = __hip_atomic_load(a.poll_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(d >> 32) == a.poll_seq && pt >= (int)(uint32_t)d) return;  // not accepted
+      if (wall_clock64() - t0 > 2000000ull) {
+        if (lane == 0) *a.poll_err = 1;
+        return;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    prev0 = make_float2((float)(uint32_t)(v & 0xffffu), (float)(uint32_t)((v >> 16) & 0xffffu));
+  } else {
+    prev0 = a.prev_pts[pt];
+  }
   const float2 init = (a.fwd.flags & 4) ? a.init_pts[pt] : make_float2(0.f, 0.f);
   float2 np;
   int st;
@@ -1086,6 +1111,11 @@ void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts
   a.back_status = back_status;
   a.n_ptr = f.n_ptr;
   a.n_max = f.n_max;
+  a.poll_slots = f.poll_slots;
+  a.poll_done = f.poll_done;
+  a.poll_seq = f.poll_seq;
+  a.poll_from = f.poll_from;
+  a.poll_err = f.poll_err;
   hipLaunchKernelGGL(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
 }
 
@@ -1633,6 +1663,10 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         const bool mine = ((acc >> lane) & 1ull) && before < room;
         if (mine) {
           a.out_pts[a.out_base + accepted + before] = make_float2((float)x, (float)y);
+          if (a.pub_slots)
+            __hip_atomic_store(&a.pub_slots[a.out_base + accepted + before],
+                               ((unsigned long long)a.pub_seq << 32) | ((unsigned)y << 16) | (unsigned)x,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (a.out_idx) a.out_idx[accepted + before] = (int)cci[j];
         }
         accepted += min(__builtin_popcountll(acc), room);
@@ -1677,6 +1711,10 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         const int ai = __builtin_amdgcn_readlane((int)cci[j], first);
         if (lane == 0) {
           a.out_pts[a.out_base + accepted] = make_float2((float)ax, (float)ay);
+          if (a.pub_slots)
+            __hip_atomic_store(&a.pub_slots[a.out_base + accepted],
+                               ((unsigned long long)a.pub_seq << 32) | ((unsigned)ay << 16) | (unsigned)ax,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (a.out_idx) a.out_idx[accepted] = ai;
         }
         accepted++;
@@ -1704,6 +1742,9 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   if (lane == 0) {
     *a.n_out = accepted;
     if (a.n_total) *a.n_total = a.out_base + accepted;
+    if (a.pub_done)
+      __hip_atomic_store(a.pub_done, ((unsigned long long)a.pub_seq << 32) | (unsigned)(a.out_base + accepted),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.host_counts) {
       a.host_counts[0] = accepted;
       a.host_counts[1] = a.out_base + accepted;
