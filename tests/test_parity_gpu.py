@@ -758,3 +758,24 @@ def test_randomized_small_cases(oracle):
                 f = ft.detector.SAEtoTimeSurface_right if cam else ft.detector.SAEtoTimeSurface_left
                 assert np.array_equal(f(ts), det.time_surface(cam, ts)), (case, b, ts)
         ft.close()
+
+
+def test_create_destroy_many_handles():
+    """handles can be created and destroyed repeatedly (streams, events, pinned and device memory are
+    all released) and several can be alive at once"""
+    import torch
+    W, H = 346, 260
+    s = SceneStream(W, H, rate=1e6, seed=1, n_rect=8, size=(25.0, 80.0))
+    L, R, _ = s.next_batch()
+    free0 = None
+    for k in range(25):
+        fts = [FE.FeatureTracker(FE.make_config(W, H, equalize=k % 2, median_blur_kernel_size=k % 3))
+               for _ in range(3)]
+        for ft in fts:
+            ft.trackEvent(event_times(L)[-1], L, R, True)
+            assert len(ft.ids) > 10
+        for ft in fts:
+            ft.close()
+        if k == 2:
+            free0 = torch.cuda.mem_get_info()[0]
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "device memory leaks per handle"
