@@ -168,10 +168,12 @@ struct esvio_fe_ctx {
   // H2D / D2H copy calls on the frame's critical path (each costs more host time than the few
   // hundred bytes take over PCIe).  z_* = device-side addresses of the h_pin / h_spec regions.
   uint8_t *z_res = nullptr, *z_spec = nullptr;
-  float2 *z_ptsA = nullptr, *z_ptsB = nullptr, *z_ptsC = nullptr, *z_new = nullptr, *z_ptsB2 = nullptr,
-         *z_ptsC2 = nullptr;
-  uint8_t *z_stA = nullptr, *z_stB = nullptr, *z_stA2 = nullptr, *z_stB2 = nullptr;
+  // (set 1 — temporal LK, then stereo LK of the survivors — exists twice, see pin_of(); its device
+  // addresses come from zdev())
+  float2 *z_new = nullptr, *z_ptsB2 = nullptr, *z_ptsC2 = nullptr;
+  uint8_t *z_stA2 = nullptr, *z_stB2 = nullptr;
   int* z_counts = nullptr;
+  int res_set = 0;  // which copy of set 1 the current frame works in
   // ---- speculative temporal LK of the next frame (replay mode): once this frame's kept points
   // and new corners are final, next frame's calcOpticalFlowPyrLK(cur -> next) pair is launched on
   // stream3 against the prefetched pyramids, so it overlaps this frame's stereo LK and host tail
@@ -193,7 +195,17 @@ struct esvio_fe_ctx {
     std::vector<int> ids;       // the new corners' ids
     std::vector<P2f> left;      // ... and left positions
   } pend;
-  hipEvent_t ev_lks_done = nullptr, ev_lknew_done = nullptr;
+  // ... and a frame that publishes nothing returns without waiting for its stereo LK at all: the
+  // whole right-camera tail (:475-575) is run by the next call, in the shadow of its own kernels,
+  // or by esvio_fe_finish.  The next frame works in the other copy of set 1 meanwhile.
+  struct PendingRight {
+    bool active = false;
+    int set = 0;                // copy of set 1 that holds this frame's stereo LK results
+    double dt = 0;              // cur_time - prev_time of that frame
+    std::vector<int> ids;       // the frame's ids / left points (no new corners: nothing published)
+    std::vector<P2f> left;
+  } pend_right;
+  hipEvent_t ev_lks_done[2] = {nullptr, nullptr}, ev_lknew_done = nullptr;
   // arc / select
   uint8_t* d_flags = nullptr;
   // per-block ordered candidate lists written by k_arc; two sets so that the Arc* of a prefetched
@@ -737,12 +749,13 @@ std::vector<P2f> undistorted_pts(const std::vector<P2f>& pts, const esvio_fe_cam
 
 // ptsVelocity (:1004-1045) incl. its quirk: with no previous map the result is sized by the LEFT
 // cur_pts whichever camera it is called for.
-std::vector<P2f> pts_velocity_fn(esvio_fe_ctx* c, std::vector<int>& ids, std::vector<P2f>& pts,
-                                 IdMap& cur_id_pts, IdMap& prev_id_pts) {
+// (dt = cur_time - prev_time and the left point count of the frame the call belongs to are passed
+// in: the right-camera tail of a frame may run during the next call, see finalize_right.)
+std::vector<P2f> pts_velocity_fn(std::vector<int>& ids, std::vector<P2f>& pts, IdMap& cur_id_pts,
+                                 IdMap& prev_id_pts, double dt, size_t n_left) {
   std::vector<P2f> vel;
   cur_id_pts.build(ids, pts);
   if (!prev_id_pts.empty()) {
-    const double dt = c->cur_time - c->prev_time;
     vel.reserve(pts.size());
     for (unsigned int i = 0; i < pts.size(); i++) {
       const P2f* prev = ids[i] != -1 ? prev_id_pts.find(ids[i]) : nullptr;
@@ -755,7 +768,7 @@ std::vector<P2f> pts_velocity_fn(esvio_fe_ctx* c, std::vector<int>& ids, std::ve
       }
     }
   } else {
-    for (unsigned int i = 0; i < c->cur_pts.size(); i++) vel.push_back(P2f{0, 0});
+    vel.assign(n_left, P2f{0, 0});
   }
   return vel;
 }
@@ -792,19 +805,21 @@ void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
 // device result block (and its pinned mirror): set 1 = temporal LK, then stereo LK of the temporal
 // survivors; set 2 = stereo LK of the newly selected corners
 struct ResLayout {
-  size_t B1, C1, SA1, SB1, CNT, A, NEW, B2, C2, SA2, SB2, total;
+  size_t B1[2], C1[2], SA1[2], SB1[2], A[2], CNT, NEW, B2, C2, SA2, SB2, total;
 };
 
 ResLayout res_layout(size_t M) {
   const size_t stM = (M + 63) / 64 * 64;
   ResLayout L;
   size_t o = 0;
-  L.B1 = o;  o += M * 8;
-  L.C1 = o;  o += M * 8;
-  L.SA1 = o; o += stM;
-  L.SB1 = o; o += stM;
+  for (int s = 0; s < 2; s++) {
+    L.B1[s] = o;  o += M * 8;
+    L.C1[s] = o;  o += M * 8;
+    L.SA1[s] = o; o += stM;
+    L.SB1[s] = o; o += stM;
+    L.A[s] = o;   o += M * 8;
+  }
   L.CNT = o; o += 64;
-  L.A = o;   o += M * 8;
   L.NEW = o; o += M * 8;
   L.B2 = o;  o += M * 8;
   L.C2 = o;  o += M * 8;
@@ -816,7 +831,7 @@ ResLayout res_layout(size_t M) {
 
 // pinned staging: a mirror of the device result block (D2H) + upload areas (H2D)
 struct Pin {
-  float2 *ptsB, *ptsC;    // set 1
+  float2 *ptsB, *ptsC;    // set 1 (the copy asked for)
   uint8_t *stA, *stB;
   int* counts;            // [16]
   float2* news;           // [kept points (as uploaded) | newly selected corners]
@@ -826,18 +841,18 @@ struct Pin {
   uint32_t* mask;         // H2D H*wpr words
 };
 
-Pin pin_of(esvio_fe_ctx* c) {
+Pin pin_of(esvio_fe_ctx* c, int set = 0) {
   const size_t M = std::max(c->cfg.max_cnt, 1);
   const ResLayout L = res_layout(M);
   Pin p;
   uint8_t* b = c->h_pin;
-  p.ptsB = (float2*)(b + L.B1);
-  p.ptsC = (float2*)(b + L.C1);
-  p.stA = b + L.SA1;
-  p.stB = b + L.SB1;
+  p.ptsB = (float2*)(b + L.B1[set]);
+  p.ptsC = (float2*)(b + L.C1[set]);
+  p.stA = b + L.SA1[set];
+  p.stB = b + L.SB1[set];
   p.counts = (int*)(b + L.CNT);
   p.news = (float2*)(b + L.NEW);
-  p.A = (float2*)(b + L.A);
+  p.A = (float2*)(b + L.A[set]);
   p.ptsB2 = (float2*)(b + L.B2);
   p.ptsC2 = (float2*)(b + L.C2);
   p.stA2 = b + L.SA2;
@@ -845,6 +860,12 @@ Pin pin_of(esvio_fe_ctx* c) {
   b += (L.total + 255) / 256 * 256;
   p.mask = (uint32_t*)b;
   return p;
+}
+
+// device-side address of a location inside the pinned block
+template <typename T>
+T* zdev(esvio_fe_ctx* c, T* host) {
+  return (T*)(c->z_res + ((uint8_t*)host - c->h_pin));
 }
 
 size_t pin_bytes(const esvio_fe_config& cfg) {
@@ -1081,6 +1102,77 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
   return 0;
 }
 
+// The right-camera tail of trackEvent (:475-575) for the first n points of a frame (all of them, or
+// only the kept ones in lazy mode): the stereo LK results of the kept points are in set 1 (by
+// survivor index, src == nullptr: identity), those of the new corners in set 2.  n_left = the
+// frame's left point count (ptsVelocity's sizing quirk).
+void right_tail(esvio_fe_ctx* c, const Pin& pin, const P2f* left, const int* ids, const int* src,
+                int n, int n_kept, double dt, size_t n_left) {
+  const esvio_fe_config& cfg = c->cfg;
+  c->ids_right.clear();
+  c->cur_right_pts.clear();
+  c->cur_un_right_pts.clear();
+  c->right_pts_velocity.clear();
+  c->cur_un_right_pts_map.clear();
+  c->track_cnt_right.clear();
+  if (n_left) {
+    // gather the stereo results: kept points from set 1, new ones from set 2
+    std::vector<uint8_t> status(n), statusRightLeft(n);
+    std::vector<P2f> reverseLeftPts(n);
+    c->cur_right_pts.resize(n);
+    const P2f *B1 = (const P2f*)pin.ptsB, *C1 = (const P2f*)pin.ptsC;
+    const P2f *B2 = (const P2f*)pin.ptsB2, *C2 = (const P2f*)pin.ptsC2;
+    for (int i = 0; i < n; i++) {
+      if (i < n_kept) {
+        const int j = src ? src[i] : i;
+        c->cur_right_pts[i] = B1[j];
+        status[i] = pin.stA[j];
+        reverseLeftPts[i] = C1[j];
+        statusRightLeft[i] = pin.stB[j];
+      } else {
+        const int j = i - n_kept;
+        c->cur_right_pts[i] = B2[j];
+        status[i] = pin.stA2[j];
+        reverseLeftPts[i] = C2[j];
+        statusRightLeft[i] = pin.stB2[j];
+      }
+    }
+    if (cfg.flow_back && !c->cur_right_pts.empty()) {
+      for (int i = 0; i < n; i++) {
+        if (status[i] && statusRightLeft[i] && in_border_event(c, c->cur_right_pts[i]) &&
+            pt_distance(left[i], reverseLeftPts[i]) <= 0.5)
+          status[i] = 1;
+        else
+          status[i] = 0;
+      }
+    }
+    c->ids_right.assign(ids, ids + n);
+    reduce_vector(c->cur_right_pts, status);
+    reduce_vector(c->ids_right, status);
+    c->track_cnt_right.assign(c->cur_right_pts.size(), 1);
+    c->cur_un_right_pts = undistorted_pts(c->cur_right_pts, cfg.cam[1]);
+    c->right_pts_velocity =
+        pts_velocity_fn(c->ids_right, c->cur_un_right_pts, c->cur_un_right_pts_map,
+                        c->prev_un_right_pts_map, dt, n_left);
+  }
+  // reference: prev = cur (copy); cur is cleared before its next use in ptsVelocity, so a swap
+  // is equivalent and avoids re-allocating ~300 map nodes per frame
+  c->prev_un_right_pts_map.swap(c->cur_un_right_pts_map);
+}
+
+// Lazy mode: the right-camera tail of the previous call's frame, which published nothing and
+// returned with its stereo LK still in flight.
+int finalize_right(esvio_fe_ctx* c) {
+  if (!c->pend_right.active) return 0;
+  esvio_fe_ctx::PendingRight& pr = c->pend_right;
+  pr.active = false;
+  const int n = (int)pr.left.size();
+  if (n) HIPCHK(c, sync_event(c->ev_lks_done[pr.set]));
+  if (pin_of(c).counts[3] != 0) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
+  right_tail(c, pin_of(c, pr.set), pr.left.data(), pr.ids.data(), nullptr, n, n, pr.dt, (size_t)n);
+  return 0;
+}
+
 // Lazy mode: append the right-camera entries of the corners the previous published frame detected
 // (their stereo LK has run meanwhile).  Equal to what the eager tail would have produced: the new
 // ids are the largest, come last in every vector, are absent from the previous frame's map (zero
@@ -1122,7 +1214,10 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                      const esvio_fe_motion* motion = nullptr) {
   const esvio_fe_config& cfg = c->cfg;
   const int M = cfg.max_cnt;
-  Pin pin = pin_of(c);
+  // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
+  // (lazy mode, pend_right) while this frame's kernels are enqueued
+  c->res_set ^= 1;
+  Pin pin = pin_of(c, c->res_set);
   c->cur_time = _cur_time;
   using clk = std::chrono::steady_clock;
   auto tp = clk::now();
@@ -1276,10 +1371,10 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       std::memcpy(pin.A, c->prev_pts.data(), (size_t)n * 8);
       // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
       // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
-      LkArgs f = make_lk(prevL, curL, c->z_ptsA, nullptr, c->z_ptsB, c->z_stA, nullptr, n, 3, 30, 0.01, 0);
+      LkArgs f = make_lk(prevL, curL, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n, 3, 30, 0.01, 0);
       LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
                          ESVIO_FE_LK_USE_INITIAL_FLOW);
-      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC, c->z_stB);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
       if (int rc = early_work()) return rc;
       lap(1);
       HIPCHK(c, sync_main(c));
@@ -1339,11 +1434,11 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   }
   if (n_surv) {
     std::memcpy(pin.A, c->cur_pts.data(), (size_t)n_surv * 8);
-    LkArgs f = make_lk(curL, curR, c->z_ptsA, nullptr, c->z_ptsB, c->z_stA, nullptr, n_surv, 3, 30,
+    LkArgs f = make_lk(curL, curR, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n_surv, 3, 30,
                        0.01, 0);
     LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
-    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC, c->z_stB);
-    if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lks_done, cur_stream(c)));
+    run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
+    if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], cur_stream(c)));
   }
   if (defer_early) {
     if (int rc = early_work()) return rc;
@@ -1380,6 +1475,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       // the left-camera bookkeeping below run under the stereo LK of the new corners
       HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
       if (int rc = finalize_pending(c)) return rc;  // (its results live where this launch writes)
+      if (int rc = finalize_right(c)) return rc;    // (idle time: k_select is running)
       // stereo LK of the new corners only (count known on the device)
       LkArgs f = make_lk(curL, curR, c->z_new + n_kept, nullptr, c->z_ptsB2, c->z_stA2, c->d_counts,
                          n_max_cnt, 3, 30, 0.01, 0);
@@ -1412,76 +1508,41 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     }
   }
   c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);  // :470-473
-  c->pts_velocity = pts_velocity_fn(c, c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map);
+  c->pts_velocity = pts_velocity_fn(c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map,
+                                    c->cur_time - c->prev_time, c->cur_pts.size());
   lap(7);
-  if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners)
+  if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners,
+  if (int rc = finalize_right(c)) return rc;    //  or the previous unpublished frame's whole tail)
   const bool lazy = c->lazy_new && detect;      // leave this frame's new corners to the next call
-  if (lazy) {
-    if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done));
+  const bool defer_right = c->lazy_new && !PUB_THIS_FRAME;  // ... or its whole right-camera tail
+  if (defer_right) {
+    // (returns with the stereo LK in flight)
+  } else if (lazy) {
+    if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));
   } else {
     HIPCHK(c, sync_main(c));  // stereo LK results
   }
   lap(6);
-  if ((n_surv || detect) && pin.counts[3] != 0)
+  if (!defer_right && (n_surv || detect) && pin.counts[3] != 0)
     return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
 
-  {  // :475-575
-    c->ids_right.clear();
-    c->cur_right_pts.clear();
-    c->cur_un_right_pts.clear();
-    c->right_pts_velocity.clear();
-    c->cur_un_right_pts_map.clear();
-    c->track_cnt_right.clear();
-    const int n_tail = lazy ? n_kept : (int)c->cur_pts.size();
+  if (defer_right) {
+    // nothing of this frame is published: its right-camera tail waits for the next call
+    c->pend_right.active = true;
+    c->pend_right.set = c->res_set;
+    c->pend_right.dt = c->cur_time - c->prev_time;
+    c->pend_right.ids = c->ids;
+    c->pend_right.left = c->cur_pts;
+  } else {
     if (lazy) {
       c->pend.active = true;
       c->pend.prev_map_was_empty = c->prev_un_right_pts_map.empty();
       c->pend.ids.assign(c->ids.begin() + n_kept, c->ids.end());
       c->pend.left.assign(c->cur_pts.begin() + n_kept, c->cur_pts.end());
     }
-    if (!c->cur_pts.empty()) {
-      const int n = n_tail;
-      // gather the stereo results: kept points from set 1 (by survivor index), new ones from set 2
-      std::vector<uint8_t> status(n), statusRightLeft(n);
-      std::vector<P2f> reverseLeftPts(n);
-      c->cur_right_pts.resize(n);
-      const P2f *B1 = (const P2f*)pin.ptsB, *C1 = (const P2f*)pin.ptsC;
-      const P2f *B2 = (const P2f*)pin.ptsB2, *C2 = (const P2f*)pin.ptsC2;
-      for (int i = 0; i < n; i++) {
-        if (i < n_kept) {
-          const int j = c->src_idx[i];
-          c->cur_right_pts[i] = B1[j];
-          status[i] = pin.stA[j];
-          reverseLeftPts[i] = C1[j];
-          statusRightLeft[i] = pin.stB[j];
-        } else {
-          const int j = i - n_kept;
-          c->cur_right_pts[i] = B2[j];
-          status[i] = pin.stA2[j];
-          reverseLeftPts[i] = C2[j];
-          statusRightLeft[i] = pin.stB2[j];
-        }
-      }
-      if (cfg.flow_back && !c->cur_right_pts.empty()) {
-        for (int i = 0; i < n; i++) {
-          if (status[i] && statusRightLeft[i] && in_border_event(c, c->cur_right_pts[i]) &&
-              pt_distance(c->cur_pts[i], reverseLeftPts[i]) <= 0.5)
-            status[i] = 1;
-          else
-            status[i] = 0;
-        }
-      }
-      c->ids_right.assign(c->ids.begin(), c->ids.begin() + n);
-      reduce_vector(c->cur_right_pts, status);
-      reduce_vector(c->ids_right, status);
-      for (size_t i = 0; i < c->cur_right_pts.size(); i++) c->track_cnt_right.push_back(1);
-      c->cur_un_right_pts = undistorted_pts(c->cur_right_pts, cfg.cam[1]);
-      c->right_pts_velocity = pts_velocity_fn(c, c->ids_right, c->cur_un_right_pts,
-                                              c->cur_un_right_pts_map, c->prev_un_right_pts_map);
-    }
-    // reference: prev = cur (copy); cur is cleared before its next use in ptsVelocity, so a swap
-    // is equivalent and avoids re-allocating ~300 map nodes per frame
-    c->prev_un_right_pts_map.swap(c->cur_un_right_pts_map);
+    right_tail(c, pin, c->cur_pts.data(), c->ids.data(), c->src_idx.data(),
+               lazy ? n_kept : (int)c->cur_pts.size(), n_kept, c->cur_time - c->prev_time,
+               c->cur_pts.size());
   }
   c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left (:585)
   c->prev_pts = c->cur_pts;
@@ -1628,6 +1689,8 @@ int track_image_impl(esvio_fe_ctx* c, double _cur_time, const uint8_t* img_left,
                      const uint8_t* img_right, bool PUB_THIS_FRAME) {
   const esvio_fe_config& cfg = c->cfg;
   const int M = cfg.max_cnt;
+  if (int rc = finalize_pending(c)) return rc;  // (a lazy trackEvent call came before)
+  if (int rc = finalize_right(c)) return rc;
   Pin pin = pin_of(c);
   c->cur_time = _cur_time;
   const bool first = !c->have_img;
@@ -1670,9 +1733,9 @@ int track_image_impl(esvio_fe_ctx* c, double _cur_time, const uint8_t* img_left,
   if (c->prev_pts.size() > 0) {  // :180-209: forward, and backward with maxLevel 3 / no initial flow
     const int n = (int)c->prev_pts.size();
     std::memcpy(pin.A, c->prev_pts.data(), (size_t)n * 8);
-    LkArgs f = make_lk(prevL, L, c->z_ptsA, nullptr, c->z_ptsB, c->z_stA, nullptr, n, 3, 30, 0.01, 0);
+    LkArgs f = make_lk(prevL, L, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n, 3, 30, 0.01, 0);
     LkArgs b = make_lk(L, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 3, 30, 0.01, 0);
-    run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC, c->z_stB);
+    run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
     HIPCHK(c, sync_main(c));
     std::vector<uint8_t> status(pin.stA, pin.stA + n);
     c->cur_pts.resize(n);
@@ -1714,7 +1777,8 @@ int track_image_impl(esvio_fe_ctx* c, double _cur_time, const uint8_t* img_left,
     }
   }
   c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);
-  c->pts_velocity = pts_velocity_fn(c, c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map);
+  c->pts_velocity = pts_velocity_fn(c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map,
+                                    c->cur_time - c->prev_time, c->cur_pts.size());
 
   if (have_right) {  // :249-318
     c->ids_right.clear();
@@ -1726,9 +1790,9 @@ int track_image_impl(esvio_fe_ctx* c, double _cur_time, const uint8_t* img_left,
     if (!c->cur_pts.empty()) {
       const int n = (int)c->cur_pts.size();
       std::memcpy(pin.A, c->cur_pts.data(), (size_t)n * 8);
-      LkArgs f = make_lk(L, R, c->z_ptsA, nullptr, c->z_ptsB, c->z_stA, nullptr, n, 3, 30, 0.01, 0);
+      LkArgs f = make_lk(L, R, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n, 3, 30, 0.01, 0);
       LkArgs b = make_lk(R, L, nullptr, nullptr, nullptr, nullptr, nullptr, n, 3, 30, 0.01, 0);
-      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC, c->z_stB);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
       HIPCHK(c, sync_main(c));
       std::vector<uint8_t> status(pin.stA, pin.stA + n);
       c->cur_right_pts.resize(n);
@@ -1743,8 +1807,9 @@ int track_image_impl(esvio_fe_ctx* c, double _cur_time, const uint8_t* img_left,
       reduce_vector(c->cur_right_pts, status);
       reduce_vector(c->ids_right, status);
       c->cur_un_right_pts = undistorted_pts(c->cur_right_pts, cfg.cam[1]);
-      c->right_pts_velocity = pts_velocity_fn(c, c->ids_right, c->cur_un_right_pts,
-                                              c->cur_un_right_pts_map, c->prev_un_right_pts_map);
+      c->right_pts_velocity =
+          pts_velocity_fn(c->ids_right, c->cur_un_right_pts, c->cur_un_right_pts_map,
+                          c->prev_un_right_pts_map, c->cur_time - c->prev_time, c->cur_pts.size());
     }
     c->prev_un_right_pts_map.swap(c->cur_un_right_pts_map);
   }
@@ -1828,7 +1893,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
   if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
   if (c->ev_sel_host) (void)hipEventDestroy(c->ev_sel_host);
-  if (c->ev_lks_done) (void)hipEventDestroy(c->ev_lks_done);
+  for (hipEvent_t e : c->ev_lks_done)
+    if (e) (void)hipEventDestroy(e);
   if (c->ev_lknew_done) (void)hipEventDestroy(c->ev_lknew_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1885,7 +1951,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_sel_host, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_lks_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_lks_done[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_lks_done[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lknew_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
@@ -1902,12 +1969,12 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     const ResLayout L = res_layout(M);
     c->res_bytes = L.total;
     if ((rc = dev_alloc(c, &c->d_res, c->res_bytes))) return bail(rc);
-    c->d_ptsB = (float2*)(c->d_res + L.B1);
-    c->d_ptsC = (float2*)(c->d_res + L.C1);
-    c->d_stA = c->d_res + L.SA1;
-    c->d_stB = c->d_res + L.SB1;
+    c->d_ptsB = (float2*)(c->d_res + L.B1[0]);
+    c->d_ptsC = (float2*)(c->d_res + L.C1[0]);
+    c->d_stA = c->d_res + L.SA1[0];
+    c->d_stB = c->d_res + L.SB1[0];
     c->d_counts = (int*)(c->d_res + L.CNT);
-    c->d_ptsA = (float2*)(c->d_res + L.A);
+    c->d_ptsA = (float2*)(c->d_res + L.A[0]);
   }
   {
     const size_t stM = (std::max<size_t>(M, 1) + 63) / 64 * 64;
@@ -1944,12 +2011,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   std::memset(c->h_pin, 0, c->h_pin_bytes);
   {
     const ResLayout L = res_layout(std::max<size_t>(M, 1));
-    c->z_ptsB = (float2*)(c->z_res + L.B1);
-    c->z_ptsC = (float2*)(c->z_res + L.C1);
-    c->z_stA = c->z_res + L.SA1;
-    c->z_stB = c->z_res + L.SB1;
     c->z_counts = (int*)(c->z_res + L.CNT);
-    c->z_ptsA = (float2*)(c->z_res + L.A);
     c->z_new = (float2*)(c->z_res + L.NEW);
     c->z_ptsB2 = (float2*)(c->z_res + L.B2);
     c->z_ptsC2 = (float2*)(c->z_res + L.C2);
@@ -1977,6 +2039,7 @@ int esvio_fe_reset(esvio_fe_handle c) {
   c->inflight.clear();
   c->spec_valid = false;
   c->pend.active = false;
+  c->pend_right.active = false;
   HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, cur_stream(c)));
   HIPCHK(c, hipMemsetAsync(c->S2, 0, (size_t)2 * c->P * 16, cur_stream(c)));
   HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
@@ -2351,6 +2414,10 @@ int esvio_fe_track_image(esvio_fe_handle c, double cur_time, const uint8_t* img_
 // id is among them; rows (x_un, y_un, 1, id*2+cam as float32, u, v, vx, vy); padding rows id -1.
 int esvio_fe_pack_track_records(esvio_fe_handle c, float* out, int32_t* n_rows) {
   if (!c || !out) return ESVIO_FE_EINVAL;
+  if (c->pend_right.active) {  // (lazy mode, packing a frame that was not to be published)
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (int rc = finalize_right(c)) return rc;
+  }
   const int rows = 2 * std::max(c->cfg.max_cnt, 1);
   int k = 0;
   std::vector<int> left_ids;
@@ -2394,6 +2461,7 @@ int esvio_fe_set_lazy_new_stereo(esvio_fe_handle c, int on) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   if (int rc = finalize_pending(c)) return rc;
+  if (int rc = finalize_right(c)) return rc;
   c->lazy_new = on != 0;
   return 0;
 }
@@ -2402,6 +2470,7 @@ int esvio_fe_finish(esvio_fe_handle c, esvio_fe_tracks* out) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   if (int rc = finalize_pending(c)) return rc;
+  if (int rc = finalize_right(c)) return rc;
   return fill_tracks(c, out);
 }
 

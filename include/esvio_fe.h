@@ -238,7 +238,11 @@ int esvio_fe_pack_track_records(esvio_fe_handle h, float* out, int32_t* n_rows);
  * (the node's PointCloud never contains corners of track_cnt 1, node:289); the right-camera entries
  * of those new corners (ids_right / cur_right_pts / cur_un_right_pts / right_pts_velocity tails) are
  * appended at the start of the next call's right-camera bookkeeping — before they can influence
- * anything — or by esvio_fe_finish, after which the state is bit-identical to the eager sequence. */
+ * anything — or by esvio_fe_finish, after which the state is bit-identical to the eager sequence.
+ * A call with pub_this_frame == 0 (the node publishes nothing of it, stereo_event_tracker_node.cpp
+ * :262) returns without waiting for its stereo LK at all: its left-camera members are complete, its
+ * right-camera members (feature_tracker.cpp:475-575) still show the previous frame until the next
+ * call, esvio_fe_finish or esvio_fe_pack_track_records completes them, again bit-identically. */
 int esvio_fe_set_lazy_new_stereo(esvio_fe_handle h, int on);
 /* complete a lazily returned frame (no-op otherwise) and copy the result members into `out` */
 int esvio_fe_finish(esvio_fe_handle h, esvio_fe_tracks* out);
