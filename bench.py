@@ -79,6 +79,9 @@ def parse():
                     help="wait for the stereo LK of newly detected corners inside the call that detects "
                          "them (default in replay mode: their right-camera entries are completed by "
                          "the next call; the published PointCloud rows never contain them)")
+    ap.add_argument("--host-threads", type=int, default=6,
+                    help="host threads of rejectWithF_event's RANSAC (esvio_fe_set_host_threads; "
+                         "the result does not depend on it); 1 = the calling thread only")
     ap.add_argument("--split", choices=["rigs", "camera"], default="rigs",
                     help="N>1 sharding: one independent stereo rig per GPU (weak scaling, default) or "
                          "BASELINE C4: left/right cameras of ONE rig on 2 GPUs")
@@ -216,6 +219,8 @@ def main():
     lazy = pipeline and not args.no_lazy
     if lazy:
         ft.set_lazy_new_stereo(True)
+    if args.host_threads > 1:
+        ft.set_host_threads(args.host_threads)
 
     def step(i, exchange=True):
         tl, tr, nl, nr, t_last = dev_batches[i]
@@ -356,6 +361,7 @@ def main():
                 "tracks_last_frame": n_tracks,
                 "pipelined_next_batch": bool(pipeline),
                 "lazy_new_corner_stereo": bool(lazy),
+                "host_threads": int(max(1, args.host_threads)),
             },
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -119,6 +119,9 @@ struct esvio_fe_ctx {
   hipStream_t stream = nullptr;   // main stream
   hipStream_t stream2 = nullptr;  // prefetch stream (next batch's SAE update / images)
   hipStream_t stream3 = nullptr;  // speculative temporal LK of the next frame
+  // stereo LK of the temporal survivors: nothing on the frame's chain reads its results before the
+  // right-camera tail, and on the main stream it would hold up the corner selection behind it
+  hipStream_t stream4 = nullptr;
   hipEvent_t ev_planes_free = nullptr;
   hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr, ev_sel_host = nullptr;
   std::string err;
@@ -174,6 +177,7 @@ struct esvio_fe_ctx {
   uint8_t *z_stA2 = nullptr, *z_stB2 = nullptr;
   int* z_counts = nullptr;
   int res_set = 0;  // which copy of set 1 the current frame works in
+  int lks_last = -1;  // copy the latest stereo LK launch (stream4) writes to, -1: none so far
   // ---- speculative temporal LK of the next frame (replay mode): once this frame's kept points
   // and new corners are final, next frame's calcOpticalFlowPyrLK(cur -> next) pair is launched on
   // stream3 against the prefetched pyramids, so it overlaps this frame's stereo LK and host tail
@@ -206,6 +210,7 @@ struct esvio_fe_ctx {
     std::vector<P2f> left;
   } pend_right;
   hipEvent_t ev_lks_done[2] = {nullptr, nullptr}, ev_lknew_done = nullptr;
+  host::RansacPool* pool = nullptr;  // esvio_fe_set_host_threads
   // arc / select
   uint8_t* d_flags = nullptr;
   // per-block ordered candidate lists written by k_arc; two sets so that the Arc* of a prefetched
@@ -244,6 +249,7 @@ struct esvio_fe_ctx {
   double phase_ms[2][8] = {};  // [published?][phase]
   uint64_t phase_count[2] = {0, 0};
   uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
+  double tr_fm_ms = 0;  // time inside find_fundamental_mat alone
 
   // ---- profiling
   bool prof_on = false;
@@ -792,8 +798,11 @@ void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
       un_cur[2 * i + 1] = (float)(FOCAL * ly[i] / 1.0 + cy);
     }
     std::vector<uint8_t> status(c->cur_pts.size());
+    const auto t0 = std::chrono::steady_clock::now();
     host::find_fundamental_mat(un_prev.data(), un_cur.data(), (int)c->cur_pts.size(),
-                               c->cfg.f_threshold, 0.99, status.data());
+                               c->cfg.f_threshold, 0.99, status.data(), c->pool);
+    if (c->trace)
+      c->tr_fm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     reduce_vector(c->prev_pts, status);
     reduce_vector(c->cur_pts, status);
     reduce_vector(c->ids, status);
@@ -1037,6 +1046,13 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
         break;
       }
       wait_planes = false;  // later batches simply follow on the same stream
+      // the right-camera pyramid slot this batch gets may be the one an earlier frame's stereo LK
+      // (stream4) still reads — in lazy mode nobody has waited for that launch yet
+      if (c->lks_last >= 0 &&
+          hipStreamWaitEvent(c->stream2, c->ev_lks_done[c->lks_last], 0) != hipSuccess) {
+        rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
+        break;
+      }
       if ((rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &b.dL, &b.dR, b.lane))) break;
       if ((rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR))) break;
       render_lk_images(c, b.time, 3, b.slotL, b.slotR, b.raw);
@@ -1218,6 +1234,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   // (lazy mode, pend_right) while this frame's kernels are enqueued
   c->res_set ^= 1;
   Pin pin = pin_of(c, c->res_set);
+  if (PUB_THIS_FRAME && c->pool) host::ransac_pool_wake(c->pool);
   c->cur_time = _cur_time;
   using clk = std::chrono::steady_clock;
   auto tp = clk::now();
@@ -1437,8 +1454,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     LkArgs f = make_lk(curL, curR, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n_surv, 3, 30,
                        0.01, 0);
     LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
-    run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
-    if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], cur_stream(c)));
+    {
+      // on its own stream.  Its inputs are complete without a device-side wait: the host has just
+      // read this frame's temporal LK results, and that launch ran behind the frame's pyramids.
+      StreamScope on_stereo_stream(c->stream4);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
+      HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], c->stream4));
+    }
+    c->lks_last = c->res_set;
   }
   if (defer_early) {
     if (int rc = early_work()) return rc;
@@ -1517,10 +1540,9 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   const bool defer_right = c->lazy_new && !PUB_THIS_FRAME;  // ... or its whole right-camera tail
   if (defer_right) {
     // (returns with the stereo LK in flight)
-  } else if (lazy) {
-    if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));
   } else {
-    HIPCHK(c, sync_main(c));  // stereo LK results
+    if (!lazy) HIPCHK(c, sync_main(c));  // stereo LK results of the new corners
+    if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));  // ... of the kept points
   }
   lap(6);
   if (!defer_right && (n_surv || detect) && pin.counts[3] != 0)
@@ -1834,8 +1856,11 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   (void)hipSetDevice(c->dev);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+  if (c->stream4) (void)hipStreamSynchronize(c->stream4);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  host::ransac_pool_destroy(c->pool);
+  c->pool = nullptr;
   if (c->trace && c->phase_frames) {
     static const char* nm[8] = {"enqueue sae+ts+pyr", "enqueue temporal LK", "sync A", "host filter",
                                 "host ransac", "host mask + enqueue detect/stereo", "sync B", "host tail"};
@@ -1851,6 +1876,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
       fprintf(stderr, " | total=%.3f\n", tot);
     }
     fprintf(stderr, "[esvio_fe trace]");
+    fprintf(stderr, "\n[esvio_fe trace] findFundamentalMat alone: %.3f ms per published frame",
+            c->phase_count[1] ? c->tr_fm_ms / c->phase_count[1] : 0.0);
     fprintf(stderr, "\n[esvio_fe trace] survivors/frame=%.1f; detect frames=%llu: candidates/frame=%.0f new/frame=%.1f\n",
             (double)c->tr_surv / c->phase_frames, (unsigned long long)c->tr_detect,
             c->tr_detect ? (double)c->tr_cand / c->tr_detect : 0.0,
@@ -1880,6 +1907,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_spec) (void)hipHostFree(c->h_spec);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  if (c->stream4) (void)hipStreamDestroy(c->stream4);
   for (auto& r : c->pending) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
@@ -1946,7 +1974,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   const bool streams_ok =
       hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
-      hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+      hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+      hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_least) == hipSuccess;
   if (!streams_ok ||
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
@@ -2034,6 +2063,7 @@ int esvio_fe_reset(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   HIPCHK(c, hipStreamSynchronize(c->stream3));
+  HIPCHK(c, hipStreamSynchronize(c->stream4));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   c->announced.clear();
   c->inflight.clear();
@@ -2302,6 +2332,16 @@ int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, doubl
   return 0;
 }
 
+int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, double thr, double conf,
+                                     int threads, uint8_t* status, int32_t* n_inliers) {
+  if (n < 0 || (n && (!p1 || !p2 || !status)) || threads < 1 || threads > 16) return ESVIO_FE_EINVAL;
+  host::RansacPool* pool = host::ransac_pool_create(threads - 1);
+  const int k = host::find_fundamental_mat(p1, p2, n, thr, conf, status, pool);
+  host::ransac_pool_destroy(pool);
+  if (n_inliers) *n_inliers = k;
+  return 0;
+}
+
 int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, double* out3) {
   if (!cam || !out3) return ESVIO_FE_EINVAL;
   host::lift_projective(*cam, u, v, out3);
@@ -2463,6 +2503,13 @@ int esvio_fe_set_lazy_new_stereo(esvio_fe_handle c, int on) {
   if (int rc = finalize_pending(c)) return rc;
   if (int rc = finalize_right(c)) return rc;
   c->lazy_new = on != 0;
+  return 0;
+}
+
+int esvio_fe_set_host_threads(esvio_fe_handle c, int threads) {
+  if (!c || threads < 1 || threads > 16) return ESVIO_FE_EINVAL;
+  host::ransac_pool_destroy(c->pool);
+  c->pool = host::ransac_pool_create(threads - 1);
   return 0;
 }
 

@@ -6,7 +6,21 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 // The per-point loops below are written over plain arrays so that the compiler vectorises them;
 // an AVX2 clone is selected at load time where the CPU has it.  Every element still goes through
@@ -464,9 +478,286 @@ int mark_inliers_bounded(const double* x1, const double* y1, const double* x2, c
 
 }  // namespace
 
+// ---------------------------------------------------------------------------- helper threads
+// The RANSAC loop is ~100-350 iterations of (draw 7 points, 7-point solver, score <= 3 models);
+// only the draws (the cv::RNG sequence) and the "is this model better than the best so far"
+// bookkeeping are sequential.  With a pool the calling thread draws the subsets in order and
+// replays the results in order — so best model, inlier flags and iteration count are those of the
+// sequential loop, bit for bit — while helper threads solve and score the iterations in between.
+// The helpers spin while a tracker is busy (a futex wake-up costs more than the whole job) and go
+// to sleep after kIdleSpinUs without work.
+namespace {
+constexpr int kRansacMaxIters = 1000;
+constexpr int kRansacWindow = 48;      // iterations drawn ahead of the replay position
+constexpr int kIdleSpinUs = 2000;
+
+inline void cpu_relax() {
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+  __builtin_ia32_pause();
+#endif
+}
+
+struct IterResult {
+  int nm;
+  int good[3];
+  double models[27];
+};
+}  // namespace
+
+struct RansacPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t wake_seq = 0;  // (under mu)
+  std::atomic<int> sleepers{0};
+  std::atomic<bool> quit{false};
+  // ---- the open job
+  alignas(64) std::atomic<uint32_t> epoch{0};  // odd while a job is open
+  alignas(64) std::atomic<int> next{0};        // next iteration to hand out
+  alignas(64) std::atomic<int> avail{0};       // subsets drawn so far
+  alignas(64) std::atomic<int> bound{0};       // best inlier count among the replayed iterations
+  alignas(64) std::atomic<int> stop{0};
+  alignas(64) std::atomic<int> active{0};      // helpers inside the job
+  const double *x1 = nullptr, *y1 = nullptr, *x2 = nullptr, *y2 = nullptr;
+  int count = 0;
+  double thr = 0;
+  std::vector<float> subsets;  // [iteration][s1(14) | s2(14)]
+  std::vector<IterResult> res;
+  std::unique_ptr<std::atomic<uint8_t>[]> ready;
+  int used = 0;  // ready[] entries to clear before the next job
+  // helpers are kept on the cores that share the caller's L3 (one CCD): an iteration is ~0.5 us of
+  // work, so the hand-over has to cost a same-die cache line transfer, not a cross-socket one
+  std::vector<int> near_cpus;  // the caller's L3 domain minus the caller's own core (empty: unknown)
+  int near_of = -1;            // the CPU that set was made for
+
+  void pin_near_caller();
+
+  void evaluate(int idx, std::vector<uint8_t>& scratch) {
+    IterResult& r = res[idx];
+    const float* s = &subsets[(size_t)idx * 28];
+    r.nm = seven_point(s, s + 14, r.models);
+    const int need = bound.load(std::memory_order_relaxed);
+    if ((int)scratch.size() < count) scratch.resize(count);
+    for (int k = 0; k < r.nm; k++)
+      r.good[k] = mark_inliers_bounded(x1, y1, x2, y2, count, r.models + 9 * k, scratch.data(), thr, need);
+    ready[idx].store(1, std::memory_order_release);
+  }
+
+  void helper() {
+    std::vector<uint8_t> scratch;
+    uint32_t seen = 0;
+    auto idle_since = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+      if (quit.load(std::memory_order_acquire)) return;
+      const uint32_t e = epoch.load(std::memory_order_acquire);
+      if (!(e & 1) || e == seen) {
+        cpu_relax();
+        if ((++spins & 1023) == 0 &&
+            std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(kIdleSpinUs)) {
+          std::unique_lock<std::mutex> lk(mu);
+          const uint64_t my = wake_seq;
+          sleepers.fetch_add(1, std::memory_order_acq_rel);
+          cv.wait(lk, [&] { return wake_seq != my || quit.load(std::memory_order_acquire); });
+          sleepers.fetch_sub(1, std::memory_order_acq_rel);
+          idle_since = std::chrono::steady_clock::now();
+        }
+        continue;
+      }
+      active.fetch_add(1, std::memory_order_acq_rel);
+      if (epoch.load(std::memory_order_acquire) == e) {
+        while (!stop.load(std::memory_order_acquire)) {
+          const int idx = next.fetch_add(1, std::memory_order_relaxed);
+          if (idx >= kRansacMaxIters) break;
+          bool go = true;
+          while (avail.load(std::memory_order_acquire) <= idx) {
+            if (stop.load(std::memory_order_acquire)) {
+              go = false;
+              break;
+            }
+            cpu_relax();
+          }
+          if (!go) break;
+          evaluate(idx, scratch);
+        }
+      }
+      active.fetch_sub(1, std::memory_order_release);
+      seen = e;
+      idle_since = std::chrono::steady_clock::now();
+    }
+  }
+};
+
+namespace {
+// "0-7,128-135" -> cpu numbers
+std::vector<int> read_cpu_list(const char* path) {
+  std::vector<int> out;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return out;
+  char buf[512];
+  if (std::fgets(buf, sizeof buf, f)) {
+    const char* p = buf;
+    while (*p) {
+      char* e;
+      const long a = std::strtol(p, &e, 10);
+      if (e == p) break;
+      long b = a;
+      p = e;
+      if (*p == '-') {
+        b = std::strtol(p + 1, &e, 10);
+        p = e;
+      }
+      for (long v = a; v <= b && out.size() < 1024; v++) out.push_back((int)v);
+      if (*p == ',') p++;
+    }
+  }
+  std::fclose(f);
+  return out;
+}
+}  // namespace
+
+void RansacPool::pin_near_caller() {
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+  const int cpu = sched_getcpu();
+  if (cpu < 0) return;
+  if (near_of >= 0) {
+    if (cpu == near_of) return;
+    for (int v : near_cpus)
+      if (v == cpu) return;  // (moved within the die: the SMT sibling, or a helper's core — fine)
+  }
+  char path[128];
+  std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  std::vector<int> l3 = read_cpu_list(path);
+  std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+  const std::vector<int> self = read_cpu_list(path);
+  near_of = cpu;
+  near_cpus.clear();
+  for (int v : l3) {
+    bool mine = v == cpu;
+    for (int w : self) mine = mine || v == w;
+    if (!mine) near_cpus.push_back(v);
+  }
+  if (near_cpus.size() < th.size()) {  // unknown topology or a tiny L3 domain: leave it to the OS
+    near_cpus.clear();
+    return;
+  }
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int v : near_cpus)
+    if (v < CPU_SETSIZE) CPU_SET(v, &set);
+  for (auto& t : th) (void)pthread_setaffinity_np(t.native_handle(), sizeof set, &set);
+#endif
+}
+
+RansacPool* ransac_pool_create(int helpers) {
+  if (helpers <= 0) return nullptr;
+  RansacPool* p = new RansacPool();
+  p->subsets.resize((size_t)kRansacMaxIters * 28);
+  p->res.resize(kRansacMaxIters);
+  p->ready.reset(new std::atomic<uint8_t>[kRansacMaxIters]);
+  for (int i = 0; i < kRansacMaxIters; i++) p->ready[i].store(0, std::memory_order_relaxed);
+  for (int i = 0; i < helpers; i++) p->th.emplace_back([p] { p->helper(); });
+  p->pin_near_caller();
+  return p;
+}
+
+void ransac_pool_wake(RansacPool* p) {
+  if (!p) return;
+  p->pin_near_caller();  // (a vDSO call unless the calling thread has moved to another die)
+  if (p->sleepers.load(std::memory_order_acquire) == 0) return;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->wake_seq++;
+  }
+  p->cv.notify_all();
+}
+
+void ransac_pool_destroy(RansacPool* p) {
+  if (!p) return;
+  p->quit.store(true, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->wake_seq++;
+  }
+  p->cv.notify_all();
+  for (auto& t : p->th) t.join();
+  delete p;
+}
+
+namespace {
+// the RANSAC loop of find_fundamental_mat with helpers (count >= 15)
+int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, double thr, double conf,
+                  const double* xy, uint8_t* status) {
+  const int kModelPoints = 7;
+  for (int i = 0; i < P->used; i++) P->ready[i].store(0, std::memory_order_relaxed);
+  P->used = 0;
+  P->x1 = xy;
+  P->y1 = xy + count;
+  P->x2 = xy + 2 * (size_t)count;
+  P->y2 = xy + 3 * (size_t)count;
+  P->count = count;
+  P->thr = thr;
+  P->next.store(0, std::memory_order_relaxed);
+  P->avail.store(0, std::memory_order_relaxed);
+  P->bound.store(kModelPoints - 1, std::memory_order_relaxed);
+  P->stop.store(0, std::memory_order_relaxed);
+  P->epoch.fetch_add(1, std::memory_order_release);  // -> odd: open
+  ransac_pool_wake(P);
+
+  OcvRng rng;
+  std::vector<uint8_t> scratch(count);
+  int drawn = 0, rp = 0, niters = kRansacMaxIters, best_good = 0, best_iter = -1, best_k = 0;
+  bool draw_failed = false;
+  for (;;) {
+    // replay, in iteration order, what has been evaluated
+    while (rp < niters && rp < drawn && P->ready[rp].load(std::memory_order_acquire)) {
+      const IterResult& r = P->res[rp];
+      for (int k = 0; k < r.nm; k++)
+        if (r.good[k] > std::max(best_good, kModelPoints - 1)) {
+          best_good = r.good[k];
+          best_iter = rp;
+          best_k = k;
+          niters = update_num_iters(conf, (double)(count - best_good) / count, kModelPoints, niters);
+        }
+      rp++;
+      P->bound.store(std::max(best_good, kModelPoints - 1), std::memory_order_relaxed);
+    }
+    if (rp >= niters || (draw_failed && rp >= drawn)) break;
+    if (!draw_failed && drawn < niters && drawn - rp < kRansacWindow) {
+      for (int j = 0; j < 4 && drawn < niters; j++) {
+        float* s = &P->subsets[(size_t)drawn * 28];
+        if (!draw_subset(m1, m2, count, s, s + 14, rng, 10000)) {
+          draw_failed = true;
+          break;
+        }
+        drawn++;
+      }
+      P->avail.store(drawn, std::memory_order_release);
+      continue;
+    }
+    // nothing to draw: take an iteration like a helper does
+    int idx = P->next.load(std::memory_order_relaxed);
+    if (idx < drawn && P->next.compare_exchange_strong(idx, idx + 1, std::memory_order_relaxed))
+      P->evaluate(idx, scratch);
+    else
+      cpu_relax();
+  }
+  P->used = std::min(kRansacMaxIters, std::max(drawn, P->next.load(std::memory_order_relaxed)));
+  P->stop.store(1, std::memory_order_release);
+  P->epoch.fetch_add(1, std::memory_order_release);  // -> even: closed
+  while (P->active.load(std::memory_order_acquire) != 0) cpu_relax();
+  if (drawn == 0) return 0;  // (the very first draw failed)
+  if (best_iter >= 0) {
+    const float t = (float)(thr * thr);
+    score_block(P->x1, P->y1, P->x2, P->y2, 0, count, P->res[best_iter].models + 9 * best_k, t, status);
+  }
+  return best_good;
+}
+}  // namespace
+
 int find_fundamental_mat(const float* m1, const float* m2, int count, double thr, double conf,
-                         uint8_t* status) {
-  const int kModelPoints = 7, kMaxIters = 1000;
+                         uint8_t* status, RansacPool* pool) {
+  const int kModelPoints = 7, kMaxIters = kRansacMaxIters;
   std::fill(status, status + count, (uint8_t)0);
   if (count < 7) return 0;
   if (thr <= 0) thr = 3;
@@ -490,6 +781,7 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
       x2[i] = m2[2 * i];
       y2[i] = m2[2 * i + 1];
     }
+    if (pool) return ransac_pooled(pool, m1, m2, count, thr, conf, xy.data(), status);
     int niters = kMaxIters, best_good = 0;
     for (int iter = 0; iter < niters; iter++) {
       if (!draw_subset(m1, m2, count, s1, s2, rng, 10000)) {

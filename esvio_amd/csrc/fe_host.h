@@ -36,8 +36,14 @@ struct BitMask {
 // cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, conf, status) [OpenCV calib3d fundam.cpp +
 // ptsetreg.cpp]: 7-point minimal solver, RANSAC for n >= 15, LMedS for 8..14, cv::RNG sequence.
 // Returns the number of inliers; status has n entries.
+// With a pool (helper threads, see fe_host.cpp) the RANSAC iterations are solved and scored in
+// parallel; the outcome is that of the sequential loop, bit for bit.
+struct RansacPool;
+RansacPool* ransac_pool_create(int helpers);
+void ransac_pool_destroy(RansacPool* p);
+void ransac_pool_wake(RansacPool* p);  // a job is coming: helpers that went to sleep start spinning
 int find_fundamental_mat(const float* p1, const float* p2, int n, double thr, double conf,
-                         uint8_t* status);
+                         uint8_t* status, RansacPool* pool = nullptr);
 
 }  // namespace host
 }  // namespace esvio

@@ -81,6 +81,7 @@ ABI_SYMBOLS = [
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
     "esvio_fe_set_next_batch", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
+    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
@@ -134,6 +135,8 @@ def load_library(build_if_missing=True):
     L.esvio_fe_track_image.argtypes = [vp, d, vp, vp, i, vp]
     L.esvio_fe_pack_track_records.argtypes = [vp, vp, vp]
     L.esvio_fe_set_lazy_new_stereo.argtypes = [vp, i]
+    L.esvio_fe_set_host_threads.argtypes = [vp, i]
+    L.esvio_fe_find_fundamental_mat_mt.argtypes = [vp, vp, i, d, d, i, vp, C.POINTER(C.c_int32)]
     L.esvio_fe_finish.argtypes = [vp, vp]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
     L.esvio_fe_export_image.argtypes = [vp, i, vp, i]
@@ -371,6 +374,10 @@ class FeatureTracker:
         just detected; finish() (or the next call) completes the right-camera vectors"""
         self._hd.check(self._hd.L.esvio_fe_set_lazy_new_stereo(self._hd.h, int(bool(on))))
 
+    def set_host_threads(self, threads):
+        """host threads for rejectWithF_event's RANSAC (results do not depend on the count)"""
+        self._hd.check(self._hd.L.esvio_fe_set_host_threads(self._hd.h, int(threads)))
+
     def finish(self, copy=True):
         """complete a lazily returned frame and refresh the result members"""
         self._hd.check(self._hd.L.esvio_fe_finish(self._hd.h, C.byref(self._tr)))
@@ -491,7 +498,7 @@ class FeatureTracker:
         return self._hd.L.esvio_fe_stream(self._hd.h)
 
 
-def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99):
+def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99, threads=1):
     """cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, conf, status) (host-side stage)."""
     L = load_library()
     p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
@@ -499,7 +506,11 @@ def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99):
     n = p1.shape[0]
     status = np.zeros(n, np.uint8)
     k = C.c_int32(0)
-    rc = L.esvio_fe_find_fundamental_mat(_p(p1), _p(p2), n, thr, conf, _p(status), C.byref(k))
+    if threads > 1:
+        rc = L.esvio_fe_find_fundamental_mat_mt(_p(p1), _p(p2), n, thr, conf, threads, _p(status),
+                                                C.byref(k))
+    else:
+        rc = L.esvio_fe_find_fundamental_mat(_p(p1), _p(p2), n, thr, conf, _p(status), C.byref(k))
     if rc:
         raise FrontendError("find_fundamental_mat rc=%d" % rc)
     return k.value, status

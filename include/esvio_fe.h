@@ -151,6 +151,10 @@ int esvio_fe_build_pyramid(esvio_fe_handle h, const uint8_t* img, int w, int hgt
  * (feature_tracker.cpp:935); host-side. Returns the inlier count in *n_inliers. */
 int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, double thr,
                                   double conf, uint8_t* status, int32_t* n_inliers);
+/* The same with `threads` - 1 helper threads solving / scoring the RANSAC iterations (a temporary
+ * pool; test tap for esvio_fe_set_host_threads): status and count are those of the call above. */
+int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, double thr,
+                                     double conf, int threads, uint8_t* status, int32_t* n_inliers);
 /* camodocal PinholeCamera::liftProjective (PinholeCamera.cc:450-510); host-side. */
 int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, double* out3);
 
@@ -244,6 +248,13 @@ int esvio_fe_pack_track_records(esvio_fe_handle h, float* out, int32_t* n_rows);
  * right-camera members (feature_tracker.cpp:475-575) still show the previous frame until the next
  * call, esvio_fe_finish or esvio_fe_pack_track_records completes them, again bit-identically. */
 int esvio_fe_set_lazy_new_stereo(esvio_fe_handle h, int on);
+/* Throughput option: rejectWithF_event's RANSAC (feature_tracker.cpp:935, ~100-350 iterations of
+ * the 7-point solver per published frame, on the frame's critical path) uses `threads` host threads
+ * (1 = the calling thread only, the default; at most 16).  The helpers only solve and score
+ * iterations; the cv::RNG draws and the best-model bookkeeping stay sequential on the calling
+ * thread, so the result is bit-identical for any thread count.  Helpers spin while frames keep
+ * coming and sleep after 2 ms without work. */
+int esvio_fe_set_host_threads(esvio_fe_handle h, int threads);
 /* complete a lazily returned frame (no-op otherwise) and copy the result members into `out` */
 int esvio_fe_finish(esvio_fe_handle h, esvio_fe_tracks* out);
 

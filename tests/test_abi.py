@@ -99,3 +99,33 @@ def test_host_ransac_matches_oracle(oracle):
         cnt_p, st_p = FE.find_fundamental_mat(p1, p2, 1.0, 0.99)
         assert cnt_o == cnt_p and np.array_equal(st_o, st_p), (trial, n)
     assert FE.find_fundamental_mat(p1[:5], p2[:5])[0] == 0
+
+
+@pytest.mark.parametrize("threads", [2, 4])
+def test_host_ransac_with_helper_threads_is_bit_identical(oracle, threads):
+    """esvio_fe_set_host_threads' RANSAC (helpers solve/score iterations, the caller draws and
+    replays in order) gives the sequential loop's inlier flags whatever the interleaving: many
+    outlier ratios (10..1000 iterations), degenerate inputs, sizes around the RANSAC/LMedS switch"""
+    rng = np.random.default_rng(17 + threads)
+    K = np.array([[460, 0, 320], [0, 460, 240], [0, 0, 1.0]])
+    for trial in range(120):
+        n = int(rng.integers(15, 320)) if trial % 10 else int(rng.integers(7, 17))
+        X = rng.uniform(-1, 1, (n, 3)) * np.array([2, 1.5, 1]) + np.array([0, 0, 4.0])
+        t = rng.normal(0, 0.05, 3)
+        x = (K @ (X + t).T).T
+        p1 = (K @ X.T).T
+        p1 = (p1[:, :2] / p1[:, 2:]).astype(np.float32)
+        p2 = (x[:, :2] / x[:, 2:]).astype(np.float32) + rng.normal(0, 0.05, (n, 2)).astype(np.float32)
+        k = int(rng.uniform(0.0, 0.6) * n)
+        p2[:k] += rng.normal(0, 8, (k, 2)).astype(np.float32)
+        if trial % 17 == 3:
+            p2[:] = p1  # no motion at all
+        if trial % 17 == 5:
+            p1[:, 1] = 100.0  # every point on one line: no subset passes the collinearity check
+            p2[:, 1] = 100.0
+        cnt_1, st_1 = FE.find_fundamental_mat(p1, p2, 1.0, 0.99)
+        cnt_t, st_t = FE.find_fundamental_mat(p1, p2, 1.0, 0.99, threads=threads)
+        assert cnt_1 == cnt_t and np.array_equal(st_1, st_t), (trial, n)
+        if trial % 4 == 0:
+            cnt_o, st_o, _ = oracle.find_fundamental(p1, p2, 1.0, 0.99)
+            assert cnt_o == cnt_t and np.array_equal(st_o, st_t), (trial, n)

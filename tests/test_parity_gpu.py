@@ -601,8 +601,8 @@ def test_median_blur_kernel_size(oracle, k):
     ft2.close()
 
 
-@pytest.mark.parametrize("lazy", [0, 1])
-def test_replay_mode_soak(oracle, lazy):
+@pytest.mark.parametrize("lazy,threads", [(0, 1), (1, 1), (1, 4)])
+def test_replay_mode_soak(oracle, lazy, threads):
     """60 frames with two batches announced ahead, irregular publish pattern, event rate changing
     from batch to batch (buffers regrow, speculative temporal LK sizes change), an empty right batch
     now and then: every frame bit-identical to the sequential oracle"""
@@ -621,6 +621,7 @@ def test_replay_mode_soak(oracle, lazy):
     kw = dict(max_cnt=120, min_dist=10, f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     ft.set_lazy_new_stereo(bool(lazy))
+    ft.set_host_threads(threads)  # (RANSAC helpers: no effect on any result)
     tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
     from esvio_amd.node import pack_track_records
     announced = 0
