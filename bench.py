@@ -79,6 +79,8 @@ def parse():
                     help="wait for the stereo LK of newly detected corners inside the call that detects "
                          "them (default in replay mode: their right-camera entries are completed by "
                          "the next call; the published PointCloud rows never contain them)")
+    ap.add_argument("--ahead", type=int, default=3, choices=[1, 2, 3],
+                    help="batches announced ahead in replay mode (esvio_fe_set_next_batch)")
     ap.add_argument("--host-threads", type=int, default=6,
                     help="host threads of rejectWithF_event's RANSAC (esvio_fe_set_host_threads; "
                          "the result does not depend on it); 1 = the calling thread only")
@@ -230,8 +232,8 @@ def main():
             if pub and exchange:
                 exch.submit_tracker(ft, async_op=True)
             return nl if rank == 0 else nr
-        if pipeline:  # replay mode: the next batches are already in HBM; announce two ahead
-            while announced[0] < min(i + 2, len(dev_batches) - 1):
+        if pipeline:  # replay mode: the next batches are already in HBM; announce them ahead
+            while announced[0] < min(i + args.ahead, len(dev_batches) - 1):
                 k = announced[0] = announced[0] + 1
                 tl2, tr2, nl2, nr2, t2 = dev_batches[k]
                 ft.set_next_batch(t2, (tl2.data_ptr(), nl2), (tr2.data_ptr(), nr2), pub_plan(k))
@@ -362,6 +364,7 @@ def main():
                 "pipelined_next_batch": bool(pipeline),
                 "lazy_new_corner_stereo": bool(lazy),
                 "host_threads": int(max(1, args.host_threads)),
+                "batches_announced_ahead": int(args.ahead) if pipeline else 0,
             },
             "roofline": roof,
             "cpu_baseline": cpu,

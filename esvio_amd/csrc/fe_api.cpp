@@ -100,7 +100,7 @@ struct Inflight : Batch {
   const EventRec *dL = nullptr, *dR = nullptr;
   bool arc_done = false;
 };
-constexpr int kPrefetchDepth = 2;
+constexpr int kPrefetchDepth = 3;
 constexpr int kLeftSlots = 2 + kPrefetchDepth;   // prev, cur, prefetched...
 constexpr int kRightSlots = 1 + kPrefetchDepth;  // cur, prefetched...
 
@@ -185,6 +185,21 @@ struct esvio_fe_ctx {
   size_t spec_bytes = 0;
   bool spec_valid = false;
   int spec_n = 0;             // number of points of that launch (= the next frame's prev_pts.size())
+  // ---- chained temporal LK of the frame after next: when the next frame publishes nothing, the
+  // frame after it tracks exactly the next frame's forward results, point by point, so its launch
+  // (stream4) is made together with the speculative one and each of its waves starts the moment the
+  // producer's wave of the same index publishes its forward result (LkArgs::chain_*).  Results:
+  // second half of h_spec, indexed like the producer's points; the intermediate frame's temporal
+  // filter gives the map from the final frame's prev_pts to those indices.
+  unsigned long long* d_chain = nullptr;  // [2 * max_cnt] published forward results
+  uint32_t chain_seq = 0;
+  bool chain_enabled = true;   // (ESVIO_FE_NO_CHAIN=1 turns it off: A/B measurements)
+  bool chain_valid = false;    // a chained launch has been made ...
+  uint64_t chain_for = 0;      // ... for the frame with this number
+  bool chain_map_ok = false;
+  std::vector<int> chain_map;  // final frame's prev_pts[j] = producer point chain_map[j]
+  uint64_t frame_no = 0;       // trackEvent calls so far
+  hipEvent_t ev_chain_done = nullptr;
   // k_select publishes each new corner as it accepts it; the speculative launch, already resident,
   // picks them up one by one instead of starting after the whole selection
   unsigned long long *d_pub_slots = nullptr, *d_pub_done = nullptr;
@@ -250,6 +265,7 @@ struct esvio_fe_ctx {
   uint64_t phase_count[2] = {0, 0};
   uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
   double tr_fm_ms = 0;  // time inside find_fundamental_mat alone
+  uint64_t tr_chain_launch = 0, tr_chain_used = 0, tr_chain_cancel = 0, tr_spec_used = 0;
 
   // ---- profiling
   bool prof_on = false;
@@ -1109,12 +1125,54 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
     f.poll_from = n_kept;
     f.poll_err = (int*)(c->z_spec + M * 16 + 2 * stM);
   }
+  // the frame after next, chained to this launch point by point (see esvio_fe_ctx::d_chain)
+  const Inflight* nxt2 = nullptr;
+  if (c->chain_enabled && !nxt.pub && c->inflight.size() >= 2 && c->inflight[0].lane == nxt.lane &&
+      !c->chain_valid)
+    nxt2 = &c->inflight[1];
+  if (nxt2) {
+    c->chain_seq = (c->chain_seq + 1) & 0x3fffffffu;
+    if (!c->chain_seq) c->chain_seq = 1;
+    f.chain_out = c->d_chain;
+    f.chain_seq = c->chain_seq;
+  }
   {
     StreamScope on_spec_stream(c->stream3);
     run_lk(c, f, c->cfg.flow_back ? &b : nullptr, Cb, sB);
   }
   HIPCHK(c, hipEventRecord(c->ev_spec_done, c->stream3));
   c->spec_valid = true;
+  if (nxt2) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt.lane], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt2->lane], 0));
+    uint8_t* zc = c->z_spec + c->spec_bytes;
+    const PyrDesc& N2 = c->pyr[nxt2->slotL].d;
+    LkArgs f2 = make_lk(N, N2, nullptr, nullptr, (float2*)zc, zc + M * 16, nullptr, n_max, 3, 30, 0.01, 0);
+    LkArgs b2 = make_lk(N2, N, nullptr, nullptr, nullptr, nullptr, nullptr, n_max, 1, 30, 0.01,
+                        ESVIO_FE_LK_USE_INITIAL_FLOW);
+    f2.chain_in = c->d_chain;
+    f2.chain_seq = c->chain_seq;
+    f2.poll_err = (int*)(zc + M * 16 + 2 * stM);
+    {
+      StreamScope on_chain_stream(c->stream4);
+      run_lk(c, f2, c->cfg.flow_back ? &b2 : nullptr, (float2*)zc + M, zc + M * 16 + stM);
+    }
+    HIPCHK(c, hipEventRecord(c->ev_chain_done, c->stream4));
+    c->chain_valid = true;
+    c->tr_chain_launch++;
+    c->chain_for = c->frame_no + 2;
+    c->chain_map_ok = false;
+  }
+  return 0;
+}
+
+// give up a chained launch whose results cannot be used (its kernel only waits for bounded times)
+int cancel_chain(esvio_fe_ctx* c) {
+  if (!c->chain_valid) return 0;
+  c->chain_valid = false;
+  c->chain_map_ok = false;
+  c->tr_chain_cancel++;
+  HIPCHK(c, hipStreamSynchronize(c->stream4));
   return 0;
 }
 
@@ -1233,6 +1291,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
   // (lazy mode, pend_right) while this frame's kernels are enqueued
   c->res_set ^= 1;
+  c->frame_no++;
   Pin pin = pin_of(c, c->res_set);
   if (PUB_THIS_FRAME && c->pool) host::ransac_pool_wake(c->pool);
   c->cur_time = _cur_time;
@@ -1355,22 +1414,38 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     use_spec = c->cur_prefetched && (int)c->prev_pts.size() == c->spec_n;
     if (!use_spec) HIPCHK(c, hipStreamSynchronize(c->stream3));
   }
+  // ... or a chained one by the call before that; if it was made for the NEXT frame, this frame
+  // is the one in between: it must publish nothing and track with the speculative results
+  bool use_chain = false;
+  if (c->chain_valid && c->chain_for == c->frame_no) {
+    use_chain = !use_spec && c->cur_prefetched && c->chain_map_ok &&
+                c->chain_map.size() == c->prev_pts.size();
+    if (!use_chain)
+      if (int rc = cancel_chain(c)) return rc;
+    c->chain_valid = false;
+  } else if (c->chain_valid && (c->chain_for != c->frame_no + 1 || PUB_THIS_FRAME || !use_spec)) {
+    if (int rc = cancel_chain(c)) return rc;
+  }
+  const bool chain_covers_next = c->chain_valid;  // (then: for frame_no + 1)
+  const bool early_results = use_spec || use_chain;
   // When to enqueue the ~12 launches of the announced batch's prefetch (early_work):
-  //  * late — the next frame's batch is already in flight (two announced ahead), so the one to
-  //    enqueue is not urgent: after everything else of this frame, where the host would only wait;
-  //  * mid — on a frame that publishes nothing, after the stereo LK, in its shadow;
+  //  * before the wait for this frame's temporal LK when that is a speculative / chained launch
+  //    still running and the frame publishes nothing: the host would only wait there;
+  //  * late — a published frame whose successor is already in flight: after everything else of the
+  //    frame, while the corner selection runs (RANSAC + mask + selection sit behind the temporal
+  //    LK wait, so nothing is put in front of them);
   //  * else right away (Arc* still has to run on the main stream, or nothing to overlap with).
   // (Handing them to a second host thread was tried: the two threads' launches serialise inside
   // the runtime and the frame got slower, so everything stays on the calling thread.)
-  const bool defer_late = !(PUB_THIS_FRAME && !arc_done) && have_next;
-  const bool defer_early = !defer_late && use_spec && !PUB_THIS_FRAME;
+  const bool before_sync = early_results && !PUB_THIS_FRAME;
+  const bool defer_late = !(PUB_THIS_FRAME && !arc_done) && have_next && !before_sync;
   if (c->prev_pts.size() > 0) {  // :405-437
     const int n = (int)c->prev_pts.size();
     const uint8_t *t_stA, *t_stB;
     const P2f *t_ptsB, *t_ptsC;
     bool spec_ok = false;
     if (use_spec) {
-      if (!defer_early && !defer_late)
+      if (!defer_late)
         if (int rc = early_work()) return rc;
       lap(1);
       HIPCHK(c, sync_event(c->ev_spec_done));
@@ -1383,6 +1458,40 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       int* wait_expired = (int*)(c->h_spec + (size_t)std::max(M, 1) * 16 + 2 * stM);
       spec_ok = *wait_expired == 0;  // (a wave gave up waiting for k_select: redo the launch below)
       *wait_expired = 0;
+    }
+    std::vector<P2f> g_ptsB, g_ptsC;
+    std::vector<uint8_t> g_stA, g_stB;
+    if (use_chain) {
+      if (!defer_late)
+        if (int rc = early_work()) return rc;
+      lap(1);
+      HIPCHK(c, sync_event(c->ev_chain_done));
+      lap(2);
+      const size_t Mx = (size_t)std::max(M, 1), stM = (Mx + 63) / 64 * 64;
+      const uint8_t* hc = c->h_spec + c->spec_bytes;
+      int* wait_expired = (int*)(hc + Mx * 16 + 2 * stM);
+      spec_ok = *wait_expired == 0;
+      *wait_expired = 0;
+      c->tr_chain_used += spec_ok;
+      if (spec_ok) {  // gather: prev_pts[j] was the producer's point chain_map[j]
+        const P2f *sB = (const P2f*)hc, *sC = (const P2f*)(hc + Mx * 8);
+        const uint8_t *sa = hc + Mx * 16, *sb = sa + stM;
+        g_ptsB.resize(n);
+        g_ptsC.resize(n);
+        g_stA.resize(n);
+        g_stB.resize(n);
+        for (int j = 0; j < n; j++) {
+          const int k = c->chain_map[j];
+          g_ptsB[j] = sB[k];
+          g_ptsC[j] = sC[k];
+          g_stA[j] = sa[k];
+          g_stB[j] = sb[k];
+        }
+        t_ptsB = g_ptsB.data();
+        t_ptsC = g_ptsC.data();
+        t_stA = g_stA.data();
+        t_stB = g_stB.data();
+      }
     }
     if (!spec_ok) {
       std::memcpy(pin.A, c->prev_pts.data(), (size_t)n * 8);
@@ -1415,13 +1524,25 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     }
     for (int i = 0; i < n; i++)
       if (status[i] && !in_border_event(c, c->cur_pts[i])) status[i] = 0;
+    if (chain_covers_next) {
+      if (use_spec && spec_ok) {  // (the producer's point i is this frame's prev_pts[i])
+        c->chain_map.clear();
+        for (int i = 0; i < n; i++)
+          if (status[i]) c->chain_map.push_back(i);
+        c->chain_map_ok = true;
+      } else if (int rc = cancel_chain(c)) {
+        return rc;
+      }
+    }
     reduce_vector(c->prev_pts, status);
     reduce_vector(c->cur_pts, status);
     reduce_vector(c->ids, status);
     reduce_vector(c->track_cnt, status);
+  } else if (chain_covers_next) {
+    if (int rc = cancel_chain(c)) return rc;
   }
 
-  if (!defer_early && !defer_late)
+  if (!defer_late)
     if (int rc = early_work()) return rc;  // (no previous points: nothing was synchronised above)
   for (auto& n : c->track_cnt) n++;  // :439-440
 
@@ -1445,7 +1566,8 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   };
   if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
     if (int rc = upload_kept()) return rc;
-    if (will_spec && n_kept && !defer_early)
+    // (c->chain_valid here: the next frame's temporal LK is already running, chained to this one's)
+    if (will_spec && n_kept && !c->chain_valid)
       if (const Inflight* nb = next_batch())
         if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
   }
@@ -1462,12 +1584,6 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], c->stream4));
     }
     c->lks_last = c->res_set;
-  }
-  if (defer_early) {
-    if (int rc = early_work()) return rc;
-    if (n_kept)
-      if (const Inflight* nb = next_batch())
-        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
   }
 
   if (PUB_THIS_FRAME) {  // :442-469
@@ -1713,6 +1829,7 @@ int track_image_impl(esvio_fe_ctx* c, double _cur_time, const uint8_t* img_left,
   const int M = cfg.max_cnt;
   if (int rc = finalize_pending(c)) return rc;  // (a lazy trackEvent call came before)
   if (int rc = finalize_right(c)) return rc;
+  if (int rc = cancel_chain(c)) return rc;
   Pin pin = pin_of(c);
   c->cur_time = _cur_time;
   const bool first = !c->have_img;
@@ -1878,13 +1995,16 @@ int esvio_fe_destroy(esvio_fe_handle c) {
     fprintf(stderr, "[esvio_fe trace]");
     fprintf(stderr, "\n[esvio_fe trace] findFundamentalMat alone: %.3f ms per published frame",
             c->phase_count[1] ? c->tr_fm_ms / c->phase_count[1] : 0.0);
+    fprintf(stderr, "\n[esvio_fe trace] chained temporal LK: %llu launched, %llu used, %llu cancelled",
+            (unsigned long long)c->tr_chain_launch, (unsigned long long)c->tr_chain_used,
+            (unsigned long long)c->tr_chain_cancel);
     fprintf(stderr, "\n[esvio_fe trace] survivors/frame=%.1f; detect frames=%llu: candidates/frame=%.0f new/frame=%.1f\n",
             (double)c->tr_surv / c->phase_frames, (unsigned long long)c->tr_detect,
             c->tr_detect ? (double)c->tr_cand / c->tr_detect : 0.0,
             c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
   void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
-                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
+                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
                   c->d_minmax};
@@ -1920,6 +2040,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->ev_planes_free) (void)hipEventDestroy(c->ev_planes_free);
   if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
   if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
+  if (c->ev_chain_done) (void)hipEventDestroy(c->ev_chain_done);
   if (c->ev_sel_host) (void)hipEventDestroy(c->ev_sel_host);
   for (hipEvent_t e : c->ev_lks_done)
     if (e) (void)hipEventDestroy(e);
@@ -1979,6 +2100,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if (!streams_ok ||
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_chain_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_sel_host, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lks_done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lks_done[1], hipEventDisableTiming) != hipSuccess ||
@@ -2008,14 +2130,19 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   {
     const size_t stM = (std::max<size_t>(M, 1) + 63) / 64 * 64;
     c->spec_bytes = std::max<size_t>(M, 1) * 16 + 2 * stM + 64;  // results + the wait-expired flag
-    if (hipHostMalloc((void**)&c->h_spec, c->spec_bytes, hipHostMallocDefault) != hipSuccess ||
+    c->spec_bytes = (c->spec_bytes + 255) / 256 * 256;
+    // (twice: the speculative launch's block, then the chained launch's)
+    if (hipHostMalloc((void**)&c->h_spec, 2 * c->spec_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostGetDevicePointer((void**)&c->z_spec, c->h_spec, 0) != hipSuccess)
       return bail(ESVIO_FE_EHIP);
-    std::memset(c->h_spec, 0, c->spec_bytes);
+    std::memset(c->h_spec, 0, 2 * c->spec_bytes);
   }
+  if ((rc = dev_alloc(c, &c->d_chain, 2 * std::max<size_t>(M, 1)))) return bail(rc);
+  c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
   if ((rc = dev_alloc(c, &c->d_pub_slots, std::max<size_t>(M, 1)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_done, 1))) return bail(rc);
-  if (hipMemsetAsync(c->d_pub_slots, 0, std::max<size_t>(M, 1) * 8, cur_stream(c)) != hipSuccess ||
+  if (hipMemsetAsync(c->d_chain, 0, std::max<size_t>(M, 1) * 16, cur_stream(c)) != hipSuccess ||
+      hipMemsetAsync(c->d_pub_slots, 0, std::max<size_t>(M, 1) * 8, cur_stream(c)) != hipSuccess ||
       hipMemsetAsync(c->d_pub_done, 0, 8, cur_stream(c)) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
   if ((rc = dev_alloc(c, &c->d_ptsD, M))) return bail(rc);
@@ -2068,6 +2195,8 @@ int esvio_fe_reset(esvio_fe_handle c) {
   c->announced.clear();
   c->inflight.clear();
   c->spec_valid = false;
+  c->chain_valid = false;
+  c->chain_map_ok = false;
   c->pend.active = false;
   c->pend_right.active = false;
   HIPCHK(c, hipMemsetAsync(c->L2, 0, (size_t)2 * c->P * 16, cur_stream(c)));

@@ -114,6 +114,15 @@ struct LkArgs {
   uint32_t poll_seq = 0;
   int poll_from = 0;
   int* poll_err = nullptr;  // set to 1 if a wait expired (host-visible)
+  // optional: two temporal launches chained point by point (frames g and g+1 when g publishes
+  // nothing, so g+1 tracks exactly g's forward results).  The producer (chain_out) publishes each
+  // point's forward result the moment it has it — two self-validating words per point,
+  // (chain_seq << 2 | alive) << 32 | float bits of x resp. y; the consumer's wave of the same index
+  // (chain_in) waits (bounded, poll_err) for them instead of reading prev_pts, and leaves
+  // status 0 for a point whose forward status was 0 or that does not exist.
+  unsigned long long* chain_out = nullptr;
+  const unsigned long long* chain_in = nullptr;
+  uint32_t chain_seq = 0;  // 30 bits, never 0
   int max_level;
   int max_count;
   double eps2;

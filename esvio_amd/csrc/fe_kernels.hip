@@ -1035,16 +1035,55 @@ struct LkKernelArgs {
   uint32_t poll_seq;
   int poll_from;
   int* poll_err;
+  unsigned long long* chain_out;  // see LkArgs::chain_*
+  const unsigned long long* chain_in;
+  uint32_t chain_seq;
 };
+
+// producer side of a chained launch: point `pt`'s forward result (alive = its status), or alive = 0
+// for a point that does not exist in this launch
+__device__ __forceinline__ void chain_publish(const LkKernelArgs& a, int pt, int lane, float2 p, int alive) {
+  if (!a.chain_out || lane != 0) return;
+  const unsigned long long hi = (unsigned long long)((a.chain_seq << 2) | (uint32_t)(alive ? 1 : 0)) << 32;
+  __hip_atomic_store(&a.chain_out[2 * pt], hi | __float_as_uint(p.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&a.chain_out[2 * pt + 1], hi | __float_as_uint(p.y), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int pt = blockIdx.x * 4 + wave;
   const int n = a.n_ptr ? *a.n_ptr : a.n_max;
-  if (pt >= n || pt >= a.n_max) return;
+  if (pt >= a.n_max) return;
+  if (pt >= n) {
+    chain_publish(a, pt, lane, make_float2(0.f, 0.f), 0);
+    return;
+  }
   float2 prev0;
-  if (a.poll_slots && pt >= a.poll_from) {
+  if (a.chain_in) {
+    // the previous frame's launch is still running (or about to): wait for this point's result
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long vx, vy;
+    for (;;) {
+      vx = __hip_atomic_load(&a.chain_in[2 * pt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vy = __hip_atomic_load(&a.chain_in[2 * pt + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(vx >> 34) == a.chain_seq && (uint32_t)(vy >> 34) == a.chain_seq) break;
+      if (wall_clock64() - t0 > 4000000ull) {  // 40 ms: the producer itself may wait 20 ms
+        if (lane == 0) *a.poll_err = 1;
+        return;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!((uint32_t)(vx >> 32) & 1u)) {  // lost (or never existed) in the previous frame
+      if (lane == 0) {
+        a.status[pt] = 0;
+        if (a.have_back) a.back_status[pt] = 0;
+      }
+      return;
+    }
+    prev0 = make_float2(__uint_as_float((uint32_t)vx), __uint_as_float((uint32_t)vy));
+  } else if (a.poll_slots && pt >= a.poll_from) {
     // this point is a corner k_select may still be about to accept: wait for its slot (or for the
     // final count to rule it out).  wall_clock64 ticks at 100 MHz: give up after 20 ms.
     const unsigned long long t0 = wall_clock64();
@@ -1053,9 +1092,13 @@ __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
       v = __hip_atomic_load(&a.poll_slots[pt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((uint32_t)(v >> 32) == a.poll_seq) break;
       const unsigned long long d = __hip_atomic_load(a.poll_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)(d >> 32) == a.poll_seq && pt >= (int)(uint32_t)d) return;  // not accepted
+      if ((uint32_t)(d >> 32) == a.poll_seq && pt >= (int)(uint32_t)d) {  // not accepted
+        chain_publish(a, pt, lane, make_float2(0.f, 0.f), 0);
+        return;
+      }
       if (wall_clock64() - t0 > 2000000ull) {
         if (lane == 0) *a.poll_err = 1;
+        chain_publish(a, pt, lane, make_float2(0.f, 0.f), 0);
         return;
       }
       __builtin_amdgcn_s_sleep(16);
@@ -1068,6 +1111,7 @@ __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
   float2 np;
   int st;
   lk_point(a.fwd, prev0, init, regJ_s[wave], lane, np, st);
+  chain_publish(a, pt, lane, np, st);
   if (lane == 0) {
     a.next_pts[pt] = np;
     a.status[pt] = (uint8_t)st;
@@ -1116,6 +1160,9 @@ void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts
   a.poll_seq = f.poll_seq;
   a.poll_from = f.poll_from;
   a.poll_err = f.poll_err;
+  a.chain_out = f.chain_out;
+  a.chain_in = f.chain_in;
+  a.chain_seq = f.chain_seq;
   hipLaunchKernelGGL(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
 }
 

@@ -202,12 +202,16 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle h, const esvio_fe_event* left,
  * pass exactly these pointers, sizes, space and cur_time (else ESVIO_FE_EINVAL) and the event memory
  * must stay valid until then.  Results are identical to the non-pipelined sequence.  After a call
  * that prefetched, the get_sae / time-surface taps already reflect the latest prefetched batch.
- * Up to two batches may be announced ahead (call this twice before a track call; the calls that
- * follow must come in the announced order): the second one's SAE update then runs a whole frame
- * early.  With two batches in flight the hint of a published frame must be exact (the SAE has
- * moved on by the time it is tracked): a published frame whose hint was 0 is refused with
- * ESVIO_FE_EINVAL.  The reference has no counterpart: it processes one batch at a time (depth-1
- * queues, node:128-142). */
+ * Up to three batches may be announced ahead (call this up to three times before a track call; the
+ * calls that follow must come in the announced order): the later ones' SAE updates then run whole
+ * frames early.  With more than one batch in flight the hint of a published frame must be exact
+ * (the SAE has moved on by the time it is tracked): a published frame whose hint was 0 is refused
+ * with ESVIO_FE_EINVAL.  With two batches' pyramids in flight and a next frame that publishes
+ * nothing (hint 0: no new corners, no RANSAC — the frame after it tracks exactly its forward LK
+ * results) the temporal LK of the frame AFTER next is launched together with the next frame's,
+ * chained to it point by point on the device; a wrong hint only discards that launch.
+ * The reference has no counterpart: it processes one batch at a time (depth-1 queues,
+ * node:128-142). */
 int esvio_fe_set_next_batch(esvio_fe_handle h, double next_cur_time, const esvio_fe_event* left,
                             size_t nL, const esvio_fe_event* right, size_t nR, int space,
                             int pub_hint);

@@ -445,7 +445,8 @@ def test_track_event_motion_compensated_end_to_end(oracle):
 
 @pytest.mark.parametrize("equalize,hint,depth,lazy", [
     (0, "none", 1, 0), (0, "right", 1, 0), (0, "wrong", 1, 0), (1, "right", 1, 0), (1, "none", 1, 0),
-    (0, "right", 2, 0), (1, "right", 2, 0), (0, "right", 2, 1), (0, "none", 1, 1), (1, "right", 2, 1)])
+    (0, "right", 2, 0), (1, "right", 2, 0), (0, "right", 2, 1), (0, "none", 1, 1), (1, "right", 2, 1),
+    (0, "right", 3, 0), (0, "right", 3, 1), (1, "right", 3, 1)])
 def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy):
     """esvio_fe_set_next_batch (replay mode: the next one or two batches' SAE update / images — and,
     with the PUB hint, their Arc* pass — run on a second stream, and the next frame's temporal LK
@@ -499,16 +500,17 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy)
 def test_two_batches_ahead_need_an_exact_pub_hint():
     """with two batches in flight the SAE has moved past a frame by the time it is tracked, so a
     published frame whose hint was 0 (no prefetched Arc* pass) is refused instead of detecting on
-    the wrong surface; a third announcement is refused too"""
+    the wrong surface; a fourth announcement is refused too"""
     W, H = 346, 260
     s = SceneStream(W, H, rate=2e6, seed=2)
-    b = [s.next_batch() for _ in range(4)]
+    b = [s.next_batch() for _ in range(5)]
     t = [event_times(x[0])[-1] for x in b]
     ft = FE.FeatureTracker(FE.make_config(W, H))
     ft.set_next_batch(t[1], b[1][0], b[1][1], False)
     ft.set_next_batch(t[2], b[2][0], b[2][1], False)
+    ft.set_next_batch(t[3], b[3][0], b[3][1], False)
     with pytest.raises(FE.FrontendError):
-        ft.set_next_batch(t[3], b[3][0], b[3][1], False)
+        ft.set_next_batch(t[4], b[4][0], b[4][1], False)
     ft.trackEvent(t[0], b[0][0], b[0][1], True)       # enqueues the prefetch of frames 1 and 2
     with pytest.raises(FE.FrontendError):
         ft.trackEvent(t[1], b[1][0], b[1][1], True)   # hint said "not published"
@@ -601,9 +603,10 @@ def test_median_blur_kernel_size(oracle, k):
     ft2.close()
 
 
-@pytest.mark.parametrize("lazy,threads", [(0, 1), (1, 1), (1, 4)])
-def test_replay_mode_soak(oracle, lazy, threads):
-    """60 frames with two batches announced ahead, irregular publish pattern, event rate changing
+@pytest.mark.parametrize("lazy,threads,ahead", [(0, 1, 2), (1, 1, 2), (1, 4, 3), (0, 1, 3)])
+def test_replay_mode_soak(oracle, lazy, threads, ahead):
+    """60 frames with two or three batches announced ahead (three: the temporal LK of the frame
+    after an unpublished one is chained to it on the device), irregular publish pattern, event rate changing
     from batch to batch (buffers regrow, speculative temporal LK sizes change), an empty right batch
     now and then: every frame bit-identical to the sequential oracle"""
     W, H = 346, 260
@@ -626,7 +629,7 @@ def test_replay_mode_soak(oracle, lazy, threads):
     from esvio_amd.node import pack_track_records
     announced = 0
     for f, (L, R) in enumerate(batches):
-        while announced < min(f + 2, len(batches) - 1):
+        while announced < min(f + ahead, len(batches) - 1):
             announced += 1
             Ln, Rn = batches[announced]
             ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
