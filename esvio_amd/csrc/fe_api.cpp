@@ -226,6 +226,10 @@ struct esvio_fe_ctx {
   } pend_right;
   hipEvent_t ev_lks_done[2] = {nullptr, nullptr}, ev_lknew_done = nullptr;
   host::RansacPool* pool = nullptr;  // esvio_fe_set_host_threads
+  // the prefetch stream's per-batch launch sequence as a HIP graph (fe_kernels.h)
+  bool graphs_enabled = true;  // (ESVIO_FE_NO_GRAPH=1: plain launches, for A/B measurements)
+  LaunchList rec;
+  LaunchGraph pf_graph;
   // arc / select
   uint8_t* d_flags = nullptr;
   // per-block ordered candidate lists written by k_arc; two sets so that the Arc* of a prefetched
@@ -236,6 +240,10 @@ struct esvio_fe_ctx {
     uint32_t *comp_xy = nullptr, *comp_idx = nullptr, *total = nullptr;
     size_t cap = 0;
   } cand[kRightSlots];
+  // per-pixel earliest candidate of a set's latest Arc* pass (ArcArgs::first_map / launch_dedup)
+  uint32_t* d_first[kRightSlots] = {};
+  uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
+  bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1: A/B measurements)
   int cand_cur = 0;
   size_t arc_cap = 0;
   uint32_t* d_mask_bits = nullptr;
@@ -266,6 +274,11 @@ struct esvio_fe_ctx {
   uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
   double tr_fm_ms = 0;  // time inside find_fundamental_mat alone
   uint64_t tr_chain_launch = 0, tr_chain_used = 0, tr_chain_cancel = 0, tr_spec_used = 0;
+  // (trace only) device-side intervals of the published frame's chain, from timing events
+  hipEvent_t ev_dbg_sel_start = nullptr;
+  double tr_gpu_sel = 0, tr_gpu_spec = 0, tr_gpu_chain = 0, tr_host_chain = 0;
+  uint64_t tr_gpu_n = 0;
+  std::chrono::steady_clock::time_point tr_sel_launch;
 
   // ---- profiling
   bool prof_on = false;
@@ -1000,8 +1013,25 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
   a.cand_xy = want_cand ? c->cand[set].xy : nullptr;
   a.cand_idx = want_cand ? c->cand[set].idx : nullptr;
   a.cand_cnt = want_cand ? c->cand[set].cnt : nullptr;
-  ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
-  launch_arc(cur_stream(c), a);
+  const bool dedup = want_cand && c->dedup_enabled && c->d_first[set] && n < (1u << 24);
+  if (dedup) {
+    // keys count down from launch to launch: 0xfe.. for the first, 0x01.. for the 254th, then the
+    // map is cleared (to all ones) and the count starts again
+    const uint32_t e = c->first_epoch[set]++ % 254u;
+    if (e == 0)
+      (void)hipMemsetAsync(c->d_first[set], 0xff, (size_t)c->P * 4, cur_stream(c));
+    a.first_map = c->d_first[set];
+    a.first_key = (254u - e) << 24;
+  }
+  {
+    ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
+    launch_arc(cur_stream(c), a);
+  }
+  if (dedup) {
+    ScopedKernel k(c, K_COMPACT, 0);
+    launch_dedup(cur_stream(c), a.cand_xy, a.cand_idx, a.cand_cnt, (n + kArcBlock - 1) / kArcBlock,
+                 a.first_map, a.first_key, c->W);
+  }
 }
 
 // wait for the main stream with a short busy poll first: the two per-frame host syncs are on the
@@ -1070,14 +1100,33 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
         break;
       }
       if ((rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &b.dL, &b.dR, b.lane))) break;
-      if ((rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR))) break;
-      render_lk_images(c, b.time, 3, b.slotL, b.slotR, b.raw);
-      PyrDesc nxt[2] = {c->pyr[b.slotL].d, c->pyr[b.slotR].d};
-      pyr_build(c, nxt, 2);
-      if (hipEventRecord(c->ev_lane_done[b.lane], c->stream2) != hipSuccess) {
-        rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
-        break;
+      // the ~11 dependent launches up to the pyramids go out as one graph (fe_kernels.h); with the
+      // per-kernel timers on they are launched one by one so that each can be bracketed
+      const bool as_graph = c->graphs_enabled && !c->prof_on;
+      if (as_graph) {
+        c->rec.clear();
+        set_launch_recorder(&c->rec);
       }
+      rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR);
+      if (!rc) {
+        render_lk_images(c, b.time, 3, b.slotL, b.slotR, b.raw);
+        PyrDesc nxt[2] = {c->pyr[b.slotL].d, c->pyr[b.slotR].d};
+        pyr_build(c, nxt, 2);
+        if (record_event(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
+          rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
+      }
+      if (as_graph) {
+        set_launch_recorder(nullptr);
+        if (!rc && launch_as_graph(c->pf_graph, c->rec, c->stream2) != hipSuccess) {
+          // (not expected; the plain path still works)
+          (void)hipGetLastError();
+          c->graphs_enabled = false;
+          destroy_launch_graph(c->pf_graph);
+          if (launch_plain(c->rec, c->stream2) != hipSuccess)
+            rc = fail(c, ESVIO_FE_EHIP, "kernel launch failed");
+        }
+      }
+      if (rc) break;
       b.arc_done = false;
       if (b.pub && b.nL) {
         if ((rc = ensure_cand_capacity(c, b.cand, b.nL))) break;
@@ -1473,6 +1522,20 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       spec_ok = *wait_expired == 0;
       *wait_expired = 0;
       c->tr_chain_used += spec_ok;
+      if (c->trace && spec_ok) {
+        float a = 0, b = 0, d = 0;
+        if (hipEventElapsedTime(&a, c->ev_dbg_sel_start, c->ev_sel_host) == hipSuccess &&
+            hipEventElapsedTime(&b, c->ev_sel_host, c->ev_spec_done) == hipSuccess &&
+            hipEventElapsedTime(&d, c->ev_sel_host, c->ev_chain_done) == hipSuccess) {
+          c->tr_gpu_sel += a;
+          c->tr_gpu_spec += b;
+          c->tr_gpu_chain += d;
+          c->tr_host_chain += std::chrono::duration<double, std::milli>(clk::now() - c->tr_sel_launch).count();
+          c->tr_gpu_n++;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
       if (spec_ok) {  // gather: prev_pts[j] was the producer's point chain_map[j]
         const P2f *sB = (const P2f*)hc, *sC = (const P2f*)(hc + Mx * 8);
         const uint8_t *sa = hc + Mx * 16, *sb = sa + stM;
@@ -1605,6 +1668,10 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       // new corners go behind the kept points: z_new = next frame's prev_pts
       // (the blocked pixels are the greedy's initial bitmap: candidates on them are skipped there)
       c->pub_seq++;
+      if (c->trace) {
+        HIPCHK(c, hipEventRecord(c->ev_dbg_sel_start, cur_stream(c)));
+        c->tr_sel_launch = clk::now();
+      }
       run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, c->d_mask_bits, c->z_counts,
                  will_spec);
       if (will_spec)
@@ -1978,6 +2045,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   host::ransac_pool_destroy(c->pool);
   c->pool = nullptr;
+  destroy_launch_graph(c->pf_graph);
   if (c->trace && c->phase_frames) {
     static const char* nm[8] = {"enqueue sae+ts+pyr", "enqueue temporal LK", "sync A", "host filter",
                                 "host ransac", "host mask + enqueue detect/stereo", "sync B", "host tail"};
@@ -1995,6 +2063,11 @@ int esvio_fe_destroy(esvio_fe_handle c) {
     fprintf(stderr, "[esvio_fe trace]");
     fprintf(stderr, "\n[esvio_fe trace] findFundamentalMat alone: %.3f ms per published frame",
             c->phase_count[1] ? c->tr_fm_ms / c->phase_count[1] : 0.0);
+    if (c->tr_gpu_n)
+      fprintf(stderr, "\n[esvio_fe trace] device: k_select %.1f us; select end -> next frame's temporal LK done "
+              "%.1f us, -> chained one done %.1f us; host: select launch -> chained results read %.1f us",
+              1e3 * c->tr_gpu_sel / c->tr_gpu_n, 1e3 * c->tr_gpu_spec / c->tr_gpu_n,
+              1e3 * c->tr_gpu_chain / c->tr_gpu_n, 1e3 * c->tr_host_chain / c->tr_gpu_n);
     fprintf(stderr, "\n[esvio_fe trace] chained temporal LK: %llu launched, %llu used, %llu cancelled",
             (unsigned long long)c->tr_chain_launch, (unsigned long long)c->tr_chain_used,
             (unsigned long long)c->tr_chain_cancel);
@@ -2014,6 +2087,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
     for (void* p : {(void*)cs.xy, (void*)cs.idx, (void*)cs.cnt, (void*)cs.comp_xy, (void*)cs.comp_idx,
                     (void*)cs.total})
       if (p) (void)hipFree(p);
+  for (uint32_t* p : c->d_first)
+    if (p) (void)hipFree(p);
   for (PyrStore& ps : c->pyr)
     if (ps.mem) (void)hipFree(ps.mem);
   for (auto& rb : c->raw)
@@ -2041,6 +2116,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
   if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
   if (c->ev_chain_done) (void)hipEventDestroy(c->ev_chain_done);
+  if (c->ev_dbg_sel_start) (void)hipEventDestroy(c->ev_dbg_sel_start);
   if (c->ev_sel_host) (void)hipEventDestroy(c->ev_sel_host);
   for (hipEvent_t e : c->ev_lks_done)
     if (e) (void)hipEventDestroy(e);
@@ -2094,14 +2170,16 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   const bool streams_ok =
       hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
+      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking,
+                                  getenv("ESVIO_FE_PF_HIGH") ? prio_greatest : prio_least) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_least) == hipSuccess;
   if (!streams_ok ||
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_spec_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_chain_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_sel_host, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_spec_done, c->trace ? 0 : hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_chain_done, c->trace ? 0 : hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_dbg_sel_start, 0) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_sel_host, c->trace ? 0 : hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lks_done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lks_done[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lknew_done, hipEventDisableTiming) != hipSuccess ||
@@ -2139,6 +2217,10 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   }
   if ((rc = dev_alloc(c, &c->d_chain, 2 * std::max<size_t>(M, 1)))) return bail(rc);
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
+  c->graphs_enabled = getenv("ESVIO_FE_NO_GRAPH") == nullptr;
+  c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
+  for (int i = 0; i < kRightSlots; i++)
+    if ((rc = dev_alloc(c, &c->d_first[i], (size_t)c->P))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_slots, std::max<size_t>(M, 1)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_done, 1))) return bail(rc);
   if (hipMemsetAsync(c->d_chain, 0, std::max<size_t>(M, 1) * 16, cur_stream(c)) != hipSuccess ||

@@ -4,7 +4,51 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace esvio {
+
+// ---- launch recording / HIP graphs -------------------------------------------------------------
+// One kernel launch costs ~3 us of host time on this stack, one hipGraphLaunch ~5 us whatever the
+// node count, one hipGraphExecKernelNodeSetParams ~0.7 us.  The per-batch sequence the prefetch
+// stream runs (SAE keys, radix passes, SAE apply, time surfaces, pyramids: 11 dependent launches
+// whose arguments change every batch) is therefore recorded instead of launched — while a
+// LaunchList is installed on the calling thread every launch_* wrapper below appends (kernel,
+// grid, block, argument bytes) to it — and then submitted as one linear graph whose nodes get the
+// new parameters (launch_as_graph).  The kernels and their arguments are exactly those of the
+// plain path.
+struct LaunchList {
+  struct Item {
+    void* func;
+    dim3 grid, block;
+    unsigned shmem;
+    uint32_t arg0, nargs;  // into arg_off / arg_size
+    hipEvent_t event;      // func == nullptr: an event record at this point of the sequence
+  };
+  std::vector<Item> items;
+  std::vector<uint32_t> arg_off, arg_size;
+  std::vector<uint8_t> blob;  // argument values, each aligned to 16 B
+  void clear() {
+    items.clear();
+    arg_off.clear();
+    arg_size.clear();
+    blob.clear();
+  }
+};
+void set_launch_recorder(LaunchList* l);  // nullptr: launch normally (per thread)
+// hipEventRecord(e, s), or an event-record node when a recorder is installed
+hipError_t record_event(hipEvent_t e, hipStream_t s);
+struct LaunchGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::vector<hipGraphNode_t> nodes;
+  LaunchList last;  // what the nodes currently hold (unchanged nodes are not touched)
+};
+// Submit the recorded launches to `s` in order: as the cached graph when the kernel sequence is
+// the same as last time (else the graph is rebuilt first).
+hipError_t launch_as_graph(LaunchGraph& g, const LaunchList& l, hipStream_t s);
+hipError_t launch_plain(const LaunchList& l, hipStream_t s);
+void destroy_launch_graph(LaunchGraph& g);
 
 // dvs_msgs::Event, 16 B AoS (reference: feature_tracker/src/dvs_msgs/Event.h:42-52)
 struct __attribute__((aligned(16))) EventRec {
@@ -152,8 +196,21 @@ struct ArcArgs {
   uint32_t* cand_xy;           // [nblk*kArcBlock] per-block ordered candidates (x | y<<16), or NULL
   uint32_t* cand_idx;          // [nblk*kArcBlock]
   uint32_t* cand_cnt;          // [nblk]
+  // per-pixel earliest candidate of this launch (optional): every candidate does
+  // atomicMin(first_map[pixel], first_key | event index); keys of later launches are smaller
+  // (first_key's top byte counts down), so the map is only cleared when that byte wraps
+  uint32_t* first_map;
+  uint32_t first_key;
 };
 void launch_arc(hipStream_t s, const ArcArgs& a);
+
+// Only the earliest candidate of a pixel can ever be accepted by the greedy selection
+// (feature_tracker.cpp:13-38: if it is accepted its disc blocks the pixel, if it is refused the
+// pixel was blocked already, and blocked pixels stay blocked), so the later ones (more than half
+// of the Arc* corners of a 5 Mev/s stream) are dropped from the per-block lists, in place and in
+// order, before the ordered compaction; the sequential stage then has less than half the work.
+void launch_dedup(hipStream_t s, uint32_t* cand_xy, uint32_t* cand_idx, uint32_t* cand_cnt,
+                  uint32_t nblk, const uint32_t* first_map, uint32_t first_key, int W);
 
 // ordered compaction of the per-block candidate lists (parallel; one block per Arc* block)
 void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand_idx,

@@ -8,7 +8,152 @@
 #include "fe_kernels.h"
 #include "fe_mc.h"
 
+#include <cstring>
+#include <tuple>
+
 namespace esvio {
+
+// ============================================================================ launch recording
+namespace {
+thread_local LaunchList* t_recorder = nullptr;
+
+template <typename T>
+void record_arg(LaunchList& l, const T& v) {
+  const size_t off = (l.blob.size() + 15) & ~(size_t)15;
+  l.blob.resize(off + sizeof(T));
+  std::memcpy(&l.blob[off], &v, sizeof(T));
+  l.arg_off.push_back((uint32_t)off);
+  l.arg_size.push_back((uint32_t)sizeof(T));
+}
+
+// every launch of this file goes through here
+template <typename... P, typename... A>
+void launch_k(void (*kernel)(P...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, A... args) {
+  static_assert(sizeof...(P) == sizeof...(A), "argument count");
+  LaunchList* l = t_recorder;
+  if (!l) {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
+    return;
+  }
+  LaunchList::Item it;
+  it.func = (void*)kernel;
+  it.grid = grid;
+  it.block = block;
+  it.shmem = shmem;
+  it.event = nullptr;
+  it.arg0 = (uint32_t)l->arg_off.size();
+  it.nargs = (uint32_t)sizeof...(P);
+  (record_arg<P>(*l, static_cast<P>(args)), ...);  // (converted to the kernel's parameter types)
+  l->items.push_back(it);
+}
+
+void fill_params(const LaunchList& l, const LaunchList::Item& it, std::vector<void*>& ptrs,
+                 hipKernelNodeParams& kp) {
+  ptrs.resize(it.nargs);
+  for (uint32_t a = 0; a < it.nargs; a++) ptrs[a] = (void*)&l.blob[l.arg_off[it.arg0 + a]];
+  kp = hipKernelNodeParams{};
+  kp.func = it.func;
+  kp.gridDim = it.grid;
+  kp.blockDim = it.block;
+  kp.sharedMemBytes = it.shmem;
+  kp.kernelParams = ptrs.data();
+  kp.extra = nullptr;
+}
+
+bool same_launch(const LaunchList& a, const LaunchList::Item& x, const LaunchList& b,
+                 const LaunchList::Item& y) {
+  if (x.func != y.func || x.nargs != y.nargs || x.shmem != y.shmem || x.grid.x != y.grid.x ||
+      x.grid.y != y.grid.y || x.grid.z != y.grid.z || x.block.x != y.block.x ||
+      x.block.y != y.block.y || x.block.z != y.block.z)
+    return false;
+  for (uint32_t k = 0; k < x.nargs; k++) {
+    const uint32_t sa = a.arg_size[x.arg0 + k];
+    if (sa != b.arg_size[y.arg0 + k] ||
+        std::memcmp(&a.blob[a.arg_off[x.arg0 + k]], &b.blob[b.arg_off[y.arg0 + k]], sa) != 0)
+      return false;
+  }
+  return true;
+}
+}  // namespace
+
+void set_launch_recorder(LaunchList* l) { t_recorder = l; }
+
+hipError_t record_event(hipEvent_t e, hipStream_t s) {
+  LaunchList* l = t_recorder;
+  if (!l) return hipEventRecord(e, s);
+  LaunchList::Item it{};
+  it.func = nullptr;
+  it.event = e;
+  it.arg0 = (uint32_t)l->arg_off.size();
+  it.nargs = 0;
+  l->items.push_back(it);
+  return hipSuccess;
+}
+
+hipError_t launch_plain(const LaunchList& l, hipStream_t s) {
+  std::vector<void*> ptrs;
+  for (const LaunchList::Item& it : l.items) {
+    if (!it.func) {
+      const hipError_t e = hipEventRecord(it.event, s);
+      if (e != hipSuccess) return e;
+      continue;
+    }
+    ptrs.resize(it.nargs);
+    for (uint32_t a = 0; a < it.nargs; a++) ptrs[a] = (void*)&l.blob[l.arg_off[it.arg0 + a]];
+    const hipError_t e = hipLaunchKernel(it.func, it.grid, it.block, ptrs.data(), it.shmem, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+void destroy_launch_graph(LaunchGraph& g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr;
+  g.graph = nullptr;
+  g.nodes.clear();
+  g.last.clear();
+}
+
+hipError_t launch_as_graph(LaunchGraph& g, const LaunchList& l, hipStream_t s) {
+  if (l.items.empty()) return hipSuccess;
+  std::vector<void*> ptrs;
+  hipKernelNodeParams kp;
+  bool same_shape = g.exec && g.last.items.size() == l.items.size();
+  for (size_t i = 0; same_shape && i < l.items.size(); i++)
+    same_shape = g.last.items[i].func == l.items[i].func && g.last.items[i].nargs == l.items[i].nargs;
+  hipError_t e;
+  if (!same_shape) {  // a linear chain of kernel nodes, in launch order
+    destroy_launch_graph(g);
+    if ((e = hipGraphCreate(&g.graph, 0)) != hipSuccess) return e;
+    g.nodes.resize(l.items.size());
+    for (size_t i = 0; i < l.items.size(); i++) {
+      const hipGraphNode_t* dep = i ? &g.nodes[i - 1] : nullptr;
+      if (!l.items[i].func) {
+        e = hipGraphAddEventRecordNode(&g.nodes[i], g.graph, dep, i ? 1 : 0, l.items[i].event);
+      } else {
+        fill_params(l, l.items[i], ptrs, kp);
+        e = hipGraphAddKernelNode(&g.nodes[i], g.graph, dep, i ? 1 : 0, &kp);
+      }
+      if (e != hipSuccess) return e;
+    }
+    if ((e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0)) != hipSuccess) return e;
+  } else {
+    for (size_t i = 0; i < l.items.size(); i++) {
+      if (!l.items[i].func) {
+        if (g.last.items[i].event != l.items[i].event &&
+            (e = hipGraphExecEventRecordNodeSetEvent(g.exec, g.nodes[i], l.items[i].event)) != hipSuccess)
+          return e;
+        continue;
+      }
+      if (same_launch(g.last, g.last.items[i], l, l.items[i])) continue;
+      fill_params(l, l.items[i], ptrs, kp);
+      if ((e = hipGraphExecKernelNodeSetParams(g.exec, g.nodes[i], &kp)) != hipSuccess) return e;
+    }
+  }
+  g.last = l;
+  return hipGraphLaunch(g.exec, s);
+}
 
 // ============================================================================ helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -87,11 +232,11 @@ void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const Even
   McParams m = McParams();  // value-initialised: enabled = 0
   if (mc) m = *mc;
   if (m.enabled)
-    hipLaunchKernelGGL(k_sae_keys<true>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
+    launch_k(k_sae_keys<true>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
                        (const uint4*)evR, nR, W, H, keys, vals, invalid_key, n_rejected, passes, bits,
                        ghist, lookback, lookback_words, m);
   else
-    hipLaunchKernelGGL(k_sae_keys<false>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
+    launch_k(k_sae_keys<false>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL,
                        (const uint4*)evR, nR, W, H, keys, vals, invalid_key, n_rejected, passes, bits,
                        ghist, lookback, lookback_words, m);
 }
@@ -230,7 +375,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
                        int shift, int bits, const uint32_t* ghist, uint32_t* lookback,
                        uint32_t* ticket, uint32_t* keys_out, uint32_t* vals_out, int* err) {
-  hipLaunchKernelGGL(k_radix_pass, dim3(radix_blocks(n)), dim3(256), 0, s, keys_in, vals_in, n, shift,
+  launch_k(k_radix_pass, dim3(radix_blocks(n)), dim3(256), 0, s, keys_in, vals_in, n, shift,
                      bits, ghist, lookback, ticket, keys_out, vals_out, err);
 }
 
@@ -303,7 +448,7 @@ void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals,
                       uint32_t* sort_scratch, uint32_t sort_scratch_words) {
   if (!n) return;
   const uint32_t need = n > sort_scratch_words ? n : sort_scratch_words;
-  hipLaunchKernelGGL(k_sae_apply, dim3((need + 255) / 256), dim3(256), 0, s, keys, vals, n,
+  launch_k(k_sae_apply, dim3((need + 255) / 256), dim3(256), 0, s, keys, vals, n,
                      (const uint4*)evL, nL, (const uint4*)evR, L2, S2, filter_threshold,
                      invalid_key, sort_scratch, sort_scratch_words);
 }
@@ -354,7 +499,7 @@ void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double 
                          double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
                          int dst_stride, int ncam) {
   const uint32_t P = (uint32_t)W * H;
-  hipLaunchKernelGGL(k_time_surface, dim3((P + 255) / 256, ncam), dim3(256), 0, s, S2, W, H,
+  launch_k(k_time_surface, dim3((P + 255) / 256, ncam), dim3(256), 0, s, S2, W, H,
                      t_sync, decay_sec, ignore_polarity, dst0, dst1, dst_stride);
 }
 
@@ -512,11 +657,11 @@ void launch_clahe(hipStream_t s, const uint8_t* raw0, const uint8_t* raw1, int r
   a.minmax = minmax;
   const int nb = (W * H + 255) / 256;
   if (stage == 0)
-    hipLaunchKernelGGL(k_clahe_lut, dim3(64, nimg), dim3(256), 0, s, a);
+    launch_k(k_clahe_lut, dim3(64, nimg), dim3(256), 0, s, a);
   else if (stage == 1)
-    hipLaunchKernelGGL(k_clahe_interp, dim3(nb, nimg), dim3(256), 0, s, a);
+    launch_k(k_clahe_interp, dim3(nb, nimg), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL(k_normalize, dim3(nb, nimg), dim3(256), 0, s, a);
+    launch_k(k_normalize, dim3(nb, nimg), dim3(256), 0, s, a);
 }
 
 // ============================================================================ pyramid
@@ -625,19 +770,19 @@ static PyrPack make_pack(const PyrDesc* p, int nimg) {
 
 void launch_pyr_down(hipStream_t s, const PyrDesc* p, int nimg, int src_level) {
   const int dw = p[0].w[src_level + 1], dh = p[0].h[src_level + 1];
-  hipLaunchKernelGGL(k_pyr_down, dim3((dw + 31) / 32, (dh + 7) / 8, nimg), dim3(256), 0, s,
+  launch_k(k_pyr_down, dim3((dw + 31) / 32, (dh + 7) / 8, nimg), dim3(256), 0, s,
                      make_pack(p, nimg), src_level);
 }
 void launch_pyr_pad(hipStream_t s, const PyrDesc* p, int nimg) {
   const int pw = p[0].w[0] + 2 * kPad;
   const int total = 2 * pw * kPad + 2 * kPad * p[0].h[0];
-  hipLaunchKernelGGL(k_pyr_pad, dim3((total + 255) / 256, p[0].levels + 1, nimg), dim3(256), 0, s,
+  launch_k(k_pyr_pad, dim3((total + 255) / 256, p[0].levels + 1, nimg), dim3(256), 0, s,
                      make_pack(p, nimg));
 }
 void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg) {
   const int total = p[0].w[0] * p[0].h[0];
   int gx = (total + 255) / 256;
-  hipLaunchKernelGGL(k_scharr, dim3(gx, p[0].levels + 1, nimg), dim3(256), 0, s,
+  launch_k(k_scharr, dim3(gx, p[0].levels + 1, nimg), dim3(256), 0, s,
                      make_pack(p, nimg));
 }
 
@@ -1163,7 +1308,7 @@ void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts
   a.chain_out = f.chain_out;
   a.chain_in = f.chain_in;
   a.chain_seq = f.chain_seq;
-  hipLaunchKernelGGL(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
+  launch_k(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
 }
 
 // ============================================================================ Arc*
@@ -1280,6 +1425,7 @@ __global__ __launch_bounds__(kArcBlock) void k_arc(ArcArgs a) {
       const uint32_t pos = blockIdx.x * kArcBlock + base + __popcll(m & ((1ull << lane) - 1ull));
       a.cand_xy[pos] = x | (y << 16);
       a.cand_idx[pos] = i;
+      if (a.first_map) atomicMin(&a.first_map[y * (uint32_t)a.W + x], a.first_key | i);
     }
     if (threadIdx.x == 0) {
       uint32_t t = 0;
@@ -1291,7 +1437,46 @@ __global__ __launch_bounds__(kArcBlock) void k_arc(ArcArgs a) {
 
 void launch_arc(hipStream_t s, const ArcArgs& a) {
   if (!a.n) return;
-  hipLaunchKernelGGL(k_arc, dim3((a.n + kArcBlock - 1) / kArcBlock), dim3(kArcBlock), 0, s, a);
+  launch_k(k_arc, dim3((a.n + kArcBlock - 1) / kArcBlock), dim3(kArcBlock), 0, s, a);
+}
+
+// see launch_dedup (fe_kernels.h): one block per Arc* block, list rewritten in place
+__global__ __launch_bounds__(kArcBlock) void k_dedup(uint32_t* __restrict__ cand_xy,
+                                                     uint32_t* __restrict__ cand_idx,
+                                                     uint32_t* __restrict__ cand_cnt,
+                                                     const uint32_t* __restrict__ first_map,
+                                                     uint32_t first_key, int W) {
+  __shared__ uint32_t wave_cnt[kArcBlock / 64];
+  const uint32_t b = blockIdx.x, c = cand_cnt[b];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  uint32_t xy = 0, idx = 0;
+  bool keep = false;
+  if (threadIdx.x < c) {
+    xy = cand_xy[(size_t)b * kArcBlock + threadIdx.x];
+    idx = cand_idx[(size_t)b * kArcBlock + threadIdx.x];
+    keep = first_map[(xy >> 16) * (uint32_t)W + (xy & 0xffffu)] == (first_key | idx);
+  }
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) wave_cnt[wave] = __popcll(m);
+  __syncthreads();  // (also: every thread has read its entry before any is overwritten)
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < kArcBlock / 64; w++) {
+    if (w < wave) base += wave_cnt[w];
+    tot += wave_cnt[w];
+  }
+  if (keep) {
+    const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    cand_xy[(size_t)b * kArcBlock + pos] = xy;
+    cand_idx[(size_t)b * kArcBlock + pos] = idx;
+  }
+  if (threadIdx.x == 0) cand_cnt[b] = tot;
+}
+
+void launch_dedup(hipStream_t s, uint32_t* cand_xy, uint32_t* cand_idx, uint32_t* cand_cnt,
+                  uint32_t nblk, const uint32_t* first_map, uint32_t first_key, int W) {
+  if (!nblk) return;
+  launch_k(k_dedup, dim3(nblk), dim3(kArcBlock), 0, s, cand_xy, cand_idx, cand_cnt, first_map,
+           first_key, W);
 }
 
 // ============================================================================ median blur
@@ -1329,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_median(const uint8_t* src0, const uint8
 
 void launch_median(hipStream_t s, const uint8_t* src0, const uint8_t* src1, int src_stride,
                    uint8_t* dst0, uint8_t* dst1, int dst_stride, int W, int H, int k, int nimg) {
-  hipLaunchKernelGGL(k_median, dim3((W + 15) / 16, (H + 15) / 16, nimg), dim3(256), 0, s, src0, src1,
+  launch_k(k_median, dim3((W + 15) / 16, (H + 15) / 16, nimg), dim3(256), 0, s, src0, src1,
                      src_stride, dst0, dst1, dst_stride, W, H, k);
 }
 
@@ -1415,9 +1600,9 @@ __global__ __launch_bounds__(64) void k_gftt_eig(GfttArgs a) {
 
 void launch_gftt_response(hipStream_t s, const GfttArgs& a) {
   const dim3 grid((a.W + 63) / 64, (a.H + 3) / 4);
-  hipLaunchKernelGGL(k_gftt_cov, grid, dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_gftt_rowsum, grid, dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_gftt_eig, dim3((a.W + 63) / 64), dim3(64), 0, s, a);
+  launch_k(k_gftt_cov, grid, dim3(256), 0, s, a);
+  launch_k(k_gftt_rowsum, grid, dim3(256), 0, s, a);
+  launch_k(k_gftt_eig, dim3((a.W + 63) / 64), dim3(64), 0, s, a);
 }
 
 // threshold + 3x3 local maximum + mask; block b owns pixels [b*kArcBlock, (b+1)*kArcBlock) in
@@ -1469,7 +1654,7 @@ __global__ __launch_bounds__(kArcBlock) void k_gftt_collect(GfttArgs a) {
 
 void launch_gftt_collect(hipStream_t s, const GfttArgs& a) {
   const uint32_t nblk = ((uint32_t)a.W * a.H + kArcBlock - 1) / kArcBlock;
-  hipLaunchKernelGGL(k_gftt_collect, dim3(nblk), dim3(kArcBlock), 0, s, a);
+  launch_k(k_gftt_collect, dim3(nblk), dim3(kArcBlock), 0, s, a);
 }
 
 __global__ __launch_bounds__(256) void k_gftt_sortprep(const uint32_t* __restrict__ comp_xy,
@@ -1502,7 +1687,7 @@ void launch_gftt_sortprep(hipStream_t s, const uint32_t* comp_xy, const uint32_t
                           uint32_t lookback_words) {
   uint32_t grid = (n + 1023) / 1024;
   grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
-  hipLaunchKernelGGL(k_gftt_sortprep, dim3(grid), dim3(256), 0, s, comp_xy, comp_val, n, keys, vals,
+  launch_k(k_gftt_sortprep, dim3(grid), dim3(256), 0, s, comp_xy, comp_val, n, keys, vals,
                      ghist, lookback, lookback_words);
 }
 
@@ -1542,7 +1727,7 @@ void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand
                     const uint32_t* cand_cnt, uint32_t nblk, uint32_t* comp_xy, uint32_t* comp_idx,
                     uint32_t* total) {
   if (!nblk) return;
-  hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(kArcBlock), 0, s, cand_xy, cand_idx, cand_cnt, nblk,
+  launch_k(k_compact, dim3(nblk), dim3(kArcBlock), 0, s, cand_xy, cand_idx, cand_cnt, nblk,
                      comp_xy, comp_idx, total);
 }
 
@@ -1801,7 +1986,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
 }
 
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
-  hipLaunchKernelGGL(k_select, dim3(1), dim3(64), lds_bytes, s, a);
+  launch_k(k_select, dim3(1), dim3(64), lds_bytes, s, a);
 }
 
 }  // namespace esvio
