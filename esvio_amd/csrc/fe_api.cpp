@@ -227,7 +227,10 @@ struct esvio_fe_ctx {
   hipEvent_t ev_lks_done[2] = {nullptr, nullptr}, ev_lknew_done = nullptr;
   host::RansacPool* pool = nullptr;  // esvio_fe_set_host_threads
   // the prefetch stream's per-batch launch sequence as a HIP graph (fe_kernels.h)
-  bool graphs_enabled = true;  // (ESVIO_FE_NO_GRAPH=1: plain launches, for A/B measurements)
+  // Off by default: measured on MI355X / ROCm 7.2 it saves ~17 us of host time per batch but the
+  // graph's kernels complete ~50 us later than the same kernels launched one by one, and the
+  // chained temporal LK then waits for the pyramids.  ESVIO_FE_GRAPH=1 turns it on.
+  bool graphs_enabled = false;
   LaunchList rec;
   LaunchGraph pf_graph;
   // arc / select
@@ -276,7 +279,8 @@ struct esvio_fe_ctx {
   uint64_t tr_chain_launch = 0, tr_chain_used = 0, tr_chain_cancel = 0, tr_spec_used = 0;
   // (trace only) device-side intervals of the published frame's chain, from timing events
   hipEvent_t ev_dbg_sel_start = nullptr;
-  double tr_gpu_sel = 0, tr_gpu_spec = 0, tr_gpu_chain = 0, tr_host_chain = 0;
+  double tr_gpu_sel = 0, tr_gpu_spec = 0, tr_gpu_chain = 0, tr_host_chain = 0, tr_gpu_pyr = 0;
+  int tr_lane = -1;  // prefetch lane of the frame being tracked
   uint64_t tr_gpu_n = 0;
   std::chrono::steady_clock::time_point tr_sel_launch;
 
@@ -1370,6 +1374,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                   "the SAE: with more than one batch announced the hint must be exact");
     c->inflight.pop_front();
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_done[b.lane], 0));
+    c->tr_lane = b.lane;
     dL = b.dL;
     dR = b.dR;
     c->slot_curL = b.slotL;
@@ -1530,6 +1535,12 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
           c->tr_gpu_sel += a;
           c->tr_gpu_spec += b;
           c->tr_gpu_chain += d;
+          float e2 = 0;
+          if (c->tr_lane >= 0 &&
+              hipEventElapsedTime(&e2, c->ev_sel_host, c->ev_lane_done[c->tr_lane]) == hipSuccess)
+            c->tr_gpu_pyr += e2;
+          else
+            (void)hipGetLastError();
           c->tr_host_chain += std::chrono::duration<double, std::milli>(clk::now() - c->tr_sel_launch).count();
           c->tr_gpu_n++;
         } else {
@@ -2065,9 +2076,11 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->phase_count[1] ? c->tr_fm_ms / c->phase_count[1] : 0.0);
     if (c->tr_gpu_n)
       fprintf(stderr, "\n[esvio_fe trace] device: k_select %.1f us; select end -> next frame's temporal LK done "
-              "%.1f us, -> chained one done %.1f us; host: select launch -> chained results read %.1f us",
+              "%.1f us, -> chained one done %.1f us (its frame's pyramids: %.1f us); host: select launch -> "
+              "chained results read %.1f us",
               1e3 * c->tr_gpu_sel / c->tr_gpu_n, 1e3 * c->tr_gpu_spec / c->tr_gpu_n,
-              1e3 * c->tr_gpu_chain / c->tr_gpu_n, 1e3 * c->tr_host_chain / c->tr_gpu_n);
+              1e3 * c->tr_gpu_chain / c->tr_gpu_n, 1e3 * c->tr_gpu_pyr / c->tr_gpu_n,
+              1e3 * c->tr_host_chain / c->tr_gpu_n);
     fprintf(stderr, "\n[esvio_fe trace] chained temporal LK: %llu launched, %llu used, %llu cancelled",
             (unsigned long long)c->tr_chain_launch, (unsigned long long)c->tr_chain_used,
             (unsigned long long)c->tr_chain_cancel);
@@ -2186,7 +2199,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
   for (int i = 0; i < kPrefetchDepth; i++)
-    if (hipEventCreateWithFlags(&c->ev_lane_done[i], hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&c->ev_lane_done[i], c->trace ? 0 : hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_lane_arc[i], hipEventDisableTiming) != hipSuccess)
       return bail(ESVIO_FE_EHIP);
   const size_t M = cfg->max_cnt;
@@ -2217,7 +2230,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   }
   if ((rc = dev_alloc(c, &c->d_chain, 2 * std::max<size_t>(M, 1)))) return bail(rc);
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
-  c->graphs_enabled = getenv("ESVIO_FE_NO_GRAPH") == nullptr;
+  c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
   for (int i = 0; i < kRightSlots; i++)
     if ((rc = dev_alloc(c, &c->d_first[i], (size_t)c->P))) return bail(rc);

@@ -648,6 +648,35 @@ def test_replay_mode_soak(oracle, lazy, threads, ahead):
     ft.close()
 
 
+@pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP"])
+def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
+    """the measurement switches read at esvio_fe_create (prefetch sequence submitted as a HIP
+    graph; no chained temporal LK; no per-pixel dedup of the Arc* candidates) leave every result
+    bit-identical to the oracle"""
+    monkeypatch.setenv(opt, "1")
+    W, H = 346, 260
+    s = SceneStream(W, H, rate=3e6, seed=77, n_rect=10, size=(25.0, 80.0))
+    batches = [s.next_batch()[:2] for _ in range(14)]
+    pubs = [f % 2 == 0 for f in range(len(batches))]
+    kw = dict(max_cnt=150, min_dist=10, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(True)
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        while announced < min(f + 3, len(batches) - 1):
+            announced += 1
+            Ln, Rn = batches[announced]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pubs[f])
+        r = tr.track_event(t, L, R, pubs[f])
+        ft.finish()
+        _compare_tracks(ft, r, (opt, f))
+    assert len(ft.ids) > 40
+    ft.close()
+
+
 def test_pack_track_records_matches_the_node_packing():
     """esvio_fe_pack_track_records == the PointCloud packing of stereo_event_tracker_node.cpp:273-329
     (python mirror node.pack_track_records) on live tracker results"""
