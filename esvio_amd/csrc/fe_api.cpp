@@ -967,7 +967,8 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* o
 }
 
 size_t select_lds_bytes(const esvio_fe_ctx* c) {
-  return ((size_t)c->H * ((c->W + 31) / 32) + 4 + 64) * 4;  // bitmap + half-width table
+  // bitmap + half-width table + the kept points whose discs seed the bitmap
+  return ((size_t)c->H * ((c->W + 31) / 32) + 4 + 64 + (size_t)std::max(c->cfg.max_cnt, 1)) * 4;
 }
 
 // ordered compaction of candidate set `set` (right behind the k_arc that filled it)
@@ -982,10 +983,12 @@ void run_compact(esvio_fe_ctx* c, uint32_t n_events, int set) {
 // `mask_bits`: blocked pixels the disc bitmap starts from (null: none, or already applied by k_arc)
 void run_select(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int out_base,
                 int32_t* out_idx, const uint32_t* mask_bits = nullptr, int* host_counts = nullptr,
-                bool publish = false) {
+                bool publish = false, const float2* stamp_pts = nullptr, int n_stamp = 0) {
   SelectArgs s = make_select_args(c, set, max_corners, out_pts, out_base, out_idx);
   s.host_counts = host_counts;
   s.init_bits = mask_bits;
+  s.stamp_pts = stamp_pts;
+  s.n_stamp = n_stamp;
   if (publish) {
     s.pub_slots = c->d_pub_slots;
     s.pub_done = c->d_pub_done;
@@ -1672,19 +1675,19 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
         if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
     if (n_max_cnt > 0) {
       detect = true;
-      std::memcpy(pin.mask, c->mask_event.bits.data(), c->mask_event.bits.size() * 4);
-      HIPCHK(c, hipMemcpyAsync(c->d_mask_bits, pin.mask, c->mask_event.bits.size() * 4,
-                               hipMemcpyHostToDevice, cur_stream(c)));
+      // Event_setMask's blocked pixels are the discs of the kept points: k_select stamps them
+      // into its bitmap itself from the points just written to pin.news (1-2 KB read in place
+      // instead of a 38 KB bitmap copied over); candidates on them are skipped there
+      if (!will_spec && n_kept) std::memcpy(pin.news, c->cur_pts.data(), (size_t)n_kept * 8);
       if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
       // new corners go behind the kept points: z_new = next frame's prev_pts
-      // (the blocked pixels are the greedy's initial bitmap: candidates on them are skipped there)
       c->pub_seq++;
       if (c->trace) {
         HIPCHK(c, hipEventRecord(c->ev_dbg_sel_start, cur_stream(c)));
         c->tr_sel_launch = clk::now();
       }
-      run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, c->d_mask_bits, c->z_counts,
-                 will_spec);
+      run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, nullptr, c->z_counts, will_spec,
+                 c->z_new, n_kept);
       if (will_spec)
         if (const Inflight* nb = next_batch())
           if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
@@ -2183,8 +2186,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   const bool streams_ok =
       hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking,
-                                  getenv("ESVIO_FE_PF_HIGH") ? prio_greatest : prio_least) == hipSuccess &&
+      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_least) == hipSuccess;
   if (!streams_ok ||

@@ -267,6 +267,12 @@ struct SelectArgs {
   int* n_total;              // out_base + accepted (feeds the LK kernels' n_ptr), may be NULL
   int* host_counts;          // optional host-mapped mirror: {accepted, out_base + accepted, total}
   const uint32_t* init_bits; // optional H*wpr words the disc bitmap starts from (blocked pixels)
+  // ... or, instead, the points whose discs ARE those blocked pixels (Event_setMask stamps
+  // cv::circle(mask, cvRound(pt), MIN_DIST, 0, -1) for every point it keeps, feature_tracker.cpp
+  // :77-86): the wave stamps them itself, so the host uploads n_stamp points, not a bitmap.
+  // Needs n_stamp more LDS words behind the half-width table.
+  const float2* stamp_pts;
+  int n_stamp;
   // optional publication of each accepted corner the moment it is accepted, for an LK launch that
   // is already waiting (LkArgs::poll_*): slot[out_base + k] = seq<<32 | y<<16 | x, and at the end
   // *done = seq<<32 | (out_base + accepted).  Device memory, relaxed agent-scope atomics; the data

@@ -1810,7 +1810,29 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   }
   const int r = a.radius;
   hwtab[lane] = lane <= r ? (int)a.hw[lane] : -1;
+  uint32_t* const spts = (uint32_t*)(hwtab + 64);
+  if (a.stamp_pts)  // (one round trip to the host-visible point list, all lanes at once)
+    for (int k = lane; k < a.n_stamp; k += 64) {
+      const float2 p = a.stamp_pts[k];
+      spts[k] = (uint32_t)__float2int_rn(p.x) | ((uint32_t)__float2int_rn(p.y) << 16);  // cvRound
+    }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  if (a.stamp_pts) {
+    const int rows = 2 * r + 1;
+    for (int t = lane; t < a.n_stamp * rows; t += 64) {
+      const int p = t / rows, row = t - p * rows;
+      const uint32_t v = spts[p];
+      const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
+      const int hwr = hwtab[row < r ? r - row : row - r];
+      if (r <= 15) {
+        stamp_row_small(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+      } else {
+        stamp_row(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+        if (r > 31) stamp_row_tail(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  }
   const uint32_t total = *a.total;
   int accepted = 0;
   // this lane's disc rows (row index lane and lane+64) and their half-widths
