@@ -648,6 +648,47 @@ def test_replay_mode_soak(oracle, lazy, threads, ahead):
     ft.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_replay_random_schedules(oracle, seed):
+    """random publish pattern, a random number of batches (0..3) announced ahead of every call, lazy
+    mode and RANSAC helper threads switched at random between calls, finish() only now and then:
+    speculative / chained launches get used, skipped and cancelled in every combination, and every
+    frame stays bit-identical to the sequential oracle"""
+    W, H = 346, 260
+    rng = np.random.default_rng(1000 + seed)
+    s = SceneStream(W, H, rate=2.5e6, seed=50 + seed, n_rect=10, size=(25.0, 80.0))
+    batches = [s.next_batch()[:2] for _ in range(36)]
+    p_pub = [0.3, 0.5, 0.7, 0.9][seed - 1]
+    pubs = [bool(rng.random() < p_pub) for _ in batches]
+    kw = dict(max_cnt=100 + 30 * seed, min_dist=8 + 2 * seed, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        if rng.random() < 0.2:
+            ft.set_lazy_new_stereo(bool(rng.integers(0, 2)))
+        if rng.random() < 0.15:
+            ft.set_host_threads(int(rng.integers(1, 5)))
+        want = f + int(rng.integers(0, 4))
+        while announced < min(max(want, announced), len(batches) - 1) and announced - f < 3:
+            announced += 1
+            Ln, Rn = batches[announced]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+        announced = max(announced, f)  # (a frame that was never announced is a plain call)
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pubs[f])
+        r = tr.track_event(t, L, R, pubs[f])
+        for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"):
+            assert np.array_equal(getattr(ft, k), getattr(r, k)), (k, f)
+        if rng.random() < 0.5:
+            ft.finish()
+            _compare_tracks(ft, r, ("random", seed, f))
+    ft.finish()
+    _compare_tracks(ft, r, ("random", seed, "end"))
+    assert len(ft.ids) > 20
+    ft.close()
+
+
 @pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP"])
 def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
     """the measurement switches read at esvio_fe_create (prefetch sequence submitted as a HIP
