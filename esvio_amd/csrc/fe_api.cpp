@@ -247,6 +247,7 @@ struct esvio_fe_ctx {
   uint32_t* d_first[kRightSlots] = {};
   uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
   bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1: A/B measurements)
+  bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1: k_time_surface + 3 x k_pyr_down)
   int cand_cur = 0;
   size_t arc_cap = 0;
   uint32_t* d_mask_bits = nullptr;
@@ -519,6 +520,10 @@ void pyr_build(esvio_fe_ctx* c, const PyrDesc* p, int nimg) {
   (void)px0;
 }
 
+// both cameras' LK images of a batch + their pyramids: render_lk_images + pyr_build, with the
+// time-surface and pyrDown launches fused into one when nothing sits between them
+void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int rawbuf);
+
 // ---------------------------------------------------------------- SAE update (both cameras)
 // Motion_correction_value -> kernel parameters; first_left_host: left.events[0] (host copy)
 McParams make_mc_params(const esvio_fe_motion* m, const esvio_fe_event& first_left) {
@@ -667,6 +672,33 @@ void render_lk_images(esvio_fe_ctx* c, double t_sync, int cams, int slotL, int s
     ScopedKernel k(c, K_CLAHE, stage == 0 ? (uint64_t)c->P * nimg : (uint64_t)c->P * 2 * nimg);
     launch_clahe(cur_stream(c), s0, s1, rl.stride[0], d0, d1, L.stride[0], c->W, c->H, c->d_lut,
                  c->d_minmax, nimg, stage);
+  }
+}
+
+void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int rawbuf) {
+  PyrDesc two[2] = {c->pyr[slotL].d, c->pyr[slotR].d};
+  const bool fused = c->fuse_ts_pyr && !c->cfg.equalize && c->cfg.median_blur_kernel_size <= 0 &&
+                     two[0].levels == 3 && two[1].levels == 3;
+  if (!fused) {
+    render_lk_images(c, t_sync, 3, slotL, slotR, rawbuf);
+    pyr_build(c, two, 2);
+    return;
+  }
+  {
+    uint64_t px = 0;
+    for (int l = 0; l <= 3; l++) px += (uint64_t)two[0].w[l] * two[0].h[l];
+    ScopedKernel k(c, K_TIME_SURFACE, ((uint64_t)c->P * 16 + px) * 2);
+    launch_ts_pyr(cur_stream(c), c->S2, t_sync, c->cfg.decay_ms / 1000.0, c->cfg.ignore_polarity, two);
+  }
+  {
+    ScopedKernel k(c, K_PYR_PAD, 0);
+    launch_pyr_pad(cur_stream(c), two, 2);
+  }
+  {
+    uint64_t all = 0;
+    for (int l = 0; l <= 3; l++) all += (uint64_t)two[0].w[l] * two[0].h[l];
+    ScopedKernel k(c, K_SCHARR, all * 5 * 2);
+    launch_scharr(cur_stream(c), two, 2);
   }
 }
 
@@ -1116,9 +1148,7 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
       }
       rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR);
       if (!rc) {
-        render_lk_images(c, b.time, 3, b.slotL, b.slotR, b.raw);
-        PyrDesc nxt[2] = {c->pyr[b.slotL].d, c->pyr[b.slotR].d};
-        pyr_build(c, nxt, 2);
+        render_and_build(c, b.time, b.slotL, b.slotR, b.raw);
         if (record_event(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
           rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
       }
@@ -1409,11 +1439,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     // camera split: the right image was imported into slot_curR by esvio_fe_import_image
     if (!c->ext_right_pending) c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;
     c->raw_cur = (c->raw_cur + 1) % kRightSlots;
-    render_lk_images(c, c->cur_time, c->ext_right_pending ? 1 : 3, c->slot_curL, c->slot_curR,
-                     c->raw_cur);
+    if (c->ext_right_pending) {
+      render_lk_images(c, c->cur_time, 1, c->slot_curL, c->slot_curR, c->raw_cur);
+      PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[c->slot_curR].d};
+      pyr_build(c, cur2, 2);
+    } else {
+      render_and_build(c, c->cur_time, c->slot_curL, c->slot_curR, c->raw_cur);
+    }
     c->ext_right_pending = false;
-    PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[c->slot_curR].d};
-    pyr_build(c, cur2, 2);
   }
   // the next frame's batch, if it is already in flight (two announced ahead), else once this
   // frame's early_work has put it there
@@ -2234,6 +2267,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
+  c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
   for (int i = 0; i < kRightSlots; i++)
     if ((rc = dev_alloc(c, &c->d_first[i], (size_t)c->P))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_slots, std::max<size_t>(M, 1)))) return bail(rc);

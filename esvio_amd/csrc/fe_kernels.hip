@@ -696,6 +696,109 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrPack pk, int src_level) {
   p.img[src_level + 1][(size_t)(y + kPad) * dstride + x + kPad] = (uint8_t)((acc + 128) >> 8);
 }
 
+static PyrPack make_pack(const PyrDesc* p, int nimg);
+
+// Time surface + the three pyrDown levels of both cameras in ONE launch (instead of
+// k_time_surface + 3 x k_pyr_down: each of those is a ~5 us kernel behind a ~3 us launch, all on the
+// prefetch stream's dependent chain).  A block owns an 8x4 tile of level 3 = 16x8 of level 2 =
+// 32x16 of level 1 = 64x32 of level 0 and recomputes the halo the 5x5 kernels need (85x53 level-0
+// pixels rendered per block, x2.2 the owned ones — fp64 exp is cheap next to three launches), level
+// by level through LDS.  Per pixel the arithmetic is ts_pixel resp. k_pyr_down's, reflect-101 taken at
+// each level's own size, so every byte equals the unfused kernels' output.
+constexpr int kFt3x = 8, kFt3y = 4;
+constexpr int kFt2x = 2 * kFt3x + 3, kFt2y = 2 * kFt3y + 3;  // 19 x 11
+constexpr int kFt1x = 2 * kFt2x + 3, kFt1y = 2 * kFt2y + 3;  // 41 x 25
+constexpr int kFt0x = 2 * kFt1x + 3, kFt0y = 2 * kFt1y + 3;  // 85 x 53
+constexpr int kFs0 = 88, kFs1 = 44, kFs2 = 20;               // LDS row strides
+constexpr int kFtThreads = 1024;  // 16 waves per block: the fp64 exp chains need the latency hiding
+
+template <int SRX, int SS, int DRX, int DRY, int DS>
+__device__ __forceinline__ void fused_down(const uint8_t* __restrict__ src_l, uint8_t* __restrict__ dst_l,
+                                           int sox, int soy, int sw, int sh, int dox, int doy, int dw,
+                                           int dh, uint8_t* __restrict__ dst_img, int dstride, int ownx0,
+                                           int owny0, int ownw, int ownh) {
+  for (int i = threadIdx.x; i < DRX * DRY; i += kFtThreads) {
+    const int ry = i / DRX, rx = i - ry * DRX;
+    const int x = dox + rx, y = doy + ry;
+    if (x < 0 || y < 0 || x >= dw || y >= dh) continue;
+    int xs[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) xs[k] = reflect101(2 * x + k - 2, sw) - sox;
+    const int wk[5] = {1, 4, 6, 4, 1};
+    int acc = 0;
+#pragma unroll
+    for (int ky = 0; ky < 5; ky++) {
+      const uint8_t* row = src_l + (reflect101(2 * y + ky - 2, sh) - soy) * SS;
+      int r = 0;
+#pragma unroll
+      for (int kx = 0; kx < 5; kx++) r += wk[kx] * (int)row[xs[kx]];
+      acc += wk[ky] * r;
+    }
+    const uint8_t v = (uint8_t)((acc + 128) >> 8);
+    if (dst_l) dst_l[ry * DS + rx] = v;
+    if (x >= ownx0 && x < ownx0 + ownw && y >= owny0 && y < owny0 + ownh)
+      dst_img[(size_t)(y + kPad) * dstride + x + kPad] = v;
+  }
+}
+
+__global__ __launch_bounds__(kFtThreads) void k_ts_pyr(const double2* __restrict__ S2, double t_sync,
+                                                double decay_sec, int ignore_polarity, PyrPack pk) {
+  __shared__ uint8_t l0[kFt0y * kFs0];
+  __shared__ uint8_t l1[kFt1y * kFs1];
+  __shared__ uint8_t l2[kFt2y * kFs2];
+  const int cam = blockIdx.z;
+  const PyrDesc& p = pk.p[cam];
+  const int W = p.w[0], H = p.h[0];
+  const int o3x = blockIdx.x * kFt3x, o3y = blockIdx.y * kFt3y;
+  const int o2x = 2 * o3x - 2, o2y = 2 * o3y - 2;
+  const int o1x = 2 * o2x - 2, o1y = 2 * o2y - 2;
+  const int o0x = 2 * o1x - 2, o0y = 2 * o1y - 2;
+  const double2* S = S2 + (size_t)cam * W * H;
+  // (four pixels per thread and step, loads first: the 16 B gathers are what the loop waits for)
+  constexpr int kN0 = kFt0x * kFt0y;
+  for (int i0 = threadIdx.x; i0 < kN0; i0 += 4 * kFtThreads) {
+    double2 sv[4];
+    int xs[4], ys[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + kFtThreads * k;
+      const int ry = i / kFt0x, rx = i - ry * kFt0x;
+      xs[k] = o0x + rx;
+      ys[k] = o0y + ry;
+      ok[k] = i < kN0 && xs[k] >= 0 && ys[k] >= 0 && xs[k] < W && ys[k] < H;
+      sv[k] = S[ok[k] ? (size_t)ys[k] * W + xs[k] : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (!ok[k]) continue;
+      const int x = xs[k], y = ys[k];
+      const uint8_t v = ts_pixel(sv[k], t_sync, decay_sec, ignore_polarity);
+      l0[(y - o0y) * kFs0 + (x - o0x)] = v;
+      if (x >= 8 * o3x && x < 8 * o3x + 8 * kFt3x && y >= 8 * o3y && y < 8 * o3y + 8 * kFt3y)
+        p.img[0][(size_t)(y + kPad) * p.stride[0] + x + kPad] = v;
+    }
+  }
+  __syncthreads();
+  fused_down<kFt0x, kFs0, kFt1x, kFt1y, kFs1>(l0, l1, o0x, o0y, W, H, o1x, o1y, p.w[1], p.h[1], p.img[1],
+                                               p.stride[1], 4 * o3x, 4 * o3y, 4 * kFt3x, 4 * kFt3y);
+  __syncthreads();
+  fused_down<kFt1x, kFs1, kFt2x, kFt2y, kFs2>(l1, l2, o1x, o1y, p.w[1], p.h[1], o2x, o2y, p.w[2], p.h[2],
+                                               p.img[2], p.stride[2], 2 * o3x, 2 * o3y, 2 * kFt3x,
+                                               2 * kFt3y);
+  __syncthreads();
+  fused_down<kFt2x, kFs2, kFt3x, kFt3y, kFt3x>(l2, nullptr, o2x, o2y, p.w[2], p.h[2], o3x, o3y, p.w[3],
+                                                p.h[3], p.img[3], p.stride[3], o3x, o3y, kFt3x, kFt3y);
+}
+
+// both cameras (p[0], p[1]), maxLevel 3
+void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay_sec,
+                   int ignore_polarity, const PyrDesc* p) {
+  const int w3 = p[0].w[3], h3 = p[0].h[3];
+  launch_k(k_ts_pyr, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, 2), dim3(kFtThreads), 0, s, S2,
+           t_sync, decay_sec, ignore_polarity, make_pack(p, 2));
+}
+
 // copyMakeBorder(level, BORDER_REFLECT_101) for every level [OpenCV buildOpticalFlowPyramid]
 __global__ __launch_bounds__(256) void k_pyr_pad(PyrPack pk) {
   const PyrDesc& p = pk.p[blockIdx.z];
