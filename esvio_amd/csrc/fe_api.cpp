@@ -274,6 +274,7 @@ struct esvio_fe_ctx {
   // sync B, host B
   bool trace = false;
   double phase_ms[2][8] = {};  // [published?][phase]
+  double pub_ms[6] = {};       // published frames: the parts of "host mask + enqueue detect/stereo"
   uint64_t phase_count[2] = {0, 0};
   uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
   double tr_fm_ms = 0;  // time inside find_fundamental_mat alone
@@ -1699,7 +1700,15 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   if (PUB_THIS_FRAME) {  // :442-469
     if (cfg.f_ransac) reject_with_f_event(c);
     lap(4);
+    auto tq = clk::now();
+    auto sub = [&](int i) {
+      if (!c->trace) return;
+      const auto now = clk::now();
+      c->pub_ms[i] += std::chrono::duration<double, std::milli>(now - tq).count();
+      tq = now;
+    };
     event_set_mask(c);
+    sub(0);
     n_kept = (int)c->cur_pts.size();
     const int n_max_cnt = M - n_kept;
     if (int rc = upload_kept()) return rc;
@@ -1721,14 +1730,17 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       }
       run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, nullptr, c->z_counts, will_spec,
                  c->z_new, n_kept);
+      sub(1);
       if (will_spec)
         if (const Inflight* nb = next_batch())
           if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
+      sub(2);
       // the selection result is in host memory once k_select is done: an event right behind it lets
       // the left-camera bookkeeping below run under the stereo LK of the new corners
       HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
       if (int rc = finalize_pending(c)) return rc;  // (its results live where this launch writes)
       if (int rc = finalize_right(c)) return rc;    // (idle time: k_select is running)
+      sub(3);
       // stereo LK of the new corners only (count known on the device)
       LkArgs f = make_lk(curL, curR, c->z_new + n_kept, nullptr, c->z_ptsB2, c->z_stA2, c->d_counts,
                          n_max_cnt, 3, 30, 0.01, 0);
@@ -1736,10 +1748,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                          0.01, 0);
       run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC2, c->z_stB2);
       if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lknew_done, cur_stream(c)));
+      sub(4);
     }
-  }
-  if (defer_late)
+    if (defer_late)
+      if (int rc = early_work()) return rc;
+    sub(5);
+  } else if (defer_late) {
     if (int rc = early_work()) return rc;
+  }
   lap(5);
   if (detect) HIPCHK(c, sync_event(c->ev_sel_host));
 
@@ -2106,6 +2122,14 @@ int esvio_fe_destroy(esvio_fe_handle c) {
         tot += c->phase_ms[pub][i] / c->phase_count[pub];
       }
       fprintf(stderr, " | total=%.3f\n", tot);
+    }
+    if (c->phase_count[1]) {
+      static const char* pn[6] = {"Event_setMask", "points + k_select launch", "speculative + chained LK launches",
+                                  "previous frame's right-camera tail", "stereo LK of new corners launch",
+                                  "next batch's prefetch launches"};
+      fprintf(stderr, "[esvio_fe trace] published frames, parts of 'host mask + enqueue', ms/frame:");
+      for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%.3f", pn[i], c->pub_ms[i] / c->phase_count[1]);
+      fprintf(stderr, "\n");
     }
     fprintf(stderr, "[esvio_fe trace]");
     fprintf(stderr, "\n[esvio_fe trace] findFundamentalMat alone: %.3f ms per published frame",
