@@ -689,10 +689,11 @@ def test_replay_random_schedules(oracle, seed):
     ft.close()
 
 
-@pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP"])
+@pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE"])
 def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
     """the measurement switches read at esvio_fe_create (prefetch sequence submitted as a HIP
-    graph; no chained temporal LK; no per-pixel dedup of the Arc* candidates) leave every result
+    graph; no chained temporal LK; no per-pixel dedup of the Arc* candidates; unfused time surface +
+    pyrDown kernels) leave every result
     bit-identical to the oracle"""
     monkeypatch.setenv(opt, "1")
     W, H = 346, 260
