@@ -648,6 +648,35 @@ def test_replay_mode_soak(oracle, lazy, threads, ahead):
     ft.close()
 
 
+def test_replay_hd_shape(oracle):
+    """BASELINE C5's sensor shape (1280x720, not a shipped resolution) with max_cnt 500 / min_dist 14
+    through the replay schedule (three batches ahead, lazy, chained temporal LK, fused time surface +
+    pyramid kernel on 160x90 level-3 tiles): bit-identical to the oracle"""
+    W, H = 1280, 720
+    s = SceneStream(W, H, rate=4e6, seed=9, n_rect=16, size=(40.0, 160.0))
+    batches = [s.next_batch()[:2] for _ in range(8)]
+    pubs = [f % 2 == 0 for f in range(len(batches))]
+    kw = dict(max_cnt=500, min_dist=14, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(True)
+    ft.set_host_threads(3)
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        while announced < min(f + 3, len(batches) - 1):
+            announced += 1
+            Ln, Rn = batches[announced]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pubs[f])
+        r = tr.track_event(t, L, R, pubs[f])
+        ft.finish()
+        _compare_tracks(ft, r, ("hd", f))
+    assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+    assert len(ft.ids) > 100
+    ft.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_replay_random_schedules(oracle, seed):
     """random publish pattern, a random number of batches (0..3) announced ahead of every call, lazy
