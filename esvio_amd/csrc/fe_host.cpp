@@ -528,6 +528,7 @@ struct RansacPool {
   // helpers are kept on the cores that share the caller's L3 (one CCD): an iteration is ~0.5 us of
   // work, so the hand-over has to cost a same-die cache line transfer, not a cross-socket one
   std::vector<int> near_cpus;  // the caller's L3 domain minus the caller's own core (empty: unknown)
+  std::vector<int> l3_cpus;    // the whole domain
   int near_of = -1;            // the CPU that set was made for
 
   void pin_near_caller();
@@ -622,8 +623,8 @@ void RansacPool::pin_near_caller() {
   if (cpu < 0) return;
   if (near_of >= 0) {
     if (cpu == near_of) return;
-    for (int v : near_cpus)
-      if (v == cpu) return;  // (moved within the die: the SMT sibling, or a helper's core — fine)
+    for (int v : l3_cpus)
+      if (v == cpu) return;  // (moved within the die — fine)
   }
   char path[128];
   std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
@@ -631,12 +632,21 @@ void RansacPool::pin_near_caller() {
   std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
   const std::vector<int> self = read_cpu_list(path);
   near_of = cpu;
+  l3_cpus = l3;
   near_cpus.clear();
+  std::vector<int> primary;  // one logical CPU per physical core of the domain, caller's core left out
   for (int v : l3) {
     bool mine = v == cpu;
     for (int w : self) mine = mine || v == w;
-    if (!mine) near_cpus.push_back(v);
+    if (mine) continue;
+    near_cpus.push_back(v);
+    std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", v);
+    const std::vector<int> sib = read_cpu_list(path);
+    if (sib.empty() || sib[0] == v) primary.push_back(v);
   }
+  // a spinning helper on the SMT sibling of another helper (or of the caller) takes issue slots
+  // from it: keep to one hardware thread per core when the domain has enough cores
+  if (primary.size() >= th.size()) near_cpus = primary;
   if (near_cpus.size() < th.size()) {  // unknown topology or a tiny L3 domain: leave it to the OS
     near_cpus.clear();
     return;
