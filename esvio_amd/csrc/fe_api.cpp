@@ -692,14 +692,10 @@ void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int 
     launch_ts_pyr(cur_stream(c), c->S2, t_sync, c->cfg.decay_ms / 1000.0, c->cfg.ignore_polarity, two);
   }
   {
-    ScopedKernel k(c, K_PYR_PAD, 0);
-    launch_pyr_pad(cur_stream(c), two, 2);
-  }
-  {
     uint64_t all = 0;
     for (int l = 0; l <= 3; l++) all += (uint64_t)two[0].w[l] * two[0].h[l];
     ScopedKernel k(c, K_SCHARR, all * 5 * 2);
-    launch_scharr(cur_stream(c), two, 2);
+    launch_pad_scharr(cur_stream(c), two, 2);
   }
 }
 

@@ -144,6 +144,7 @@ void launch_pyr_down(hipStream_t s, const PyrDesc* p, int nimg, int src_level);
 void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay_sec,
                    int ignore_polarity, const PyrDesc* p);
 void launch_pyr_pad(hipStream_t s, const PyrDesc* p, int nimg);
+void launch_pad_scharr(hipStream_t s, const PyrDesc* p, int nimg);  // k_pyr_pad + k_scharr, one launch
 void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg);
 
 // ---- LK ---------------------------------------------------------------------------------

@@ -864,6 +864,64 @@ __global__ __launch_bounds__(256) void k_scharr(PyrPack pk) {
   }
 }
 
+// k_pyr_pad and k_scharr in one launch: the derivative of an edge pixel takes its neighbours by
+// reflect-101 from the interior (= the values the border ring is about to receive), so the two
+// parts do not depend on each other; blocks [0, n_scharr) differentiate, the rest fill the ring.
+__global__ __launch_bounds__(256) void k_pad_scharr(PyrPack pk, int n_scharr) {
+  const PyrDesc& p = pk.p[blockIdx.z];
+  const int level = blockIdx.y;
+  if (level > p.levels) return;
+  const int w = p.w[level], h = p.h[level], stride = p.stride[level];
+  if ((int)blockIdx.x < n_scharr) {
+    const uint8_t* img = p.img[level] + (size_t)kPad * stride + kPad;
+    int* deriv = (int*)(p.deriv[level]) + (size_t)kPad * stride + kPad;
+    const int total = w * h;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += n_scharr * 256) {
+      const int y = i / w, x = i - y * w;
+      const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+      const uint8_t* r0 = img + (size_t)reflect101(y - 1, h) * stride;
+      const uint8_t* r1 = img + (size_t)y * stride;
+      const uint8_t* r2 = img + (size_t)reflect101(y + 1, h) * stride;
+      const int a0 = r0[xm], a1 = r0[x], a2 = r0[xp];
+      const int b0 = r1[xm], b2 = r1[xp];
+      const int c0 = r2[xm], c1 = r2[x], c2 = r2[xp];
+      const int ix = ((a2 + c2) * 3 + b2 * 10) - ((a0 + c0) * 3 + b0 * 10);
+      const int iy = ((c2 - a2) + (c0 - a0)) * 3 + (c1 - a1) * 10;
+      deriv[(size_t)y * stride + x] = (int)(((unsigned)(uint16_t)(int16_t)iy << 16) | (uint16_t)(int16_t)ix);
+    }
+    return;
+  }
+  const int n_pad = gridDim.x - n_scharr;
+  const int pw = w + 2 * kPad;
+  const int band = pw * kPad, side = kPad * h, total = 2 * band + 2 * side;
+  for (int i = ((int)blockIdx.x - n_scharr) * 256 + threadIdx.x; i < total; i += n_pad * 256) {
+    int x, y;
+    if (i < band) {
+      y = i / pw;
+      x = i - y * pw;
+    } else if (i < 2 * band) {
+      const int j = i - band;
+      y = j / pw;
+      x = j - y * pw;
+      y += kPad + h;
+    } else if (i < 2 * band + side) {
+      const int j = i - 2 * band;
+      y = j / kPad;
+      x = j - y * kPad;
+      y += kPad;
+    } else {
+      const int j = i - 2 * band - side;
+      y = j / kPad;
+      x = j - y * kPad;
+      y += kPad;
+      x += kPad + w;
+    }
+    const int sx = reflect101(x - kPad, w), sy = reflect101(y - kPad, h);
+    uint8_t* img = p.img[level];
+    img[(size_t)y * stride + x] = img[(size_t)(sy + kPad) * stride + sx + kPad];
+  }
+}
+
 static PyrPack make_pack(const PyrDesc* p, int nimg) {
   PyrPack pk;
   for (int i = 0; i < nimg; i++) pk.p[i] = p[i];
@@ -881,6 +939,13 @@ void launch_pyr_pad(hipStream_t s, const PyrDesc* p, int nimg) {
   const int total = 2 * pw * kPad + 2 * kPad * p[0].h[0];
   launch_k(k_pyr_pad, dim3((total + 255) / 256, p[0].levels + 1, nimg), dim3(256), 0, s,
                      make_pack(p, nimg));
+}
+void launch_pad_scharr(hipStream_t s, const PyrDesc* p, int nimg) {
+  const int n_scharr = (p[0].w[0] * p[0].h[0] + 255) / 256;
+  const int pw = p[0].w[0] + 2 * kPad;
+  const int n_pad = (2 * pw * kPad + 2 * kPad * p[0].h[0] + 255) / 256;
+  launch_k(k_pad_scharr, dim3(n_scharr + n_pad, p[0].levels + 1, nimg), dim3(256), 0, s,
+           make_pack(p, nimg), n_scharr);
 }
 void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg) {
   const int total = p[0].w[0] * p[0].h[0];
