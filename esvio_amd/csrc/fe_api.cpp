@@ -278,6 +278,7 @@ struct esvio_fe_ctx {
   uint64_t phase_count[2] = {0, 0};
   uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
   double tr_fm_ms = 0;  // time inside find_fundamental_mat alone
+  double tr_fm_max_ms = 0, tr_lift_ms = 0;  // ... its slowest call; the two liftProjective batches
   uint64_t tr_chain_launch = 0, tr_chain_used = 0, tr_chain_cancel = 0, tr_spec_used = 0;
   // (trace only) device-side intervals of the published frame's chain, from timing events
   hipEvent_t ev_dbg_sel_start = nullptr;
@@ -849,6 +850,7 @@ void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
     std::vector<float> un_cur(n * 2), un_prev(n * 2);
     std::vector<double> lx(n), ly(n);
     const double cx = c->W / 2.0, cy = c->H / 2.0;
+    const auto tl = std::chrono::steady_clock::now();
     host::lift_projective_batch(cam, &c->prev_pts[0].x, (int)n, lx.data(), ly.data());
     for (size_t i = 0; i < n; i++) {  // p[2] == 1.0: x / 1.0 is exact
       un_prev[2 * i] = (float)(FOCAL * lx[i] / 1.0 + cx);
@@ -863,8 +865,12 @@ void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
     const auto t0 = std::chrono::steady_clock::now();
     host::find_fundamental_mat(un_prev.data(), un_cur.data(), (int)c->cur_pts.size(),
                                c->cfg.f_threshold, 0.99, status.data(), c->pool);
-    if (c->trace)
-      c->tr_fm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (c->trace) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      c->tr_fm_ms += ms;
+      c->tr_fm_max_ms = std::max(c->tr_fm_max_ms, ms);
+      c->tr_lift_ms += std::chrono::duration<double, std::milli>(t0 - tl).count();
+    }
     reduce_vector(c->prev_pts, status);
     reduce_vector(c->cur_pts, status);
     reduce_vector(c->ids, status);
@@ -2128,8 +2134,11 @@ int esvio_fe_destroy(esvio_fe_handle c) {
       fprintf(stderr, "\n");
     }
     fprintf(stderr, "[esvio_fe trace]");
-    fprintf(stderr, "\n[esvio_fe trace] findFundamentalMat alone: %.3f ms per published frame",
-            c->phase_count[1] ? c->tr_fm_ms / c->phase_count[1] : 0.0);
+    fprintf(stderr, "\n[esvio_fe trace] findFundamentalMat alone: %.3f ms per published frame (slowest call %.3f ms, "
+            "%.3f without it); the two liftProjective batches before it: %.3f ms",
+            c->phase_count[1] ? c->tr_fm_ms / c->phase_count[1] : 0.0, c->tr_fm_max_ms,
+            c->phase_count[1] > 1 ? (c->tr_fm_ms - c->tr_fm_max_ms) / (c->phase_count[1] - 1) : 0.0,
+            c->phase_count[1] ? c->tr_lift_ms / c->phase_count[1] : 0.0);
     if (c->tr_gpu_n)
       fprintf(stderr, "\n[esvio_fe trace] device: k_select %.1f us; select end -> next frame's temporal LK done "
               "%.1f us, -> chained one done %.1f us (its frame's pyramids: %.1f us); host: select launch -> "

@@ -497,12 +497,39 @@ inline void cpu_relax() {
 #endif
 }
 
-struct IterResult {
-  int nm;
+struct alignas(64) IterResult {
+  std::atomic<uint32_t> tag{0};  // == the job's epoch once the rest is complete (same cache line as
+  int nm;                        // nm / good: the replay touches one line per iteration)
   int good[3];
   double models[27];
 };
 }  // namespace
+
+// State of one job.  Two of them alternate (job parity): a helper that is descheduled in the middle
+// of an iteration keeps working on its own job's buffers and cannot touch the next job's; the
+// caller does not wait for it (it redoes an iteration whose result does not arrive, and only a
+// buffer's next use, two jobs later, waits for helpers still inside it).
+struct RansacJob {
+  alignas(64) std::atomic<int> next{0};    // next iteration to hand out
+  alignas(64) std::atomic<int> avail{0};   // subsets drawn so far
+  alignas(64) std::atomic<int> bound{0};   // best inlier count among the replayed iterations
+  alignas(64) std::atomic<int> active{0};  // helpers inside this job
+  std::vector<double> xy;                  // x1 | y1 | x2 | y2, count each
+  int count = 0;
+  double thr = 0;
+  std::vector<float> subsets;  // [iteration][s1(14) | s2(14)]
+  std::unique_ptr<IterResult[]> res;
+
+  void evaluate(int idx, IterResult& r, std::vector<uint8_t>& scratch) const {
+    const float* s = &subsets[(size_t)idx * 28];
+    r.nm = seven_point(s, s + 14, r.models);
+    const int need = bound.load(std::memory_order_relaxed);
+    if ((int)scratch.size() < count) scratch.resize(count);
+    const double *x1 = xy.data(), *y1 = x1 + count, *x2 = y1 + count, *y2 = x2 + count;
+    for (int k = 0; k < r.nm; k++)
+      r.good[k] = mark_inliers_bounded(x1, y1, x2, y2, count, r.models + 9 * k, scratch.data(), thr, need);
+  }
+};
 
 struct RansacPool {
   std::vector<std::thread> th;
@@ -511,20 +538,8 @@ struct RansacPool {
   uint64_t wake_seq = 0;  // (under mu)
   std::atomic<int> sleepers{0};
   std::atomic<bool> quit{false};
-  // ---- the open job
-  alignas(64) std::atomic<uint32_t> epoch{0};  // odd while a job is open
-  alignas(64) std::atomic<int> next{0};        // next iteration to hand out
-  alignas(64) std::atomic<int> avail{0};       // subsets drawn so far
-  alignas(64) std::atomic<int> bound{0};       // best inlier count among the replayed iterations
-  alignas(64) std::atomic<int> stop{0};
-  alignas(64) std::atomic<int> active{0};      // helpers inside the job
-  const double *x1 = nullptr, *y1 = nullptr, *x2 = nullptr, *y2 = nullptr;
-  int count = 0;
-  double thr = 0;
-  std::vector<float> subsets;  // [iteration][s1(14) | s2(14)]
-  std::vector<IterResult> res;
-  std::unique_ptr<std::atomic<uint8_t>[]> ready;
-  int used = 0;  // ready[] entries to clear before the next job
+  alignas(64) std::atomic<uint32_t> epoch{0};  // odd while a job is open; job (epoch >> 1) & 1
+  RansacJob job[2];
   // helpers are kept on the cores that share the caller's L3 (one CCD): an iteration is ~0.5 us of
   // work, so the hand-over has to cost a same-die cache line transfer, not a cross-socket one
   std::vector<int> near_cpus;  // the caller's L3 domain minus the caller's own core (empty: unknown)
@@ -532,17 +547,6 @@ struct RansacPool {
   int near_of = -1;            // the CPU that set was made for
 
   void pin_near_caller();
-
-  void evaluate(int idx, std::vector<uint8_t>& scratch) {
-    IterResult& r = res[idx];
-    const float* s = &subsets[(size_t)idx * 28];
-    r.nm = seven_point(s, s + 14, r.models);
-    const int need = bound.load(std::memory_order_relaxed);
-    if ((int)scratch.size() < count) scratch.resize(count);
-    for (int k = 0; k < r.nm; k++)
-      r.good[k] = mark_inliers_bounded(x1, y1, x2, y2, count, r.models + 9 * k, scratch.data(), thr, need);
-    ready[idx].store(1, std::memory_order_release);
-  }
 
   void helper() {
     std::vector<uint8_t> scratch;
@@ -565,24 +569,25 @@ struct RansacPool {
         }
         continue;
       }
-      active.fetch_add(1, std::memory_order_acq_rel);
-      if (epoch.load(std::memory_order_acquire) == e) {
-        while (!stop.load(std::memory_order_acquire)) {
-          const int idx = next.fetch_add(1, std::memory_order_relaxed);
-          if (idx >= kRansacMaxIters) break;
-          bool go = true;
-          while (avail.load(std::memory_order_acquire) <= idx) {
-            if (stop.load(std::memory_order_acquire)) {
-              go = false;
-              break;
-            }
-            cpu_relax();
+      RansacJob& J = job[(e >> 1) & 1];
+      J.active.fetch_add(1, std::memory_order_acq_rel);
+      // (the job may have closed — and this buffer's next job opened — in between: then leave)
+      while (epoch.load(std::memory_order_acquire) == e) {
+        const int idx = J.next.fetch_add(1, std::memory_order_relaxed);
+        if (idx >= kRansacMaxIters) break;
+        bool go = true;
+        while (J.avail.load(std::memory_order_acquire) <= idx) {
+          if (epoch.load(std::memory_order_acquire) != e) {
+            go = false;
+            break;
           }
-          if (!go) break;
-          evaluate(idx, scratch);
+          cpu_relax();
         }
+        if (!go) break;
+        J.evaluate(idx, J.res[idx], scratch);
+        J.res[idx].tag.store(e, std::memory_order_release);
       }
-      active.fetch_sub(1, std::memory_order_release);
+      J.active.fetch_sub(1, std::memory_order_release);
       seen = e;
       idle_since = std::chrono::steady_clock::now();
     }
@@ -662,10 +667,10 @@ void RansacPool::pin_near_caller() {
 RansacPool* ransac_pool_create(int helpers) {
   if (helpers <= 0) return nullptr;
   RansacPool* p = new RansacPool();
-  p->subsets.resize((size_t)kRansacMaxIters * 28);
-  p->res.resize(kRansacMaxIters);
-  p->ready.reset(new std::atomic<uint8_t>[kRansacMaxIters]);
-  for (int i = 0; i < kRansacMaxIters; i++) p->ready[i].store(0, std::memory_order_relaxed);
+  for (RansacJob& J : p->job) {
+    J.subsets.resize((size_t)kRansacMaxIters * 28);
+    J.res.reset(new IterResult[kRansacMaxIters]);
+  }
   for (int i = 0; i < helpers; i++) p->th.emplace_back([p] { p->helper(); });
   p->pin_near_caller();
   return p;
@@ -699,67 +704,80 @@ namespace {
 int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, double thr, double conf,
                   const double* xy, uint8_t* status) {
   const int kModelPoints = 7;
-  for (int i = 0; i < P->used; i++) P->ready[i].store(0, std::memory_order_relaxed);
-  P->used = 0;
-  P->x1 = xy;
-  P->y1 = xy + count;
-  P->x2 = xy + 2 * (size_t)count;
-  P->y2 = xy + 3 * (size_t)count;
-  P->count = count;
-  P->thr = thr;
-  P->next.store(0, std::memory_order_relaxed);
-  P->avail.store(0, std::memory_order_relaxed);
-  P->bound.store(kModelPoints - 1, std::memory_order_relaxed);
-  P->stop.store(0, std::memory_order_relaxed);
-  P->epoch.fetch_add(1, std::memory_order_release);  // -> odd: open
+  const uint32_t e = P->epoch.load(std::memory_order_relaxed) + 1;  // (odd: this job's tag)
+  RansacJob& J = P->job[(e >> 1) & 1];
+  // a helper that stalled inside this buffer's previous job (two jobs ago) is waited for here
+  while (J.active.load(std::memory_order_acquire) != 0) cpu_relax();
+  J.xy.assign(xy, xy + 4 * (size_t)count);
+  J.count = count;
+  J.thr = thr;
+  J.next.store(0, std::memory_order_relaxed);
+  J.avail.store(0, std::memory_order_relaxed);
+  J.bound.store(kModelPoints - 1, std::memory_order_relaxed);
+  P->epoch.store(e, std::memory_order_release);  // open
   ransac_pool_wake(P);
 
   OcvRng rng;
   std::vector<uint8_t> scratch(count);
-  int drawn = 0, rp = 0, niters = kRansacMaxIters, best_good = 0, best_iter = -1, best_k = 0;
-  bool draw_failed = false;
+  IterResult local;
+  double best_F[9];
+  int drawn = 0, rp = 0, niters = kRansacMaxIters, best_good = 0;
+  bool draw_failed = false, have_best = false;
+  unsigned stalled = 0;
   for (;;) {
     // replay, in iteration order, what has been evaluated
-    while (rp < niters && rp < drawn && P->ready[rp].load(std::memory_order_acquire)) {
-      const IterResult& r = P->res[rp];
-      for (int k = 0; k < r.nm; k++)
-        if (r.good[k] > std::max(best_good, kModelPoints - 1)) {
-          best_good = r.good[k];
-          best_iter = rp;
-          best_k = k;
+    while (rp < niters && rp < drawn) {
+      const IterResult* r = nullptr;
+      __builtin_prefetch(&J.res[std::min(rp + 4, kRansacMaxIters - 1)]);
+      if (J.res[rp].tag.load(std::memory_order_acquire) == e) {
+        r = &J.res[rp];
+      } else if (stalled > 64) {
+        // whoever took this iteration is not delivering (descheduled?): do it here, the late
+        // result is simply never looked at
+        J.evaluate(rp, local, scratch);
+        r = &local;
+      } else {
+        break;
+      }
+      stalled = 0;
+      for (int k = 0; k < r->nm; k++)
+        if (r->good[k] > std::max(best_good, kModelPoints - 1)) {
+          best_good = r->good[k];
+          std::memcpy(best_F, r->models + 9 * k, sizeof(best_F));
+          have_best = true;
           niters = update_num_iters(conf, (double)(count - best_good) / count, kModelPoints, niters);
         }
       rp++;
-      P->bound.store(std::max(best_good, kModelPoints - 1), std::memory_order_relaxed);
+      J.bound.store(std::max(best_good, kModelPoints - 1), std::memory_order_relaxed);
     }
     if (rp >= niters || (draw_failed && rp >= drawn)) break;
     if (!draw_failed && drawn < niters && drawn - rp < kRansacWindow) {
       for (int j = 0; j < 4 && drawn < niters; j++) {
-        float* s = &P->subsets[(size_t)drawn * 28];
+        float* s = &J.subsets[(size_t)drawn * 28];
         if (!draw_subset(m1, m2, count, s, s + 14, rng, 10000)) {
           draw_failed = true;
           break;
         }
         drawn++;
       }
-      P->avail.store(drawn, std::memory_order_release);
+      J.avail.store(drawn, std::memory_order_release);
       continue;
     }
     // nothing to draw: take an iteration like a helper does
-    int idx = P->next.load(std::memory_order_relaxed);
-    if (idx < drawn && P->next.compare_exchange_strong(idx, idx + 1, std::memory_order_relaxed))
-      P->evaluate(idx, scratch);
-    else
+    int idx = J.next.load(std::memory_order_relaxed);
+    if (idx < drawn && J.next.compare_exchange_strong(idx, idx + 1, std::memory_order_relaxed)) {
+      J.evaluate(idx, J.res[idx], scratch);
+      J.res[idx].tag.store(e, std::memory_order_release);
+    } else {
       cpu_relax();
+      stalled++;
+    }
   }
-  P->used = std::min(kRansacMaxIters, std::max(drawn, P->next.load(std::memory_order_relaxed)));
-  P->stop.store(1, std::memory_order_release);
-  P->epoch.fetch_add(1, std::memory_order_release);  // -> even: closed
-  while (P->active.load(std::memory_order_acquire) != 0) cpu_relax();
+  P->epoch.store(e + 1, std::memory_order_release);  // closed; helpers drop out on their own
   if (drawn == 0) return 0;  // (the very first draw failed)
-  if (best_iter >= 0) {
-    const float t = (float)(thr * thr);
-    score_block(P->x1, P->y1, P->x2, P->y2, 0, count, P->res[best_iter].models + 9 * best_k, t, status);
+  if (have_best) {
+    const double *x1 = J.xy.data(), *y1 = x1 + count, *x2 = y1 + count, *y2 = x2 + count;
+    score_block(x1, y1, x2, y2, 0, count, best_F, (float)(thr * thr), status);
   }
   return best_good;
 }
