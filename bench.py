@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=0,
                     help="host threads of rejectWithF_event's RANSAC (esvio_fe_set_host_threads; "
                          "the result does not depend on it); 1 = the calling thread only; "
-                         "0 = min(6, usable CPUs / (2 * ranks)): the helpers spin, so all ranks' "
+                         "0 = min(8, usable CPUs / (2 * ranks)): the helpers spin, so all ranks' "
                          "threads together have to stay inside the CPU quota")
     ap.add_argument("--split", choices=["rigs", "camera"], default="rigs",
                     help="N>1 sharding: one independent stereo rig per GPU (weak scaling, default) or "
@@ -224,7 +224,7 @@ def main():
     if lazy:
         ft.set_lazy_new_stereo(True)
     if args.host_threads <= 0:
-        args.host_threads = max(1, min(6, usable_cpus() // (2 * max(world, 1))))
+        args.host_threads = max(1, min(8, usable_cpus() // (2 * max(world, 1))))
     if args.host_threads > 1:
         ft.set_host_threads(args.host_threads)
 

@@ -498,11 +498,11 @@ inline void cpu_relax() {
 }
 
 struct alignas(64) IterResult {
-  std::atomic<uint32_t> tag{0};  // == the job's epoch once the rest is complete (same cache line as
-  int nm;                        // nm / good: the replay touches one line per iteration)
+  int nm;
   int good[3];
   double models[27];
 };
+constexpr uint32_t kCollinear = 0xffffffffu;  // summary code: the drawn subset fails checkSubset
 }  // namespace
 
 // State of one job.  Two of them alternate (job parity): a helper that is descheduled in the middle
@@ -515,19 +515,44 @@ struct RansacJob {
   alignas(64) std::atomic<int> bound{0};   // best inlier count among the replayed iterations
   alignas(64) std::atomic<int> active{0};  // helpers inside this job
   std::vector<double> xy;                  // x1 | y1 | x2 | y2, count each
+  std::vector<float> pts;                  // m1 | m2 (interleaved x,y), 2*count each
   int count = 0;
   double thr = 0;
-  std::vector<float> subsets;  // [iteration][s1(14) | s2(14)]
+  // The caller only runs the cv::RNG index draws (7 distinct indices per iteration, ~15 ns); the
+  // gather and getSubset's collinearity test are part of the evaluation.  A subset that fails the
+  // test (the reference then redraws, consuming more random numbers) is reported as kCollinear and
+  // the caller continues sequentially from that iteration's saved generator state.
+  std::vector<int32_t> picks;  // [iteration][8]
   std::unique_ptr<IterResult[]> res;
+  // per iteration (epoch << 32) | max inlier count of its models (or kCollinear): 8 iterations per
+  // cache line, so the in-order replay costs ~1/8 of a line transfer per iteration and reads the
+  // full result only when the iteration improves on the best model
+  std::unique_ptr<std::atomic<uint64_t>[]> summary;
 
-  void evaluate(int idx, IterResult& r, std::vector<uint8_t>& scratch) const {
-    const float* s = &subsets[(size_t)idx * 28];
-    r.nm = seven_point(s, s + 14, r.models);
+  uint32_t evaluate(int idx, IterResult& r, std::vector<uint8_t>& scratch) const {
+    float s1[14], s2[14];
+    const float *m1 = pts.data(), *m2 = m1 + 2 * (size_t)count;
+    const int32_t* pk = &picks[(size_t)idx * 8];
+    for (int i = 0; i < 7; i++) {
+      s1[2 * i] = m1[2 * pk[i]];
+      s1[2 * i + 1] = m1[2 * pk[i] + 1];
+      s2[2 * i] = m2[2 * pk[i]];
+      s2[2 * i + 1] = m2[2 * pk[i] + 1];
+    }
+    if (last_point_collinear(s1, 7) || last_point_collinear(s2, 7)) {
+      r.nm = -1;
+      return kCollinear;
+    }
+    r.nm = seven_point(s1, s2, r.models);
     const int need = bound.load(std::memory_order_relaxed);
     if ((int)scratch.size() < count) scratch.resize(count);
     const double *x1 = xy.data(), *y1 = x1 + count, *x2 = y1 + count, *y2 = x2 + count;
-    for (int k = 0; k < r.nm; k++)
+    int best = 0;
+    for (int k = 0; k < r.nm; k++) {
       r.good[k] = mark_inliers_bounded(x1, y1, x2, y2, count, r.models + 9 * k, scratch.data(), thr, need);
+      best = std::max(best, r.good[k]);
+    }
+    return (uint32_t)best;
   }
 };
 
@@ -584,8 +609,8 @@ struct RansacPool {
           cpu_relax();
         }
         if (!go) break;
-        J.evaluate(idx, J.res[idx], scratch);
-        J.res[idx].tag.store(e, std::memory_order_release);
+        const uint32_t code = J.evaluate(idx, J.res[idx], scratch);
+        J.summary[idx].store(((uint64_t)e << 32) | code, std::memory_order_release);
       }
       J.active.fetch_sub(1, std::memory_order_release);
       seen = e;
@@ -668,8 +693,10 @@ RansacPool* ransac_pool_create(int helpers) {
   if (helpers <= 0) return nullptr;
   RansacPool* p = new RansacPool();
   for (RansacJob& J : p->job) {
-    J.subsets.resize((size_t)kRansacMaxIters * 28);
+    J.picks.resize((size_t)kRansacMaxIters * 8);
     J.res.reset(new IterResult[kRansacMaxIters]);
+    J.summary.reset(new std::atomic<uint64_t>[kRansacMaxIters]);
+    for (int i = 0; i < kRansacMaxIters; i++) J.summary[i].store(0, std::memory_order_relaxed);
   }
   for (int i = 0; i < helpers; i++) p->th.emplace_back([p] { p->helper(); });
   p->pin_near_caller();
@@ -709,6 +736,9 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
   // a helper that stalled inside this buffer's previous job (two jobs ago) is waited for here
   while (J.active.load(std::memory_order_acquire) != 0) cpu_relax();
   J.xy.assign(xy, xy + 4 * (size_t)count);
+  J.pts.resize(4 * (size_t)count);
+  std::memcpy(J.pts.data(), m1, 2 * (size_t)count * sizeof(float));
+  std::memcpy(J.pts.data() + 2 * (size_t)count, m2, 2 * (size_t)count * sizeof(float));
   J.count = count;
   J.thr = thr;
   J.next.store(0, std::memory_order_relaxed);
@@ -719,44 +749,60 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
 
   OcvRng rng;
   std::vector<uint8_t> scratch(count);
+  std::vector<uint64_t> rng_before;  // generator state ahead of each iteration's draw
+  rng_before.reserve(256);
   IterResult local;
   double best_F[9];
+  const double *x1 = J.xy.data(), *y1 = x1 + count, *x2 = y1 + count, *y2 = x2 + count;
   int drawn = 0, rp = 0, niters = kRansacMaxIters, best_good = 0;
-  bool draw_failed = false, have_best = false;
+  bool have_best = false;
+  int collinear_at = -1;
   unsigned stalled = 0;
-  for (;;) {
+  while (collinear_at < 0) {
     // replay, in iteration order, what has been evaluated
     while (rp < niters && rp < drawn) {
-      const IterResult* r = nullptr;
-      __builtin_prefetch(&J.res[std::min(rp + 4, kRansacMaxIters - 1)]);
-      if (J.res[rp].tag.load(std::memory_order_acquire) == e) {
-        r = &J.res[rp];
+      const IterResult* r = &J.res[rp];
+      const uint64_t sm = J.summary[rp].load(std::memory_order_acquire);
+      uint32_t code;
+      if ((uint32_t)(sm >> 32) == e) {
+        code = (uint32_t)sm;
       } else if (stalled > 64) {
         // whoever took this iteration is not delivering (descheduled?): do it here, the late
         // result is simply never looked at
-        J.evaluate(rp, local, scratch);
+        code = J.evaluate(rp, local, scratch);
         r = &local;
       } else {
         break;
       }
       stalled = 0;
-      for (int k = 0; k < r->nm; k++)
-        if (r->good[k] > std::max(best_good, kModelPoints - 1)) {
-          best_good = r->good[k];
-          std::memcpy(best_F, r->models + 9 * k, sizeof(best_F));
-          have_best = true;
-          niters = update_num_iters(conf, (double)(count - best_good) / count, kModelPoints, niters);
-        }
+      if (code == kCollinear) {
+        collinear_at = rp;
+        break;
+      }
+      if ((int)code > std::max(best_good, kModelPoints - 1))
+        for (int k = 0; k < r->nm; k++)
+          if (r->good[k] > std::max(best_good, kModelPoints - 1)) {
+            best_good = r->good[k];
+            std::memcpy(best_F, r->models + 9 * k, sizeof(best_F));
+            have_best = true;
+            niters = update_num_iters(conf, (double)(count - best_good) / count, kModelPoints, niters);
+          }
       rp++;
       J.bound.store(std::max(best_good, kModelPoints - 1), std::memory_order_relaxed);
     }
-    if (rp >= niters || (draw_failed && rp >= drawn)) break;
-    if (!draw_failed && drawn < niters && drawn - rp < kRansacWindow) {
-      for (int j = 0; j < 4 && drawn < niters; j++) {
-        float* s = &J.subsets[(size_t)drawn * 28];
-        if (!draw_subset(m1, m2, count, s, s + 14, rng, 10000)) {
-          draw_failed = true;
-          break;
+    if (rp >= niters || collinear_at >= 0) break;
+    if (drawn < niters && drawn - rp < kRansacWindow) {
+      for (int j = 0; j < 8 && drawn < niters; j++) {  // RANSACPointSetRegistrator::getSubset's draws
+        rng_before.push_back(rng.s);
+        int32_t* pk = &J.picks[(size_t)drawn * 8];
+        for (int i = 0; i < 7; i++) {
+          int pick, q;
+          for (;;) {
+            pick = pk[i] = rng.uniform(0, count);
+            for (q = 0; q < i; q++)
+              if (pick == pk[q]) break;
+            if (q == i) break;
+          }
         }
         drawn++;
       }
@@ -766,19 +812,37 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
     // nothing to draw: take an iteration like a helper does
     int idx = J.next.load(std::memory_order_relaxed);
     if (idx < drawn && J.next.compare_exchange_strong(idx, idx + 1, std::memory_order_relaxed)) {
-      J.evaluate(idx, J.res[idx], scratch);
-      J.res[idx].tag.store(e, std::memory_order_release);
+      const uint32_t code = J.evaluate(idx, J.res[idx], scratch);
+      J.summary[idx].store(((uint64_t)e << 32) | code, std::memory_order_release);
     } else {
       cpu_relax();
       stalled++;
     }
   }
   P->epoch.store(e + 1, std::memory_order_release);  // closed; helpers drop out on their own
-  if (drawn == 0) return 0;  // (the very first draw failed)
-  if (have_best) {
-    const double *x1 = J.xy.data(), *y1 = x1 + count, *x2 = y1 + count, *y2 = x2 + count;
-    score_block(x1, y1, x2, y2, 0, count, best_F, (float)(thr * thr), status);
+  if (collinear_at >= 0) {
+    // the loop as the reference runs it, from the iteration whose first subset was rejected
+    rng.s = rng_before[collinear_at];
+    float s1[14], s2[14];
+    for (int iter = collinear_at; iter < niters; iter++) {
+      if (!draw_subset(m1, m2, count, s1, s2, rng, 10000)) {
+        if (iter == 0) return 0;
+        break;
+      }
+      const int nm = seven_point(s1, s2, local.models);
+      for (int k = 0; k < nm; k++) {
+        const int good = mark_inliers_bounded(x1, y1, x2, y2, count, local.models + 9 * k, scratch.data(), thr,
+                                              std::max(best_good, kModelPoints - 1));
+        if (good > std::max(best_good, kModelPoints - 1)) {
+          best_good = good;
+          std::memcpy(best_F, local.models + 9 * k, sizeof(best_F));
+          have_best = true;
+          niters = update_num_iters(conf, (double)(count - good) / count, kModelPoints, niters);
+        }
+      }
+    }
   }
+  if (have_best) score_block(x1, y1, x2, y2, 0, count, best_F, (float)(thr * thr), status);
   return best_good;
 }
 }  // namespace
