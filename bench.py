@@ -112,6 +112,28 @@ def usable_cpus():
     return n
 
 
+def bind_rank_to_cores(local_rank, n_local):
+    """N ranks on one node: give each rank its own contiguous block of physical cores (with all their
+    hardware threads), so that one rank's spinning RANSAC helpers — which stay on the calling
+    thread's L3 domain — never share a core with another rank's threads.  Returns the number of
+    cores of the block, or None when the topology cannot be read."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        cores = {}
+        for c in allowed:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                cores.setdefault(f.read().strip(), []).append(c)
+        keys = sorted(cores, key=lambda k: min(cores[k]))
+        per = len(keys) // n_local
+        if per < 1:
+            return None
+        mine = keys[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, {c for k in mine for c in cores[k]})
+        return len(mine)
+    except Exception:
+        return None
+
+
 def cpu_all_cores(batches, args, W, H):
     """besides the like-for-like single-core figure, one independent oracle tracker per
     host core over the same batches, all started together; value = all events / slowest process."""
@@ -161,6 +183,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    total_cpus = usable_cpus()  # (before this rank is bound to its share of the cores)
+    if world > 1:
+        bind_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     import torch
 
     if not torch.cuda.is_available():
@@ -224,7 +249,7 @@ def main():
     if lazy:
         ft.set_lazy_new_stereo(True)
     if args.host_threads <= 0:
-        args.host_threads = max(1, min(8, usable_cpus() // (2 * max(world, 1))))
+        args.host_threads = max(1, min(8, total_cpus // (2 * max(world, 1))))
     if args.host_threads > 1:
         ft.set_host_threads(args.host_threads)
 
