@@ -2124,9 +2124,8 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         }
         continue;
       }
-      while (accepted < a.max_corners) {
-        const unsigned long long m = __ballot(alive);
-        if (!m) break;
+      unsigned long long m = m_alive;  // (live candidates of this sub-chunk, in stream order)
+      while (m && accepted < a.max_corners) {
         const int first = __ffsll((long long)m) - 1;
         const int ax = __builtin_amdgcn_readlane(x, first);
         const int ay = __builtin_amdgcn_readlane(y, first);
@@ -2152,11 +2151,14 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
           stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
           stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
         }
+        m &= m - 1ull;
+        if (!m) break;  // (the usual case once the image has filled up: one live candidate)
         // ... and kill this sub-chunk's remaining candidates geometrically: inside the disc iff
-        // |dx| <= hw[|dy|] (the same table the stamp uses), so no LDS round trip per accept
+        // |dx| <= hw[|dy|] (the same table the stamp uses), so no bitmap round trip per accept
         const int dy = y > ay ? y - ay : ay - y, dx = x > ax ? x - ax : ax - x;
         const int hwd = hwtab[min(dy, 63)];
         alive = alive && lane > first && !(dy <= r && dx <= hwd);
+        m = __ballot(alive);
       }
       if (accepted >= a.max_corners) break;
     }
