@@ -2059,6 +2059,8 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         const int room = a.max_corners - accepted;
         while (rem && __builtin_popcountll(acc) < room) {
           // a group of live candidates, staged so that the table look-ups are in flight together
+          // (candidates the previous groups' discs have already killed are not looked at again)
+          rem &= ~dead;
           unsigned long long bit[kSelectGroup], Bdy[kSelectGroup];
           int dxs[kSelectGroup], hws[kSelectGroup];
 #pragma unroll
