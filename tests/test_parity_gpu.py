@@ -73,13 +73,14 @@ def test_sae_adversarial_duplicates(oracle):
 
 
 def test_sae_segment_lengths_around_the_wave_path(oracle):
-    """per-pixel segments of every length around the hand-over to the wave-per-segment kernel (16/17)
-    and around its 64-event step (63..65, 127..129, 200): long same-polarity bursts inside the
-    refractory window, polarity flips, equal stamps and stamps going BACKWARDS inside the batch;
+    """per-pixel segments of every length around the grouped fetch (8 positions per step) and the
+    wave width (63..65, 127..129), up to 1600 events on one pixel: long same-polarity bursts inside
+    the refractory window, polarity flips, equal stamps and stamps going BACKWARDS inside the batch;
     two batches so the carried-in state matters"""
     W, H = 346, 260
     rng = np.random.default_rng(11)
-    lengths = [1, 2, 15, 16, 17, 18, 31, 63, 64, 65, 66, 127, 128, 129, 200, 513]
+    lengths = [1, 2, 15, 16, 17, 18, 31, 63, 64, 65, 66, 127, 128, 129, 200, 511, 512, 513, 514, 575,
+               576, 577, 1025, 1600]
     ft = _mk(W, H)
     det = oracle.Detector(W, H)
     for batch in range(2):
