@@ -138,6 +138,8 @@ struct esvio_fe_ctx {
   size_t ev_cap = 0;
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr;
   size_t sort_cap = 0, hist_cap = 0;
+  size_t sae_ev_min = (size_t)1 << 20;  // batches of at least this many events: k_sae_apply_ev
+  uint8_t* sae_marks = nullptr;         // [sort_cap] its per-event "stores L / stores S" marks
   unsigned long long* d_rejected = nullptr;
   // left: slots 0..kLeftSlots-1 rotate (prev, cur, up to kPrefetchDepth being prefetched);
   // right: the kRightSlots after them (cur + prefetched)
@@ -413,6 +415,9 @@ int ensure_sort_capacity(esvio_fe_ctx* c, size_t n) {
       if (int rc = dev_alloc(c, &c->vals[i], cap)) return rc;
     }
     c->sort_cap = cap;
+    if (c->sae_marks) (void)hipFree(c->sae_marks);
+    c->sae_marks = nullptr;
+    if (int rc = dev_alloc(c, &c->sae_marks, cap)) return rc;
   }
   // [ghist + tickets | lookback for every pass]
   const size_t head = ((size_t)kRadixMaxPasses << kRadixMaxBits) + 64;
@@ -590,8 +595,12 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
   }
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
-    launch_sae_apply(cur_stream(c), c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
-                     c->cfg.feature_filter_threshold, c->invalid_key, c->hist, head);
+    if (n >= c->sae_ev_min)  // many events per pixel: one lane per event
+      launch_sae_apply_ev(cur_stream(c), c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
+                          c->cfg.feature_filter_threshold, c->invalid_key, c->hist, head, c->sae_marks);
+    else
+      launch_sae_apply(cur_stream(c), c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
+                       c->cfg.feature_filter_threshold, c->invalid_key, c->hist, head);
   }
   return 0;
 }
@@ -2154,7 +2163,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->tr_detect ? (double)c->tr_cand / c->tr_detect : 0.0,
             c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
-  void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist,
+  void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
@@ -2297,6 +2306,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
   c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
+  if (const char* v = getenv("ESVIO_FE_SAE_EV_MIN")) c->sae_ev_min = (size_t)strtoull(v, nullptr, 10);
   for (int i = 0; i < kRightSlots; i++)
     if ((rc = dev_alloc(c, &c->d_first[i], (size_t)c->P))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_slots, std::max<size_t>(M, 1)))) return bail(rc);

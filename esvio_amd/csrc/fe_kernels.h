@@ -119,6 +119,12 @@ void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals,
                       const EventRec* evL, uint32_t nL, const EventRec* evR, double2* L2,
                       double2* S2, double filter_threshold, uint32_t invalid_key,
                       uint32_t* sort_scratch, uint32_t sort_scratch_words);
+// the same update with one lane per EVENT instead of one per pixel (see k_sae_apply_ev): for batches
+// with many events per pixel, where the per-pixel walk leaves most lanes idle
+void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* vals, uint32_t n,
+                         const EventRec* evL, uint32_t nL, const EventRec* evR, double2* L2,
+                         double2* S2, double filter_threshold, uint32_t invalid_key,
+                         uint32_t* sort_scratch, uint32_t sort_scratch_words, uint8_t* marks /* [n] */);
 
 // ---- time surface -----------------------------------------------------------------------
 // renders ncam cameras (S2 + cam*P) into level-0 interiors of dst[cam]

@@ -453,6 +453,178 @@ void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals,
                      invalid_key, sort_scratch, sort_scratch_words);
 }
 
+// ---- per-event form of the same update -------------------------------------------------------
+// Every sorted position gets a lane.  What an event needs from its pixel's history is only the time
+// of the nearest earlier event of its own and of the other polarity (that IS L[p] / L[!p] when it is
+// processed), so pass flags are computed for all events at once; L[q] ends up as the time of the
+// pixel's last event of polarity q, S[q] as that of its last PASSING event of polarity q; the lane
+// that finds itself to be that event marks it, and a second launch (k_sae_apply_ev_write) stores
+// the marked events' times — the lanes that fall back to the stored planes (no earlier event of
+// that polarity in the batch) and the lanes that replace them can sit in different waves, so reads
+// and writes of the planes are kept in different launches.  Inside a wave "nearest earlier" /
+// "any later" are ballots restricted to the lane's run of equal keys plus a lane shuffle; only the
+// first run of a wave can have history before the wave and only the last run a future after it —
+// those two are resolved by the whole wave scanning 64 positions at a time backwards (until both
+// polarities are found or the segment starts) and forwards (re-evaluating the pass rule with the
+// carried times, until what this wave's candidates need is decided or the segment ends).
+__global__ __launch_bounds__(256) void k_sae_apply_ev(const uint32_t* __restrict__ keys,
+                                                      const uint32_t* __restrict__ vals, uint32_t n,
+                                                      const uint4* __restrict__ evL, uint32_t nL,
+                                                      const uint4* __restrict__ evR,
+                                                      double2* __restrict__ L2,
+                                                      double2* __restrict__ S2, double thr,
+                                                      uint32_t invalid_key,
+                                                      uint32_t* __restrict__ sort_scratch,
+                                                      uint32_t sort_scratch_words,
+                                                      uint8_t* __restrict__ marks) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < sort_scratch_words) sort_scratch[i] = 0;
+  const int lane = lane_id();
+  const uint32_t base = i - (uint32_t)lane;
+  if (base >= n) return;  // (wave-uniform)
+  const bool in = i < n;
+  const uint32_t k = in ? keys[i] : 0xffffffffu;
+  const bool valid = in && k != invalid_key;
+  const uint32_t idx = vals[in ? i : n - 1];
+  const uint4 ev = idx >= nL ? evR[idx - nL] : evL[idx];
+  const double t = ev_time(ev.y, ev.z);
+  const bool p = (ev.w & 0xffu) != 0;
+  auto msb = [](unsigned long long m) { return 63 - __clzll((long long)m); };
+  const unsigned long long self = 1ull << lane, below = self - 1ull, above = ~(below | self);
+  // this lane's run of equal keys inside the wave: lanes startL..endL
+  const uint32_t k_up = __shfl_up(k, 1);
+  const unsigned long long heads = __ballot(lane == 0 || k_up != k);
+  const int startL = msb(heads & (below | self));
+  const unsigned long long h_above = heads & above;
+  const int endL = h_above ? __builtin_ctzll(h_above) - 1 : 63;
+  const unsigned long long seg = (endL == 63 ? ~0ull : ((2ull << endL) - 1ull)) & ~((1ull << startL) - 1ull);
+  const unsigned long long m1 = __ballot(valid && p), m0 = __ballot(valid && !p);
+  const unsigned long long b1 = m1 & seg & below, b0 = m0 & seg & below;
+  const double q1 = __shfl(t, b1 ? msb(b1) : lane), q0 = __shfl(t, b0 ? msb(b0) : lane);
+  // history before the wave (first run only)
+  const uint32_t k_first = __builtin_amdgcn_readfirstlane(k);
+  const bool cont_before = base > 0 && k_first != invalid_key && keys[base - 1] == k_first;
+  double c1 = 0, c0 = 0;
+  bool f1 = false, f0 = false;
+  if (cont_before) {
+    for (uint32_t end = base;;) {  // positions [end-64, end)
+      const bool ok = end >= 64u - (uint32_t)lane;  // end - 64 + lane >= 0
+      const uint32_t j = end - 64u + (uint32_t)lane;
+      const bool inb = ok && keys[ok ? j : 0] == k_first;  // (a suffix of the lanes: sorted keys)
+      const uint32_t jd = vals[inb ? j : base];
+      const uint4 e2 = jd >= nL ? evR[jd - nL] : evL[jd];
+      const double t2 = ev_time(e2.y, e2.z);
+      const bool p2 = (e2.w & 0xffu) != 0;
+      const unsigned long long mm1 = __ballot(inb && p2), mm0 = __ballot(inb && !p2);
+      const double x1 = __shfl(t2, mm1 ? msb(mm1) : 0), x0 = __shfl(t2, mm0 ? msb(mm0) : 0);
+      if (!f1 && mm1) {
+        c1 = x1;
+        f1 = true;
+      }
+      if (!f0 && mm0) {
+        c0 = x0;
+        f0 = true;
+      }
+      if ((f1 && f0) || __ballot(inb) != ~0ull) break;
+      end -= 64;
+    }
+  }
+  const bool first_run = startL == 0 && cont_before;
+  // the stored planes, where the batch holds no earlier event of that polarity for this pixel
+  double2 Lst = make_double2(0, 0);
+  const bool need1 = !b1 && !(first_run && f1), need0 = !b0 && !(first_run && f0);
+  if (valid && (need1 || need0)) Lst = L2[k];
+  const double prev1 = b1 ? q1 : (first_run && f1 ? c1 : Lst.y);
+  const double prev0 = b0 ? q0 : (first_run && f0 ? c0 : Lst.x);
+  const double t_last = p ? prev1 : prev0, t_last_inv = p ? prev0 : prev1;
+  const bool pass = valid && ((t > __dadd_rn(t_last, thr)) || (t_last_inv > t_last));
+  const unsigned long long s1 = __ballot(pass && p), s0 = __ballot(pass && !p);
+  bool later_any = ((p ? m1 : m0) & seg & above) != 0;    // a later event of my polarity exists
+  bool later_pass = ((p ? s1 : s0) & seg & above) != 0;   // ... a later passing one
+  // future after the wave (last run only)
+  const uint32_t k_last = __shfl(k, 63);
+  const bool cont_after = base + 64 < n && k_last != invalid_key && keys[base + 64 < n ? base + 64 : 0] == k_last;
+  if (cont_after) {
+    // the last run's lanes: [lastStart, 63]
+    const int lastStart = msb(heads);
+    const unsigned long long lastseg = ~((1ull << lastStart) - 1ull);
+    const bool whole = lastStart == 0 && cont_before;  // the run has history before this wave too
+    // times of the nearest events of either polarity as of the end of this wave
+    const unsigned long long l1 = m1 & lastseg, l0 = m0 & lastseg;
+    const double2 Ll = L2[k_last];
+    double E1 = l1 ? __shfl(t, msb(l1)) : (whole && f1 ? c1 : Ll.y);
+    double E0 = l0 ? __shfl(t, msb(l0)) : (whole && f0 ? c0 : Ll.x);
+    // what this wave's candidates still need to know
+    bool want_any1 = (l1 != 0), want_any0 = (l0 != 0);              // "is my last p=q event the pixel's last?"
+    bool want_pass1 = (s1 & lastseg) != 0, want_pass0 = (s0 & lastseg) != 0;
+    bool any1 = false, any0 = false, ps1 = false, ps0 = false;
+    for (uint32_t pos = base + 64;; pos += 64) {
+      const uint32_t j = pos + (uint32_t)lane;
+      const bool inb = j < n && keys[j < n ? j : n - 1] == k_last;  // (a prefix of the lanes)
+      const unsigned long long m_in = __ballot(inb);
+      if (!m_in) break;
+      const uint32_t jd = vals[inb ? j : base];
+      const uint4 e2 = jd >= nL ? evR[jd - nL] : evL[jd];
+      const double t2 = ev_time(e2.y, e2.z);
+      const bool p2 = (e2.w & 0xffu) != 0;
+      const unsigned long long mm1 = __ballot(inb && p2), mm0 = __ballot(inb && !p2);
+      const unsigned long long bb1 = mm1 & below, bb0 = mm0 & below;
+      const double y1 = __shfl(t2, bb1 ? msb(bb1) : lane), y0 = __shfl(t2, bb0 ? msb(bb0) : lane);
+      const double pv1 = bb1 ? y1 : E1, pv0 = bb0 ? y0 : E0;
+      const double tl = p2 ? pv1 : pv0, ti = p2 ? pv0 : pv1;
+      const bool pass2 = inb && ((t2 > __dadd_rn(tl, thr)) || (ti > tl));
+      const unsigned long long ss1 = __ballot(pass2 && p2), ss0 = __ballot(pass2 && !p2);
+      any1 = any1 || mm1;
+      any0 = any0 || mm0;
+      ps1 = ps1 || ss1;
+      ps0 = ps0 || ss0;
+      const double z1 = __shfl(t2, mm1 ? msb(mm1) : 0), z0 = __shfl(t2, mm0 ? msb(mm0) : 0);
+      if (mm1) E1 = z1;
+      if (mm0) E0 = z0;
+      const bool done = (!want_any1 || any1) && (!want_any0 || any0) && (!want_pass1 || ps1) &&
+                        (!want_pass0 || ps0);
+      if (done || m_in != ~0ull) break;
+    }
+    if ((lastseg >> lane) & 1ull) {
+      later_any = later_any || (p ? any1 : any0);
+      later_pass = later_pass || (p ? ps1 : ps0);
+    }
+  }
+  if (in) marks[i] = (uint8_t)((valid && !later_any ? 1 : 0) | (pass && !later_pass ? 2 : 0));
+}
+
+__global__ __launch_bounds__(256) void k_sae_apply_ev_write(const uint32_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ vals, uint32_t n,
+                                                            const uint4* __restrict__ evL, uint32_t nL,
+                                                            const uint4* __restrict__ evR,
+                                                            double2* __restrict__ L2,
+                                                            double2* __restrict__ S2,
+                                                            const uint8_t* __restrict__ marks) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = marks[i];
+  if (!f) return;
+  const uint32_t k = keys[i], idx = vals[i];
+  const uint4 ev = idx >= nL ? evR[idx - nL] : evL[idx];
+  const double t = ev_time(ev.y, ev.z);
+  const int q = (ev.w & 0xffu) != 0 ? 1 : 0;
+  if (f & 1u) ((double*)&L2[k])[q] = t;
+  if (f & 2u) ((double*)&S2[k])[q] = t;
+}
+
+void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* vals, uint32_t n,
+                         const EventRec* evL, uint32_t nL, const EventRec* evR, double2* L2,
+                         double2* S2, double filter_threshold, uint32_t invalid_key,
+                         uint32_t* sort_scratch, uint32_t sort_scratch_words, uint8_t* marks) {
+  if (!n) return;
+  const uint32_t need = n > sort_scratch_words ? n : sort_scratch_words;
+  launch_k(k_sae_apply_ev, dim3((need + 255) / 256), dim3(256), 0, s, keys, vals, n, (const uint4*)evL,
+           nL, (const uint4*)evR, L2, S2, filter_threshold, invalid_key, sort_scratch, sort_scratch_words,
+           marks);
+  launch_k(k_sae_apply_ev_write, dim3((n + 255) / 256), dim3(256), 0, s, keys, vals, n, (const uint4*)evL,
+           nL, (const uint4*)evR, L2, S2, (const uint8_t*)marks);
+}
+
 // ============================================================================ time surface
 // SAEtoTimeSurface_left/right (event_detector.cc:230-305): one 16 B {S0,S1} read and one u8 write
 // per pixel.  u8 = saturate_cast<uchar>(cvRound(v*127.5+127.5)) (ignore_polarity: v*255+0).

@@ -44,9 +44,13 @@ def test_sae_and_time_surface_uniform(oracle, W, H, n):
     ft.close()
 
 
-def test_sae_adversarial_duplicates(oracle):
-    """many events on few pixels, equal timestamps, alternating polarity, border pixels,
-    out-of-sensor events (skipped + counted)"""
+@pytest.mark.parametrize("ev_min", [None, "0"])
+def test_sae_adversarial_duplicates(oracle, ev_min, monkeypatch):
+    """many events on few pixels (segments of ~8000), equal timestamps, alternating polarity, border
+    pixels, out-of-sensor events (skipped + counted); with ESVIO_FE_SAE_EV_MIN=0 through the
+    per-event kernels (k_sae_apply_ev) that large batches use"""
+    if ev_min is not None:
+        monkeypatch.setenv("ESVIO_FE_SAE_EV_MIN", ev_min)
     W, H = 346, 260
     rng = np.random.default_rng(7)
     n = 50000
@@ -72,11 +76,15 @@ def test_sae_adversarial_duplicates(oracle):
     ft.close()
 
 
-def test_sae_segment_lengths_around_the_wave_path(oracle):
+@pytest.mark.parametrize("ev_min", [None, "0"])
+def test_sae_segment_lengths_around_the_wave_path(oracle, ev_min, monkeypatch):
     """per-pixel segments of every length around the grouped fetch (8 positions per step) and the
     wave width (63..65, 127..129), up to 1600 events on one pixel: long same-polarity bursts inside
     the refractory window, polarity flips, equal stamps and stamps going BACKWARDS inside the batch;
-    two batches so the carried-in state matters"""
+    two batches so the carried-in state matters.  With ESVIO_FE_SAE_EV_MIN=0 through the per-event
+    kernels: runs that start before / end after a wave, backward and forward scans of every depth."""
+    if ev_min is not None:
+        monkeypatch.setenv("ESVIO_FE_SAE_EV_MIN", ev_min)
     W, H = 346, 260
     rng = np.random.default_rng(11)
     lengths = [1, 2, 15, 16, 17, 18, 31, 63, 64, 65, 66, 127, 128, 129, 200, 511, 512, 513, 514, 575,
@@ -719,11 +727,12 @@ def test_replay_random_schedules(oracle, seed):
     ft.close()
 
 
-@pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE"])
+@pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE",
+                                 "ESVIO_FE_SAE_EV_MIN"])
 def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
     """the measurement switches read at esvio_fe_create (prefetch sequence submitted as a HIP
     graph; no chained temporal LK; no per-pixel dedup of the Arc* candidates; unfused time surface +
-    pyrDown kernels) leave every result
+    pyrDown kernels; the per-event SAE apply kernels for batches of >= 1 event instead of >= 2^20) leave every result
     bit-identical to the oracle"""
     monkeypatch.setenv(opt, "1")
     W, H = 346, 260
