@@ -250,6 +250,7 @@ struct esvio_fe_ctx {
   uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
   bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1: A/B measurements)
   bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1: k_time_surface + 3 x k_pyr_down)
+  bool disc_tab_only = false;              // (ESVIO_FE_DISC_TABLE=1: k_select's table look-ups)
   int cand_cur = 0;
   size_t arc_cap = 0;
   uint32_t* d_mask_bits = nullptr;
@@ -997,6 +998,7 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* o
   s.max_corners = max_corners;
   s.radius = c->cfg.min_dist;
   for (int i = 0; i <= kMaxDiscR; i++) s.hw[i] = i < (int)c->hw.size() ? (int8_t)c->hw[i] : -1;
+  s.disc_c = c->disc_tab_only ? -1 : disc_threshold(s.hw, s.radius);
   s.out_pts = out_pts;
   s.out_idx = out_idx;
   s.out_base = out_base;
@@ -1919,6 +1921,7 @@ int gftt_run(esvio_fe_ctx* c, const PyrDesc& d, int max_corners, double quality,
   sa.wpr = (c->W + 31) / 32;
   sa.max_corners = max_corners;
   euclid_halfwidths(min_distance, sa.hw, &sa.radius);
+  sa.disc_c = c->disc_tab_only ? -1 : disc_threshold(sa.hw, sa.radius);
   sa.out_pts = out_pts;
   sa.out_idx = nullptr;
   sa.out_base = out_base;
@@ -2306,6 +2309,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
   c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
+  c->disc_tab_only = getenv("ESVIO_FE_DISC_TABLE") != nullptr;
   if (const char* v = getenv("ESVIO_FE_SAE_EV_MIN")) c->sae_ev_min = (size_t)strtoull(v, nullptr, 10);
   for (int i = 0; i < kRightSlots; i++)
     if ((rc = dev_alloc(c, &c->d_first[i], (size_t)c->P))) return bail(rc);

@@ -270,6 +270,10 @@ struct SelectArgs {
   int max_corners;
   int radius;
   int8_t hw[kMaxDiscR + 1];  // cv::circle half-widths per |dy|
+  // >= 0: "|dx| <= hw[|dy|]" is the same set as "dx*dx + dy*dy <= disc_c" (true for cv::circle's
+  // table at every radius 1..63 and for the open Euclidean disc; disc_threshold() checks it), so
+  // disc membership is two multiply-adds instead of a table look-up; -1: use the table
+  int disc_c;
   float2* out_pts;           // accepted corners are written at out_pts[out_base + k]
   int32_t* out_idx;          // may be NULL
   int out_base;
@@ -292,5 +296,7 @@ struct SelectArgs {
   uint32_t pub_seq;
 };
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes);
+// the threshold described at SelectArgs::disc_c for a half-width table, or -1 if there is none
+int disc_threshold(const int8_t* hw, int radius);
 
 }  // namespace esvio

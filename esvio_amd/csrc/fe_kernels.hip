@@ -2235,6 +2235,23 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
           rem &= ~dead;
           unsigned long long bit[kSelectGroup], Bdy[kSelectGroup];
           int dxs[kSelectGroup], hws[kSelectGroup];
+          if (a.disc_c >= 0) {  // (wave-uniform) disc membership without the table
+#pragma unroll
+            for (int g = 0; g < kSelectGroup; g++) {
+              const int q = rem ? __builtin_ctzll(rem) : 0;
+              bit[g] = rem & (0ull - rem);
+              rem &= rem - 1ull;
+              const int ddx = x - __builtin_amdgcn_readlane(x, q), ddy = y - __builtin_amdgcn_readlane(y, q);
+              Bdy[g] = bal(ddx * ddx + ddy * ddy <= a.disc_c);
+            }
+#pragma unroll
+            for (int g = 0; g < kSelectGroup; g++) {
+              const unsigned long long t = bit[g] & ~dead;  // candidate still free?
+              acc |= t;
+              dead |= t ? Bdy[g] : 0ull;
+            }
+            continue;
+          }
 #pragma unroll
           for (int g = 0; g < kSelectGroup; g++) {
             const int q = rem ? __builtin_ctzll(rem) : 0;
@@ -2330,8 +2347,9 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         // ... and kill this sub-chunk's remaining candidates geometrically: inside the disc iff
         // |dx| <= hw[|dy|] (the same table the stamp uses), so no bitmap round trip per accept
         const int dy = y > ay ? y - ay : ay - y, dx = x > ax ? x - ax : ax - x;
-        const int hwd = hwtab[min(dy, 63)];
-        alive = alive && lane > first && !(dy <= r && dx <= hwd);
+        const bool inside = a.disc_c >= 0 ? dx * dx + dy * dy <= a.disc_c
+                                          : (dy <= r && dx <= hwtab[min(dy, 63)]);
+        alive = alive && lane > first && !inside;
         m = __ballot(alive);
       }
       if (accepted >= a.max_corners) break;
@@ -2349,6 +2367,17 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
       a.host_counts[2] = (int)total;
     }
   }
+}
+
+int disc_threshold(const int8_t* hw, int radius) {
+  long inside = -1, outside = (long)(radius + 1) * (radius + 1);
+  for (int dy = 0; dy <= radius && dy <= kMaxDiscR; dy++) {
+    const long h = hw[dy];
+    if (h >= 0) inside = inside > h * h + (long)dy * dy ? inside : h * h + (long)dy * dy;
+    const long o = (h + 1) * (h + 1) + (long)dy * dy;  // (h = -1: the row's centre pixel is outside)
+    outside = outside < o ? outside : o;
+  }
+  return inside >= 0 && inside < outside ? (int)inside : -1;
 }
 
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
