@@ -1685,6 +1685,12 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   const bool will_spec = have_next || had_announced;
   auto upload_kept = [&]() -> int {
     if (!will_spec || !n_kept) return 0;
+    // pin.news is a single buffer and the previous published frame's lazy stereo LK of its new
+    // corners reads its points from there (z_new + its n_kept) in place.  Up to ~1000 points every
+    // wave of that launch is resident from the start and has loaded its point long before the host
+    // gets here (it had to wait for this frame's temporal LK first); a larger launch runs in
+    // several rounds of blocks, so its completion is awaited before the slots are overwritten.
+    if (c->pend.active && M > 1024) HIPCHK(c, sync_event(c->ev_lknew_done));
     std::memcpy(pin.news, c->cur_pts.data(), (size_t)n_kept * 8);  // read in place by the LK
     return 0;
   };
@@ -2405,6 +2411,7 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle c, const esvio_fe_event* left,
                                   const esvio_fe_motion* motion, uint64_t* n_rejected) {
   if (!c || !motion || !nL || !left || (nR && !right)) return ESVIO_FE_EINVAL;
   if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  if (!c->inflight.empty()) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
   HIPCHK(c, hipSetDevice(c->dev));
   esvio_fe_event first;
   if (int rc = first_event_host(c, left, space, &first)) return rc;
@@ -2416,7 +2423,9 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle c, const esvio_fe_event* left,
   unsigned long long rej = 0;
   HIPCHK(c, hipMemcpyAsync(&rej, c->d_rejected, 8, hipMemcpyDeviceToHost, cur_stream(c)));
   HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
+  if (pin_of(c).counts[3]) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
   if (n_rejected) *n_rejected = rej;
+  if (c->prof_on) resolve_profile(c);
   return 0;
 }
 

@@ -47,13 +47,17 @@ class TrackExchange:
 
     def submit(self, rec, async_op=True):
         """rec: (2*max_cnt, 8) float32 numpy block from node.pack_track_records"""
-        self.wait()
         t = self.torch.from_numpy(np.ascontiguousarray(rec, np.float32))
         if self.stream is not None:
             with self.torch.cuda.stream(self.stream):
+                # Work.wait() of an NCCL collective orders the CURRENT stream behind it: taken
+                # inside the side-stream scope, so that the copy below cannot overwrite `send`
+                # while the previous all_gather is still reading it
+                self.wait()
                 self.send.copy_(t)
                 self.pending = self.dist.all_gather_into_tensor(self.recv_flat, self.send, async_op=async_op)
         else:
+            self.wait()
             self.send.copy_(t)
             self.pending = self.dist.all_gather_into_tensor(self.recv_flat, self.send, async_op=async_op)
         return self.pending
@@ -62,13 +66,13 @@ class TrackExchange:
         """like submit(ft.pack_track_records()), without the detour through pageable memory"""
         if self.stage is None:
             return self.submit(ft.pack_track_records(), async_op)
-        self.wait()
         i = self.stage_i
         self.stage_i ^= 1
         if self.stage_ev[i] is not None:
             self.stage_ev[i].synchronize()  # its previous upload has long finished
         ft.pack_track_records(self.stage[i].numpy())
         with self.torch.cuda.stream(self.stream) if self.stream is not None else _null():
+            self.wait()  # (inside the scope: orders THIS stream behind the previous collective)
             self.send.copy_(self.stage[i], non_blocking=True)
             ev = self.torch.cuda.Event()
             ev.record()

@@ -1,10 +1,22 @@
 """Host harness mirroring the caller of trackEvent: ``handle_stereo_event`` of the reference's
 stereo_event_tracker node (feature_tracker/src/stereo_event_tracker_node.cpp:145-344) without ROS:
-first-frame drop, stream-discontinuity reset, publish-rate control, PointCloud-equivalent packing.
+first-frame drop, stream-discontinuity re-arm, publish-rate control, PointCloud-equivalent packing.
 
-Plain host bookkeeping over the FeatureTracker mirror; no compute happens here.
+Plain host bookkeeping over the FeatureTracker mirror; no compute happens here.  The C++ twin of
+this file is tools/replay_node.cpp (same rules, drives the C ABI directly).
 """
+import math
+
 import numpy as np
+
+
+def c_round(x):
+    """C `round()` (half away from zero), which the node's frequency control uses (node:177);
+    Python's round() is half-to-even and differs when pub_count/dt lands on x.5 with even x."""
+    r = math.floor(x)
+    if x - r >= 0.5:  # (x - floor(x) is exact in binary floating point)
+        r += 1
+    return int(r)
 
 from .events import event_times
 
@@ -29,7 +41,7 @@ class FreqControl:
         if dt <= 0:
             return False
         rate = 1.0 * self.pub_count / dt
-        if round(rate) <= self.FREQ:
+        if c_round(rate) <= self.FREQ:
             if abs(rate - self.FREQ) < 0.01 * self.FREQ:
                 self.first_image_time = msg_timestamp
                 self.pub_count = 0
@@ -47,7 +59,7 @@ class FreqControl:
         dt = msg_timestamp - self.first_image_time
         if dt <= 0:
             return False
-        return round(1.0 * self.pub_count / dt) <= self.FREQ
+        return c_round(1.0 * self.pub_count / dt) <= self.FREQ
 
 
 def pack_point_cloud(ft):
@@ -88,9 +100,13 @@ class StereoEventTrackerNode:
     published PointCloud rows or None (first frame, reset, non-published frame, swallowed first
     publish)."""
 
-    def __init__(self, tracker, freq):
+    def __init__(self, tracker, freq, reset_tracker_on_restart=False):
         self.trackerData = tracker
         self.freq = freq
+        # NOT reference behaviour (kept for callers that own both ends): also clear the tracker when
+        # the stream is discontinuous.  The reference only re-arms the node and publishes `restart`.
+        self.reset_tracker_on_restart = reset_tracker_on_restart
+        self.restart_flag = False  # what pub_restart would have carried for the latest call
         self.first_image_flag = True
         self.first_image_time = 0.0
         self.last_image_time = 0.0
@@ -100,6 +116,7 @@ class StereoEventTrackerNode:
         self.FREQ = freq if freq != 0 else 100
 
     def handle(self, event_left, event_right, msg_timestamp):
+        self.restart_flag = False
         if len(event_left) == 0:  # node:150
             return None
         if self.first_image_flag:  # node:155-161
@@ -112,11 +129,15 @@ class StereoEventTrackerNode:
             self.last_image_time = 0
             self.pub_count = 1
             self.restart_count += 1
-            self.trackerData.reset()
+            # the reference publishes restart_flag and returns: the tracker keeps its SAE planes,
+            # tracks, ids and previous image across the gap
+            self.restart_flag = True
+            if self.reset_tracker_on_restart:
+                self.trackerData.reset()
             return None
         self.last_image_time = msg_timestamp
         rate = 1.0 * self.pub_count / (msg_timestamp - self.first_image_time)
-        if round(rate) <= self.FREQ:  # node:177-188
+        if c_round(rate) <= self.FREQ:  # node:177-188
             pub = True
             if abs(rate - self.FREQ) < 0.01 * self.FREQ:
                 self.first_image_time = msg_timestamp
@@ -150,9 +171,11 @@ class StereoImageTrackerNode:
         self.pub_count = 1
         self.init_pub = False
         self.restart_count = 0
+        self.restart_flag = False
         self.FREQ = freq if freq != 0 else 100
 
     def handle(self, img_left, img_right, msg_timestamp):
+        self.restart_flag = False
         if self.first_image_flag:  # :58-64
             self.first_image_flag = False
             self.first_image_time = msg_timestamp
@@ -163,10 +186,11 @@ class StereoImageTrackerNode:
             self.last_image_time = 0
             self.pub_count = 1
             self.restart_count += 1
+            self.restart_flag = True
             return None
         self.last_image_time = msg_timestamp
         rate = 1.0 * self.pub_count / (msg_timestamp - self.first_image_time)
-        if round(rate) <= self.FREQ:  # :81-91
+        if c_round(rate) <= self.FREQ:  # :81-91
             pub = True
             if abs(rate - self.FREQ) < 0.01 * self.FREQ:
                 self.first_image_time = msg_timestamp

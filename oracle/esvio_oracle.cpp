@@ -613,6 +613,7 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
     int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
     float fA11 = 0, fA12 = 0, fA22 = 0;
+    float qA11[4] = {0, 0, 0, 0}, qA12[4] = {0, 0, 0, 0}, qA22[4] = {0, 0, 0, 0};
     int64_t iA11 = 0, iA12 = 0, iA22 = 0;
     for (int y = 0; y < win; y++) {
       const uint8_t* src = I + (ptrdiff_t)(y + iprevY) * stepI + iprevX;
@@ -636,6 +637,21 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
           fA11 += (float)(ixval * ixval);
           fA12 += (float)(ixval * iyval);
           fA22 += (float)(iyval * iyval);
+        } else if (accum == 2) {
+          // x86 SIMD128 build [OpenCV 4.2 lkpyramid.cpp, `#if CV_SIMD128 && !CV_NEON`, recalled]:
+          // the vector loop runs while x <= win - 8 (8 pixels per step as two halves of 4), lane k
+          // of qA11/qA12/qA22 takes pixel x = 4m + k; the rest of the row goes to the scalar float
+          // accumulator.  (v_muladd without FMA = mul then add; the products are < 2^24: exact.)
+          const float fx = (float)ixval, fy = (float)iyval;
+          if (x < (win / 8) * 8) {
+            qA11[x & 3] += fx * fx;
+            qA12[x & 3] += fx * fy;
+            qA22[x & 3] += fy * fy;
+          } else {
+            fA11 += (float)(ixval * ixval);
+            fA12 += (float)(ixval * iyval);
+            fA22 += (float)(iyval * iyval);
+          }
         } else {
           iA11 += (int64_t)(ixval * ixval);
           iA12 += (int64_t)(ixval * iyval);
@@ -645,6 +661,13 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
     }
     float A11, A12, A22;
     if (accum == 0) {  // typedef float acctype (default OpenCV build, scalar loop order)
+      A11 = fA11 * FLT_SCALE;
+      A12 = fA12 * FLT_SCALE;
+      A22 = fA22 * FLT_SCALE;
+    } else if (accum == 2) {  // iA11 += v_reduce_sum(qA11): SSE horizontal sum (q0+q2)+(q1+q3)
+      fA11 += (qA11[0] + qA11[2]) + (qA11[1] + qA11[3]);
+      fA12 += (qA12[0] + qA12[2]) + (qA12[1] + qA12[3]);
+      fA22 += (qA22[0] + qA22[2]) + (qA22[1] + qA22[3]);
       A11 = fA11 * FLT_SCALE;
       A12 = fA12 * FLT_SCALE;
       A22 = fA22 * FLT_SCALE;
@@ -681,6 +704,7 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
       iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
       iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
       float fb1 = 0, fb2 = 0;
+      float qb0[4] = {0, 0, 0, 0}, qb1[4] = {0, 0, 0, 0};
       int64_t ib1 = 0, ib2 = 0;
       for (int y = 0; y < win; y++) {
         const uint8_t* Jptr = J + (ptrdiff_t)(y + inextY) * stepJ + inextX;
@@ -694,6 +718,31 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
                        Iptr[x];
             fb1 += (float)(diff * dIptr[0]);
             fb2 += (float)(diff * dIptr[1]);
+          }
+        } else if (accum == 2) {
+          // x86 SIMD128 build [OpenCV 4.2, recalled]: per step of 8 pixels x0..x0+7 the zips put
+          // (It_k, It_k+4) against (Ix_k, Ix_k+4) / (Iy_k, Iy_k+4), v_dotprod (pmaddwd) adds each
+          // pair exactly in int32, v_cvt_f32 rounds, then one float add per lane:
+          //   qb0 = {bx(0,4), by(0,4), bx(1,5), by(1,5)},  qb1 = {bx(2,6), by(2,6), bx(3,7), by(3,7)}
+          int dv[64];  // win <= 64 (21 at every call site)
+          for (int x = 0; x < win; x++)
+            dv[x] = CV_DESCALE(Jptr[x] * iw00 + Jptr[x + 1] * iw01 + Jptr[x + stepJ] * iw10 +
+                                   Jptr[x + stepJ + 1] * iw11,
+                               W_BITS1 - 5) -
+                    Iptr[x];
+          int x = 0;
+          for (; x <= win - 8; x += 8) {
+            for (int k = 0; k < 4; k++) {
+              const int sx = dv[x + k] * dIptr[2 * (x + k)] + dv[x + k + 4] * dIptr[2 * (x + k + 4)];
+              const int sy = dv[x + k] * dIptr[2 * (x + k) + 1] + dv[x + k + 4] * dIptr[2 * (x + k + 4) + 1];
+              float* q = k < 2 ? qb0 : qb1;
+              q[(k & 1) * 2] += (float)sx;
+              q[(k & 1) * 2 + 1] += (float)sy;
+            }
+          }
+          for (; x < win; x++) {
+            fb1 += (float)(dv[x] * dIptr[2 * x]);
+            fb2 += (float)(dv[x] * dIptr[2 * x + 1]);
           }
         } else {
           int64_t r1 = 0, r2 = 0;  // row sums fit easily; exact
@@ -711,6 +760,13 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
       }
       float b1, b2;
       if (accum == 0) {
+        b1 = fb1 * FLT_SCALE;
+        b2 = fb2 * FLT_SCALE;
+      } else if (accum == 2) {
+        // v_recombine(v_interleave_pairs(qb0 + qb1), 0, qf0, qf1); ib1 += v_reduce_sum(qf0) ...
+        const float s0 = qb0[0] + qb1[0], s1 = qb0[1] + qb1[1], s2 = qb0[2] + qb1[2], s3 = qb0[3] + qb1[3];
+        fb1 += (s0 + 0.f) + (s2 + 0.f);
+        fb2 += (s1 + 0.f) + (s3 + 0.f);
         b1 = fb1 * FLT_SCALE;
         b2 = fb2 * FLT_SCALE;
       } else {

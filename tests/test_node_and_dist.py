@@ -87,15 +87,38 @@ def test_handle_stereo_event_flow():
     assert tr.calls[-1][3] is True and out is not None and out.shape[1] == 8
     got = [node.handle(ev, ev, 5.2 + k / 30.0) for k in range(30)]
     assert any(g is not None and g.shape[1] == 8 for g in got)
-    # time gap > 1 s: reset, next frame is treated as first (node:163-173)
+    # time gap > 1 s: the node re-arms (restart flag published) and the next frame is treated as the
+    # first one; the tracker itself is NOT reset (node:163-173 only touches the node's own flags)
     n = len(tr.calls)
-    assert node.handle(ev, ev, 9.0) is None and tr.resets == 1 and len(tr.calls) == n
-    assert node.handle(ev, ev, 9.03) is None and len(tr.calls) == n
+    assert node.handle(ev, ev, 9.0) is None and node.restart_flag and node.restart_count == 1
+    assert tr.resets == 0 and len(tr.calls) == n
+    assert node.handle(ev, ev, 9.03) is None and len(tr.calls) == n and not node.restart_flag
     node.handle(ev, ev, 9.06)
     assert len(tr.calls) == n + 1
-    # time going backwards also resets
+    # time going backwards re-arms as well
     node.handle(ev, ev, 8.0)
-    assert tr.resets == 2
+    assert node.restart_count == 2 and node.restart_flag and tr.resets == 0
+    # the non-reference option clears the tracker too
+    tr2 = _StubTracker()
+    node2 = StereoEventTrackerNode(tr2, freq=15, reset_tracker_on_restart=True)
+    node2.handle(ev, ev, 5.0)
+    node2.handle(ev, ev, 9.0)
+    assert tr2.resets == 1
+
+
+def test_freq_control_rounds_like_c():
+    """node:177 calls C round(): half away from zero.  pub_count / dt = 10.5 at FREQ 10 must NOT
+    publish (round -> 11); Python's round() would give 10 and publish."""
+    from esvio_amd.node import c_round
+    assert [c_round(v) for v in (0.5, 1.5, 2.5, 10.5, 10.49, 11.5, 0.49999999999999994)] == \
+        [1, 2, 3, 11, 10, 12, 0]
+    fc = FreqControl(10)
+    fc.pub_this_frame(0.0)           # first frame
+    fc.pub_count = 21
+    assert fc.peek(2.0) is False     # 21 / 2.0 = 10.5 -> 11 > 10
+    assert fc.pub_this_frame(2.0) is False
+    fc.pub_count = 20
+    assert fc.pub_this_frame(2.0) is True
 
 
 def _free_port():

@@ -2,8 +2,11 @@
 
 Bars: SAE planes, time-surface bytes, corner flags and selected corner indices bit-exact;
 pyramid / Scharr bit-exact; LK positions bit-exact against the oracle's exact-sum mode (both
-sides accumulate the normal equations in int64) and <= 1e-4 px against its float-sum mode
-on >= 99% of points (status flips counted and bounded).
+sides accumulate the normal equations exactly).  Against float accumulation — what the reference's
+x86 OpenCV build does — the difference is a measured distribution, asserted as measured
+(tests/lk_orders.py, also run on CPU by tests/test_lk_float_orders.py): vs the SIMD128 lane order
+of OpenCV 4.2 p90 <= 5e-5 px, p99 <= 2.5e-4, max <= 5e-4, >= 95 % of the points within 1e-4 px, no
+status flips; vs the scalar loop order p90 <= 1.5e-4, max <= 6e-4, >= 85 % within 1e-4.
 """
 import numpy as np
 import pytest
@@ -11,6 +14,8 @@ import pytest
 from esvio_amd import frontend as FE
 from esvio_amd.events import EVENT_DTYPE, event_times, make_events
 from esvio_amd.synth import SceneStream, uniform_batch
+
+import lk_orders
 
 pytestmark = pytest.mark.gpu
 
@@ -217,15 +222,13 @@ def test_lk_parity(oracle):
         assert np.array_equal(g_st, c_st)
         assert np.array_equal(g_pts.view(np.uint32), c_pts.view(np.uint32)), \
             "max |d| = %g" % np.abs(g_pts - c_pts).max()
-        # float-accumulator oracle (OpenCV's default scalar loop order).  The reference's float
-        # sums are order- (SIMD-width-) dependent, so this is a band, not an identity: most
-        # points within 1e-4 px, all within 1e-3 px, status flips bounded.
-        f_pts, f_st = oracle.lk(prev, nxt, pts, init, max_level=ml, flags=flags, accum=0)
-        both = (f_st == 1) & (g_st == 1)
-        flips = int((f_st != g_st).sum())
-        d = np.abs(f_pts[both] - g_pts[both]).max(axis=1)
-        assert flips <= 3 and (d <= 1e-4).mean() >= 0.85 and d.max() <= 1e-3, \
-            (flips, (d <= 1e-4).mean(), d.max())
+        # float accumulation (what the reference's OpenCV does; order- and SIMD-width-dependent):
+        # a measured band, not an identity — see tests/lk_orders.py for the numbers
+        for accum in (2, 0):
+            f_pts, f_st = oracle.lk(prev, nxt, pts, init, max_level=ml, flags=flags, accum=accum)
+            dist = lk_orders.distribution(g_pts, g_st, f_pts, f_st)
+            print("LK GPU vs float order %d (maxLevel %d flags %d): %s" % (accum, ml, flags, dist))
+            lk_orders.assert_band(dist, accum)
     ok = g_st == 1
     assert ok.sum() > 150
     ft.close()
