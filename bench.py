@@ -32,29 +32,52 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+# stats label (esvio_fe_kernel_name) -> the kernel functions launched under it
+KERNEL_FUNCS = {
+    "k_sae_keys": ["k_sae_keys"], "k_radix_pass": ["k_radix_pass"],
+    "k_sae_apply": ["k_sae_apply", "k_sae_apply_ev", "k_sae_apply_ev_write"],
+    "k_time_surface": ["k_time_surface", "k_ts_pyr", "k_median"], "k_clahe": ["k_clahe_lut", "k_clahe_interp", "k_normalize"],
+    "k_pyr_down": ["k_pyr_down"], "k_pyr_pad": ["k_pyr_pad"], "k_scharr": ["k_scharr", "k_pad_scharr"],
+    "k_lk": ["k_lk"], "k_arc": ["k_arc_ev"], "k_arc_map": ["k_arc_map"],
+    "k_compact": ["k_compact", "k_dedup"], "k_select": ["k_select"],
+}
+# kernels whose reads are per-lane gathers, not wide coalesced streams: the guide calibrates the 2x
+# FETCH_SIZE correction for coalesced reads only
+GATHER_KERNELS = {"k_sae_apply", "k_lk", "k_arc", "k_arc_map", "k_select", "k_compact"}
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this same
-    command (profiles/*_bench_c3.json, made by tools/rocprof_summary.py from separate
-    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).  Units are KB; per MI355X_MICROARCH.md §HBM the
-    gfx950 FETCH_SIZE counter reports half of a coalesced read stream, hence 2*FETCH + WRITE."""
+    """HBM bytes per launch of the kernels behind stats label `kernel` from the newest committed
+    rocprofv3 PMC summary of this same command (profiles/*_bench_c3.json, made by
+    tools/rocprof_summary.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).  Units
+    are KB; per MI355X_MICROARCH.md §HBM the gfx950 FETCH_SIZE counter reports half of a coalesced
+    read stream, hence 2*FETCH + WRITE.  Returns (bytes, source file, note)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_c3.json")))
     if not files:
-        return None, None
+        return None, None, None
     try:
         d = json.load(open(files[-1]))
-        f = w = None
-        for name, v in d["pmc"].get("FETCH_SIZE", {}).items():
-            if ("::" + kernel + "(") in name or name.startswith(kernel) or ("::" + kernel + "<") in name:
-                f = v["avg"]
-        for name, v in d["pmc"].get("WRITE_SIZE", {}).items():
-            if ("::" + kernel + "(") in name or name.startswith(kernel) or ("::" + kernel + "<") in name:
-                w = v["avg"]
-        if f is None or w is None:
-            return None, None
-        return int((2.0 * f + w) * 1024), os.path.basename(files[-1])
+        funcs = KERNEL_FUNCS.get(kernel, [kernel])
+
+        def total(counter):
+            tot, disp = 0.0, 0
+            for name, v in d["pmc"].get(counter, {}).items():
+                base = name.split("(")[0].split("<")[0].split("::")[-1].replace("void ", "").strip()
+                if base in funcs:
+                    tot += v["avg"] * v["dispatches"]
+                    disp = max(disp, v["dispatches"])
+            return tot, disp
+        f, nf = total("FETCH_SIZE")
+        w, nw = total("WRITE_SIZE")
+        if not nf or not nw:
+            return None, None, None
+        note = ("2x FETCH_SIZE correction applied; it is calibrated for wide coalesced reads only — "
+                "uncalibrated for this gather kernel (raw FETCH+WRITE = %d B)" % int((f / nf + w / nw) * 1024)
+                if kernel in GATHER_KERNELS else "2x FETCH_SIZE correction (coalesced stream)")
+        return int((2.0 * f / nf + w / nw) * 1024), os.path.basename(files[-1]), note
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def parse():
@@ -86,9 +109,16 @@ def parse():
                          "the result does not depend on it); 1 = the calling thread only; "
                          "0 = min(8, usable CPUs / (2 * ranks)): the helpers spin, so all ranks' "
                          "threads together have to stay inside the CPU quota")
-    ap.add_argument("--split", choices=["rigs", "camera"], default="rigs",
-                    help="N>1 sharding: one independent stereo rig per GPU (weak scaling, default) or "
-                         "BASELINE C4: left/right cameras of ONE rig on 2 GPUs")
+    ap.add_argument("--split", choices=["rigs", "camera", "time"], default="rigs",
+                    help="N>1 sharding: one independent stereo rig per GPU (weak scaling, default); "
+                         "BASELINE C4: left/right cameras of ONE rig on 2 GPUs; BASELINE C5: ONE stream, "
+                         "every batch time-sliced over the N GPUs for the SAE update")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="times the timed --steps region is run over the continued stream (the first "
+                         "is the headline ms_per_step; all are reported); 0 = 5 up to 30 steps, else 3")
+    ap.add_argument("--max-cnt", type=int, default=300)
+    ap.add_argument("--no-host-pass", action="store_true",
+                    help="skip the extra pass with the events in host memory (host_resident_events)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the N>1 path)")
     return ap.parse_args()
@@ -205,21 +235,24 @@ def main():
 
     from esvio_amd import frontend as FE
     from esvio_amd.events import event_times
-    from esvio_amd.dist import CameraSplitRig, TrackExchange
-    from esvio_amd.node import FreqControl, pack_track_records
+    from esvio_amd.dist import CameraSplitRig, TimeSlicedSae, TrackExchange
+    from esvio_amd.node import FreqControl
     from esvio_amd.synth import SceneStream
 
     W, H = args.width, args.height
-    n_frames = args.warmup + args.steps
+    repeats = args.repeats if args.repeats > 0 else (5 if args.steps <= 30 else 3)
+    n_frames = args.warmup + args.steps * repeats
     n_prof = 0 if args.no_profile_pass else min(args.steps, 30)
     # ---- synthetic stream (per rank: an independent rig, different seed), resident in HBM
     cam_split = args.split == "camera" and world > 1
+    time_split = args.split == "time" and world > 1
     if cam_split and world != 2:
         raise SystemExit("--split camera needs exactly 2 ranks")
+    one_rig = cam_split or time_split
     scene = SceneStream(W, H, rate=args.rate, batch_hz=args.batch_hz,
-                        seed=args.seed + (0 if cam_split else 1000 * rank))
+                        seed=args.seed + (0 if one_rig else 1000 * rank))
     host_batches, dev_batches = [], []
-    for _ in range(n_frames + n_prof):
+    for _ in range(n_frames):
         L, R, _ = scene.next_batch()
         host_batches.append((L, R))
         tl = torch.from_numpy(L.view(np.uint8).reshape(-1)).cuda()
@@ -227,8 +260,7 @@ def main():
         dev_batches.append((tl, tr, len(L), len(R), event_times(L)[-1]))
     torch.cuda.synchronize()
 
-    cfg = FE.make_config(W, H, device=dev_index, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1)
-    ft = FE.FeatureTracker(cfg)
+    cfg = FE.make_config(W, H, device=dev_index, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1)
     # PUB_THIS_FRAME depends on the batch timestamps only (node:155-188), so the whole plan is known
     # up front; replay mode hands it to esvio_fe_set_next_batch as the PUB hint
     fc = FreqControl(args.freq)
@@ -237,40 +269,60 @@ def main():
         pub_flags.append(fc.pub_this_frame(b[4]))
         if pub_flags[-1]:
             fc.published()
-    pub_plan = lambda k: pub_flags[k]
-    announced = [0]
-    exch = (TrackExchange(cfg.max_cnt, world, device=xdev, dist=dist,
-                          stream=torch.cuda.Stream() if xdev == "cuda" else None)
-            if world > 1 else None)
-
-    rig = CameraSplitRig(ft, rank, dist, device=xdev) if cam_split else None
-    pipeline = not args.no_pipeline and not cam_split
-    lazy = pipeline and not args.no_lazy
-    if lazy:
-        ft.set_lazy_new_stereo(True)
     if args.host_threads <= 0:
         args.host_threads = max(1, min(8, total_cpus // (2 * max(world, 1))))
-    if args.host_threads > 1:
-        ft.set_host_threads(args.host_threads)
 
-    def step(i, exchange=True):
-        tl, tr, nl, nr, t_last = dev_batches[i]
-        pub = pub_flags[i]
-        if rig is not None:  # C4: rank 0 = left camera + tracking, rank 1 = right camera
-            rig.track(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub)
-            if pub and exchange:
-                exch.submit_tracker(ft, async_op=True)
-            return nl if rank == 0 else nr
-        if pipeline:  # replay mode: the next batches are already in HBM; announce them ahead
-            while announced[0] < min(i + args.ahead, len(dev_batches) - 1):
-                k = announced[0] = announced[0] + 1
-                tl2, tr2, nl2, nr2, t2 = dev_batches[k]
-                ft.set_next_batch(t2, (tl2.data_ptr(), nl2), (tr2.data_ptr(), nr2), pub_plan(k))
-        ft.trackEvent(t_last, (tl.data_ptr(), nl), (tr.data_ptr(), nr), pub, copy=False)
-        if pub:
-            if exch is not None and exchange:  # merge all rigs' tracked corners (async)
-                exch.submit_tracker(ft, async_op=True)
-        return nl + nr
+    class Runner:
+        """one tracker + the schedule it is driven with"""
+
+        def __init__(self, pipeline, lazy, batches, exch=None, rig=None, tsl=None):
+            self.ft = FE.FeatureTracker(cfg)
+            self.pipeline, self.lazy, self.batches, self.exch, self.rig, self.tsl = pipeline, lazy, batches, exch, rig, tsl
+            self.announced = 0
+            if lazy:
+                self.ft.set_lazy_new_stereo(True)
+            if args.host_threads > 1:
+                self.ft.set_host_threads(args.host_threads)
+
+        def arg(self, k):
+            b = self.batches[k]
+            if isinstance(b[0], np.ndarray):  # host-resident events
+                return b[0], b[1], len(b[0]), len(b[1]), event_times(b[0])[-1]
+            return (b[0].data_ptr(), b[2]), (b[1].data_ptr(), b[3]), b[2], b[3], b[4]
+
+        def step(self, i, exchange=True):
+            L, R, nl, nr, t_last = self.arg(i)
+            pub = pub_flags[i]
+            ft = self.ft
+            if self.rig is not None:  # C4: rank 0 = left camera + tracking, rank 1 = right camera
+                self.rig.track(t_last, L, R, pub)
+                if pub and exchange:
+                    self.exch.submit_tracker(ft, async_op=True)
+                return nl if rank == 0 else nr
+            if self.tsl is not None:  # C5: every rank applies its time slice of the batch to the SAE
+                self.tsl.track(t_last, L, R, pub)
+                return (nl + nr) if rank == 0 else 0
+            if self.pipeline:  # replay mode: the next batches are already in HBM; announce them ahead
+                while self.announced < min(i + args.ahead, len(self.batches) - 1):
+                    k = self.announced = self.announced + 1
+                    L2, R2, _, _, t2 = self.arg(k)
+                    ft.set_next_batch(t2, L2, R2, pub_flags[k])
+            ft.trackEvent(t_last, L, R, pub, copy=False)
+            if pub and self.exch is not None and exchange:  # merge all rigs' tracked corners (async)
+                self.exch.submit_tracker(ft, async_op=True)
+            return nl + nr
+
+    exch = (TrackExchange(cfg.max_cnt, world, device=xdev, dist=dist,
+                          stream=torch.cuda.Stream() if xdev == "cuda" else None)
+            if world > 1 and not time_split else None)
+    pipeline = not args.no_pipeline and not one_rig
+    lazy = pipeline and not args.no_lazy
+    main_run = Runner(pipeline, lazy, dev_batches, exch=exch)
+    ft = main_run.ft
+    if cam_split:
+        main_run.rig = CameraSplitRig(ft, rank, dist, device=xdev)
+    if time_split:
+        main_run.tsl = TimeSlicedSae(ft, rank, world, dist, device=xdev)
 
     def barrier():
         if world > 1:
@@ -278,75 +330,125 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    n_events = 0
-    for i in range(args.warmup, n_frames):
-        n_events += step(i)
-    if lazy:
-        ft.finish(copy=False)  # the last published frame's deferred right-camera entries
-    if exch is not None:
-        exch.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
-    tot = torch.tensor([float(n_events), elapsed], dtype=torch.float64, device=xdev)
-    if world > 1:
-        ev_t = tot.clone()
-        dist.all_reduce(ev_t[0:1], op=dist.ReduceOp.SUM)
-        dist.all_reduce(ev_t[1:2], op=dist.ReduceOp.MAX)
-        tot = ev_t
-    total_events, max_elapsed = float(tot[0].item()), float(tot[1].item())
+        main_run.step(i)
+    # ---- the timed region: EXACTLY --steps steps (pass 0 is the headline); the same region is then
+    # repeated over the continued stream (passes 1..R-1) so that the spread can be reported
+    passes = []
+    for r in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        n_events = 0
+        lo = args.warmup + r * args.steps
+        for i in range(lo, lo + args.steps):
+            n_events += main_run.step(i)
+        if lazy:
+            ft.finish(copy=False)  # the last published frame's deferred right-camera entries
+        if exch is not None:
+            exch.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        tot = torch.tensor([float(n_events), elapsed], dtype=torch.float64, device=xdev)
+        if world > 1:
+            dist.all_reduce(tot[0:1], op=dist.ReduceOp.SUM)
+            dist.all_reduce(tot[1:2], op=dist.ReduceOp.MAX)
+        passes.append((float(tot[0].item()), float(tot[1].item()), n_events))
+    total_events, max_elapsed, n_events = passes[0]
     n_tracks = (len(ft.ids), len(ft.ids_right))
 
-    # ---- per-kernel pass: same stream continued, HIP events around every launch on the handle's
-    # stream (kept out of the timed region above because event records cost host time)
+    # ---- per-kernel pass (rank 0): HIP events around every launch on the stream it is launched on
+    # (kept out of the timed region because the records cost host time).  Two schedules over the
+    # first frames of the same stream, each on its own tracker:
+    #   "kernels"            strictly one batch in flight, nothing speculative or lazy: clean per-launch
+    #                        durations (no k_lk launch waits for k_select or for another k_lk)
+    #   "kernels_pipelined"  the replay schedule of the timed region: durations of the speculative /
+    #                        chained k_lk launches include the time their waves wait for their inputs
     roof = None
-    kernels = {}
-    if n_prof and (rank == 0 or cam_split):  # camera split: the rig needs both ranks every frame
-        ft.set_profiling(True)
-        ft.reset_kernel_stats()
-        tp0 = time.perf_counter()
-        for i in range(n_frames, n_frames + n_prof):
-            step(i, exchange=False)  # rank-0-only pass: no collectives
+    kernels, kernels_pipe = {}, {}
+    prof_ms = {}
+
+    def kernel_pass(pipe):
+        run = Runner(pipe, pipe and lazy, dev_batches)
+        for i in range(min(args.warmup, 6)):
+            run.step(i, exchange=False)
         torch.cuda.synchronize()
-        prof_ms_per_step = (time.perf_counter() - tp0) / n_prof * 1e3
-        stats = ft.kernel_stats()
-        ft.set_profiling(False)
-        for k, s in stats.items():
-            if s["launches"]:
-                avg_us = s["ms"] / s["launches"] * 1e3
-                gbs = (s["alg_bytes"] / s["launches"]) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-                kernels[k] = dict(total_ms=round(s["ms"], 4), launches=s["launches"],
-                                  avg_us=round(avg_us, 3),
-                                  alg_bytes_per_launch=s["alg_bytes"] // s["launches"],
-                                  achieved_GBs=round(gbs, 2))
+        run.ft.set_profiling(True)
+        run.ft.reset_kernel_stats()
+        tp0 = time.perf_counter()
+        lo = min(args.warmup, 6)
+        for i in range(lo, lo + n_prof):
+            run.step(i, exchange=False)
+        if pipe and lazy:
+            run.ft.finish(copy=False)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - tp0) / n_prof * 1e3
+        stats = run.ft.kernel_stats()
+        run.ft.close()
+        out = {}
+        for k, st in stats.items():
+            if st["launches"]:
+                avg_us = st["ms"] / st["launches"] * 1e3
+                gbs = (st["alg_bytes"] / st["launches"]) / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+                out[k] = dict(total_ms=round(st["ms"], 4), launches=st["launches"], avg_us=round(avg_us, 3),
+                              alg_bytes_per_launch=st["alg_bytes"] // st["launches"],
+                              achieved_GBs=round(gbs, 2), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 5))
+        return out, ms
+
+    if n_prof and rank == 0 and not one_rig:
+        kernels, prof_ms["one_batch_in_flight"] = kernel_pass(False)
+        if pipeline:
+            kp, prof_ms["replay"] = kernel_pass(True)
+            kernels_pipe = {k: dict(avg_us=v["avg_us"], launches=v["launches"]) for k, v in kp.items()}
         for k in kernels:  # PMC-measured HBM bytes per launch beside the algorithmic ones
-            kernels[k]["hbm_bytes_per_launch_pmc"] = pmc_traffic(k)[0]
+            tb, _, note = pmc_traffic(k)
+            kernels[k]["hbm_bytes_per_launch_pmc"] = tb
+            if note:
+                kernels[k]["pmc_note"] = note
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
         if dom:
             d = kernels[dom]
-            traffic, src = pmc_traffic(dom)
+            traffic, src, note = pmc_traffic(dom)
             roof = dict(bound="hbm", kernel=dom, achieved=d["achieved_GBs"], peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(d["achieved_GBs"] / HBM_PEAK_GBS, 6), traffic=traffic,
-                        traffic_source=src, avg_launch_us=d["avg_us"],
+                        traffic_source=src, traffic_note=note, avg_launch_us=d["avg_us"],
+                        avg_launch_us_replay_schedule=kernels_pipe.get(dom, {}).get("avg_us"),
                         alg_bytes_per_launch=d["alg_bytes_per_launch"],
-                        profiled_ms_per_step=round(prof_ms_per_step, 4),
-                        note="k_lk is dependent-instruction-latency bound (one wave per point, <=30 "
-                             "serial iterations per level), not HBM bound; see DESIGN.md section 4")
+                        profiled_ms_per_step=round(prof_ms["one_batch_in_flight"], 4),
+                        schedule="one batch in flight, no speculative / chained / lazy launches "
+                                 "(clean kernel durations); the timed region uses the replay schedule")
+
+    # ---- the same replay schedule with the events in HOST memory (what the drop-in binding of
+    # INTEGRATION.md passes): every batch then crosses PCIe inside the call that prefetches it
+    host_res = None
+    if rank == 0 and not one_rig and not args.no_host_pass:
+        run = Runner(pipeline, lazy, host_batches)
+        for i in range(args.warmup):
+            run.step(i, exchange=False)
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        ev = 0
+        for i in range(args.warmup, args.warmup + args.steps):
+            ev += run.step(i, exchange=False)
+        if lazy:
+            run.ft.finish(copy=False)
+        torch.cuda.synchronize()
+        th = time.perf_counter() - th0
+        run.ft.close()
+        host_res = dict(value=round(ev / th / 1e6, 3), unit="Mevents/s", ms_per_step=round(th / args.steps * 1e3, 4),
+                        h2d_GBs=round(ev * 16 / th / 1e9, 2),
+                        note="events handed over as pageable host buffers (ESVIO_FE_HOST); never `value`")
 
     # ---- CPU baseline: the oracle (single-threaded port of the reference path) on a bounded sample
     cpu = None
     if rank == 0 and args.cpu_frames > 0:
         from oracle import oracle as O
-        ocfg = O.make_config(W, H, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1, lk_accum=1)
+        ocfg = O.make_config(W, H, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1, lk_accum=1)
         tr_o = O.Tracker(ocfg)
         fco = FreqControl(args.freq)
         nfr = min(args.cpu_frames, len(host_batches))
         ev = 0
+        O.lk_pair_stats(True)
         tc0 = time.perf_counter()
         for i in range(nfr):
             L, R = host_batches[i]
@@ -364,10 +466,28 @@ def main():
                    ms_per_step=round(tc / nfr * 1e3, 3),
                    stage_ms_per_step={k: round(v / nfr * 1e3, 3) for k, v in st.items()},
                    host_cpus=os.cpu_count(), usable_cpus=usable_cpus())
+        if roof and roof["kernel"] == "k_lk":
+            # Issue model of the dominant kernel: one wave per point walks its <= 30 iterations per
+            # level serially, the launch lasts as long as its slowest point.  Iteration counts come
+            # from the CPU baseline run above (same frames, same arithmetic); instructions per
+            # iteration from the gfx950 ISA of lk_point's loop; issue rate of a lone wave from
+            # tools/clock_probe.hip.
+            ps = O.lk_pair_stats(True)
+            instr, cyc, ghz = 175, 5.2, 2.4
+            us_iter = instr * cyc / (ghz * 1e3)
+            roof["issue_model"] = dict(
+                iterations_slowest_point_per_launch=round(ps["slowest_mean"], 1),
+                iterations_mean_per_point=round(ps["mean_per_point"], 1),
+                instructions_per_iteration=instr, cycles_per_instruction_lone_wave=cyc, clock_GHz=ghz,
+                us_per_iteration=round(us_iter, 3),
+                modeled_us=round(ps["slowest_mean"] * us_iter, 1), measured_us=roof["avg_launch_us"],
+                note="latency-bound by construction: the HBM fraction of this kernel says nothing about "
+                     "its quality; the streaming kernels' fractions are in `kernels`")
         if args.cpu_procs != 0:
             cpu["all_cores"] = cpu_all_cores(host_batches[:nfr], args, W, H)
 
     if rank == 0:
+        ms_all = sorted(p[1] / args.steps * 1e3 for p in passes)
         out = {
             "metric": "Mevents/s through time-surface+detect+track @640x480",
             "value": round(total_events / max_elapsed / 1e6, 3),
@@ -377,27 +497,35 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong" if cam_split else "weak",
+            "scaling": "strong" if one_rig else "weak",
             "vs_baseline": None,
             "dtype": "f64 timestamps / u8 images / int64 LK sums",
             "data": "synthetic",
             "config": {
                 "workload": "C3 (superset of C2): stereo %dx%d scene stream, %.1f Mev/s per camera, "
                             "%g Hz batches, full SAE+TS+pyramid+LK(temporal,stereo)+Arc*+select, "
-                            "max_cnt 300 min_dist 10 flow_back 1 equalize 0 freq %d"
-                            % (W, H, args.rate / 1e6, args.batch_hz, args.freq),
+                            "max_cnt %d min_dist 10 flow_back 1 equalize 0 freq %d"
+                            % (W, H, args.rate / 1e6, args.batch_hz, args.max_cnt, args.freq),
                 "events_per_step_per_gpu": int(n_events / args.steps),
                 "parallelism": ("left/right camera split, 1 rig on 2 GPUs" if cam_split else
-                                "1 rig per GPU") if world > 1 else "single GPU",
+                                "one stream time-sliced over %d GPUs (SAE update), tracking on rank 0" % world
+                                if time_split else "1 rig per GPU") if world > 1 else "single GPU",
                 "tracks_last_frame": n_tracks,
                 "pipelined_next_batch": bool(pipeline),
                 "lazy_new_corner_stereo": bool(lazy),
                 "host_threads": int(max(1, args.host_threads)),
                 "batches_announced_ahead": int(args.ahead) if pipeline else 0,
             },
+            # the timed --steps region repeated over the continued stream (pass 0 = ms_per_step above)
+            "repeats": dict(passes=repeats, ms_per_step=[round(p[1] / args.steps * 1e3, 4) for p in passes],
+                            median=round(ms_all[len(ms_all) // 2], 4), min=round(ms_all[0], 4),
+                            max=round(ms_all[-1], 4),
+                            value_median=round(passes[0][0] / args.steps / ms_all[len(ms_all) // 2] / 1e3, 3)),
+            "host_resident_events": host_res,
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,
+            "kernels_replay_schedule": kernels_pipe,
         }
         print(json.dumps(out))
     ft.close()

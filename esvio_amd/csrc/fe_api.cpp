@@ -59,7 +59,8 @@ struct IdMap {
 
 const char* const kKernelNames[K_COUNT] = {
     "k_sae_keys", "k_radix_pass", "k_sae_apply",
-    "k_time_surface", "k_clahe", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select"};
+    "k_time_surface", "k_clahe", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select",
+    "k_arc_map"};
 
 struct KStat {
   double ms = 0;
@@ -147,6 +148,12 @@ struct esvio_fe_ctx {
   int slot_prevL = 0, slot_curL = 0, slot_curR = kLeftSlots;
   bool have_img = false;
   bool ext_right_pending = false;  // esvio_fe_import_image(cam=1) done for the next frame
+  // time-sliced stream (esvio_fe_sae_slice_*): scratch planes a slice is applied to, and the one-shot
+  // "the planes already hold the next frame's batch" set by esvio_fe_sae_slice_commit
+  double2 *L2s = nullptr, *S2s = nullptr;
+  double* slice_stage = nullptr;  // device staging for host-side slice planes
+  size_t slice_stage_doubles = 0;
+  bool ext_sae_pending = false;
   // ---- next-batch prefetch (esvio_fe_set_next_batch)
   std::deque<Batch> announced;     // announced, nothing enqueued yet (<= kPrefetchDepth)
   std::deque<Inflight> inflight;   // SAE update / images / pyramids enqueued on the prefetch stream
@@ -247,6 +254,9 @@ struct esvio_fe_ctx {
   } cand[kRightSlots];
   // per-pixel earliest candidate of a set's latest Arc* pass (ArcArgs::first_map / launch_dedup)
   uint32_t* d_first[kRightSlots] = {};
+  // per-pixel, per-polarity result of the event-independent part of isCorner (k_arc_map), one map
+  // per candidate set
+  uint8_t* d_cmap[kRightSlots] = {};
   uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
   bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1: A/B measurements)
   bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1: k_time_surface + 3 x k_pyr_down)
@@ -569,9 +579,11 @@ int first_event_host(esvio_fe_ctx* c, const esvio_fe_event* left, int space, esv
 }
 
 int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR,
-               uint32_t nR, const McParams* mc = nullptr) {
+               uint32_t nR, const McParams* mc = nullptr, double2* L2 = nullptr, double2* S2 = nullptr) {
   const uint32_t n = nL + nR;
   if (!n) return 0;
+  if (!L2) L2 = c->L2;  // (other planes: the scratch pair of the time-slice entry points)
+  if (!S2) S2 = c->S2;
   if (int rc = ensure_sort_capacity(c, n)) return rc;
   const int passes = (c->key_bits + 6) / 7;
   const int bits = (c->key_bits + passes - 1) / passes;
@@ -597,10 +609,10 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
     if (n >= c->sae_ev_min)  // many events per pixel: one lane per event
-      launch_sae_apply_ev(cur_stream(c), c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
+      launch_sae_apply_ev(cur_stream(c), c->keys[cur], c->vals[cur], n, evL, nL, evR, L2, S2,
                           c->cfg.feature_filter_threshold, c->invalid_key, c->hist, head, c->sae_marks);
     else
-      launch_sae_apply(cur_stream(c), c->keys[cur], c->vals[cur], n, evL, nL, evR, c->L2, c->S2,
+      launch_sae_apply(cur_stream(c), c->keys[cur], c->vals[cur], n, evL, nL, evR, L2, S2,
                        c->cfg.feature_filter_threshold, c->invalid_key, c->hist, head);
   }
   return 0;
@@ -983,6 +995,7 @@ void clear_tracker_state(esvio_fe_ctx* c) {
   c->slot_prevL = c->slot_curL = 0;
   c->slot_curR = kLeftSlots;
   c->ext_right_pending = false;
+  c->ext_sae_pending = false;
   c->cur_time = c->prev_time = 0;
 }
 
@@ -1075,6 +1088,12 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
       (void)hipMemsetAsync(c->d_first[set], 0xff, (size_t)c->P * 4, cur_stream(c));
     a.first_map = c->d_first[set];
     a.first_key = (254u - e) << 24;
+  }
+  a.cmap = c->d_cmap[set];
+  {
+    // one 16 B {S0,S1} and one 16 B {L0,L1} read per pixel + the TS byte, one map byte written
+    ScopedKernel k(c, K_ARC_MAP, (uint64_t)c->P * 34);
+    launch_arc_map(cur_stream(c), a);
   }
   {
     ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
@@ -1437,7 +1456,12 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     c->cur_prefetched = false;
     if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
     // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
-    if (motion) {
+    if (c->ext_sae_pending) {
+      // esvio_fe_sae_slice_commit has put this batch into the planes already (its SAE update ran
+      // time-sliced over several GPUs); the events are still needed below for Arc*
+      if (motion) return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update has no motion-compensated form");
+      c->ext_sae_pending = false;
+    } else if (motion) {
       esvio_fe_event first_ev;
       if (int rc = first_event_host(c, left, space, &first_ev)) return rc;
       const McParams mc = make_mc_params(motion, first_ev);
@@ -2172,7 +2196,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->tr_detect ? (double)c->tr_cand / c->tr_detect : 0.0,
             c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
-  void* ptrs[] = {c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
+  void* ptrs[] = {c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
@@ -2184,6 +2208,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
                     (void*)cs.total})
       if (p) (void)hipFree(p);
   for (uint32_t* p : c->d_first)
+    if (p) (void)hipFree(p);
+  for (uint8_t* p : c->d_cmap)
     if (p) (void)hipFree(p);
   for (PyrStore& ps : c->pyr)
     if (ps.mem) (void)hipFree(ps.mem);
@@ -2319,6 +2345,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if (const char* v = getenv("ESVIO_FE_SAE_EV_MIN")) c->sae_ev_min = (size_t)strtoull(v, nullptr, 10);
   for (int i = 0; i < kRightSlots; i++)
     if ((rc = dev_alloc(c, &c->d_first[i], (size_t)c->P))) return bail(rc);
+  for (int i = 0; i < kRightSlots; i++)
+    if ((rc = dev_alloc(c, &c->d_cmap[i], (size_t)c->P))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_slots, std::max<size_t>(M, 1)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_done, 1))) return bail(rc);
   if (hipMemsetAsync(c->d_chain, 0, std::max<size_t>(M, 1) * 16, cur_stream(c)) != hipSuccess ||
@@ -2426,6 +2454,105 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle c, const esvio_fe_event* left,
   if (pin_of(c).counts[3]) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
   if (n_rejected) *n_rejected = rej;
   if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+// ---- one stream time-sliced across GPUs -----------------------------------------
+namespace {
+int slice_scratch(esvio_fe_ctx* c) {
+  if (c->L2s) return 0;
+  if (int rc = dev_alloc(c, &c->L2s, (size_t)2 * c->P)) return rc;
+  if (int rc = dev_alloc(c, &c->S2s, (size_t)2 * c->P)) return rc;
+  return 0;
+}
+// device address of `k` consecutive plane sets given in `space` (host ones are staged)
+int slice_planes_in(esvio_fe_ctx* c, const double* p, size_t sets, int space, const double** dev) {
+  const size_t nd = sets * 4 * (size_t)c->P;
+  if (space == ESVIO_FE_DEVICE || !nd) {
+    *dev = p;
+    return 0;
+  }
+  if (space != ESVIO_FE_HOST) return fail(c, ESVIO_FE_EINVAL, "bad memory space %d", space);
+  if (nd > c->slice_stage_doubles) {
+    if (c->slice_stage) (void)hipFree(c->slice_stage);
+    c->slice_stage = nullptr;
+    c->slice_stage_doubles = 0;
+    if (int rc = dev_alloc(c, &c->slice_stage, nd)) return rc;
+    c->slice_stage_doubles = nd;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->slice_stage, p, nd * 8, hipMemcpyHostToDevice, cur_stream(c)));
+  *dev = c->slice_stage;
+  return 0;
+}
+int slice_planes_out(esvio_fe_ctx* c, const double2* src, double* out, int space) {
+  const size_t bytes = (size_t)4 * c->P * 8;
+  HIPCHK(c, hipMemcpyAsync(out, src, bytes, space == ESVIO_FE_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                           cur_stream(c)));
+  HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
+  if (pin_of(c).counts[3]) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
+  return 0;
+}
+}  // namespace
+
+size_t esvio_fe_sae_plane_doubles(esvio_fe_handle c) { return c ? (size_t)4 * c->P : 0; }
+
+int esvio_fe_sae_slice_last(esvio_fe_handle c, const esvio_fe_event* left, size_t nL,
+                            const esvio_fe_event* right, size_t nR, int space, double* last_out,
+                            int out_space) {
+  if (!c || !last_out || (nL && !left) || (nR && !right)) return ESVIO_FE_EINVAL;
+  if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  if (!c->inflight.empty() || !c->announced.empty())
+    return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update cannot be mixed with esvio_fe_set_next_batch");
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = slice_scratch(c)) return rc;
+  const EventRec *dL, *dR;
+  if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
+  // L[p] is overwritten by every event whatever the carried-in state is (event_detector.cc:158), so
+  // the slice's last event time per (pixel, polarity) is what the ordinary update leaves in planes
+  // that start out as "nothing"
+  launch_fill_f64(cur_stream(c), (double*)c->L2s, (size_t)4 * c->P, kSliceNone);
+  launch_fill_f64(cur_stream(c), (double*)c->S2s, (size_t)4 * c->P, kSliceNone);
+  if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, nullptr, c->L2s, c->S2s)) return rc;
+  return slice_planes_out(c, c->L2s, last_out, out_space);
+}
+
+int esvio_fe_sae_slice_apply(esvio_fe_handle c, const esvio_fe_event* left, size_t nL,
+                             const esvio_fe_event* right, size_t nR, int space,
+                             const double* last_before, int n_before, int in_space, double* s_out,
+                             int out_space) {
+  if (!c || !s_out || n_before < 0 || (n_before && !last_before) || (nL && !left) || (nR && !right))
+    return ESVIO_FE_EINVAL;
+  if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = slice_scratch(c)) return rc;
+  const size_t nd = (size_t)4 * c->P;
+  // carried-in L = the planes before the batch overlaid with the earlier slices in stream order;
+  // with it every pass decision of this slice is the sequential loop's (S never enters a decision)
+  HIPCHK(c, hipMemcpyAsync(c->L2s, c->L2, nd * 8, hipMemcpyDeviceToDevice, cur_stream(c)));
+  const double* dl = nullptr;
+  if (int rc = slice_planes_in(c, last_before, (size_t)n_before, in_space, &dl)) return rc;
+  for (int k = 0; k < n_before; k++)
+    launch_overlay_f64(cur_stream(c), (double*)c->L2s, dl + (size_t)k * nd, nd, kSliceNone);
+  launch_fill_f64(cur_stream(c), (double*)c->S2s, nd, kSliceNone);
+  const EventRec *dL, *dR;
+  if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
+  if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, nullptr, c->L2s, c->S2s)) return rc;
+  return slice_planes_out(c, c->S2s, s_out, out_space);
+}
+
+int esvio_fe_sae_slice_commit(esvio_fe_handle c, const double* last_all, const double* s_all, int n_slices,
+                              int space) {
+  if (!c || n_slices < 1 || !last_all || !s_all) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  const size_t nd = (size_t)4 * c->P;
+  for (int pass = 0; pass < 2; pass++) {  // (one staging buffer: L first, then S)
+    const double* dp = nullptr;
+    if (int rc = slice_planes_in(c, pass ? s_all : last_all, (size_t)n_slices, space, &dp)) return rc;
+    double* dst = pass ? (double*)c->S2 : (double*)c->L2;
+    for (int k = 0; k < n_slices; k++) launch_overlay_f64(cur_stream(c), dst, dp + (size_t)k * nd, nd, kSliceNone);
+    HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
+  }
+  c->ext_sae_pending = true;
   return 0;
 }
 
@@ -2862,6 +2989,13 @@ int esvio_fe_set_profiling(esvio_fe_handle c, int on) {
   c->prof_on = on != 0;
   return 0;
 }
+int esvio_fe_device_memory(esvio_fe_handle c, size_t* free_bytes, size_t* total_bytes) {
+  if (!c || !free_bytes || !total_bytes) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemGetInfo(free_bytes, total_bytes));
+  return 0;
+}
+
 int esvio_fe_kernel_count(void) { return K_COUNT; }
 const char* esvio_fe_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
 int esvio_fe_get_kernel_stats(esvio_fe_handle c, int id, double* total_ms, uint64_t* launches,

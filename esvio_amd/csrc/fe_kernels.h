@@ -92,6 +92,7 @@ enum KernelId {
   K_ARC,
   K_COMPACT,
   K_SELECT,
+  K_ARC_MAP,
   K_COUNT
 };
 
@@ -125,6 +126,12 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
                          const EventRec* evL, uint32_t nL, const EventRec* evR, double2* L2,
                          double2* S2, double filter_threshold, uint32_t invalid_key,
                          uint32_t* sort_scratch, uint32_t sort_scratch_words, uint8_t* marks /* [n] */);
+
+// ---- time-slice composition (one stream cut into N slices, one per GPU) -------------------
+constexpr double kSliceNone = -1.0;  // "this slice wrote nothing here" (event times are >= 0)
+void launch_fill_f64(hipStream_t s, double* p, size_t n, double v);
+// dst[i] = src[i] unless src[i] == none
+void launch_overlay_f64(hipStream_t s, double* dst, const double* src, size_t n, double none);
 
 // ---- time surface -----------------------------------------------------------------------
 // renders ncam cameras (S2 + cam*P) into level-0 interiors of dst[cam]
@@ -213,8 +220,12 @@ struct ArcArgs {
   // (first_key's top byte counts down), so the map is only cleared when that byte wraps
   uint32_t* first_map;
   uint32_t first_key;
+  // [W*H] per-pixel result of the event-independent part of isCorner (bit p: polarity p), written
+  // by launch_arc_map from the planes as they are, read by launch_arc
+  uint8_t* cmap;
 };
-void launch_arc(hipStream_t s, const ArcArgs& a);
+void launch_arc_map(hipStream_t s, const ArcArgs& a);  // per pixel x polarity (rings, L[!p] > L[p], TS, border)
+void launch_arc(hipStream_t s, const ArcArgs& a);      // per event, in stream order (needs the map)
 
 // Only the earliest candidate of a pixel can ever be accepted by the greedy selection
 // (feature_tracker.cpp:13-38: if it is accepted its disc blocks the pixel, if it is refused the

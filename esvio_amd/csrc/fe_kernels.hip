@@ -8,6 +8,7 @@
 #include "fe_kernels.h"
 #include "fe_mc.h"
 
+#include <algorithm>
 #include <cstring>
 #include <tuple>
 
@@ -623,6 +624,34 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
            marks);
   launch_k(k_sae_apply_ev_write, dim3((n + 255) / 256), dim3(256), 0, s, keys, vals, n, (const uint4*)evL,
            nL, (const uint4*)evR, L2, S2, (const uint8_t*)marks);
+}
+
+// ============================================================================ time-slice composition
+// One stream's batch cut into N time slices, one per GPU.  A slice's effect on
+// the planes is exchanged as planes holding kSliceNone where the slice wrote nothing; the planes
+// after the whole batch are the pre-batch planes overlaid with the slices in stream order.
+__global__ __launch_bounds__(256) void k_fill_f64(double* __restrict__ p, size_t n, double v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_overlay_f64(double* __restrict__ dst, const double* __restrict__ src,
+                                                     size_t n, double none) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double v = src[i];
+    if (v != none) dst[i] = v;
+  }
+}
+
+void launch_fill_f64(hipStream_t s, double* p, size_t n, double v) {
+  if (!n) return;
+  launch_k(k_fill_f64, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, p, n, v);
+}
+
+void launch_overlay_f64(hipStream_t s, double* dst, const double* src, size_t n, double none) {
+  if (!n) return;
+  launch_k(k_overlay_f64, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, dst, src, n,
+           none);
 }
 
 // ============================================================================ time surface
@@ -1705,12 +1734,56 @@ __device__ __forceinline__ bool arc_ring(const double* ring, int tstride) {
          ((newest_segment_size >= (N - KMAX)) && (newest_segment_size <= (N - KMIN)));
 }
 
-// EventDetector::isCorner (event_detector.cc:308-544) for every event of the batch in parallel,
-// fused with the two cheap tests Event_FeaturesToTrack does first (feature_tracker.cpp:25-26:
-// blocked-mask bit and time-surface == TS_LK_THRESHOLD), and an in-block ordered compaction of
-// the survivors (ballot + popcount), so the sequential greedy stage only sees candidates.
-__global__ __launch_bounds__(kArcBlock) void k_arc(ArcArgs a) {
+// EventDetector::isCorner (event_detector.cc:308-544) for a whole batch, in two kernels.
+//
+// isCorner is called after the whole batch is in the SAE (feature_tracker.cpp:356-368, then :458),
+// and its two ring tests (:337-541) read nothing but the post-batch S[p] around (x,y): their result
+// is a property of (pixel, polarity), not of the event.  Of the pre-check (:315)
+//     if (et > L[p] + thr || L[!p] > L[p]) return false;
+// only the first term looks at the event.  So
+//   k_arc_map   one thread per PIXEL evaluates  border && TS(y,x) != TS_LK_THRESHOLD &&
+//               !(L[!p] > L[p]) && small ring && large ring  for p = 0, 1 — at most one polarity
+//               survives the L comparison unless L[0] == L[1] — and writes a 2-bit map;
+//   k_arc_ev    one lane per EVENT streams the batch in order: flag = map bit of (pixel, polarity)
+//               && !(et > L[p] + thr); L is only fetched for events whose map bit is set; the
+//               blocked-mask test of Event_FeaturesToTrack (feature_tracker.cpp:25) and the ordered
+//               in-block compaction of the survivors (ballot + popcount) as before.
+// The ring values of x-adjacent threads are adjacent in memory (coalesced 8 B of every 16 B pair,
+// each line reused by the 16/20 ring offsets out of L1/L2); the ring itself sits in a
+// thread-private LDS column because the arc walk indexes it dynamically.
+__global__ __launch_bounds__(kArcBlock) void k_arc_map(ArcArgs a) {
   __shared__ double ring_s[20 * kArcBlock];  // 40 KiB: [ring idx][thread]
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4 pixel patch per block
+  const int x = blockIdx.x * 64 + tx, y = blockIdx.y * (kArcBlock / 64) + ty;
+  if (x >= a.W || y >= a.H) return;
+  const uint32_t px = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
+  uint32_t bits = 0;
+  bool ok = !(x < a.border || x >= a.W - a.border || y < a.border || y >= a.H - a.border);
+  // (the rings reach 4 pixels out; the reference would index out of its matrices for MIN_DIST < 3)
+  ok = ok && x >= 4 && y >= 4 && x < a.W - 4 && y < a.H - 4;
+  if (ok && a.ts) ok = (double)a.ts[(size_t)(y + kPad) * a.ts_stride + x + kPad] != a.ts_lk_threshold;
+  if (ok) {
+    const double2 Lv = a.L2[px];
+    double* ring = ring_s + threadIdx.x;  // thread-private LDS column
+#pragma unroll 1
+    for (int pol = 0; pol < 2; pol++) {
+      const double t_last = pol ? Lv.y : Lv.x, t_last_inv = pol ? Lv.x : Lv.y;
+      if (t_last_inv > t_last) continue;
+      const double* S = (const double*)a.S2 + pol;
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        ring[k * kArcBlock] = S[2 * ((size_t)(y + c_small[k][1]) * a.W + (x + c_small[k][0]))];
+      if (!arc_ring<16, 4, 6>(ring, kArcBlock)) continue;
+#pragma unroll
+      for (int k = 0; k < 20; k++)
+        ring[k * kArcBlock] = S[2 * ((size_t)(y + c_large[k][1]) * a.W + (x + c_large[k][0]))];
+      if (arc_ring<20, 5, 8>(ring, kArcBlock)) bits |= 1u << pol;
+    }
+  }
+  a.cmap[px] = (uint8_t)bits;
+}
+
+__global__ __launch_bounds__(kArcBlock) void k_arc_ev(ArcArgs a) {
   __shared__ uint32_t wave_cnt[kArcBlock / 64];
   const uint32_t i = blockIdx.x * kArcBlock + threadIdx.x;
   bool corner = false;
@@ -1722,35 +1795,13 @@ __global__ __launch_bounds__(kArcBlock) void k_arc(ArcArgs a) {
     if (x < (uint32_t)a.W && y < (uint32_t)a.H) {
       const int pol = (e.w & 0xffu) ? 1 : 0;
       const uint32_t px = y * (uint32_t)a.W + x;
-      bool ok = true;
-      if (a.mask_bits) ok = !((a.mask_bits[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
-      if (ok && a.ts)
-        ok = (double)a.ts[(size_t)(y + kPad) * a.ts_stride + x + kPad] != a.ts_lk_threshold;
+      bool ok = (a.cmap[px] >> pol) & 1u;
+      if (ok && a.mask_bits) ok = !((a.mask_bits[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
       if (ok) {
-        const double et = ev_time(e.y, e.z);
-        const double2 Lv = a.L2[px];
-        const double t_last = pol ? Lv.y : Lv.x;
-        const double t_last_inv = pol ? Lv.x : Lv.y;
-        if ((et > __dadd_rn(t_last, a.filter_threshold)) || (t_last_inv > t_last)) ok = false;
+        const double t_last = ((const double*)a.L2)[2 * (size_t)px + pol];
+        if (ev_time(e.y, e.z) > __dadd_rn(t_last, a.filter_threshold)) ok = false;
       }
-      if (ok && ((int)x < a.border || (int)x >= a.W - a.border || (int)y < a.border ||
-                 (int)y >= a.H - a.border))
-        ok = false;
-      if (ok) {
-        const double* S = (const double*)a.S2 + pol;
-        double* ring = ring_s + threadIdx.x;  // thread-private LDS column
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-          ring[k * kArcBlock] =
-              S[2 * ((size_t)(y + c_small[k][1]) * a.W + (x + c_small[k][0]))];
-        if (arc_ring<16, 4, 6>(ring, kArcBlock)) {
-#pragma unroll
-          for (int k = 0; k < 20; k++)
-            ring[k * kArcBlock] =
-                S[2 * ((size_t)(y + c_large[k][1]) * a.W + (x + c_large[k][0]))];
-          corner = arc_ring<20, 5, 8>(ring, kArcBlock);
-        }
-      }
+      corner = ok;
     }
     if (a.flags) a.flags[i] = corner ? 1 : 0;
   }
@@ -1775,9 +1826,14 @@ __global__ __launch_bounds__(kArcBlock) void k_arc(ArcArgs a) {
   }
 }
 
+void launch_arc_map(hipStream_t s, const ArcArgs& a) {
+  launch_k(k_arc_map, dim3((a.W + 63) / 64, (a.H + kArcBlock / 64 - 1) / (kArcBlock / 64)), dim3(kArcBlock), 0,
+           s, a);
+}
+
 void launch_arc(hipStream_t s, const ArcArgs& a) {
   if (!a.n) return;
-  launch_k(k_arc, dim3((a.n + kArcBlock - 1) / kArcBlock), dim3(kArcBlock), 0, s, a);
+  launch_k(k_arc_ev, dim3((a.n + kArcBlock - 1) / kArcBlock), dim3(kArcBlock), 0, s, a);
 }
 
 // see launch_dedup (fe_kernels.h): one block per Arc* block, list rewritten in place

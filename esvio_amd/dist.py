@@ -145,3 +145,80 @@ class CameraSplitRig:
             self.ft.trackEvent(cur_time, event_left, empty, pub_this_frame, copy=False)
             return self.ft
         return None
+
+
+def time_slice(n, world, rank):
+    """[lo, hi) of slice `rank` when n stream-ordered events are cut into `world` consecutive slices"""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+class TimeSlicedSae:
+    """BASELINE config C5 / SURVEY.md §8e.2: ONE stream, every batch cut into `world` consecutive time
+    slices, rank r applies slice r to the SAE (createSAE_left/right, event_detector.cc:149-166), two
+    all-gathers compose the planes, rank 0 (the rank the host feeds) runs the rest of trackEvent on
+    them.  Exact for any timestamps, ties and duplicates across the cuts:
+
+    * `L[p] = t` is unconditional (:158): a slice's last event time per (camera, pixel, polarity)
+      does not depend on what came before -> sae_slice_last, all-gather #1;
+    * the pass rule (:155) reads only L: with the exact carried-in L (planes before the batch
+      overlaid with the earlier slices) every decision of a slice is the sequential loop's ->
+      sae_slice_apply gives the time of the slice's last PASSING event, all-gather #2;
+    * planes after the batch = planes before it overlaid with the slices in order -> sae_slice_commit
+      on every rank (each needs them as the next batch's starting point).
+
+    `engine` is anything with sae_plane_doubles / sae_slice_last / sae_slice_apply / sae_slice_commit
+    and (rank 0) trackEvent: a frontend.FeatureTracker on the GPU, or the oracle-backed stand-in the
+    CPU tests use.  Cost: two all-gathers of a full plane set (2 cameras x W*H x 2 doubles) per
+    batch — at 1280x720 29.5 MB per rank — which is more than the SAE update of the slices saves on
+    one node; it is the capability SURVEY names, not a speed-up at these sizes."""
+
+    def __init__(self, engine, rank, world, dist, device="cpu"):
+        import torch
+        self.torch = torch
+        self.ft = engine
+        self.rank, self.world, self.dist = rank, world, dist
+        nd = engine.sae_plane_doubles()
+        self.nd = nd
+        self.on_gpu = device != "cpu"
+        kw = dict(dtype=torch.float64, device=device)
+        self.mine = torch.empty(nd, **kw)
+        self.last_all = torch.empty(world * nd, **kw)
+        self.s_all = torch.empty(world * nd, **kw)
+
+    def _arg(self, t, n_sets=1):
+        return (t.data_ptr(), n_sets) if self.on_gpu else t.numpy()
+
+    @staticmethod
+    def _cut(ev, lo, hi):
+        if isinstance(ev, tuple):  # (device pointer, count) of 16 B records
+            return (ev[0] + 16 * lo, hi - lo)
+        return ev[lo:hi]
+
+    @staticmethod
+    def _len(ev):
+        return ev[1] if isinstance(ev, tuple) else len(ev)
+
+    def apply_batch(self, event_left, event_right):
+        """the batch's SAE update, sliced; afterwards every rank's planes hold the batch"""
+        d, r, w = self.dist, self.rank, self.world
+        L = self._cut(event_left, *time_slice(self._len(event_left), w, r))
+        R = self._cut(event_right, *time_slice(self._len(event_right), w, r))
+        self.ft.sae_slice_last(L, R, self._arg(self.mine))
+        if self.on_gpu:
+            self.torch.cuda.current_stream().synchronize()
+        d.all_gather_into_tensor(self.last_all, self.mine)
+        if self.on_gpu:
+            self.torch.cuda.current_stream().synchronize()
+        self.ft.sae_slice_apply(L, R, self._arg(self.last_all, r), r, self._arg(self.mine))
+        d.all_gather_into_tensor(self.s_all, self.mine)
+        if self.on_gpu:
+            self.torch.cuda.current_stream().synchronize()
+        self.ft.sae_slice_commit(self._arg(self.last_all, w), self._arg(self.s_all, w), w)
+
+    def track(self, cur_time, event_left, event_right, pub_this_frame):
+        """cur_time = last LEFT event's stamp (node:190).  Returns the tracker on rank 0."""
+        self.apply_batch(event_left, event_right)
+        if self.rank == 0:
+            self.ft.trackEvent(cur_time, event_left, event_right, pub_this_frame, copy=False)
+            return self.ft
+        return None

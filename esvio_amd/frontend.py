@@ -86,6 +86,8 @@ ABI_SYMBOLS = [
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
     "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
+    "esvio_fe_sae_plane_doubles", "esvio_fe_sae_slice_last", "esvio_fe_sae_slice_apply",
+    "esvio_fe_sae_slice_commit", "esvio_fe_device_memory",
 ]
 
 _lib = None
@@ -149,6 +151,12 @@ def load_library(build_if_missing=True):
     L.esvio_fe_reset_kernel_stats.argtypes = [vp]
     L.esvio_fe_stream.restype = vp
     L.esvio_fe_stream.argtypes = [vp]
+    L.esvio_fe_device_memory.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    L.esvio_fe_sae_plane_doubles.restype = sz
+    L.esvio_fe_sae_plane_doubles.argtypes = [vp]
+    L.esvio_fe_sae_slice_last.argtypes = [vp, vp, sz, vp, sz, i, vp, i]
+    L.esvio_fe_sae_slice_apply.argtypes = [vp, vp, sz, vp, sz, i, vp, i, i, vp, i]
+    L.esvio_fe_sae_slice_commit.argtypes = [vp, vp, vp, i, i]
     _lib = L
     return L
 
@@ -406,6 +414,45 @@ class FeatureTracker:
 
     def reset(self):
         self._hd.check(self._hd.L.esvio_fe_reset(self._hd.h))
+
+    def device_memory(self):
+        """(free, total) bytes of the handle's device"""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        self._hd.check(self._hd.L.esvio_fe_device_memory(self._hd.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    # ---- one stream time-sliced across GPUs (esvio_fe_sae_slice_*); plane sets are numpy float64
+    # arrays (host) or (device_ptr, n_sets) tuples
+    def sae_plane_doubles(self):
+        return int(self._hd.L.esvio_fe_sae_plane_doubles(self._hd.h))
+
+    @staticmethod
+    def _planes_arg(a):
+        if isinstance(a, tuple):
+            return C.c_void_p(a[0]), DEVICE
+        return _p(a), HOST
+
+    def sae_slice_last(self, event_left, event_right, out):
+        pl, nl, sl, k1 = _events_arg(event_left)
+        pr, nr, sr, k2 = _events_arg(event_right)
+        assert sl == sr
+        po, so = self._planes_arg(out)
+        self._hd.check(self._hd.L.esvio_fe_sae_slice_last(self._hd.h, pl, nl, pr, nr, sl, po, so))
+
+    def sae_slice_apply(self, event_left, event_right, last_before, n_before, s_out):
+        pl, nl, sl, k1 = _events_arg(event_left)
+        pr, nr, sr, k2 = _events_arg(event_right)
+        assert sl == sr
+        pi, si = self._planes_arg(last_before) if n_before else (None, HOST)
+        po, so = self._planes_arg(s_out)
+        self._hd.check(self._hd.L.esvio_fe_sae_slice_apply(self._hd.h, pl, nl, pr, nr, sl, pi, int(n_before),
+                                                          si, po, so))
+
+    def sae_slice_commit(self, last_all, s_all, n_slices):
+        pa, sa = self._planes_arg(last_all)
+        pb, sb = self._planes_arg(s_all)
+        assert sa == sb
+        self._hd.check(self._hd.L.esvio_fe_sae_slice_commit(self._hd.h, pa, pb, int(n_slices), sa))
 
     def gettimesurface(self, cam=0):
         out = np.empty((self.cfg.height, self.cfg.width), np.uint8)

@@ -276,6 +276,35 @@ int esvio_fe_get_time_surface(esvio_fe_handle h, int cam, uint8_t* out);
 int esvio_fe_export_image(esvio_fe_handle h, int cam, uint8_t* dst, int space);
 int esvio_fe_import_image(esvio_fe_handle h, int cam, const uint8_t* src, int space);
 
+/* ---- one stream time-sliced across GPUs (BASELINE config C5) ------------- */
+/* createSAE_left/right (event_detector.cc:149-166) for ONE batch cut into N consecutive slices of the
+ * stream, one per GPU.  Every rank holds the planes as they were before the batch.  Per batch:
+ *   1. rank r: esvio_fe_sae_slice_last(its slice) -> last_r: per (camera, pixel, polarity) the time of
+ *      the slice's last event, ESVIO_FE_SLICE_NONE where it has none (L[p] = t is unconditional,
+ *      :158, so this does not depend on what came before);          all-gather last_0..last_{N-1}
+ *   2. rank r: esvio_fe_sae_slice_apply(its slice, last_0..last_{r-1}) -> s_r: the time of the
+ *      slice's last event that PASSES `t > L[p] + thr || L[!p] > L[p]` (:155), evaluated with the
+ *      exact carried-in L (planes before the batch overlaid with the earlier slices), NONE where no
+ *      event passes — the decisions are the sequential loop's for any timestamps; all-gather s_r
+ *   3. every rank: esvio_fe_sae_slice_commit(all last, all s): planes after the batch = planes
+ *      before it overlaid with the slices in order.  The next esvio_fe_track_event call on this
+ *      handle then takes the batch's SAE update as done (it still needs the batch's left events
+ *      for Arc*) — one shot, like esvio_fe_import_image.
+ * A plane set is esvio_fe_sae_plane_doubles(h) = 2 cameras x width*height x 2 polarities doubles in
+ * the handle's own order (opaque to the caller; it only travels between handles of the same size).
+ * Not to be mixed with esvio_fe_set_next_batch. */
+#define ESVIO_FE_SLICE_NONE (-1.0)
+size_t esvio_fe_sae_plane_doubles(esvio_fe_handle h);
+int esvio_fe_sae_slice_last(esvio_fe_handle h, const esvio_fe_event* left, size_t nL,
+                            const esvio_fe_event* right, size_t nR, int space, double* last_out,
+                            int out_space);
+int esvio_fe_sae_slice_apply(esvio_fe_handle h, const esvio_fe_event* left, size_t nL,
+                             const esvio_fe_event* right, size_t nR, int space,
+                             const double* last_before /* [n_before] plane sets */, int n_before,
+                             int in_space, double* s_out, int out_space);
+int esvio_fe_sae_slice_commit(esvio_fe_handle h, const double* last_all, const double* s_all,
+                              int n_slices, int space);
+
 /* ---- measurement --------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the handle's stream (off by default; when on, every launch is
  * bracketed by hipEventRecord and resolved lazily). */
@@ -288,6 +317,8 @@ int esvio_fe_get_kernel_stats(esvio_fe_handle h, int kernel_id, double* total_ms
 int esvio_fe_reset_kernel_stats(esvio_fe_handle h);
 /* the hipStream_t the handle launches on (as void*) */
 void* esvio_fe_stream(esvio_fe_handle h);
+/* hipMemGetInfo on the handle's device, through the HIP runtime the library itself is linked to */
+int esvio_fe_device_memory(esvio_fe_handle h, size_t* free_bytes, size_t* total_bytes);
 
 #ifdef __cplusplus
 }

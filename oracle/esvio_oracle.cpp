@@ -561,6 +561,31 @@ void scharr_padded(const uint8_t* src, int w, int h, int pad, std::vector<int16_
 
 // diagnostics: total LK iterations / (point,level) visits since the last reset
 unsigned long long g_lk_iters = 0, g_lk_visits = 0, g_lk_maxed = 0;
+// ... and per forward+backward PAIR of calls (what one fused k_lk launch runs per point): the
+// iterations of the slowest point and of the average point, summed over the pairs
+std::vector<int> g_lk_pair;          // per-point iterations of the pair being measured
+bool g_lk_pair_on = false;
+unsigned long long g_lk_pairs = 0, g_lk_pair_max_sum = 0, g_lk_pair_pts = 0, g_lk_pair_iter_sum = 0,
+                   g_lk_pair_max_max = 0;
+void lk_pair_begin(int n) {
+  g_lk_pair.assign((size_t)n, 0);
+  g_lk_pair_on = true;
+}
+void lk_pair_end() {
+  g_lk_pair_on = false;
+  if (g_lk_pair.empty()) return;
+  int mx = 0;
+  unsigned long long sum = 0;
+  for (int v : g_lk_pair) {
+    mx = std::max(mx, v);
+    sum += (unsigned long long)v;
+  }
+  g_lk_pairs++;
+  g_lk_pair_max_sum += (unsigned long long)mx;
+  g_lk_pair_max_max = std::max(g_lk_pair_max_max, (unsigned long long)mx);
+  g_lk_pair_pts += g_lk_pair.size();
+  g_lk_pair_iter_sum += sum;
+}
 
 // LKTrackerInvoker::operator() for all points at one level (video/src/lkpyramid.cpp) [OpenCV]
 // I, J: level images padded by `win` with BORDER_REFLECT_101; dI: Scharr (Ix,Iy) of I padded by
@@ -691,6 +716,7 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
     g_lk_visits++;
     for (int j = 0; j < maxCount; j++) {
       g_lk_iters++;
+      if (g_lk_pair_on && (size_t)ptidx < g_lk_pair.size()) g_lk_pair[ptidx]++;
       if (j == maxCount - 1) g_lk_maxed++;
       int inextX = cv_floor_f(nextX), inextY = cv_floor_f(nextY);
       if (inextX < -win || inextX >= cols || inextY < -win || inextY >= rows) {
@@ -1553,13 +1579,16 @@ int track_event(Tracker* t, double _cur_time, const oracle_event* left, size_t n
     int n = (int)t->prev_pts.size();
     std::vector<uint8_t> status(n);
     t->cur_pts.resize(n);
+    lk_pair_begin(n);
     calc_lk(t->prev_img_left.data(), t->cur_img_left.data(), W, H, &t->prev_pts[0].x,
             &t->cur_pts[0].x, status.data(), n, WIN, 3, 30, 0.01, 0, c.lk_accum);
+    if (!c.flow_back) lk_pair_end();
     if (c.flow_back) {
       std::vector<uint8_t> reverse_status(n);
       std::vector<P2f> reverse_pts = t->prev_pts;
       calc_lk(t->cur_img_left.data(), t->prev_img_left.data(), W, H, &t->cur_pts[0].x,
               &reverse_pts[0].x, reverse_status.data(), n, WIN, 1, 30, 0.01, 4, c.lk_accum);
+      lk_pair_end();
       for (size_t i = 0; i < status.size(); i++) {
         if (status[i] && reverse_status[i] && pt_distance(t->prev_pts[i], reverse_pts[i]) <= 0.5)
           status[i] = 1;
@@ -1617,11 +1646,14 @@ int track_event(Tracker* t, double _cur_time, const oracle_event* left, size_t n
       std::vector<P2f> reverseLeftPts(n);
       std::vector<uint8_t> status(n), statusRightLeft(n);
       t->cur_right_pts.resize(n);
+      lk_pair_begin(n);
       calc_lk(t->cur_img_left.data(), t->cur_img_right.data(), W, H, &t->cur_pts[0].x,
               &t->cur_right_pts[0].x, status.data(), n, WIN, 3, 30, 0.01, 0, c.lk_accum);
+      if (!(c.flow_back && !t->cur_right_pts.empty())) lk_pair_end();
       if (c.flow_back && !t->cur_right_pts.empty()) {
         calc_lk(t->cur_img_right.data(), t->cur_img_left.data(), W, H, &t->cur_right_pts[0].x,
                 &reverseLeftPts[0].x, statusRightLeft.data(), n, WIN, 3, 30, 0.01, 0, c.lk_accum);
+        lk_pair_end();
         for (size_t i = 0; i < status.size(); i++) {
           if (status[i] && statusRightLeft[i] && in_border_event(t, t->cur_right_pts[i]) &&
               pt_distance(t->cur_pts[i], reverseLeftPts[i]) <= 0.5)
@@ -2142,6 +2174,14 @@ void oracle_lk_iter_stats(unsigned long long* out3, int reset) {
   out3[1] = g_lk_visits;
   out3[2] = g_lk_maxed;
   if (reset) g_lk_iters = g_lk_visits = g_lk_maxed = 0;
+}
+void oracle_lk_pair_stats(unsigned long long* out5, int reset) {
+  out5[0] = g_lk_pairs;          // forward+backward pairs (= fused launches)
+  out5[1] = g_lk_pair_max_sum;   // sum over pairs of the slowest point's iterations
+  out5[2] = g_lk_pair_pts;       // points over all pairs
+  out5[3] = g_lk_pair_iter_sum;  // iterations over all points of all pairs
+  out5[4] = g_lk_pair_max_max;   // slowest point of any pair
+  if (reset) g_lk_pairs = g_lk_pair_max_sum = g_lk_pair_pts = g_lk_pair_iter_sum = g_lk_pair_max_max = 0;
 }
 void oracle_tracker_stage_seconds(void* tv, double* out6) {
   std::memcpy(out6, ((Tracker*)tv)->stage_s, sizeof(double) * 6);

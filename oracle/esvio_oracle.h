@@ -173,6 +173,9 @@ void oracle_tracker_time_surface(void* t, int cam, uint8_t* out);
 void* oracle_tracker_detector(void* t);
 /* diagnostics: {LK iterations, (point,level) visits, visits that hit maxCount} */
 void oracle_lk_iter_stats(unsigned long long* out3, int reset);
+/* per forward+backward pair of LK calls of the trackers (what one fused GPU launch runs per point):
+ * {pairs, sum of the slowest point's iterations, points, iterations, slowest point of any pair} */
+void oracle_lk_pair_stats(unsigned long long* out5, int reset);
 /* per-stage wall-clock accumulators (seconds): sae, ts, lk_temporal, detect, lk_stereo, host */
 void oracle_tracker_stage_seconds(void* t, double* out6);
 

@@ -126,6 +126,7 @@ def lib():
         L.oracle_euclid_halfwidths.argtypes = [i, vp]
         L.oracle_track_image.restype = i
         L.oracle_track_image.argtypes = [vp, d, vp, vp, i, C.POINTER(Tracks)]
+        L.oracle_lk_pair_stats.argtypes = [vp, i]
         _lib = L
     return _lib
 
@@ -416,3 +417,13 @@ class Tracker:
         out = np.zeros(6, np.float64)
         lib().oracle_tracker_stage_seconds(self.h, _p(out))
         return dict(zip(("sae", "ts", "lk_temporal", "detect", "lk_stereo", "host"), out))
+
+
+def lk_pair_stats(reset=False):
+    """iterations per forward+backward pair of LK calls the trackers made (what one fused GPU launch
+    runs per point): dict(pairs, slowest_mean, slowest_max, mean_per_point)"""
+    out = np.zeros(5, np.uint64)
+    lib().oracle_lk_pair_stats(_p(out), int(reset))
+    pairs, mx_sum, pts, it_sum, mx_mx = (int(v) for v in out)
+    return dict(pairs=pairs, slowest_mean=mx_sum / max(pairs, 1), slowest_max=mx_mx,
+                mean_per_point=it_sum / max(pts, 1))

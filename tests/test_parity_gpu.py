@@ -880,7 +880,11 @@ def test_randomized_small_cases(oracle):
 def test_create_destroy_many_handles():
     """handles can be created and destroyed repeatedly (streams, events, pinned and device memory are
     all released) and several can be alive at once"""
-    import torch
+    probe = FE.FeatureTracker(FE.make_config(346, 260))  # (stays alive: only asks for the free memory)
+
+    def free_bytes():
+        return probe.device_memory()[0]
+
     W, H = 346, 260
     s = SceneStream(W, H, rate=1e6, seed=1, n_rect=8, size=(25.0, 80.0))
     L, R, _ = s.next_batch()
@@ -894,5 +898,6 @@ def test_create_destroy_many_handles():
         for ft in fts:
             ft.close()
         if k == 2:
-            free0 = torch.cuda.mem_get_info()[0]
-    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "device memory leaks per handle"
+            free0 = free_bytes()
+    assert free_bytes() >= free0 - (64 << 20), "device memory leaks per handle"
+    probe.close()
