@@ -18,6 +18,7 @@ FLAGS = [
     "-fno-fast-math",
     "-Wall", "-Wno-unused-function",
     "-Wl,-rpath,/opt/rocm/lib",
+    "-ldl",
 ]
 
 
@@ -40,6 +41,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+TOOL_SRC = os.path.join(HERE, "..", "tools", "replay_node.cpp")
+TOOL_BIN = os.path.join(HERE, "..", "tools", "replay_node")
+
+
+def build_tools(force=False):
+    """tools/replay_node: the C++ host harness (handle_stereo_event over the C ABI), plain g++"""
+    src, out = os.path.abspath(TOOL_SRC), os.path.abspath(TOOL_BIN)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(
+            os.path.getmtime(src), os.path.getmtime(LIB), os.path.getmtime(os.path.join(HERE, "..", "include", "esvio_fe.h"))):
+        return out
+    cxx = os.environ.get("CXX", "g++")
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-Wall", src, "-I" + os.path.abspath(os.path.join(HERE, "..", "include")),
+                           "-L" + HERE, "-lesvio_fe", "-Wl,-rpath,$ORIGIN/../esvio_amd", "-Wl,-rpath,/opt/rocm/lib",
+                           "-Wl,-rpath-link,/opt/rocm/lib", "-ldl", "-o", out])
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)
+    print(build_tools(force="--force" in sys.argv))

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <utility>
@@ -140,6 +141,14 @@ struct esvio_fe_ctx {
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr;
   size_t sort_cap = 0, hist_cap = 0;
   size_t sae_ev_min = (size_t)1 << 20;  // batches of at least this many events: k_sae_apply_ev
+  // tiled SAE update (default; ESVIO_FE_SAE_SORT=1 or a sensor too large for one digit: the radix
+  // sort form above)
+  bool tiled = false;
+  TileGeom tgeom{};
+  EventRec* d_part = nullptr;  // the batch's events partitioned by bucket
+  size_t part_cap = 0;
+  uint32_t* d_tile = nullptr;  // TileScratch
+  size_t tile_cap = 0;
   uint8_t* sae_marks = nullptr;         // [sort_cap] its per-event "stores L / stores S" marks
   unsigned long long* d_rejected = nullptr;
   // left: slots 0..kLeftSlots-1 rotate (prev, cur, up to kPrefetchDepth being prefetched);
@@ -154,6 +163,9 @@ struct esvio_fe_ctx {
   double* slice_stage = nullptr;  // device staging for host-side slice planes
   size_t slice_stage_doubles = 0;
   bool ext_sae_pending = false;
+  // esvio_fe_exchange_tracks: send / receive buffers of the all-gather and the pinned pack area
+  float *x_send = nullptr, *x_recv = nullptr, *x_pin = nullptr;
+  size_t x_recv_cap = 0;
   // ---- next-batch prefetch (esvio_fe_set_next_batch)
   std::deque<Batch> announced;     // announced, nothing enqueued yet (<= kPrefetchDepth)
   std::deque<Inflight> inflight;   // SAE update / images / pyramids enqueued on the prefetch stream
@@ -256,7 +268,8 @@ struct esvio_fe_ctx {
   uint32_t* d_first[kRightSlots] = {};
   // per-pixel, per-polarity result of the event-independent part of isCorner (k_arc_map), one map
   // per candidate set
-  uint8_t* d_cmap[kRightSlots] = {};
+  uint32_t* d_cmap[kRightSlots] = {};
+  uint8_t* d_touched[kRightSlots] = {};  // (pixel, polarity) pairs a batch's left events hit
   uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
   bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1: A/B measurements)
   bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1: k_time_surface + 3 x k_pyr_down)
@@ -578,12 +591,57 @@ int first_event_host(esvio_fe_ctx* c, const esvio_fe_event* left, int space, esv
   return 0;
 }
 
+int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
+                     double2* L2, double2* S2) {
+  const uint32_t n = nL + nR;
+  if (n > c->part_cap) {
+    const size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
+    if (c->d_part) (void)hipFree(c->d_part);
+    c->d_part = nullptr;
+    c->part_cap = 0;
+    if (int rc = dev_alloc(c, &c->d_part, cap)) return rc;
+    c->part_cap = cap;
+  }
+  const size_t nblk_cap = (c->part_cap + 2047) / 2048;  // (2048 events per scatter block at least)
+  const size_t head = (size_t)3 * kTileMaxBins + 64;
+  const size_t need = head + (nblk_cap + 2 * (size_t)kTileMaxGroups) * kTileMaxBins;
+  if (need > c->tile_cap) {
+    if (c->d_tile) (void)hipFree(c->d_tile);
+    c->d_tile = nullptr;
+    c->tile_cap = 0;
+    if (int rc = dev_alloc(c, &c->d_tile, need)) return rc;
+    c->tile_cap = need;
+  }
+  TileScratch sc;
+  sc.totals = c->d_tile;
+  sc.tile_off = c->d_tile + kTileMaxBins;
+  sc.tile_order = c->d_tile + 2 * kTileMaxBins + 32;
+  sc.P = c->d_tile + head;
+  sc.T = sc.P + nblk_cap * kTileMaxBins;
+  sc.C = sc.T + (size_t)kTileMaxGroups * kTileMaxBins;
+  {
+    ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
+    launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected);
+  }
+  {
+    ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 16 B in, 16 B out
+    launch_tile_scatter(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_part);
+  }
+  {
+    ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
+    launch_tile_apply(cur_stream(c), c->d_part, c->tgeom, sc, L2, S2, c->cfg.feature_filter_threshold,
+                      c->z_counts + 3);
+  }
+  return 0;
+}
+
 int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR,
                uint32_t nR, const McParams* mc = nullptr, double2* L2 = nullptr, double2* S2 = nullptr) {
   const uint32_t n = nL + nR;
   if (!n) return 0;
   if (!L2) L2 = c->L2;  // (other planes: the scratch pair of the time-slice entry points)
   if (!S2) S2 = c->S2;
+  if (c->tiled && !mc) return sae_update_tiled(c, evL, nL, evR, nR, L2, S2);
   if (int rc = ensure_sort_capacity(c, n)) return rc;
   const int passes = (c->key_bits + 6) / 7;
   const int bits = (c->key_bits + passes - 1) / passes;
@@ -1090,9 +1148,12 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
     a.first_key = (254u - e) << 24;
   }
   a.cmap = c->d_cmap[set];
+  a.touched = c->d_touched[set];
   {
-    // one 16 B {S0,S1} and one 16 B {L0,L1} read per pixel + the TS byte, one map byte written
-    ScopedKernel k(c, K_ARC_MAP, (uint64_t)c->P * 34);
+    // the events' x,y,p once more (16 B records) -> touched bits; then per touched pair its 16/20
+    // ring values (counted once per pixel: 16 B) + {L0,L1}
+    ScopedKernel k(c, K_ARC_MAP, (uint64_t)n * 16 + (uint64_t)c->P * 32);
+    launch_arc_mark(cur_stream(c), a);
     launch_arc_map(cur_stream(c), a);
   }
   {
@@ -2196,7 +2257,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->tr_detect ? (double)c->tr_cand / c->tr_detect : 0.0,
             c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
-  void* ptrs[] = {c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
+  if (c->x_pin) (void)hipHostFree(c->x_pin);
+  void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_tile, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
@@ -2209,7 +2271,9 @@ int esvio_fe_destroy(esvio_fe_handle c) {
       if (p) (void)hipFree(p);
   for (uint32_t* p : c->d_first)
     if (p) (void)hipFree(p);
-  for (uint8_t* p : c->d_cmap)
+  for (uint32_t* p : c->d_cmap)
+    if (p) (void)hipFree(p);
+  for (uint8_t* p : c->d_touched)
     if (p) (void)hipFree(p);
   for (PyrStore& ps : c->pyr)
     if (ps.mem) (void)hipFree(ps.mem);
@@ -2343,10 +2407,17 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
   c->disc_tab_only = getenv("ESVIO_FE_DISC_TABLE") != nullptr;
   if (const char* v = getenv("ESVIO_FE_SAE_EV_MIN")) c->sae_ev_min = (size_t)strtoull(v, nullptr, 10);
+  c->tiled = make_tile_geom(c->W, c->H, &c->tgeom) && getenv("ESVIO_FE_SAE_SORT") == nullptr;
   for (int i = 0; i < kRightSlots; i++)
     if ((rc = dev_alloc(c, &c->d_first[i], (size_t)c->P))) return bail(rc);
-  for (int i = 0; i < kRightSlots; i++)
-    if ((rc = dev_alloc(c, &c->d_cmap[i], (size_t)c->P))) return bail(rc);
+  for (int i = 0; i < kRightSlots; i++) {
+    const size_t words = arc_bitmap_words(c->W, c->H);
+    if ((rc = dev_alloc(c, &c->d_cmap[i], words))) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_touched[i], arc_flag_bytes(c->W, c->H)))) return bail(rc);
+    if (hipMemsetAsync(c->d_cmap[i], 0, words * 4, cur_stream(c)) != hipSuccess ||
+        hipMemsetAsync(c->d_touched[i], 0, arc_flag_bytes(c->W, c->H), cur_stream(c)) != hipSuccess)
+      return bail(ESVIO_FE_EHIP);
+  }
   if ((rc = dev_alloc(c, &c->d_pub_slots, std::max<size_t>(M, 1)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_done, 1))) return bail(rc);
   if (hipMemsetAsync(c->d_chain, 0, std::max<size_t>(M, 1) * 16, cur_stream(c)) != hipSuccess ||
@@ -2933,6 +3004,50 @@ int esvio_fe_pack_track_records(esvio_fe_handle c, float* out, int32_t* n_rows) 
     for (int i = 0; i < 8; i++) r[i] = 0.f;
     r[3] = -1.f;
   }
+  return 0;
+}
+
+// ---- RCCL hand-off (north-star: "a single RCCL all-gather over xGMI to merge tracked corners") ----
+// RCCL is looked up at run time (dlopen librccl.so), so the library does not depend on it unless
+// this entry point is used.
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/,
+                                 hipStream_t);
+nccl_allgather_fn rccl_all_gather() {
+  static nccl_allgather_fn fn = []() -> nccl_allgather_fn {
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return lib ? (nccl_allgather_fn)dlsym(lib, "ncclAllGather") : nullptr;
+  }();
+  return fn;
+}
+}  // namespace
+
+int esvio_fe_exchange_tracks(esvio_fe_handle c, void* nccl_comm, int world, float* gathered) {
+  if (!c || !nccl_comm || world < 1 || !gathered) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  nccl_allgather_fn all_gather = rccl_all_gather();
+  if (!all_gather) return fail(c, ESVIO_FE_ENOTIMPL, "librccl.so not found (dlopen): %s", dlerror());
+  const size_t rows = (size_t)2 * std::max(c->cfg.max_cnt, 1), cnt = rows * 8;
+  if (!c->x_send) {
+    if (int rc = dev_alloc(c, &c->x_send, cnt)) return rc;
+    HIPCHK(c, hipHostMalloc((void**)&c->x_pin, cnt * sizeof(float), hipHostMallocDefault));
+  }
+  if ((size_t)world * cnt > c->x_recv_cap) {
+    if (c->x_recv) (void)hipFree(c->x_recv);
+    c->x_recv = nullptr;
+    c->x_recv_cap = 0;
+    if (int rc = dev_alloc(c, &c->x_recv, (size_t)world * cnt)) return rc;
+    c->x_recv_cap = (size_t)world * cnt;
+  }
+  if (int rc = esvio_fe_pack_track_records(c, c->x_pin, nullptr)) return rc;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->x_send, c->x_pin, cnt * 4, hipMemcpyHostToDevice, st));
+  const int nrc = all_gather(c->x_send, c->x_recv, cnt, 7 /* ncclFloat32 */, nccl_comm, st);
+  if (nrc != 0) return fail(c, ESVIO_FE_EHIP, "ncclAllGather failed: %d", nrc);
+  HIPCHK(c, hipMemcpyAsync(gathered, c->x_recv, (size_t)world * cnt * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
   return 0;
 }
 

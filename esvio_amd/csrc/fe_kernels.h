@@ -127,6 +127,56 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
                          double2* S2, double filter_threshold, uint32_t invalid_key,
                          uint32_t* sort_scratch, uint32_t sort_scratch_words, uint8_t* marks /* [n] */);
 
+// ---- SAE update, tiled form (default) --------------------------------------------------------
+// The sensor is cut into tiles of tw x th pixels; a tile of one camera is a bucket.  One stable
+// partition of the raw 16 B event records by bucket (k_tile_hist + k_tile_scan + k_tile_scatter:
+// one digit of <= 11 bits, no atomics or spins across blocks), then one block per bucket applies
+// its events in stream order
+// with the tile's L planes in LDS (k_tile_apply).  Replaces key generation + 3 radix passes over
+// (key, index) pairs + a gathering apply: per event 16 B are read three times and written once.
+struct TileGeom {
+  int W, H;
+  int tw, th;            // tile size in pixels (tw * th <= kTileMaxPx)
+  int tiles_x, tiles_y;  // tiles per camera
+  int nt_cam;            // tiles_x * tiles_y
+  int nbins;             // 2 * nt_cam + 1 (last bin: out-of-sensor events)
+  int bits;              // ceil(log2(nbins))
+  int pix_bits;          // ceil(log2(tw * th))
+};
+constexpr int kTileMaxBins = 2048;
+constexpr int kTileMaxPx = 2048;
+constexpr int kTileScatterThreads = 256;
+// smallest tile whose bucket count fits one digit; false: sensor too large for the tiled form
+bool make_tile_geom(int W, int H, TileGeom* g);
+inline uint32_t tile_scatter_events_per_block(uint32_t n) { return n >= (1u << 20) ? 4096u : 2048u; }
+inline uint32_t tile_scatter_blocks(uint32_t n) {
+  const uint32_t e = tile_scatter_events_per_block(n);
+  return (n + e - 1) / e;
+}
+// scatter block b owns the events [b*TE, (b+1)*TE); k_tile_hist block `seg` counts the buckets of
+// the `group` scatter blocks seg*group ..., so that the count matrices stay small: at most
+// kTileMaxGroups groups
+constexpr uint32_t kTileMaxGroups = 512;
+inline uint32_t tile_hist_group(uint32_t nblk) { return (nblk + kTileMaxGroups - 1) / kTileMaxGroups; }
+// scratch (uint32 words)
+struct TileScratch {
+  uint32_t* totals;    // [nbins] events per bucket
+  uint32_t* tile_off;  // [nbins + 1] exclusive bucket offsets into `part`, written by k_tile_scatter
+  uint32_t* tile_order;  // [nbins - 1] buckets by descending size class, written by k_tile_scatter
+  uint32_t* P;         // [nblk][nbins] bucket counts of the earlier scatter blocks of the same group
+  uint32_t* T;         // [ngroups][nbins] bucket counts per group
+  uint32_t* C;         // [ngroups][nbins] ... of all earlier groups
+};
+// k_tile_hist + k_tile_scan: P, C, totals; out-of-sensor events added to *n_rejected
+void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
+                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected);
+// stable partition of [left; right] into `part` by bucket
+void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
+                         const TileGeom& g, const TileScratch& sc, EventRec* part);
+// createSAE_left/right (event_detector.cc:149-166, :212-228) per bucket, events in stream order
+void launch_tile_apply(hipStream_t s, const EventRec* part, const TileGeom& g, const TileScratch& sc,
+                       double2* L2, double2* S2, double filter_threshold, int* err);
+
 // ---- time-slice composition (one stream cut into N slices, one per GPU) -------------------
 constexpr double kSliceNone = -1.0;  // "this slice wrote nothing here" (event times are >= 0)
 void launch_fill_f64(hipStream_t s, double* p, size_t n, double v);
@@ -220,12 +270,20 @@ struct ArcArgs {
   // (first_key's top byte counts down), so the map is only cleared when that byte wraps
   uint32_t* first_map;
   uint32_t first_key;
-  // [W*H] per-pixel result of the event-independent part of isCorner (bit p: polarity p), written
-  // by launch_arc_map from the planes as they are, read by launch_arc
-  uint8_t* cmap;
+  // touched: one flag byte per (pixel, polarity), index 2*pixel + polarity (arc_flag_bytes()), set by
+  //          launch_arc_mark for every pair the batch has an event of, consumed (and cleared) by
+  //          launch_arc_map; must start out zeroed
+  // cmap:    bitmap, bit 2*pixel + polarity (arc_bitmap_words() words): result of the
+  //          event-independent part of isCorner for the touched pairs, written by launch_arc_map
+  //          from the planes as they are, read by launch_arc
+  uint8_t* touched;
+  uint32_t* cmap;
 };
-void launch_arc_map(hipStream_t s, const ArcArgs& a);  // per pixel x polarity (rings, L[!p] > L[p], TS, border)
-void launch_arc(hipStream_t s, const ArcArgs& a);      // per event, in stream order (needs the map)
+inline size_t arc_bitmap_words(int W, int H) { return ((size_t)2 * W * H + 31) / 32 + 64; }
+inline size_t arc_flag_bytes(int W, int H) { return (size_t)2 * W * H + 1024; }
+void launch_arc_mark(hipStream_t s, const ArcArgs& a);  // per event: which (pixel, polarity) pairs occur
+void launch_arc_map(hipStream_t s, const ArcArgs& a);   // per touched pair (rings, L[!p] > L[p], TS, border)
+void launch_arc(hipStream_t s, const ArcArgs& a);       // per event, in stream order (needs the map)
 
 // Only the earliest candidate of a pixel can ever be accepted by the greedy selection
 // (feature_tracker.cpp:13-38: if it is accepted its disc blocks the pixel, if it is refused the

@@ -626,6 +626,421 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
            nL, (const uint4*)evR, L2, S2, (const uint8_t*)marks);
 }
 
+// ============================================================================ SAE update, tiled
+// See fe_kernels.h (TileGeom).  Bucket of an event = camera * nt_cam + (y / th) * tiles_x + x / tw,
+// or the last bin for an out-of-sensor event.
+bool make_tile_geom(int W, int H, TileGeom* g) {
+  static const int cand[][2] = {{32, 16}, {32, 32}, {64, 32}};
+  for (const auto& c : cand) {
+    const int tx = (W + c[0] - 1) / c[0], ty = (H + c[1] - 1) / c[1];
+    const int nb = 2 * tx * ty + 1;
+    if (nb > kTileMaxBins || c[0] * c[1] > kTileMaxPx) continue;
+    g->W = W;
+    g->H = H;
+    g->tw = c[0];
+    g->th = c[1];
+    g->tiles_x = tx;
+    g->tiles_y = ty;
+    g->nt_cam = tx * ty;
+    g->nbins = nb;
+    g->bits = 1;
+    while ((1 << g->bits) < nb) g->bits++;
+    g->pix_bits = 1;
+    while ((1 << g->pix_bits) < c[0] * c[1]) g->pix_bits++;
+    return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ uint32_t tile_bin(const TileGeom& g, uint32_t xy, bool right) {
+  const uint32_t x = xy & 0xffffu, y = xy >> 16;
+  if (x >= (uint32_t)g.W || y >= (uint32_t)g.H) return (uint32_t)g.nbins - 1u;
+  // tw is 32 or 64, th 16 or 32: shifts
+  const uint32_t tx = x >> (g.tw == 64 ? 6 : 5), ty = y >> (g.th == 32 ? 5 : 4);
+  return (right ? (uint32_t)g.nt_cam : 0u) + ty * (uint32_t)g.tiles_x + tx;
+}
+
+// Per-block bucket counts without global atomics or look-back: block `seg` of k_tile_hist walks the
+// `group` scatter blocks seg*group .. seg*group+group-1 one after the other — scatter block b owns
+// the events [b*TE, (b+1)*TE) of the stream — and writes, per scatter block, the exclusive prefix of
+// the bucket counts inside its group (P[b][bucket], one coalesced row) and the group totals
+// (T[seg][bucket]); k_tile_scan turns the group totals into exclusive prefixes over the groups
+// (C[seg][bucket]) and bucket totals.  k_tile_scatter then knows where every event goes:
+// bucket start + C[group][bucket] + P[block][bucket] + rank inside the block.
+constexpr int kTileHistThreads = 1024;
+__global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __restrict__ evL, uint32_t nL,
+                                                   const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
+                                                   uint32_t te, uint32_t nblk, uint32_t group,
+                                                   uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm) {
+  __shared__ uint32_t h[kTileMaxBins], run[kTileMaxBins];
+  const int nb = g.nbins;
+  for (int i = threadIdx.x; i < nb; i += kTileHistThreads) run[i] = 0;
+  const uint32_t n = nL + nR;
+  for (uint32_t k = 0; k < group; k++) {
+    const uint32_t b = blockIdx.x * group + k;
+    if (b >= nblk) break;
+    for (int i = threadIdx.x; i < nb; i += kTileHistThreads) h[i] = 0;
+    __syncthreads();
+    const uint32_t lo = b * te, hi = min(lo + te, n);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kTileHistThreads) {
+      const bool right = i >= nL;
+      // only x,y are needed here: one dword of the 16 B record
+      const uint32_t xy = right ? ((const uint32_t*)evR)[4 * (size_t)(i - nL)] : ((const uint32_t*)evL)[4 * (size_t)i];
+      atomicAdd(&h[tile_bin(g, xy, right)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
+      const uint32_t r = run[i];
+      Pm[(size_t)b * nb + i] = r;
+      run[i] = r + h[i];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += kTileHistThreads) Tm[(size_t)blockIdx.x * nb + i] = run[i];
+}
+
+// exclusive prefix of the group totals over the groups, per bucket: lane = bucket, the 16 waves of a
+// block take consecutive ranges of groups
+constexpr int kTileScanThreads = 1024;
+__global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* __restrict__ Tm, uint32_t nseg,
+                                                                int nb, uint32_t* __restrict__ Cm,
+                                                                uint32_t* __restrict__ totals,
+                                                                unsigned long long* n_rejected) {
+  __shared__ uint32_t part[kTileScanThreads / 64][64];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  constexpr int NW = kTileScanThreads / 64;
+  const int bin = blockIdx.x * 64 + lane;
+  const bool ok = bin < nb;
+  const uint32_t per = (nseg + NW - 1) / NW;
+  const uint32_t s0 = min((uint32_t)wave * per, nseg), s1 = min(s0 + per, nseg);
+  uint32_t sum = 0;
+  for (uint32_t s = s0; s < s1; s++) sum += ok ? Tm[(size_t)s * nb + bin] : 0u;
+  part[wave][lane] = sum;
+  __syncthreads();
+  uint32_t carry = 0, tot = 0;
+  for (int w = 0; w < NW; w++) {
+    const uint32_t v = part[w][lane];
+    if (w < wave) carry += v;
+    tot += v;
+  }
+  for (uint32_t s = s0; s < s1; s++) {
+    if (!ok) break;
+    const uint32_t v = Tm[(size_t)s * nb + bin];
+    Cm[(size_t)s * nb + bin] = carry;
+    carry += v;
+  }
+  if (wave == 0 && ok) {
+    totals[bin] = tot;
+    if (bin == nb - 1 && tot) atomicAdd(n_rejected, (unsigned long long)tot);  // out-of-sensor events
+  }
+}
+
+void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
+                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected) {
+  const uint32_t n = nL + nR;
+  if (!n) return;
+  const uint32_t te = tile_scatter_events_per_block(n), nblk = tile_scatter_blocks(n);
+  const uint32_t group = tile_hist_group(nblk), nseg = (nblk + group - 1) / group;
+  launch_k(k_tile_hist, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, te, nblk,
+           group, sc.P, sc.T);
+  launch_k(k_tile_scan, dim3((g.nbins + 63) / 64), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,
+           g.nbins, sc.C, sc.totals, n_rejected);
+}
+
+// Stable partition by bucket: a block ranks its 256 * ROUNDS consecutive events stably (wave-level
+// match-any by ballots keeps stream order inside a bucket) and writes the 16 B records to their
+// final places.
+template <int ROUNDS>
+__global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
+    const uint4* __restrict__ evL, uint32_t nL, const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
+    uint32_t group, const uint32_t* __restrict__ Pm, const uint32_t* __restrict__ Cm,
+    const uint32_t* __restrict__ totals, uint4* __restrict__ part, uint32_t* __restrict__ tile_off,
+    uint32_t* __restrict__ tile_order) {
+  __shared__ uint32_t wave_cnt[4][kTileMaxBins];  // 32 KiB
+  __shared__ uint32_t bin_base[kTileMaxBins];     // 8 KiB
+  __shared__ uint32_t wave_tot[4];
+  constexpr int TE = kTileScatterThreads * ROUNDS;
+  constexpr int KB = kTileMaxBins / kTileScatterThreads;  // bins per thread (8)
+  const int nb = g.nbins;
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  for (int i = threadIdx.x; i < 4 * kTileMaxBins; i += kTileScatterThreads) (&wave_cnt[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t tile = blockIdx.x;
+  const uint32_t n = nL + nR;
+
+  uint4 rec[ROUNDS];
+  uint32_t rank[ROUNDS];
+  const uint32_t wbase = tile * TE + wave * (TE / 4);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint32_t i = wbase + r * 64 + lane;
+    rec[r] = i < nL ? evL[i] : (i < n ? evR[i - nL] : make_uint4(0xffffffffu, 0, 0, 0));
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint32_t i = wbase + r * 64 + lane;
+    const bool ok = i < n;
+    const uint32_t d = tile_bin(g, rec[r].x, i >= nL);
+    // match-any on the bucket: lanes holding the same bucket, in lane (= stream) order
+    unsigned long long m = __ballot(ok);
+    for (int b = 0; b < g.bits; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t before = __popcll(m & lt);
+    const uint32_t cnt = __popcll(m);
+    uint32_t base = 0;
+    if (ok) base = wave_cnt[wave][d];
+    rank[r] = base + before;
+    if (ok && before == 0) wave_cnt[wave][d] = base + cnt;  // one leader per bucket
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  }
+  // exclusive scan of the bucket totals: thread t owns bins [t*KB, t*KB+KB)
+  {
+    uint32_t loc[KB], sum = 0;
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int b = threadIdx.x * KB + k;
+      loc[k] = b < nb ? totals[b] : 0u;
+      sum += loc[k];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; w++) run += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int b = threadIdx.x * KB + k;
+      bin_base[b] = run;
+      if (tile == 0 && b <= nb) tile_off[b] = run;  // (b == nb: the total)
+      run += loc[k];
+    }
+    if (tile == gridDim.x - 1) {
+      // the order k_tile_apply takes the buckets in: largest size class (floor(log2(events))) first,
+      // so that a bucket with many times the average number of events starts at once and the
+      // launch does not end with it (counting sort by class; the order inside a class is arbitrary)
+      __shared__ uint32_t cls_cnt[33];
+      if (threadIdx.x < 33) cls_cnt[threadIdx.x] = 0;
+      __syncthreads();
+      const int nt = nb - 1;
+#pragma unroll
+      for (int k = 0; k < KB; k++) {
+        const int b = threadIdx.x * KB + k;
+        if (b < nt) atomicAdd(&cls_cnt[loc[k] ? 32 - __clz(loc[k]) : 0], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {  // exclusive prefix, largest class first
+        uint32_t acc = 0;
+        for (int c = 32; c >= 0; c--) {
+          const uint32_t t = cls_cnt[c];
+          cls_cnt[c] = acc;
+          acc += t;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < KB; k++) {
+        const int b = threadIdx.x * KB + k;
+        if (b < nt) tile_order[atomicAdd(&cls_cnt[loc[k] ? 32 - __clz(loc[k]) : 0], 1u)] = (uint32_t)b;
+      }
+    }
+  }
+  __syncthreads();
+  // first position of (this block, wave, bucket): bucket start + earlier groups + earlier blocks of
+  // the group + earlier waves of the block
+  const uint32_t* Prow = Pm + (size_t)tile * nb;
+  const uint32_t* Crow = Cm + (size_t)(tile / group) * nb;
+  for (int d = threadIdx.x; d < nb; d += kTileScatterThreads) {
+    uint32_t run = bin_base[d] + Crow[d] + Prow[d];
+    for (int w = 0; w < 4; w++) {
+      const uint32_t t = wave_cnt[w][d];
+      wave_cnt[w][d] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint32_t i = wbase + r * 64 + lane;
+    if (i < n) {
+      const uint32_t d = tile_bin(g, rec[r].x, i >= nL);
+      part[wave_cnt[wave][d] + rank[r]] = rec[r];
+    }
+  }
+}
+
+void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
+                         const TileGeom& g, const TileScratch& sc, EventRec* part) {
+  const uint32_t n = nL + nR;
+  if (!n) return;
+  const uint32_t nblk = tile_scatter_blocks(n), group = tile_hist_group(nblk);
+  if (tile_scatter_events_per_block(n) == 4096u)
+    launch_k(k_tile_scatter<16>, dim3(nblk), dim3(kTileScatterThreads), 0, s, (const uint4*)evL, nL,
+             (const uint4*)evR, nR, g, group, (const uint32_t*)sc.P, (const uint32_t*)sc.C,
+             (const uint32_t*)sc.totals, (uint4*)part, sc.tile_off, sc.tile_order);
+  else
+    launch_k(k_tile_scatter<8>, dim3(nblk), dim3(kTileScatterThreads), 0, s, (const uint4*)evL, nL,
+             (const uint4*)evR, nR, g, group, (const uint32_t*)sc.P, (const uint32_t*)sc.C,
+             (const uint32_t*)sc.totals, (uint4*)part, sc.tile_off, sc.tile_order);
+}
+
+// One block per bucket.  The tile's {L[0],L[1]} sit in LDS; the bucket's events are taken in turns
+// of kTileTurn chunks of 64, one wave per turn, waves taking the turns round-robin.  What an event
+// needs is the time of the nearest earlier event of its own and of the other polarity at its pixel
+// (that IS L[p] / L[!p] when the sequential loop reaches it): inside the chunk by a match-any on the
+// pixel (ballots) and a lane shuffle, before the chunk from LDS.  The LDS reads and the L[p] = t
+// writes of a chunk's last event per (pixel, polarity) must follow those of all earlier chunks: a
+// ticket in LDS orders the turns — a wave does the reads and writes of its kTileTurn chunks back to
+// back while it holds the ticket (LDS executes a wave's accesses in order), everything else
+// (loads, ballots, the pass rule) runs unordered.  S is the time of the pixel's last PASSING event,
+// kept as the largest passing position (LDS atomic max, any order) and turned into a time at the end.
+// Only touched pixels are written back.
+constexpr int kTileApplyThreads = 1024;
+constexpr int kTileTurn = 4;
+__global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
+    const uint4* __restrict__ part, const uint32_t* __restrict__ tile_off,
+    const uint32_t* __restrict__ tile_order, TileGeom g, double2* __restrict__ L2, double2* __restrict__ S2,
+    double thr, int* __restrict__ err) {
+  __shared__ double2 Ls[kTileMaxPx];          // 32 KiB
+  __shared__ uint32_t Sidx[2 * kTileMaxPx];   // 16 KiB: 1 + position of the last passing event
+  __shared__ uint32_t touched[kTileMaxPx / 32];
+  __shared__ uint32_t s_done;
+  const uint32_t tile = tile_order[blockIdx.x];
+  const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
+  if (beg == end) return;
+  const uint32_t cam = tile >= (uint32_t)g.nt_cam ? 1u : 0u;
+  const uint32_t tt = tile - cam * (uint32_t)g.nt_cam;
+  const int ty = (int)(tt / (uint32_t)g.tiles_x), tx = (int)(tt - (uint32_t)ty * (uint32_t)g.tiles_x);
+  const int x0 = tx * g.tw, y0 = ty * g.th;
+  const int npx = g.tw * g.th;
+  const int twsh = g.tw == 64 ? 6 : 5;
+  const size_t P = (size_t)g.W * g.H;
+  for (int p = threadIdx.x; p < npx; p += kTileApplyThreads) {
+    const int gx = x0 + (p & (g.tw - 1)), gy = y0 + (p >> twsh);
+    Ls[p] = (gx < g.W && gy < g.H) ? L2[cam * P + (size_t)gy * g.W + gx] : make_double2(0, 0);
+    Sidx[2 * p] = 0;
+    Sidx[2 * p + 1] = 0;
+  }
+  for (int i = threadIdx.x; i < kTileMaxPx / 32; i += kTileApplyThreads) touched[i] = 0;
+  if (threadIdx.x == 0) s_done = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  constexpr int NW = kTileApplyThreads / 64;
+  const uint32_t nchunks = (end - beg + 63u) / 64u;
+  const uint32_t nturns = (nchunks + kTileTurn - 1) / kTileTurn;
+  const unsigned long long self = 1ull << lane, below = self - 1ull, above = ~(below | self);
+  auto msb = [](unsigned long long m) { return 63 - __clzll((long long)m); };
+  // (a wave's next turn is requested while it works on the current one)
+  uint4 nxt[kTileTurn];
+#pragma unroll
+  for (int k = 0; k < kTileTurn; k++) {
+    const uint32_t i = beg + ((uint32_t)wave * kTileTurn + k) * 64u + (uint32_t)lane;
+    nxt[k] = part[i < end ? i : beg];
+  }
+  for (uint32_t turn = wave; turn < nturns; turn += NW) {
+    uint32_t pixk[kTileTurn];
+    double tk[kTileTurn], ts_in[kTileTurn], to_in[kTileTurn];
+    uint32_t flg[kTileTurn];  // 1 valid, 2 polarity, 4 has same-polarity predecessor in the chunk, 8 other, 16 last
+    uint4 cur[kTileTurn];
+#pragma unroll
+    for (int k = 0; k < kTileTurn; k++) {
+      cur[k] = nxt[k];
+      const uint32_t i = beg + ((turn + NW) * kTileTurn + k) * 64u + (uint32_t)lane;
+      nxt[k] = part[i < end ? i : beg];
+    }
+#pragma unroll
+    for (int k = 0; k < kTileTurn; k++) {
+      const uint32_t i = beg + (turn * kTileTurn + k) * 64u + (uint32_t)lane;
+      const bool valid = i < end;
+      const uint4 e = cur[k];
+      const uint32_t pix = (((e.x >> 16) - (uint32_t)y0) << twsh) + ((e.x & 0xffffu) - (uint32_t)x0);
+      const bool pol = (e.w & 0xffu) != 0;
+      const double t = ev_time(e.y, e.z);
+      unsigned long long m = __ballot(valid);
+      for (int b = 0; b < g.pix_bits; b++) {
+        const unsigned long long bal = __ballot((pix >> b) & 1u);
+        m &= ((pix >> b) & 1u) ? bal : ~bal;
+      }
+      const unsigned long long m1 = __ballot(valid && pol);
+      const unsigned long long same = m & (pol ? m1 : ~m1), opp = m & (pol ? ~m1 : m1);
+      const unsigned long long bs = same & below, bo = opp & below;
+      ts_in[k] = __shfl(t, bs ? msb(bs) : lane);
+      to_in[k] = __shfl(t, bo ? msb(bo) : lane);
+      pixk[k] = valid ? pix : 0u;
+      tk[k] = t;
+      flg[k] = (valid ? 1u : 0u) | (pol ? 2u : 0u) | (bs ? 4u : 0u) | (bo ? 8u : 0u) |
+               ((valid && (same & above) == 0) ? 16u : 0u);
+    }
+    // ---- ordered part: after every earlier turn's
+    if (lane == 0) {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != turn) {
+        if (++spins > (1u << 26)) {  // bounded: never hang the GPU
+          *err = 2;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __asm__ volatile("" ::: "memory");
+    double2 fb[kTileTurn];
+#pragma unroll
+    for (int k = 0; k < kTileTurn; k++) {
+      fb[k] = make_double2(0, 0);
+      if ((flg[k] & 1u) && (flg[k] & 12u) != 12u) fb[k] = Ls[pixk[k]];
+      __asm__ volatile("" ::: "memory");
+      if (flg[k] & 16u) ((double*)&Ls[pixk[k]])[(flg[k] >> 1) & 1u] = tk[k];
+      __asm__ volatile("" ::: "memory");
+    }
+    // (LDS executes a wave's instructions in order: the ticket becomes visible after the accesses above)
+    if (lane == 0) __hip_atomic_store(&s_done, turn + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // ---- unordered again
+#pragma unroll
+    for (int k = 0; k < kTileTurn; k++) {
+      const bool pol = (flg[k] & 2u) != 0;
+      const double prev_same = (flg[k] & 4u) ? ts_in[k] : (pol ? fb[k].y : fb[k].x);
+      const double prev_opp = (flg[k] & 8u) ? to_in[k] : (pol ? fb[k].x : fb[k].y);
+      const bool pass = (flg[k] & 1u) && ((tk[k] > __dadd_rn(prev_same, thr)) || (prev_opp > prev_same));
+      const uint32_t pos = (turn * kTileTurn + k) * 64u + (uint32_t)lane + 1u;
+      if (pass) atomicMax(&Sidx[2 * pixk[k] + (pol ? 1 : 0)], pos);
+      if (flg[k] & 16u) atomicOr(&touched[pixk[k] >> 5], 1u << (pixk[k] & 31));
+    }
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < npx; p += kTileApplyThreads) {
+    if (!((touched[p >> 5] >> (p & 31)) & 1u)) continue;
+    const int gx = x0 + (p & (g.tw - 1)), gy = y0 + (p >> twsh);
+    const size_t k = cam * P + (size_t)gy * g.W + gx;
+    L2[k] = Ls[p];
+    const uint32_t s0 = Sidx[2 * p], s1 = Sidx[2 * p + 1];
+    if (s0 | s1) {
+      double2 Sv = S2[k];
+      if (s0) {
+        const uint4 e = part[beg + s0 - 1u];
+        Sv.x = ev_time(e.y, e.z);
+      }
+      if (s1) {
+        const uint4 e = part[beg + s1 - 1u];
+        Sv.y = ev_time(e.y, e.z);
+      }
+      S2[k] = Sv;
+    }
+  }
+}
+
+void launch_tile_apply(hipStream_t s, const EventRec* part, const TileGeom& g, const TileScratch& sc,
+                       double2* L2, double2* S2, double filter_threshold, int* err) {
+  launch_k(k_tile_apply, dim3(2 * g.nt_cam), dim3(kTileApplyThreads), 0, s, (const uint4*)part,
+           (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold, err);
+}
+
 // ============================================================================ time-slice composition
 // One stream's batch cut into N time slices, one per GPU.  A slice's effect on
 // the planes is exchanged as planes holding kSliceNone where the slice wrote nothing; the planes
@@ -1734,53 +2149,87 @@ __device__ __forceinline__ bool arc_ring(const double* ring, int tstride) {
          ((newest_segment_size >= (N - KMAX)) && (newest_segment_size <= (N - KMIN)));
 }
 
-// EventDetector::isCorner (event_detector.cc:308-544) for a whole batch, in two kernels.
+// EventDetector::isCorner (event_detector.cc:308-544) for a whole batch, in three kernels.
 //
 // isCorner is called after the whole batch is in the SAE (feature_tracker.cpp:356-368, then :458),
 // and its two ring tests (:337-541) read nothing but the post-batch S[p] around (x,y): their result
 // is a property of (pixel, polarity), not of the event.  Of the pre-check (:315)
 //     if (et > L[p] + thr || L[!p] > L[p]) return false;
 // only the first term looks at the event.  So
-//   k_arc_map   one thread per PIXEL evaluates  border && TS(y,x) != TS_LK_THRESHOLD &&
-//               !(L[!p] > L[p]) && small ring && large ring  for p = 0, 1 — at most one polarity
-//               survives the L comparison unless L[0] == L[1] — and writes a 2-bit map;
-//   k_arc_ev    one lane per EVENT streams the batch in order: flag = map bit of (pixel, polarity)
-//               && !(et > L[p] + thr); L is only fetched for events whose map bit is set; the
-//               blocked-mask test of Event_FeaturesToTrack (feature_tracker.cpp:25) and the ordered
-//               in-block compaction of the survivors (ballot + popcount) as before.
-// The ring values of x-adjacent threads are adjacent in memory (coalesced 8 B of every 16 B pair,
-// each line reused by the 16/20 ring offsets out of L1/L2); the ring itself sits in a
-// thread-private LDS column because the arc walk indexes it dynamically.
+//   k_arc_mark  one lane per EVENT sets the flag byte of its (pixel, polarity) (plain stores: the
+//               batch's 3-20 events per touched pixel collapse to one flag);
+//   k_arc_map   a block owns kArcRegion consecutive pixels: it collects the region's flagged pairs
+//               that pass  border / TS(y,x) != TS_LK_THRESHOLD / !(L[!p] > L[p])  into an LDS list
+//               (clearing the flags for the next batch) and evaluates the small and the large ring
+//               for those with all lanes busy — the ring of a pair sits in a thread-private LDS
+//               column because the arc walk indexes it dynamically; the result is bit
+//               (pixel, polarity) of a bitmap;
+//   k_arc_ev    one lane per EVENT streams the batch in order: flag = map bit && !(et > L[p] + thr)
+//               (L is only fetched for events whose map bit is set), the blocked-mask test of
+//               Event_FeaturesToTrack (feature_tracker.cpp:25) and the ordered in-block compaction
+//               of the survivors (ballot + popcount) as before.
+constexpr int kArcRegion = 256;  // pixels per k_arc_map block: 512 (pixel, polarity) flag bytes
+
+__global__ __launch_bounds__(256) void k_arc_mark(const uint4* __restrict__ ev, uint32_t n, int W, int H,
+                                                  uint8_t* __restrict__ touched) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t xy = ((const uint32_t*)ev)[4 * (size_t)i], pw = ((const uint32_t*)ev)[4 * (size_t)i + 3];
+    const uint32_t x = xy & 0xffffu, y = xy >> 16;
+    // (plain byte stores: every writer of a byte writes the same value)
+    if (x < (uint32_t)W && y < (uint32_t)H) touched[2u * (y * (uint32_t)W + x) + ((pw & 0xffu) ? 1u : 0u)] = 1;
+  }
+}
+
 __global__ __launch_bounds__(kArcBlock) void k_arc_map(ArcArgs a) {
   __shared__ double ring_s[20 * kArcBlock];  // 40 KiB: [ring idx][thread]
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4 pixel patch per block
-  const int x = blockIdx.x * 64 + tx, y = blockIdx.y * (kArcBlock / 64) + ty;
-  if (x >= a.W || y >= a.H) return;
-  const uint32_t px = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
-  uint32_t bits = 0;
-  bool ok = !(x < a.border || x >= a.W - a.border || y < a.border || y >= a.H - a.border);
-  // (the rings reach 4 pixels out; the reference would index out of its matrices for MIN_DIST < 3)
-  ok = ok && x >= 4 && y >= 4 && x < a.W - 4 && y < a.H - 4;
-  if (ok && a.ts) ok = (double)a.ts[(size_t)(y + kPad) * a.ts_stride + x + kPad] != a.ts_lk_threshold;
-  if (ok) {
-    const double2 Lv = a.L2[px];
-    double* ring = ring_s + threadIdx.x;  // thread-private LDS column
-#pragma unroll 1
-    for (int pol = 0; pol < 2; pol++) {
-      const double t_last = pol ? Lv.y : Lv.x, t_last_inv = pol ? Lv.x : Lv.y;
-      if (t_last_inv > t_last) continue;
-      const double* S = (const double*)a.S2 + pol;
-#pragma unroll
-      for (int k = 0; k < 16; k++)
-        ring[k * kArcBlock] = S[2 * ((size_t)(y + c_small[k][1]) * a.W + (x + c_small[k][0]))];
-      if (!arc_ring<16, 4, 6>(ring, kArcBlock)) continue;
-#pragma unroll
-      for (int k = 0; k < 20; k++)
-        ring[k * kArcBlock] = S[2 * ((size_t)(y + c_large[k][1]) * a.W + (x + c_large[k][0]))];
-      if (arc_ring<20, 5, 8>(ring, kArcBlock)) bits |= 1u << pol;
+  __shared__ uint16_t list_b[2 * kArcRegion];  // surviving pairs (2 * pixel + polarity, region-local)
+  __shared__ uint32_t n_b;
+  const uint32_t P = (uint32_t)a.W * (uint32_t)a.H;
+  const uint32_t pair0 = blockIdx.x * (2u * kArcRegion);  // first (pixel, polarity) pair of the region
+  if (threadIdx.x == 0) n_b = 0;
+  __syncthreads();
+  // thread t looks at pairs pair0 + 2t, 2t+1 (= the two polarities of pixel pair0/2 + t)
+  {
+    const uint32_t px = (pair0 >> 1) + threadIdx.x;
+    uint32_t f = 0;
+    if (px < P) {
+      f = ((const uint16_t*)a.touched)[px];
+      if (f) ((uint16_t*)a.touched)[px] = 0;  // (consumed: the next batch starts from cleared flags)
+    }
+    if (threadIdx.x < (2 * kArcRegion) / 32) {  // the region's result bits start out 0
+      const uint32_t w = (pair0 >> 5) + threadIdx.x;
+      if (w < (2u * P + 31u) / 32u) a.cmap[w] = 0;
+    }
+    if (f) {
+      const int y = (int)(px / (uint32_t)a.W), x = (int)(px - (uint32_t)y * (uint32_t)a.W);
+      bool ok = !(x < a.border || x >= a.W - a.border || y < a.border || y >= a.H - a.border);
+      // (the rings reach 4 pixels out; the reference would index out of its matrices for MIN_DIST < 3)
+      ok = ok && x >= 4 && y >= 4 && x < a.W - 4 && y < a.H - 4;
+      if (ok && a.ts) ok = (double)a.ts[(size_t)(y + kPad) * a.ts_stride + x + kPad] != a.ts_lk_threshold;
+      if (ok) {
+        const double2 Lv = a.L2[px];
+        // polarity p survives unless L[!p] > L[p]
+        if ((f & 0x00ffu) && !(Lv.y > Lv.x)) list_b[atomicAdd(&n_b, 1u)] = (uint16_t)(2u * threadIdx.x);
+        if ((f & 0xff00u) && !(Lv.x > Lv.y)) list_b[atomicAdd(&n_b, 1u)] = (uint16_t)(2u * threadIdx.x + 1u);
+      }
     }
   }
-  a.cmap[px] = (uint8_t)bits;
+  __syncthreads();
+  const uint32_t nb = n_b;
+  double* ring = ring_s + threadIdx.x;  // thread-private LDS column
+  for (uint32_t i = threadIdx.x; i < nb; i += kArcBlock) {
+    const uint32_t pair = pair0 + list_b[i], px = pair >> 1, pol = pair & 1u;
+    const int y = (int)(px / (uint32_t)a.W), x = (int)(px - (uint32_t)y * (uint32_t)a.W);
+    const double* S = (const double*)a.S2 + pol;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      ring[k * kArcBlock] = S[2 * ((size_t)(y + c_small[k][1]) * a.W + (x + c_small[k][0]))];
+    if (!arc_ring<16, 4, 6>(ring, kArcBlock)) continue;
+#pragma unroll
+    for (int k = 0; k < 20; k++)
+      ring[k * kArcBlock] = S[2 * ((size_t)(y + c_large[k][1]) * a.W + (x + c_large[k][0]))];
+    if (arc_ring<20, 5, 8>(ring, kArcBlock)) atomicOr(&a.cmap[pair >> 5], 1u << (pair & 31));
+  }
 }
 
 __global__ __launch_bounds__(kArcBlock) void k_arc_ev(ArcArgs a) {
@@ -1795,7 +2244,8 @@ __global__ __launch_bounds__(kArcBlock) void k_arc_ev(ArcArgs a) {
     if (x < (uint32_t)a.W && y < (uint32_t)a.H) {
       const int pol = (e.w & 0xffu) ? 1 : 0;
       const uint32_t px = y * (uint32_t)a.W + x;
-      bool ok = (a.cmap[px] >> pol) & 1u;
+      const uint32_t pair = 2u * px + (uint32_t)pol;
+      bool ok = (a.cmap[pair >> 5] >> (pair & 31)) & 1u;
       if (ok && a.mask_bits) ok = !((a.mask_bits[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
       if (ok) {
         const double t_last = ((const double*)a.L2)[2 * (size_t)px + pol];
@@ -1826,9 +2276,16 @@ __global__ __launch_bounds__(kArcBlock) void k_arc_ev(ArcArgs a) {
   }
 }
 
+void launch_arc_mark(hipStream_t s, const ArcArgs& a) {
+  if (!a.n) return;
+  uint32_t grid = (a.n + 1023) / 1024;
+  if (grid > 2048) grid = 2048;
+  launch_k(k_arc_mark, dim3(grid), dim3(256), 0, s, (const uint4*)a.ev, a.n, a.W, a.H, a.touched);
+}
+
 void launch_arc_map(hipStream_t s, const ArcArgs& a) {
-  launch_k(k_arc_map, dim3((a.W + 63) / 64, (a.H + kArcBlock / 64 - 1) / (kArcBlock / 64)), dim3(kArcBlock), 0,
-           s, a);
+  const uint32_t P = (uint32_t)a.W * (uint32_t)a.H;
+  launch_k(k_arc_map, dim3((P + kArcRegion - 1) / kArcRegion), dim3(kArcBlock), 0, s, a);
 }
 
 void launch_arc(hipStream_t s, const ArcArgs& a) {

@@ -87,7 +87,7 @@ ABI_SYMBOLS = [
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
     "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
     "esvio_fe_sae_plane_doubles", "esvio_fe_sae_slice_last", "esvio_fe_sae_slice_apply",
-    "esvio_fe_sae_slice_commit", "esvio_fe_device_memory",
+    "esvio_fe_sae_slice_commit", "esvio_fe_device_memory", "esvio_fe_exchange_tracks",
 ]
 
 _lib = None
@@ -152,6 +152,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_stream.restype = vp
     L.esvio_fe_stream.argtypes = [vp]
     L.esvio_fe_device_memory.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    L.esvio_fe_exchange_tracks.argtypes = [vp, vp, i, vp]
     L.esvio_fe_sae_plane_doubles.restype = sz
     L.esvio_fe_sae_plane_doubles.argtypes = [vp]
     L.esvio_fe_sae_slice_last.argtypes = [vp, vp, sz, vp, sz, i, vp, i]

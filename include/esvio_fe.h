@@ -241,6 +241,15 @@ int esvio_fe_track_image(esvio_fe_handle h, double cur_time, const uint8_t* img_
  * This fixed-size block is the unit the multi-GPU all_gather exchanges. */
 int esvio_fe_pack_track_records(esvio_fe_handle h, float* out, int32_t* n_rows);
 
+/* The north-star's merge step from C/C++: one ncclAllGather (RCCL over xGMI) of this handle's
+ * esvio_fe_pack_track_records block over `nccl_comm` (a ncclComm_t of `world` ranks whose rank uses
+ * this handle's device), enqueued on the handle's stream; `gathered` (host) receives
+ * world x 2*max_cnt x 8 floats, rank by rank, on every rank.  19.2 KB per rank at max_cnt 300:
+ * latency-bound, xGMI bandwidth is irrelevant.  RCCL is dlopen'ed on first use
+ * (ESVIO_FE_ENOTIMPL if librccl.so cannot be found).  Replaces: the ROS topic hop of
+ * stereo_event_tracker_node.cpp:340 when several GPUs feed one estimator. */
+int esvio_fe_exchange_tracks(esvio_fe_handle h, void* nccl_comm, int world, float* gathered);
+
 /* Throughput option: with `on`, a published esvio_fe_track_event call returns without waiting for
  * the stereo LK of the corners it has just detected.  Everything else in its results is complete
  * (the node's PointCloud never contains corners of track_cnt 1, node:289); the right-camera entries

@@ -49,13 +49,19 @@ def test_sae_and_time_surface_uniform(oracle, W, H, n):
     ft.close()
 
 
-@pytest.mark.parametrize("ev_min", [None, "0"])
-def test_sae_adversarial_duplicates(oracle, ev_min, monkeypatch):
+SAE_PATHS = {  # the tiled update (default) and the two forms of the radix-sort one
+    "tiled": {}, "sort_walk": {"ESVIO_FE_SAE_SORT": "1"},
+    "sort_per_event": {"ESVIO_FE_SAE_SORT": "1", "ESVIO_FE_SAE_EV_MIN": "0"},
+}
+
+
+@pytest.mark.parametrize("path", list(SAE_PATHS))
+def test_sae_adversarial_duplicates(oracle, path, monkeypatch):
     """many events on few pixels (segments of ~8000), equal timestamps, alternating polarity, border
-    pixels, out-of-sensor events (skipped + counted); with ESVIO_FE_SAE_EV_MIN=0 through the
-    per-event kernels (k_sae_apply_ev) that large batches use"""
-    if ev_min is not None:
-        monkeypatch.setenv("ESVIO_FE_SAE_EV_MIN", ev_min)
+    pixels, out-of-sensor events (skipped + counted); through the tiled update (k_tile_*), the
+    sort + per-pixel walk and the sort + per-event kernels (k_sae_apply_ev)"""
+    for k, v in SAE_PATHS[path].items():
+        monkeypatch.setenv(k, v)
     W, H = 346, 260
     rng = np.random.default_rng(7)
     n = 50000
@@ -81,15 +87,15 @@ def test_sae_adversarial_duplicates(oracle, ev_min, monkeypatch):
     ft.close()
 
 
-@pytest.mark.parametrize("ev_min", [None, "0"])
-def test_sae_segment_lengths_around_the_wave_path(oracle, ev_min, monkeypatch):
+@pytest.mark.parametrize("path", list(SAE_PATHS))
+def test_sae_segment_lengths_around_the_wave_path(oracle, path, monkeypatch):
     """per-pixel segments of every length around the grouped fetch (8 positions per step) and the
     wave width (63..65, 127..129), up to 1600 events on one pixel: long same-polarity bursts inside
     the refractory window, polarity flips, equal stamps and stamps going BACKWARDS inside the batch;
     two batches so the carried-in state matters.  With ESVIO_FE_SAE_EV_MIN=0 through the per-event
     kernels: runs that start before / end after a wave, backward and forward scans of every depth."""
-    if ev_min is not None:
-        monkeypatch.setenv("ESVIO_FE_SAE_EV_MIN", ev_min)
+    for k, v in SAE_PATHS[path].items():
+        monkeypatch.setenv(k, v)
     W, H = 346, 260
     rng = np.random.default_rng(11)
     lengths = [1, 2, 15, 16, 17, 18, 31, 63, 64, 65, 66, 127, 128, 129, 200, 511, 512, 513, 514, 575,
@@ -731,13 +737,15 @@ def test_replay_random_schedules(oracle, seed):
 
 
 @pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE",
-                                 "ESVIO_FE_SAE_EV_MIN"])
+                                 "ESVIO_FE_SAE_SORT", "ESVIO_FE_SAE_SORT+ESVIO_FE_SAE_EV_MIN"])
 def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
     """the measurement switches read at esvio_fe_create (prefetch sequence submitted as a HIP
     graph; no chained temporal LK; no per-pixel dedup of the Arc* candidates; unfused time surface +
-    pyrDown kernels; the per-event SAE apply kernels for batches of >= 1 event instead of >= 2^20) leave every result
-    bit-identical to the oracle"""
-    monkeypatch.setenv(opt, "1")
+    pyrDown kernels; the radix-sort form of the SAE update instead of the tiled one, with the
+    per-pixel walk and with the per-event apply kernels for batches of >= 1 event instead of >= 2^20)
+    leave every result bit-identical to the oracle"""
+    for o in opt.split("+"):
+        monkeypatch.setenv(o, "1")
     W, H = 346, 260
     s = SceneStream(W, H, rate=3e6, seed=77, n_rect=10, size=(25.0, 80.0))
     batches = [s.next_batch()[:2] for _ in range(14)]
