@@ -592,7 +592,7 @@ int first_event_host(esvio_fe_ctx* c, const esvio_fe_event* left, int space, esv
 }
 
 int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                     double2* L2, double2* S2) {
+                     double2* L2, double2* S2, uint8_t* arc_touched) {
   const uint32_t n = nL + nR;
   if (n > c->part_cap) {
     const size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
@@ -621,7 +621,7 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
   sc.C = sc.T + (size_t)kTileMaxGroups * kTileMaxBins;
   {
     ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
-    launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected);
+    launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected, arc_touched);
   }
   {
     ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 16 B in, 16 B out
@@ -629,19 +629,27 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
   }
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
-    launch_tile_apply(cur_stream(c), c->d_part, c->tgeom, sc, L2, S2, c->cfg.feature_filter_threshold,
+    launch_tile_apply(cur_stream(c), c->d_part, n, c->tgeom, sc, L2, S2, c->cfg.feature_filter_threshold,
                       c->z_counts + 3);
   }
   return 0;
 }
 
+// arc_set >= 0: this batch's Arc* pass will run into candidate set arc_set; *arc_marked tells
+// whether the update has set that set's touched flags on its way (else run_arc does it)
 int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR,
-               uint32_t nR, const McParams* mc = nullptr, double2* L2 = nullptr, double2* S2 = nullptr) {
+               uint32_t nR, const McParams* mc = nullptr, double2* L2 = nullptr, double2* S2 = nullptr,
+               int arc_set = -1, bool* arc_marked = nullptr) {
   const uint32_t n = nL + nR;
   if (!n) return 0;
   if (!L2) L2 = c->L2;  // (other planes: the scratch pair of the time-slice entry points)
   if (!S2) S2 = c->S2;
-  if (c->tiled && !mc) return sae_update_tiled(c, evL, nL, evR, nR, L2, S2);
+  if (arc_marked) *arc_marked = false;
+  if (c->tiled && !mc) {
+    uint8_t* mark = arc_set >= 0 && nL ? c->d_touched[arc_set] : nullptr;
+    if (arc_marked) *arc_marked = mark != nullptr;
+    return sae_update_tiled(c, evL, nL, evR, nR, L2, S2, mark);
+  }
   if (int rc = ensure_sort_capacity(c, n)) return rc;
   const int passes = (c->key_bits + 6) / 7;
   const int bits = (c->key_bits + passes - 1) / passes;
@@ -1118,7 +1126,7 @@ void run_select(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int 
 // Arc* flags (+ ordered per-block candidate lists into set `set`) for the left events; `ts` is the
 // RAW left time surface the TS_LK_THRESHOLD test reads (null: no test)
 void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts, bool use_mask,
-             bool want_flags, bool want_cand, int set) {
+             bool want_flags, bool want_cand, int set, bool marked = false) {
   ArcArgs a{};
   a.ev = ev;
   a.n = n;
@@ -1153,7 +1161,7 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
     // the events' x,y,p once more (16 B records) -> touched bits; then per touched pair its 16/20
     // ring values (counted once per pixel: 16 B) + {L0,L1}
     ScopedKernel k(c, K_ARC_MAP, (uint64_t)n * 16 + (uint64_t)c->P * 32);
-    launch_arc_mark(cur_stream(c), a);
+    if (!marked) launch_arc_mark(cur_stream(c), a);  // (else: done by the SAE update's first pass)
     launch_arc_map(cur_stream(c), a);
   }
   {
@@ -1240,7 +1248,9 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
         c->rec.clear();
         set_launch_recorder(&c->rec);
       }
-      rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR);
+      bool arc_marked = false;
+      rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR, nullptr, nullptr, nullptr,
+                      b.pub && b.nL ? b.cand : -1, &arc_marked);
       if (!rc) {
         render_and_build(c, b.time, b.slotL, b.slotR, b.raw);
         if (record_event(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
@@ -1262,7 +1272,7 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
       if (b.pub && b.nL) {
         if ((rc = ensure_cand_capacity(c, b.cand, b.nL))) break;
         const PyrDesc& ts = c->cfg.equalize ? c->raw[b.raw][0].d : c->pyr[b.slotL].d;
-        run_arc(c, b.dL, (uint32_t)b.nL, &ts, false, false, true, b.cand);
+        run_arc(c, b.dL, (uint32_t)b.nL, &ts, false, false, true, b.cand, arc_marked);
         run_compact(c, (uint32_t)b.nL, b.cand);
         if (hipEventRecord(c->ev_lane_arc[b.lane], c->stream2) != hipSuccess) {
           rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
@@ -1486,7 +1496,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
 
   const EventRec *dL = nullptr, *dR = nullptr;
   const bool first = !c->have_img;
-  bool arc_done = false, arc_prefetched = false;
+  bool arc_done = false, arc_prefetched = false, arc_marked_main = false;
   int arc_lane = 0;
   if (!c->inflight.empty()) {
     // this batch was announced with esvio_fe_set_next_batch and its SAE update, images and
@@ -1527,7 +1537,8 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       if (int rc = first_event_host(c, left, space, &first_ev)) return rc;
       const McParams mc = make_mc_params(motion, first_ev);
       if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
-    } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR)) {
+    } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, nullptr, nullptr, nullptr,
+                                   PUB_THIS_FRAME ? c->cand_cur : -1, &arc_marked_main)) {
       return rc;
     }
     // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; slot rotation replaces the
@@ -1586,7 +1597,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     if (PUB_THIS_FRAME && !arc_done) {
       if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
       const PyrDesc ts = raw_ts_desc(c, 0);
-      run_arc(c, dL, (uint32_t)nL, &ts, false, false, true, c->cand_cur);
+      run_arc(c, dL, (uint32_t)nL, &ts, false, false, true, c->cand_cur, arc_marked_main);
       run_compact(c, (uint32_t)nL, c->cand_cur);
       arc_done = true;
       main_reads_planes = true;

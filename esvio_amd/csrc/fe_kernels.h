@@ -167,14 +167,17 @@ struct TileScratch {
   uint32_t* T;         // [ngroups][nbins] bucket counts per group
   uint32_t* C;         // [ngroups][nbins] ... of all earlier groups
 };
-// k_tile_hist + k_tile_scan: P, C, totals; out-of-sensor events added to *n_rejected
+// k_tile_hist + k_tile_scan: P, C, totals; out-of-sensor events added to *n_rejected.  arc_touched
+// (optional): ArcArgs::touched of the Arc* pass this batch will get — the left events' flags are
+// set here, in the pass that reads every record anyway, instead of by launch_arc_mark
 void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected);
+                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected,
+                      uint8_t* arc_touched);
 // stable partition of [left; right] into `part` by bucket
 void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
                          const TileGeom& g, const TileScratch& sc, EventRec* part);
 // createSAE_left/right (event_detector.cc:149-166, :212-228) per bucket, events in stream order
-void launch_tile_apply(hipStream_t s, const EventRec* part, const TileGeom& g, const TileScratch& sc,
+void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const TileGeom& g, const TileScratch& sc,
                        double2* L2, double2* S2, double filter_threshold, int* err);
 
 // ---- time-slice composition (one stream cut into N slices, one per GPU) -------------------

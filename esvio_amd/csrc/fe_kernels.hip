@@ -671,7 +671,8 @@ constexpr int kTileHistThreads = 1024;
 __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __restrict__ evL, uint32_t nL,
                                                    const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
                                                    uint32_t te, uint32_t nblk, uint32_t group,
-                                                   uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm) {
+                                                   uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm,
+                                                   uint8_t* __restrict__ arc_touched) {
   __shared__ uint32_t h[kTileMaxBins], run[kTileMaxBins];
   const int nb = g.nbins;
   for (int i = threadIdx.x; i < nb; i += kTileHistThreads) run[i] = 0;
@@ -686,7 +687,13 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
       const bool right = i >= nL;
       // only x,y are needed here: one dword of the 16 B record
       const uint32_t xy = right ? ((const uint32_t*)evR)[4 * (size_t)(i - nL)] : ((const uint32_t*)evL)[4 * (size_t)i];
-      atomicAdd(&h[tile_bin(g, xy, right)], 1u);
+      const uint32_t bin = tile_bin(g, xy, right);
+      atomicAdd(&h[bin], 1u);
+      // k_arc_mark's job for a batch whose Arc* pass is coming: flag the LEFT events' (pixel, polarity)
+      if (arc_touched && !right && bin != (uint32_t)nb - 1u) {
+        const uint32_t pw = ((const uint32_t*)evL)[4 * (size_t)i + 3];
+        arc_touched[2u * ((xy >> 16) * (uint32_t)g.W + (xy & 0xffffu)) + ((pw & 0xffu) ? 1u : 0u)] = 1;
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
@@ -736,13 +743,14 @@ __global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* 
 }
 
 void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected) {
+                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected,
+                      uint8_t* arc_touched) {
   const uint32_t n = nL + nR;
   if (!n) return;
   const uint32_t te = tile_scatter_events_per_block(n), nblk = tile_scatter_blocks(n);
   const uint32_t group = tile_hist_group(nblk), nseg = (nblk + group - 1) / group;
   launch_k(k_tile_hist, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, te, nblk,
-           group, sc.P, sc.T);
+           group, sc.P, sc.T, arc_touched);
   launch_k(k_tile_scan, dim3((g.nbins + 63) / 64), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,
            g.nbins, sc.C, sc.totals, n_rejected);
 }
@@ -902,15 +910,19 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
 // (loads, ballots, the pass rule) runs unordered.  S is the time of the pixel's last PASSING event,
 // kept as the largest passing position (LDS atomic max, any order) and turned into a time at the end.
 // Only touched pixels are written back.
-constexpr int kTileApplyThreads = 1024;
 constexpr int kTileTurn = 4;
+template <int kTileApplyThreads>
 __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
     const uint4* __restrict__ part, const uint32_t* __restrict__ tile_off,
     const uint32_t* __restrict__ tile_order, TileGeom g, double2* __restrict__ L2, double2* __restrict__ S2,
     double thr, int* __restrict__ err) {
-  __shared__ double2 Ls[kTileMaxPx];          // 32 KiB
-  __shared__ uint32_t Sidx[2 * kTileMaxPx];   // 16 KiB: 1 + position of the last passing event
-  __shared__ uint32_t touched[kTileMaxPx / 32];
+  // LDS (dynamic, sized by the tile): Ls[npx] double2 | Sidx[2 npx] (1 + position of the last
+  // passing event) | touched[npx / 32]  = 24 B + 1 bit per pixel: 12 KiB for 32x16, 48 KiB for 64x32
+  extern __shared__ double2 tile_lds[];
+  const int npx = g.tw * g.th;
+  double2* Ls = tile_lds;
+  uint32_t* Sidx = (uint32_t*)(Ls + npx);
+  uint32_t* touched = Sidx + 2 * npx;
   __shared__ uint32_t s_done;
   const uint32_t tile = tile_order[blockIdx.x];
   const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
@@ -919,7 +931,6 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
   const uint32_t tt = tile - cam * (uint32_t)g.nt_cam;
   const int ty = (int)(tt / (uint32_t)g.tiles_x), tx = (int)(tt - (uint32_t)ty * (uint32_t)g.tiles_x);
   const int x0 = tx * g.tw, y0 = ty * g.th;
-  const int npx = g.tw * g.th;
   const int twsh = g.tw == 64 ? 6 : 5;
   const size_t P = (size_t)g.W * g.H;
   for (int p = threadIdx.x; p < npx; p += kTileApplyThreads) {
@@ -928,7 +939,7 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
     Sidx[2 * p] = 0;
     Sidx[2 * p + 1] = 0;
   }
-  for (int i = threadIdx.x; i < kTileMaxPx / 32; i += kTileApplyThreads) touched[i] = 0;
+  for (int i = threadIdx.x; i < npx / 32; i += kTileApplyThreads) touched[i] = 0;
   if (threadIdx.x == 0) s_done = 0;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -1035,10 +1046,18 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
   }
 }
 
-void launch_tile_apply(hipStream_t s, const EventRec* part, const TileGeom& g, const TileScratch& sc,
+void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const TileGeom& g, const TileScratch& sc,
                        double2* L2, double2* S2, double filter_threshold, int* err) {
-  launch_k(k_tile_apply, dim3(2 * g.nt_cam), dim3(kTileApplyThreads), 0, s, (const uint4*)part,
-           (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold, err);
+  const int npx = g.tw * g.th;
+  const unsigned lds = (unsigned)(npx * 24 + npx / 8 + 16);
+  // a turn is 256 events: with a few turns per bucket 4 waves are plenty and many blocks fit a CU,
+  // with thousands of events per bucket 16 waves keep the ticket moving
+  if (n / (uint32_t)(2 * g.nt_cam) >= 2048u)
+    launch_k(k_tile_apply<1024>, dim3(2 * g.nt_cam), dim3(1024), lds, s, (const uint4*)part,
+             (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold, err);
+  else
+    launch_k(k_tile_apply<256>, dim3(2 * g.nt_cam), dim3(256), lds, s, (const uint4*)part,
+             (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold, err);
 }
 
 // ============================================================================ time-slice composition

@@ -91,8 +91,10 @@ typedef struct esvio_fe_ctx* esvio_fe_handle;
  * (stereo_event_tracker_node.cpp:45), EventDetector::init (event_detector.cc:47-70). */
 int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out);
 int esvio_fe_destroy(esvio_fe_handle h);
-/* stream-discontinuity path (stereo_event_tracker_node.cpp:163-173): clears SAE planes,
- * images, tracks and ids as a freshly created handle (n_id keeps counting). */
+/* Clears SAE planes, images, tracks and ids as a freshly created handle (n_id keeps counting).
+ * NOT what the reference does on a stream discontinuity: stereo_event_tracker_node.cpp:163-173 only
+ * re-arms the node's own flags and publishes `restart`, the tracker keeps everything — a drop-in
+ * caller does not call this there (tools/replay_node.cpp, esvio_amd/node.py). */
 int esvio_fe_reset(esvio_fe_handle h);
 const char* esvio_fe_last_error(esvio_fe_handle h);
 const char* esvio_fe_version(void);

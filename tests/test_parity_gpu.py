@@ -325,7 +325,7 @@ def _compare_tracks(ft, r, tag, id_offset=0):
 
 def test_empty_right_batches_reset_and_capacity_growth(oracle):
     """right batch may be empty (node:150 only guards the left one); buffers grow when a later batch
-    is larger; esvio_fe_reset (node:163-173) behaves like a fresh tracker except that ids keep
+    is larger; esvio_fe_reset behaves like a fresh tracker except that ids keep
     counting (n_id is a static in the reference, feature_tracker.cpp:9)."""
     W, H = 346, 260
     kw = dict(max_cnt=80, min_dist=10, f_ransac=1)

@@ -1,14 +1,29 @@
+# rocprofv3 passes behind profiles/<tag>_*: the default bench (C3) in the replay schedule (with the
+# per-cycle device timeline) and with one batch in flight (clean per-kernel durations), the two PMC
+# passes (separate runs, never combined with tracing), and the C5 sensor shape.   usage: TAG=r02a bash tools/profile_bench.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r01k
+TAG=${TAG:-r02}
+O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
-CMD="python bench.py --steps 40 --warmup 5 --cpu-frames 0 --no-profile-pass"
+CMD="python bench.py --steps 40 --warmup 5 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- $CMD > $O/trace.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- $CMD > $O/fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write -- $CMD > $O/write.log 2>&1
-find $O -name "*.db" | head
-T=$(find $O/trace -name "*.db" | head -1); F=$(find $O/fetch -name "*.db" | head -1); W=$(find $O/write -name "*.db" | head -1)
-python tools/rocprof_summary.py --trace $T --pmc FETCH_SIZE=$F --pmc WRITE_SIZE=$W --out $R/gpurun_out/r01k_bench_c3 --note "round 1k (as 1h + fused k_ts_pyr and k_pad_scharr, k_select disc threshold; 1h = 1g + lazy right tail, RANSAC helper threads, stereo LK stream, chained temporal LK at prefetch depth 3, candidate dedup, kept-point discs stamped by k_select), python bench.py --steps 40 --warmup 5 --cpu-frames 0 --no-profile-pass (C3 640x480 stereo, ego scene), MI355X; FETCH_SIZE/WRITE_SIZE in KB per dispatch, separate --pmc passes"
-grep value $O/trace.log | cut -c1-200
-python bench.py > $R/gpurun_out/r01k_bench_default.json 2> $R/gpurun_out/r01k_bench_default.err; tail -c 1500 $R/gpurun_out/r01k_bench_default.json
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/plain -o plain -- $CMD --no-pipeline > $O/plain.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- $CMD --no-pipeline > $O/fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write -- $CMD --no-pipeline > $O/write.log 2>&1
+T=$(find $O/trace -name "*.db" | head -1); P=$(find $O/plain -name "*.db" | head -1)
+F=$(find $O/fetch -name "*.db" | head -1); W=$(find $O/write -name "*.db" | head -1)
+python tools/rocprof_summary.py --trace $P --pmc FETCH_SIZE=$F --pmc WRITE_SIZE=$W --out $R/gpurun_out/${TAG}_bench_c3 --note "$TAG, one batch in flight (--no-pipeline: no speculative / chained / lazy launches, clean kernel durations): $CMD --no-pipeline (C3 640x480 stereo), MI355X; FETCH_SIZE/WRITE_SIZE in KB per dispatch, separate --pmc passes of the same command" > /dev/null
+python tools/rocprof_summary.py --trace $T --out $R/gpurun_out/${TAG}_bench_c3_replay --note "$TAG, replay schedule (3 batches announced ahead, lazy): $CMD; the k_lk average contains the time speculative / chained launches wait for their inputs" > /dev/null
+python tools/timeline.py $T > $R/gpurun_out/${TAG}_bench_c3_replay_timeline.txt 2>&1
+grep -h '"value"' $O/trace.log $O/plain.log | cut -c1-160
+CMD5="python bench.py --width 1280 --height 720 --rate 1e8 --steps 12 --warmup 3 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass"
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- $CMD5 > $O/c5.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE -d $O/c5f -o c5f -- $CMD5 > $O/c5f.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE -d $O/c5w -o c5w -- $CMD5 > $O/c5w.log 2>&1
+T5=$(find $O/c5 -name "*.db" | head -1); F5=$(find $O/c5f -name "*.db" | head -1); W5=$(find $O/c5w -name "*.db" | head -1)
+python tools/rocprof_summary.py --trace $T5 --pmc FETCH_SIZE=$F5 --pmc WRITE_SIZE=$W5 --out $R/gpurun_out/${TAG}_c5shape --note "$TAG, C5's sensor shape on one GPU: $CMD5 (1280x720 stereo, 100 Mev/s per camera, 6.7 M events per step), MI355X" > /dev/null
+grep -h '"value"' $O/c5.log | cut -c1-160
+head -30 $R/gpurun_out/${TAG}_bench_c3_replay_timeline.txt
+rm -rf $O/trace $O/plain $O/fetch $O/write $O/c5 $O/c5f $O/c5w

@@ -24,6 +24,30 @@ def main():
         n = n.split("(")[0].split("<")[0]
         return n.split("::")[-1].replace("void ", "").strip()
     rows = [(short(n), s, e, qid) for n, s, e, qid in rows]
+    # how much of the device time is overlapped: sum of the kernel durations against the time at
+    # least one kernel is running (union of the intervals), whole trace and per HIP stream / queue
+    def union(iv):
+        iv = sorted(iv)
+        tot, cs, ce = 0, None, None
+        for s0, e0 in iv:
+            if cs is None or s0 > ce:
+                if cs is not None:
+                    tot += ce - cs
+                cs, ce = s0, e0
+            else:
+                ce = max(ce, e0)
+        return tot + (ce - cs if cs is not None else 0)
+    span = (max(r[2] for r in rows) - min(r[1] for r in rows)) / 1e6
+    ssum = sum(r[2] - r[1] for r in rows) / 1e6
+    ubusy = union([(r[1], r[2]) for r in rows]) / 1e6
+    print("whole trace: span %.3f ms, sum of kernel durations %.3f ms, union busy %.3f ms "
+          "(concurrency %.2fx, device idle %.1f%% of the span)" % (span, ssum, ubusy, ssum / max(ubusy, 1e-9),
+                                                                   100.0 * (1 - ubusy / span)))
+    by_q = defaultdict(list)
+    for r in rows:
+        by_q[r[3]].append((r[1], r[2]))
+    for qid, iv in sorted(by_q.items(), key=lambda kv: -sum(e0 - s0 for s0, e0 in kv[1])):
+        print("  stream/queue %-4s %6d dispatches, busy %.3f ms" % (qid, len(iv), union(iv) / 1e6))
     sel = [i for i, r in enumerate(rows) if "k_select" in r[0]]
     if not sel:
         print(sorted(set(r[0] for r in rows)))
