@@ -685,15 +685,13 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
     const uint32_t lo = b * te, hi = min(lo + te, n);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kTileHistThreads) {
       const bool right = i >= nL;
-      // only x,y are needed here: one dword of the 16 B record
-      const uint32_t xy = right ? ((const uint32_t*)evR)[4 * (size_t)(i - nL)] : ((const uint32_t*)evL)[4 * (size_t)i];
+      const uint4 e = right ? evR[i - nL] : evL[i];  // (whole records: one fully coalesced 1 KiB request per wave)
+      const uint32_t xy = e.x;
       const uint32_t bin = tile_bin(g, xy, right);
       atomicAdd(&h[bin], 1u);
       // k_arc_mark's job for a batch whose Arc* pass is coming: flag the LEFT events' (pixel, polarity)
-      if (arc_touched && !right && bin != (uint32_t)nb - 1u) {
-        const uint32_t pw = ((const uint32_t*)evL)[4 * (size_t)i + 3];
-        arc_touched[2u * ((xy >> 16) * (uint32_t)g.W + (xy & 0xffffu)) + ((pw & 0xffu) ? 1u : 0u)] = 1;
-      }
+      if (arc_touched && !right && bin != (uint32_t)nb - 1u)
+        arc_touched[2u * ((xy >> 16) * (uint32_t)g.W + (xy & 0xffffu)) + ((e.w & 0xffu) ? 1u : 0u)] = 1;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
@@ -911,7 +909,7 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
 // kept as the largest passing position (LDS atomic max, any order) and turned into a time at the end.
 // Only touched pixels are written back.
 constexpr int kTileTurn = 4;
-template <int kTileApplyThreads>
+template <int kTileApplyThreads, int kPixBits>
 __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
     const uint4* __restrict__ part, const uint32_t* __restrict__ tile_off,
     const uint32_t* __restrict__ tile_order, TileGeom g, double2* __restrict__ L2, double2* __restrict__ S2,
@@ -975,9 +973,11 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
       const bool pol = (e.w & 0xffu) != 0;
       const double t = ev_time(e.y, e.z);
       unsigned long long m = __ballot(valid);
-      for (int b = 0; b < g.pix_bits; b++) {
-        const unsigned long long bal = __ballot((pix >> b) & 1u);
-        m &= ((pix >> b) & 1u) ? bal : ~bal;
+#pragma unroll
+      for (int b = 0; b < kPixBits; b++) {
+        const int sx = ((int)(pix << (31 - b))) >> 31;  // -1 where the bit is set, else 0
+        const unsigned long long bal = __ballot(sx != 0);
+        m &= ~(bal ^ (unsigned long long)(long long)sx);  // lanes with the bit: bal, the others: ~bal
       }
       const unsigned long long m1 = __ballot(valid && pol);
       const unsigned long long same = m & (pol ? m1 : ~m1), opp = m & (pol ? ~m1 : m1);
@@ -1052,12 +1052,18 @@ void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const Ti
   const unsigned lds = (unsigned)(npx * 24 + npx / 8 + 16);
   // a turn is 256 events: with a few turns per bucket 4 waves are plenty and many blocks fit a CU,
   // with thousands of events per bucket 16 waves keep the ticket moving
-  if (n / (uint32_t)(2 * g.nt_cam) >= 2048u)
-    launch_k(k_tile_apply<1024>, dim3(2 * g.nt_cam), dim3(1024), lds, s, (const uint4*)part,
-             (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold, err);
-  else
-    launch_k(k_tile_apply<256>, dim3(2 * g.nt_cam), dim3(256), lds, s, (const uint4*)part,
-             (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold, err);
+  const bool big = n / (uint32_t)(2 * g.nt_cam) >= 2048u;
+#define ESVIO_TILE_APPLY(T, B)                                                                            \
+  launch_k(k_tile_apply<T, B>, dim3(2 * g.nt_cam), dim3(T), lds, s, (const uint4*)part,                  \
+           (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold, err)
+  if (g.pix_bits == 9) {
+    if (big) ESVIO_TILE_APPLY(1024, 9); else ESVIO_TILE_APPLY(256, 9);
+  } else if (g.pix_bits == 10) {
+    if (big) ESVIO_TILE_APPLY(1024, 10); else ESVIO_TILE_APPLY(256, 10);
+  } else {
+    if (big) ESVIO_TILE_APPLY(1024, 11); else ESVIO_TILE_APPLY(256, 11);
+  }
+#undef ESVIO_TILE_APPLY
 }
 
 // ============================================================================ time-slice composition
