@@ -677,27 +677,45 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
   const int nb = g.nbins;
   for (int i = threadIdx.x; i < nb; i += kTileHistThreads) run[i] = 0;
   const uint32_t n = nL + nR;
-  for (uint32_t k = 0; k < group; k++) {
-    const uint32_t b = blockIdx.x * group + k;
-    if (b >= nblk) break;
-    for (int i = threadIdx.x; i < nb; i += kTileHistThreads) h[i] = 0;
-    __syncthreads();
-    const uint32_t lo = b * te, hi = min(lo + te, n);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += kTileHistThreads) {
-      const bool right = i >= nL;
-      const uint4 e = right ? evR[i - nL] : evL[i];  // (whole records: one fully coalesced 1 KiB request per wave)
-      const uint32_t xy = e.x;
-      const uint32_t bin = tile_bin(g, xy, right);
-      atomicAdd(&h[bin], 1u);
-      // k_arc_mark's job for a batch whose Arc* pass is coming: flag the LEFT events' (pixel, polarity)
-      if (arc_touched && !right && bin != (uint32_t)nb - 1u)
-        arc_touched[2u * ((xy >> 16) * (uint32_t)g.W + (xy & 0xffffu)) + ((e.w & 0xffu) ? 1u : 0u)] = 1;
+  // (te <= 4 * kTileHistThreads: a thread has at most 4 events per scatter block; the records of up
+  // to 4 scatter blocks are requested together so that their latencies overlap)
+  constexpr int UB = 4, UE = 4;
+  for (uint32_t k0 = 0; k0 < group; k0 += UB) {
+    uint32_t bins[UB][UE];
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      const uint32_t b = blockIdx.x * group + k0 + u;
+      const uint32_t lo = b * te, hi = (k0 + u < group && b < nblk) ? min(lo + te, n) : lo;
+#pragma unroll
+      for (int j = 0; j < UE; j++) {
+        const uint32_t i = lo + threadIdx.x + j * kTileHistThreads;
+        bins[u][j] = 0xffffffffu;
+        if (j * kTileHistThreads < (int)te && i < hi) {
+          const bool right = i >= nL;
+          const uint4 e = right ? evR[i - nL] : evL[i];  // (whole records: one coalesced 1 KiB request per wave)
+          const uint32_t bin = tile_bin(g, e.x, right);
+          bins[u][j] = bin;
+          // k_arc_mark's job for a batch whose Arc* pass is coming: flag the LEFT events' (pixel, polarity)
+          if (arc_touched && !right && bin != (uint32_t)nb - 1u)
+            arc_touched[2u * ((e.x >> 16) * (uint32_t)g.W + (e.x & 0xffffu)) + ((e.w & 0xffu) ? 1u : 0u)] = 1;
+        }
+      }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
-      const uint32_t r = run[i];
-      Pm[(size_t)b * nb + i] = r;
-      run[i] = r + h[i];
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      const uint32_t b = blockIdx.x * group + k0 + u;
+      if (k0 + u >= group || b >= nblk) break;
+      for (int i = threadIdx.x; i < nb; i += kTileHistThreads) h[i] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < UE; j++)
+        if (bins[u][j] != 0xffffffffu) atomicAdd(&h[bins[u][j]], 1u);
+      __syncthreads();
+      for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
+        const uint32_t r = run[i];
+        Pm[(size_t)b * nb + i] = r;
+        run[i] = r + h[i];
+      }
     }
   }
   __syncthreads();
