@@ -621,7 +621,7 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
   sc.C = sc.T + (size_t)kTileMaxGroups * kTileMaxBins;
   {
     ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
-    launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected, arc_touched);
+    launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected);
   }
   {
     ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 16 B in, 16 B out
@@ -630,7 +630,7 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
     launch_tile_apply(cur_stream(c), c->d_part, n, c->tgeom, sc, L2, S2, c->cfg.feature_filter_threshold,
-                      c->z_counts + 3);
+                      arc_touched, c->z_counts + 3);
   }
   return 0;
 }
@@ -1145,7 +1145,10 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
   a.cand_xy = want_cand ? c->cand[set].xy : nullptr;
   a.cand_idx = want_cand ? c->cand[set].idx : nullptr;
   a.cand_cnt = want_cand ? c->cand[set].cnt : nullptr;
-  const bool dedup = want_cand && c->dedup_enabled && c->d_first[set] && n < (1u << 24);
+  // Worth it for batches of the usual size (k_select, on the frame's device chain, sees half the
+  // candidates: 54 against 57 us at 0.17 M left events, the atomics and k_dedup run on the prefetch
+  // stream); at 3.3 M left events the 0.8 M atomics cost k_arc_ev 43 us and save k_select 8.
+  const bool dedup = want_cand && c->dedup_enabled && c->d_first[set] && n < (1u << 20);
   if (dedup) {
     // keys count down from launch to launch: 0xfe.. for the first, 0x01.. for the 254th, then the
     // map is cleared (to all ones) and the count starts again

@@ -167,18 +167,18 @@ struct TileScratch {
   uint32_t* T;         // [ngroups][nbins] bucket counts per group
   uint32_t* C;         // [ngroups][nbins] ... of all earlier groups
 };
-// k_tile_hist + k_tile_scan: P, C, totals; out-of-sensor events added to *n_rejected.  arc_touched
-// (optional): ArcArgs::touched of the Arc* pass this batch will get — the left events' flags are
-// set here, in the pass that reads every record anyway, instead of by launch_arc_mark
+// k_tile_hist + k_tile_scan: P, C, totals; out-of-sensor events added to *n_rejected
 void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected,
-                      uint8_t* arc_touched);
+                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected);
 // stable partition of [left; right] into `part` by bucket
 void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
                          const TileGeom& g, const TileScratch& sc, EventRec* part);
-// createSAE_left/right (event_detector.cc:149-166, :212-228) per bucket, events in stream order
+// createSAE_left/right (event_detector.cc:149-166, :212-228) per bucket, events in stream order.
+// arc_touched (optional): ArcArgs::touched of the Arc* pass this batch will get — the left camera's
+// touched (pixel, polarity) flags are written here, from the tiles' own bookkeeping, instead of by
+// launch_arc_mark
 void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const TileGeom& g, const TileScratch& sc,
-                       double2* L2, double2* S2, double filter_threshold, int* err);
+                       double2* L2, double2* S2, double filter_threshold, uint8_t* arc_touched, int* err);
 
 // ---- time-slice composition (one stream cut into N slices, one per GPU) -------------------
 constexpr double kSliceNone = -1.0;  // "this slice wrote nothing here" (event times are >= 0)

@@ -671,8 +671,7 @@ constexpr int kTileHistThreads = 1024;
 __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __restrict__ evL, uint32_t nL,
                                                    const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
                                                    uint32_t te, uint32_t nblk, uint32_t group,
-                                                   uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm,
-                                                   uint8_t* __restrict__ arc_touched) {
+                                                   uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm) {
   __shared__ uint32_t h[kTileMaxBins], run[kTileMaxBins];
   const int nb = g.nbins;
   for (int i = threadIdx.x; i < nb; i += kTileHistThreads) run[i] = 0;
@@ -695,9 +694,6 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
           const uint4 e = right ? evR[i - nL] : evL[i];  // (whole records: one coalesced 1 KiB request per wave)
           const uint32_t bin = tile_bin(g, e.x, right);
           bins[u][j] = bin;
-          // k_arc_mark's job for a batch whose Arc* pass is coming: flag the LEFT events' (pixel, polarity)
-          if (arc_touched && !right && bin != (uint32_t)nb - 1u)
-            arc_touched[2u * ((e.x >> 16) * (uint32_t)g.W + (e.x & 0xffffu)) + ((e.w & 0xffu) ? 1u : 0u)] = 1;
         }
       }
     }
@@ -759,14 +755,13 @@ __global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* 
 }
 
 void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected,
-                      uint8_t* arc_touched) {
+                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected) {
   const uint32_t n = nL + nR;
   if (!n) return;
   const uint32_t te = tile_scatter_events_per_block(n), nblk = tile_scatter_blocks(n);
   const uint32_t group = tile_hist_group(nblk), nseg = (nblk + group - 1) / group;
   launch_k(k_tile_hist, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, te, nblk,
-           group, sc.P, sc.T, arc_touched);
+           group, sc.P, sc.T);
   launch_k(k_tile_scan, dim3((g.nbins + 63) / 64), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,
            g.nbins, sc.C, sc.totals, n_rejected);
 }
@@ -931,9 +926,10 @@ template <int kTileApplyThreads, int kPixBits>
 __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
     const uint4* __restrict__ part, const uint32_t* __restrict__ tile_off,
     const uint32_t* __restrict__ tile_order, TileGeom g, double2* __restrict__ L2, double2* __restrict__ S2,
-    double thr, int* __restrict__ err) {
+    double thr, uint8_t* __restrict__ arc_touched, int* __restrict__ err) {
   // LDS (dynamic, sized by the tile): Ls[npx] double2 | Sidx[2 npx] (1 + position of the last
-  // passing event) | touched[npx / 32]  = 24 B + 1 bit per pixel: 12 KiB for 32x16, 48 KiB for 64x32
+  // passing event) | touched[npx / 16] (one bit per (pixel, polarity))  = 24 B + 2 bits per pixel:
+  // 12 KiB for 32x16, 48 KiB for 64x32
   extern __shared__ double2 tile_lds[];
   const int npx = g.tw * g.th;
   double2* Ls = tile_lds;
@@ -955,7 +951,7 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
     Sidx[2 * p] = 0;
     Sidx[2 * p + 1] = 0;
   }
-  for (int i = threadIdx.x; i < npx / 32; i += kTileApplyThreads) touched[i] = 0;
+  for (int i = threadIdx.x; i < npx / 16; i += kTileApplyThreads) touched[i] = 0;
   if (threadIdx.x == 0) s_done = 0;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -1039,15 +1035,21 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
       const bool pass = (flg[k] & 1u) && ((tk[k] > __dadd_rn(prev_same, thr)) || (prev_opp > prev_same));
       const uint32_t pos = (turn * kTileTurn + k) * 64u + (uint32_t)lane + 1u;
       if (pass) atomicMax(&Sidx[2 * pixk[k] + (pol ? 1 : 0)], pos);
-      if (flg[k] & 16u) atomicOr(&touched[pixk[k] >> 5], 1u << (pixk[k] & 31));
+      if (flg[k] & 16u) atomicOr(&touched[pixk[k] >> 4], 1u << (2u * (pixk[k] & 15u) + (pol ? 1u : 0u)));
     }
   }
   __syncthreads();
   for (int p = threadIdx.x; p < npx; p += kTileApplyThreads) {
-    if (!((touched[p >> 5] >> (p & 31)) & 1u)) continue;
+    const uint32_t tb = (touched[p >> 4] >> (2 * (p & 15))) & 3u;
+    if (!tb) continue;
     const int gx = x0 + (p & (g.tw - 1)), gy = y0 + (p >> twsh);
     const size_t k = cam * P + (size_t)gy * g.W + gx;
     L2[k] = Ls[p];
+    // k_arc_mark's job for a batch whose Arc* pass is coming: the LEFT camera's touched
+    // (pixel, polarity) flags, here from the tile's own bookkeeping instead of one scattered byte
+    // store per event
+    if (arc_touched && cam == 0)
+      ((uint16_t*)arc_touched)[k] = (uint16_t)((tb & 1u) | ((tb & 2u) << 7));
     const uint32_t s0 = Sidx[2 * p], s1 = Sidx[2 * p + 1];
     if (s0 | s1) {
       double2 Sv = S2[k];
@@ -1065,15 +1067,16 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
 }
 
 void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const TileGeom& g, const TileScratch& sc,
-                       double2* L2, double2* S2, double filter_threshold, int* err) {
+                       double2* L2, double2* S2, double filter_threshold, uint8_t* arc_touched, int* err) {
   const int npx = g.tw * g.th;
-  const unsigned lds = (unsigned)(npx * 24 + npx / 8 + 16);
+  const unsigned lds = (unsigned)(npx * 24 + npx / 4 + 16);
   // a turn is 256 events: with a few turns per bucket 4 waves are plenty and many blocks fit a CU,
   // with thousands of events per bucket 16 waves keep the ticket moving
   const bool big = n / (uint32_t)(2 * g.nt_cam) >= 2048u;
 #define ESVIO_TILE_APPLY(T, B)                                                                            \
   launch_k(k_tile_apply<T, B>, dim3(2 * g.nt_cam), dim3(T), lds, s, (const uint4*)part,                  \
-           (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold, err)
+           (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold,     \
+           arc_touched, err)
   if (g.pix_bits == 9) {
     if (big) ESVIO_TILE_APPLY(1024, 9); else ESVIO_TILE_APPLY(256, 9);
   } else if (g.pix_bits == 10) {

@@ -381,6 +381,33 @@ def test_sae_time_surface_1280x720(oracle):
     ft.close()
 
 
+@pytest.mark.parametrize("W,H,why", [(1280, 960, "64x32 tiles, 11 pixel bits (32x32 would need 2401 buckets)"),
+                                     (97, 61, "sensor smaller than four tiles, ragged tile edges")])
+def test_sae_other_sensor_sizes(oracle, W, H, why):
+    """the tiled SAE update picks its tile by sensor size (32x16 up to ~0.5 MP, 32x32 up to ~1 MP,
+    64x32 beyond; a handle cannot be larger than ~1.3 MP because k_select keeps one bit per pixel in
+    LDS): planes, a time surface and the corner flags at sizes that take the other branches"""
+    rng = np.random.default_rng(W)
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    n = 400_000 if W > 1000 else 30_000
+    t0 = 2_000_000_000
+    for b in range(2):
+        L = uniform_batch(W, H, n, t0 + b * 33333, 33333, rng)
+        R = uniform_batch(W, H, n // 2, t0 + b * 33333, 33333, rng)
+        # a busy patch straddling tile borders (long per-pixel histories), some out-of-sensor events
+        L["x"][::4] = (W // 2 - 20) + (L["x"][::4] % 40)
+        L["y"][::4] = (H // 2 - 20) + (L["y"][::4] % 40)
+        L["x"][5::1000] = W + 3
+        assert ft.detector.createSAE_stereo(L, R) == det.create_sae(0, L) + det.create_sae(1, R)
+        for cam in (0, 1):
+            _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+        t = event_times(L)[-1]
+        assert np.array_equal(ft.detector.SAEtoTimeSurface_left(t), det.time_surface(0, t))
+        assert np.array_equal(ft.detector.isCorner(L[:100_000]), det.corner_flags(L[:100_000]))
+    ft.close()
+
+
 def test_selection_large_radius(oracle):
     """min_dist 40 (> 31: two disc rows per lane in k_select) and a tiny max_cnt"""
     W, H = 640, 480
