@@ -1,0 +1,12 @@
+# round 2, GPU call 13: benches + rocprofv3 passes (profiles r02b)
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r02m
+timeout 900 python bench.py > gpurun_out/r02m/bench_default.json 2> gpurun_out/r02m/bench_default.err
+timeout 600 python bench.py --width 1280 --height 720 --rate 1e8 --steps 12 --warmup 3 --repeats 3 --cpu-frames 0 --no-host-pass > gpurun_out/r02m/bench_c5shape.json 2> gpurun_out/r02m/bench_c5shape.err
+python - <<'P'
+import json
+for f in ("bench_default","bench_c5shape"):
+    d=json.load(open("gpurun_out/r02m/%s.json"%f))
+    print(f, d["value"], d["ms_per_step"], d.get("repeats"))
+P
+TAG=r02b bash tools/profile_bench.sh 2>&1 | tail -12
