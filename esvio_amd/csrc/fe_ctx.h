@@ -1,0 +1,419 @@
+// fe_ctx.h — the handle (esvio_fe_ctx) and the small helpers every part of the library uses.
+// Internal: the public boundary is include/esvio_fe.h.
+//
+//   fe_stages.cpp  device memory, the per-stage launches (SAE update, rendering, pyramids, LK, Arc*,
+//                  selection) and the <= max_cnt-point host bookkeeping of the reference
+//   fe_track.cpp   FeatureTracker::trackEvent: the per-frame sequence and its replay-mode scheduler
+//                  (prefetch stream, speculative / chained temporal LK, lazy right-camera tails)
+//   fe_image.cpp   FeatureTracker::trackImage and goodFeaturesToTrack
+//   fe_api.cpp     the C ABI entry points
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <map>
+#include <string>
+#include <utility>
+#include <deque>
+#include <vector>
+
+#include "../../include/esvio_fe.h"
+#include "fe_host.h"
+#include "fe_kernels.h"
+#include "fe_mc.h"
+
+using namespace esvio;
+
+namespace esvio {
+namespace fe {
+
+struct P2f {
+  float x, y;
+};
+
+// std::map<int, cv::Point2f> as ptsVelocity uses it (insert-if-absent, find, empty, clear), kept as a
+// sorted flat vector: same semantics, no node allocations per frame
+struct IdMap {
+  std::vector<std::pair<int, P2f>> v;
+  bool empty() const { return v.empty(); }
+  void clear() { v.clear(); }
+  void swap(IdMap& o) { v.swap(o.v); }
+  void build(const std::vector<int>& ids, const std::vector<P2f>& pts) {
+    v.clear();
+    v.reserve(ids.size());
+    for (size_t i = 0; i < ids.size(); i++) v.emplace_back(ids[i], pts[i]);
+    std::stable_sort(v.begin(), v.end(),
+                     [](const std::pair<int, P2f>& a, const std::pair<int, P2f>& b) { return a.first < b.first; });
+    // map::insert keeps the first element of equal keys
+    v.erase(std::unique(v.begin(), v.end(),
+                        [](const std::pair<int, P2f>& a, const std::pair<int, P2f>& b) { return a.first == b.first; }),
+            v.end());
+  }
+  const P2f* find(int id) const {
+    auto it = std::lower_bound(v.begin(), v.end(), id,
+                               [](const std::pair<int, P2f>& a, int k) { return a.first < k; });
+    return (it != v.end() && it->first == id) ? &it->second : nullptr;
+  }
+};
+
+const char* const kKernelNames[K_COUNT] = {
+    "k_sae_keys", "k_radix_pass", "k_sae_apply",
+    "k_time_surface", "k_clahe", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select",
+    "k_arc_map"};
+
+struct KStat {
+  double ms = 0;
+  uint64_t launches = 0;
+  uint64_t bytes = 0;
+};
+
+struct ProfRec {
+  int id;
+  hipEvent_t a, b;
+  uint64_t bytes;
+};
+
+// buildOpticalFlowPyramid's level count [OpenCV video/lkpyramid.cpp]
+inline int pyr_levels(int w, int h, int win, int max_level) {
+  int sw = w, sh = h;
+  for (int level = 0; level <= max_level; ++level) {
+    sw = (sw + 1) / 2;
+    sh = (sh + 1) / 2;
+    if (sw <= win || sh <= win) return level;
+  }
+  return max_level;
+}
+
+// esvio_fe_set_next_batch: a batch announced ahead of its trackEvent call ...
+struct Batch {
+  const esvio_fe_event *left = nullptr, *right = nullptr;
+  size_t nL = 0, nR = 0;
+  int space = 0;
+  double time = 0;
+  int pub = 0;  // caller's PUB_THIS_FRAME hint
+};
+// ... and, once its SAE update / images / pyramids (/ Arc*) are enqueued on the prefetch stream,
+// the resources they were given
+struct Inflight : Batch {
+  int lane = 0;  // staging buffer + event pair
+  int slotL = 0, slotR = 0, raw = 0, cand = 0;
+  const EventRec *dL = nullptr, *dR = nullptr;
+  bool arc_done = false;
+};
+constexpr int kPrefetchDepth = 3;
+constexpr int kLeftSlots = 2 + kPrefetchDepth;   // prev, cur, prefetched...
+constexpr int kRightSlots = 1 + kPrefetchDepth;  // cur, prefetched...
+
+struct PyrStore {
+  PyrDesc d{};
+  void* mem = nullptr;
+  size_t bytes = 0;
+  int w = 0, h = 0, max_level = -1;
+};
+
+}  // namespace fe
+}  // namespace esvio
+using namespace esvio::fe;
+
+struct esvio_fe_ctx {
+  esvio_fe_config cfg{};
+  int dev = 0;
+  hipStream_t stream = nullptr;   // main stream
+  hipStream_t stream2 = nullptr;  // prefetch stream (next batch's SAE update / images)
+  hipStream_t stream3 = nullptr;  // speculative temporal LK of the next frame
+  // stereo LK of the temporal survivors: nothing on the frame's chain reads its results before the
+  // right-camera tail, and on the main stream it would hold up the corner selection behind it
+  hipStream_t stream4 = nullptr;
+  hipEvent_t ev_planes_free = nullptr;
+  hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr, ev_sel_host = nullptr;
+  std::string err;
+  int W = 0, H = 0;
+  uint32_t P = 0;
+  int key_bits = 0;
+  uint32_t invalid_key = 0;
+  std::vector<int> hw;  // disc half-widths for min_dist
+
+  // ---- device state
+  double2* L2 = nullptr;  // [2P] {L[0],L[1]} per (cam,pixel)
+  double2* S2 = nullptr;  // [2P] {S[0],S[1]}
+  EventRec* d_ev = nullptr;
+  size_t ev_cap = 0;
+  uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr;
+  size_t sort_cap = 0, hist_cap = 0;
+  size_t sae_ev_min = (size_t)1 << 20;  // batches of at least this many events: k_sae_apply_ev
+  // tiled SAE update (default; ESVIO_FE_SAE_SORT=1 or a sensor too large for one digit: the radix
+  // sort form above)
+  bool tiled = false;
+  TileGeom tgeom{};
+  EventRec* d_part = nullptr;  // the batch's events partitioned by bucket
+  size_t part_cap = 0;
+  uint32_t* d_tile = nullptr;  // TileScratch
+  size_t tile_cap = 0;
+  uint8_t* sae_marks = nullptr;         // [sort_cap] its per-event "stores L / stores S" marks
+  unsigned long long* d_rejected = nullptr;
+  // left: slots 0..kLeftSlots-1 rotate (prev, cur, up to kPrefetchDepth being prefetched);
+  // right: the kRightSlots after them (cur + prefetched)
+  PyrStore pyr[kLeftSlots + kRightSlots];
+  int slot_prevL = 0, slot_curL = 0, slot_curR = kLeftSlots;
+  bool have_img = false;
+  bool ext_right_pending = false;  // esvio_fe_import_image(cam=1) done for the next frame
+  // time-sliced stream (esvio_fe_sae_slice_*): scratch planes a slice is applied to, and the one-shot
+  // "the planes already hold the next frame's batch" set by esvio_fe_sae_slice_commit
+  double2 *L2s = nullptr, *S2s = nullptr;
+  double* slice_stage = nullptr;  // device staging for host-side slice planes
+  size_t slice_stage_doubles = 0;
+  bool ext_sae_pending = false;
+  // esvio_fe_exchange_tracks: send / receive buffers of the all-gather and the pinned pack area
+  float *x_send = nullptr, *x_recv = nullptr, *x_pin = nullptr;
+  size_t x_recv_cap = 0;
+  // ---- next-batch prefetch (esvio_fe_set_next_batch)
+  std::deque<Batch> announced;     // announced, nothing enqueued yet (<= kPrefetchDepth)
+  std::deque<Inflight> inflight;   // SAE update / images / pyramids enqueued on the prefetch stream
+  bool cur_prefetched = false;     // the frame being processed came from the prefetch stream
+  EventRec* d_evp[kPrefetchDepth] = {};  // host-event staging, one per prefetch lane
+  size_t evp_cap[kPrefetchDepth] = {};
+  hipEvent_t ev_lane_done[kPrefetchDepth] = {}, ev_lane_arc[kPrefetchDepth] = {};
+  PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images
+  PyrStore med_tmp[2];  // median_blur_kernel_size > 0: the surfaces before cv::medianBlur
+  // equalize: raw time surfaces (single padded level each, left/right) + CLAHE scratch
+  PyrStore raw[kRightSlots][2];  // [buffer][cam], rotating like the right pyramids
+  int raw_cur = 0;
+  uint8_t* d_lut = nullptr;
+  int* d_minmax = nullptr;
+  // device-side point / status buffers of the standalone entry points (LK, featuresToTrack) and the
+  // selection counters; one allocation with the layout of ResLayout
+  uint8_t* d_res = nullptr;
+  size_t res_bytes = 0;
+  float2 *d_ptsA = nullptr, *d_ptsB = nullptr, *d_ptsC = nullptr, *d_ptsD = nullptr;
+  uint8_t *d_stA = nullptr, *d_stB = nullptr;
+  int* d_counts = nullptr;  // [0]=n_out (select) [1]=n_total (kept + new: the LK kernels' n_ptr)
+  // The per-frame path works on the pinned host block itself (device-visible): the LK kernels read
+  // their points from it and write results into it, k_select mirrors its counters into it — no
+  // H2D / D2H copy calls on the frame's critical path (each costs more host time than the few
+  // hundred bytes take over PCIe).  z_* = device-side addresses of the h_pin / h_spec regions.
+  uint8_t *z_res = nullptr, *z_spec = nullptr;
+  // (set 1 — temporal LK, then stereo LK of the survivors — exists twice, see pin_of(); its device
+  // addresses come from zdev())
+  float2 *z_new = nullptr, *z_ptsB2 = nullptr, *z_ptsC2 = nullptr;
+  uint8_t *z_stA2 = nullptr, *z_stB2 = nullptr;
+  int* z_counts = nullptr;
+  int res_set = 0;  // which copy of set 1 the current frame works in
+  int lks_last = -1;  // copy the latest stereo LK launch (stream4) writes to, -1: none so far
+  // ---- speculative temporal LK of the next frame (replay mode): once this frame's kept points
+  // and new corners are final, next frame's calcOpticalFlowPyrLK(cur -> next) pair is launched on
+  // stream3 against the prefetched pyramids, so it overlaps this frame's stereo LK and host tail
+  uint8_t* h_spec = nullptr;  // pinned, device-visible: [ptsB | ptsC | stA | stB] of that launch
+  size_t spec_bytes = 0;
+  bool spec_valid = false;
+  int spec_n = 0;             // number of points of that launch (= the next frame's prev_pts.size())
+  // ---- chained temporal LK of the frame after next: when the next frame publishes nothing, the
+  // frame after it tracks exactly the next frame's forward results, point by point, so its launch
+  // (stream4) is made together with the speculative one and each of its waves starts the moment the
+  // producer's wave of the same index publishes its forward result (LkArgs::chain_*).  Results:
+  // second half of h_spec, indexed like the producer's points; the intermediate frame's temporal
+  // filter gives the map from the final frame's prev_pts to those indices.
+  unsigned long long* d_chain = nullptr;  // [2 * max_cnt] published forward results
+  uint32_t chain_seq = 0;
+  bool chain_enabled = true;   // (ESVIO_FE_NO_CHAIN=1 turns it off: A/B measurements)
+  bool chain_valid = false;    // a chained launch has been made ...
+  uint64_t chain_for = 0;      // ... for the frame with this number
+  bool chain_map_ok = false;
+  std::vector<int> chain_map;  // final frame's prev_pts[j] = producer point chain_map[j]
+  uint64_t frame_no = 0;       // trackEvent calls so far
+  hipEvent_t ev_chain_done = nullptr;
+  // k_select publishes each new corner as it accepts it; the speculative launch, already resident,
+  // picks them up one by one instead of starting after the whole selection
+  unsigned long long *d_pub_slots = nullptr, *d_pub_done = nullptr;
+  uint32_t pub_seq = 0;
+  // ---- lazy stereo of new corners (esvio_fe_set_lazy_new_stereo): a published frame returns
+  // without waiting for the stereo LK of the corners it has just detected; their right-camera
+  // entries are appended by the next call (before anything reads them) or by esvio_fe_finish
+  bool lazy_new = false;
+  struct PendingNew {
+    bool active = false;
+    bool prev_map_was_empty = false;
+    std::vector<int> ids;       // the new corners' ids
+    std::vector<P2f> left;      // ... and left positions
+  } pend;
+  // ... and a frame that publishes nothing returns without waiting for its stereo LK at all: the
+  // whole right-camera tail (:475-575) is run by the next call, in the shadow of its own kernels,
+  // or by esvio_fe_finish.  The next frame works in the other copy of set 1 meanwhile.
+  struct PendingRight {
+    bool active = false;
+    int set = 0;                // copy of set 1 that holds this frame's stereo LK results
+    double dt = 0;              // cur_time - prev_time of that frame
+    std::vector<int> ids;       // the frame's ids / left points (no new corners: nothing published)
+    std::vector<P2f> left;
+  } pend_right;
+  hipEvent_t ev_lks_done[2] = {nullptr, nullptr}, ev_lknew_done = nullptr;
+  host::RansacPool* pool = nullptr;  // esvio_fe_set_host_threads
+  // the prefetch stream's per-batch launch sequence as a HIP graph (fe_kernels.h)
+  // Off by default: measured on MI355X / ROCm 7.2 it saves ~17 us of host time per batch but the
+  // graph's kernels complete ~50 us later than the same kernels launched one by one, and the
+  // chained temporal LK then waits for the pyramids.  ESVIO_FE_GRAPH=1 turns it on.
+  bool graphs_enabled = false;
+  LaunchList rec;
+  LaunchGraph pf_graph;
+  // arc / select
+  uint8_t* d_flags = nullptr;
+  // per-block ordered candidate lists written by k_arc; two sets so that the Arc* of a prefetched
+  // batch (prefetch stream) never overwrites the set the current frame's selection still reads
+  struct CandSet {
+    uint32_t *xy = nullptr, *idx = nullptr, *cnt = nullptr;
+    // ... and their ordered compaction into one stream (k_compact, launched right behind k_arc)
+    uint32_t *comp_xy = nullptr, *comp_idx = nullptr, *total = nullptr;
+    size_t cap = 0;
+  } cand[kRightSlots];
+  // per-pixel earliest candidate of a set's latest Arc* pass (ArcArgs::first_map / launch_dedup)
+  uint32_t* d_first[kRightSlots] = {};
+  // per-pixel, per-polarity result of the event-independent part of isCorner (k_arc_map), one map
+  // per candidate set
+  uint32_t* d_cmap[kRightSlots] = {};
+  uint8_t* d_touched[kRightSlots] = {};  // (pixel, polarity) pairs a batch's left events hit
+  uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
+  bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1: A/B measurements)
+  bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1: k_time_surface + 3 x k_pyr_down)
+  bool disc_tab_only = false;              // (ESVIO_FE_DISC_TABLE=1: k_select's table look-ups)
+  int cand_cur = 0;
+  size_t arc_cap = 0;
+  uint32_t* d_mask_bits = nullptr;
+  // goodFeaturesToTrack scratch (image front-end), allocated on first use
+  float4 *d_gftt_cov = nullptr, *d_gftt_rowsum = nullptr;
+  float* d_gftt_eig = nullptr;
+  uint32_t* d_gftt_max = nullptr;
+  int32_t* d_sel_idx = nullptr;
+  // pinned host staging (layout: pin_of())
+  uint8_t* h_pin = nullptr;
+  size_t h_pin_bytes = 0;
+
+  // ---- FeatureTracker state (feature_tracker.h:119-173)
+  int n_id = 0;
+  double cur_time = 0, prev_time = 0;
+  std::vector<P2f> prev_pts, cur_pts, cur_right_pts, n_pts;
+  std::vector<P2f> cur_un_pts, cur_un_right_pts, pts_velocity, right_pts_velocity;
+  std::vector<int> ids, ids_right, track_cnt, track_cnt_right;
+  std::vector<int> src_idx;  // per cur_pts entry: index into the speculative stereo-LK results
+  IdMap cur_un_pts_map, prev_un_pts_map, cur_un_right_pts_map, prev_un_right_pts_map;
+  host::BitMask mask_event;
+
+  // ---- host phase trace (ESVIO_FE_TRACE=1): stage, sae+ts enqueue, sync A, host A, enqueue B,
+  // sync B, host B
+  bool trace = false;
+  double phase_ms[2][8] = {};  // [published?][phase]
+  double pub_ms[6] = {};       // published frames: the parts of "host mask + enqueue detect/stereo"
+  uint64_t phase_count[2] = {0, 0};
+  uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
+  double tr_fm_ms = 0;  // time inside find_fundamental_mat alone
+  double tr_fm_max_ms = 0, tr_lift_ms = 0;  // ... its slowest call; the two liftProjective batches
+  uint64_t tr_chain_launch = 0, tr_chain_used = 0, tr_chain_cancel = 0, tr_spec_used = 0;
+  // (trace only) device-side intervals of the published frame's chain, from timing events
+  hipEvent_t ev_dbg_sel_start = nullptr;
+  double tr_gpu_sel = 0, tr_gpu_spec = 0, tr_gpu_chain = 0, tr_host_chain = 0, tr_gpu_pyr = 0;
+  int tr_lane = -1;  // prefetch lane of the frame being tracked
+  uint64_t tr_gpu_n = 0;
+  std::chrono::steady_clock::time_point tr_sel_launch;
+
+  // ---- profiling
+  bool prof_on = false;
+  KStat stats[K_COUNT];
+  std::vector<ProfRec> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace esvio {
+namespace fe {
+
+// The stream the helpers enqueue on: the main stream unless the calling thread has switched to
+// another one (prefetch -> stream2, speculative LK -> stream3).
+inline thread_local hipStream_t t_stream_override = nullptr;
+inline hipStream_t cur_stream(const esvio_fe_ctx* c) {
+  return t_stream_override ? t_stream_override : c->stream;
+}
+struct StreamScope {
+  hipStream_t saved;
+  explicit StreamScope(hipStream_t s) : saved(t_stream_override) { t_stream_override = s; }
+  ~StreamScope() { t_stream_override = saved; }
+};
+
+inline int fail(esvio_fe_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    c->err = buf;
+  }
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail((c), ESVIO_FE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                  __FILE__, __LINE__);                                                       \
+  } while (0)
+
+// ---------------------------------------------------------------- profiling
+inline hipEvent_t get_event(esvio_fe_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ScopedKernel {  // brackets one launch with HIP events on the handle's stream
+  esvio_fe_ctx* c;
+  int id;
+  uint64_t bytes;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedKernel(esvio_fe_ctx* ctx, int kid, uint64_t alg_bytes) : c(ctx), id(kid), bytes(alg_bytes) {
+    if (c->prof_on) {
+      a = get_event(c);
+      b = get_event(c);
+      (void)hipEventRecord(a, cur_stream(c));
+    }
+  }
+  ~ScopedKernel() {
+    if (a) {
+      (void)hipEventRecord(b, cur_stream(c));
+      c->pending.push_back(ProfRec{id, a, b, bytes});
+    }
+  }
+};
+
+inline void resolve_profile(esvio_fe_ctx* c) {  // main stream idle; prefetch-stream records may be pending
+  std::vector<ProfRec> keep;
+  for (auto& r : c->pending) {
+    float ms = 0;
+    const hipError_t e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e == hipErrorNotReady) {
+      keep.push_back(r);
+      continue;
+    }
+    if (e == hipSuccess) {
+      c->stats[r.id].ms += ms;
+      c->stats[r.id].launches++;
+      c->stats[r.id].bytes += r.bytes;
+    }
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->pending.swap(keep);
+  (void)hipGetLastError();
+}
+
+}  // namespace fe
+}  // namespace esvio

@@ -1,0 +1,757 @@
+// fe_track.cpp — FeatureTracker::trackEvent (reference: feature_tracker/src/feature_tracker.cpp:340-603)
+// as a per-frame sequence over the stage launches of fe_stages.cpp, and the replay-mode scheduler
+// around it: next-batch prefetch on a second stream, speculative and chained temporal LK, lazy
+// right-camera tails.  Results are those of the plain sequence in every mode.
+#include "fe_internal.h"
+
+namespace esvio {
+namespace fe {
+
+// ---------------------------------------------------------------- next-batch prefetch
+// Enqueue the SAE update, time surfaces and pyramids of the batch announced with
+// esvio_fe_set_next_batch on the second stream; they overlap the rest of the current frame (stereo
+// LK, selection) and the host work between calls.  Waits for ev_planes_free (recorded on the main
+// stream once the current frame has finished reading the SAE planes) when `wait_planes`; a frame
+// that itself came from the prefetch stream and runs no Arc* on the main stream reads neither the
+// planes nor the raw surfaces there, so the next prefetch only has to follow its own stream.
+// With the caller's PUB hint the Arc* pass of the batch runs here too (into the other candidate
+// set), which takes it off the main stream's per-frame chain.
+int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
+  int rc = 0;
+  StreamScope on_prefetch_stream(c->stream2);
+  while (!rc && !c->announced.empty() && (int)c->inflight.size() < kPrefetchDepth) {
+    Inflight b;
+    static_cast<Batch&>(b) = c->announced.front();
+    // resources nobody is using: not the current frame's, not another prefetched batch's
+    auto taken = [&](int Inflight::*m, int v) {
+      for (const Inflight& o : c->inflight)
+        if (o.*m == v) return true;
+      return false;
+    };
+    b.lane = 0;
+    while (taken(&Inflight::lane, b.lane)) b.lane++;
+    b.slotL = 0;
+    while (b.slotL == c->slot_prevL || b.slotL == c->slot_curL || taken(&Inflight::slotL, b.slotL))
+      b.slotL++;
+    b.slotR = kLeftSlots;
+    while (b.slotR == c->slot_curR || taken(&Inflight::slotR, b.slotR)) b.slotR++;
+    b.raw = 0;
+    while (b.raw == c->raw_cur || taken(&Inflight::raw, b.raw)) b.raw++;
+    b.cand = 0;
+    while (b.cand == c->cand_cur || taken(&Inflight::cand, b.cand)) b.cand++;
+    do {
+      if (wait_planes && hipStreamWaitEvent(c->stream2, c->ev_planes_free, 0) != hipSuccess) {
+        rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
+        break;
+      }
+      wait_planes = false;  // later batches simply follow on the same stream
+      // the right-camera pyramid slot this batch gets may be the one an earlier frame's stereo LK
+      // (stream4) still reads — in lazy mode nobody has waited for that launch yet
+      if (c->lks_last >= 0 &&
+          hipStreamWaitEvent(c->stream2, c->ev_lks_done[c->lks_last], 0) != hipSuccess) {
+        rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
+        break;
+      }
+      if ((rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &b.dL, &b.dR, b.lane))) break;
+      // the ~11 dependent launches up to the pyramids go out as one graph (fe_kernels.h); with the
+      // per-kernel timers on they are launched one by one so that each can be bracketed
+      const bool as_graph = c->graphs_enabled && !c->prof_on;
+      if (as_graph) {
+        c->rec.clear();
+        set_launch_recorder(&c->rec);
+      }
+      bool arc_marked = false;
+      rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR, nullptr, nullptr, nullptr,
+                      b.pub && b.nL ? b.cand : -1, &arc_marked);
+      if (!rc) {
+        render_and_build(c, b.time, b.slotL, b.slotR, b.raw);
+        if (record_event(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
+          rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
+      }
+      if (as_graph) {
+        set_launch_recorder(nullptr);
+        if (!rc && launch_as_graph(c->pf_graph, c->rec, c->stream2) != hipSuccess) {
+          // (not expected; the plain path still works)
+          (void)hipGetLastError();
+          c->graphs_enabled = false;
+          destroy_launch_graph(c->pf_graph);
+          if (launch_plain(c->rec, c->stream2) != hipSuccess)
+            rc = fail(c, ESVIO_FE_EHIP, "kernel launch failed");
+        }
+      }
+      if (rc) break;
+      b.arc_done = false;
+      if (b.pub && b.nL) {
+        if ((rc = ensure_cand_capacity(c, b.cand, b.nL))) break;
+        const PyrDesc& ts = c->cfg.equalize ? c->raw[b.raw][0].d : c->pyr[b.slotL].d;
+        run_arc(c, b.dL, (uint32_t)b.nL, &ts, false, false, true, b.cand, arc_marked);
+        run_compact(c, (uint32_t)b.nL, b.cand);
+        if (hipEventRecord(c->ev_lane_arc[b.lane], c->stream2) != hipSuccess) {
+          rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
+          break;
+        }
+        b.arc_done = true;
+      }
+      c->inflight.push_back(b);
+      c->announced.pop_front();
+    } while (0);
+  }
+  return rc;
+}
+
+// Launch the NEXT frame's temporal forward/backward LK (feature_tracker.cpp:410,417 of the next
+// call) now: its inputs are final once this frame's kept points (written to z_new[0..n_kept)) and
+// new corners (written by k_select behind them, total count in d_counts[1]) are known, and the next
+// frame's pyramids are already being built on the prefetch stream.
+int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame's batch */,
+                          int n_kept, bool with_new) {
+  const size_t M = std::max(c->cfg.max_cnt, 1);
+  const size_t stM = (M + 63) / 64 * 64;
+  // (kept points: already in host memory; new corners: published one by one by the k_select that
+  // has just been launched — the waves of points >= n_kept wait for their slot)
+  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_lane_done[nxt.lane], 0));
+  float2* B = (float2*)c->z_spec;  // results land in the pinned block itself
+  float2* Cb = B + M;
+  uint8_t* sA = c->z_spec + M * 16;
+  uint8_t* sB = sA + stM;
+  const PyrDesc& P = c->pyr[c->slot_curL].d;
+  const PyrDesc& N = c->pyr[nxt.slotL].d;
+  const int n_max = with_new ? (int)M : n_kept;
+  LkArgs f = make_lk(P, N, c->z_new, nullptr, B, sA, nullptr, n_max, 3, 30, 0.01, 0);
+  LkArgs b = make_lk(N, P, nullptr, nullptr, nullptr, nullptr, nullptr, n_max, 1, 30, 0.01,
+                     ESVIO_FE_LK_USE_INITIAL_FLOW);
+  if (with_new) {
+    f.poll_slots = c->d_pub_slots;
+    f.poll_done = c->d_pub_done;
+    f.poll_seq = c->pub_seq;
+    f.poll_from = n_kept;
+    f.poll_err = (int*)(c->z_spec + M * 16 + 2 * stM);
+  }
+  // the frame after next, chained to this launch point by point (see esvio_fe_ctx::d_chain)
+  const Inflight* nxt2 = nullptr;
+  if (c->chain_enabled && !nxt.pub && c->inflight.size() >= 2 && c->inflight[0].lane == nxt.lane &&
+      !c->chain_valid)
+    nxt2 = &c->inflight[1];
+  if (nxt2) {
+    c->chain_seq = (c->chain_seq + 1) & 0x3fffffffu;
+    if (!c->chain_seq) c->chain_seq = 1;
+    f.chain_out = c->d_chain;
+    f.chain_seq = c->chain_seq;
+  }
+  {
+    StreamScope on_spec_stream(c->stream3);
+    run_lk(c, f, c->cfg.flow_back ? &b : nullptr, Cb, sB);
+  }
+  HIPCHK(c, hipEventRecord(c->ev_spec_done, c->stream3));
+  c->spec_valid = true;
+  if (nxt2) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt.lane], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt2->lane], 0));
+    uint8_t* zc = c->z_spec + c->spec_bytes;
+    const PyrDesc& N2 = c->pyr[nxt2->slotL].d;
+    LkArgs f2 = make_lk(N, N2, nullptr, nullptr, (float2*)zc, zc + M * 16, nullptr, n_max, 3, 30, 0.01, 0);
+    LkArgs b2 = make_lk(N2, N, nullptr, nullptr, nullptr, nullptr, nullptr, n_max, 1, 30, 0.01,
+                        ESVIO_FE_LK_USE_INITIAL_FLOW);
+    f2.chain_in = c->d_chain;
+    f2.chain_seq = c->chain_seq;
+    f2.poll_err = (int*)(zc + M * 16 + 2 * stM);
+    {
+      StreamScope on_chain_stream(c->stream4);
+      run_lk(c, f2, c->cfg.flow_back ? &b2 : nullptr, (float2*)zc + M, zc + M * 16 + stM);
+    }
+    HIPCHK(c, hipEventRecord(c->ev_chain_done, c->stream4));
+    c->chain_valid = true;
+    c->tr_chain_launch++;
+    c->chain_for = c->frame_no + 2;
+    c->chain_map_ok = false;
+  }
+  return 0;
+}
+
+// give up a chained launch whose results cannot be used (its kernel only waits for bounded times)
+int cancel_chain(esvio_fe_ctx* c) {
+  if (!c->chain_valid) return 0;
+  c->chain_valid = false;
+  c->chain_map_ok = false;
+  c->tr_chain_cancel++;
+  HIPCHK(c, hipStreamSynchronize(c->stream4));
+  return 0;
+}
+
+// The right-camera tail of trackEvent (:475-575) for the first n points of a frame (all of them, or
+// only the kept ones in lazy mode): the stereo LK results of the kept points are in set 1 (by
+// survivor index, src == nullptr: identity), those of the new corners in set 2.  n_left = the
+// frame's left point count (ptsVelocity's sizing quirk).
+void right_tail(esvio_fe_ctx* c, const Pin& pin, const P2f* left, const int* ids, const int* src,
+                int n, int n_kept, double dt, size_t n_left) {
+  const esvio_fe_config& cfg = c->cfg;
+  c->ids_right.clear();
+  c->cur_right_pts.clear();
+  c->cur_un_right_pts.clear();
+  c->right_pts_velocity.clear();
+  c->cur_un_right_pts_map.clear();
+  c->track_cnt_right.clear();
+  if (n_left) {
+    // gather the stereo results: kept points from set 1, new ones from set 2
+    std::vector<uint8_t> status(n), statusRightLeft(n);
+    std::vector<P2f> reverseLeftPts(n);
+    c->cur_right_pts.resize(n);
+    const P2f *B1 = (const P2f*)pin.ptsB, *C1 = (const P2f*)pin.ptsC;
+    const P2f *B2 = (const P2f*)pin.ptsB2, *C2 = (const P2f*)pin.ptsC2;
+    for (int i = 0; i < n; i++) {
+      if (i < n_kept) {
+        const int j = src ? src[i] : i;
+        c->cur_right_pts[i] = B1[j];
+        status[i] = pin.stA[j];
+        reverseLeftPts[i] = C1[j];
+        statusRightLeft[i] = pin.stB[j];
+      } else {
+        const int j = i - n_kept;
+        c->cur_right_pts[i] = B2[j];
+        status[i] = pin.stA2[j];
+        reverseLeftPts[i] = C2[j];
+        statusRightLeft[i] = pin.stB2[j];
+      }
+    }
+    if (cfg.flow_back && !c->cur_right_pts.empty()) {
+      for (int i = 0; i < n; i++) {
+        if (status[i] && statusRightLeft[i] && in_border_event(c, c->cur_right_pts[i]) &&
+            pt_distance(left[i], reverseLeftPts[i]) <= 0.5)
+          status[i] = 1;
+        else
+          status[i] = 0;
+      }
+    }
+    c->ids_right.assign(ids, ids + n);
+    reduce_vector(c->cur_right_pts, status);
+    reduce_vector(c->ids_right, status);
+    c->track_cnt_right.assign(c->cur_right_pts.size(), 1);
+    c->cur_un_right_pts = undistorted_pts(c->cur_right_pts, cfg.cam[1]);
+    c->right_pts_velocity =
+        pts_velocity_fn(c->ids_right, c->cur_un_right_pts, c->cur_un_right_pts_map,
+                        c->prev_un_right_pts_map, dt, n_left);
+  }
+  // reference: prev = cur (copy); cur is cleared before its next use in ptsVelocity, so a swap
+  // is equivalent and avoids re-allocating ~300 map nodes per frame
+  c->prev_un_right_pts_map.swap(c->cur_un_right_pts_map);
+}
+
+// Lazy mode: the right-camera tail of the previous call's frame, which published nothing and
+// returned with its stereo LK still in flight.
+int finalize_right(esvio_fe_ctx* c) {
+  if (!c->pend_right.active) return 0;
+  esvio_fe_ctx::PendingRight& pr = c->pend_right;
+  pr.active = false;
+  const int n = (int)pr.left.size();
+  if (n) HIPCHK(c, sync_event(c->ev_lks_done[pr.set]));
+  if (pin_of(c).counts[3] != 0) return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
+  right_tail(c, pin_of(c, pr.set), pr.left.data(), pr.ids.data(), nullptr, n, n, pr.dt, (size_t)n);
+  return 0;
+}
+
+// Lazy mode: append the right-camera entries of the corners the previous published frame detected
+// (their stereo LK has run meanwhile).  Equal to what the eager tail would have produced: the new
+// ids are the largest, come last in every vector, are absent from the previous frame's map (zero
+// velocity, feature_tracker.cpp:1026-1040) and extend the (sorted) map the next frame reads.
+int finalize_pending(esvio_fe_ctx* c) {
+  if (!c->pend.active) return 0;
+  c->pend.active = false;
+  HIPCHK(c, sync_event(c->ev_lknew_done));
+  Pin pin = pin_of(c);
+  const esvio_fe_config& cfg = c->cfg;
+  const P2f *B2 = (const P2f*)pin.ptsB2, *C2 = (const P2f*)pin.ptsC2;
+  std::vector<P2f> add;
+  std::vector<int> add_ids;
+  for (size_t j = 0; j < c->pend.ids.size(); j++) {
+    bool ok = pin.stA2[j] != 0;
+    if (cfg.flow_back)
+      ok = ok && pin.stB2[j] && in_border_event(c, B2[j]) && pt_distance(c->pend.left[j], C2[j]) <= 0.5;
+    if (ok) {
+      add.push_back(B2[j]);
+      add_ids.push_back(c->pend.ids[j]);
+    }
+  }
+  if (add.empty()) return 0;
+  const std::vector<P2f> un = undistorted_pts(add, cfg.cam[1]);
+  for (size_t j = 0; j < add.size(); j++) {
+    c->ids_right.push_back(add_ids[j]);
+    c->cur_right_pts.push_back(add[j]);
+    c->cur_un_right_pts.push_back(un[j]);
+    c->track_cnt_right.push_back(1);
+    if (!c->pend.prev_map_was_empty) c->right_pts_velocity.push_back(P2f{0, 0});
+    c->prev_un_right_pts_map.v.emplace_back(add_ids[j], un[j]);  // (already swapped: next frame's prev)
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- trackEvent
+int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* left, size_t nL,
+                     const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME,
+                     const esvio_fe_motion* motion) {
+  const esvio_fe_config& cfg = c->cfg;
+  const int M = cfg.max_cnt;
+  // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
+  // (lazy mode, pend_right) while this frame's kernels are enqueued
+  c->res_set ^= 1;
+  c->frame_no++;
+  Pin pin = pin_of(c, c->res_set);
+  if (PUB_THIS_FRAME && c->pool) host::ransac_pool_wake(c->pool);
+  c->cur_time = _cur_time;
+  using clk = std::chrono::steady_clock;
+  auto tp = clk::now();
+  auto lap = [&](int i) {
+    if (!c->trace) return;
+    auto now = clk::now();
+    c->phase_ms[PUB_THIS_FRAME ? 1 : 0][i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    tp = now;
+  };
+
+  const EventRec *dL = nullptr, *dR = nullptr;
+  const bool first = !c->have_img;
+  bool arc_done = false, arc_prefetched = false, arc_marked_main = false;
+  int arc_lane = 0;
+  if (!c->inflight.empty()) {
+    // this batch was announced with esvio_fe_set_next_batch and its SAE update, images and
+    // pyramids were enqueued on the prefetch stream during an earlier call
+    const Inflight b = c->inflight.front();
+    if (left != b.left || nL != b.nL || right != b.right || nR != b.nR || space != b.space ||
+        _cur_time != b.time || motion)
+      return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
+    if (PUB_THIS_FRAME && !b.arc_done && c->inflight.size() > 1)
+      return fail(c, ESVIO_FE_EINVAL,
+                  "PUB hint was 0 for a published frame and a later batch is already applied to "
+                  "the SAE: with more than one batch announced the hint must be exact");
+    c->inflight.pop_front();
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_done[b.lane], 0));
+    c->tr_lane = b.lane;
+    dL = b.dL;
+    dR = b.dR;
+    c->slot_curL = b.slotL;
+    c->slot_curR = b.slotR;
+    c->raw_cur = b.raw;
+    c->cur_prefetched = true;
+    if (b.arc_done) {  // candidates of this batch are in its own set
+      c->cand_cur = b.cand;
+      arc_lane = b.lane;
+      arc_done = arc_prefetched = true;
+    }
+  } else {
+    c->cur_prefetched = false;
+    if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
+    // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
+    if (c->ext_sae_pending) {
+      // esvio_fe_sae_slice_commit has put this batch into the planes already (its SAE update ran
+      // time-sliced over several GPUs); the events are still needed below for Arc*
+      if (motion) return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update has no motion-compensated form");
+      c->ext_sae_pending = false;
+    } else if (motion) {
+      esvio_fe_event first_ev;
+      if (int rc = first_event_host(c, left, space, &first_ev)) return rc;
+      const McParams mc = make_mc_params(motion, first_ev);
+      if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
+    } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, nullptr, nullptr, nullptr,
+                                   PUB_THIS_FRAME ? c->cand_cur : -1, &arc_marked_main)) {
+      return rc;
+    }
+    // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; slot rotation replaces the
+    // cv::Mat header swaps of :390-403,:585.  Left slots 0..2: {prev, cur, free}.
+    int sl = 0;
+    while (!first && (sl == c->slot_prevL || sl == c->slot_curL)) sl++;
+    c->slot_curL = sl;
+    // camera split: the right image was imported into slot_curR by esvio_fe_import_image
+    if (!c->ext_right_pending) c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;
+    c->raw_cur = (c->raw_cur + 1) % kRightSlots;
+    if (c->ext_right_pending) {
+      render_lk_images(c, c->cur_time, 1, c->slot_curL, c->slot_curR, c->raw_cur);
+      PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[c->slot_curR].d};
+      pyr_build(c, cur2, 2);
+    } else {
+      render_and_build(c, c->cur_time, c->slot_curL, c->slot_curR, c->raw_cur);
+    }
+    c->ext_right_pending = false;
+  }
+  // the next frame's batch, if it is already in flight (two announced ahead), else once this
+  // frame's early_work has put it there
+  bool have_next = !c->inflight.empty();
+  Inflight next_b = have_next ? c->inflight.front() : Inflight();
+  const bool had_announced = !c->announced.empty();
+  auto next_batch = [&]() -> const Inflight* {
+    if (!have_next && had_announced) {
+      if (!c->inflight.empty()) {
+        next_b = c->inflight.front();
+        have_next = true;
+      }
+    }
+    return have_next ? &next_b : nullptr;
+  };
+  if (first) c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left = img_left (:391)
+  c->have_img = true;
+  const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
+  const PyrDesc& curL = c->pyr[c->slot_curL].d;
+  const PyrDesc& curR = c->pyr[c->slot_curR].d;
+  // what THIS frame enqueues on the main stream that reads the SAE planes / raw time surfaces:
+  // its own SAE update + rendering unless prefetched, and Arc* unless that ran with the prefetch
+  bool main_reads_planes = !c->cur_prefetched;
+
+  c->cur_pts.clear();
+  c->cur_right_pts.clear();
+  lap(0);
+
+  // Arc* for every left event does not depend on the tracks: on published frames it is enqueued
+  // now (behind the temporal LK) without the blocked-pixel mask, so it runs under the host-side
+  // filtering / RANSAC / Event_setMask; the mask becomes k_select's initial bitmap.  After it
+  // nothing of this frame reads the planes on the main stream, so the announced next batch is
+  // started on the prefetch stream.
+  bool early_done = false;
+  auto early_work = [&]() -> int {
+    if (early_done) return 0;
+    early_done = true;
+    if (PUB_THIS_FRAME && !arc_done) {
+      if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
+      const PyrDesc ts = raw_ts_desc(c, 0);
+      run_arc(c, dL, (uint32_t)nL, &ts, false, false, true, c->cand_cur, arc_marked_main);
+      run_compact(c, (uint32_t)nL, c->cand_cur);
+      arc_done = true;
+      main_reads_planes = true;
+    }
+    if (!had_announced) return 0;
+    if (main_reads_planes) HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
+    return prefetch_next(c, main_reads_planes);
+  };
+
+  // a speculative launch of this very temporal LK may have been made by the previous call
+  bool use_spec = false;
+  if (c->spec_valid) {
+    c->spec_valid = false;
+    use_spec = c->cur_prefetched && (int)c->prev_pts.size() == c->spec_n;
+    if (!use_spec) HIPCHK(c, hipStreamSynchronize(c->stream3));
+  }
+  // ... or a chained one by the call before that; if it was made for the NEXT frame, this frame
+  // is the one in between: it must publish nothing and track with the speculative results
+  bool use_chain = false;
+  if (c->chain_valid && c->chain_for == c->frame_no) {
+    use_chain = !use_spec && c->cur_prefetched && c->chain_map_ok &&
+                c->chain_map.size() == c->prev_pts.size();
+    if (!use_chain)
+      if (int rc = cancel_chain(c)) return rc;
+    c->chain_valid = false;
+  } else if (c->chain_valid && (c->chain_for != c->frame_no + 1 || PUB_THIS_FRAME || !use_spec)) {
+    if (int rc = cancel_chain(c)) return rc;
+  }
+  const bool chain_covers_next = c->chain_valid;  // (then: for frame_no + 1)
+  const bool early_results = use_spec || use_chain;
+  // When to enqueue the ~12 launches of the announced batch's prefetch (early_work):
+  //  * before the wait for this frame's temporal LK when that is a speculative / chained launch
+  //    still running and the frame publishes nothing: the host would only wait there;
+  //  * late — a published frame whose successor is already in flight: after everything else of the
+  //    frame, while the corner selection runs (RANSAC + mask + selection sit behind the temporal
+  //    LK wait, so nothing is put in front of them);
+  //  * else right away (Arc* still has to run on the main stream, or nothing to overlap with).
+  // (Handing them to a second host thread was tried: the two threads' launches serialise inside
+  // the runtime and the frame got slower, so everything stays on the calling thread.)
+  const bool before_sync = early_results && !PUB_THIS_FRAME;
+  const bool defer_late = !(PUB_THIS_FRAME && !arc_done) && have_next && !before_sync;
+  if (c->prev_pts.size() > 0) {  // :405-437
+    const int n = (int)c->prev_pts.size();
+    const uint8_t *t_stA, *t_stB;
+    const P2f *t_ptsB, *t_ptsC;
+    bool spec_ok = false;
+    if (use_spec) {
+      if (!defer_late)
+        if (int rc = early_work()) return rc;
+      lap(1);
+      HIPCHK(c, sync_event(c->ev_spec_done));
+      lap(2);
+      const size_t stM = ((size_t)std::max(M, 1) + 63) / 64 * 64;
+      t_ptsB = (const P2f*)c->h_spec;
+      t_ptsC = (const P2f*)(c->h_spec + (size_t)std::max(M, 1) * 8);
+      t_stA = c->h_spec + (size_t)std::max(M, 1) * 16;
+      t_stB = t_stA + stM;
+      int* wait_expired = (int*)(c->h_spec + (size_t)std::max(M, 1) * 16 + 2 * stM);
+      spec_ok = *wait_expired == 0;  // (a wave gave up waiting for k_select: redo the launch below)
+      *wait_expired = 0;
+    }
+    std::vector<P2f> g_ptsB, g_ptsC;
+    std::vector<uint8_t> g_stA, g_stB;
+    if (use_chain) {
+      if (!defer_late)
+        if (int rc = early_work()) return rc;
+      lap(1);
+      HIPCHK(c, sync_event(c->ev_chain_done));
+      lap(2);
+      const size_t Mx = (size_t)std::max(M, 1), stM = (Mx + 63) / 64 * 64;
+      const uint8_t* hc = c->h_spec + c->spec_bytes;
+      int* wait_expired = (int*)(hc + Mx * 16 + 2 * stM);
+      spec_ok = *wait_expired == 0;
+      *wait_expired = 0;
+      c->tr_chain_used += spec_ok;
+      if (c->trace && spec_ok) {
+        float a = 0, b = 0, d = 0;
+        if (hipEventElapsedTime(&a, c->ev_dbg_sel_start, c->ev_sel_host) == hipSuccess &&
+            hipEventElapsedTime(&b, c->ev_sel_host, c->ev_spec_done) == hipSuccess &&
+            hipEventElapsedTime(&d, c->ev_sel_host, c->ev_chain_done) == hipSuccess) {
+          c->tr_gpu_sel += a;
+          c->tr_gpu_spec += b;
+          c->tr_gpu_chain += d;
+          float e2 = 0;
+          if (c->tr_lane >= 0 &&
+              hipEventElapsedTime(&e2, c->ev_sel_host, c->ev_lane_done[c->tr_lane]) == hipSuccess)
+            c->tr_gpu_pyr += e2;
+          else
+            (void)hipGetLastError();
+          c->tr_host_chain += std::chrono::duration<double, std::milli>(clk::now() - c->tr_sel_launch).count();
+          c->tr_gpu_n++;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+      if (spec_ok) {  // gather: prev_pts[j] was the producer's point chain_map[j]
+        const P2f *sB = (const P2f*)hc, *sC = (const P2f*)(hc + Mx * 8);
+        const uint8_t *sa = hc + Mx * 16, *sb = sa + stM;
+        g_ptsB.resize(n);
+        g_ptsC.resize(n);
+        g_stA.resize(n);
+        g_stB.resize(n);
+        for (int j = 0; j < n; j++) {
+          const int k = c->chain_map[j];
+          g_ptsB[j] = sB[k];
+          g_ptsC[j] = sC[k];
+          g_stA[j] = sa[k];
+          g_stB[j] = sb[k];
+        }
+        t_ptsB = g_ptsB.data();
+        t_ptsC = g_ptsC.data();
+        t_stA = g_stA.data();
+        t_stB = g_stB.data();
+      }
+    }
+    if (!spec_ok) {
+      std::memcpy(pin.A, c->prev_pts.data(), (size_t)n * 8);
+      // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
+      // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
+      LkArgs f = make_lk(prevL, curL, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n, 3, 30, 0.01, 0);
+      LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
+                         ESVIO_FE_LK_USE_INITIAL_FLOW);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
+      if (int rc = early_work()) return rc;
+      lap(1);
+      HIPCHK(c, sync_main(c));
+      lap(2);
+      t_ptsB = (const P2f*)pin.ptsB;
+      t_ptsC = (const P2f*)pin.ptsC;
+      t_stA = pin.stA;
+      t_stB = pin.stB;
+    }
+    std::vector<uint8_t> status(t_stA, t_stA + n);
+    c->cur_pts.resize(n);
+    std::memcpy(c->cur_pts.data(), t_ptsB, (size_t)n * 8);
+    if (cfg.flow_back) {
+      const P2f* reverse_pts = t_ptsC;
+      for (int i = 0; i < n; i++) {
+        if (status[i] && t_stB[i] && pt_distance(c->prev_pts[i], reverse_pts[i]) <= 0.5)
+          status[i] = 1;
+        else
+          status[i] = 0;
+      }
+    }
+    for (int i = 0; i < n; i++)
+      if (status[i] && !in_border_event(c, c->cur_pts[i])) status[i] = 0;
+    if (chain_covers_next) {
+      if (use_spec && spec_ok) {  // (the producer's point i is this frame's prev_pts[i])
+        c->chain_map.clear();
+        for (int i = 0; i < n; i++)
+          if (status[i]) c->chain_map.push_back(i);
+        c->chain_map_ok = true;
+      } else if (int rc = cancel_chain(c)) {
+        return rc;
+      }
+    }
+    reduce_vector(c->prev_pts, status);
+    reduce_vector(c->cur_pts, status);
+    reduce_vector(c->ids, status);
+    reduce_vector(c->track_cnt, status);
+  } else if (chain_covers_next) {
+    if (int rc = cancel_chain(c)) return rc;
+  }
+
+  if (!defer_late)
+    if (int rc = early_work()) return rc;  // (no previous points: nothing was synchronised above)
+  for (auto& n : c->track_cnt) n++;  // :439-440
+
+  // ---- speculative stereo LK of every temporal survivor (a superset of the points that survive
+  // rejectWithF_event / Event_setMask): per-point results do not depend on the other points, so
+  // this is exactly cv::calcOpticalFlowPyrLK(curL, curR, cur_pts, ...) (:490) and its reverse (:495)
+  // for the kept points — launched now so that it overlaps the host-side RANSAC + mask.
+  const int n_surv = (int)c->cur_pts.size();
+  c->src_idx.resize(n_surv);
+  for (int i = 0; i < n_surv; i++) c->src_idx[i] = i;
+  lap(3);
+  bool detect = false;
+  int n_kept = n_surv;
+  // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
+  // launched as soon as this frame's points are final
+  const bool will_spec = have_next || had_announced;
+  auto upload_kept = [&]() -> int {
+    if (!will_spec || !n_kept) return 0;
+    // pin.news is a single buffer and the previous published frame's lazy stereo LK of its new
+    // corners reads its points from there (z_new + its n_kept) in place.  Up to ~1000 points every
+    // wave of that launch is resident from the start and has loaded its point long before the host
+    // gets here (it had to wait for this frame's temporal LK first); a larger launch runs in
+    // several rounds of blocks, so its completion is awaited before the slots are overwritten.
+    if (c->pend.active && M > 1024) HIPCHK(c, sync_event(c->ev_lknew_done));
+    std::memcpy(pin.news, c->cur_pts.data(), (size_t)n_kept * 8);  // read in place by the LK
+    return 0;
+  };
+  if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
+    if (int rc = upload_kept()) return rc;
+    // (c->chain_valid here: the next frame's temporal LK is already running, chained to this one's)
+    if (will_spec && n_kept && !c->chain_valid)
+      if (const Inflight* nb = next_batch())
+        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
+  }
+  if (n_surv) {
+    std::memcpy(pin.A, c->cur_pts.data(), (size_t)n_surv * 8);
+    LkArgs f = make_lk(curL, curR, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n_surv, 3, 30,
+                       0.01, 0);
+    LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
+    {
+      // on its own stream.  Its inputs are complete without a device-side wait: the host has just
+      // read this frame's temporal LK results, and that launch ran behind the frame's pyramids.
+      StreamScope on_stereo_stream(c->stream4);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
+      HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], c->stream4));
+    }
+    c->lks_last = c->res_set;
+  }
+
+  if (PUB_THIS_FRAME) {  // :442-469
+    if (cfg.f_ransac) reject_with_f_event(c);
+    lap(4);
+    auto tq = clk::now();
+    auto sub = [&](int i) {
+      if (!c->trace) return;
+      const auto now = clk::now();
+      c->pub_ms[i] += std::chrono::duration<double, std::milli>(now - tq).count();
+      tq = now;
+    };
+    event_set_mask(c);
+    sub(0);
+    n_kept = (int)c->cur_pts.size();
+    const int n_max_cnt = M - n_kept;
+    if (int rc = upload_kept()) return rc;
+    if (n_max_cnt <= 0 && will_spec && n_kept)
+      if (const Inflight* nb = next_batch())
+        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
+    if (n_max_cnt > 0) {
+      detect = true;
+      // Event_setMask's blocked pixels are the discs of the kept points: k_select stamps them
+      // into its bitmap itself from the points just written to pin.news (1-2 KB read in place
+      // instead of a 38 KB bitmap copied over); candidates on them are skipped there
+      if (!will_spec && n_kept) std::memcpy(pin.news, c->cur_pts.data(), (size_t)n_kept * 8);
+      if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
+      // new corners go behind the kept points: z_new = next frame's prev_pts
+      c->pub_seq++;
+      if (c->trace) {
+        HIPCHK(c, hipEventRecord(c->ev_dbg_sel_start, cur_stream(c)));
+        c->tr_sel_launch = clk::now();
+      }
+      run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, nullptr, c->z_counts, will_spec,
+                 c->z_new, n_kept);
+      sub(1);
+      if (will_spec)
+        if (const Inflight* nb = next_batch())
+          if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
+      sub(2);
+      // the selection result is in host memory once k_select is done: an event right behind it lets
+      // the left-camera bookkeeping below run under the stereo LK of the new corners
+      HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
+      if (int rc = finalize_pending(c)) return rc;  // (its results live where this launch writes)
+      if (int rc = finalize_right(c)) return rc;    // (idle time: k_select is running)
+      sub(3);
+      // stereo LK of the new corners only (count known on the device)
+      LkArgs f = make_lk(curL, curR, c->z_new + n_kept, nullptr, c->z_ptsB2, c->z_stA2, c->d_counts,
+                         n_max_cnt, 3, 30, 0.01, 0);
+      LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, c->d_counts, n_max_cnt, 3, 30,
+                         0.01, 0);
+      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC2, c->z_stB2);
+      if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lknew_done, cur_stream(c)));
+      sub(4);
+    }
+    if (defer_late)
+      if (int rc = early_work()) return rc;
+    sub(5);
+  } else if (defer_late) {
+    if (int rc = early_work()) return rc;
+  }
+  lap(5);
+  if (detect) HIPCHK(c, sync_event(c->ev_sel_host));
+
+  int n_new = 0;
+  if (PUB_THIS_FRAME) {
+    c->n_pts.clear();
+    if (detect) {
+      n_new = pin.counts[0];
+      c->tr_cand += (uint64_t)pin.counts[2];
+      c->tr_new += (uint64_t)n_new;
+      c->tr_detect++;
+      const P2f* np = (const P2f*)pin.news + n_kept;
+      for (int i = 0; i < n_new; i++) c->n_pts.push_back(np[i]);
+    }
+    for (auto& p : c->n_pts) {  // :463-468
+      c->cur_pts.push_back(p);
+      c->ids.push_back(c->n_id++);
+      c->track_cnt.push_back(1);
+    }
+  }
+  c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);  // :470-473
+  c->pts_velocity = pts_velocity_fn(c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map,
+                                    c->cur_time - c->prev_time, c->cur_pts.size());
+  lap(7);
+  if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners,
+  if (int rc = finalize_right(c)) return rc;    //  or the previous unpublished frame's whole tail)
+  const bool lazy = c->lazy_new && detect;      // leave this frame's new corners to the next call
+  const bool defer_right = c->lazy_new && !PUB_THIS_FRAME;  // ... or its whole right-camera tail
+  if (defer_right) {
+    // (returns with the stereo LK in flight)
+  } else {
+    if (!lazy) HIPCHK(c, sync_main(c));  // stereo LK results of the new corners
+    if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));  // ... of the kept points
+  }
+  lap(6);
+  if (!defer_right && (n_surv || detect) && pin.counts[3] != 0)
+    return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
+
+  if (defer_right) {
+    // nothing of this frame is published: its right-camera tail waits for the next call
+    c->pend_right.active = true;
+    c->pend_right.set = c->res_set;
+    c->pend_right.dt = c->cur_time - c->prev_time;
+    c->pend_right.ids = c->ids;
+    c->pend_right.left = c->cur_pts;
+  } else {
+    if (lazy) {
+      c->pend.active = true;
+      c->pend.prev_map_was_empty = c->prev_un_right_pts_map.empty();
+      c->pend.ids.assign(c->ids.begin() + n_kept, c->ids.end());
+      c->pend.left.assign(c->cur_pts.begin() + n_kept, c->cur_pts.end());
+    }
+    right_tail(c, pin, c->cur_pts.data(), c->ids.data(), c->src_idx.data(),
+               lazy ? n_kept : (int)c->cur_pts.size(), n_kept, c->cur_time - c->prev_time,
+               c->cur_pts.size());
+  }
+  c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left (:585)
+  c->prev_pts = c->cur_pts;
+  c->prev_un_pts_map.swap(c->cur_un_pts_map);
+  c->prev_time = c->cur_time;
+  c->spec_n = (int)c->prev_pts.size();
+  lap(7);
+  c->phase_frames++;
+  c->phase_count[PUB_THIS_FRAME ? 1 : 0]++;
+  c->tr_surv += (uint64_t)n_surv;
+  if (c->prof_on) resolve_profile(c);
+  return 0;
+}
+
+
+}  // namespace fe
+}  // namespace esvio
