@@ -672,14 +672,16 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
                                                    const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
                                                    uint32_t te, uint32_t nblk, uint32_t group,
                                                    uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm) {
-  __shared__ uint32_t h[kTileMaxBins], run[kTileMaxBins];
+  constexpr int UB = 4, UE = 4;
+  __shared__ uint32_t h[UB][kTileMaxBins], run[kTileMaxBins];  // 40 KiB
   const int nb = g.nbins;
   for (int i = threadIdx.x; i < nb; i += kTileHistThreads) run[i] = 0;
   const uint32_t n = nL + nR;
-  // (te <= 4 * kTileHistThreads: a thread has at most 4 events per scatter block; the records of up
-  // to 4 scatter blocks are requested together so that their latencies overlap)
-  constexpr int UB = 4, UE = 4;
+  // (te <= 4 * kTileHistThreads: a thread has at most 4 events per scatter block.)  Up to 4 scatter
+  // blocks at a time: their records are requested together, counted into 4 LDS histograms between
+  // one pair of barriers, then the 4 rows of P are written from the running prefix.
   for (uint32_t k0 = 0; k0 < group; k0 += UB) {
+    for (int i = threadIdx.x; i < UB * kTileMaxBins; i += kTileHistThreads) (&h[0][0])[i] = 0;
     uint32_t bins[UB][UE];
 #pragma unroll
     for (int u = 0; u < UB; u++) {
@@ -692,63 +694,66 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
         if (j * kTileHistThreads < (int)te && i < hi) {
           const bool right = i >= nL;
           const uint4 e = right ? evR[i - nL] : evL[i];  // (whole records: one coalesced 1 KiB request per wave)
-          const uint32_t bin = tile_bin(g, e.x, right);
-          bins[u][j] = bin;
+          bins[u][j] = tile_bin(g, e.x, right);
         }
       }
     }
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < UB; u++) {
-      const uint32_t b = blockIdx.x * group + k0 + u;
-      if (k0 + u >= group || b >= nblk) break;
-      for (int i = threadIdx.x; i < nb; i += kTileHistThreads) h[i] = 0;
-      __syncthreads();
+    for (int u = 0; u < UB; u++)
 #pragma unroll
       for (int j = 0; j < UE; j++)
-        if (bins[u][j] != 0xffffffffu) atomicAdd(&h[bins[u][j]], 1u);
-      __syncthreads();
-      for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
-        const uint32_t r = run[i];
-        Pm[(size_t)b * nb + i] = r;
-        run[i] = r + h[i];
+        if (bins[u][j] != 0xffffffffu) atomicAdd(&h[u][bins[u][j]], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
+      uint32_t r = run[i];
+#pragma unroll
+      for (int u = 0; u < UB; u++) {
+        const uint32_t b = blockIdx.x * group + k0 + u;
+        if (k0 + u < group && b < nblk) {
+          Pm[(size_t)b * nb + i] = r;
+          r += h[u][i];
+        }
       }
+      run[i] = r;
     }
+    __syncthreads();
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nb; i += kTileHistThreads) Tm[(size_t)blockIdx.x * nb + i] = run[i];
 }
 
-// exclusive prefix of the group totals over the groups, per bucket: lane = bucket, the 16 waves of a
-// block take consecutive ranges of groups
-constexpr int kTileScanThreads = 1024;
+// exclusive prefix of the group totals over the groups, per bucket
+constexpr int kTileScanThreads = 256, kTileScanBins = 16;
 __global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* __restrict__ Tm, uint32_t nseg,
                                                                 int nb, uint32_t* __restrict__ Cm,
                                                                 uint32_t* __restrict__ totals,
                                                                 unsigned long long* n_rejected) {
-  __shared__ uint32_t part[kTileScanThreads / 64][64];
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  constexpr int NW = kTileScanThreads / 64;
-  const int bin = blockIdx.x * 64 + lane;
+  // thread = (bucket of the block's 16, one of 16 consecutive ranges of groups)
+  constexpr int NR = kTileScanThreads / kTileScanBins;
+  __shared__ uint32_t part[NR][kTileScanBins];
+  const int bl = threadIdx.x % kTileScanBins, r = threadIdx.x / kTileScanBins;
+  const int bin = blockIdx.x * kTileScanBins + bl;
   const bool ok = bin < nb;
-  const uint32_t per = (nseg + NW - 1) / NW;
-  const uint32_t s0 = min((uint32_t)wave * per, nseg), s1 = min(s0 + per, nseg);
+  const uint32_t per = (nseg + NR - 1) / NR;
+  const uint32_t s0 = min((uint32_t)r * per, nseg), s1 = min(s0 + per, nseg);
   uint32_t sum = 0;
-  for (uint32_t s = s0; s < s1; s++) sum += ok ? Tm[(size_t)s * nb + bin] : 0u;
-  part[wave][lane] = sum;
+  for (uint32_t sg = s0; sg < s1; sg++) sum += ok ? Tm[(size_t)sg * nb + bin] : 0u;
+  part[r][bl] = sum;
   __syncthreads();
   uint32_t carry = 0, tot = 0;
-  for (int w = 0; w < NW; w++) {
-    const uint32_t v = part[w][lane];
-    if (w < wave) carry += v;
+  for (int w = 0; w < NR; w++) {
+    const uint32_t v = part[w][bl];
+    if (w < r) carry += v;
     tot += v;
   }
-  for (uint32_t s = s0; s < s1; s++) {
-    if (!ok) break;
-    const uint32_t v = Tm[(size_t)s * nb + bin];
-    Cm[(size_t)s * nb + bin] = carry;
+  if (!ok) return;
+  for (uint32_t sg = s0; sg < s1; sg++) {
+    const uint32_t v = Tm[(size_t)sg * nb + bin];
+    Cm[(size_t)sg * nb + bin] = carry;
     carry += v;
   }
-  if (wave == 0 && ok) {
+  if (r == 0) {
     totals[bin] = tot;
     if (bin == nb - 1 && tot) atomicAdd(n_rejected, (unsigned long long)tot);  // out-of-sensor events
   }
@@ -762,7 +767,7 @@ void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const Eve
   const uint32_t group = tile_hist_group(nblk), nseg = (nblk + group - 1) / group;
   launch_k(k_tile_hist, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, te, nblk,
            group, sc.P, sc.T);
-  launch_k(k_tile_scan, dim3((g.nbins + 63) / 64), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,
+  launch_k(k_tile_scan, dim3((g.nbins + kTileScanBins - 1) / kTileScanBins), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,
            g.nbins, sc.C, sc.totals, n_rejected);
 }
 
@@ -1004,11 +1009,18 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
                ((valid && (same & above) == 0) ? 16u : 0u);
     }
     // ---- ordered part: after every earlier turn's
+    bool gave_up = false;
     if (lane == 0) {
       uint32_t spins = 0;
-      while (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != turn) {
-        if (++spins > (1u << 26)) {  // bounded: never hang the GPU
+      uint32_t d;
+      // (bounded: never hang the GPU.  A wave that gives up poisons the ticket, so that the block's
+      // other waves give up at once instead of timing out one turn after the other; the host sees
+      // *err and fails the call)
+      while ((d = __hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != turn) {
+        if (d == 0xffffffffu || ++spins > (1u << 21)) {
           *err = 2;
+          gave_up = true;
+          __hip_atomic_store(&s_done, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           break;
         }
       }
@@ -1025,7 +1037,8 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
       __asm__ volatile("" ::: "memory");
     }
     // (LDS executes a wave's instructions in order: the ticket becomes visible after the accesses above)
-    if (lane == 0) __hip_atomic_store(&s_done, turn + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0 && !gave_up)
+      __hip_atomic_store(&s_done, turn + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // ---- unordered again
 #pragma unroll
     for (int k = 0; k < kTileTurn; k++) {
