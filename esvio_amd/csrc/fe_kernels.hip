@@ -9,6 +9,7 @@
 #include "fe_mc.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <tuple>
 
@@ -1083,20 +1084,28 @@ void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const Ti
                        double2* L2, double2* S2, double filter_threshold, uint8_t* arc_touched, int* err) {
   const int npx = g.tw * g.th;
   const unsigned lds = (unsigned)(npx * 24 + npx / 4 + 16);
-  // a turn is 256 events: with a few turns per bucket 4 waves are plenty and many blocks fit a CU,
-  // with thousands of events per bucket 16 waves keep the ticket moving
+  // a turn is 256 events: with a few turns per bucket 4 waves are plenty and many blocks fit a CU;
+  // with thousands of events per bucket 8 waves (measured at 6.7 M events, 1841 buckets: 73 us with
+  // 512 threads, 82 with 256, 112 with 1024; turns of 2 / 4 / 8 chunks at 512 threads: 90 / 73 / 111)
   const bool big = n / (uint32_t)(2 * g.nt_cam) >= 2048u;
 #define ESVIO_TILE_APPLY(T, B)                                                                            \
   launch_k(k_tile_apply<T, B>, dim3(2 * g.nt_cam), dim3(T), lds, s, (const uint4*)part,                  \
            (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold,     \
            arc_touched, err)
+  static const int force_threads = getenv("ESVIO_FE_APPLY_THREADS") ? atoi(getenv("ESVIO_FE_APPLY_THREADS")) : 0;
+  const int threads = force_threads ? force_threads : (big ? 512 : 256);
+#define ESVIO_TILE_APPLY_B(B)                     \
+  if (threads >= 1024) ESVIO_TILE_APPLY(1024, B); \
+  else if (threads >= 512) ESVIO_TILE_APPLY(512, B); \
+  else ESVIO_TILE_APPLY(256, B)
   if (g.pix_bits == 9) {
-    if (big) ESVIO_TILE_APPLY(1024, 9); else ESVIO_TILE_APPLY(256, 9);
+    ESVIO_TILE_APPLY_B(9);
   } else if (g.pix_bits == 10) {
-    if (big) ESVIO_TILE_APPLY(1024, 10); else ESVIO_TILE_APPLY(256, 10);
+    ESVIO_TILE_APPLY_B(10);
   } else {
-    if (big) ESVIO_TILE_APPLY(1024, 11); else ESVIO_TILE_APPLY(256, 11);
+    ESVIO_TILE_APPLY_B(11);
   }
+#undef ESVIO_TILE_APPLY_B
 #undef ESVIO_TILE_APPLY
 }
 

@@ -129,3 +129,19 @@ def test_host_ransac_with_helper_threads_is_bit_identical(oracle, threads):
         if trial % 4 == 0:
             cnt_o, st_o, _ = oracle.find_fundamental(p1, p2, 1.0, 0.99)
             assert cnt_o == cnt_t and np.array_equal(st_o, st_t), (trial, n)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/esvio_fe.h is the drop-in boundary: it must compile as C99 (no C++ / HIP / torch types)
+    and a C translation unit must link against the library's exports"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "esvio_fe.h"\n'
+                   'int main(void) { esvio_fe_config c; esvio_fe_tracks t; esvio_fe_motion m; (void)c; (void)t; (void)m;\n'
+                   '  return esvio_fe_kernel_count() > 0 && esvio_fe_version() != 0 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(root, "include"), str(src)])
