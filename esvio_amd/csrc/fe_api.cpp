@@ -71,7 +71,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& cs : c->cand)
-    for (void* p : {(void*)cs.xy, (void*)cs.idx, (void*)cs.cnt, (void*)cs.comp_xy, (void*)cs.comp_idx,
+    for (void* p : {(void*)cs.xy, (void*)cs.idx, (void*)cs.cnt, (void*)cs.grp, (void*)cs.comp_xy, (void*)cs.comp_idx,
                     (void*)cs.total})
       if (p) (void)hipFree(p);
   for (uint32_t* p : c->d_first)

@@ -268,7 +268,7 @@ struct esvio_fe_ctx {
   struct CandSet {
     uint32_t *xy = nullptr, *idx = nullptr, *cnt = nullptr;
     // ... and their ordered compaction into one stream (k_compact, launched right behind k_arc)
-    uint32_t *comp_xy = nullptr, *comp_idx = nullptr, *total = nullptr;
+    uint32_t *comp_xy = nullptr, *comp_idx = nullptr, *total = nullptr, *grp = nullptr;
     size_t cap = 0;
   } cand[kRightSlots];
   // per-pixel earliest candidate of a set's latest Arc* pass (ArcArgs::first_map / launch_dedup)

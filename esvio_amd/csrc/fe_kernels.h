@@ -297,9 +297,11 @@ void launch_dedup(hipStream_t s, uint32_t* cand_xy, uint32_t* cand_idx, uint32_t
                   uint32_t nblk, const uint32_t* first_map, uint32_t first_key, int W);
 
 // ordered compaction of the per-block candidate lists (parallel; one block per Arc* block)
+// grp_scratch (optional, [nblk / 64 + 1]): with more than 2048 blocks the counts are summed per 64
+// blocks first (k_compact_groups)
 void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand_idx,
                     const uint32_t* cand_cnt, uint32_t nblk, uint32_t* comp_xy, uint32_t* comp_idx,
-                    uint32_t* total);
+                    uint32_t* total, uint32_t* grp_scratch = nullptr);
 
 // ---- goodFeaturesToTrack (image front-end) ----------------------------------
 // cv::goodFeaturesToTrack(img, n, quality, minDistance, mask) with blockSize 3 / gradientSize 3 /

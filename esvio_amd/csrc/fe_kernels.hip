@@ -2217,6 +2217,81 @@ __device__ __forceinline__ bool arc_ring(const double* ring, int tstride) {
          ((newest_segment_size >= (N - KMAX)) && (newest_segment_size <= (N - KMIN)));
 }
 
+// The same ring test on RANKS.  isCorner only ever compares ring values with each other (>, >=, <
+// and minima of them), so replacing every value by the number of ring values strictly below it
+// (equal values get equal ranks) leaves every decision unchanged — and the ranks (4 or 5 bits) of a
+// whole ring fit one or two 64-bit registers, which a lane can index with a variable shift: no LDS
+// column, no LDS round trip per step of the arc walk.
+template <int N>
+struct RingRanks {
+  unsigned long long lo, hi;  // N <= 16: 4 bits each in lo; N = 20: 5 bits each, 10 per word
+  __device__ __forceinline__ int get(int i) const {
+    if (N <= 16) return (int)((lo >> (4 * i)) & 15ull);
+    return i < 10 ? (int)((lo >> (5 * i)) & 31ull) : (int)((hi >> (5 * (i - 10))) & 31ull);
+  }
+};
+
+template <int N, int KMIN, int KMAX>
+__device__ __forceinline__ bool arc_ring_ranks(const double (&v)[N]) {
+  int r[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = 0;
+#pragma unroll
+  for (int i = 1; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) {
+      r[i] += v[j] < v[i] ? 1 : 0;
+      r[j] += v[i] < v[j] ? 1 : 0;
+    }
+  RingRanks<N> rk;
+  rk.lo = 0;
+  rk.hi = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    if (N <= 16) rk.lo |= (unsigned long long)r[i] << (4 * i);
+    else if (i < 10) rk.lo |= (unsigned long long)r[i] << (5 * i);
+    else rk.hi |= (unsigned long long)r[i] << (5 * (i - 10));
+  }
+  int segment_new_min_t = r[0];
+  int arc_right_idx = 0;
+#pragma unroll
+  for (int i = 1; i < N; i++)
+    if (r[i] > segment_new_min_t) {
+      segment_new_min_t = r[i];
+      arc_right_idx = i;
+    }
+  int arc_left_idx = arc_right_idx == 0 ? N - 1 : arc_right_idx - 1;
+  arc_right_idx = arc_right_idx == N - 1 ? 0 : arc_right_idx + 1;
+  int arc_left_value = rk.get(arc_left_idx);
+  int arc_right_value = rk.get(arc_right_idx);
+  int arc_left_min_t = arc_left_value;
+  int arc_right_min_t = arc_right_value;
+  int newest_segment_size = KMIN;
+#pragma unroll
+  for (int iteration = 1; iteration < N; iteration++) {
+    const bool right = arc_right_value > arc_left_value;
+    const int val = right ? arc_right_value : arc_left_value;
+    const int mn = right ? arc_right_min_t : arc_left_min_t;
+    if (iteration < KMIN) {
+      if (mn < segment_new_min_t) segment_new_min_t = mn;
+    } else if (val >= segment_new_min_t) {
+      newest_segment_size = iteration + 1;
+      if (mn < segment_new_min_t) segment_new_min_t = mn;
+    }
+    if (right) {
+      arc_right_idx = arc_right_idx == N - 1 ? 0 : arc_right_idx + 1;
+      arc_right_value = rk.get(arc_right_idx);
+      if (arc_right_value < arc_right_min_t) arc_right_min_t = arc_right_value;
+    } else {
+      arc_left_idx = arc_left_idx == 0 ? N - 1 : arc_left_idx - 1;
+      arc_left_value = rk.get(arc_left_idx);
+      if (arc_left_value < arc_left_min_t) arc_left_min_t = arc_left_value;
+    }
+  }
+  return (newest_segment_size <= KMAX) ||
+         ((newest_segment_size >= (N - KMAX)) && (newest_segment_size <= (N - KMIN)));
+}
+
 // EventDetector::isCorner (event_detector.cc:308-544) for a whole batch, in three kernels.
 //
 // isCorner is called after the whole batch is in the SAE (feature_tracker.cpp:356-368, then :458),
@@ -2229,9 +2304,9 @@ __device__ __forceinline__ bool arc_ring(const double* ring, int tstride) {
 //   k_arc_map   a block owns kArcRegion consecutive pixels: it collects the region's flagged pairs
 //               that pass  border / TS(y,x) != TS_LK_THRESHOLD / !(L[!p] > L[p])  into an LDS list
 //               (clearing the flags for the next batch) and evaluates the small and the large ring
-//               for those with all lanes busy — the ring of a pair sits in a thread-private LDS
-//               column because the arc walk indexes it dynamically; the result is bit
-//               (pixel, polarity) of a bitmap;
+//               for those with all lanes busy, on the RANKS of the ring values packed into
+//               registers (arc_ring_ranks: no LDS column, no LDS round trip per step of the arc
+//               walk); the result is bit (pixel, polarity) of a bitmap;
 //   k_arc_ev    one lane per EVENT streams the batch in order: flag = map bit && !(et > L[p] + thr)
 //               (L is only fetched for events whose map bit is set), the blocked-mask test of
 //               Event_FeaturesToTrack (feature_tracker.cpp:25) and the ordered in-block compaction
@@ -2249,7 +2324,6 @@ __global__ __launch_bounds__(256) void k_arc_mark(const uint4* __restrict__ ev, 
 }
 
 __global__ __launch_bounds__(kArcBlock) void k_arc_map(ArcArgs a) {
-  __shared__ double ring_s[20 * kArcBlock];  // 40 KiB: [ring idx][thread]
   __shared__ uint16_t list_b[2 * kArcRegion];  // surviving pairs (2 * pixel + polarity, region-local)
   __shared__ uint32_t n_b;
   const uint32_t P = (uint32_t)a.W * (uint32_t)a.H;
@@ -2284,19 +2358,18 @@ __global__ __launch_bounds__(kArcBlock) void k_arc_map(ArcArgs a) {
   }
   __syncthreads();
   const uint32_t nb = n_b;
-  double* ring = ring_s + threadIdx.x;  // thread-private LDS column
   for (uint32_t i = threadIdx.x; i < nb; i += kArcBlock) {
     const uint32_t pair = pair0 + list_b[i], px = pair >> 1, pol = pair & 1u;
     const int y = (int)(px / (uint32_t)a.W), x = (int)(px - (uint32_t)y * (uint32_t)a.W);
     const double* S = (const double*)a.S2 + pol;
+    double v16[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-      ring[k * kArcBlock] = S[2 * ((size_t)(y + c_small[k][1]) * a.W + (x + c_small[k][0]))];
-    if (!arc_ring<16, 4, 6>(ring, kArcBlock)) continue;
+    for (int k = 0; k < 16; k++) v16[k] = S[2 * ((size_t)(y + c_small[k][1]) * a.W + (x + c_small[k][0]))];
+    if (!arc_ring_ranks<16, 4, 6>(v16)) continue;
+    double v20[20];
 #pragma unroll
-    for (int k = 0; k < 20; k++)
-      ring[k * kArcBlock] = S[2 * ((size_t)(y + c_large[k][1]) * a.W + (x + c_large[k][0]))];
-    if (arc_ring<20, 5, 8>(ring, kArcBlock)) atomicOr(&a.cmap[pair >> 5], 1u << (pair & 31));
+    for (int k = 0; k < 20; k++) v20[k] = S[2 * ((size_t)(y + c_large[k][1]) * a.W + (x + c_large[k][0]))];
+    if (arc_ring_ranks<20, 5, 8>(v20)) atomicOr(&a.cmap[pair >> 5], 1u << (pair & 31));
   }
 }
 
@@ -2619,17 +2692,37 @@ void launch_gftt_sortprep(hipStream_t s, const uint32_t* comp_xy, const uint32_t
 // k_select is the inherently sequential greedy: ONE wave, bitmap of blocked pixels + new discs in
 // LDS (seeded with Event_setMask's bitmap, so k_arc can run before that mask exists — the mask
 // test of feature_tracker.cpp:25 commutes with the corner test), 64 candidates per sub-chunk.
+// (many blocks: the counts of every 64 consecutive blocks are summed first, so that a block adds up
+// nblk/64 + 64 numbers instead of nblk)
+constexpr int kCompactGroup = 64;
+__global__ __launch_bounds__(256) void k_compact_groups(const uint32_t* __restrict__ cand_cnt, uint32_t nblk,
+                                                        uint32_t* __restrict__ grp) {
+  const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lo = gi * kCompactGroup;
+  if (lo >= nblk) return;
+  uint32_t s = 0;
+  for (uint32_t j = lo; j < min(lo + kCompactGroup, nblk); j++) s += cand_cnt[j];
+  grp[gi] = s;
+}
+
 __global__ __launch_bounds__(kArcBlock) void k_compact(const uint32_t* __restrict__ cand_xy,
                                                        const uint32_t* __restrict__ cand_idx,
                                                        const uint32_t* __restrict__ cand_cnt,
                                                        uint32_t nblk, uint32_t* __restrict__ comp_xy,
                                                        uint32_t* __restrict__ comp_idx,
-                                                       uint32_t* __restrict__ total) {
+                                                       uint32_t* __restrict__ total,
+                                                       const uint32_t* __restrict__ grp) {
   __shared__ uint32_t part[kArcBlock / 64];
   const uint32_t b = blockIdx.x;
   // exclusive prefix of the counts of all earlier blocks (every block recomputes its own)
   uint32_t s = 0;
-  for (uint32_t j = threadIdx.x; j < b; j += kArcBlock) s += cand_cnt[j];
+  if (grp) {
+    const uint32_t g = b / kCompactGroup;
+    for (uint32_t j = threadIdx.x; j < g; j += kArcBlock) s += grp[j];
+    for (uint32_t j = g * kCompactGroup + threadIdx.x; j < b; j += kArcBlock) s += cand_cnt[j];
+  } else {
+    for (uint32_t j = threadIdx.x; j < b; j += kArcBlock) s += cand_cnt[j];
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane_id() == 0) part[threadIdx.x >> 6] = s;
@@ -2646,10 +2739,15 @@ __global__ __launch_bounds__(kArcBlock) void k_compact(const uint32_t* __restric
 
 void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand_idx,
                     const uint32_t* cand_cnt, uint32_t nblk, uint32_t* comp_xy, uint32_t* comp_idx,
-                    uint32_t* total) {
+                    uint32_t* total, uint32_t* grp_scratch) {
   if (!nblk) return;
+  const bool grouped = grp_scratch && nblk > 2048;  // (below that the extra launch costs more than it saves)
+  if (grouped) {
+    const uint32_t ngrp = (nblk + kCompactGroup - 1) / kCompactGroup;
+    launch_k(k_compact_groups, dim3((ngrp + 255) / 256), dim3(256), 0, s, cand_cnt, nblk, grp_scratch);
+  }
   launch_k(k_compact, dim3(nblk), dim3(kArcBlock), 0, s, cand_xy, cand_idx, cand_cnt, nblk,
-                     comp_xy, comp_idx, total);
+                     comp_xy, comp_idx, total, (const uint32_t*)(grouped ? grp_scratch : nullptr));
 }
 
 // OR the bits of columns [xa,xb] that fall into word (w0+k) of row yy; rows/words outside the

@@ -56,13 +56,14 @@ int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n) {
   if (n <= s.cap) return 0;
   size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
   cap = (cap + kArcBlock - 1) / kArcBlock * kArcBlock;
-  void* ptrs[] = {s.xy, s.idx, s.cnt, s.comp_xy, s.comp_idx, s.total};
+  void* ptrs[] = {s.xy, s.idx, s.cnt, s.comp_xy, s.comp_idx, s.total, s.grp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   s = esvio_fe_ctx::CandSet();
   if (int rc = dev_alloc(c, &s.xy, cap)) return rc;
   if (int rc = dev_alloc(c, &s.idx, cap)) return rc;
   if (int rc = dev_alloc(c, &s.cnt, cap / kArcBlock)) return rc;
+  if (int rc = dev_alloc(c, &s.grp, cap / kArcBlock / 64 + 2)) return rc;
   if (int rc = dev_alloc(c, &s.comp_xy, cap)) return rc;
   if (int rc = dev_alloc(c, &s.comp_idx, cap)) return rc;
   if (int rc = dev_alloc(c, &s.total, 1)) return rc;
@@ -667,7 +668,7 @@ void run_compact(esvio_fe_ctx* c, uint32_t n_events, int set) {
   const uint32_t nblk = (n_events + kArcBlock - 1) / kArcBlock;
   const esvio_fe_ctx::CandSet& cs = c->cand[set];
   ScopedKernel k(c, K_COMPACT, 0);
-  launch_compact(cur_stream(c), cs.xy, cs.idx, cs.cnt, nblk, cs.comp_xy, cs.comp_idx, cs.total);
+  launch_compact(cur_stream(c), cs.xy, cs.idx, cs.cnt, nblk, cs.comp_xy, cs.comp_idx, cs.total, cs.grp);
 }
 
 // the sequential greedy (Event_FeaturesToTrack) over the compacted candidates of set `set`;
