@@ -408,6 +408,43 @@ def test_sae_other_sensor_sizes(oracle, W, H, why):
     ft.close()
 
 
+@pytest.mark.parametrize("path", ["tiled", "sort_per_event"])
+def test_sae_bucket_sizes_around_chunk_and_turn_boundaries(oracle, path, monkeypatch):
+    """the tiled apply takes a bucket's events in chunks of 64 and turns of 256 (one wave per turn,
+    ticket-ordered): buckets of exactly 0, 1, 63..65, 255..257, 511..513, 1023..1025, 2047..2049 and
+    4096 + 1 events, packed onto a handful of pixels of one tile so that nearly every event has its
+    predecessors in an earlier chunk / turn / wave; ties, polarity flips and backward stamps inside;
+    two batches so the carried-in planes matter"""
+    for k, v in SAE_PATHS[path].items():
+        monkeypatch.setenv(k, v)
+    W, H = 346, 260
+    sizes = [0, 1, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4097]
+    rng = np.random.default_rng(23)
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    for batch in range(2):
+        xs, ys, ts, ps = [], [], [], []
+        for i, n in enumerate(sizes):
+            # tile i (32x16 tiles at this size: 11 tiles per row), 1-5 pixels inside it
+            tx, ty = (i % 10) * 32, (i // 10) * 16 + 32 * batch
+            npx = 1 + i % 5
+            xs.append(tx + rng.integers(0, npx, n))
+            ys.append(np.full(n, ty + 3))
+            ts.append(8_000_000 + 50_000 * batch + np.cumsum(rng.choice([0, 0, 400, 11_000, -900], n)))
+            ps.append((np.cumsum(rng.random(n) < 0.2) + i) % 2)
+        x, y, t, p = (np.concatenate(v) for v in (xs, ys, ts, ps))
+        t = np.maximum(t, 1)
+        # interleave the buckets (each bucket's own order stays as generated)
+        order = np.argsort(np.concatenate([np.arange(len(v)) * (1.0 + 1e-3 * k) for k, v in enumerate(xs)]),
+                           kind="stable")
+        ev = make_events(x[order], y[order], t[order], p[order])
+        for cam, evc in ((0, ev), (1, ev[::-1].copy())):
+            (ft.detector.createSAE_left if cam == 0 else ft.detector.createSAE_right)(evc)
+            det.create_sae(cam, evc)
+            _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+    ft.close()
+
+
 def test_selection_large_radius(oracle):
     """min_dist 40 (> 31: two disc rows per lane in k_select) and a tiny max_cnt"""
     W, H = 640, 480
