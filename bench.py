@@ -117,6 +117,12 @@ def parse():
                     help="times the timed --steps region is run over the continued stream (the first "
                          "is the headline ms_per_step; all are reported); 0 = 5 up to 30 steps, else 3")
     ap.add_argument("--max-cnt", type=int, default=300)
+    ap.add_argument("--torch-exchange", action="store_true",
+                    help="merge the tracked corners through torch.distributed (TrackExchange) also over "
+                         "RCCL, instead of the library's own communicator (A/B)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with one rank: still create the process group and run the track exchange "
+                         "(all_gather over RCCL with world size 1) — exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--no-host-pass", action="store_true",
                     help="skip the extra pass with the events in host memory (host_resident_events)")
     ap.add_argument("--dist-backend", default="nccl",
@@ -210,6 +216,10 @@ def cpu_all_cores(batches, args, W, H):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: whatever libraries print through C stdio on fd 1
+    # (RCCL's version banner, for one) goes to stderr instead
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -223,9 +233,11 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist  # (the collective path runs, possibly with a single rank)
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", dev_index))
@@ -245,7 +257,7 @@ def main():
     n_prof = 0 if args.no_profile_pass else min(args.steps, 30)
     # ---- synthetic stream (per rank: an independent rig, different seed), resident in HBM
     cam_split = args.split == "camera" and world > 1
-    time_split = args.split == "time" and world > 1
+    time_split = args.split == "time" and multi
     if cam_split and world != 2:
         raise SystemExit("--split camera needs exactly 2 ranks")
     one_rig = cam_split or time_split
@@ -275,8 +287,12 @@ def main():
     class Runner:
         """one tracker + the schedule it is driven with"""
 
-        def __init__(self, pipeline, lazy, batches, exch=None, rig=None, tsl=None):
+        def __init__(self, pipeline, lazy, batches, exch=None, rig=None, tsl=None, comm=None):
             self.ft = FE.FeatureTracker(cfg)
+            self.comm = comm is not None
+            if comm is not None:
+                self.ft.comm_init(comm, rank, world)
+                self.ft.set_auto_exchange(True)  # every published frame's records, enqueued under the next call's wait
             self.pipeline, self.lazy, self.batches, self.exch, self.rig, self.tsl = pipeline, lazy, batches, exch, rig, tsl
             self.announced = 0
             if lazy:
@@ -308,16 +324,30 @@ def main():
                     L2, R2, _, _, t2 = self.arg(k)
                     ft.set_next_batch(t2, L2, R2, pub_flags[k])
             ft.trackEvent(t_last, L, R, pub, copy=False)
-            if pub and self.exch is not None and exchange:  # merge all rigs' tracked corners (async)
-                self.exch.submit_tracker(ft, async_op=True)
+            if pub and exchange:  # merge all rigs' tracked corners (asynchronous)
+                if self.comm:
+                    pass  # (esvio_fe_set_auto_exchange: the library does it)
+                elif self.exch is not None:
+                    self.exch.submit_tracker(ft, async_op=True)
             return nl + nr
 
+    # The merge of every rank's tracked corners (north-star hand-off).  Over RCCL it runs inside the
+    # library on the handle's own communicator (esvio_fe_comm_init / esvio_fe_exchange_begin: pack,
+    # upload, ncclAllGather, download on a side stream; ~20 us of host time per published frame); the
+    # torch.distributed mirror (TrackExchange, ~100 us of Python / c10d per published frame) serves
+    # the gloo dry runs.
+    lib_exchange = multi and not time_split and not cam_split and args.dist_backend == "nccl" and not args.torch_exchange
     exch = (TrackExchange(cfg.max_cnt, world, device=xdev, dist=dist,
                           stream=torch.cuda.Stream() if xdev == "cuda" else None)
-            if world > 1 and not time_split else None)
+            if multi and not time_split and not lib_exchange else None)
+    comm_id = None
+    if lib_exchange:
+        box = [FE.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm_id = box[0]
     pipeline = not args.no_pipeline and not one_rig
     lazy = pipeline and not args.no_lazy
-    main_run = Runner(pipeline, lazy, dev_batches, exch=exch)
+    main_run = Runner(pipeline, lazy, dev_batches, exch=exch, comm=comm_id)
     ft = main_run.ft
     if cam_split:
         main_run.rig = CameraSplitRig(ft, rank, dist, device=xdev)
@@ -325,7 +355,7 @@ def main():
         main_run.tsl = TimeSlicedSae(ft, rank, world, dist, device=xdev)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -345,12 +375,14 @@ def main():
             ft.finish(copy=False)  # the last published frame's deferred right-camera entries
         if exch is not None:
             exch.wait()
+        if comm_id is not None and any(pub_flags[lo:lo + args.steps]):
+            ft.exchange_end(want=False)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         tot = torch.tensor([float(n_events), elapsed], dtype=torch.float64, device=xdev)
-        if world > 1:
+        if multi:
             dist.all_reduce(tot[0:1], op=dist.ReduceOp.SUM)
             dist.all_reduce(tot[1:2], op=dist.ReduceOp.MAX)
         passes.append((float(tot[0].item()), float(tot[1].item()), n_events))
@@ -515,6 +547,8 @@ def main():
                 "lazy_new_corner_stereo": bool(lazy),
                 "host_threads": int(max(1, args.host_threads)),
                 "batches_announced_ahead": int(args.ahead) if pipeline else 0,
+                "track_exchange": ("library (ncclAllGather on the handle's communicator)" if comm_id is not None else
+                                   "torch.distributed all_gather_into_tensor" if exch is not None else "none"),
             },
             # the timed --steps region repeated over the continued stream (pass 0 = ms_per_step above)
             "repeats": dict(passes=repeats, ms_per_step=[round(p[1] / args.steps * 1e3, 4) for p in passes],
@@ -527,9 +561,9 @@ def main():
             "kernels": kernels,
             "kernels_replay_schedule": kernels_pipe,
         }
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ft.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

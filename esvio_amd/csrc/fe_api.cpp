@@ -2,6 +2,60 @@
 // layer over fe_stages.cpp / fe_track.cpp / fe_image.cpp.
 #include "fe_internal.h"
 
+// RCCL is looked up at run time (dlopen librccl.so), so the library does not depend on it unless the
+// exchange entry points are used.
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/,
+                                 hipStream_t);
+struct NcclId {
+  char internal[128];  // ncclUniqueId
+};
+typedef int (*nccl_get_id_fn)(NcclId*);
+typedef int (*nccl_init_rank_fn)(void** /*ncclComm_t* */, int, NcclId, int);
+typedef int (*nccl_destroy_fn)(void*);
+// an RCCL that is already in the process (e.g. the one a PyTorch process group uses) is preferred
+// to loading a second one
+void* rccl_lib() {
+  static void* lib = []() -> void* {
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names)
+      if (void* l = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL)) return l;
+    for (const char* n : names)
+      if (void* l = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) return l;
+    return dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  }();
+  return lib;
+}
+template <class F>
+F rccl_sym(const char* name) {
+  void* l = rccl_lib();
+  return l ? (F)dlsym(l, name) : nullptr;
+}
+nccl_allgather_fn rccl_all_gather() {
+  static nccl_allgather_fn fn = rccl_sym<nccl_allgather_fn>("ncclAllGather");
+  return fn;
+}
+int exchange_buffers(esvio_fe_ctx* c, int world) {
+  const size_t cnt = (size_t)2 * std::max(c->cfg.max_cnt, 1) * 8;
+  if (!c->x_send) {
+    if (int rc = dev_alloc(c, &c->x_send, cnt)) return rc;
+    HIPCHK(c, hipHostMalloc((void**)&c->x_pin, cnt * sizeof(float), hipHostMallocDefault));
+  }
+  if ((size_t)world * cnt > c->x_recv_cap) {
+    if (c->x_recv) (void)hipFree(c->x_recv);
+    if (c->x_pin_recv) (void)hipHostFree(c->x_pin_recv);
+    c->x_recv = nullptr;
+    c->x_pin_recv = nullptr;
+    c->x_recv_cap = 0;
+    if (int rc = dev_alloc(c, &c->x_recv, (size_t)world * cnt)) return rc;
+    HIPCHK(c, hipHostMalloc((void**)&c->x_pin_recv, (size_t)world * cnt * sizeof(float), hipHostMallocDefault));
+    c->x_recv_cap = (size_t)world * cnt;
+  }
+  return 0;
+}
+}  // namespace
+
+
 // ==================================================================================== C ABI
 extern "C" {
 
@@ -62,7 +116,13 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->tr_detect ? (double)c->tr_cand / c->tr_detect : 0.0,
             c->tr_detect ? (double)c->tr_new / c->tr_detect : 0.0);
   }
+  if (c->x_pending) (void)hipEventSynchronize(c->x_done);
+  if (c->x_comm)
+    if (nccl_destroy_fn destroy = rccl_sym<nccl_destroy_fn>("ncclCommDestroy")) (void)destroy(c->x_comm);
+  if (c->x_stream) (void)hipStreamDestroy(c->x_stream);
+  if (c->x_done) (void)hipEventDestroy(c->x_done);
   if (c->x_pin) (void)hipHostFree(c->x_pin);
+  if (c->x_pin_recv) (void)hipHostFree(c->x_pin_recv);
   void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_tile, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx,
@@ -813,39 +873,13 @@ int esvio_fe_pack_track_records(esvio_fe_handle c, float* out, int32_t* n_rows) 
 }
 
 // ---- RCCL hand-off (north-star: "a single RCCL all-gather over xGMI to merge tracked corners") ----
-// RCCL is looked up at run time (dlopen librccl.so), so the library does not depend on it unless
-// this entry point is used.
-namespace {
-typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/,
-                                 hipStream_t);
-nccl_allgather_fn rccl_all_gather() {
-  static nccl_allgather_fn fn = []() -> nccl_allgather_fn {
-    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    return lib ? (nccl_allgather_fn)dlsym(lib, "ncclAllGather") : nullptr;
-  }();
-  return fn;
-}
-}  // namespace
-
 int esvio_fe_exchange_tracks(esvio_fe_handle c, void* nccl_comm, int world, float* gathered) {
   if (!c || !nccl_comm || world < 1 || !gathered) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   nccl_allgather_fn all_gather = rccl_all_gather();
   if (!all_gather) return fail(c, ESVIO_FE_ENOTIMPL, "librccl.so not found (dlopen): %s", dlerror());
-  const size_t rows = (size_t)2 * std::max(c->cfg.max_cnt, 1), cnt = rows * 8;
-  if (!c->x_send) {
-    if (int rc = dev_alloc(c, &c->x_send, cnt)) return rc;
-    HIPCHK(c, hipHostMalloc((void**)&c->x_pin, cnt * sizeof(float), hipHostMallocDefault));
-  }
-  if ((size_t)world * cnt > c->x_recv_cap) {
-    if (c->x_recv) (void)hipFree(c->x_recv);
-    c->x_recv = nullptr;
-    c->x_recv_cap = 0;
-    if (int rc = dev_alloc(c, &c->x_recv, (size_t)world * cnt)) return rc;
-    c->x_recv_cap = (size_t)world * cnt;
-  }
+  const size_t cnt = (size_t)2 * std::max(c->cfg.max_cnt, 1) * 8;
+  if (int rc = exchange_buffers(c, world)) return rc;
   if (int rc = esvio_fe_pack_track_records(c, c->x_pin, nullptr)) return rc;
   hipStream_t st = c->stream;
   HIPCHK(c, hipMemcpyAsync(c->x_send, c->x_pin, cnt * 4, hipMemcpyHostToDevice, st));
@@ -853,6 +887,92 @@ int esvio_fe_exchange_tracks(esvio_fe_handle c, void* nccl_comm, int world, floa
   if (nrc != 0) return fail(c, ESVIO_FE_EHIP, "ncclAllGather failed: %d", nrc);
   HIPCHK(c, hipMemcpyAsync(gathered, c->x_recv, (size_t)world * cnt * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  return 0;
+}
+
+int esvio_fe_comm_unique_id(uint8_t id[128]) {
+  if (!id) return ESVIO_FE_EINVAL;
+  nccl_get_id_fn get_id = rccl_sym<nccl_get_id_fn>("ncclGetUniqueId");
+  if (!get_id) return ESVIO_FE_ENOTIMPL;
+  NcclId u;
+  if (get_id(&u) != 0) return ESVIO_FE_EHIP;
+  std::memcpy(id, u.internal, 128);
+  return 0;
+}
+
+int esvio_fe_comm_init(esvio_fe_handle c, const uint8_t id[128], int rank, int world) {
+  if (!c || !id || world < 1 || rank < 0 || rank >= world) return ESVIO_FE_EINVAL;
+  if (c->x_comm) return fail(c, ESVIO_FE_EINVAL, "the handle has a communicator already");
+  HIPCHK(c, hipSetDevice(c->dev));
+  nccl_init_rank_fn init_rank = rccl_sym<nccl_init_rank_fn>("ncclCommInitRank");
+  if (!init_rank || !rccl_all_gather()) return fail(c, ESVIO_FE_ENOTIMPL, "librccl.so not found (dlopen)");
+  NcclId u;
+  std::memcpy(u.internal, id, 128);
+  void* comm = nullptr;
+  const int nrc = init_rank(&comm, world, u, rank);
+  if (nrc != 0 || !comm) return fail(c, ESVIO_FE_EHIP, "ncclCommInitRank failed: %d", nrc);
+  c->x_comm = comm;
+  c->x_world = world;
+  if (!c->x_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->x_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->x_done, hipEventDisableTiming));
+  }
+  return exchange_buffers(c, world);
+}
+
+}  // extern "C"
+namespace esvio {
+namespace fe {
+int exchange_pack(esvio_fe_ctx* c) {
+  // (the previous exchange has to be through with the pinned areas)
+  if (c->x_pending) HIPCHK(c, hipEventSynchronize(c->x_done));
+  c->x_pending = false;
+  if (int rc = esvio_fe_pack_track_records(c, c->x_pin, nullptr)) return rc;
+  c->x_deferred = true;
+  return 0;
+}
+int exchange_flush(esvio_fe_ctx* c) {
+  if (!c->x_deferred) return 0;
+  c->x_deferred = false;
+  const size_t cnt = (size_t)2 * std::max(c->cfg.max_cnt, 1) * 8;
+  HIPCHK(c, hipMemcpyAsync(c->x_send, c->x_pin, cnt * 4, hipMemcpyHostToDevice, c->x_stream));
+  const int nrc = rccl_all_gather()(c->x_send, c->x_recv, cnt, 7 /* ncclFloat32 */, c->x_comm, c->x_stream);
+  if (nrc != 0) return fail(c, ESVIO_FE_EHIP, "ncclAllGather failed: %d", nrc);
+  HIPCHK(c, hipMemcpyAsync(c->x_pin_recv, c->x_recv, (size_t)c->x_world * cnt * 4, hipMemcpyDeviceToHost,
+                           c->x_stream));
+  HIPCHK(c, hipEventRecord(c->x_done, c->x_stream));
+  c->x_pending = true;
+  return 0;
+}
+}  // namespace fe
+}  // namespace esvio
+extern "C" {
+
+int esvio_fe_exchange_begin(esvio_fe_handle c) {
+  if (!c) return ESVIO_FE_EINVAL;
+  if (!c->x_comm) return fail(c, ESVIO_FE_EINVAL, "esvio_fe_comm_init has not been called");
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = exchange_flush(c)) return rc;  // (an automatic one that is still waiting goes first)
+  if (int rc = exchange_pack(c)) return rc;
+  return exchange_flush(c);
+}
+
+int esvio_fe_set_auto_exchange(esvio_fe_handle c, int on) {
+  if (!c) return ESVIO_FE_EINVAL;
+  if (on && !c->x_comm) return fail(c, ESVIO_FE_EINVAL, "esvio_fe_comm_init has not been called");
+  c->x_auto = on != 0;
+  return 0;
+}
+
+int esvio_fe_exchange_end(esvio_fe_handle c, float* gathered) {
+  if (!c) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = exchange_flush(c)) return rc;
+  if (!c->x_pending) return fail(c, ESVIO_FE_EINVAL, "no exchange in flight");
+  HIPCHK(c, hipEventSynchronize(c->x_done));
+  c->x_pending = false;
+  if (gathered)
+    std::memcpy(gathered, c->x_pin_recv, (size_t)c->x_world * 2 * std::max(c->cfg.max_cnt, 1) * 8 * sizeof(float));
   return 0;
 }
 

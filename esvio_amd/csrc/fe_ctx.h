@@ -171,8 +171,17 @@ struct esvio_fe_ctx {
   size_t slice_stage_doubles = 0;
   bool ext_sae_pending = false;
   // esvio_fe_exchange_tracks: send / receive buffers of the all-gather and the pinned pack area
-  float *x_send = nullptr, *x_recv = nullptr, *x_pin = nullptr;
+  float *x_send = nullptr, *x_recv = nullptr, *x_pin = nullptr, *x_pin_recv = nullptr;
   size_t x_recv_cap = 0;
+  // esvio_fe_comm_init: the handle's own RCCL communicator, the side stream the asynchronous
+  // exchange runs on and the event that marks its end
+  void* x_comm = nullptr;
+  int x_world = 0;
+  hipStream_t x_stream = nullptr;
+  hipEvent_t x_done = nullptr;
+  bool x_pending = false;
+  bool x_auto = false;      // esvio_fe_set_auto_exchange: every published frame's records are exchanged
+  bool x_deferred = false;  // packed records waiting to be enqueued (by the next call, under its device wait)
   // ---- next-batch prefetch (esvio_fe_set_next_batch)
   std::deque<Batch> announced;     // announced, nothing enqueued yet (<= kPrefetchDepth)
   std::deque<Inflight> inflight;   // SAE update / images / pyramids enqueued on the prefetch stream

@@ -104,6 +104,13 @@ int track_event_impl(esvio_fe_ctx* c, double cur_time, const esvio_fe_event* lef
                      const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME,
                      const esvio_fe_motion* motion = nullptr);
 
+// ---------------------------------------------------------------- fe_api.cpp (track exchange)
+// pack the current frame's PointCloud records into the pinned send area (waits for the previous
+// exchange to be through with it) and mark them "to be enqueued"; enqueue what is marked: upload +
+// ncclAllGather + download on the exchange stream (no-op when nothing is marked)
+int exchange_pack(esvio_fe_ctx* c);
+int exchange_flush(esvio_fe_ctx* c);
+
 // ---------------------------------------------------------------- fe_image.cpp
 void euclid_halfwidths(double md, int8_t* hw /*[kMaxDiscR+1]*/, int* radius);
 int gftt_run(esvio_fe_ctx* c, const PyrDesc& d, int max_corners, double quality, double min_distance,

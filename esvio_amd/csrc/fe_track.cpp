@@ -460,6 +460,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       if (!defer_late)
         if (int rc = early_work()) return rc;
       lap(1);
+      if (int rc = exchange_flush(c)) return rc;  // (host time that would be spent waiting)
       HIPCHK(c, sync_event(c->ev_spec_done));
       lap(2);
       const size_t stM = ((size_t)std::max(M, 1) + 63) / 64 * 64;
@@ -477,6 +478,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       if (!defer_late)
         if (int rc = early_work()) return rc;
       lap(1);
+      if (int rc = exchange_flush(c)) return rc;
       HIPCHK(c, sync_event(c->ev_chain_done));
       lap(2);
       const size_t Mx = (size_t)std::max(M, 1), stM = (Mx + 63) / 64 * 64;
@@ -534,6 +536,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                          ESVIO_FE_LK_USE_INITIAL_FLOW);
       run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
       if (int rc = early_work()) return rc;
+      if (int rc = exchange_flush(c)) return rc;
       lap(1);
       HIPCHK(c, sync_main(c));
       lap(2);
@@ -749,6 +752,12 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->phase_count[PUB_THIS_FRAME ? 1 : 0]++;
   c->tr_surv += (uint64_t)n_surv;
   if (c->prof_on) resolve_profile(c);
+  // esvio_fe_set_auto_exchange: what an earlier published frame left to enqueue goes out now at the
+  // latest (normally it went out above, where this call waited for its temporal LK anyway); this
+  // frame's records, if it publishes, are packed now and enqueued by the next call
+  if (int rc = exchange_flush(c)) return rc;
+  if (c->x_auto && c->x_comm && PUB_THIS_FRAME)
+    if (int rc = exchange_pack(c)) return rc;
   return 0;
 }
 

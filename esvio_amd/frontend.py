@@ -88,6 +88,8 @@ ABI_SYMBOLS = [
     "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
     "esvio_fe_sae_plane_doubles", "esvio_fe_sae_slice_last", "esvio_fe_sae_slice_apply",
     "esvio_fe_sae_slice_commit", "esvio_fe_device_memory", "esvio_fe_exchange_tracks",
+    "esvio_fe_comm_unique_id", "esvio_fe_comm_init", "esvio_fe_exchange_begin", "esvio_fe_exchange_end",
+    "esvio_fe_set_auto_exchange",
 ]
 
 _lib = None
@@ -153,6 +155,11 @@ def load_library(build_if_missing=True):
     L.esvio_fe_stream.argtypes = [vp]
     L.esvio_fe_device_memory.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
     L.esvio_fe_exchange_tracks.argtypes = [vp, vp, i, vp]
+    L.esvio_fe_comm_unique_id.argtypes = [vp]
+    L.esvio_fe_comm_init.argtypes = [vp, vp, i, i]
+    L.esvio_fe_exchange_begin.argtypes = [vp]
+    L.esvio_fe_exchange_end.argtypes = [vp, vp]
+    L.esvio_fe_set_auto_exchange.argtypes = [vp, i]
     L.esvio_fe_sae_plane_doubles.restype = sz
     L.esvio_fe_sae_plane_doubles.argtypes = [vp]
     L.esvio_fe_sae_slice_last.argtypes = [vp, vp, sz, vp, sz, i, vp, i]
@@ -416,6 +423,25 @@ class FeatureTracker:
     def reset(self):
         self._hd.check(self._hd.L.esvio_fe_reset(self._hd.h))
 
+    # ---- the handle's own RCCL communicator: asynchronous exchange of the track records
+    def comm_init(self, unique_id, rank, world):
+        """unique_id: the 128 bytes of comm_unique_id() made on rank 0"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._hd.check(self._hd.L.esvio_fe_comm_init(self._hd.h, buf, int(rank), int(world)))
+        self._x_world = int(world)
+
+    def set_auto_exchange(self, on=True):
+        self._hd.check(self._hd.L.esvio_fe_set_auto_exchange(self._hd.h, int(bool(on))))
+
+    def exchange_begin(self):
+        self._hd.check(self._hd.L.esvio_fe_exchange_begin(self._hd.h))
+
+    def exchange_end(self, want=True):
+        """wait for the latest exchange_begin; -> (world, 2*max_cnt, 8) float32, or None"""
+        out = np.empty((self._x_world, 2 * self.cfg.max_cnt, 8), np.float32) if want else None
+        self._hd.check(self._hd.L.esvio_fe_exchange_end(self._hd.h, _p(out)))
+        return out
+
     def device_memory(self):
         """(free, total) bytes of the handle's device"""
         f, t = C.c_size_t(0), C.c_size_t(0)
@@ -544,6 +570,15 @@ class FeatureTracker:
     @property
     def stream(self):
         return self._hd.L.esvio_fe_stream(self._hd.h)
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0); 128 bytes to hand to every rank's comm_init"""
+    buf = (C.c_uint8 * 128)()
+    rc = load_library().esvio_fe_comm_unique_id(buf)
+    if rc:
+        raise FrontendError("esvio_fe_comm_unique_id rc=%d (librccl.so not found?)" % rc)
+    return bytes(buf)
 
 
 def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99, threads=1):

@@ -254,6 +254,25 @@ int esvio_fe_pack_track_records(esvio_fe_handle h, float* out, int32_t* n_rows);
  * (ESVIO_FE_ENOTIMPL if librccl.so cannot be found).  Replaces: the ROS topic hop of
  * stereo_event_tracker_node.cpp:340 when several GPUs feed one estimator. */
 int esvio_fe_exchange_tracks(esvio_fe_handle h, void* nccl_comm, int world, float* gathered);
+/* The same exchange without a stop on the caller's thread, over a communicator the handle owns:
+ * rank 0 makes an id (esvio_fe_comm_unique_id = ncclGetUniqueId) and passes it to the other ranks by
+ * whatever side channel the launcher has; every rank calls esvio_fe_comm_init once
+ * (ncclCommInitRank).  esvio_fe_exchange_begin packs the current frame's records and enqueues
+ * upload + ncclAllGather + download on a stream of its own — it returns at once, the next frames'
+ * kernels run beside it; esvio_fe_exchange_end waits for the latest begun exchange and copies the
+ * world x 2*max_cnt x 8 floats out (gathered may be NULL: wait only).  One exchange in flight:
+ * begin waits for the previous one. */
+int esvio_fe_comm_unique_id(uint8_t id[128]);
+int esvio_fe_comm_init(esvio_fe_handle h, const uint8_t id[128], int rank, int world);
+int esvio_fe_exchange_begin(esvio_fe_handle h);
+int esvio_fe_exchange_end(esvio_fe_handle h, float* gathered);
+/* With `on`, every esvio_fe_track_event call with pub_this_frame != 0 exchanges its records by itself:
+ * they are packed at the end of that call and the upload / ncclAllGather / download are enqueued by
+ * the NEXT call at the point where it waits for its temporal LK anyway (or at its end), so the
+ * exchange costs the calling thread no time of its own.  esvio_fe_exchange_end returns the latest
+ * one (enqueuing it first if the next call has not come yet).  Every rank must publish the same
+ * frames (the node's frequency control reads timestamps only). */
+int esvio_fe_set_auto_exchange(esvio_fe_handle h, int on);
 
 /* Throughput option: with `on`, a published esvio_fe_track_event call returns without waiting for
  * the stereo LK of the corners it has just detected.  Everything else in its results is complete

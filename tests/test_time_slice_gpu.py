@@ -126,3 +126,15 @@ def test_time_sliced_stream_two_ranks(oracle):
         for k in KEYS:
             assert np.array_equal(res[0][b][1][k], ref[b][1][k]), (b, k)
     assert len(ref[-1][1]["ids"]) > 100
+
+
+def test_device_plane_sets_and_rccl_world1():
+    """DEVICE-space plane sets (torch CUDA tensors) through the three entry points, and
+    TimeSlicedSae / TrackExchange over RCCL with a process group of one rank, in a fresh interpreter
+    (torch initialises the GPU before the library does)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "slice_device_worker.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
