@@ -179,57 +179,120 @@ struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-
   int uniform(int lo, int hi) { return lo == hi ? lo : (int)(next() % (unsigned)(hi - lo) + lo); }
 };
 
-// Two orthonormal vectors spanning the null space of the 7x9 epipolar system: Householder QR of
-// A^T (9x7); the last two columns of Q.  [OpenCV takes rows 7,8 of V^T from SVDecomp; for a
-// rank-7 system that is the same plane, so the cubic below has the same F solutions.]  The
-// operation order matches the oracle's restatement exactly, so both produce identical bits (two
-// different null-space bases differ by rounding and can flip a knife-edge inlier decision).
+// Two orthonormal vectors spanning the null space of the 7x9 epipolar system, obtained the way
+// run7Point obtains them: SVDecomp(A, W, U, Vt, MODIFY_A + FULL_UV) and rows 7, 8 of Vt.  For a
+// matrix with fewer rows than columns cv::SVD runs its one-sided Jacobi sweep on the 7 rows of A
+// themselves (length 9): cyclic Hestenes rotations (pairs (0,1),(0,2)..(5,6), at most 30 sweeps, a
+// pair skipped when |<ri,rj>| <= 10 eps sqrt(|ri|^2 |rj|^2), squared norms carried along), rows
+// sorted by norm (selection sort, largest first) and normalised.  Rows 7 and 8 are not determined by
+// the data; OpenCV fills each with +-1/9 from cv::RNG(0x12345678) (bit 8 of the generator's 32-bit
+// outputs), projects the rows above out of it twice (rescaling by the L1 norm after every
+// projection) and normalises — restated here step for step [OpenCV 4.2 core/src/lapack.cpp,
+// JacobiSVDImpl_<double>: minval = DBL_MIN, eps = 10 DBL_EPSILON; not in /root/reference].  Every
+// sum runs in index order in double, mul and add stay separate (-ffp-contract=off).
 //
-// Same arithmetic as the straightforward triple loop (per matrix entry: the same products added in
-// the same order), arranged for the vector units: the reflector is applied to all columns of R / all
-// rows of Q at once (Q is kept transposed), and the columns of R left of the current one — which
-// nothing reads any more — are not updated.
+// Which basis of the null plane is used matters only through rounding (the three F solutions are
+// those of the same cubic), but that is enough to move a point that lies within float rounding of
+// the 1 px threshold across it, so the basis is OpenCV's and not a cheaper one.
 ESVIO_SIMD_CLONES
 void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
-  constexpr int M = 9, N = 7, NP = 8, MP = 12;
-  alignas(32) double R[M][NP], QT[M][MP];  // QT[i][j] = Q[j][i]
-  for (int i = 0; i < M; i++) {
-    for (int j = 0; j < N; j++) R[i][j] = A[j][i];
-    R[i][N] = 0;
-    for (int j = 0; j < MP; j++) QT[i][j] = (i == j);
+  constexpr int M = 9, N = 7, N1 = 9, MP = 12;
+  constexpr double kMin = DBL_MIN, kEps = DBL_EPSILON * 10;
+  alignas(32) double R[N1][MP];
+  double W[N];
+  for (int i = 0; i < N1; i++)
+    for (int k = 0; k < MP; k++) R[i][k] = (i < N && k < M) ? A[i][k] : 0.0;
+  for (int i = 0; i < N; i++) {
+    double sd = 0;
+    for (int k = 0; k < M; k++) sd += R[i][k] * R[i][k];
+    W[i] = sd;
   }
-  for (int k = 0; k < N; k++) {
-    double norm = 0;
-    for (int i = k; i < M; i++) norm += R[i][k] * R[i][k];
-    norm = std::sqrt(norm);
-    if (norm == 0) continue;
-    const double alpha = R[k][k] > 0 ? -norm : norm;
-    double v[M] = {0};
-    for (int i = k; i < M; i++) v[i] = R[i][k];
-    v[k] -= alpha;
-    double vn = 0;
-    for (int i = k; i < M; i++) vn += v[i] * v[i];
-    if (vn == 0) continue;
-    if (k + 1 < N) {  // R <- H R, columns right of k (column j is only ever read for step j)
-      alignas(32) double t[NP] = {0};
-      for (int i = k; i < M; i++)
-        for (int j = 0; j < NP; j++) t[j] += v[i] * R[i][j];
-      for (int j = 0; j < NP; j++) t[j] = 2 * t[j] / vn;
-      for (int i = k; i < M; i++)
-        for (int j = 0; j < NP; j++) R[i][j] -= t[j] * v[i];
-    }
-    {  // Q <- Q H
-      alignas(32) double t[MP] = {0};
-      for (int i = k; i < M; i++)
-        for (int j = 0; j < MP; j++) t[j] += QT[i][j] * v[i];
-      for (int j = 0; j < MP; j++) t[j] = 2 * t[j] / vn;
-      for (int i = k; i < M; i++)
-        for (int j = 0; j < MP; j++) QT[i][j] -= t[j] * v[i];
+  for (int sweep = 0; sweep < 30; sweep++) {  // max(m, 30)
+    bool changed = false;
+    for (int i = 0; i < N - 1; i++)
+      for (int j = i + 1; j < N; j++) {
+        double* __restrict ri = R[i];
+        double* __restrict rj = R[j];
+        double a = W[i], b = W[j], p = 0;
+        for (int k = 0; k < M; k++) p += ri[k] * rj[k];
+        if (std::fabs(p) <= kEps * std::sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = hypot(p, beta);
+        double c, s;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = std::sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = std::sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        alignas(32) double t0[MP], t1[MP];
+        for (int k = 0; k < MP; k++) {  // (the padding lanes stay 0)
+          t0[k] = c * ri[k] + s * rj[k];
+          t1[k] = -s * ri[k] + c * rj[k];
+        }
+        a = b = 0;
+        for (int k = 0; k < M; k++) {
+          a += t0[k] * t0[k];
+          b += t1[k] * t1[k];
+        }
+        for (int k = 0; k < MP; k++) {
+          ri[k] = t0[k];
+          rj[k] = t1[k];
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = true;
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < N; i++) {
+    double sd = 0;
+    for (int k = 0; k < M; k++) sd += R[i][k] * R[i][k];
+    W[i] = std::sqrt(sd);
+  }
+  for (int i = 0; i < N - 1; i++) {
+    int j = i;
+    for (int k = i + 1; k < N; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      std::swap(W[i], W[j]);
+      for (int k = 0; k < MP; k++) std::swap(R[i][k], R[j][k]);
     }
   }
-  for (int i = 0; i < M; i++) {
-    f1[i] = QT[7][i];
-    f2[i] = QT[8][i];
+  uint64_t rng = 0x12345678;  // cv::RNG(0x12345678)
+  for (int i = 0; i < N1; i++) {
+    double sd = i < N ? W[i] : 0;
+    for (int attempt = 0; attempt < 100 && sd <= kMin; attempt++) {
+      const double v0 = 1. / M;
+      for (int k = 0; k < M; k++) {
+        rng = (uint64_t)(unsigned)rng * 4164903690U + (unsigned)(rng >> 32);
+        R[i][k] = ((unsigned)rng & 256) != 0 ? v0 : -v0;
+      }
+      for (int round = 0; round < 2; round++)
+        for (int j = 0; j < i; j++) {
+          sd = 0;
+          for (int k = 0; k < M; k++) sd += R[i][k] * R[j][k];
+          double asum = 0;
+          for (int k = 0; k < M; k++) {
+            const double t = R[i][k] - sd * R[j][k];
+            R[i][k] = t;
+            asum += std::fabs(t);
+          }
+          asum = asum > kEps * 100 ? 1 / asum : 0;
+          for (int k = 0; k < M; k++) R[i][k] *= asum;
+        }
+      sd = 0;
+      for (int k = 0; k < M; k++) sd += R[i][k] * R[i][k];
+      sd = std::sqrt(sd);
+    }
+    const double s = sd > kMin ? 1 / sd : 0.;
+    for (int k = 0; k < M; k++) R[i][k] *= s;
+  }
+  for (int k = 0; k < M; k++) {
+    f1[k] = R[7][k];
+    f2[k] = R[8][k];
   }
 }
 

@@ -991,10 +991,121 @@ struct CvRNG {  // cv::RNG (core/operations.hpp): multiply-with-carry
   int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
 };
 
-// null space basis of a 7x9 system = last two columns of Q from Householder QR of A^T.
-// [OpenCV uses SVDecomp's last two right singular vectors; any orthonormal basis of the same
-// 2-D null space yields the same cubic roots / F matrices up to rounding.]
-void nullspace_7x9(const double* a /*7x9 row-major*/, double* f1, double* f2) {
+// One-sided Jacobi SVD as OpenCV's core/src/lapack.cpp runs it for doubles (JacobiSVDImpl_ with
+// minval = DBL_MIN, eps = DBL_EPSILON*10; restated from the published algorithm, OpenCV 4.2 is not in
+// /root/reference).  `at` holds n rows of length m (row stride `step`), m >= n: the rows are rotated
+// pairwise (Hestenes) until they are mutually orthogonal, their norms are the singular values (sorted
+// in decreasing order, rows swapped along), and each row is divided by its norm.  Rows n..n1-1 — the
+// part of a FULL_UV basis the data does not determine — are made the way OpenCV makes them: a
+// vector of +-1/m drawn from cv::RNG(0x12345678) (bit 8 of each 32-bit output), two rounds of
+// Gram-Schmidt against the rows above with an L1 rescale after each projection, then an L2
+// normalisation; the same is done for a row whose singular value is <= minval.
+// (The rotations of the second factor, V^T in OpenCV's call, do not feed back into `at` and are
+// left out.)
+void jacobi_svd_rows(double* at, int step, double* w, int m, int n, int n1) {
+  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+  double W[16];
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) sd += at[i * step + k] * at[i * step + k];
+    W[i] = sd;
+  }
+  const int max_iter = std::max(m, 30);
+  for (int iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+    for (int i = 0; i < n - 1; i++)
+      for (int j = i + 1; j < n; j++) {
+        double *ai = at + i * step, *aj = at + j * step;
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < m; k++) p += ai[k] * aj[k];
+        if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = hypot(p, beta);
+        double c, s;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = std::sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = std::sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (int k = 0; k < m; k++) {
+          const double t0 = c * ai[k] + s * aj[k];
+          const double t1 = -s * ai[k] + c * aj[k];
+          ai[k] = t0;
+          aj[k] = t1;
+          a += t0 * t0;
+          b += t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = true;
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) sd += at[i * step + k] * at[i * step + k];
+    W[i] = std::sqrt(sd);
+  }
+  for (int i = 0; i < n - 1; i++) {  // selection sort, largest first
+    int j = i;
+    for (int k = i + 1; k < n; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      std::swap(W[i], W[j]);
+      for (int k = 0; k < m; k++) std::swap(at[i * step + k], at[j * step + k]);
+    }
+  }
+  for (int i = 0; i < n; i++) w[i] = W[i];
+  CvRNG rng(0x12345678);
+  for (int i = 0; i < n1; i++) {
+    double sd = i < n ? W[i] : 0;
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+      const double val0 = 1. / m;
+      for (int k = 0; k < m; k++) at[i * step + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+      for (int iter = 0; iter < 2; iter++)
+        for (int j = 0; j < i; j++) {
+          sd = 0;
+          for (int k = 0; k < m; k++) sd += at[i * step + k] * at[j * step + k];
+          double asum = 0;
+          for (int k = 0; k < m; k++) {
+            const double t = at[i * step + k] - sd * at[j * step + k];
+            at[i * step + k] = t;
+            asum += std::fabs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+          for (int k = 0; k < m; k++) at[i * step + k] *= asum;
+        }
+      sd = 0;
+      for (int k = 0; k < m; k++) sd += at[i * step + k] * at[i * step + k];
+      sd = std::sqrt(sd);
+    }
+    const double s = sd > minval ? 1 / sd : 0.;
+    for (int k = 0; k < m; k++) at[i * step + k] *= s;
+  }
+}
+
+int g_nullspace_mode = 0;  // 0: cv::SVDecomp's route (what run7Point calls); 1: Householder QR
+
+// FMEstimatorCallback::run7Point's SVDecomp(A, W, U, Vt, MODIFY_A + FULL_UV) for the 7x9 system: rows
+// < cols, so cv::SVD works on A itself as the row set (m = 9, n = 7) and completes it to 9 rows;
+// f1, f2 are rows 7 and 8 of that V^T.
+void nullspace_7x9_svd(const double* a /*7x9 row-major*/, double* f1, double* f2) {
+  double at[9 * 9] = {0}, w[7];
+  std::memcpy(at, a, 7 * 9 * sizeof(double));
+  jacobi_svd_rows(at, 9, w, 9, 7, 9);
+  std::memcpy(f1, at + 7 * 9, 9 * sizeof(double));
+  std::memcpy(f2, at + 8 * 9, 9 * sizeof(double));
+}
+
+// The same plane from a Householder QR of A^T (last two columns of Q): any orthonormal basis of the
+// 2-D null space yields the same cubic roots / F matrices up to rounding.  Kept as the comparison
+// that measures how much the choice of basis moves RANSAC's inlier decisions
+// (tests/test_ransac_nullspace.py); not what the product does.
+void nullspace_7x9_qr(const double* a /*7x9 row-major*/, double* f1, double* f2) {
   const int m = 9, n = 7;
   double R[9][7];
   for (int i = 0; i < m; i++)
@@ -1031,6 +1142,13 @@ void nullspace_7x9(const double* a /*7x9 row-major*/, double* f1, double* f2) {
     f1[i] = Q[i][7];
     f2[i] = Q[i][8];
   }
+}
+
+void nullspace_7x9(const double* a, double* f1, double* f2) {
+  if (g_nullspace_mode == 1)
+    nullspace_7x9_qr(a, f1, f2);
+  else
+    nullspace_7x9_svd(a, f1, f2);
 }
 
 // cv::solveCubic (core/src/mathfuncs.cpp)
@@ -2059,6 +2177,13 @@ int oracle_find_fundamental_ransac(const float* p1, const float* p2, int n, doub
                                    uint8_t* status, double* F9) {
   return find_fundamental(p1, p2, n, thr, conf, status, F9);
 }
+void oracle_set_nullspace_mode(int mode) { g_nullspace_mode = mode; }
+int oracle_svd_rows(double* at, int m, int n, int n1, double* w) {
+  if (m < n || n1 < n || n1 > m || n > 16) return -1;
+  jacobi_svd_rows(at, m, w, m, n, n1);
+  return 0;
+}
+int oracle_seven_point(const float* p1, const float* p2, double* F27) { return run_7point(p1, p2, F27); }
 
 void* oracle_tracker_create(const oracle_config* cfg) {
   if (cfg->median_blur_kernel_size < 0) return nullptr;

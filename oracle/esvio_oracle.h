@@ -117,6 +117,14 @@ void oracle_lift_projective(const oracle_camera* cam, double u, double v, double
  * (status then all 0 like OpenCV's empty-F return). */
 int oracle_find_fundamental_ransac(const float* p1, const float* p2, int n, double thr,
                                    double conf, uint8_t* status, double* F9);
+/* run7Point's null space: 0 = cv::SVDecomp's one-sided Jacobi route (default, what OpenCV calls),
+ * 1 = Householder QR of A^T (same plane, another basis; only for measuring what the basis moves) */
+void oracle_set_nullspace_mode(int mode);
+/* the Jacobi SVD itself on n rows of length m (m >= n, n <= 16), completed to n1 rows; `at` is
+ * n1 x m row-major, rows >= n ignored on input.  Out: orthonormal rows, w[n] singular values. */
+int oracle_svd_rows(double* at, int m, int n, int n1, double* w);
+/* FMEstimatorCallback::run7Point on 7 point pairs: up to 3 row-major F into F27; returns how many */
+int oracle_seven_point(const float* p1, const float* p2, double* F27);
 
 /* ------------------------------------------------------------------ motion compensation */
 /* the fields of Motion_correction_value that createSAE_* (5 args) reads

@@ -107,6 +107,11 @@ def lib():
         L.oracle_normalize_minmax.argtypes = [vp, sz]
         L.oracle_find_fundamental_ransac.restype = i
         L.oracle_find_fundamental_ransac.argtypes = [vp, vp, i, d, d, vp, vp]
+        L.oracle_set_nullspace_mode.argtypes = [i]
+        L.oracle_svd_rows.restype = i
+        L.oracle_svd_rows.argtypes = [vp, i, i, i, vp]
+        L.oracle_seven_point.restype = i
+        L.oracle_seven_point.argtypes = [vp, vp, vp]
         L.oracle_tracker_create.restype = vp
         L.oracle_tracker_create.argtypes = [C.POINTER(Config)]
         L.oracle_tracker_destroy.argtypes = [vp]
@@ -326,6 +331,35 @@ def lift_projective(cam, u, v):
     out = np.empty(3, np.float64)
     lib().oracle_lift_projective(C.byref(c), float(u), float(v), _p(out))
     return out
+
+
+def set_nullspace_mode(mode):
+    """0: cv::SVDecomp's Jacobi route (default); 1: Householder QR (comparison only)"""
+    lib().oracle_set_nullspace_mode(int(mode))
+
+
+def svd_rows(a, n1=None):
+    """One-sided Jacobi SVD of the n rows of `a` (n x m, m >= n) as cv::SVD runs it, completed to
+    n1 orthonormal rows -> (rows[n1, m], w[n])"""
+    a = np.ascontiguousarray(a, np.float64)
+    n, m = a.shape
+    n1 = n if n1 is None else n1
+    at = np.zeros((n1, m), np.float64)
+    at[:n] = a
+    w = np.zeros(n, np.float64)
+    if lib().oracle_svd_rows(_p(at), m, n, n1, _p(w)) != 0:
+        raise ValueError("svd_rows: bad shape")
+    return at, w
+
+
+def seven_point(p1, p2):
+    """run7Point on 7 pairs -> list of 3x3 F"""
+    p1 = np.ascontiguousarray(p1, np.float32)
+    p2 = np.ascontiguousarray(p2, np.float32)
+    assert p1.shape == (7, 2) and p2.shape == (7, 2)
+    F = np.zeros(27, np.float64)
+    k = lib().oracle_seven_point(_p(p1), _p(p2), _p(F))
+    return [F[9 * j:9 * j + 9].reshape(3, 3).copy() for j in range(max(k, 0))]
 
 
 def find_fundamental(p1, p2, thr=1.0, conf=0.99):
