@@ -364,7 +364,9 @@ def main():
     # ---- the timed region: EXACTLY --steps steps (pass 0 is the headline); the same region is then
     # repeated over the continued stream (passes 1..R-1) so that the spread can be reported
     passes = []
+    ransac_passes = []
     for r in range(repeats):
+        FE.ransac_stats(reset=True)
         barrier()
         t0 = time.perf_counter()
         n_events = 0
@@ -386,8 +388,15 @@ def main():
             dist.all_reduce(tot[0:1], op=dist.ReduceOp.SUM)
             dist.all_reduce(tot[1:2], op=dist.ReduceOp.MAX)
         passes.append((float(tot[0].item()), float(tot[1].item()), n_events))
+        ransac_passes.append(FE.ransac_stats())
     total_events, max_elapsed, n_events = passes[0]
     n_tracks = (len(ft.ids), len(ft.ids_right))
+    # rejectWithF_event's host RANSAC inside each timed pass (this rank)
+    host_ransac = [None if not rs["calls"] else dict(
+        calls=rs["calls"], mean_points=round(rs["points"] / rs["calls"], 1),
+        mean_iterations=round(rs["iterations"] / rs["calls"], 1), mean_us=round(rs["us"] / rs["calls"], 2),
+        lmeds_calls=rs["lmeds_calls"], lmeds_mean_us=round(rs["lmeds_us"] / max(rs["lmeds_calls"], 1), 2),
+        us_per_step=round((rs["us"] + rs["lmeds_us"]) / args.steps, 2)) for rs in ransac_passes]
 
     # ---- per-kernel pass (rank 0): HIP events around every launch on the stream it is launched on
     # (kept out of the timed region because the records cost host time).  Two schedules over the
@@ -556,6 +565,7 @@ def main():
                             max=round(ms_all[-1], 4),
                             value_median=round(passes[0][0] / args.steps / ms_all[len(ms_all) // 2] / 1e3, 3)),
             "host_resident_events": host_res,
+            "host_ransac": host_ransac,
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,

@@ -16,6 +16,7 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",          # keep mul+add separate: bit parity with the x86 reference build
     "-fno-fast-math",
+    "-fno-math-errno",            # sqrt() may be the instruction (same value), so lane loops vectorise
     "-Wall", "-Wno-unused-function",
     "-Wl,-rpath,/opt/rocm/lib",
     "-ldl",

@@ -101,6 +101,9 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->phase_count[1] ? c->tr_fm_ms / c->phase_count[1] : 0.0, c->tr_fm_max_ms,
             c->phase_count[1] > 1 ? (c->tr_fm_ms - c->tr_fm_max_ms) / (c->phase_count[1] - 1) : 0.0,
             c->phase_count[1] ? c->tr_lift_ms / c->phase_count[1] : 0.0);
+    fprintf(stderr, "\n[esvio_fe trace] rejectWithF_event calls by point count: %llu with < 8 (skipped), %llu with "
+            "8..14 (LMedS, 300 hypotheses), %llu with >= 15 (RANSAC)", (unsigned long long)c->tr_fm_class[0],
+            (unsigned long long)c->tr_fm_class[1], (unsigned long long)c->tr_fm_class[2]);
     if (c->tr_gpu_n)
       fprintf(stderr, "\n[esvio_fe trace] device: k_select %.1f us; select end -> next frame's temporal LK done "
               "%.1f us, -> chained one done %.1f us (its frame's pyramids: %.1f us); host: select launch -> "
@@ -705,6 +708,18 @@ int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, doubl
   const int k = host::find_fundamental_mat(p1, p2, n, thr, conf, status);
   if (n_inliers) *n_inliers = k;
   return 0;
+}
+
+int esvio_fe_ransac_stats(uint64_t* out6, int reset) {
+  if (!out6) return ESVIO_FE_EINVAL;
+  const host::RansacStats r = host::ransac_stats(reset != 0);
+  out6[0] = r.calls;
+  out6[1] = r.iterations;
+  out6[2] = r.points;
+  out6[3] = r.ns;
+  out6[4] = r.lmeds_calls;
+  out6[5] = r.lmeds_ns;
+  return ESVIO_FE_OK;
 }
 
 int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, double thr, double conf,

@@ -319,6 +319,7 @@ struct esvio_fe_ctx {
   double pub_ms[6] = {};       // published frames: the parts of "host mask + enqueue detect/stereo"
   uint64_t phase_count[2] = {0, 0};
   uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
+  uint64_t tr_fm_class[3] = {};  // rejectWithF_event calls with < 8 points (skipped), 8..14 (LMedS), >= 15 (RANSAC)
   double tr_fm_ms = 0;  // time inside find_fundamental_mat alone
   double tr_fm_max_ms = 0, tr_lift_ms = 0;  // ... its slowest call; the two liftProjective batches
   uint64_t tr_chain_launch = 0, tr_chain_used = 0, tr_chain_cancel = 0, tr_spec_used = 0;

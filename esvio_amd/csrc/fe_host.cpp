@@ -296,6 +296,160 @@ void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
   }
 }
 
+// The same decomposition for kLanes independent systems at once, one per vector lane.  A single
+// system is a chain of dependent operations (dot product -> hypot -> sqrt/div -> rotation, ~85
+// times), so one at a time the vector units idle; side by side every lane performs exactly the
+// scalar sequence above on its own data: a pair that a lane skips leaves that lane's rows and norms
+// untouched (selected by mask), a lane that has converged sees only skipped pairs in the sweeps the
+// others still need, and the sweep limit is common.  hypot stays the libm call, per lane.  The
+// made-up rows use the first draw of the sign vector (the same for every system); a lane that
+// would need OpenCV's retry (a zero singular value or a vanished projection) makes the function
+// return false and the caller does those systems with the scalar routine.
+constexpr int kLanes = 8;
+
+ESVIO_SIMD_CLONES
+bool epipolar_nullspace_lanes(const double (*A)[7][9], double (*f1)[9], double (*f2)[9]) {
+  constexpr int M = 9, N = 7, L = kLanes;
+  constexpr double kMin = DBL_MIN, kEps = DBL_EPSILON * 10;
+  alignas(64) double R[9][M][L];
+  alignas(64) double W[N][L];
+  for (int i = 0; i < N; i++)
+    for (int k = 0; k < M; k++)
+      for (int l = 0; l < L; l++) R[i][k][l] = A[l][i][k];
+  for (int i = 0; i < N; i++) {
+    alignas(64) double sd[L];
+    for (int l = 0; l < L; l++) sd[l] = 0;
+    for (int k = 0; k < M; k++)
+      for (int l = 0; l < L; l++) sd[l] += R[i][k][l] * R[i][k][l];
+    for (int l = 0; l < L; l++) W[i][l] = sd[l];
+  }
+  for (int sweep = 0; sweep < 30; sweep++) {
+    bool changed = false;
+    for (int i = 0; i < N - 1; i++)
+      for (int j = i + 1; j < N; j++) {
+        alignas(64) double p[L], lim[L];
+        alignas(64) int64_t on[L];
+        for (int l = 0; l < L; l++) p[l] = 0;
+        for (int k = 0; k < M; k++)
+          for (int l = 0; l < L; l++) p[l] += R[i][k][l] * R[j][k][l];
+        for (int l = 0; l < L; l++) lim[l] = kEps * std::sqrt(W[i][l] * W[j][l]);
+        int64_t any = 0;
+        for (int l = 0; l < L; l++) {
+          on[l] = !(std::fabs(p[l]) <= lim[l]) ? -1 : 0;
+          any |= on[l];
+        }
+        if (!any) continue;
+        changed = true;
+        alignas(64) double beta[L], gamma[L], c[L], s[L], a[L], b[L];
+        for (int l = 0; l < L; l++) {
+          p[l] *= 2;
+          beta[l] = W[i][l] - W[j][l];
+          gamma[l] = 1;
+        }
+        for (int l = 0; l < L; l++)
+          if (on[l]) gamma[l] = hypot(p[l], beta[l]);
+        for (int l = 0; l < L; l++) {  // both branches of the scalar code, the lane's own one kept
+          const double delta = (gamma[l] - beta[l]) * 0.5;
+          const double s_neg = std::sqrt(delta / gamma[l]);
+          const double c_neg = p[l] / (gamma[l] * s_neg * 2);
+          const double c_pos = std::sqrt((gamma[l] + beta[l]) / (gamma[l] * 2));
+          const double s_pos = p[l] / (gamma[l] * c_pos * 2);
+          const bool neg = beta[l] < 0;
+          c[l] = neg ? c_neg : c_pos;
+          s[l] = neg ? s_neg : s_pos;
+          a[l] = 0;
+          b[l] = 0;
+        }
+        for (int k = 0; k < M; k++)
+          for (int l = 0; l < L; l++) {
+            const double x = R[i][k][l], y = R[j][k][l];
+            const double t0 = c[l] * x + s[l] * y, t1 = -s[l] * x + c[l] * y;
+            R[i][k][l] = on[l] ? t0 : x;
+            R[j][k][l] = on[l] ? t1 : y;
+            a[l] += t0 * t0;
+            b[l] += t1 * t1;
+          }
+        for (int l = 0; l < L; l++) {
+          W[i][l] = on[l] ? a[l] : W[i][l];
+          W[j][l] = on[l] ? b[l] : W[j][l];
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < N; i++) {
+    alignas(64) double sd[L];
+    for (int l = 0; l < L; l++) sd[l] = 0;
+    for (int k = 0; k < M; k++)
+      for (int l = 0; l < L; l++) sd[l] += R[i][k][l] * R[i][k][l];
+    for (int l = 0; l < L; l++) W[i][l] = std::sqrt(sd[l]);
+  }
+  bool plain = true;
+  for (int l = 0; l < L; l++) {
+    for (int i = 0; i < N - 1; i++) {
+      int j = i;
+      for (int k = i + 1; k < N; k++)
+        if (W[j][l] < W[k][l]) j = k;
+      if (i != j) {
+        std::swap(W[i][l], W[j][l]);
+        for (int k = 0; k < M; k++) std::swap(R[i][k][l], R[j][k][l]);
+      }
+    }
+    for (int i = 0; i < N; i++) plain = plain && W[i][l] > kMin;
+  }
+  if (!plain) return false;
+  for (int i = 0; i < N; i++) {
+    alignas(64) double inv[L];
+    for (int l = 0; l < L; l++) inv[l] = 1 / W[i][l];
+    for (int k = 0; k < M; k++)
+      for (int l = 0; l < L; l++) R[i][k][l] *= inv[l];
+  }
+  uint64_t rng = 0x12345678;
+  for (int i = N; i < 9; i++) {
+    const double v0 = 1. / M;
+    for (int k = 0; k < M; k++) {
+      rng = (uint64_t)(unsigned)rng * 4164903690U + (unsigned)(rng >> 32);
+      const double v = ((unsigned)rng & 256) != 0 ? v0 : -v0;
+      for (int l = 0; l < L; l++) R[i][k][l] = v;
+    }
+    alignas(64) double sd[L], asum[L];
+    for (int round = 0; round < 2; round++)
+      for (int j = 0; j < i; j++) {
+        for (int l = 0; l < L; l++) {
+          sd[l] = 0;
+          asum[l] = 0;
+        }
+        for (int k = 0; k < M; k++)
+          for (int l = 0; l < L; l++) sd[l] += R[i][k][l] * R[j][k][l];
+        for (int k = 0; k < M; k++)
+          for (int l = 0; l < L; l++) {
+            const double t = R[i][k][l] - sd[l] * R[j][k][l];
+            R[i][k][l] = t;
+            asum[l] += std::fabs(t);
+          }
+        for (int l = 0; l < L; l++) asum[l] = asum[l] > kEps * 100 ? 1 / asum[l] : 0;
+        for (int k = 0; k < M; k++)
+          for (int l = 0; l < L; l++) R[i][k][l] *= asum[l];
+      }
+    for (int l = 0; l < L; l++) sd[l] = 0;
+    for (int k = 0; k < M; k++)
+      for (int l = 0; l < L; l++) sd[l] += R[i][k][l] * R[i][k][l];
+    for (int l = 0; l < L; l++) {
+      sd[l] = std::sqrt(sd[l]);
+      plain = plain && sd[l] > kMin;
+    }
+    if (!plain) return false;
+    for (int l = 0; l < L; l++) sd[l] = 1 / sd[l];
+    for (int k = 0; k < M; k++)
+      for (int l = 0; l < L; l++) R[i][k][l] *= sd[l];
+  }
+  for (int l = 0; l < L; l++)
+    for (int k = 0; k < M; k++) {
+      f1[l][k] = R[7][k][l];
+      f2[l][k] = R[8][k][l];
+    }
+  return true;
+}
+
 // cv::solveCubic [OpenCV core/mathfuncs.cpp]
 int solve_cubic(const double coef[4], double roots[3]) {
   double a0 = coef[0], a1 = coef[1], a2 = coef[2], a3 = coef[3];
@@ -367,16 +521,18 @@ int solve_cubic(const double coef[4], double roots[3]) {
   return n;
 }
 
-// FMEstimatorCallback::run7Point [OpenCV calib3d/fundam.cpp]; F: up to 3 row-major 3x3
-int seven_point(const float* m1, const float* m2, double* F) {
-  double A[7][9];
+// FMEstimatorCallback::run7Point [OpenCV calib3d/fundam.cpp]: the 7x9 system ...
+void epipolar_system(const float* m1, const float* m2, double A[7][9]) {
   for (int i = 0; i < 7; i++) {
     const double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
     const double row[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1};
     std::memcpy(A[i], row, sizeof(row));
   }
-  double f1[9], f2[9];
-  epipolar_nullspace(A, f1, f2);
+}
+
+// ... and, from the basis f1, f2 of its null space, the matrices lambda f1 + (1 - lambda) f2 of
+// determinant 0; F: up to 3 row-major 3x3 (f1 is overwritten)
+int seven_point_from_basis(double f1[9], const double f2[9], double* F) {
   for (int i = 0; i < 9; i++) f1[i] -= f2[i];
   double c[4], r[3] = {0, 0, 0};
   double t0 = f2[4] * f2[8] - f2[5] * f2[7];
@@ -410,6 +566,23 @@ int seven_point(const float* m1, const float* m2, double* F) {
     for (int i = 0; i < 8; i++) F[i] = f1[i] * lambda + f2[i] * mu;
   }
   return n;
+}
+
+int seven_point(const float* m1, const float* m2, double* F) {
+  double A[7][9], f1[9], f2[9];
+  epipolar_system(m1, m2, A);
+  epipolar_nullspace(A, f1, f2);
+  return seven_point_from_basis(f1, f2, F);
+}
+
+// seven_point for cnt <= kLanes subsets side by side (s1/s2: 14 floats per subset); nm[l] and
+// models[l] are what seven_point returns for subset l
+void seven_point_lanes(int cnt, const float (*s1)[14], const float (*s2)[14], int* nm, double (*models)[27]) {
+  double A[kLanes][7][9], f1[kLanes][9], f2[kLanes][9];
+  for (int l = 0; l < kLanes; l++) epipolar_system(s1[l < cnt ? l : 0], s2[l < cnt ? l : 0], A[l]);
+  if (!epipolar_nullspace_lanes(A, f1, f2))
+    for (int l = 0; l < cnt; l++) epipolar_nullspace(A[l], f1[l], f2[l]);
+  for (int l = 0; l < cnt; l++) nm[l] = seven_point_from_basis(f1[l], f2[l], models[l]);
 }
 
 // FMEstimatorCallback::computeError: max of the two squared point-to-epipolar-line distances
@@ -446,7 +619,7 @@ bool last_point_collinear(const float* m, int count) {  // haveCollinearPoints
 
 // RANSACPointSetRegistrator::getSubset for modelPoints = 7
 bool draw_subset(const float* m1, const float* m2, int count, float* s1, float* s2, OcvRng& rng,
-                 int max_attempts) {
+                 int max_attempts, int32_t* picked = nullptr) {
   int idx[7];
   int i = 0, iters = 0;
   for (; iters < max_attempts; iters++) {
@@ -467,6 +640,8 @@ bool draw_subset(const float* m1, const float* m2, int count, float* s1, float* 
     if (i == 7 && (last_point_collinear(s1, i) || last_point_collinear(s2, i))) continue;
     break;
   }
+  if (picked)
+    for (int k = 0; k < 7; k++) picked[k] = idx[k];
   return i == 7 && iters < max_attempts;
 }
 
@@ -551,7 +726,7 @@ int mark_inliers_bounded(const double* x1, const double* y1, const double* x2, c
 // to sleep after kIdleSpinUs without work.
 namespace {
 constexpr int kRansacMaxIters = 1000;
-constexpr int kRansacWindow = 48;      // iterations drawn ahead of the replay position
+constexpr int kRansacWindow = 128;     // iterations drawn ahead of the replay position (>= threads x kLanes)
 constexpr int kIdleSpinUs = 2000;
 
 inline void cpu_relax() {
@@ -581,6 +756,7 @@ struct RansacJob {
   std::vector<float> pts;                  // m1 | m2 (interleaved x,y), 2*count each
   int count = 0;
   double thr = 0;
+  bool lmeds = false;  // score = median of the errors (as float bits in good[]), not an inlier count
   // The caller only runs the cv::RNG index draws (7 distinct indices per iteration, ~15 ns); the
   // gather and getSubset's collinearity test are part of the evaluation.  A subset that fails the
   // test (the reference then redraws, consuming more random numbers) is reported as kCollinear and
@@ -594,6 +770,42 @@ struct RansacJob {
 
   uint32_t evaluate(int idx, IterResult& r, std::vector<uint8_t>& scratch) const {
     float s1[14], s2[14];
+    if (!gather(idx, s1, s2)) {
+      r.nm = -1;
+      return kCollinear;
+    }
+    r.nm = seven_point(s1, s2, r.models);
+    return score(r, scratch);
+  }
+
+  // Iterations [idx0, idx0 + cnt), cnt <= kLanes, their 7-point systems solved side by side; each
+  // iteration's summary is published as soon as it is scored.  Same results as evaluate() one by one.
+  void evaluate_lanes(int idx0, int cnt, uint32_t e, std::vector<uint8_t>& scratch) {
+    float s1[kLanes][14], s2[kLanes][14];
+    int lane_of[kLanes], nm[kLanes], live = 0;
+    double models[kLanes][27];
+    for (int i = 0; i < cnt; i++) {
+      if (gather(idx0 + i, s1[live], s2[live])) {
+        lane_of[i] = live++;
+      } else {
+        lane_of[i] = -1;
+        res[idx0 + i].nm = -1;
+        summary[idx0 + i].store(((uint64_t)e << 32) | kCollinear, std::memory_order_release);
+      }
+    }
+    if (!live) return;
+    seven_point_lanes(live, s1, s2, nm, models);
+    for (int i = 0; i < cnt; i++) {
+      if (lane_of[i] < 0) continue;
+      IterResult& r = res[idx0 + i];
+      r.nm = nm[lane_of[i]];
+      if (r.nm > 0) std::memcpy(r.models, models[lane_of[i]], sizeof(double) * 9 * r.nm);
+      summary[idx0 + i].store(((uint64_t)e << 32) | score(r, scratch), std::memory_order_release);
+    }
+  }
+
+ private:
+  bool gather(int idx, float* s1, float* s2) const {  // false: getSubset's checkSubset rejects it
     const float *m1 = pts.data(), *m2 = m1 + 2 * (size_t)count;
     const int32_t* pk = &picks[(size_t)idx * 8];
     for (int i = 0; i < 7; i++) {
@@ -602,11 +814,19 @@ struct RansacJob {
       s2[2 * i] = m2[2 * pk[i]];
       s2[2 * i + 1] = m2[2 * pk[i] + 1];
     }
-    if (last_point_collinear(s1, 7) || last_point_collinear(s2, 7)) {
-      r.nm = -1;
-      return kCollinear;
+    return !(last_point_collinear(s1, 7) || last_point_collinear(s2, 7));
+  }
+  uint32_t score(IterResult& r, std::vector<uint8_t>& scratch) const {
+    if (lmeds) {  // LMeDSPointSetRegistrator::run: the median of computeError's values per model
+      const float *m1 = pts.data(), *m2 = m1 + 2 * (size_t)count;
+      float errs[16];
+      for (int k = 0; k < r.nm; k++) {
+        epipolar_errors(m1, m2, count, r.models + 9 * k, errs);
+        std::nth_element(errs, errs + count / 2, errs + count);
+        std::memcpy(&r.good[k], &errs[count / 2], sizeof(float));
+      }
+      return 0;
     }
-    r.nm = seven_point(s1, s2, r.models);
     const int need = bound.load(std::memory_order_relaxed);
     if ((int)scratch.size() < count) scratch.resize(count);
     const double *x1 = xy.data(), *y1 = x1 + count, *x2 = y1 + count, *y2 = x2 + count;
@@ -661,10 +881,13 @@ struct RansacPool {
       J.active.fetch_add(1, std::memory_order_acq_rel);
       // (the job may have closed — and this buffer's next job opened — in between: then leave)
       while (epoch.load(std::memory_order_acquire) == e) {
-        const int idx = J.next.fetch_add(1, std::memory_order_relaxed);
+        // (subsets are published in groups of kLanes starting at multiples of kLanes; only the last
+        // group of a job can be shorter)
+        const int idx = J.next.fetch_add(kLanes, std::memory_order_relaxed);
         if (idx >= kRansacMaxIters) break;
         bool go = true;
-        while (J.avail.load(std::memory_order_acquire) <= idx) {
+        int avail;
+        while ((avail = J.avail.load(std::memory_order_acquire)) <= idx) {
           if (epoch.load(std::memory_order_acquire) != e) {
             go = false;
             break;
@@ -672,8 +895,7 @@ struct RansacPool {
           cpu_relax();
         }
         if (!go) break;
-        const uint32_t code = J.evaluate(idx, J.res[idx], scratch);
-        J.summary[idx].store(((uint64_t)e << 32) | code, std::memory_order_release);
+        J.evaluate_lanes(idx, std::min(kLanes, avail - idx), e, scratch);
       }
       J.active.fetch_sub(1, std::memory_order_release);
       seen = e;
@@ -752,8 +974,8 @@ void RansacPool::pin_near_caller() {
 #endif
 }
 
-RansacPool* ransac_pool_create(int helpers) {
-  if (helpers <= 0) return nullptr;
+namespace {
+RansacPool* ransac_pool_alloc() {
   RansacPool* p = new RansacPool();
   for (RansacJob& J : p->job) {
     J.picks.resize((size_t)kRansacMaxIters * 8);
@@ -761,6 +983,13 @@ RansacPool* ransac_pool_create(int helpers) {
     J.summary.reset(new std::atomic<uint64_t>[kRansacMaxIters]);
     for (int i = 0; i < kRansacMaxIters; i++) J.summary[i].store(0, std::memory_order_relaxed);
   }
+  return p;
+}
+}  // namespace
+
+RansacPool* ransac_pool_create(int helpers) {
+  if (helpers <= 0) return nullptr;
+  RansacPool* p = ransac_pool_alloc();
   for (int i = 0; i < helpers; i++) p->th.emplace_back([p] { p->helper(); });
   p->pin_near_caller();
   return p;
@@ -790,9 +1019,27 @@ void ransac_pool_destroy(RansacPool* p) {
 }
 
 namespace {
+std::atomic<uint64_t> g_rs_calls{0}, g_rs_iters{0}, g_rs_points{0}, g_rs_ns{0}, g_rs_lm_calls{0}, g_rs_lm_ns{0};
+}  // namespace
+
+RansacStats ransac_stats(bool reset) {
+  RansacStats r{g_rs_calls.load(), g_rs_iters.load(), g_rs_points.load(), g_rs_ns.load(),
+                g_rs_lm_calls.load(), g_rs_lm_ns.load()};
+  if (reset) {
+    g_rs_lm_calls = 0;
+    g_rs_lm_ns = 0;
+    g_rs_calls = 0;
+    g_rs_iters = 0;
+    g_rs_points = 0;
+    g_rs_ns = 0;
+  }
+  return r;
+}
+
+namespace {
 // the RANSAC loop of find_fundamental_mat with helpers (count >= 15)
 int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, double thr, double conf,
-                  const double* xy, uint8_t* status) {
+                  const double* xy, uint8_t* status, int* iterations) {
   const int kModelPoints = 7;
   const uint32_t e = P->epoch.load(std::memory_order_relaxed) + 1;  // (odd: this job's tag)
   RansacJob& J = P->job[(e >> 1) & 1];
@@ -804,11 +1051,12 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
   std::memcpy(J.pts.data() + 2 * (size_t)count, m2, 2 * (size_t)count * sizeof(float));
   J.count = count;
   J.thr = thr;
+  J.lmeds = false;
   J.next.store(0, std::memory_order_relaxed);
   J.avail.store(0, std::memory_order_relaxed);
   J.bound.store(kModelPoints - 1, std::memory_order_relaxed);
   P->epoch.store(e, std::memory_order_release);  // open
-  ransac_pool_wake(P);
+  if (!P->th.empty()) ransac_pool_wake(P);
 
   OcvRng rng;
   std::vector<uint8_t> scratch(count);
@@ -855,7 +1103,7 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
     }
     if (rp >= niters || collinear_at >= 0) break;
     if (drawn < niters && drawn - rp < kRansacWindow) {
-      for (int j = 0; j < 8 && drawn < niters; j++) {  // RANSACPointSetRegistrator::getSubset's draws
+      for (int j = 0; j < kLanes && drawn < niters; j++) {  // RANSACPointSetRegistrator::getSubset's draws
         rng_before.push_back(rng.s);
         int32_t* pk = &J.picks[(size_t)drawn * 8];
         for (int i = 0; i < 7; i++) {
@@ -874,9 +1122,8 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
     }
     // nothing to draw: take an iteration like a helper does
     int idx = J.next.load(std::memory_order_relaxed);
-    if (idx < drawn && J.next.compare_exchange_strong(idx, idx + 1, std::memory_order_relaxed)) {
-      const uint32_t code = J.evaluate(idx, J.res[idx], scratch);
-      J.summary[idx].store(((uint64_t)e << 32) | code, std::memory_order_release);
+    if (idx < drawn && J.next.compare_exchange_strong(idx, idx + kLanes, std::memory_order_relaxed)) {
+      J.evaluate_lanes(idx, std::min(kLanes, drawn - idx), e, scratch);
     } else {
       cpu_relax();
       stalled++;
@@ -905,24 +1152,88 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
       }
     }
   }
+  *iterations = niters;
   if (have_best) score_block(x1, y1, x2, y2, 0, count, best_F, (float)(thr * thr), status);
   return best_good;
+}
+
+// LMeDSPointSetRegistrator::run for 8..14 points: a fixed number of hypotheses (300 at confidence
+// 0.99), the one with the smallest median error wins (the first one on ties), inliers within
+// 2.5 * 1.4826 * (1 + 5/(n - 7)) * sqrt(median).  The subsets do not depend on the models, so they
+// are all drawn first — getSubset's own loop, collinearity retries included — and then solved
+// kLanes at a time by the calling thread and the pool's helpers; the medians are compared in
+// iteration order.
+int lmeds_pooled(RansacPool* P, const float* m1, const float* m2, int count, double conf, uint8_t* status) {
+  const int kModelPoints = 7;
+  const int niters = update_num_iters(conf, 0.45, kModelPoints, kRansacMaxIters);
+  const uint32_t e = P->epoch.load(std::memory_order_relaxed) + 1;
+  RansacJob& J = P->job[(e >> 1) & 1];
+  while (J.active.load(std::memory_order_acquire) != 0) cpu_relax();
+  OcvRng rng;
+  float s1[14], s2[14];
+  int nsub = 0;
+  for (; nsub < niters; nsub++)
+    if (!draw_subset(m1, m2, count, s1, s2, rng, 300, &J.picks[(size_t)nsub * 8])) break;
+  if (nsub == 0) return 0;
+  J.pts.resize(4 * (size_t)count);
+  std::memcpy(J.pts.data(), m1, 2 * (size_t)count * sizeof(float));
+  std::memcpy(J.pts.data() + 2 * (size_t)count, m2, 2 * (size_t)count * sizeof(float));
+  J.count = count;
+  J.lmeds = true;
+  J.next.store(0, std::memory_order_relaxed);
+  J.avail.store(nsub, std::memory_order_relaxed);
+  P->epoch.store(e, std::memory_order_release);  // open
+  if (!P->th.empty()) ransac_pool_wake(P);
+  std::vector<uint8_t> scratch;
+  IterResult local;
+  double best[9], min_median = DBL_MAX;
+  unsigned stalled = 0;
+  for (int rp = 0; rp < nsub;) {
+    const IterResult* r = &J.res[rp];
+    const uint64_t sm = J.summary[rp].load(std::memory_order_acquire);
+    if ((uint32_t)(sm >> 32) != e) {
+      int idx = J.next.load(std::memory_order_relaxed);
+      if (idx < nsub && J.next.compare_exchange_strong(idx, idx + kLanes, std::memory_order_relaxed)) {
+        J.evaluate_lanes(idx, std::min(kLanes, nsub - idx), e, scratch);
+        continue;
+      }
+      if (++stalled <= 64) {
+        cpu_relax();
+        continue;
+      }
+      J.evaluate(rp, local, scratch);  // (its taker is not delivering)
+      r = &local;
+    }
+    stalled = 0;
+    for (int k = 0; k < r->nm; k++) {
+      float med;
+      std::memcpy(&med, &r->good[k], sizeof(float));
+      if ((double)med < min_median) {
+        min_median = med;
+        std::memcpy(best, r->models + 9 * k, sizeof(best));
+      }
+    }
+    rp++;
+  }
+  P->epoch.store(e + 1, std::memory_order_release);  // closed
+  if (min_median < DBL_MAX) {
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (count - kModelPoints)) * std::sqrt(min_median);
+    sigma = std::max(sigma, 0.001);
+    std::vector<float> err(count);
+    return mark_inliers(m1, m2, count, best, err, status, sigma);
+  }
+  return 0;
 }
 }  // namespace
 
 int find_fundamental_mat(const float* m1, const float* m2, int count, double thr, double conf,
                          uint8_t* status, RansacPool* pool) {
-  const int kModelPoints = 7, kMaxIters = kRansacMaxIters;
   std::fill(status, status + count, (uint8_t)0);
   if (count < 7) return 0;
   if (thr <= 0) thr = 3;
   if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
-  std::vector<float> err(count);
-  std::vector<uint8_t> mask(count);
-  float s1[14], s2[14];
-  double models[27], best[9];
-  OcvRng rng;
   if (count == 7) {
+    double models[27];
     const int n = seven_point(m1, m2, models);
     std::fill(status, status + count, (uint8_t)1);
     return n > 0 ? count : 0;
@@ -936,54 +1247,35 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
       x2[i] = m2[2 * i];
       y2[i] = m2[2 * i + 1];
     }
-    if (pool) return ransac_pooled(pool, m1, m2, count, thr, conf, xy.data(), status);
-    int niters = kMaxIters, best_good = 0;
-    for (int iter = 0; iter < niters; iter++) {
-      if (!draw_subset(m1, m2, count, s1, s2, rng, 10000)) {
-        if (iter == 0) return 0;
-        break;
-      }
-      const int nm = seven_point(s1, s2, models);
-      if (nm <= 0) continue;
-      for (int k = 0; k < nm; k++) {
-        const int good = mark_inliers_bounded(x1, y1, x2, y2, count, models + 9 * k, mask.data(), thr,
-                                              std::max(best_good, kModelPoints - 1));
-        if (good > std::max(best_good, kModelPoints - 1)) {
-          std::memcpy(status, mask.data(), count);
-          best_good = good;
-          niters = update_num_iters(conf, (double)(count - good) / count, kModelPoints, niters);
-        }
-      }
+    // without helper threads the same loop runs on a pool of none: the calling thread draws, solves
+    // the subsets kLanes at a time and replays them in order
+    static thread_local std::unique_ptr<RansacPool> solo;
+    if (!pool) {
+      if (!solo) solo.reset(ransac_pool_alloc());
+      pool = solo.get();
     }
-    return best_good;
+    const auto t0 = std::chrono::steady_clock::now();
+    int iters = 0;
+    const int good = ransac_pooled(pool, m1, m2, count, thr, conf, xy.data(), status, &iters);
+    g_rs_calls.fetch_add(1, std::memory_order_relaxed);
+    g_rs_iters.fetch_add((uint64_t)iters, std::memory_order_relaxed);
+    g_rs_points.fetch_add((uint64_t)count, std::memory_order_relaxed);
+    g_rs_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                          std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+    return good;
   }
   // LMedS for 8..14 points
-  const int niters = update_num_iters(conf, 0.45, kModelPoints, kMaxIters);
-  double min_median = DBL_MAX;
-  std::vector<float> errs(count);
-  for (int iter = 0; iter < niters; iter++) {
-    if (!draw_subset(m1, m2, count, s1, s2, rng, 300)) {
-      if (iter == 0) return 0;
-      break;
-    }
-    const int nm = seven_point(s1, s2, models);
-    if (nm <= 0) continue;
-    for (int k = 0; k < nm; k++) {
-      epipolar_errors(m1, m2, count, models + 9 * k, errs.data());
-      std::nth_element(errs.begin(), errs.begin() + count / 2, errs.end());
-      const double median = errs[count / 2];
-      if (median < min_median) {
-        min_median = median;
-        std::memcpy(best, models + 9 * k, sizeof(best));
-      }
-    }
+  const auto t0 = std::chrono::steady_clock::now();
+  static thread_local std::unique_ptr<RansacPool> solo_lm;
+  if (!pool) {
+    if (!solo_lm) solo_lm.reset(ransac_pool_alloc());
+    pool = solo_lm.get();
   }
-  if (min_median < DBL_MAX) {
-    double sigma = 2.5 * 1.4826 * (1 + 5. / (count - kModelPoints)) * std::sqrt(min_median);
-    sigma = std::max(sigma, 0.001);
-    return mark_inliers(m1, m2, count, best, err, status, sigma);
-  }
-  return 0;
+  const int good = lmeds_pooled(pool, m1, m2, count, conf, status);
+  g_rs_lm_calls.fetch_add(1, std::memory_order_relaxed);
+  g_rs_lm_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                           std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+  return good;
 }
 
 }  // namespace host

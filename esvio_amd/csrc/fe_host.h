@@ -42,6 +42,13 @@ struct RansacPool;
 RansacPool* ransac_pool_create(int helpers);
 void ransac_pool_destroy(RansacPool* p);
 void ransac_pool_wake(RansacPool* p);  // a job is coming: helpers that went to sleep start spinning
+// process-wide counters of find_fundamental_mat: its RANSAC branch (>= 15 points) — calls,
+// hypotheses replayed (the loop's iteration count), points, nanoseconds inside the call — and its
+// LMedS branch (8..14 points: a fixed 300 hypotheses) — calls, nanoseconds
+struct RansacStats {
+  uint64_t calls, iterations, points, ns, lmeds_calls, lmeds_ns;
+};
+RansacStats ransac_stats(bool reset);
 int find_fundamental_mat(const float* p1, const float* p2, int n, double thr, double conf,
                          uint8_t* status, RansacPool* pool = nullptr);
 

@@ -517,6 +517,7 @@ std::vector<P2f> pts_velocity_fn(std::vector<int>& ids, std::vector<P2f>& pts, I
 }
 
 void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
+  if (c->trace) c->tr_fm_class[c->cur_pts.size() < 8 ? 0 : c->cur_pts.size() < 15 ? 1 : 2]++;
   if (c->cur_pts.size() >= 8) {
     const esvio_fe_camera& cam = c->cfg.cam[0];
     const double FOCAL = c->cfg.focal_length;

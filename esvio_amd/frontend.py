@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
     "esvio_fe_set_next_batch", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
-    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt",
+    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
@@ -140,6 +140,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_pack_track_records.argtypes = [vp, vp, vp]
     L.esvio_fe_set_lazy_new_stereo.argtypes = [vp, i]
     L.esvio_fe_set_host_threads.argtypes = [vp, i]
+    L.esvio_fe_ransac_stats.argtypes = [vp, i]
     L.esvio_fe_find_fundamental_mat_mt.argtypes = [vp, vp, i, d, d, i, vp, C.POINTER(C.c_int32)]
     L.esvio_fe_finish.argtypes = [vp, vp]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
@@ -579,6 +580,18 @@ def comm_unique_id():
     if rc:
         raise FrontendError("esvio_fe_comm_unique_id rc=%d (librccl.so not found?)" % rc)
     return bytes(buf)
+
+
+def ransac_stats(reset=False):
+    """process-wide counters of the host findFundamentalMat: RANSAC branch dict(calls, iterations,
+    points, us) + LMedS branch (lmeds_calls, lmeds_us)"""
+    out = (C.c_uint64 * 6)()
+    L = load_library()
+    rc = L.esvio_fe_ransac_stats(out, 1 if reset else 0)
+    if rc != 0:
+        raise FrontendError("ransac_stats rc=%d" % rc)
+    return {"calls": int(out[0]), "iterations": int(out[1]), "points": int(out[2]), "us": out[3] / 1e3,
+            "lmeds_calls": int(out[4]), "lmeds_us": out[5] / 1e3}
 
 
 def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99, threads=1):

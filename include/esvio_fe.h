@@ -160,6 +160,10 @@ int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, doubl
  * pool; test tap for esvio_fe_set_host_threads): status and count are those of the call above. */
 int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, double thr,
                                      double conf, int threads, uint8_t* status, int32_t* n_inliers);
+/* Measurement tap: process-wide counters of that function since the last reset — out6 = {calls,
+ * loop iterations, points, nanoseconds inside the calls} of its RANSAC branch (>= 15 points) and
+ * {calls, nanoseconds} of its LMedS branch (8..14 points, what OpenCV runs below 15). */
+int esvio_fe_ransac_stats(uint64_t* out6, int reset);
 /* camodocal PinholeCamera::liftProjective (PinholeCamera.cc:450-510); host-side. */
 int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, double* out3);
 

@@ -115,6 +115,41 @@ def test_product_matches_oracle_with_opencv_basis(oracle):
         assert cnt == ocnt and np.array_equal(status, ostatus), seed
 
 
+def test_lmeds_sizes_match_oracle_with_and_without_helpers(oracle):
+    """8..14 points: OpenCV runs LMedS there (300 hypotheses at confidence 0.99).  The product draws
+    all subsets first and solves them 8 at a time, on helper threads too; flags and count are those
+    of the oracle's plain loop."""
+    for seed in range(60):
+        n = 8 + seed % 7
+        p1, p2, _, _ = two_view(n, seed % 3, [0.0, 0.1, 0.3][seed % 3], 5100 + seed)
+        ocnt, ostatus = oracle.find_fundamental(p1, p2, 1.0, 0.99)[:2]
+        for threads in (1, 3):
+            cnt, status = FE.find_fundamental_mat(p1, p2, 1.0, 0.99, threads=threads)
+            assert cnt == ocnt and np.array_equal(status, ostatus), (seed, n, threads)
+    before = FE.ransac_stats()
+    FE.find_fundamental_mat(p1, p2, 1.0, 0.99)
+    after = FE.ransac_stats()
+    assert after["lmeds_calls"] == before["lmeds_calls"] + 1 and after["calls"] == before["calls"]
+
+
+def _small_motion_view(n, n_out, sigma, seed, scale):
+    """two_view with the camera motion scaled down: `scale` 0.01 moves the points ~0.35 px between the
+    views — the regime of consecutive 30 Hz time surfaces, where the 7x9 system is close to rank 6"""
+    rng = np.random.default_rng(seed)
+    K = np.array([[460.0, 0, 320], [0, 460, 240], [0, 0, 1]])
+    from test_ransac_kat import _rot
+    R = _rot(*(rng.uniform(-0.05, 0.05, 3) * scale))
+    t = (rng.uniform(-0.3, 0.3, 3) + np.array([0.25, 0, 0])) * scale
+    X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(3, 9, n)], 1)
+    x1, x2 = (K @ X.T).T, (K @ (R @ X.T + t[:, None])).T
+    p1, p2 = x1[:, :2] / x1[:, 2:], x2[:, :2] / x2[:, 2:]
+    for i in range(n - n_out, n):
+        p2[i] += rng.normal(0, 1, 2) / np.sqrt(2) * rng.uniform(4, 40)
+    p1 = p1 + rng.normal(0, sigma, p1.shape)
+    p2 = p2 + rng.normal(0, sigma, p2.shape)
+    return p1.astype(np.float32), p2.astype(np.float32)
+
+
 def test_what_the_basis_moves(oracle, capsys):
     """Same RANSAC loop, same draws; only the basis of the null plane differs.  The F candidates are
     the roots of the same cubic, so they agree to rounding and flags differ only where a point's
@@ -138,7 +173,27 @@ def test_what_the_basis_moves(oracle, capsys):
     finally:
         oracle.set_nullspace_mode(0)
     with capsys.disabled():
-        print("\n[null-space basis] scenes with any differing flag: %d / %d; flags: %d / %d (%.3f %%)"
-              % (flipped_scenes, scenes, flipped_points, points, 100.0 * flipped_points / points))
-    # the basis is a rounding-level choice: most scenes are untouched
-    assert flipped_scenes <= scenes // 3
+        print("\n[null-space basis] 29 px motion: scenes with any differing flag: %d / %d; flags: %d / %d"
+              % (flipped_scenes, scenes, flipped_points, points))
+    # well-conditioned systems: the basis is a rounding-level choice
+    assert flipped_scenes <= scenes // 10
+    # ... but consecutive event frames move the points by less than a pixel; the 7x9 system is then
+    # nearly rank 6, its null plane is determined to far fewer digits, and the basis decides flags
+    small = small_scenes = small_flags = 0
+    try:
+        for seed in range(150):
+            p1, p2 = _small_motion_view(200, 30, 0.1, 40000 + seed, 0.01)
+            oracle.set_nullspace_mode(0)
+            s0 = oracle.find_fundamental(p1, p2, 1.0, 0.99)[1]
+            oracle.set_nullspace_mode(1)
+            s1 = oracle.find_fundamental(p1, p2, 1.0, 0.99)[1]
+            small += 1
+            d = int((s0 != s1).sum())
+            small_flags += d
+            small_scenes += d > 0
+    finally:
+        oracle.set_nullspace_mode(0)
+    with capsys.disabled():
+        print("[null-space basis] 0.35 px motion: scenes with any differing flag: %d / %d; flags: %d / %d"
+              % (small_scenes, small, small_flags, small * 200))
+    assert small_scenes >= 1  # (why the product follows cv::SVD's route instead of a cheaper basis)
