@@ -7,10 +7,8 @@ so their agreement with each other (tests/test_abi.py) pins neither.
 What these tests can and cannot say: a RANSAC run returns the consensus set of the best 7-point
 hypothesis; with noise-free inliers and outliers placed > 3 px off their epipolar lines that set is
 the true inlier set for ANY correct implementation (the seed only changes which all-inlier sample
-finds it).  With pixel noise the set depends on the hypothesis drawn; then only bounds hold.  Against
-real OpenCV the 7-point null space (SVD there, Householder QR here) flips knife-edge decisions —
-points whose epipolar distance is within float rounding of the 1 px threshold; the noise-free cases
-below have no such points, the noisy ones count them."""
+finds it).  With pixel noise the set depends on the hypothesis drawn; then only bounds hold.  (The
+7-point solver's null space follows cv::SVDecomp — tests/test_ransac_nullspace.py.)"""
 import numpy as np
 import pytest
 
