@@ -342,12 +342,36 @@ def main():
             if multi and not time_split and not lib_exchange else None)
     comm_id = None
     if lib_exchange:
-        box = [FE.comm_unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = FE.comm_unique_id()
+            except FE.FrontendError as e:  # (no librccl to dlopen: every rank takes the torch.distributed path)
+                print("bench: %s; exchanging through torch.distributed instead" % e, file=sys.stderr)
         dist.broadcast_object_list(box, src=0)
         comm_id = box[0]
     pipeline = not args.no_pipeline and not one_rig
     lazy = pipeline and not args.no_lazy
-    main_run = Runner(pipeline, lazy, dev_batches, exch=exch, comm=comm_id)
+    try:
+        main_run = Runner(pipeline, lazy, dev_batches, exch=exch, comm=comm_id)
+        comm_ok = 1.0
+    except FE.FrontendError as e:
+        if comm_id is None:
+            raise
+        print("bench: rank %d: esvio_fe_comm_init failed (%s)" % (rank, e), file=sys.stderr)
+        main_run = Runner(pipeline, lazy, dev_batches, exch=exch, comm=None)
+        comm_ok = 0.0
+    if lib_exchange:
+        # the library communicator is used only if every rank has it; otherwise all ranks exchange
+        # through torch.distributed (RCCL as well), so that the collectives still match up
+        flag = torch.tensor([comm_ok if comm_id is not None else 0.0], device=xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 1.0:
+            comm_id = None
+            main_run.comm = False
+            main_run.ft.set_auto_exchange(False)
+            main_run.exch = exch = TrackExchange(cfg.max_cnt, world, device=xdev, dist=dist,
+                                                 stream=torch.cuda.Stream() if xdev == "cuda" else None)
     ft = main_run.ft
     if cam_split:
         main_run.rig = CameraSplitRig(ft, rank, dist, device=xdev)
