@@ -1165,15 +1165,15 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
 // iteration order.
 int lmeds_pooled(RansacPool* P, const float* m1, const float* m2, int count, double conf, uint8_t* status) {
   const int kModelPoints = 7;
-  const int niters = update_num_iters(conf, 0.45, kModelPoints, kRansacMaxIters);
+  const int niters = std::max(update_num_iters(conf, 0.45, kModelPoints, kRansacMaxIters), 3);
   const uint32_t e = P->epoch.load(std::memory_order_relaxed) + 1;
   RansacJob& J = P->job[(e >> 1) & 1];
   while (J.active.load(std::memory_order_acquire) != 0) cpu_relax();
   OcvRng rng;
   float s1[14], s2[14];
   int nsub = 0;
-  for (; nsub < niters; nsub++)
-    if (!draw_subset(m1, m2, count, s1, s2, rng, 300, &J.picks[(size_t)nsub * 8])) break;
+  for (; nsub < niters; nsub++)  // (getSubset's default of 1000 attempts; the RANSAC loop passes 10000)
+    if (!draw_subset(m1, m2, count, s1, s2, rng, 1000, &J.picks[(size_t)nsub * 8])) break;
   if (nsub == 0) return 0;
   J.pts.resize(4 * (size_t)count);
   std::memcpy(J.pts.data(), m1, 2 * (size_t)count * sizeof(float));

@@ -1412,10 +1412,11 @@ int find_fundamental(const float* m1, const float* m2, int count, double thr, do
   // LMeDSPointSetRegistrator::run
   const double outlierRatio = 0.45;
   int niters = ransac_update_num_iters(conf, outlierRatio, modelPoints, maxIters);
+  niters = std::max(niters, 3);
   double minMedian = DBL_MAX;
   std::vector<float> errs(count);
   for (int iter = 0; iter < niters; iter++) {
-    bool found = get_subset(m1, m2, count, ms1, ms2, rng, 300);
+    bool found = get_subset(m1, m2, count, ms1, ms2, rng, 1000);  // getSubset's default maxAttempts
     if (!found) {
       if (iter == 0) return 0;
       break;
