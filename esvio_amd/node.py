@@ -95,13 +95,67 @@ def pack_track_records(ft, max_cnt):
     return rec
 
 
+class MotionCorrection:
+    """The node's side of motion compensation (Do_motion_correction: 1): imu_callback / state_callback
+    (stereo_event_tracker_node.cpp:102-125) fill two queues, handle_stereo_event (node:195-252)
+    builds the Motion_correction_value of a batch from them.  ``value(...)`` returns the arguments of
+    ``frontend.make_motion`` / ``oracle.make_motion``.
+
+    Where the reference leaves a local uninitialised — State_ and temp_a when the back end has sent no
+    new odometry, omega_avg_ when there is no IMU message at or after the batch's first event — the
+    field is zero here; zero acceleration is below the warp's threshold."""
+
+    def __init__(self, fx, fy, cx, cy):
+        self.K = (float(fx), float(fy), float(cx), float(cy))  # the YAML's fx, fy, cx, cy (parameters.cpp:221-224)
+        self.imu_buf = []
+        self.odom_buffer_ = []
+        self.last_imu_t = 0.0
+        self.v_cur = np.zeros(3, np.float32)  # file-scope Eigen::Vector3f (node:48-49): zero at start
+        self.v_pre = np.zeros(3, np.float32)
+        self.t_pre = 0.0
+        self.t_cur = 0.0
+
+    def imu_callback(self, stamp, angular_velocity, linear_acceleration=(0.0, 0.0, 0.0)):
+        if stamp <= self.last_imu_t:  # "imu message in disorder!"
+            return
+        self.last_imu_t = stamp
+        self.imu_buf.append((float(stamp), tuple(map(float, angular_velocity)), tuple(map(float, linear_acceleration))))
+
+    def state_callback(self, stamp, linear_velocity):
+        self.odom_buffer_.append((float(stamp), tuple(map(float, linear_velocity))))
+
+    def value(self, t_left_0, t_left_1):
+        v = np.zeros(3, np.float64)
+        accel = np.zeros(3, np.float32)
+        omega = np.zeros(3, np.float32)
+        if self.imu_buf:
+            if self.odom_buffer_:
+                t, vel = self.odom_buffer_.pop(0)
+                v[:] = vel
+                self.v_pre = self.v_cur.copy()
+                self.v_cur = v.astype(np.float32)
+                self.t_pre, self.t_cur = self.t_cur, t
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    # (float - float) / double, stored to a float
+                    accel = ((self.v_cur - self.v_pre).astype(np.float64) / (self.t_cur - self.t_pre)).astype(np.float32)
+            while self.imu_buf and self.imu_buf[0][0] < t_left_0:
+                self.imu_buf.pop(0)
+            if self.imu_buf:
+                omega = np.asarray(self.imu_buf[0][1], np.float64).astype(np.float32)
+        return dict(t1=float(t_left_1), v=tuple(v), v_pre=tuple(self.v_pre), accel=tuple(accel),
+                    omega=tuple(omega), fx=self.K[0], fy=self.K[1], cx=self.K[2], cy=self.K[3])
+
+
 class StereoEventTrackerNode:
     """handle_stereo_event (node:145-344).  ``handle(left, right, msg_timestamp)`` returns the
     published PointCloud rows or None (first frame, reset, non-published frame, swallowed first
-    publish)."""
+    publish).  With ``motion`` (a MotionCorrection and the module whose ``make_motion`` builds the
+    tracker's argument) the batch takes the motion-compensated trackEvent (node:194-254)."""
 
-    def __init__(self, tracker, freq, reset_tracker_on_restart=False):
+    def __init__(self, tracker, freq, reset_tracker_on_restart=False, motion=None, make_motion=None):
         self.trackerData = tracker
+        self.motion = motion
+        self.make_motion = make_motion
         self.freq = freq
         # NOT reference behaviour (kept for callers that own both ends): also clear the tracker when
         # the stream is discontinuous.  The reference only re-arms the node and publishes `restart`.
@@ -115,7 +169,9 @@ class StereoEventTrackerNode:
         self.restart_count = 0
         self.FREQ = freq if freq != 0 else 100
 
-    def handle(self, event_left, event_right, msg_timestamp):
+    def handle(self, event_left, event_right, msg_timestamp, header_stamp=None):
+        """header_stamp: event_left.header.stamp (only read with motion compensation; default
+        msg_timestamp, which is what sync_process passes: the same stamp)"""
         self.restart_flag = False
         if len(event_left) == 0:  # node:150
             return None
@@ -145,7 +201,12 @@ class StereoEventTrackerNode:
         else:
             pub = False
         msg_timestamp_left = event_times(event_left[-1:])[0]  # node:190
-        self.trackerData.trackEvent(msg_timestamp_left, event_left, event_right, pub)
+        if self.motion is None:
+            self.trackerData.trackEvent(msg_timestamp_left, event_left, event_right, pub)
+        else:
+            t_left_1 = msg_timestamp if header_stamp is None else header_stamp
+            mv = self.make_motion(**self.motion.value(event_times(event_left[:1])[0], t_left_1))
+            self.trackerData.trackEvent(msg_timestamp_left, event_left, event_right, pub, measurements=mv)
         if not pub:
             return None
         self.pub_count += 1

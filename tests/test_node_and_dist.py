@@ -106,6 +106,63 @@ def test_handle_stereo_event_flow():
     assert tr2.resets == 1
 
 
+def test_motion_correction_value_assembly():
+    """node:102-125,195-252 by hand: the velocity pair and the acceleration come from the last two
+    odometry messages (one consumed per batch), omega from the first IMU message not older than the
+    batch's first event; IMU messages out of order are dropped; nothing is assembled without IMU."""
+    from esvio_amd.node import MotionCorrection
+    mc = MotionCorrection(300.0, 301.0, 160.0, 120.0)
+    # no IMU yet: everything zero (the reference's locals are uninitialised there), odometry untouched
+    mc.state_callback(9.0, (1.0, 2.0, 3.0))
+    v = mc.value(10.0, 10.03)
+    assert v["t1"] == 10.03 and v["v"] == (0.0, 0.0, 0.0) and v["accel"] == (0.0, 0.0, 0.0)
+    assert v["omega"] == (0.0, 0.0, 0.0) and len(mc.odom_buffer_) == 1
+    assert (v["fx"], v["fy"], v["cx"], v["cy"]) == (300.0, 301.0, 160.0, 120.0)
+    # IMU: one before the batch, one inside, one out of order (dropped)
+    mc.imu_callback(9.99, (0.1, 0.2, 0.3))
+    mc.imu_callback(10.01, (0.4, 0.5, 0.6))
+    mc.imu_callback(10.005, (9.0, 9.0, 9.0))
+    assert len(mc.imu_buf) == 2
+    v = mc.value(10.0, 10.03)
+    # first odometry message: v_pre = old v_cur = 0, v_cur = (1,2,3), t_pre = 0, t_cur = 9 -> a = v / 9
+    assert v["v"] == (1.0, 2.0, 3.0) and v["v_pre"] == (0.0, 0.0, 0.0)
+    assert v["accel"] == tuple(np.float32(x / 9.0) for x in (1.0, 2.0, 3.0))
+    assert v["omega"] == tuple(np.float32(x) for x in (0.4, 0.5, 0.6))  # 9.99 < t_left_0 was popped
+    assert len(mc.imu_buf) == 1 and not mc.odom_buffer_
+    # second odometry message 0.1 s later: a = (float32 difference) / 0.1 as float32
+    mc.state_callback(9.1, (1.7, 1.4, 3.05))
+    v = mc.value(10.033, 10.066)
+    d = np.float32([1.7, 1.4, 3.05]) - np.float32([1.0, 2.0, 3.0])
+    want = tuple((d.astype(np.float64) / (9.1 - 9.0)).astype(np.float32))
+    assert v["accel"] == want and v["v_pre"] == (1.0, 2.0, 3.0) and v["v"] == (1.7, 1.4, 3.05)
+    assert v["omega"] == (0.0, 0.0, 0.0) and not mc.imu_buf  # the 10.01 message is older than this batch
+    # no new odometry: State_ / temp_a are zero, the previous velocity persists
+    mc.imu_callback(10.07, (1.0, 1.0, 1.0))
+    v = mc.value(10.066, 10.1)
+    assert v["v"] == (0.0, 0.0, 0.0) and v["accel"] == (0.0, 0.0, 0.0) and v["v_pre"] == (1.0, 2.0, 3.0)
+    assert v["omega"] == (1.0, 1.0, 1.0)
+
+
+def test_node_passes_the_motion_value_to_the_tracker():
+    from esvio_amd.node import MotionCorrection
+
+    class Tr(_StubTracker):
+        def trackEvent(self, t, L, R, pub, measurements=None):
+            self.calls.append((t, len(L), len(R), pub, measurements))
+
+    tr = Tr()
+    mc = MotionCorrection(1.0, 2.0, 3.0, 4.0)
+    node = StereoEventTrackerNode(tr, freq=15, motion=mc, make_motion=lambda **kw: kw)
+    ev = make_events([1, 2], [1, 2], [5_000_000, 5_010_000], [1, 0])
+    mc.imu_callback(5.005, (0.5, 0.0, -0.5))
+    mc.state_callback(4.9, (1.0, 0.0, 0.0))
+    node.handle(ev, ev, 5.0)
+    node.handle(ev, ev, 5.0333, header_stamp=5.02)
+    m = tr.calls[-1][4]
+    assert m["t1"] == 5.02 and m["v"] == (1.0, 0.0, 0.0) and m["omega"] == (0.5, 0.0, -0.5)
+    assert m["fx"] == 1.0 and m["cy"] == 4.0
+
+
 def test_freq_control_rounds_like_c():
     """node:177 calls C round(): half away from zero.  pub_count / dt = 10.5 at FREQ 10 must NOT
     publish (round -> 11); Python's round() would give 10 and publish."""

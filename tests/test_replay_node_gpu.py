@@ -36,11 +36,16 @@ def _messages():
 
 
 def _write_log(path, msgs):
+    """kinds 0/1: (kind, stamp, events); 2: (2, stamp, 6 doubles — IMU); 3: (3, stamp, 3 doubles — odometry)"""
+    version = 2 if any(m[0] > 1 for m in msgs) else 1
     with open(path, "wb") as f:
-        f.write(b"ESVB" + struct.pack("<IIII", 1, W, H, len(msgs)))
-        for cam, stamp, ev in msgs:
-            f.write(struct.pack("<BBBBId", cam, 0, 0, 0, len(ev), stamp))
-            f.write(np.ascontiguousarray(ev).tobytes())
+        f.write(b"ESVB" + struct.pack("<IIII", version, W, H, len(msgs)))
+        for kind, stamp, body in msgs:
+            f.write(struct.pack("<BBBBId", kind, 0, 0, 0, len(body), stamp))
+            if kind <= 1:
+                f.write(np.ascontiguousarray(body).tobytes())
+            else:
+                f.write(np.asarray(body, np.float64).tobytes())
 
 
 def _read_dump(path):
@@ -62,12 +67,52 @@ def _c_round(x):
     return r + 1 if x - r >= 0.5 else r
 
 
-def _oracle_node(oracle, msgs):
+class _Imu:
+    """imu_callback / state_callback and the Motion_correction_value of node:102-125,195-252, restated
+    for the oracle side (float32 where the node holds Eigen::Vector3f; zeros where it leaves locals
+    uninitialised)"""
+
+    def __init__(self, K):
+        self.K, self.imu, self.odo, self.last = K, [], [], 0.0
+        self.v_cur = np.zeros(3, np.float32)
+        self.v_pre = np.zeros(3, np.float32)
+        self.t_pre = self.t_cur = 0.0
+
+    def deliver(self, kind, stamp, body):
+        if kind == 2:
+            if stamp > self.last:
+                self.last = stamp
+                self.imu.append((stamp, body[:3]))
+        else:
+            self.odo.append((stamp, body))
+
+    def value(self, oracle, L, header_stamp):
+        t0 = event_times(L[:1])[0]
+        v, a, w = np.zeros(3), np.zeros(3, np.float32), np.zeros(3, np.float32)
+        if self.imu:
+            if self.odo:
+                t, vel = self.odo.pop(0)
+                v = np.asarray(vel, np.float64)
+                self.v_pre, self.v_cur = self.v_cur, v.astype(np.float32)
+                self.t_pre, self.t_cur = self.t_cur, t
+                a = ((self.v_cur - self.v_pre).astype(np.float64) / (self.t_cur - self.t_pre)).astype(np.float32)
+            while self.imu and self.imu[0][0] < t0:
+                self.imu.pop(0)
+            if self.imu:
+                w = np.asarray(self.imu[0][1], np.float64).astype(np.float32)
+        return oracle.make_motion(header_stamp, v=v, v_pre=self.v_pre, accel=a, omega=w, fx=self.K[0],
+                                  fy=self.K[1], cx=self.K[2], cy=self.K[3])
+
+
+def _oracle_node(oracle, msgs, mc_K=None):
     """stereo_event_tracker_node.cpp:372-418 (pairing) and :145-344 (handle_stereo_event), restated
-    here, over the oracle tracker"""
+    here, over the oracle tracker.  mc_K: Do_motion_correction with these fx, fy, cx, cy."""
     tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **KW))
+    imu = _Imu(mc_K) if mc_K else None
     ql, qr, pairs = [], [], []
-    for cam, stamp, ev in msgs:
+    for mi, (cam, stamp, ev) in enumerate(msgs):
+        if cam > 1:
+            continue
         (ql if cam == 0 else qr).append((stamp, ev))
         while ql and qr:
             tl, trr = ql[0][0], qr[0][0]
@@ -76,10 +121,15 @@ def _oracle_node(oracle, msgs):
             elif tl > trr + 0.2:
                 qr.pop(0)
             else:
-                pairs.append((ql.pop(0), qr.pop(0)))
+                pairs.append((ql.pop(0), qr.pop(0), mi))
     first, first_t, last_t, pub_count, init_pub = True, 0.0, 0.0, 1, False
     out = []
-    for (stamp, L), (_, R) in pairs:
+    delivered = 0
+    for (stamp, L), (_, R), ready in pairs:
+        while delivered < ready:  # callbacks in log order; the pair is handled when it is complete
+            if msgs[delivered][0] > 1 and imu:
+                imu.deliver(*msgs[delivered])
+            delivered += 1
         if len(L) == 0:
             continue
         if first:
@@ -94,7 +144,10 @@ def _oracle_node(oracle, msgs):
         pub = _c_round(rate) <= FREQ
         if pub and abs(rate - FREQ) < 0.01 * FREQ:
             first_t, pub_count = stamp, 0
-        r = tr.track_event(event_times(L)[-1], L, R, pub)
+        if imu is None:
+            r = tr.track_event(event_times(L)[-1], L, R, pub)
+        else:
+            r = tr.track_event(event_times(L)[-1], L, R, pub, motion=imu.value(oracle, L, stamp))
         rows = np.zeros((0, 8), np.float32)
         published = 0
         if pub:
@@ -153,3 +206,42 @@ def test_replay_node_matches_the_oracle_node(oracle, tmp_path):
             assert np.array_equal(g[3].view(np.uint32), r[3].view(np.uint32)), (name, k)
         if name == "rccl":
             assert " 0 RCCL exchanges" not in stdout, stdout
+
+
+def test_replay_node_motion_compensation(oracle, tmp_path):
+    """Do_motion_correction: 1 — the harness assembles the Motion_correction_value from logged IMU and
+    back-end odometry messages (node:102-125,195-252) and calls esvio_fe_track_event_mc.  The IMU
+    runs at 200 Hz with one message out of order; the back end reports a velocity per batch that
+    jumps, so that some batches exceed the 5 m/s^2 gate and are warped and others are not."""
+    ev_msgs = _messages()[:28]
+    K = (0.9 * W, 0.9 * W, W / 2.0 + 2.5, H / 2.0 - 1.25)
+    rng = np.random.default_rng(3)
+    msgs, t_imu, k_odo = [], None, 0
+    for cam, stamp, ev in ev_msgs:
+        if cam == 0:
+            t0 = event_times(ev[:1])[0]
+            if t_imu is None:
+                t_imu = t0 - 0.01
+            while t_imu < stamp:  # IMU messages up to this batch's stamp
+                msgs.append((2, t_imu, list(rng.uniform(-0.3, 0.3, 3)) + [0.0, 0.0, 9.8]))
+                if len(msgs) % 37 == 0:
+                    msgs.append((2, t_imu - 0.002, [9.0, 9.0, 9.0, 0, 0, 0]))  # out of order: dropped
+                t_imu += 0.005
+            if k_odo % 5 != 4:  # (every fifth batch comes without a new back-end state)
+                jump = 0.3 if k_odo % 2 else 0.02
+                msgs.append((3, stamp - 0.004, [0.4 + jump, -0.2 - jump / 2, 0.1 * (k_odo % 3)]))
+            k_odo += 1
+        msgs.append((cam, stamp, ev))
+    log = str(tmp_path / "log_mc.esvb")
+    _write_log(log, msgs)
+    ref = _oracle_node(oracle, msgs, mc_K=K)
+    plain = _oracle_node(oracle, msgs)
+    assert sum(f[2] for f in ref) >= 4
+    # the warp matters: the published rows differ from those of the uncompensated node
+    assert any(a[3].shape != b[3].shape or not np.array_equal(a[3], b[3]) for a, b in zip(ref, plain))
+    got, stdout = _run(tmp_path, log, "mc", "mc=1", "fx=%r" % K[0], "fy=%r" % K[1], "cx=%r" % K[2], "cy=%r" % K[3])
+    assert len(got) == len(ref), (len(got), len(ref), stdout)
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert g[:3] == r[:3], (k, g[:3], r[:3])
+        assert g[3].shape == r[3].shape, k
+        assert np.array_equal(g[3].view(np.uint32), r[3].view(np.uint32)), k

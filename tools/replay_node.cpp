@@ -7,13 +7,20 @@
 //   replay_node <log.esvb> <dump.bin> [key=value ...]
 //
 // keys: max_cnt min_dist freq equalize flow_back f_threshold f_ransac decay_ms filter_thr
+//       mc (1: Do_motion_correction — the Motion_correction_value of node:192-254 is assembled from the
+//       logged IMU / odometry messages and the batch goes through esvio_fe_track_event_mc; ahead = 0)
+//       fx fy cx cy (the YAML's intrinsics the warp uses; default: the left camera's)
 //       ahead (0: one batch in flight like the reference; 1..3: esvio_fe_set_next_batch replay mode)
 //       lazy threads  (throughput options, results identical)   rccl (1: also all-gather every
 //       published frame's records over a one-rank RCCL communicator, esvio_fe_exchange_tracks)
 //
-// Log format (little endian): "ESVB" u32 version=1 u32 width u32 height u32 n_messages, then per
-// message: u8 cam (0 left, 1 right) u8 pad[3] u32 n_events f64 header_stamp, n_events x 16 B
-// dvs_msgs::Event records (esvio_fe_event).
+// Log format (little endian): "ESVB" u32 version (1 or 2) u32 width u32 height u32 n_messages, then
+// per message: u8 kind u8 pad[3] u32 n f64 header_stamp and
+//   kind 0 / 1  dvs_msgs/EventArray of the left / right camera: n x 16 B dvs_msgs::Event (esvio_fe_event)
+//   kind 2      sensor_msgs/Imu (version 2): n = 6 f64 — angular_velocity xyz, linear_acceleration xyz
+//   kind 3      nav_msgs/Odometry of the back end (version 2): n = 3 f64 — twist.twist.linear xyz
+// Messages are delivered to the callbacks in log order; a left/right pair is handled as soon as its
+// second message has arrived (the reference's spinner and sync_process threads interleave freely).
 // Dump format: "ESVD" u32 n_frames, per frame: f64 stamp u8 restart_flag u8 published u8 pad[2]
 // u32 n_rows, n_rows x 8 f32 (x_un, y_un, 1, id*2+cam, u, v, vx, vy).
 //
@@ -41,6 +48,13 @@ struct EventArray {  // dvs_msgs::EventArray: header.stamp + events
   std::vector<esvio_fe_event> events;
 };
 
+struct ImuMsg {  // sensor_msgs::Imu: header.stamp, angular_velocity, linear_acceleration
+  double stamp, w[3], a[3];
+};
+struct OdomMsg {  // nav_msgs::Odometry: header.stamp, twist.twist.linear
+  double stamp, v[3];
+};
+
 struct Frame {
   double stamp;
   uint8_t restart, published;
@@ -57,6 +71,14 @@ struct Node {
   bool first_image_flag = true, init_pub = false, PUB_THIS_FRAME = false;
   double first_image_time = 0, last_image_time = 0;
   int pub_count = 1;
+  // motion compensation (node:33-34,48-50,102-125): the IMU and back-end odometry queues, the last
+  // two velocities the back end reported and their times (file-scope objects: zero at start)
+  bool Do_motion_correction = false;
+  double K[4] = {0, 0, 0, 0};  // fx, fy, cx, cy of the YAML
+  std::deque<ImuMsg> imu_buf;
+  std::deque<OdomMsg> odom_buffer_;
+  double last_imu_t = 0, t_pre = 0, t_cur = 0;
+  float v_cur[3] = {0, 0, 0}, v_pre[3] = {0, 0, 0};
   // result buffers (what the node reads from FeatureTracker's public members, node:289-322)
   std::vector<int32_t> ids, track_cnt, ids_right;
   std::vector<float> cur_pts, cur_un_pts, pts_velocity, cur_right_pts, cur_un_right_pts, right_pts_velocity;
@@ -78,6 +100,46 @@ struct Node {
     tr.cur_un_pts = cur_un_pts.data(); tr.pts_velocity = pts_velocity.data(); tr.ids_right = ids_right.data();
     tr.cur_right_pts = cur_right_pts.data(); tr.cur_un_right_pts = cur_un_right_pts.data();
     tr.right_pts_velocity = right_pts_velocity.data();
+  }
+
+  void imu_callback(const ImuMsg& m) {  // node:109-125
+    if (m.stamp <= last_imu_t) return;  // "imu message in disorder!"
+    last_imu_t = m.stamp;
+    imu_buf.push_back(m);
+  }
+  void state_callback(const OdomMsg& m) { odom_buffer_.push_back(m); }  // node:102-107
+
+  // The Motion_correction_value of node:195-252 as an esvio_fe_motion.  Where the reference leaves a
+  // local uninitialised (State_ and temp_a without a new odometry message, omega_avg_ without an IMU
+  // message at or after the batch's first event) the field is zero here: zero acceleration is below
+  // a_motion_compensation_threshold, i.e. the batch is not warped.
+  esvio_fe_motion motion_value(const EventArray& L) {
+    esvio_fe_motion mo{};
+    const double t_left_0 = to_sec(L.events[0]);
+    mo.t1 = L.stamp;  // t_left_1 = event_left.header.stamp (trackEvent re-reads both times itself, :621-622)
+    if (!imu_buf.empty()) {
+      if (!odom_buffer_.empty()) {
+        const OdomMsg o = odom_buffer_.front();
+        odom_buffer_.pop_front();
+        for (int i = 0; i < 3; i++) {
+          mo.v[i] = o.v[i];      // State_[0..2] = temp_v (doubles)
+          v_pre[i] = v_cur[i];   // Vector3f
+          v_cur[i] = (float)o.v[i];
+        }
+        t_pre = t_cur;
+        t_cur = o.stamp;
+        for (int i = 0; i < 3; i++) mo.accel[i] = (float)((double)(v_cur[i] - v_pre[i]) / (t_cur - t_pre));
+      }
+      while (!imu_buf.empty() && imu_buf.front().stamp < t_left_0) imu_buf.pop_front();
+      if (!imu_buf.empty())
+        for (int i = 0; i < 3; i++) mo.omega[i] = (float)imu_buf.front().w[i];
+    }
+    for (int i = 0; i < 3; i++) mo.v_pre[i] = v_pre[i];
+    mo.fx = K[0];  // detector.init(COL, ROW, fx, fy, cx, cy) (feature_tracker.cpp:616): the YAML's
+    mo.fy = K[1];  // fx, fy, cx, cy (parameters.cpp:221-224)
+    mo.cx = K[2];
+    mo.cy = K[3];
+    return mo;
   }
 
   // the frequency-control decision of node:177-188 for a frame at `t` — `commit` false: only look
@@ -133,8 +195,15 @@ struct Node {
         announced_ahead++;
       }
     }
-    int rc = esvio_fe_track_event(h, msg_timestamp_left, L.events.data(), L.events.size(), R.events.data(),
-                                  R.events.size(), ESVIO_FE_HOST, PUB_THIS_FRAME ? 1 : 0, &tr);
+    int rc;
+    if (!Do_motion_correction) {  // node:192-193
+      rc = esvio_fe_track_event(h, msg_timestamp_left, L.events.data(), L.events.size(), R.events.data(),
+                                R.events.size(), ESVIO_FE_HOST, PUB_THIS_FRAME ? 1 : 0, &tr);
+    } else {  // node:194-254
+      const esvio_fe_motion mo = motion_value(L);
+      rc = esvio_fe_track_event_mc(h, msg_timestamp_left, L.events.data(), L.events.size(), R.events.data(),
+                                   R.events.size(), ESVIO_FE_HOST, PUB_THIS_FRAME ? 1 : 0, &mo, &tr);
+    }
     if (rc) return rc;
     if (announced_ahead > 0) announced_ahead--;
     if (PUB_THIS_FRAME) {
@@ -179,12 +248,20 @@ struct Node {
   int announced_ahead = 0;
 };
 
-bool read_log(const char* path, int* W, int* H, std::vector<std::pair<int, EventArray>>* msgs) {
+struct Message {  // one logged message of any kind
+  int kind = 0;
+  EventArray ev;  // kinds 0, 1
+  ImuMsg imu{};   // kind 2
+  OdomMsg odom{}; // kind 3
+};
+
+bool read_log(const char* path, int* W, int* H, std::vector<Message>* msgs) {
   FILE* fp = fopen(path, "rb");
   if (!fp) return false;
   char magic[4];
   uint32_t hdr[4];
-  if (fread(magic, 1, 4, fp) != 4 || std::memcmp(magic, "ESVB", 4) != 0 || fread(hdr, 4, 4, fp) != 4 || hdr[0] != 1) {
+  if (fread(magic, 1, 4, fp) != 4 || std::memcmp(magic, "ESVB", 4) != 0 || fread(hdr, 4, 4, fp) != 4 ||
+      (hdr[0] != 1 && hdr[0] != 2)) {
     fclose(fp);
     return false;
   }
@@ -195,11 +272,25 @@ bool read_log(const char* path, int* W, int* H, std::vector<std::pair<int, Event
     uint32_t n;
     double stamp;
     if (fread(cam, 1, 4, fp) != 4 || fread(&n, 4, 1, fp) != 1 || fread(&stamp, 8, 1, fp) != 1) break;
-    EventArray a;
-    a.stamp = stamp;
-    a.events.resize(n);
-    if (n && fread(a.events.data(), 16, n, fp) != n) break;
-    msgs->emplace_back((int)cam[0], std::move(a));
+    Message m;
+    m.kind = (int)cam[0];
+    if (m.kind <= 1) {
+      m.ev.stamp = stamp;
+      m.ev.events.resize(n);
+      if (n && fread(m.ev.events.data(), 16, n, fp) != n) break;
+    } else if (m.kind == 2 && n == 6 && hdr[0] >= 2) {
+      double v[6];
+      if (fread(v, 8, 6, fp) != 6) break;
+      m.imu = ImuMsg{stamp, {v[0], v[1], v[2]}, {v[3], v[4], v[5]}};
+    } else if (m.kind == 3 && n == 3 && hdr[0] >= 2) {
+      double v[3];
+      if (fread(v, 8, 3, fp) != 3) break;
+      m.odom = OdomMsg{stamp, {v[0], v[1], v[2]}};
+    } else {
+      fclose(fp);
+      return false;
+    }
+    msgs->push_back(std::move(m));
   }
   fclose(fp);
   return true;
@@ -215,14 +306,14 @@ int main(int argc, char** argv) {
   std::map<std::string, double> kv = {{"max_cnt", 300}, {"min_dist", 10},   {"freq", 15},     {"equalize", 0},
                                       {"flow_back", 1}, {"f_threshold", 1}, {"f_ransac", 1},  {"decay_ms", 20},
                                       {"filter_thr", 0.01}, {"ahead", 0},   {"lazy", 0},      {"threads", 1},
-                                      {"rccl", 0}};
+                                      {"rccl", 0},          {"mc", 0}};
   for (int i = 3; i < argc; i++) {
     const char* eq = std::strchr(argv[i], '=');
     if (!eq) continue;
     kv[std::string(argv[i], eq - argv[i])] = atof(eq + 1);
   }
   int W = 0, H = 0;
-  std::vector<std::pair<int, EventArray>> msgs;
+  std::vector<Message> msgs;
   if (!read_log(argv[1], &W, &H, &msgs)) {
     fprintf(stderr, "cannot read %s\n", argv[1]);
     return 2;
@@ -240,6 +331,15 @@ int main(int argc, char** argv) {
   node.FREQ = (int)kv["freq"] == 0 ? 100 : (int)kv["freq"];  // parameters.cpp:278-279
   node.ahead = (int)kv["ahead"];
   node.lazy = kv["lazy"] != 0;
+  node.Do_motion_correction = kv["mc"] != 0;
+  if (node.Do_motion_correction && node.ahead > 0) {
+    fprintf(stderr, "mc=1 needs ahead=0: an announced batch has no motion-compensated form\n");
+    return 2;
+  }
+  node.K[0] = kv.count("fx") ? kv["fx"] : c.cam[0].fx;
+  node.K[1] = kv.count("fy") ? kv["fy"] : c.cam[0].fy;
+  node.K[2] = kv.count("cx") ? kv["cx"] : c.cam[0].cx;
+  node.K[3] = kv.count("cy") ? kv["cy"] : c.cam[0].cy;
   int rc = esvio_fe_create(&c, &node.h);
   if (rc) {
     fprintf(stderr, "esvio_fe_create failed: %d\n", rc);
@@ -267,9 +367,12 @@ int main(int argc, char** argv) {
   // has no load, so every logged message is considered.)
   std::deque<const EventArray*> ql, qr;
   std::vector<std::pair<const EventArray*, const EventArray*>> pairs;
+  std::vector<size_t> ready_at;  // index of the message that completed the pair
   size_t thrown = 0;
-  for (auto& m : msgs) {
-    (m.first == 0 ? ql : qr).push_back(&m.second);
+  for (size_t mi = 0; mi < msgs.size(); mi++) {
+    const Message& m = msgs[mi];
+    if (m.kind > 1) continue;
+    (m.kind == 0 ? ql : qr).push_back(&m.ev);
     while (!ql.empty() && !qr.empty()) {
       const double tl = ql.front()->stamp, trr = qr.front()->stamp;
       if (tl < trr - 0.2) {
@@ -280,12 +383,19 @@ int main(int argc, char** argv) {
         thrown++;
       } else {
         pairs.emplace_back(ql.front(), qr.front());
+        ready_at.push_back(mi);
         ql.pop_front();
         qr.pop_front();
       }
     }
   }
+  size_t delivered = 0;  // IMU / odometry messages reach their callbacks in log order, a pair is
+                         // handled when its second message has arrived
   for (size_t i = 0; i < pairs.size(); i++) {
+    for (; delivered < ready_at[i]; delivered++) {
+      if (msgs[delivered].kind == 2) node.imu_callback(msgs[delivered].imu);
+      if (msgs[delivered].kind == 3) node.state_callback(msgs[delivered].odom);
+    }
     if (pairs[i].first->events.empty()) continue;  // node:408
     std::vector<std::pair<const EventArray*, const EventArray*>> next;
     for (size_t k = i + 1; k < pairs.size() && (int)next.size() < node.ahead; k++) {
