@@ -41,8 +41,8 @@ def _write_log(path, msgs):
     with open(path, "wb") as f:
         f.write(b"ESVB" + struct.pack("<IIII", version, W, H, len(msgs)))
         for kind, stamp, body in msgs:
-            f.write(struct.pack("<BBBBId", kind, 0, 0, 0, len(body), stamp))
-            if kind <= 1:
+            f.write(struct.pack("<BBBBId", kind, 0, 0, 0, body.size if kind >= 4 else len(body), stamp))
+            if kind <= 1 or kind >= 4:
                 f.write(np.ascontiguousarray(body).tobytes())
             else:
                 f.write(np.asarray(body, np.float64).tobytes())
@@ -241,6 +241,95 @@ def test_replay_node_motion_compensation(oracle, tmp_path):
     assert any(a[3].shape != b[3].shape or not np.array_equal(a[3], b[3]) for a, b in zip(ref, plain))
     got, stdout = _run(tmp_path, log, "mc", "mc=1", "fx=%r" % K[0], "fy=%r" % K[1], "cx=%r" % K[2], "cy=%r" % K[3])
     assert len(got) == len(ref), (len(got), len(ref), stdout)
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert g[:3] == r[:3], (k, g[:3], r[:3])
+        assert g[3].shape == r[3].shape, k
+        assert np.array_equal(g[3].view(np.uint32), r[3].view(np.uint32)), k
+
+
+def _oracle_image_node(oracle, msgs, kw):
+    """stereo_image_tracker_node.cpp:210-250 (pairing within a second) and :54-183
+    (handle_stereo_image), restated here, over the oracle tracker"""
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    il, ir, out = [], [], []
+    first, first_t, last_t, pub_count, init_pub = True, 0.0, 0.0, 1, False
+    for kind, stamp, img in msgs:
+        (il if kind == 4 else ir).append((stamp, img))
+        while il and ir:
+            tl, trr = il[0][0], ir[0][0]
+            if tl <= trr - 1:
+                il.pop(0)
+                continue
+            if tl > trr + 1:
+                ir.pop(0)
+                continue
+            (stamp_l, L), (_, R) = il.pop(0), ir.pop(0)
+            if first:
+                first, first_t, last_t = False, stamp_l, stamp_l
+                continue
+            if stamp_l - last_t > 1.0 or stamp_l < last_t:
+                first, last_t, pub_count = True, 0.0, 1
+                out.append((stamp_l, 1, 0, np.zeros((0, 8), np.float32)))
+                continue
+            last_t = stamp_l
+            rate = 1.0 * pub_count / (stamp_l - first_t)
+            pub = _c_round(rate) <= FREQ
+            if pub and abs(rate - FREQ) < 0.01 * FREQ:
+                first_t, pub_count = stamp_l, 0
+            r = tr.track_image(stamp_l, L, R, pub)
+            rows, published = np.zeros((0, 8), np.float32), 0
+            if pub:
+                pub_count += 1
+                rr, ids = [], set()
+                for j in range(len(r.ids)):
+                    if r.track_cnt[j] > 1:
+                        ids.add(int(r.ids[j]))
+                        rr.append((r.cur_un_pts[j, 0], r.cur_un_pts[j, 1], 1.0, np.float32(int(r.ids[j]) * 2),
+                                   r.cur_pts[j, 0], r.cur_pts[j, 1], r.pts_velocity[j, 0], r.pts_velocity[j, 1]))
+                for j in range(len(r.ids_right)):
+                    if int(r.ids_right[j]) in ids:
+                        rr.append((r.cur_un_right_pts[j, 0], r.cur_un_right_pts[j, 1], 1.0,
+                                   np.float32(int(r.ids_right[j]) * 2 + 1), r.cur_right_pts[j, 0],
+                                   r.cur_right_pts[j, 1], r.right_pts_velocity[j, 0], r.right_pts_velocity[j, 1]))
+                if not init_pub:
+                    init_pub = True
+                else:
+                    published, rows = 1, np.asarray(rr, np.float32).reshape(-1, 8)
+            out.append((stamp_l, 0, published, rows))
+    return out
+
+
+@pytest.mark.parametrize("equalize", [0, 1])
+def test_replay_image_node(oracle, tmp_path, equalize):
+    """the reference's second node (stereo_image_tracker_node.cpp) through the same harness: a log of
+    mono8 image messages, pairing within 1 s, handle_stereo_image -> esvio_fe_track_image, the
+    PointCloud rows of every published frame; with a 1.4 s hole in the stream, a right image that
+    arrives 1.2 s late and one that never arrives (the reference then pairs what it has)"""
+    from esvio_amd.synth import ImageStream
+    s = ImageStream(W, H, velocity=(3, -2), disparity=9, seed=8)
+    msgs = []
+    t_shift = 0.0
+    for f in range(24):
+        L, R, t = s.next_frame()
+        if f == 9:
+            t_shift = 1.4
+        t += t_shift
+        msgs.append((4, t, L))
+        if f != 15:  # (a right image that never arrives: the pairing goes on with the next one)
+            msgs.append((5, t + 0.0005 + (1.2 if f == 4 else 0.0), R))
+    kw = dict(max_cnt=120, min_dist=20, flow_back=1, equalize=equalize)
+    log = str(tmp_path / "log_img.esvb")
+    _write_log(log, msgs)
+    ref = _oracle_image_node(oracle, msgs, kw)
+    assert sum(f[2] for f in ref) >= 4 and sum(f[1] for f in ref) >= 1
+    assert max(f[3].shape[0] for f in ref) > 60
+    from esvio_amd import build as B
+    dump = str(tmp_path / "img.bin")
+    p = subprocess.run([B.build_tools(), log, dump, "max_cnt=120", "min_dist=20", "freq=%d" % FREQ,
+                        "equalize=%d" % equalize], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = _read_dump(dump)
+    assert len(got) == len(ref), (len(got), len(ref), p.stdout)
     for k, (g, r) in enumerate(zip(got, ref)):
         assert g[:3] == r[:3], (k, g[:3], r[:3])
         assert g[3].shape == r[3].shape, k

@@ -19,6 +19,11 @@
 //   kind 0 / 1  dvs_msgs/EventArray of the left / right camera: n x 16 B dvs_msgs::Event (esvio_fe_event)
 //   kind 2      sensor_msgs/Imu (version 2): n = 6 f64 — angular_velocity xyz, linear_acceleration xyz
 //   kind 3      nav_msgs/Odometry of the back end (version 2): n = 3 f64 — twist.twist.linear xyz
+//   kind 4 / 5  sensor_msgs/Image (mono8) of the left / right camera (version 2): n = width*height bytes.
+//               A log with images is replayed the way the reference's second node does it
+//               (stereo_image_tracker_node.cpp: sync_process :210-250 pairs within 1 s,
+//               handle_stereo_image :54-183 -> esvio_fe_track_image); the two nodes are separate
+//               processes in the reference, so a log holds either events or images.
 // Messages are delivered to the callbacks in log order; a left/right pair is handled as soon as its
 // second message has arrived (the reference's spinner and sync_process threads interleave freely).
 // Dump format: "ESVD" u32 n_frames, per frame: f64 stamp u8 restart_flag u8 published u8 pad[2]
@@ -155,6 +160,63 @@ struct Node {
     return false;
   }
 
+  // the PointCloud of node:273-329 (stereo_image_tracker_node.cpp:113-168 is the same loop)
+  void pack_rows(Frame& f) {
+    std::set<int> hash_ids;
+    for (int j = 0; j < tr.n_left; j++)
+      if (track_cnt[j] > 1) {  // node:289
+        hash_ids.insert(ids[j]);
+        const float row[8] = {cur_un_pts[2 * j], cur_un_pts[2 * j + 1], 1.f, (float)(ids[j] * 2 + 0),
+                              cur_pts[2 * j], cur_pts[2 * j + 1], pts_velocity[2 * j], pts_velocity[2 * j + 1]};
+        f.rows.insert(f.rows.end(), row, row + 8);
+      }
+    for (int j = 0; j < tr.n_right; j++)
+      if (hash_ids.count(ids_right[j])) {  // node:309
+        const float row[8] = {cur_un_right_pts[2 * j], cur_un_right_pts[2 * j + 1], 1.f,
+                              (float)(ids_right[j] * 2 + 1), cur_right_pts[2 * j], cur_right_pts[2 * j + 1],
+                              right_pts_velocity[2 * j], right_pts_velocity[2 * j + 1]};
+        f.rows.insert(f.rows.end(), row, row + 8);
+      }
+  }
+
+  // handle_stereo_image (stereo_image_tracker_node.cpp:54-183): the same first-frame / discontinuity
+  // / publish-rate rules, trackImage, the same PointCloud.  (EQUALIZE's CLAHE of both images, :92-96,
+  // is the handle's `equalize` option.)
+  int handle_image(const std::vector<uint8_t>& L, const std::vector<uint8_t>& R, double msg_timestamp) {
+    Frame f{msg_timestamp, 0, 0, {}};
+    if (first_image_flag) {  // :58-64
+      first_image_flag = false;
+      first_image_time = msg_timestamp;
+      last_image_time = msg_timestamp;
+      return 0;
+    }
+    if (msg_timestamp - last_image_time > 1.0 || msg_timestamp < last_image_time) {  // :66-78
+      first_image_flag = true;
+      last_image_time = 0;
+      pub_count = 1;
+      f.restart = 1;
+      out.push_back(f);
+      return 0;
+    }
+    last_image_time = msg_timestamp;
+    PUB_THIS_FRAME = freq_rule(msg_timestamp, true);  // :81-91
+    const int rc = esvio_fe_track_image(h, msg_timestamp, L.data(), R.empty() ? nullptr : R.data(),
+                                        PUB_THIS_FRAME ? 1 : 0, &tr);  // :100
+    if (rc) return rc;
+    if (PUB_THIS_FRAME) {
+      pub_count++;  // :113-115
+      pack_rows(f);
+      if (!init_pub) {  // :171-176
+        init_pub = true;
+        f.rows.clear();
+      } else {
+        f.published = 1;
+      }
+    }
+    out.push_back(f);
+    return 0;
+  }
+
   // handle_stereo_event (node:145-344).  `next`: the batches that will follow (replay mode only).
   int handle(const EventArray& L, const EventArray& R, double msg_timestamp,
              const std::vector<std::pair<const EventArray*, const EventArray*>>& next) {
@@ -208,21 +270,7 @@ struct Node {
     if (announced_ahead > 0) announced_ahead--;
     if (PUB_THIS_FRAME) {
       pub_count++;  // node:268
-      std::set<int> hash_ids;
-      for (int j = 0; j < tr.n_left; j++)
-        if (track_cnt[j] > 1) {  // node:289
-          hash_ids.insert(ids[j]);
-          const float row[8] = {cur_un_pts[2 * j], cur_un_pts[2 * j + 1], 1.f, (float)(ids[j] * 2 + 0),
-                                cur_pts[2 * j], cur_pts[2 * j + 1], pts_velocity[2 * j], pts_velocity[2 * j + 1]};
-          f.rows.insert(f.rows.end(), row, row + 8);
-        }
-      for (int j = 0; j < tr.n_right; j++)
-        if (hash_ids.count(ids_right[j])) {  // node:309
-          const float row[8] = {cur_un_right_pts[2 * j], cur_un_right_pts[2 * j + 1], 1.f,
-                                (float)(ids_right[j] * 2 + 1), cur_right_pts[2 * j], cur_right_pts[2 * j + 1],
-                                right_pts_velocity[2 * j], right_pts_velocity[2 * j + 1]};
-          f.rows.insert(f.rows.end(), row, row + 8);
-        }
+      pack_rows(f);
       if (comm) {  // the multi-GPU hand-off: every rank's records, here a communicator of one rank
         gathered.assign((size_t)2 * cfg.max_cnt * 8, 0.f);
         if ((rc = esvio_fe_exchange_tracks(h, comm, 1, gathered.data()))) return rc;
@@ -253,6 +301,8 @@ struct Message {  // one logged message of any kind
   EventArray ev;  // kinds 0, 1
   ImuMsg imu{};   // kind 2
   OdomMsg odom{}; // kind 3
+  double stamp = 0;            // kinds 4, 5
+  std::vector<uint8_t> image;  // kinds 4, 5
 };
 
 bool read_log(const char* path, int* W, int* H, std::vector<Message>* msgs) {
@@ -286,6 +336,10 @@ bool read_log(const char* path, int* W, int* H, std::vector<Message>* msgs) {
       double v[3];
       if (fread(v, 8, 3, fp) != 3) break;
       m.odom = OdomMsg{stamp, {v[0], v[1], v[2]}};
+    } else if ((m.kind == 4 || m.kind == 5) && n == hdr[1] * hdr[2] && hdr[0] >= 2) {
+      m.stamp = stamp;
+      m.image.resize(n);
+      if (fread(m.image.data(), 1, n, fp) != n) break;
     } else {
       fclose(fp);
       return false;
@@ -294,6 +348,30 @@ bool read_log(const char* path, int* W, int* H, std::vector<Message>* msgs) {
   }
   fclose(fp);
   return true;
+}
+
+int write_dump(const char* path, Node& node, size_t n_pairs, size_t thrown) {
+  FILE* fo = fopen(path, "wb");
+  if (!fo) return 2;
+  const uint32_t nf = (uint32_t)node.out.size();
+  fwrite("ESVD", 1, 4, fo);
+  fwrite(&nf, 4, 1, fo);
+  size_t n_pub = 0, n_rows = 0;
+  for (const Frame& f : node.out) {
+    const uint8_t flags[4] = {f.restart, f.published, 0, 0};
+    const uint32_t n = (uint32_t)(f.rows.size() / 8);
+    fwrite(&f.stamp, 8, 1, fo);
+    fwrite(flags, 1, 4, fo);
+    fwrite(&n, 4, 1, fo);
+    if (n) fwrite(f.rows.data(), 4, f.rows.size(), fo);
+    n_pub += f.published;
+    n_rows += n;
+  }
+  fclose(fo);
+  printf("replay_node: %zu message pairs (%zu thrown), %u frames tracked or restarted, %zu published, %zu rows, "
+         "%d RCCL exchanges\n", n_pairs, thrown, nf, n_pub, n_rows, node.exchanges);
+  esvio_fe_destroy(node.h);
+  return 0;
 }
 
 }  // namespace
@@ -362,6 +440,39 @@ int main(int argc, char** argv) {
     }
   }
 
+  bool image_log = false;
+  for (const Message& m : msgs) image_log = image_log || m.kind == 4 || m.kind == 5;
+  if (image_log) {
+    // sync_process of the image node (stereo_image_tracker_node.cpp:210-250): pair when the stamps
+    // are within a second, else throw the older one
+    std::deque<const Message*> il, ir;
+    size_t pairs_n = 0, thrown_n = 0;
+    for (const Message& m : msgs) {
+      if (m.kind != 4 && m.kind != 5) continue;
+      (m.kind == 4 ? il : ir).push_back(&m);
+      while (!il.empty() && !ir.empty()) {
+        const double tl = il.front()->stamp, trr = ir.front()->stamp;
+        if (tl <= trr - 1) {
+          il.pop_front();
+          thrown_n++;
+        } else if (tl > trr + 1) {
+          ir.pop_front();
+          thrown_n++;
+        } else {
+          rc = node.handle_image(il.front()->image, ir.front()->image, tl);
+          if (rc) {
+            fprintf(stderr, "image pair %zu failed: %d %s\n", pairs_n, rc, esvio_fe_last_error(node.h));
+            return 1;
+          }
+          pairs_n++;
+          il.pop_front();
+          ir.pop_front();
+        }
+      }
+    }
+    return write_dump(argv[2], node, pairs_n, thrown_n);
+  }
+
   // sync_process (node:372-418) over the logged messages: two queues, pair when |dt| <= 0.2 s, else
   // throw the older one.  (The reference's queues hold one message and drop under load; a replay
   // has no load, so every logged message is considered.)
@@ -418,25 +529,5 @@ int main(int argc, char** argv) {
       return 1;
     }
   }
-  FILE* fo = fopen(argv[2], "wb");
-  if (!fo) return 2;
-  const uint32_t nf = (uint32_t)node.out.size();
-  fwrite("ESVD", 1, 4, fo);
-  fwrite(&nf, 4, 1, fo);
-  size_t n_pub = 0, n_rows = 0;
-  for (const Frame& f : node.out) {
-    const uint8_t flags[4] = {f.restart, f.published, 0, 0};
-    const uint32_t n = (uint32_t)(f.rows.size() / 8);
-    fwrite(&f.stamp, 8, 1, fo);
-    fwrite(flags, 1, 4, fo);
-    fwrite(&n, 4, 1, fo);
-    if (n) fwrite(f.rows.data(), 4, f.rows.size(), fo);
-    n_pub += f.published;
-    n_rows += n;
-  }
-  fclose(fo);
-  printf("replay_node: %zu message pairs (%zu thrown), %u frames tracked or restarted, %zu published, %zu rows, "
-         "%d RCCL exchanges\n", pairs.size(), thrown, nf, n_pub, n_rows, node.exchanges);
-  esvio_fe_destroy(node.h);
-  return 0;
+  return write_dump(argv[2], node, pairs.size(), thrown);
 }
