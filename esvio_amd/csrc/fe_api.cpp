@@ -128,7 +128,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->x_pin_recv) (void)hipHostFree(c->x_pin_recv);
   void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_tile, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
-                  c->d_mask_bits, c->d_sel_idx,
+                  c->d_mask_bits, c->d_sel_idx, c->d_sel_bitmap,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
                   c->d_minmax};
   for (void* p : ptrs)
@@ -327,8 +327,10 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipMemsetAsync(c->d_counts, 0, 64, cur_stream(c)) != hipSuccess ||
       hipStreamSynchronize(cur_stream(c)) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
-  size_t lds = select_lds_bytes(c);
-  if (lds > 160 * 1024) return bail(ESVIO_FE_EINVAL);
+  // The greedy selections (Event_FeaturesToTrack, goodFeaturesToTrack's min-distance pass) keep
+  // their one-bit-per-pixel map in LDS; above ~1.3 M pixels (the frame cameras of the shipped ESVIO
+  // configs go up to 1920x1200) it lives in device memory instead (k_select_gbm)
+  c->select_ok = select_lds_bytes(c) <= 160 * 1024;
   *out = c;
   return 0;
 }

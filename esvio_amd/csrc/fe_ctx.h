@@ -314,6 +314,8 @@ struct esvio_fe_ctx {
 
   // ---- host phase trace (ESVIO_FE_TRACE=1): stage, sae+ts enqueue, sync A, host A, enqueue B,
   // sync B, host B
+  bool select_ok = true;  // the greedy selection's bitmap fits LDS
+  uint32_t* d_sel_bitmap = nullptr;  // ... else it lives here (k_select_gbm)
   bool trace = false;
   double phase_ms[2][8] = {};  // [published?][phase]
   double pub_ms[6] = {};       // published frames: the parts of "host mask + enqueue detect/stereo"

@@ -95,11 +95,19 @@ int gftt_run(esvio_fe_ctx* c, const PyrDesc& d, int max_corners, double quality,
   sa.n_total = c->d_counts + 1;
   sa.host_counts = host_counts;
   sa.init_bits = nullptr;
+  sa.gbitmap = nullptr;
   sa.pub_slots = nullptr;
   sa.pub_done = nullptr;
   sa.pub_seq = 0;
+  size_t lds = select_lds_bytes(c);
+  if (!c->select_ok) {  // a frame camera's size: the min-distance bitmap goes to device memory
+    if (!c->d_sel_bitmap)
+      if (int rc = dev_alloc(c, &c->d_sel_bitmap, (size_t)c->H * sa.wpr + 4)) return rc;
+    sa.gbitmap = c->d_sel_bitmap;
+    lds = select_tables_lds_bytes(c);
+  }
   ScopedKernel k(c, K_SELECT, 0);
-  launch_select(cur_stream(c), sa, select_lds_bytes(c));
+  launch_select(cur_stream(c), sa, lds);
   return 0;
 }
 

@@ -86,6 +86,7 @@ void clear_tracker_state(esvio_fe_ctx* c);
 SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int out_base,
                             int32_t* out_idx);
 size_t select_lds_bytes(const esvio_fe_ctx* c);
+size_t select_tables_lds_bytes(const esvio_fe_ctx* c);
 void run_compact(esvio_fe_ctx* c, uint32_t n_events, int set);
 void run_select(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int out_base, int32_t* out_idx,
                 const uint32_t* mask_bits = nullptr, int* host_counts = nullptr, bool publish = false,

@@ -354,6 +354,9 @@ struct SelectArgs {
   int* n_out;                // number accepted
   int* n_total;              // out_base + accepted (feeds the LK kernels' n_ptr), may be NULL
   int* host_counts;          // optional host-mapped mirror: {accepted, out_base + accepted, total}
+  // non-null: the disc bitmap lives here (H*wpr + 4 words of device memory) instead of in LDS — for
+  // sensors whose bitmap does not fit the 160 KiB (k_select_gbm; LDS then holds the tables only)
+  uint32_t* gbitmap;
   const uint32_t* init_bits; // optional H*wpr words the disc bitmap starts from (blocked pixels)
   // ... or, instead, the points whose discs ARE those blocked pixels (Event_setMask stamps
   // cv::circle(mask, cvRound(pt), MIN_DIST, 0, -1) for every point it keeps, feature_tracker.cpp

@@ -2752,6 +2752,29 @@ void launch_compact(hipStream_t s, const uint32_t* cand_xy, const uint32_t* cand
 
 // OR the bits of columns [xa,xb] that fall into word (w0+k) of row yy; rows/words outside the
 // image contribute 0 to a clamped (valid) address, so there is no branch
+// GBM: the bitmap lives in global memory (sensors whose bitmap does not fit LDS: the image front-end
+// at the frame cameras' sizes) — its words are then read and OR-ed with device-scope atomics, which
+// are performed at L2, so that a read never sees a stale line of the CU's vector cache.
+template <bool GBM>
+__device__ __forceinline__ void bm_or(uint32_t* p, uint32_t bits) {
+  if (GBM)
+    __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+template <bool GBM>
+__device__ __forceinline__ uint32_t bm_read(const uint32_t* p) {
+  if (GBM) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool GBM>
+__device__ __forceinline__ void bm_fence() {  // earlier ORs of this wave are visible to its later reads
+  if (GBM)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  else
+    bm_fence<GBM>();
+}
+template <bool GBM>
 __device__ __forceinline__ void stamp_words(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
                                             int hw, int k0, int k1) {
   const bool valid = hw >= 0 && (unsigned)yy < (unsigned)H;
@@ -2764,16 +2787,17 @@ __device__ __forceinline__ void stamp_words(uint32_t* lds, int wpr, int W, int H
     const int w = w0 + k;
     const int lo = max(xa - (w << 5), 0), hi = min(xb - (w << 5), 31);
     const uint32_t bits = hi >= lo ? (((2u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-    __hip_atomic_fetch_or(lds + rowbase + min(w, wpr - 1), bits, __ATOMIC_RELAXED,
-                          __HIP_MEMORY_SCOPE_WAVEFRONT);
+    bm_or<GBM>(lds + rowbase + min(w, wpr - 1), bits);
   }
 }
+template <bool GBM>
 __device__ __forceinline__ void stamp_row(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
                                           int hw) {
-  stamp_words(lds, wpr, W, H, ax, yy, hw, 0, 3);  // 2*31+1 = 63 px -> at most 3 words
+  stamp_words<GBM>(lds, wpr, W, H, ax, yy, hw, 0, 3);  // 2*31+1 = 63 px -> at most 3 words
 }
 // radius <= 15: the row's span is at most 31 px, i.e. one 64-bit shifted mask = two words (the
 // second OR is 0 when the span stays inside one word; the bitmap is followed by spare words)
+template <bool GBM>
 __device__ __forceinline__ void stamp_row_small(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
                                                 int hw) {
   const bool valid = hw >= 0 && (unsigned)yy < (unsigned)H;
@@ -2781,12 +2805,13 @@ __device__ __forceinline__ void stamp_row_small(uint32_t* lds, int wpr, int W, i
   const int len = valid ? xb - xa + 1 : 0;  // <= 31
   const unsigned long long mm = (unsigned long long)((1u << len) - 1u) << (xa & 31);
   uint32_t* wp = lds + (min(max(yy, 0), H - 1) * wpr + (xa >> 5));
-  __hip_atomic_fetch_or(wp, (uint32_t)mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  __hip_atomic_fetch_or(wp + 1, (uint32_t)(mm >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  bm_or<GBM>(wp, (uint32_t)mm);
+  bm_or<GBM>(wp + 1, (uint32_t)(mm >> 32));
 }
+template <bool GBM>
 __device__ __forceinline__ void stamp_row_tail(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
                                                int hw) {
-  stamp_words(lds, wpr, W, H, ax, yy, hw, 3, 5);  // r <= 63: 127 px -> at most 5 words
+  stamp_words<GBM>(lds, wpr, W, H, ax, yy, hw, 3, 5);  // r <= 63: 127 px -> at most 5 words
 }
 
 // sub-chunks with more live candidates than this are resolved as a batch (see k_select)
@@ -2794,12 +2819,14 @@ constexpr int kSelectBatchMin = 4;
 constexpr int kSelectGroup = 8;
 constexpr int kSelectLaneStampMin = 12;  // accepted discs per sub-chunk above which each lane stamps its own
 
-__global__ __launch_bounds__(64) void k_select(SelectArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  uint32_t* const bitmap = lds;  // H * wpr words, bit set = inside a disc stamped by this call
+template <bool GBM>
+__device__ __forceinline__ void select_body(const SelectArgs& a, uint32_t* lds_base) {
+  // H * wpr words (+ spare), bit set = inside a disc stamped by this call
+  uint32_t* const lds = GBM ? a.gbitmap : lds_base;  // (named for its usual home)
+  uint32_t* const bitmap = lds;
   const int lane = lane_id();
   const int nwords = a.H * a.wpr;
-  int* const hwtab = (int*)(lds + ((nwords + 3) & ~3));  // cv::circle half-widths by |dy|, -1 beyond r
+  int* const hwtab = (int*)(GBM ? lds_base : lds_base + ((nwords + 3) & ~3));  // cv::circle half-widths by |dy|, -1 beyond r
   // the bitmap starts empty, or from the caller's blocked-pixel bitmap (Event_setMask): a candidate
   // on a blocked pixel is then skipped exactly like one inside an already stamped disc
   if (a.init_bits) {
@@ -2826,6 +2853,8 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         for (int k = i; k < nwords; k++) lds[k] = 0;
       }
     }
+    if (GBM)  // (the spare words behind the bitmap the two-word stamps may touch)
+      for (int k = nwords + lane; k < nwords + 4; k += 64) lds[k] = 0;
   }
   const int r = a.radius;
   hwtab[lane] = lane <= r ? (int)a.hw[lane] : -1;
@@ -2835,7 +2864,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
       const float2 p = a.stamp_pts[k];
       spts[k] = (uint32_t)__float2int_rn(p.x) | ((uint32_t)__float2int_rn(p.y) << 16);  // cvRound
     }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  bm_fence<GBM>();
   if (a.stamp_pts) {
     const int rows = 2 * r + 1;
     for (int t = lane; t < a.n_stamp * rows; t += 64) {
@@ -2844,13 +2873,13 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
       const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
       const int hwr = hwtab[row < r ? r - row : row - r];
       if (r <= 15) {
-        stamp_row_small(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+        stamp_row_small<GBM>(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
       } else {
-        stamp_row(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
-        if (r > 31) stamp_row_tail(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+        stamp_row<GBM>(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+        if (r > 31) stamp_row_tail<GBM>(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+    bm_fence<GBM>();
   }
   const uint32_t total = *a.total;
   int accepted = 0;
@@ -2881,13 +2910,13 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
       nci[j] = a.comp_idx[i];
     }
     {  // fast path: all 256 candidates of this step already blocked -> next step
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+      bm_fence<GBM>();
       bool any = false;
 #pragma unroll
       for (int j = 0; j < SUB; j++) {
         const int x = cxy[j] & 0xffff, y = cxy[j] >> 16;
         any = any || ((base + j * 64 + lane < total) &&
-                      !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u));
+                      !((bm_read<GBM>(bitmap + (y * a.wpr + (x >> 5))) >> (x & 31)) & 1u));
       }
       if (!__ballot(any)) continue;
     }
@@ -2897,8 +2926,8 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
       const bool have = i < total;
       const int x = cxy[j] & 0xffff, y = cxy[j] >> 16;
       // discs stamped while earlier sub-chunks were processed are visible through the bitmap
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-      bool alive = have && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+      bm_fence<GBM>();
+      bool alive = have && !((bm_read<GBM>(bitmap + (y * a.wpr + (x >> 5))) >> (x & 31)) & 1u);
       const unsigned long long m_alive = __ballot(alive);
       if (__builtin_popcountll(m_alive) > kSelectBatchMin) {
         // Many live candidates in this sub-chunk (the usual case while the image is still empty):
@@ -2969,10 +2998,10 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
           for (int row = 0; row <= 2 * r; row++) {
             const int hwr = mine ? (int)a.hw[row < r ? r - row : row - r] : -1;
             if (r <= 15) {
-              stamp_row_small(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+              stamp_row_small<GBM>(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
             } else {
-              stamp_row(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
-              if (r > 31) stamp_row_tail(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+              stamp_row<GBM>(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
+              if (r > 31) stamp_row_tail<GBM>(lds, a.wpr, a.W, a.H, x, y - r + row, hwr);
             }
           }
         } else {
@@ -2981,14 +3010,14 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
             const int q = __builtin_ctzll(todo);
             const int ax = __builtin_amdgcn_readlane(x, q), ay = __builtin_amdgcn_readlane(y, q);
             if (r <= 15) {
-              stamp_row_small(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+              stamp_row_small<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
               continue;
             }
-            stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+            stamp_row<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
             if (r > 31) {
-              stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
-              stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
-              stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
+              stamp_row<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
+              stamp_row_tail<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+              stamp_row_tail<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
             }
           }
         }
@@ -3012,14 +3041,14 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
         // stamp the disc for the LATER sub-chunks (LDS atomic OR, not waited for here): one lane
         // per row, branch-free: the row's span [xa,xb] touches at most 3 words for r <= 31
         if (r <= 15) {
-          stamp_row_small(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+          stamp_row_small<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
         } else {
-          stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+          stamp_row<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
         }
         if (r > 31) {  // wave-uniform: rows 64.. of a large disc
-          stamp_row(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
-          stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
-          stamp_row_tail(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
+          stamp_row<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
+          stamp_row_tail<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_a, hw_a);
+          stamp_row_tail<GBM>(lds, a.wpr, a.W, a.H, ax, ay - r + row_b, hw_b);
         }
         m &= m - 1ull;
         if (!m) break;  // (the usual case once the image has filled up: one live candidate)
@@ -3048,6 +3077,16 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
   }
 }
 
+__global__ __launch_bounds__(64) void k_select(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  select_body<false>(a, lds);
+}
+// the same selection with the bitmap in global memory (a.gbitmap)
+__global__ __launch_bounds__(64) void k_select_gbm(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  select_body<true>(a, lds);
+}
+
 int disc_threshold(const int8_t* hw, int radius) {
   long inside = -1, outside = (long)(radius + 1) * (radius + 1);
   for (int dy = 0; dy <= radius && dy <= kMaxDiscR; dy++) {
@@ -3060,7 +3099,10 @@ int disc_threshold(const int8_t* hw, int radius) {
 }
 
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
-  launch_k(k_select, dim3(1), dim3(64), lds_bytes, s, a);
+  if (a.gbitmap)
+    launch_k(k_select_gbm, dim3(1), dim3(64), lds_bytes, s, a);
+  else
+    launch_k(k_select, dim3(1), dim3(64), lds_bytes, s, a);
 }
 
 }  // namespace esvio

@@ -653,6 +653,7 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* o
   s.n_total = c->d_counts + 1;
   s.host_counts = nullptr;
   s.init_bits = nullptr;
+  s.gbitmap = nullptr;
   s.pub_slots = nullptr;
   s.pub_done = nullptr;
   s.pub_seq = 0;
@@ -662,6 +663,9 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* o
 size_t select_lds_bytes(const esvio_fe_ctx* c) {
   // bitmap + half-width table + the kept points whose discs seed the bitmap
   return ((size_t)c->H * ((c->W + 31) / 32) + 4 + 64 + (size_t)std::max(c->cfg.max_cnt, 1)) * 4;
+}
+size_t select_tables_lds_bytes(const esvio_fe_ctx* c) {  // with the bitmap in global memory
+  return (4 + 64 + (size_t)std::max(c->cfg.max_cnt, 1)) * 4;
 }
 
 // ordered compaction of candidate set `set` (right behind the k_arc that filled it)
@@ -687,8 +691,14 @@ void run_select(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int 
     s.pub_done = c->d_pub_done;
     s.pub_seq = c->pub_seq;
   }
+  size_t lds = select_lds_bytes(c);
+  if (!c->select_ok) {  // the bitmap does not fit LDS: it lives in device memory (slower, same result)
+    if (!c->d_sel_bitmap && dev_alloc(c, &c->d_sel_bitmap, (size_t)c->H * s.wpr + 4) != 0) return;
+    s.gbitmap = c->d_sel_bitmap;
+    lds = select_tables_lds_bytes(c);
+  }
   ScopedKernel k(c, K_SELECT, 0);
-  launch_select(cur_stream(c), s, select_lds_bytes(c));
+  launch_select(cur_stream(c), s, lds);
 }
 
 // Arc* flags (+ ordered per-block candidate lists into set `set`) for the left events; `ts` is the

@@ -89,9 +89,11 @@ typedef struct esvio_fe_ctx* esvio_fe_handle;
 /* ---- lifetime ------------------------------------------------------------------------ */
 /* replaces: global `esvio::EventDetector detector` (feature_tracker.cpp:7), `trackerData`
  * (stereo_event_tracker_node.cpp:45), EventDetector::init (event_detector.cc:47-70). */
-/* Limits (ESVIO_FE_EINVAL beyond them): 42 <= width, height <= 8192 and width*height <= ~1.3 M pixels
- * (the greedy selection keeps one bit per pixel in LDS: 1280x960 fits, 1920x1080 does not);
- * 1 <= max_cnt <= 65536; 3 <= min_dist <= 63; median_blur_kernel_size <= 7. */
+/* Limits (ESVIO_FE_EINVAL beyond them): 42 <= width, height <= 8192; 1 <= max_cnt <= 65536;
+ * 3 <= min_dist <= 63; median_blur_kernel_size <= 7.  Up to ~1.3 M pixels (1280x960) the greedy
+ * corner selections keep their one-bit-per-pixel map in LDS; above that (the frame cameras of the
+ * shipped ESVIO configs go up to 1920x1200) the map lives in device memory: same results, a slower
+ * selection. */
 int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out);
 int esvio_fe_destroy(esvio_fe_handle h);
 /* Clears SAE planes, images, tracks and ids as a freshly created handle (n_id keeps counting).

@@ -385,8 +385,7 @@ def test_sae_time_surface_1280x720(oracle):
                                      (97, 61, "sensor smaller than four tiles, ragged tile edges")])
 def test_sae_other_sensor_sizes(oracle, W, H, why):
     """the tiled SAE update picks its tile by sensor size (32x16 up to ~0.5 MP, 32x32 up to ~1 MP,
-    64x32 beyond; a handle cannot be larger than ~1.3 MP because k_select keeps one bit per pixel in
-    LDS): planes, a time surface and the corner flags at sizes that take the other branches"""
+    64x32 beyond): planes, a time surface and the corner flags at sizes that take the other branches"""
     rng = np.random.default_rng(W)
     ft = _mk(W, H)
     det = oracle.Detector(W, H)
@@ -405,6 +404,41 @@ def test_sae_other_sensor_sizes(oracle, W, H, why):
         t = event_times(L)[-1]
         assert np.array_equal(ft.detector.SAEtoTimeSurface_left(t), det.time_surface(0, t))
         assert np.array_equal(ft.detector.isCorner(L[:100_000]), det.corner_flags(L[:100_000]))
+    ft.close()
+
+
+def test_event_path_on_a_sensor_beyond_the_lds_bitmap(oracle):
+    """1920x1080 events (2.07 M pixels): the greedy selection's bitmap does not fit LDS and lives in
+    device memory (k_select_gbm); the SAE update takes whichever form the size allows.  Planes, time
+    surface, corner flags, the selected corners (with a mask) and three frames of trackEvent equal
+    the oracle's."""
+    W, H = 1920, 1080
+    s = SceneStream(W, H, rate=6e6, seed=77)
+    ft = _mk(W, H, max_cnt=200, min_dist=25)
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, max_cnt=200, min_dist=25, f_ransac=1))
+    det = oracle.Detector(W, H, min_dist=25)
+    for f in range(3):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, True)
+        _compare_tracks(ft, tr.track_event(t, L, R, True), ("hd", f))
+        det.create_sae(0, L)
+        det.create_sae(1, R)
+        for cam in (0, 1):
+            _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+    assert len(ft.ids) > 100
+    ts = det.time_surface(0, t)
+    assert np.array_equal(ft.detector.SAEtoTimeSurface_left(t), ts)
+    assert np.array_equal(ft.detector.isCorner(L[:50_000]), det.corner_flags(L[:50_000]))
+    rng = np.random.default_rng(5)
+    mask = np.zeros((H, W), np.uint8)  # nonzero: blocked
+    for _ in range(40):
+        x, y = rng.integers(0, W - 80), rng.integers(0, H - 80)
+        mask[y:y + rng.integers(10, 80), x:x + rng.integers(10, 80)] = 255
+    for maxc in (1, 57, 200):
+        xy_g, idx_g = ft.Event_FeaturesToTrack(L, maxc, mask)
+        xy_c, idx_c = det.features_to_track(L, maxc, 25, mask, ts)
+        assert np.array_equal(idx_g, idx_c) and np.array_equal(xy_g, xy_c), maxc
     ft.close()
 
 
@@ -652,6 +686,24 @@ def test_track_image_end_to_end_matches_oracle(oracle, equalize):
         ft.trackImage(t, L, R, pub)
         _compare_tracks(ft, tr.track_image(t, L, R, pub), ("image", equalize, f))
     assert len(ft.ids) > 100 and ft.track_cnt.max() >= 6 and len(ft.ids_right) > 80
+    ft.close()
+
+
+@pytest.mark.parametrize("W,H,max_cnt,min_dist", [(1440, 1080, 175, 40), (1920, 1200, 200, 30), (1224, 1024, 150, 20)])
+def test_track_image_at_the_shipped_frame_camera_sizes(oracle, W, H, max_cnt, min_dist):
+    """the frame cameras of the shipped ESVIO configs (config/esvio_DSEC, esvio_ecmd, esvio_VECtor:
+    cam0_esvio.yaml image_width/height, esvio.yaml max_cnt_img / min_dist_img): above ~1.3 M pixels
+    the min-distance bitmap of the selection lives in device memory; trackImage equals the oracle's"""
+    from esvio_amd.synth import ImageStream
+    s = ImageStream(W, H, velocity=(5, 3), disparity=14, seed=W)
+    kw = dict(max_cnt=max_cnt, min_dist=min_dist, flow_back=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(3):
+        L, R, t = s.next_frame()
+        ft.trackImage(t, L, R, f != 1)
+        _compare_tracks(ft, tr.track_image(t, L, R, f != 1), ("image", W, f))
+    assert len(ft.ids) > max_cnt // 2 and len(ft.ids_right) > max_cnt // 4
     ft.close()
 
 
