@@ -95,6 +95,9 @@ def parse():
                     help="processes for the all-cores CPU figure (-1 = os.cpu_count(), 0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--equalize", type=int, default=0, choices=[0, 1],
+                    help="1: CLAHE + normalize of the time surface before LK (config/esio_DSEC ships "
+                         "equalize: 1; the headline stays at 0, the other shipped configs' setting)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not announce the next batch (esvio_fe_set_next_batch): strictly one "
                          "batch in flight, like the reference's depth-1 queues")
@@ -272,7 +275,8 @@ def main():
         dev_batches.append((tl, tr, len(L), len(R), event_times(L)[-1]))
     torch.cuda.synchronize()
 
-    cfg = FE.make_config(W, H, device=dev_index, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1)
+    cfg = FE.make_config(W, H, device=dev_index, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1,
+                         equalize=args.equalize)
     # PUB_THIS_FRAME depends on the batch timestamps only (node:155-188), so the whole plan is known
     # up front; replay mode hands it to esvio_fe_set_next_batch as the PUB hint
     fc = FreqControl(args.freq)
@@ -508,7 +512,8 @@ def main():
     cpu = None
     if rank == 0 and args.cpu_frames > 0:
         from oracle import oracle as O
-        ocfg = O.make_config(W, H, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1, lk_accum=1)
+        ocfg = O.make_config(W, H, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1, lk_accum=1,
+                             equalize=args.equalize)
         tr_o = O.Tracker(ocfg)
         fco = FreqControl(args.freq)
         nfr = min(args.cpu_frames, len(host_batches))
@@ -569,8 +574,8 @@ def main():
             "config": {
                 "workload": "C3 (superset of C2): stereo %dx%d scene stream, %.1f Mev/s per camera, "
                             "%g Hz batches, full SAE+TS+pyramid+LK(temporal,stereo)+Arc*+select, "
-                            "max_cnt %d min_dist 10 flow_back 1 equalize 0 freq %d"
-                            % (W, H, args.rate / 1e6, args.batch_hz, args.max_cnt, args.freq),
+                            "max_cnt %d min_dist 10 flow_back 1 equalize %d freq %d"
+                            % (W, H, args.rate / 1e6, args.batch_hz, args.max_cnt, args.equalize, args.freq),
                 "events_per_step_per_gpu": int(n_events / args.steps),
                 "parallelism": ("left/right camera split, 1 rig on 2 GPUs" if cam_split else
                                 "one stream time-sliced over %d GPUs (SAE update), tracking on rank 0" % world
