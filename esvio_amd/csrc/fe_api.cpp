@@ -153,6 +153,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
     if (c->ev_lane_done[i]) (void)hipEventDestroy(c->ev_lane_done[i]);
     if (c->ev_lane_arc[i]) (void)hipEventDestroy(c->ev_lane_arc[i]);
   }
+  if (c->h_img) (void)hipHostFree(c->h_img);
+  if (c->d_img) (void)hipFree(c->d_img);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_spec) (void)hipHostFree(c->h_spec);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -526,10 +528,10 @@ int esvio_fe_export_image(esvio_fe_handle c, int cam, uint8_t* dst, int space) {
   if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   const PyrDesc& d = cam ? c->pyr[c->slot_curR].d : c->pyr[c->slot_curL].d;
+  if (space == ESVIO_FE_HOST) return copy_level0_out(c, d, dst);  // (staged: no 2-D copy over PCIe)
   const int stride = d.stride[0];
   HIPCHK(c, hipMemcpy2DAsync(dst, c->W, d.img[0] + (size_t)kPad * stride + kPad, stride, c->W, c->H,
-                             space == ESVIO_FE_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
-                             cur_stream(c)));
+                             hipMemcpyDeviceToDevice, cur_stream(c)));
   HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   return 0;
 }
@@ -544,10 +546,12 @@ int esvio_fe_import_image(esvio_fe_handle c, int cam, const uint8_t* src, int sp
   c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;  // next trackEvent's curR
   const PyrDesc& d = c->pyr[c->slot_curR].d;
   const int stride = d.stride[0];
-  HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, src, c->W, c->W, c->H,
-                             space == ESVIO_FE_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                             cur_stream(c)));
-  if (space == ESVIO_FE_HOST) HIPCHK(c, hipStreamSynchronize(cur_stream(c)));  // caller may reuse src
+  if (space == ESVIO_FE_HOST) {  // (staged through pinned memory: src is free again on return)
+    if (int rc = copy_level0_in(c, d, src)) return rc;
+  } else {
+    HIPCHK(c, hipMemcpy2DAsync(d.img[0] + (size_t)kPad * stride + kPad, stride, src, c->W, c->W, c->H,
+                               hipMemcpyDeviceToDevice, cur_stream(c)));
+  }
   c->ext_right_pending = true;
   return 0;
 }

@@ -299,6 +299,10 @@ struct esvio_fe_ctx {
   uint32_t* d_gftt_max = nullptr;
   int32_t* d_sel_idx = nullptr;
   // pinned host staging (layout: pin_of())
+  uint8_t* h_img = nullptr;  // copy_level0_in's staging ring: pinned host side ...
+  uint8_t* d_img = nullptr;  // ... and its device side (linear images)
+  size_t img_stage_bytes = 0;
+  unsigned img_stage_next = 0;
   uint8_t* h_pin = nullptr;
   size_t h_pin_bytes = 0;
 
