@@ -269,6 +269,26 @@ def test_track_event_end_to_end(oracle):
     ft.close()
 
 
+def test_track_event_at_epoch_timestamps(oracle):
+    """ros::Time stamps of a live system: seconds since 1970 (1.7e9), where a double resolves 2.4e-7 s.
+    Everything that subtracts times (the SAE rule's 10 ms filter, the decay, ptsVelocity's dt) does it
+    in double on both sides: six frames of trackEvent equal the oracle's, velocities included."""
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=4e6, seed=9, t0_us=1_700_000_000_000_000)
+    kw = dict(f_ransac=1, max_cnt=200)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(6):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        assert t > 1.7e9
+        ft.trackEvent(t, L, R, f % 2 == 0)
+        _compare_tracks(ft, tr.track_event(t, L, R, f % 2 == 0), ("epoch", f))
+        assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+    assert len(ft.ids) > 60 and np.abs(ft.pts_velocity).max() > 0
+    ft.close()
+
+
 @pytest.mark.parametrize("W,H", [(640, 480), (346, 260)])
 def test_equalize_clahe_normalize(oracle, W, H):
     """equalize: 1 (config/esio_DSEC/esio.yaml:90): CLAHE(40, 8x8) + normalize(0,255,MINMAX) of the
