@@ -26,7 +26,7 @@
 // an AVX2 clone is selected at load time where the CPU has it.  Every element still goes through
 // the same IEEE operations in the same order (no contraction, no reassociation), so results do not
 // depend on the vector width.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(ESVIO_NO_SIMD_CLONES)  // (sanitizer builds: no ifunc resolvers)
 #define ESVIO_SIMD_CLONES
 #else
 #define ESVIO_SIMD_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))

@@ -1,5 +1,7 @@
 // ransac_bench.cpp — host-only timing of rejectWithF_event's RANSAC with 0..N helper threads
-//   g++ -O3 -std=c++17 -ffp-contract=off -pthread tools/ransac_bench.cpp esvio_amd/csrc/fe_host.cpp -o /tmp/ransac_bench
+//   g++ -O3 -std=c++17 -ffp-contract=off -fno-math-errno -pthread tools/ransac_bench.cpp esvio_amd/csrc/fe_host.cpp -Iinclude -o /tmp/ransac_bench
+//   ransac_bench [points [outlier fraction [repetitions]]]   (8..14 points take the LMedS branch)
+// tests/test_host_sanitizers.py builds it with -fsanitize=thread and -fsanitize=address,undefined.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -14,7 +16,7 @@ using namespace esvio::host;
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 160;
   const double outl = argc > 2 ? atof(argv[2]) : 0.37;
-  const int reps = 2000;
+  const int reps = argc > 3 ? atoi(argv[3]) : 2000;
   std::mt19937 g(5);
   std::uniform_real_distribution<double> U(-1, 1);
   std::normal_distribution<double> N(0, 1);
