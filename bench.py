@@ -95,6 +95,11 @@ def parse():
                     help="processes for the all-cores CPU figure (-1 = os.cpu_count(), 0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--stream", choices=["scene", "poisson"], default="scene",
+                    help="scene (default): edges of a static scene seen from a moving stereo rig plus 7 %% Poisson "
+                         "noise — corners that exist and can be tracked, so LK, RANSAC and the selection do "
+                         "their real work; poisson: homogeneous Poisson events only (BASELINE's wording), "
+                         "where every corner is noise and the tracker mostly re-detects")
     ap.add_argument("--equalize", type=int, default=0, choices=[0, 1],
                     help="1: CLAHE + normalize of the time surface before LK (config/esio_DSEC ships "
                          "equalize: 1; the headline stays at 0, the other shipped configs' setting)")
@@ -252,7 +257,7 @@ def main():
     from esvio_amd.events import event_times
     from esvio_amd.dist import CameraSplitRig, TimeSlicedSae, TrackExchange
     from esvio_amd.node import FreqControl
-    from esvio_amd.synth import SceneStream
+    from esvio_amd.synth import PoissonStream, SceneStream
 
     W, H = args.width, args.height
     repeats = args.repeats if args.repeats > 0 else (5 if args.steps <= 30 else 3)
@@ -264,8 +269,9 @@ def main():
     if cam_split and world != 2:
         raise SystemExit("--split camera needs exactly 2 ranks")
     one_rig = cam_split or time_split
-    scene = SceneStream(W, H, rate=args.rate, batch_hz=args.batch_hz,
-                        seed=args.seed + (0 if one_rig else 1000 * rank))
+    stream_seed = args.seed + (0 if one_rig else 1000 * rank)
+    scene = (PoissonStream(W, H, rate=args.rate, batch_hz=args.batch_hz, seed=stream_seed) if args.stream == "poisson"
+             else SceneStream(W, H, rate=args.rate, batch_hz=args.batch_hz, seed=stream_seed))
     host_batches, dev_batches = [], []
     for _ in range(n_frames):
         L, R, _ = scene.next_batch()
@@ -572,10 +578,10 @@ def main():
             "dtype": "f64 timestamps / u8 images / int64 LK sums",
             "data": "synthetic",
             "config": {
-                "workload": "C3 (superset of C2): stereo %dx%d scene stream, %.1f Mev/s per camera, "
+                "workload": "C3 (superset of C2): stereo %dx%d %s stream, %.1f Mev/s per camera, "
                             "%g Hz batches, full SAE+TS+pyramid+LK(temporal,stereo)+Arc*+select, "
                             "max_cnt %d min_dist 10 flow_back 1 equalize %d freq %d"
-                            % (W, H, args.rate / 1e6, args.batch_hz, args.max_cnt, args.equalize, args.freq),
+                            % (W, H, args.stream, args.rate / 1e6, args.batch_hz, args.max_cnt, args.equalize, args.freq),
                 "events_per_step_per_gpu": int(n_events / args.steps),
                 "parallelism": ("left/right camera split, 1 rig on 2 GPUs" if cam_split else
                                 "one stream time-sliced over %d GPUs (SAE update), tracking on rank 0" % world

@@ -27,6 +27,26 @@ def uniform_batch(W, H, n, t0_us, dur_us, rng):
     return make_events(x, y, t, p)
 
 
+class PoissonStream:
+    """Homogeneous Poisson events on both cameras (BASELINE's "synthetic Poisson event stream"):
+    uniform pixels, uniform polarity, a Poisson count per batch, times uniform in the batch — no
+    structure, so the corners Arc* finds and LK follows are noise.  Same interface as SceneStream."""
+
+    def __init__(self, W=640, H=480, rate=5e6, batch_hz=30.0, t0_us=1_000_000_000, seed=12345):
+        self.W, self.H, self.rate = W, H, rate
+        self.dur_us = int(round(1e6 / batch_hz))
+        self.t_us = int(t0_us)
+        self.rng = np.random.default_rng(seed)
+
+    def next_batch(self):
+        lam = self.rate * self.dur_us * 1e-6
+        nl, nr = (max(1, int(self.rng.poisson(lam))) for _ in range(2))
+        L = uniform_batch(self.W, self.H, nl, self.t_us, self.dur_us, self.rng)
+        R = uniform_batch(self.W, self.H, nr, self.t_us, self.dur_us, self.rng)
+        self.t_us += self.dur_us
+        return L, R, self.t_us
+
+
 class SceneStream:
     """Stereo scene stream.  ``next_batch()`` -> (left, right, t_end_us)."""
 
