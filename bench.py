@@ -100,6 +100,9 @@ def parse():
                          "noise — corners that exist and can be tracked, so LK, RANSAC and the selection do "
                          "their real work; poisson: homogeneous Poisson events only (BASELINE's wording), "
                          "where every corner is noise and the tracker mostly re-detects")
+    ap.add_argument("--lk-accum", type=int, default=1, choices=[1, 2],
+                    help="1 (default): exact LK sums; 2: float sums in the order of the reference's x86 OpenCV "
+                         "build (k_lk_f32), what to run for tracks identical to that build's")
     ap.add_argument("--equalize", type=int, default=0, choices=[0, 1],
                     help="1: CLAHE + normalize of the time surface before LK (config/esio_DSEC ships "
                          "equalize: 1; the headline stays at 0, the other shipped configs' setting)")
@@ -282,7 +285,7 @@ def main():
     torch.cuda.synchronize()
 
     cfg = FE.make_config(W, H, device=dev_index, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1,
-                         equalize=args.equalize)
+                         equalize=args.equalize, lk_accum=args.lk_accum)
     # PUB_THIS_FRAME depends on the batch timestamps only (node:155-188), so the whole plan is known
     # up front; replay mode hands it to esvio_fe_set_next_batch as the PUB hint
     fc = FreqControl(args.freq)
@@ -518,8 +521,8 @@ def main():
     cpu = None
     if rank == 0 and args.cpu_frames > 0:
         from oracle import oracle as O
-        ocfg = O.make_config(W, H, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1, lk_accum=1,
-                             equalize=args.equalize)
+        ocfg = O.make_config(W, H, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1,
+                             lk_accum=args.lk_accum, equalize=args.equalize)
         tr_o = O.Tracker(ocfg)
         fco = FreqControl(args.freq)
         nfr = min(args.cpu_frames, len(host_batches))

@@ -189,7 +189,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     return ESVIO_FE_EINVAL;
   if (cfg->max_cnt < 1 || cfg->max_cnt > 65536) return ESVIO_FE_EINVAL;
   if (cfg->min_dist < 3 || cfg->min_dist > kMaxDiscR) return ESVIO_FE_EINVAL;  // Arc* ring r=4
-  if (cfg->lk_accum != 1) return ESVIO_FE_EINVAL;
+  if (cfg->lk_accum != 1 && cfg->lk_accum != 2) return ESVIO_FE_EINVAL;
   if (cfg->median_blur_kernel_size < 0) return ESVIO_FE_EINVAL;
   if (cfg->median_blur_kernel_size > kMaxMedianK) return ESVIO_FE_ENOTIMPL;  // ksize > 15
   if (cfg->equalize != 0 && cfg->equalize != 1) return ESVIO_FE_EINVAL;

@@ -243,6 +243,7 @@ struct LkArgs {
   int max_count;
   double eps2;
   int flags;
+  int accum = 1;  // 1: exact integer sums (k_lk); 2: float sums in the reference build's order (k_lk_f32)
 };
 // one launch runs call `f`; if `b` != NULL the same wave then runs call `b` with prevPts = f's
 // result and initial flow = f's prevPts (the forward/backward check of feature_tracker.cpp:410-418

@@ -1794,9 +1794,154 @@ __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+// ---- lk_accum 2: the sums of the LK normal equations in float, in the order of OpenCV 4.2's x86
+// SIMD128 build (typedef float acctype; oracle/esvio_oracle.cpp calc_lk, accum == 2, restated from
+// recall — unpinned): per window row the vector loop takes columns 0..15, lane k of a float32x4
+// accumulator getting columns k, k+4, k+8, k+12 (A matrix: one product per add; b vector: the
+// products of columns x, x+4 of a step of 8 added in int32 first, converted, then one add), the
+// columns 16..20 go to a scalar accumulator; at the end scalar += horizontal sum of the lanes.
+// A float sum in a prescribed order is a chain of dependent adds, so it cannot be spread over the
+// wave: the lanes compute the per-pixel integer terms as before, put them into LDS, and a handful
+// of lanes walk their chains (the longest: 105 adds) while the rest idle.  About twice the
+// per-iteration time of the exact-sum mode.
+constexpr int kLkAccZero = 2 * kLkWin * kLkWin;  // index of a word that holds 0 (for the empty slots)
+constexpr int kLkAccWords = kLkAccZero + 4;       // two ints per window pixel + the zero word
+
+// Every chain takes five terms per window row (a vector lane four — or two pairs — and a zero, the
+// tail its five columns), so that all chain lanes run one loop in lock step: 105 dependent adds,
+// the next row's operands fetched from LDS while the current row is added.  Adding +0.f is exact.
+
+// lanes 0..11: vector chains (type = lane / 4: A11, A12, A22; k = lane % 4), lanes 12..14: the tails
+__device__ __forceinline__ void lk_float_sums_A(const int* s, int lane, float& A11, float& A12, float& A22) {
+  constexpr int NP2 = kLkWin * kLkWin;
+  const int typ = lane < 12 ? lane >> 2 : (lane < 15 ? lane - 12 : 0);
+  const int oa = typ == 2 ? NP2 : 0, ob = typ == 0 ? 0 : NP2;  // factor planes: ix = 0, iy = NP2
+  int col[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) col[j] = lane < 12 ? (j < 4 ? 4 * j + (lane & 3) : -1) : (lane < 15 ? 16 + j : -1);
+  float acc = 0.f;
+  int va[5], vb[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    va[j] = s[col[j] < 0 ? kLkAccZero : oa + col[j]];
+    vb[j] = s[col[j] < 0 ? kLkAccZero : ob + col[j]];
+  }
+  for (int y = 0; y < kLkWin; y++) {
+    int na[5], nb[5];
+    const int base = (y + 1 < kLkWin ? y + 1 : y) * kLkWin;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      na[j] = s[col[j] < 0 ? kLkAccZero : oa + base + col[j]];
+      nb[j] = s[col[j] < 0 ? kLkAccZero : ob + base + col[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) acc = __fadd_rn(acc, __fmul_rn((float)va[j], (float)vb[j]));  // (products < 2^24: exact)
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      va[j] = na[j];
+      vb[j] = nb[j];
+    }
+  }
+  const float kScale = 1.f / (float)(1 << 20);  // FLT_SCALE
+  float out[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const float q0 = __shfl(acc, 4 * t), q1 = __shfl(acc, 4 * t + 1), q2 = __shfl(acc, 4 * t + 2),
+                q3 = __shfl(acc, 4 * t + 3), tail = __shfl(acc, 12 + t);
+    out[t] = __fmul_rn(__fadd_rn(tail, __fadd_rn(__fadd_rn(q0, q2), __fadd_rn(q1, q3))), kScale);
+  }
+  A11 = out[0];
+  A12 = out[1];
+  A22 = out[2];
+}
+
+// The b vector is summed once per LK iteration, so its chains get one more stage: the 546 float terms
+// (8 vector chains x 21 rows x 2 pair sums, 2 tails x 21 rows x 5 columns) are produced by all 64 lanes
+// from the integer products in LDS — nine terms per lane, sources and destination decoded once per
+// launch — into T[chain][row][8 floats] (slots a chain does not use stay +0.f), and a chain lane then
+// only reads a row (two LDS instructions) and adds its five terms.
+constexpr int kLkChains = 10, kLkTermsPerLane = 9;
+constexpr int kLkTermWords = kLkChains * kLkWin * 8;
+
+struct LkTermPlan {
+  int16_t a[kLkTermsPerLane], b[kLkTermsPerLane], d[kLkTermsPerLane];  // int sources (b: or the zero word), float destination
+};
+
+__device__ __forceinline__ LkTermPlan lk_term_plan(int lane) {
+  constexpr int NP2 = kLkWin * kLkWin, kVec = 8 * kLkWin * 2, kAll = kVec + 2 * kLkWin * 5;
+  LkTermPlan p;
+#pragma unroll
+  for (int r = 0; r < kLkTermsPerLane; r++) {
+    const int t = r * 64 + lane;
+    int chain, row, slot, ca, cb;
+    if (t < kVec) {  // vector chains 0..7 (component = chain / 4, k = chain % 4): pair (8 j + k, 8 j + k + 4)
+      chain = t / (kLkWin * 2);
+      const int q = t - chain * (kLkWin * 2);
+      row = q >> 1;
+      slot = q & 1;
+      ca = 8 * slot + (chain & 3);
+      cb = ca + 4;
+    } else {  // tails 8, 9: column 16 + j alone
+      const int u = (t < kAll ? t : kVec) - kVec;
+      chain = 8 + u / (kLkWin * 5);
+      const int q = u - (chain - 8) * (kLkWin * 5);
+      row = q / 5;
+      slot = q - row * 5;
+      ca = 16 + slot;
+      cb = -1;
+    }
+    const int o = (chain < 8 ? chain >> 2 : chain - 8) ? NP2 : 0;
+    p.a[r] = (int16_t)(o + row * kLkWin + ca);
+    p.b[r] = (int16_t)(cb < 0 ? kLkAccZero : o + row * kLkWin + cb);
+    p.d[r] = (int16_t)(t < kAll ? (chain * kLkWin + row) * 8 + slot : -1);
+  }
+  return p;
+}
+
+__device__ __forceinline__ void lk_float_sums_b(const int* s, float* T, const LkTermPlan& plan, int lane, float& b1,
+                                                float& b2) {
+#pragma unroll
+  for (int r = 0; r < kLkTermsPerLane; r++) {
+    const float v = (float)(s[plan.a[r]] + s[plan.b[r]]);  // pmaddwd's int32 pair sum, then v_cvt_f32
+    if (plan.d[r] >= 0) T[plan.d[r]] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  // lanes 0..9 walk chains 0..9 (the others walk chain 0 again and are not looked at)
+  const float4* row = (const float4*)(T + (lane < kLkChains ? lane : 0) * kLkWin * 8);
+  float acc = 0.f;
+  float4 c0 = row[0];
+  float c4 = ((const float*)row)[4];
+#pragma unroll
+  for (int y = 0; y < kLkWin; y++) {
+    const int yn = y + 1 < kLkWin ? y + 1 : y;
+    const float4 n0 = row[2 * yn];
+    const float n4 = ((const float*)(row + 2 * yn))[4];
+    acc = __fadd_rn(acc, c0.x);
+    acc = __fadd_rn(acc, c0.y);
+    acc = __fadd_rn(acc, c0.z);
+    acc = __fadd_rn(acc, c0.w);
+    acc = __fadd_rn(acc, c4);
+    c0 = n0;
+    c4 = n4;
+  }
+  const float kScale = 1.f / (float)(1 << 20);
+  float out[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const float k0 = __shfl(acc, 4 * c), k1 = __shfl(acc, 4 * c + 1), k2 = __shfl(acc, 4 * c + 2),
+                k3 = __shfl(acc, 4 * c + 3), tail = __shfl(acc, 8 + c);
+    const float s0 = __fadd_rn(k0, k2), s2 = __fadd_rn(k1, k3);
+    out[c] = __fmul_rn(__fadd_rn(tail, __fadd_rn(__fadd_rn(s0, 0.f), __fadd_rn(s2, 0.f))), kScale);
+  }
+  b1 = out[0];
+  b2 = out[1];
+}
+
 // one calcOpticalFlowPyrLK call for one point; returns nextPts[pt] and status
+template <int ACCUM>
 __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, const float2 init,
-                                         uint32_t* regJ, int lane, float2& np_out, int& st_out) {
+                                         uint32_t* regJ, int* acc_s, float* acc_t, const LkTermPlan* plan, int lane,
+                                         float2& np_out, int& st_out) {
   constexpr int WIN = kLkWin, NP = 7, NPP = (NP + 1) / 2, NL = kMaxLevels;
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
@@ -1879,9 +2024,22 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         pIxp[L][m] = pack16(pIx[2 * m], pIx[2 * m + 1]);
         pIyp[L][m] = pack16(pIy[2 * m], pIy[2 * m + 1]);
       }
-      float fdummy;
-      wave_sum2_exact(sA11, sA12, rl, A11[L], A12[L]);  // already scaled by FLT_SCALE = 2^-20
-      wave_sum2_exact(sA22, kRedSeed, rl, A22[L], fdummy);
+      if (ACCUM == 2) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous level's readers)
+        if (on) {
+#pragma unroll
+          for (int k = 0; k < NP; k++) {
+            acc_s[row * kLkWin + x0 + k] = pIx[k];
+            acc_s[kLkWin * kLkWin + row * kLkWin + x0 + k] = pIy[k];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+        lk_float_sums_A(acc_s, lane, A11[L], A12[L], A22[L]);
+      } else {
+        float fdummy;
+        wave_sum2_exact(sA11, sA12, rl, A11[L], A12[L]);  // already scaled by FLT_SCALE = 2^-20
+        wave_sum2_exact(sA22, kRedSeed, rl, A22[L], fdummy);
+      }
       const float D = A11[L] * A22[L] - A12[L] * A12[L];
       const float minEig =
           (A22[L] + A11[L] - sqrtf((A11[L] - A22[L]) * (A11[L] - A22[L]) + 4.f * A12[L] * A12[L])) /
@@ -1992,7 +2150,34 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         sb2 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, pIyp[L][m]), sb2, false);
       }
       float b1, b2;
-      wave_sum2_exact(sb1, sb2, rl, b1, b2);  // already scaled by FLT_SCALE
+      if (ACCUM == 2) {
+        // the per-pixel products diff * Ix, diff * Iy (exact in int32) -> LDS -> the float chains
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+#pragma unroll
+        for (int m = 0; m < NPP; m++) {
+          const uint32_t hi8 = __builtin_amdgcn_perm(t[2 * m + 1], t[2 * m], 0x06050201u);
+          const us2 val = __builtin_bit_cast(us2, hi8) >> (unsigned short)1;
+          const ss2 diff = __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]);
+          const uint32_t ixp = pIxp[L][m], iyp = pIyp[L][m];
+          const int px0 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, ixp & 0x0000ffffu), 0, false);
+          const int py0 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, iyp & 0x0000ffffu), 0, false);
+          const int px1 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, ixp & 0xffff0000u), 0, false);
+          const int py1 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, iyp & 0xffff0000u), 0, false);
+          if (on) {
+            const int i = row * kLkWin + x0 + 2 * m;
+            acc_s[i] = px0;
+            acc_s[kLkWin * kLkWin + i] = py0;
+            if (2 * m + 1 < NP) {
+              acc_s[i + 1] = px1;
+              acc_s[kLkWin * kLkWin + i + 1] = py1;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+        lk_float_sums_b(acc_s, acc_t, *plan, lane, b1, b2);
+      } else {
+        wave_sum2_exact(sb1, sb2, rl, b1, b2);  // already scaled by FLT_SCALE
+      }
       const float dx = (A12[L] * b2 - A22[L] * b1) * Dinv[L];
       const float dy = (A12[L] * b1 - A11[L] * b2) * Dinv[L];
       nextX += dx;
@@ -2061,8 +2246,9 @@ __device__ __forceinline__ void chain_publish(const LkKernelArgs& a, int pt, int
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
+template <int ACCUM>
+__device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (*regJ_s)[kLkRegDw], int* acc_s,
+                                               float* acc_t, const LkTermPlan* plan) {
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int pt = blockIdx.x * 4 + wave;
   const int n = a.n_ptr ? *a.n_ptr : a.n_max;
@@ -2121,7 +2307,7 @@ __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
   const float2 init = (a.fwd.flags & 4) ? a.init_pts[pt] : make_float2(0.f, 0.f);
   float2 np;
   int st;
-  lk_point(a.fwd, prev0, init, regJ_s[wave], lane, np, st);
+  lk_point<ACCUM>(a.fwd, prev0, init, regJ_s[wave], acc_s, acc_t, plan, lane, np, st);
   chain_publish(a, pt, lane, np, st);
   if (lane == 0) {
     a.next_pts[pt] = np;
@@ -2130,12 +2316,29 @@ __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
   if (a.have_back) {
     float2 bp;
     int bs;
-    lk_point(a.back, np, prev0, regJ_s[wave], lane, bp, bs);
+    lk_point<ACCUM>(a.back, np, prev0, regJ_s[wave], acc_s, acc_t, plan, lane, bp, bs);
     if (lane == 0) {
       a.back_pts[pt] = bp;
       a.back_status[pt] = (uint8_t)bs;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
+  lk_kernel_body<1>(a, regJ_s, nullptr, nullptr, nullptr);
+}
+// lk_accum 2: float sums in the reference build's order (see lk_float_sums_A / _b)
+__global__ __launch_bounds__(256) void k_lk_f32(LkKernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
+  __shared__ int acc_all[4][kLkAccWords];
+  __shared__ __attribute__((aligned(16))) float term_all[4][kLkTermWords];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) acc_all[wave][kLkAccZero] = 0;
+  for (int i = lane; i < kLkTermWords; i += 64) term_all[wave][i] = 0.f;  // (unused slots stay +0.f)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  const LkTermPlan plan = lk_term_plan(lane);
+  lk_kernel_body<2>(a, regJ_s, acc_all[wave], term_all[wave], &plan);
 }
 
 void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts,
@@ -2174,7 +2377,10 @@ void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts
   a.chain_out = f.chain_out;
   a.chain_in = f.chain_in;
   a.chain_seq = f.chain_seq;
-  launch_k(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
+  if (f.accum == 2)
+    launch_k(k_lk_f32, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
+  else
+    launch_k(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
 }
 
 // ============================================================================ Arc*

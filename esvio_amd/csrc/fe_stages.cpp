@@ -413,7 +413,9 @@ void run_lk(esvio_fe_ctx* c, const LkArgs& f, const LkArgs* b, float2* back_pts,
   uint64_t bytes = (uint64_t)f.n_max * (f.max_level + 1) * kLkWin * kLkWin * 5;
   if (b) bytes += (uint64_t)f.n_max * (b->max_level + 1) * kLkWin * kLkWin * 5;
   ScopedKernel k(c, K_LK, bytes);
-  launch_lk(cur_stream(c), f, b, back_pts, back_status);
+  LkArgs fa = f;
+  fa.accum = c->cfg.lk_accum;
+  launch_lk(cur_stream(c), fa, b, back_pts, back_status);
 }
 
 // A caller's W x H image <-> level 0 of a padded pyramid.  Not as one 2-D copy between the caller's

@@ -186,7 +186,7 @@ def make_config(W, H, device=-1, **kw):
     c.equalize = kw.get("equalize", 0)
     c.f_threshold = kw.get("f_threshold", 1.0)
     c.f_ransac = kw.get("f_ransac", 1)
-    c.lk_accum = 1
+    c.lk_accum = kw.get("lk_accum", 1)
     c.focal_length = kw.get("focal_length", 460)
     c.device = device
     cams = kw.get("cams")
