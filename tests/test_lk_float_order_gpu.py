@@ -79,3 +79,19 @@ def test_track_event_with_the_float_order(oracle, replay):
         _compare_tracks(ft, r, ("float order", replay, f))
     assert len(ft.ids) > 80
     ft.close()
+
+
+def test_track_image_with_the_float_order(oracle):
+    """the image front-end takes the same LK kernel: trackImage with lk_accum 2 on both sides"""
+    from esvio_amd.synth import ImageStream
+    W, H = 640, 480
+    s = ImageStream(W, H, velocity=(4, -3), disparity=11, seed=6)
+    kw = dict(max_cnt=150, min_dist=30, flow_back=1, lk_accum=2)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
+    for f in range(5):
+        L, R, t = s.next_frame()
+        ft.trackImage(t, L, R, f != 2)
+        _compare_tracks(ft, tr.track_image(t, L, R, f != 2), ("image float order", f))
+    assert len(ft.ids) > 80 and len(ft.ids_right) > 50
+    ft.close()
