@@ -300,8 +300,8 @@ def main():
     class Runner:
         """one tracker + the schedule it is driven with"""
 
-        def __init__(self, pipeline, lazy, batches, exch=None, rig=None, tsl=None, comm=None):
-            self.ft = FE.FeatureTracker(cfg)
+        def __init__(self, pipeline, lazy, batches, exch=None, rig=None, tsl=None, comm=None, config=None):
+            self.ft = FE.FeatureTracker(config if config is not None else cfg)
             self.comm = comm is not None
             if comm is not None:
                 self.ft.comm_init(comm, rank, world)
@@ -517,6 +517,30 @@ def main():
                         h2d_GBs=round(ev * 16 / th / 1e9, 2),
                         note="events handed over as pageable host buffers (ESVIO_FE_HOST); never `value`")
 
+    # ---- the same replay schedule with the LK sums accumulated in float in the order of the reference's
+    # x86 OpenCV build (lk_accum 2, k_lk_f32): what a caller runs who needs that build's tracks rather
+    # than the exact sums.  Reported beside `value`, never as it.
+    float_lk = None
+    if rank == 0 and not one_rig and not args.no_host_pass and args.lk_accum == 1:
+        fcfg = FE.make_config(W, H, device=dev_index, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1,
+                              equalize=args.equalize, lk_accum=2)
+        run = Runner(pipeline, lazy, dev_batches, config=fcfg)
+        for i in range(args.warmup):
+            run.step(i, exchange=False)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        ev = 0
+        for i in range(args.warmup, args.warmup + args.steps):
+            ev += run.step(i, exchange=False)
+        if lazy:
+            run.ft.finish(copy=False)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf0
+        run.ft.close()
+        float_lk = dict(value=round(ev / tf / 1e6, 3), unit="Mevents/s", ms_per_step=round(tf / args.steps * 1e3, 4),
+                        note="lk_accum 2: LK sums in float in the order of the reference's x86 OpenCV build "
+                             "(bit-exact against the oracle's float-order mode); never `value`")
+
     # ---- CPU baseline: the oracle (single-threaded port of the reference path) on a bounded sample
     cpu = None
     if rank == 0 and args.cpu_frames > 0:
@@ -603,6 +627,7 @@ def main():
                             max=round(ms_all[-1], 4),
                             value_median=round(passes[0][0] / args.steps / ms_all[len(ms_all) // 2] / 1e3, 3)),
             "host_resident_events": host_res,
+            "float_order_lk": float_lk,
             "host_ransac": host_ransac,
             "roofline": roof,
             "cpu_baseline": cpu,
