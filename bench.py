@@ -499,7 +499,7 @@ def main():
     # ---- the same replay schedule with the events in HOST memory (what the drop-in binding of
     # INTEGRATION.md passes): every batch then crosses PCIe inside the call that prefetches it
     host_res = None
-    if rank == 0 and not one_rig and not args.no_host_pass:
+    if rank == 0 and world == 1 and not one_rig and not args.no_host_pass:
         run = Runner(pipeline, lazy, host_batches)
         for i in range(args.warmup):
             run.step(i, exchange=False)
@@ -521,7 +521,7 @@ def main():
     # x86 OpenCV build (lk_accum 2, k_lk_f32): what a caller runs who needs that build's tracks rather
     # than the exact sums.  Reported beside `value`, never as it.
     float_lk = None
-    if rank == 0 and not one_rig and not args.no_host_pass and args.lk_accum == 1:
+    if rank == 0 and world == 1 and not one_rig and not args.no_host_pass and args.lk_accum == 1:
         fcfg = FE.make_config(W, H, device=dev_index, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1,
                               equalize=args.equalize, lk_accum=2)
         run = Runner(pipeline, lazy, dev_batches, config=fcfg)
@@ -543,7 +543,7 @@ def main():
 
     # ---- CPU baseline: the oracle (single-threaded port of the reference path) on a bounded sample
     cpu = None
-    if rank == 0 and args.cpu_frames > 0:
+    if rank == 0 and world == 1 and args.cpu_frames > 0:  # (the CPU baseline is an N = 1 figure)
         from oracle import oracle as O
         ocfg = O.make_config(W, H, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1,
                              lk_accum=args.lk_accum, equalize=args.equalize)
