@@ -1863,11 +1863,13 @@ __device__ __forceinline__ void lk_float_sums_A(const int* s, int lane, float& A
 constexpr int kLkChains = 10, kLkTermsPerLane = 9;
 constexpr int kLkTermWords = kLkChains * kLkWin * 8;
 
-struct LkTermPlan {
-  int16_t a[kLkTermsPerLane], b[kLkTermsPerLane], d[kLkTermsPerLane];  // int sources (b: or the zero word), float destination
+struct LkTermPlan {  // LDS addresses, fixed for the launch: int sources (b: or the zero word), float destination
+  const int* a[kLkTermsPerLane];
+  const int* b[kLkTermsPerLane];
+  float* d[kLkTermsPerLane];
 };
 
-__device__ __forceinline__ LkTermPlan lk_term_plan(int lane) {
+__device__ __forceinline__ LkTermPlan lk_term_plan(int lane, const int* s, float* T) {
   constexpr int NP2 = kLkWin * kLkWin, kVec = 8 * kLkWin * 2, kAll = kVec + 2 * kLkWin * 5;
   LkTermPlan p;
 #pragma unroll
@@ -1891,9 +1893,9 @@ __device__ __forceinline__ LkTermPlan lk_term_plan(int lane) {
       cb = -1;
     }
     const int o = (chain < 8 ? chain >> 2 : chain - 8) ? NP2 : 0;
-    p.a[r] = (int16_t)(o + row * kLkWin + ca);
-    p.b[r] = (int16_t)(cb < 0 ? kLkAccZero : o + row * kLkWin + cb);
-    p.d[r] = (int16_t)(t < kAll ? (chain * kLkWin + row) * 8 + slot : -1);
+    p.a[r] = s + o + row * kLkWin + ca;
+    p.b[r] = s + (cb < 0 ? kLkAccZero : o + row * kLkWin + cb);
+    p.d[r] = T + (t < kAll ? (chain * kLkWin + row) * 8 + slot : kLkTermWords);  // (beyond the table: a spare word)
   }
   return p;
 }
@@ -1901,10 +1903,8 @@ __device__ __forceinline__ LkTermPlan lk_term_plan(int lane) {
 __device__ __forceinline__ void lk_float_sums_b(const int* s, float* T, const LkTermPlan& plan, int lane, float& b1,
                                                 float& b2) {
 #pragma unroll
-  for (int r = 0; r < kLkTermsPerLane; r++) {
-    const float v = (float)(s[plan.a[r]] + s[plan.b[r]]);  // pmaddwd's int32 pair sum, then v_cvt_f32
-    if (plan.d[r] >= 0) T[plan.d[r]] = v;
-  }
+  for (int r = 0; r < kLkTermsPerLane; r++)
+    *plan.d[r] = (float)(*plan.a[r] + *plan.b[r]);  // pmaddwd's int32 pair sum, then v_cvt_f32
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
   // lanes 0..9 walk chains 0..9 (the others walk chain 0 again and are not looked at)
   const float4* row = (const float4*)(T + (lane < kLkChains ? lane : 0) * kLkWin * 8);
@@ -2332,12 +2332,12 @@ __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
 __global__ __launch_bounds__(256) void k_lk_f32(LkKernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
   __shared__ int acc_all[4][kLkAccWords];
-  __shared__ __attribute__((aligned(16))) float term_all[4][kLkTermWords];
+  __shared__ __attribute__((aligned(16))) float term_all[4][kLkTermWords + 4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) acc_all[wave][kLkAccZero] = 0;
   for (int i = lane; i < kLkTermWords; i += 64) term_all[wave][i] = 0.f;  // (unused slots stay +0.f)
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-  const LkTermPlan plan = lk_term_plan(lane);
+  const LkTermPlan plan = lk_term_plan(lane, acc_all[wave], term_all[wave]);
   lk_kernel_body<2>(a, regJ_s, acc_all[wave], term_all[wave], &plan);
 }
 
