@@ -1,0 +1,145 @@
+"""soak.py — randomized end-to-end parity soak on the GPU: for `--minutes` minutes, random sensor sizes,
+event rates, feature budgets, equalize / lk_accum / median settings, publish patterns and replay
+schedules (0..3 batches announced ahead, lazy mode and helper threads switched between calls, finish()
+now and then); every frame's public result vectors are compared bit for bit with the oracle's.
+Stops at the first difference and prints the configuration that produced it.
+
+    python tools/soak.py --minutes 10 [--seed 1]
+"""
+import argparse
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from esvio_amd import frontend as FE
+from esvio_amd.events import event_times
+from esvio_amd.synth import ImageStream, PoissonStream, SceneStream
+from oracle import oracle as O
+
+FIELDS = ("cur_pts", "cur_un_pts", "pts_velocity", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity")
+
+
+def same(ft, r, left_only=False):
+    if not (np.array_equal(ft.ids, r.ids) and np.array_equal(ft.track_cnt, r.track_cnt)):
+        return "ids / track_cnt"
+    if not left_only and not np.array_equal(ft.ids_right, r.ids_right):
+        return "ids_right"
+    for k in FIELDS[:3] if left_only else FIELDS:
+        a, b = getattr(ft, k), getattr(r, k)
+        if a.shape != b.shape or not np.array_equal(a.view(np.uint32), b.view(np.uint32)):
+            return k
+    return None
+
+
+def image_case(rng, case):
+    """the image front-end: trackImage over a translating texture, a frame without a right image now and then"""
+    W, H = [(346, 260), (640, 480), (1224, 1024), (1440, 1080)][int(rng.integers(0, 4))]
+    kw = dict(max_cnt=int(rng.integers(30, 250)), min_dist=int(rng.integers(8, 45)), equalize=int(rng.random() < 0.3),
+              lk_accum=1 + int(rng.random() < 0.3), flow_back=int(rng.random() < 0.85))
+    seed = int(rng.integers(0, 1 << 30))
+    s = ImageStream(W, H, velocity=(int(rng.integers(-6, 7)), int(rng.integers(-5, 6))), disparity=int(rng.integers(4, 20)),
+                    seed=seed)
+    n = int(rng.integers(3, 8))
+    desc = dict(case=case, kind="image", W=W, H=H, seed=seed, frames=n, **kw)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = O.Tracker(O.make_config(W, H, **kw))
+    try:
+        for f in range(n):
+            L, R, t = s.next_frame()
+            if rng.random() < 0.15:
+                R = None
+            pub = bool(rng.random() < 0.7)
+            ft.trackImage(t, L, R, pub)
+            bad = same(ft, tr.track_image(t, L, R, pub))
+            if bad:
+                return desc, "frame %d: %s differs" % (f, bad)
+    finally:
+        ft.close()
+    return desc, None
+
+
+def one_case(rng, case):
+    if rng.random() < 0.1:
+        return image_case(rng, case)
+    W, H = [(346, 260), (640, 480), (173, 131), (800, 600), (1280, 720)][int(rng.integers(0, 5))]
+    rate = float(rng.choice([3e5, 1e6, 3e6, 8e6])) * (W * H / (640 * 480)) ** 0.5
+    kw = dict(max_cnt=int(rng.integers(20, 400)), min_dist=int(rng.integers(3, 41)), f_ransac=1,
+              equalize=int(rng.random() < 0.25), lk_accum=1 + int(rng.random() < 0.3), flow_back=int(rng.random() < 0.85),
+              median_blur_kernel_size=int(rng.random() < 0.1))
+    seed = int(rng.integers(0, 1 << 30))
+    stream = (PoissonStream(W, H, rate=rate, seed=seed) if rng.random() < 0.15 else
+              SceneStream(W, H, rate=rate, seed=seed, n_rect=int(rng.integers(4, 30))))
+    n = int(rng.integers(6, 22))
+    batches = [stream.next_batch()[:2] for _ in range(n)]
+    p_pub = float(rng.choice([0.3, 0.5, 0.8, 1.0]))
+    pubs = [bool(rng.random() < p_pub) for _ in batches]
+    desc = dict(case=case, W=W, H=H, rate=rate, seed=seed, frames=n, p_pub=p_pub, **kw)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = O.Tracker(O.make_config(W, H, **kw))
+    replay = rng.random() < 0.7
+    mc = (not replay) and rng.random() < 0.4  # Do_motion_correction (no announced batches with it)
+    desc["replay"], desc["mc"] = bool(replay), bool(mc)
+    announced = 0
+    try:
+        for f, (L, R) in enumerate(batches):
+            if replay:
+                if rng.random() < 0.2:
+                    ft.set_lazy_new_stereo(bool(rng.integers(0, 2)))
+                if rng.random() < 0.15:
+                    ft.set_host_threads(int(rng.integers(1, 6)))
+                announced = max(announced, f)
+                want = min(f + int(rng.integers(0, 4)), len(batches) - 1)
+                while announced < want:
+                    announced += 1
+                    Ln, Rn = batches[announced]
+                    ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+            t = event_times(L)[-1]
+            if mc:
+                te = event_times(L)
+                mv = dict(t1=te[0] + float(rng.uniform(-0.2, 1.3)) * (te[-1] - te[0]), v=tuple(rng.uniform(-1, 1, 3)),
+                          v_pre=tuple(rng.uniform(-1, 1, 3)), accel=tuple(rng.uniform(-6, 6, 3)),
+                          omega=tuple(rng.uniform(-3, 3, 3) * (10 if rng.random() < 0.1 else 1)),
+                          fx=0.9 * W, fy=0.9 * W, cx=W / 2.0 + 1.5, cy=H / 2.0 - 0.75)
+                ft.trackEvent(t, L, R, pubs[f], measurements=FE.make_motion(**mv))
+                r = tr.track_event(t, L, R, pubs[f], motion=O.make_motion(**mv))
+            else:
+                ft.trackEvent(t, L, R, pubs[f])
+                r = tr.track_event(t, L, R, pubs[f])
+            left_only = False
+            if replay and (rng.random() < 0.5 or f == len(batches) - 1):
+                ft.finish()
+            elif replay:
+                left_only = True  # (a lazy frame's right-camera entries are completed by the next call)
+            bad = same(ft, r, left_only)
+            if bad:
+                return desc, "frame %d: %s differs" % (f, bad)
+        if not np.array_equal(ft.gettimesurface(0), tr.time_surface(0)):
+            return desc, "time surface differs"
+    finally:
+        ft.close()
+    return desc, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=5.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    cases = frames = 0
+    while time.time() - t0 < a.minutes * 60:
+        desc, err = one_case(rng, cases)
+        cases += 1
+        frames += desc["frames"]
+        if err:
+            print("MISMATCH", err, desc)
+            sys.exit(1)
+    print("soak: %d cases, %d frames, %.1f min, no difference" % (cases, frames, (time.time() - t0) / 60))
+
+
+if __name__ == "__main__":
+    main()
