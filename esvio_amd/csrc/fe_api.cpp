@@ -128,7 +128,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->x_pin_recv) (void)hipHostFree(c->x_pin_recv);
   void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_tile, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
-                  c->d_mask_bits, c->d_sel_idx, c->d_sel_bitmap,
+                  c->d_mask_bits, c->d_sel_idx, c->d_sel_bitmap, c->d_eq_tmp,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
                   c->d_minmax};
   for (void* p : ptrs)

@@ -318,6 +318,7 @@ struct esvio_fe_ctx {
 
   // ---- host phase trace (ESVIO_FE_TRACE=1): stage, sae+ts enqueue, sync A, host A, enqueue B,
   // sync B, host B
+  uint8_t* d_eq_tmp = nullptr;  // equalize: the two CLAHE outputs before normalisation (linear W x H each)
   bool select_ok = true;  // the greedy selection's bitmap fits LDS
   uint32_t* d_sel_bitmap = nullptr;  // ... else it lives here (k_select_gbm)
   bool trace = false;

@@ -200,6 +200,8 @@ void launch_median(hipStream_t s, const uint8_t* src0, const uint8_t* src1, int 
 
 // ---- CLAHE + normalize (equalize: 1) ---------------------------------------------------------
 // stage 0: per-tile LUTs, stage 1: LUT blending + min/max, stage 2: MINMAX normalisation in place
+void launch_norm_pyr(hipStream_t s, const uint8_t* src0, const uint8_t* src1, int src_stride, const int* minmax,
+                     const PyrDesc* p);
 void launch_clahe(hipStream_t s, const uint8_t* raw0, const uint8_t* raw1, int raw_stride,
                   uint8_t* dst0, uint8_t* dst1, int dst_stride, int W, int H, uint8_t* lut,
                   int* minmax, int nimg, int stage);

@@ -1439,8 +1439,19 @@ __device__ __forceinline__ void fused_down(const uint8_t* __restrict__ src_l, ui
   }
 }
 
-__global__ __launch_bounds__(kFtThreads) void k_ts_pyr(const double2* __restrict__ S2, double t_sync,
-                                                double decay_sec, int ignore_polarity, PyrPack pk) {
+// FROM_IMG: level 0 is not rendered from the SAE but is cv::normalize(., 0, 255, NORM_MINMAX) of an
+// existing u8 image (the CLAHE output of the `equalize: 1` branch, k_clahe_interp) whose extremes are
+// in minmax[2 cam .. 2 cam + 1] — k_normalize's arithmetic per pixel — so that branch, too, goes from
+// its level-0 source to the four pyramid levels in one launch.
+struct EqSrc {
+  const uint8_t* img[2];  // pixel (0,0) of the two un-normalised images
+  int stride;
+  const int* minmax;
+};
+
+template <bool FROM_IMG>
+__device__ __forceinline__ void ts_pyr_body(const double2* __restrict__ S2, double t_sync, double decay_sec,
+                                            int ignore_polarity, const EqSrc& eq, const PyrPack& pk) {
   __shared__ uint8_t l0[kFt0y * kFs0];
   __shared__ uint8_t l1[kFt1y * kFs1];
   __shared__ uint8_t l2[kFt2y * kFs2];
@@ -1451,10 +1462,26 @@ __global__ __launch_bounds__(kFtThreads) void k_ts_pyr(const double2* __restrict
   const int o2x = 2 * o3x - 2, o2y = 2 * o3y - 2;
   const int o1x = 2 * o2x - 2, o1y = 2 * o2y - 2;
   const int o0x = 2 * o1x - 2, o0y = 2 * o1y - 2;
+  constexpr int kN0 = kFt0x * kFt0y;
+  if (FROM_IMG) {
+    const double smin = eq.minmax[2 * cam], smax = eq.minmax[2 * cam + 1];
+    const double scale = 255.0 * (__dsub_rn(smax, smin) > 2.2204460492503131e-16 ? 1. / __dsub_rn(smax, smin) : 0);
+    const float fa = (float)scale, fb = (float)__dsub_rn(0.0, __dmul_rn(smin, scale));
+    const uint8_t* src = eq.img[cam];
+    for (int i = threadIdx.x; i < kN0; i += kFtThreads) {
+      const int ry = i / kFt0x, rx = i - ry * kFt0x;
+      const int x = o0x + rx, y = o0y + ry;
+      if (x < 0 || y < 0 || x >= W || y >= H) continue;
+      const int r = __float2int_rn(__fadd_rn(__fmul_rn((float)src[(size_t)y * eq.stride + x], fa), fb));
+      const uint8_t v = (uint8_t)((unsigned)r <= 255u ? r : r > 0 ? 255 : 0);
+      l0[ry * kFs0 + rx] = v;
+      if (x >= 8 * o3x && x < 8 * o3x + 8 * kFt3x && y >= 8 * o3y && y < 8 * o3y + 8 * kFt3y)
+        p.img[0][(size_t)(y + kPad) * p.stride[0] + x + kPad] = v;
+    }
+  }
   const double2* S = S2 + (size_t)cam * W * H;
   // (four pixels per thread and step, loads first: the 16 B gathers are what the loop waits for)
-  constexpr int kN0 = kFt0x * kFt0y;
-  for (int i0 = threadIdx.x; i0 < kN0; i0 += 4 * kFtThreads) {
+  for (int i0 = threadIdx.x; !FROM_IMG && i0 < kN0; i0 += 4 * kFtThreads) {
     double2 sv[4];
     int xs[4], ys[4];
     bool ok[4];
@@ -1489,12 +1516,33 @@ __global__ __launch_bounds__(kFtThreads) void k_ts_pyr(const double2* __restrict
                                                 p.h[3], p.img[3], p.stride[3], o3x, o3y, kFt3x, kFt3y);
 }
 
+__global__ __launch_bounds__(kFtThreads) void k_ts_pyr(const double2* __restrict__ S2, double t_sync,
+                                                double decay_sec, int ignore_polarity, PyrPack pk) {
+  ts_pyr_body<false>(S2, t_sync, decay_sec, ignore_polarity, EqSrc{}, pk);
+}
+__global__ __launch_bounds__(kFtThreads) void k_norm_pyr(EqSrc eq, PyrPack pk) {
+  ts_pyr_body<true>(nullptr, 0.0, 0.0, 0, eq, pk);
+}
+
 // both cameras (p[0], p[1]), maxLevel 3
 void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay_sec,
                    int ignore_polarity, const PyrDesc* p) {
   const int w3 = p[0].w[3], h3 = p[0].h[3];
   launch_k(k_ts_pyr, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, 2), dim3(kFtThreads), 0, s, S2,
            t_sync, decay_sec, ignore_polarity, make_pack(p, 2));
+}
+
+// the `equalize: 1` branch: normalize + the three pyrDown levels of both cameras (see EqSrc)
+void launch_norm_pyr(hipStream_t s, const uint8_t* src0, const uint8_t* src1, int src_stride, const int* minmax,
+                     const PyrDesc* p) {
+  const int w3 = p[0].w[3], h3 = p[0].h[3];
+  EqSrc eq;
+  eq.img[0] = src0;
+  eq.img[1] = src1;
+  eq.stride = src_stride;
+  eq.minmax = minmax;
+  launch_k(k_norm_pyr, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, 2), dim3(kFtThreads), 0, s, eq,
+           make_pack(p, 2));
 }
 
 // copyMakeBorder(level, BORDER_REFLECT_101) for every level [OpenCV buildOpticalFlowPyramid]

@@ -362,6 +362,35 @@ void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int 
   PyrDesc two[2] = {c->pyr[slotL].d, c->pyr[slotR].d};
   const bool fused = c->fuse_ts_pyr && !c->cfg.equalize && c->cfg.median_blur_kernel_size <= 0 &&
                      two[0].levels == 3 && two[1].levels == 3;
+  const bool fused_eq = c->fuse_ts_pyr && c->cfg.equalize && c->cfg.median_blur_kernel_size <= 0 &&
+                        two[0].levels == 3 && two[1].levels == 3;
+  if (fused_eq) {
+    // time surfaces -> raw; CLAHE LUTs; CLAHE output -> a linear scratch pair (no in-place normalise:
+    // the fused kernel's blocks read their neighbours' pixels); normalise + pyramid levels; borders + Scharr
+    if (!c->d_eq_tmp)
+      if (dev_alloc(c, &c->d_eq_tmp, (size_t)2 * c->P) != 0) return;
+    const PyrDesc& rl = c->raw[rawbuf][0].d;
+    const PyrDesc& rr = c->raw[rawbuf][1].d;
+    render_ts(c, t_sync, rl.img[0], rr.img[0], 2, c->S2);
+    for (int stage = 0; stage < 2; stage++) {
+      ScopedKernel k(c, K_CLAHE, stage == 0 ? (uint64_t)c->P * 2 : (uint64_t)c->P * 4);
+      launch_clahe(cur_stream(c), px00(rl), px00(rr), rl.stride[0], c->d_eq_tmp, c->d_eq_tmp + c->P, c->W, c->W,
+                   c->H, c->d_lut, c->d_minmax, 2, stage);
+    }
+    {
+      uint64_t px = 0;
+      for (int l = 0; l <= 3; l++) px += (uint64_t)two[0].w[l] * two[0].h[l];
+      ScopedKernel k(c, K_PYR_DOWN, ((uint64_t)c->P + px) * 2);
+      launch_norm_pyr(cur_stream(c), c->d_eq_tmp, c->d_eq_tmp + c->P, c->W, c->d_minmax, two);
+    }
+    {
+      uint64_t all = 0;
+      for (int l = 0; l <= 3; l++) all += (uint64_t)two[0].w[l] * two[0].h[l];
+      ScopedKernel k(c, K_SCHARR, all * 5 * 2);
+      launch_pad_scharr(cur_stream(c), two, 2);
+    }
+    return;
+  }
   if (!fused) {
     render_lk_images(c, t_sync, 3, slotL, slotR, rawbuf);
     pyr_build(c, two, 2);
