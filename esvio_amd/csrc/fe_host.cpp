@@ -1238,6 +1238,13 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
     std::fill(status, status + count, (uint8_t)1);
     return n > 0 ? count : 0;
   }
+  // without helper threads the same loops run on a pool of none: the calling thread draws, solves the
+  // subsets kLanes at a time and replays them in order
+  static thread_local std::unique_ptr<RansacPool> solo;
+  if (!pool) {
+    if (!solo) solo.reset(ransac_pool_alloc());
+    pool = solo.get();
+  }
   if (count >= 15) {  // RANSAC
     std::vector<double> xy((size_t)4 * count);
     double *x1 = xy.data(), *y1 = x1 + count, *x2 = y1 + count, *y2 = x2 + count;
@@ -1246,13 +1253,6 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
       y1[i] = m1[2 * i + 1];
       x2[i] = m2[2 * i];
       y2[i] = m2[2 * i + 1];
-    }
-    // without helper threads the same loop runs on a pool of none: the calling thread draws, solves
-    // the subsets kLanes at a time and replays them in order
-    static thread_local std::unique_ptr<RansacPool> solo;
-    if (!pool) {
-      if (!solo) solo.reset(ransac_pool_alloc());
-      pool = solo.get();
     }
     const auto t0 = std::chrono::steady_clock::now();
     int iters = 0;
@@ -1266,11 +1266,6 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
   }
   // LMedS for 8..14 points
   const auto t0 = std::chrono::steady_clock::now();
-  static thread_local std::unique_ptr<RansacPool> solo_lm;
-  if (!pool) {
-    if (!solo_lm) solo_lm.reset(ransac_pool_alloc());
-    pool = solo_lm.get();
-  }
   const int good = lmeds_pooled(pool, m1, m2, count, conf, status);
   g_rs_lm_calls.fetch_add(1, std::memory_order_relaxed);
   g_rs_lm_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
