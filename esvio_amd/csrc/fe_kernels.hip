@@ -1855,41 +1855,55 @@ __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
 constexpr int kLkAccZero = 2 * kLkWin * kLkWin;  // index of a word that holds 0 (for the empty slots)
 constexpr int kLkAccWords = kLkAccZero + 4;       // two ints per window pixel + the zero word
 
-// Every chain takes five terms per window row (a vector lane four — or two pairs — and a zero, the
-// tail its five columns), so that all chain lanes run one loop in lock step: 105 dependent adds,
-// the next row's operands fetched from LDS while the current row is added.  Adding +0.f is exact.
-
-// lanes 0..11: vector chains (type = lane / 4: A11, A12, A22; k = lane % 4), lanes 12..14: the tails
-__device__ __forceinline__ void lk_float_sums_A(const int* s, int lane, float& A11, float& A12, float& A22) {
-  constexpr int NP2 = kLkWin * kLkWin;
-  const int typ = lane < 12 ? lane >> 2 : (lane < 15 ? lane - 12 : 0);
-  const int oa = typ == 2 ? NP2 : 0, ob = typ == 0 ? 0 : NP2;  // factor planes: ix = 0, iy = NP2
-  int col[5];
-#pragma unroll
-  for (int j = 0; j < 5; j++) col[j] = lane < 12 ? (j < 4 ? 4 * j + (lane & 3) : -1) : (lane < 15 ? 16 + j : -1);
+// Every chain takes five terms per window row (a vector lane four — or two pair sums — and zeros, the
+// tail its five columns), kept as floats in LDS, T[chain][row][8]: slots a chain does not use hold
+// +0.f (adding it is exact), so that all chain lanes run one loop in lock step — 105 dependent adds,
+// a row fetched with two LDS instructions while the previous one is added.
+__device__ __forceinline__ float lk_chain_walk(const float* T, int chain) {
+  const float4* row = (const float4*)(T + chain * kLkWin * 8);
   float acc = 0.f;
-  int va[5], vb[5];
+  float4 c0 = row[0];
+  float c4 = ((const float*)row)[4];
 #pragma unroll
-  for (int j = 0; j < 5; j++) {
-    va[j] = s[col[j] < 0 ? kLkAccZero : oa + col[j]];
-    vb[j] = s[col[j] < 0 ? kLkAccZero : ob + col[j]];
-  }
   for (int y = 0; y < kLkWin; y++) {
-    int na[5], nb[5];
-    const int base = (y + 1 < kLkWin ? y + 1 : y) * kLkWin;
+    const int yn = y + 1 < kLkWin ? y + 1 : y;
+    const float4 n0 = row[2 * yn];
+    const float n4 = ((const float*)(row + 2 * yn))[4];
+    acc = __fadd_rn(acc, c0.x);
+    acc = __fadd_rn(acc, c0.y);
+    acc = __fadd_rn(acc, c0.z);
+    acc = __fadd_rn(acc, c0.w);
+    acc = __fadd_rn(acc, c4);
+    c0 = n0;
+    c4 = n4;
+  }
+  return acc;
+}
+
+// A matrix (once per pyramid level): fifteen chains — type t = A11, A12, A22: vector lanes 4 t + k
+// (k = column mod 4, slot = column / 4, columns 0..15), tail 12 + t (columns 16..20).  The pixel
+// lanes write their own products (< 2^24: exact in float) straight into TA; the combination is
+// tail + ((q0 + q2) + (q1 + q3)), v_reduce_sum's order, times FLT_SCALE.
+constexpr int kLkChainsA = 15;
+constexpr int kLkTermWordsA = kLkChainsA * kLkWin * 8;
+
+__device__ __forceinline__ void lk_float_sums_A(float* TA, bool on, int row, int x0, const int* pIx, const int* pIy,
+                                                int lane, float& A11, float& A12, float& A22) {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous level's readers)
+  if (on) {
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-      na[j] = s[col[j] < 0 ? kLkAccZero : oa + base + col[j]];
-      nb[j] = s[col[j] < 0 ? kLkAccZero : ob + base + col[j]];
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) acc = __fadd_rn(acc, __fmul_rn((float)va[j], (float)vb[j]));  // (products < 2^24: exact)
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      va[j] = na[j];
-      vb[j] = nb[j];
+    for (int k = 0; k < 7; k++) {
+      const int x = x0 + k;
+      const bool vec = x < 16;
+      const int base = ((vec ? (x & 3) : 12) * kLkWin + row) * 8 + (vec ? x >> 2 : x - 16);
+      const int step = (vec ? 4 : 1) * kLkWin * 8;  // from one type's chain to the next type's
+      TA[base] = (float)(pIx[k] * pIx[k]);
+      TA[base + step] = (float)(pIx[k] * pIy[k]);
+      TA[base + 2 * step] = (float)(pIy[k] * pIy[k]);
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  const float acc = lk_chain_walk(TA, lane < kLkChainsA ? lane : 0);
   const float kScale = 1.f / (float)(1 << 20);  // FLT_SCALE
   float out[3];
 #pragma unroll
@@ -1955,23 +1969,7 @@ __device__ __forceinline__ void lk_float_sums_b(const int* s, float* T, const Lk
     *plan.d[r] = (float)(*plan.a[r] + *plan.b[r]);  // pmaddwd's int32 pair sum, then v_cvt_f32
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
   // lanes 0..9 walk chains 0..9 (the others walk chain 0 again and are not looked at)
-  const float4* row = (const float4*)(T + (lane < kLkChains ? lane : 0) * kLkWin * 8);
-  float acc = 0.f;
-  float4 c0 = row[0];
-  float c4 = ((const float*)row)[4];
-#pragma unroll
-  for (int y = 0; y < kLkWin; y++) {
-    const int yn = y + 1 < kLkWin ? y + 1 : y;
-    const float4 n0 = row[2 * yn];
-    const float n4 = ((const float*)(row + 2 * yn))[4];
-    acc = __fadd_rn(acc, c0.x);
-    acc = __fadd_rn(acc, c0.y);
-    acc = __fadd_rn(acc, c0.z);
-    acc = __fadd_rn(acc, c0.w);
-    acc = __fadd_rn(acc, c4);
-    c0 = n0;
-    c4 = n4;
-  }
+  const float acc = lk_chain_walk(T, lane < kLkChains ? lane : 0);
   const float kScale = 1.f / (float)(1 << 20);
   float out[2];
 #pragma unroll
@@ -1988,8 +1986,8 @@ __device__ __forceinline__ void lk_float_sums_b(const int* s, float* T, const Lk
 // one calcOpticalFlowPyrLK call for one point; returns nextPts[pt] and status
 template <int ACCUM>
 __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, const float2 init,
-                                         uint32_t* regJ, int* acc_s, float* acc_t, const LkTermPlan* plan, int lane,
-                                         float2& np_out, int& st_out) {
+                                         uint32_t* regJ, int* acc_s, float* acc_t, float* acc_ta,
+                                         const LkTermPlan* plan, int lane, float2& np_out, int& st_out) {
   constexpr int WIN = kLkWin, NP = 7, NPP = (NP + 1) / 2, NL = kMaxLevels;
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
@@ -2073,16 +2071,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         pIyp[L][m] = pack16(pIy[2 * m], pIy[2 * m + 1]);
       }
       if (ACCUM == 2) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous level's readers)
-        if (on) {
-#pragma unroll
-          for (int k = 0; k < NP; k++) {
-            acc_s[row * kLkWin + x0 + k] = pIx[k];
-            acc_s[kLkWin * kLkWin + row * kLkWin + x0 + k] = pIy[k];
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-        lk_float_sums_A(acc_s, lane, A11[L], A12[L], A22[L]);
+        lk_float_sums_A(acc_ta, on, row, x0, pIx, pIy, lane, A11[L], A12[L], A22[L]);
       } else {
         float fdummy;
         wave_sum2_exact(sA11, sA12, rl, A11[L], A12[L]);  // already scaled by FLT_SCALE = 2^-20
@@ -2296,7 +2285,7 @@ __device__ __forceinline__ void chain_publish(const LkKernelArgs& a, int pt, int
 
 template <int ACCUM>
 __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (*regJ_s)[kLkRegDw], int* acc_s,
-                                               float* acc_t, const LkTermPlan* plan) {
+                                               float* acc_t, float* acc_ta, const LkTermPlan* plan) {
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int pt = blockIdx.x * 4 + wave;
   const int n = a.n_ptr ? *a.n_ptr : a.n_max;
@@ -2355,7 +2344,7 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
   const float2 init = (a.fwd.flags & 4) ? a.init_pts[pt] : make_float2(0.f, 0.f);
   float2 np;
   int st;
-  lk_point<ACCUM>(a.fwd, prev0, init, regJ_s[wave], acc_s, acc_t, plan, lane, np, st);
+  lk_point<ACCUM>(a.fwd, prev0, init, regJ_s[wave], acc_s, acc_t, acc_ta, plan, lane, np, st);
   chain_publish(a, pt, lane, np, st);
   if (lane == 0) {
     a.next_pts[pt] = np;
@@ -2364,7 +2353,7 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
   if (a.have_back) {
     float2 bp;
     int bs;
-    lk_point<ACCUM>(a.back, np, prev0, regJ_s[wave], acc_s, acc_t, plan, lane, bp, bs);
+    lk_point<ACCUM>(a.back, np, prev0, regJ_s[wave], acc_s, acc_t, acc_ta, plan, lane, bp, bs);
     if (lane == 0) {
       a.back_pts[pt] = bp;
       a.back_status[pt] = (uint8_t)bs;
@@ -2374,19 +2363,21 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
 
 __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
-  lk_kernel_body<1>(a, regJ_s, nullptr, nullptr, nullptr);
+  lk_kernel_body<1>(a, regJ_s, nullptr, nullptr, nullptr, nullptr);
 }
 // lk_accum 2: float sums in the reference build's order (see lk_float_sums_A / _b)
 __global__ __launch_bounds__(256) void k_lk_f32(LkKernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
   __shared__ int acc_all[4][kLkAccWords];
   __shared__ __attribute__((aligned(16))) float term_all[4][kLkTermWords + 4];
+  __shared__ __attribute__((aligned(16))) float term_a[4][kLkTermWordsA];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) acc_all[wave][kLkAccZero] = 0;
   for (int i = lane; i < kLkTermWords; i += 64) term_all[wave][i] = 0.f;  // (unused slots stay +0.f)
+  for (int i = lane; i < kLkTermWordsA; i += 64) term_a[wave][i] = 0.f;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
   const LkTermPlan plan = lk_term_plan(lane, acc_all[wave], term_all[wave]);
-  lk_kernel_body<2>(a, regJ_s, acc_all[wave], term_all[wave], &plan);
+  lk_kernel_body<2>(a, regJ_s, acc_all[wave], term_all[wave], term_a[wave], &plan);
 }
 
 void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts,

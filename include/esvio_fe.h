@@ -65,7 +65,7 @@ typedef struct esvio_fe_config {
   int32_t lk_accum;                 /* how calcOpticalFlowPyrLK's sums are accumulated: 1 = exactly (int64;
                                      * the default everywhere), 2 = in float in the order of OpenCV 4.2's
                                      * x86 SIMD128 build, i.e. the reference's own build (restated from
-                                     * recall; 2.7x the LK time) */
+                                     * recall; 2.5x the LK time) */
   int32_t focal_length;             /* FOCAL_LENGTH, 460 (parameters.cpp:274) */
   int32_t device;                   /* HIP device ordinal, -1 = current device */
   esvio_fe_camera cam[2];           /* event_left_calib / event_right_calib */

@@ -1,4 +1,5 @@
-"""LK kernel micro-benchmark: per-iteration latency of k_lk on noise images (forces maxCount)."""
+"""LK kernel micro-benchmark: per-iteration latency of k_lk on noise images (forces maxCount).
+    python tools/lk_microbench.py [lk_accum]      1 (default): exact sums; 2: the float order (k_lk_f32)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -8,7 +9,8 @@ from oracle import oracle as O
 
 W, H = 640, 480
 rng = np.random.default_rng(0)
-ft = FE.FeatureTracker(FE.make_config(W, H))
+ACC = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+ft = FE.FeatureTracker(FE.make_config(W, H, lk_accum=ACC))
 ft.set_profiling(True)
 L_ = O.lib(); out = (C.c_ulonglong * 3)()
 for name, (a, b) in {
@@ -25,7 +27,7 @@ for name, (a, b) in {
                 g, st = ft.calcOpticalFlowPyrLK(a, b, pts, maxLevel=ml)
             s = ft.kernel_stats()["k_lk"]
             L_.oracle_lk_iter_stats(out, 1)
-            c, cs = O.lk(a, b, pts, max_level=ml, accum=1)
+            c, cs = O.lk(a, b, pts, max_level=ml, accum=ACC)
             L_.oracle_lk_iter_stats(out, 0)
             assert np.array_equal(g.view(np.uint32), c.view(np.uint32)) and np.array_equal(st, cs)
             print("%-6s n=%3d maxLevel=%d  k_lk avg %.2f us   oracle iters=%d visits=%d (%.1f/visit)" % (
