@@ -716,6 +716,12 @@ int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, doubl
   return 0;
 }
 
+int esvio_fe_host_hypot(const double* x, const double* y, int n, double* out) {
+  if (n < 0 || (n && (!x || !y || !out))) return ESVIO_FE_EINVAL;
+  host::host_hypot(x, y, n, out);
+  return ESVIO_FE_OK;
+}
+
 int esvio_fe_ransac_stats(uint64_t* out6, int reset) {
   if (!out6) return ESVIO_FE_EINVAL;
   const host::RansacStats r = host::ransac_stats(reset != 0);

@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
     "esvio_fe_set_next_batch", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
-    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats",
+    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
@@ -141,6 +141,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_set_lazy_new_stereo.argtypes = [vp, i]
     L.esvio_fe_set_host_threads.argtypes = [vp, i]
     L.esvio_fe_ransac_stats.argtypes = [vp, i]
+    L.esvio_fe_host_hypot.argtypes = [vp, vp, i, vp]
     L.esvio_fe_find_fundamental_mat_mt.argtypes = [vp, vp, i, d, d, i, vp, C.POINTER(C.c_int32)]
     L.esvio_fe_finish.argtypes = [vp, vp]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
@@ -580,6 +581,17 @@ def comm_unique_id():
     if rc:
         raise FrontendError("esvio_fe_comm_unique_id rc=%d (librccl.so not found?)" % rc)
     return bytes(buf)
+
+
+def host_hypot(x, y):
+    """the hypot of the 7-point solver's Jacobi rotations (glibc 2.35's algorithm, inlined in the library)"""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.ascontiguousarray(y, np.float64)
+    out = np.empty_like(x)
+    rc = load_library().esvio_fe_host_hypot(_p(x), _p(y), x.size, _p(out))
+    if rc != 0:
+        raise FrontendError("host_hypot rc=%d" % rc)
+    return out
 
 
 def ransac_stats(reset=False):

@@ -145,3 +145,27 @@ def test_header_is_plain_c(tmp_path):
                    '  return esvio_fe_kernel_count() > 0 && esvio_fe_version() != 0 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                            "-I", os.path.join(root, "include"), str(src)])
+
+
+def test_host_hypot_is_the_hosts_libm_hypot():
+    """cv::SVD's Jacobi rotations call libm's hypot; the library inlines glibc 2.35's algorithm (so that
+    eight 7-point systems share one instruction stream).  It has to BE this host's hypot, bit for bit —
+    numpy's hypot is the libm call — over magnitudes the solver sees (1e5..1e23), wide exponent
+    ranges, near-equal and very unequal operands, zeros, and the scaled branches (huge / tiny)."""
+    rng = np.random.default_rng(12)
+    n = 2_000_000
+    x = rng.normal(size=n) * 10.0 ** rng.uniform(-40, 40, n)
+    y = x * rng.uniform(-3, 3, n)
+    y[::5] = rng.normal(size=len(y[::5])) * 10.0 ** rng.uniform(-40, 40, len(y[::5]))
+    x[::1001] = 0.0
+    y[::1003] = 0.0
+    xs = [x, rng.integers(0, 100000, n).astype(np.float64), 2.0 ** rng.uniform(500, 1020, 50000),
+          2.0 ** rng.uniform(-1070, -440, 50000), rng.uniform(1e5, 1e23, n)]
+    ys = [y, rng.integers(0, 100000, n).astype(np.float64), 2.0 ** rng.uniform(480, 1020, 50000),
+          2.0 ** rng.uniform(-1070, -440, 50000), rng.uniform(1e5, 1e23, n) * 10.0 ** rng.uniform(-20, 3, n)]
+    for a, b in zip(xs, ys):
+        with np.errstate(over="ignore", under="ignore"):
+            want = np.hypot(a, b)
+        got = FE.host_hypot(a, b)
+        bad = got.view(np.uint64) != want.view(np.uint64)
+        assert not bad.any(), (int(bad.sum()), a[bad][:3], b[bad][:3])
