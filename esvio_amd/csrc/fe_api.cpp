@@ -101,6 +101,13 @@ int esvio_fe_destroy(esvio_fe_handle c) {
             c->phase_count[1] ? c->tr_fm_ms / c->phase_count[1] : 0.0, c->tr_fm_max_ms,
             c->phase_count[1] > 1 ? (c->tr_fm_ms - c->tr_fm_max_ms) / (c->phase_count[1] - 1) : 0.0,
             c->phase_count[1] ? c->tr_lift_ms / c->phase_count[1] : 0.0);
+    for (int pub = 0; pub < 2; pub++)
+      if (c->phase_count[pub])
+        fprintf(stderr, "\n[esvio_fe trace] %s frames, host bookkeeping, ms/frame: left undistort + velocity=%.4f previous "
+                "frames' right tails=%.4f this frame's right tail=%.4f copies + profile + exchange=%.4f",
+                pub ? "published" : "unpublished", c->tail_ms[pub][0] / c->phase_count[pub],
+                c->tail_ms[pub][1] / c->phase_count[pub], c->tail_ms[pub][2] / c->phase_count[pub],
+                c->tail_ms[pub][3] / c->phase_count[pub]);
     fprintf(stderr, "\n[esvio_fe trace] rejectWithF_event calls by point count: %llu with < 8 (skipped), %llu with "
             "8..14 (LMedS, 300 hypotheses), %llu with >= 15 (RANSAC)", (unsigned long long)c->tr_fm_class[0],
             (unsigned long long)c->tr_fm_class[1], (unsigned long long)c->tr_fm_class[2]);

@@ -324,6 +324,7 @@ struct esvio_fe_ctx {
   bool trace = false;
   double phase_ms[2][8] = {};  // [published?][phase]
   double pub_ms[6] = {};       // published frames: the parts of "host mask + enqueue detect/stereo"
+  double tail_ms[2][4] = {};   // [published?]: left bookkeeping, previous frames' right tails, this frame's right tail, the rest
   uint64_t phase_count[2] = {0, 0};
   uint64_t phase_frames = 0, tr_cand = 0, tr_new = 0, tr_detect = 0, tr_surv = 0;
   uint64_t tr_fm_class[3] = {};  // rejectWithF_event calls with < 8 points (skipped), 8..14 (LMedS), >= 15 (RANSAC)

@@ -706,12 +706,21 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       c->track_cnt.push_back(1);
     }
   }
+  auto tt = clk::now();
+  auto tail_lap = [&](int i) {
+    if (!c->trace) return;
+    const auto now = clk::now();
+    c->tail_ms[PUB_THIS_FRAME ? 1 : 0][i] += std::chrono::duration<double, std::milli>(now - tt).count();
+    tt = now;
+  };
   c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);  // :470-473
   c->pts_velocity = pts_velocity_fn(c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map,
                                     c->cur_time - c->prev_time, c->cur_pts.size());
   lap(7);
+  tail_lap(0);
   if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners,
   if (int rc = finalize_right(c)) return rc;    //  or the previous unpublished frame's whole tail)
+  tail_lap(1);
   const bool lazy = c->lazy_new && detect;      // leave this frame's new corners to the next call
   const bool defer_right = c->lazy_new && !PUB_THIS_FRAME;  // ... or its whole right-camera tail
   if (defer_right) {
@@ -721,6 +730,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));  // ... of the kept points
   }
   lap(6);
+  tt = clk::now();
   if (!defer_right && (n_surv || detect) && pin.counts[3] != 0)
     return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
 
@@ -742,6 +752,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                lazy ? n_kept : (int)c->cur_pts.size(), n_kept, c->cur_time - c->prev_time,
                c->cur_pts.size());
   }
+  tail_lap(2);
   c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left (:585)
   c->prev_pts = c->cur_pts;
   c->prev_un_pts_map.swap(c->cur_un_pts_map);
@@ -758,6 +769,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   if (int rc = exchange_flush(c)) return rc;
   if (c->x_auto && c->x_comm && PUB_THIS_FRAME)
     if (int rc = exchange_pack(c)) return rc;
+  tail_lap(3);
   return 0;
 }
 
