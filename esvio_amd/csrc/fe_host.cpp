@@ -179,39 +179,26 @@ struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-
   int uniform(int lo, int hi) { return lo == hi ? lo : (int)(next() % (unsigned)(hi - lo) + lo); }
 };
 
-// hypot as glibc 2.35 computes it (sysdeps/ieee754/dbl-64/e_hypot.c, the build without FMA: a square
-// root and one correction step, after C. Borges, "An improved algorithm for hypot(a, b)") for finite
-// arguments — the value cv::SVD's `hypot(p, beta)` gets from this image's libm, restated so that it
-// can be inlined next to the rotations instead of reached through eight PLT calls per pair (on the
-// build container's Xeon that halves the RANSAC call; on the GPU box's EPYC 9575F, whose libm call
-// takes 8 ns, it is neutral).  Bit-identical to libm's on 2e8 random pairs; the same is
-// asserted against the host's libm in tests/test_abi.py, so a libm that computes hypot differently
-// shows up there and not as a parity difference somewhere downstream.  (mul and add stay separate:
-// -ffp-contract=off.)
-inline double glibc_hypot_kernel(double ax, double ay) {  // ax >= ay >= 0, no overflow / underflow in the squares
-  const double h = std::sqrt(ax * ax + ay * ay);
-  const bool close = h <= 2.0 * ay;
-  const double delta = h - (close ? ay : ax);
-  const double t1 = close ? ax * (2.0 * delta - ax) : 2.0 * delta * (ax - 2.0 * ay);
-  const double t2 = close ? (delta - 2.0 * (ax - ay)) * delta : (4.0 * delta - ay) * ay + delta * delta;
-  return h - (t1 + t2) / (2.0 * h);
-}
-constexpr double kHypotLarge = 0x1p+511, kHypotTiny = 0x1p-459, kHypotEps = 0x1p-54, kHypotScale = 0x1p-600;
-
-inline double glibc_hypot(double x, double y) {  // finite x, y
-  x = std::fabs(x);
-  y = std::fabs(y);
-  double ax = x < y ? y : x, ay = x < y ? x : y;
-  if (ax > kHypotLarge) {
-    if (ay <= ax * kHypotEps) return ax + ay;
-    return glibc_hypot_kernel(ax * kHypotScale, ay * kHypotScale) / kHypotScale;
+// cv::hypot [OpenCV 4.2 core/src/lapack.cpp]: JacobiSVDImpl_'s `hypot((double)p, beta)` is an
+// unqualified call inside namespace cv, where the file's own
+//     template<typename _Tp> static inline _Tp hypot(_Tp a, _Tp b)
+// (declared just above JacobiImpl_) hides ::hypot — so the rotations get a * sqrt(1 + (b/a)^2), not
+// libm's correctly-scaled hypot; the two differ in the last bit often enough to matter.
+// Restated from the published source, unpinned like every OpenCV restatement here.  IEEE division,
+// square root, multiply and add only (mul and add stay separate: -ffp-contract=off): no libm, so the
+// value does not depend on the host's glibc, and the same code runs in the vector lanes.
+inline double cv_hypot(double a, double b) {
+  a = std::fabs(a);
+  b = std::fabs(b);
+  if (a > b) {
+    b /= a;
+    return a * std::sqrt(1 + b * b);
   }
-  if (ay < kHypotTiny) {
-    if (ax >= ay / kHypotEps) return ax + ay;
-    return glibc_hypot_kernel(ax / kHypotScale, ay / kHypotScale) * kHypotScale;
+  if (b > 0) {
+    a /= b;
+    return b * std::sqrt(1 + a * a);
   }
-  if (ax >= ay / kHypotEps) return ax + ay;
-  return glibc_hypot_kernel(ax, ay);
+  return 0;
 }
 
 // Two orthonormal vectors spanning the null space of the 7x9 epipolar system, obtained the way
@@ -252,7 +239,7 @@ void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
         for (int k = 0; k < M; k++) p += ri[k] * rj[k];
         if (std::fabs(p) <= kEps * std::sqrt(a * b)) continue;
         p *= 2;
-        const double beta = a - b, gamma = glibc_hypot(p, beta);
+        const double beta = a - b, gamma = cv_hypot(p, beta);
         double c, s;
         if (beta < 0) {
           const double delta = (gamma - beta) * 0.5;
@@ -336,7 +323,7 @@ void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
 // times), so one at a time the vector units idle; side by side every lane performs exactly the
 // scalar sequence above on its own data: a pair that a lane skips leaves that lane's rows and norms
 // untouched (selected by mask), a lane that has converged sees only skipped pairs in the sweeps the
-// others still need, and the sweep limit is common.  hypot is glibc_hypot, all lanes at once.  The
+// others still need, and the sweep limit is common.  hypot is cv_hypot, all lanes at once.  The
 // made-up rows use the first draw of the sign vector (the same for every system); a lane that
 // would need OpenCV's retry (a zero singular value or a vanished projection) makes the function
 // return false and the caller does those systems with the scalar routine.
@@ -381,24 +368,14 @@ bool epipolar_nullspace_lanes(const double (*A)[7][9], double (*f1)[9], double (
           beta[l] = W[i][l] - W[j][l];
           gamma[l] = 1;
         }
-        {  // gamma = hypot(p, beta) for the lanes that rotate (glibc_hypot, its common case vectorised)
-          alignas(64) double ax[L], ay[L];
-          bool common = true;
-          for (int l = 0; l < L; l++) {
-            const double x = on[l] ? std::fabs(p[l]) : 1.0, y = on[l] ? std::fabs(beta[l]) : 1.0;
-            ax[l] = x < y ? y : x;
-            ay[l] = x < y ? x : y;
-            common = common && !(ax[l] > kHypotLarge) && !(ay[l] < kHypotTiny);
-          }
-          if (common) {
-            for (int l = 0; l < L; l++) {
-              const double g = glibc_hypot_kernel(ax[l], ay[l]);
-              gamma[l] = ax[l] >= ay[l] / kHypotEps ? ax[l] + ay[l] : g;
-            }
-          } else {  // (a zero or a huge operand somewhere: the scaled branches, one lane at a time)
-            for (int l = 0; l < L; l++)
-              if (on[l]) gamma[l] = glibc_hypot(p[l], beta[l]);
-          }
+        // gamma = cv_hypot(p, beta) for the lanes that rotate: hi * sqrt(1 + (lo / hi)^2) with hi / lo the
+        // larger / smaller magnitude is the scalar routine's value on either of its branches (a lane
+        // that rotates has p != 0, so hi > 0)
+        for (int l = 0; l < L; l++) {
+          const double x = on[l] ? std::fabs(p[l]) : 1.0, y = on[l] ? std::fabs(beta[l]) : 1.0;
+          const double hi = x > y ? x : y, lo = x > y ? y : x;
+          const double r = lo / hi;
+          gamma[l] = hi * std::sqrt(1 + r * r);
         }
         for (int l = 0; l < L; l++) {  // both branches of the scalar code, the lane's own one kept
           const double delta = (gamma[l] - beta[l]) * 0.5;
@@ -1075,7 +1052,7 @@ std::atomic<uint64_t> g_rs_calls{0}, g_rs_iters{0}, g_rs_points{0}, g_rs_ns{0}, 
 }  // namespace
 
 void host_hypot(const double* x, const double* y, int n, double* out) {
-  for (int i = 0; i < n; i++) out[i] = glibc_hypot(x[i], y[i]);
+  for (int i = 0; i < n; i++) out[i] = cv_hypot(x[i], y[i]);
 }
 
 RansacStats ransac_stats(bool reset) {

@@ -42,7 +42,7 @@ struct RansacPool;
 RansacPool* ransac_pool_create(int helpers);
 void ransac_pool_destroy(RansacPool* p);
 void ransac_pool_wake(RansacPool* p);  // a job is coming: helpers that went to sleep start spinning
-// test tap: the hypot the 7-point solver's Jacobi rotations use (glibc 2.35's algorithm, inlined)
+// test tap: the hypot the 7-point solver's Jacobi rotations use (cv::hypot of OpenCV's lapack.cpp)
 void host_hypot(const double* x, const double* y, int n, double* out);
 // process-wide counters of find_fundamental_mat: its RANSAC branch (>= 15 points) — calls,
 // hypotheses replayed (the loop's iteration count), points, nanoseconds inside the call — and its

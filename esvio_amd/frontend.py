@@ -584,7 +584,7 @@ def comm_unique_id():
 
 
 def host_hypot(x, y):
-    """the hypot of the 7-point solver's Jacobi rotations (glibc 2.35's algorithm, inlined in the library)"""
+    """the hypot of the 7-point solver's Jacobi rotations: cv::hypot of OpenCV's lapack.cpp, a*sqrt(1+(b/a)^2)"""
     x = np.ascontiguousarray(x, np.float64)
     y = np.ascontiguousarray(y, np.float64)
     out = np.empty_like(x)

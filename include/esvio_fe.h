@@ -165,9 +165,9 @@ int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, doubl
  * pool; test tap for esvio_fe_set_host_threads): status and count are those of the call above. */
 int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, double thr,
                                      double conf, int threads, uint8_t* status, int32_t* n_inliers);
-/* Test tap: the hypot inside that function's 7-point solver (cv::SVD's Jacobi rotations call libm's
- * hypot; the library inlines glibc 2.35's algorithm so that eight hypotheses share one instruction
- * stream) — the tests hold it against the host's libm. Finite arguments. */
+/* Test tap: the hypot inside that function's 7-point solver: cv::SVD's Jacobi rotations call hypot
+ * unqualified inside namespace cv, which resolves to lapack.cpp's own a*sqrt(1+(b/a)^2) template, not
+ * to libm's; IEEE operations only, so the result does not depend on the host's libm. */
 int esvio_fe_host_hypot(const double* x, const double* y, int n, double* out);
 /* Measurement tap: process-wide counters of that function since the last reset — out6 = {calls,
  * loop iterations, points, nanoseconds inside the calls} of its RANSAC branch (>= 15 points) and

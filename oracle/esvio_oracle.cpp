@@ -991,6 +991,23 @@ struct CvRNG {  // cv::RNG (core/operations.hpp): multiply-with-carry
   int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
 };
 
+// cv::hypot: the template of core/src/lapack.cpp (declared above JacobiImpl_) that JacobiSVDImpl_'s
+// unqualified `hypot((double)p, beta)` resolves to inside namespace cv — not libm's hypot
+// [OpenCV 4.2, recalled]
+static double cv_hypot(double a, double b) {
+  a = std::fabs(a);
+  b = std::fabs(b);
+  if (a > b) {
+    b /= a;
+    return a * std::sqrt(1 + b * b);
+  }
+  if (b > 0) {
+    a /= b;
+    return b * std::sqrt(1 + a * a);
+  }
+  return 0;
+}
+
 // One-sided Jacobi SVD as OpenCV's core/src/lapack.cpp runs it for doubles (JacobiSVDImpl_ with
 // minval = DBL_MIN, eps = DBL_EPSILON*10; restated from the published algorithm, OpenCV 4.2 is not in
 // /root/reference).  `at` holds n rows of length m (row stride `step`), m >= n: the rows are rotated
@@ -1020,7 +1037,7 @@ void jacobi_svd_rows(double* at, int step, double* w, int m, int n, int n1) {
         for (int k = 0; k < m; k++) p += ai[k] * aj[k];
         if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
         p *= 2;
-        const double beta = a - b, gamma = hypot(p, beta);
+        const double beta = a - b, gamma = cv_hypot(p, beta);
         double c, s;
         if (beta < 0) {
           const double delta = (gamma - beta) * 0.5;

@@ -147,25 +147,32 @@ def test_header_is_plain_c(tmp_path):
                            "-I", os.path.join(root, "include"), str(src)])
 
 
-def test_host_hypot_is_the_hosts_libm_hypot():
-    """cv::SVD's Jacobi rotations call libm's hypot; the library inlines glibc 2.35's algorithm (so that
-    eight 7-point systems share one instruction stream).  It has to BE this host's hypot, bit for bit —
-    numpy's hypot is the libm call — over magnitudes the solver sees (1e5..1e23), wide exponent
-    ranges, near-equal and very unequal operands, zeros, and the scaled branches (huge / tiny)."""
+def test_host_hypot_is_cv_hypot():
+    """cv::SVD's Jacobi rotations call hypot unqualified inside namespace cv, where lapack.cpp's own
+    template (a * sqrt(1 + (b/a)^2)) hides libm's — so the library's rotations use that formula, in IEEE
+    operations only.  Held here against the same formula evaluated by numpy (each step one correctly
+    rounded IEEE operation, so bit for bit), over the magnitudes the solver sees, wide exponent ranges,
+    near-equal and very unequal operands and zeros; and shown to differ from libm's hypot in the last
+    bit on a visible share of inputs (which is why it matters which one the restatement uses)."""
     rng = np.random.default_rng(12)
-    n = 2_000_000
+    n = 1_000_000
     x = rng.normal(size=n) * 10.0 ** rng.uniform(-40, 40, n)
     y = x * rng.uniform(-3, 3, n)
     y[::5] = rng.normal(size=len(y[::5])) * 10.0 ** rng.uniform(-40, 40, len(y[::5]))
     x[::1001] = 0.0
     y[::1003] = 0.0
-    xs = [x, rng.integers(0, 100000, n).astype(np.float64), 2.0 ** rng.uniform(500, 1020, 50000),
-          2.0 ** rng.uniform(-1070, -440, 50000), rng.uniform(1e5, 1e23, n)]
-    ys = [y, rng.integers(0, 100000, n).astype(np.float64), 2.0 ** rng.uniform(480, 1020, 50000),
-          2.0 ** rng.uniform(-1070, -440, 50000), rng.uniform(1e5, 1e23, n) * 10.0 ** rng.uniform(-20, 3, n)]
+    xs = [x, rng.integers(0, 100000, n).astype(np.float64), rng.uniform(1e5, 1e23, n)]
+    ys = [y, rng.integers(0, 100000, n).astype(np.float64), rng.uniform(1e5, 1e23, n) * 10.0 ** rng.uniform(-20, 3, n)]
+    differs_from_libm = 0
     for a, b in zip(xs, ys):
-        with np.errstate(over="ignore", under="ignore"):
-            want = np.hypot(a, b)
+        aa, bb = np.abs(a), np.abs(b)
+        hi, lo = np.maximum(aa, bb), np.minimum(aa, bb)
+        with np.errstate(all="ignore"):
+            r = lo / hi
+            want = np.where(hi > 0, hi * np.sqrt(1 + r * r), 0.0)
+            libm = np.hypot(a, b)
         got = FE.host_hypot(a, b)
         bad = got.view(np.uint64) != want.view(np.uint64)
         assert not bad.any(), (int(bad.sum()), a[bad][:3], b[bad][:3])
+        differs_from_libm += int((got != libm).sum())
+    assert differs_from_libm > 1000
