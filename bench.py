@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 # stats label (esvio_fe_kernel_name) -> the kernel functions launched under it
 KERNEL_FUNCS = {
-    "k_sae_keys": ["k_sae_keys", "k_tile_hist", "k_tile_scan"], "k_radix_pass": ["k_radix_pass", "k_tile_scatter"],
+    "k_sae_keys": ["k_sae_keys", "k_tile_hist", "k_tile_scan", "k_mc_warp"], "k_radix_pass": ["k_radix_pass", "k_tile_scatter"],
     "k_sae_apply": ["k_sae_apply", "k_sae_apply_ev", "k_sae_apply_ev_write", "k_tile_apply"],
     "k_time_surface": ["k_time_surface", "k_ts_pyr", "k_median"], "k_clahe": ["k_clahe_lut", "k_clahe_interp", "k_normalize"],
     "k_pyr_down": ["k_pyr_down"], "k_pyr_pad": ["k_pyr_pad"], "k_scharr": ["k_scharr", "k_pad_scharr"],
@@ -106,6 +106,10 @@ def parse():
     ap.add_argument("--equalize", type=int, default=0, choices=[0, 1],
                     help="1: CLAHE + normalize of the time surface before LK (config/esio_DSEC ships "
                          "equalize: 1; the headline stays at 0, the other shipped configs' setting)")
+    ap.add_argument("--mc", type=int, default=0, choices=[0, 1],
+                    help="1: the motion-compensated overload (Do_motion_correction: 1 in 3 of the 9 shipped configs): "
+                         "every batch carries a Motion_correction_value with |accel| > 5 m/s^2, so all events before "
+                         "the header stamp are warped (per-event Matrix3f::exp) before the SAE update")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not announce the next batch (esvio_fe_set_next_batch): strictly one "
                          "batch in flight, like the reference's depth-1 queues")
@@ -225,8 +229,26 @@ def cpu_all_cores(batches, args, W, H):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks ourselves — the same
+    command line the driver uses for N > 1 (one process per GPU under torch.distributed.run, RCCL
+    rendezvous on 127.0.0.1) — and let rank 0's JSON line through.  Does not return."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this stack)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     # stdout carries exactly ONE line, the JSON: whatever libraries print through C stdio on fd 1
     # (RCCL's version banner, for one) goes to stderr instead
     real_stdout = os.dup(1)
@@ -241,8 +263,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the front-end has no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
+    if world > n_dev and args.dist_backend == "nccl":
+        # more ranks than devices (a dry run of the N > 1 path on a smaller box): RCCL refuses two
+        # ranks on one device, so the collectives go through gloo and the line says so
+        if rank == 0:
+            print("bench: %d ranks on %d device(s): dry run over gloo, not a scaling measurement" % (world, n_dev),
+                  file=sys.stderr)
+        args.dist_backend = "gloo"
     dist = None
     multi = world > 1 or args.force_dist  # (the collective path runs, possibly with a single rank)
     if multi:
@@ -278,7 +308,7 @@ def main():
     host_batches, dev_batches = [], []
     for _ in range(n_frames):
         L, R, _ = scene.next_batch()
-        host_batches.append((L, R))
+        host_batches.append((L, R, len(L), len(R), event_times(L)[-1]))
         tl = torch.from_numpy(L.view(np.uint8).reshape(-1)).cuda()
         tr = torch.from_numpy(R.view(np.uint8).reshape(-1)).cuda()
         dev_batches.append((tl, tr, len(L), len(R), event_times(L)[-1]))
@@ -296,6 +326,18 @@ def main():
             fc.published()
     if args.host_threads <= 0:
         args.host_threads = max(1, min(8, total_cpus // (2 * max(world, 1))))
+
+    def motion_of(mod, i):
+        """the Motion_correction_value of batch i (--mc 1): header stamp = the batch's last event, a
+        slowly varying angular rate and velocity, |accel| = 7.1 m/s^2 (> 5: the warp is applied)"""
+        if not args.mc:
+            return None
+        cam = cfg.cam[0]
+        w = 0.1 * np.sin(0.37 * i)
+        return mod.make_motion(host_batches[i][4], v=(0.08 + w, -0.03, 0.02), v_pre=(0.07 + w, -0.025, 0.015),
+                               accel=(4.0, 5.0, 3.0), omega=(0.2 + w, -0.3, 0.4 - w),
+                               fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy)
+    motions = [motion_of(FE, i) for i in range(n_frames)]
 
     class Runner:
         """one tracker + the schedule it is driven with"""
@@ -316,7 +358,7 @@ def main():
         def arg(self, k):
             b = self.batches[k]
             if isinstance(b[0], np.ndarray):  # host-resident events
-                return b[0], b[1], len(b[0]), len(b[1]), event_times(b[0])[-1]
+                return b
             return (b[0].data_ptr(), b[2]), (b[1].data_ptr(), b[3]), b[2], b[3], b[4]
 
         def step(self, i, exchange=True):
@@ -332,11 +374,14 @@ def main():
                 self.tsl.track(t_last, L, R, pub)
                 return (nl + nr) if rank == 0 else 0
             if self.pipeline:  # replay mode: the next batches are already in HBM; announce them ahead
-                while self.announced < min(i + args.ahead, len(self.batches) - 1):
+                # (host-resident batches one further: a batch is staged through pinned chunks under the
+                # call after its announcement and taken up by the prefetch stream in the call after that)
+                ahead = args.ahead + (1 if isinstance(self.batches[0][0], np.ndarray) else 0)
+                while self.announced < min(i + ahead, len(self.batches) - 1):
                     k = self.announced = self.announced + 1
                     L2, R2, _, _, t2 = self.arg(k)
-                    ft.set_next_batch(t2, L2, R2, pub_flags[k])
-            ft.trackEvent(t_last, L, R, pub, copy=False)
+                    ft.set_next_batch(t2, L2, R2, pub_flags[k], measurements=motions[k])
+            ft.trackEvent(t_last, L, R, pub, copy=False, measurements=motions[i])
             if pub and exchange:  # merge all rigs' tracked corners (asynchronous)
                 if self.comm:
                     pass  # (esvio_fe_set_auto_exchange: the library does it)
@@ -554,10 +599,10 @@ def main():
         O.lk_pair_stats(True)
         tc0 = time.perf_counter()
         for i in range(nfr):
-            L, R = host_batches[i]
-            t_last = event_times(L)[-1]
+            L, R = host_batches[i][:2]
+            t_last = host_batches[i][4]
             pub = fco.pub_this_frame(t_last)
-            tr_o.track_event(t_last, L, R, pub)
+            tr_o.track_event(t_last, L, R, pub, motion=motion_of(O, i))
             if pub:
                 fco.published()
             ev += len(L) + len(R)
@@ -587,7 +632,7 @@ def main():
                 note="latency-bound by construction: the HBM fraction of this kernel says nothing about "
                      "its quality; the streaming kernels' fractions are in `kernels`")
         if args.cpu_procs != 0:
-            cpu["all_cores"] = cpu_all_cores(host_batches[:nfr], args, W, H)
+            cpu["all_cores"] = cpu_all_cores([b[:2] for b in host_batches[:nfr]], args, W, H)
 
     if rank == 0:
         ms_all = sorted(p[1] / args.steps * 1e3 for p in passes)
@@ -595,7 +640,8 @@ def main():
             "metric": "Mevents/s through time-surface+detect+track @640x480",
             "value": round(total_events / max_elapsed / 1e6, 3),
             "unit": "Mevents/s",
-            "n_gpus": world,
+            "n_gpus": world,  # = the communicator's size (one rank per GPU)
+            "devices_used": min(world, n_dev),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 4),
@@ -614,6 +660,7 @@ def main():
                                 "one stream time-sliced over %d GPUs (SAE update), tracking on rank 0" % world
                                 if time_split else "1 rig per GPU") if world > 1 else "single GPU",
                 "tracks_last_frame": n_tracks,
+                "motion_comp": bool(args.mc),
                 "pipelined_next_batch": bool(pipeline),
                 "lazy_new_corner_stereo": bool(lazy),
                 "host_threads": int(max(1, args.host_threads)),

@@ -72,6 +72,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   host::ransac_pool_destroy(c->pool);
   c->pool = nullptr;
+  stager_destroy(c);
   destroy_launch_graph(c->pf_graph);
   if (c->trace && c->phase_frames) {
     static const char* nm[8] = {"enqueue sae+ts+pyr", "enqueue temporal LK", "sync A", "host filter",
@@ -133,7 +134,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->x_done) (void)hipEventDestroy(c->x_done);
   if (c->x_pin) (void)hipHostFree(c->x_pin);
   if (c->x_pin_recv) (void)hipHostFree(c->x_pin_recv);
-  void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_tile, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
+  void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_warp, c->d_tile, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx, c->d_sel_bitmap, c->d_eq_tmp,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
@@ -278,6 +279,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     std::memset(c->h_spec, 0, 2 * c->spec_bytes);
   }
   if ((rc = dev_alloc(c, &c->d_chain, 2 * std::max<size_t>(M, 1)))) return bail(rc);
+  c->stage_threads = stager_threads_from_env();
+  if (const char* v = getenv("ESVIO_FE_FAULT")) esvio_fe_debug_inject(c, atoi(v));
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
@@ -352,6 +355,12 @@ int esvio_fe_reset(esvio_fe_handle c) {
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   c->announced.clear();
   c->inflight.clear();
+  stager_drain(c);
+  c->cur_stage = -1;
+  // (a call that failed with ESVIO_FE_EINTERNAL: the expired wait's flag, the sort's scratch words)
+  pin_of(c).counts[3] = 0;
+  if (c->hist) HIPCHK(c, hipMemsetAsync(c->hist, 0, c->hist_cap * 4, cur_stream(c)));
+  std::memset(c->h_spec, 0, 2 * c->spec_bytes);
   c->spec_valid = false;
   c->chain_valid = false;
   c->chain_map_ok = false;
@@ -391,9 +400,7 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle c, const esvio_fe_event* left,
   if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
   if (!c->inflight.empty()) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
   HIPCHK(c, hipSetDevice(c->dev));
-  esvio_fe_event first;
-  if (int rc = first_event_host(c, left, space, &first)) return rc;
-  const McParams mc = make_mc_params(motion, first);
+  const McParams mc = make_mc_params(motion);
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, cur_stream(c)));
@@ -1034,15 +1041,15 @@ int esvio_fe_finish(esvio_fe_handle c, esvio_fe_tracks* out) {
   return fill_tracks(c, out);
 }
 
-int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio_fe_event* left,
-                            size_t nL, const esvio_fe_event* right, size_t nR, int space,
-                            int pub_hint) {
+static int set_next_batch_impl(esvio_fe_handle c, double next_cur_time, const esvio_fe_event* left,
+                               size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                               int pub_hint, const esvio_fe_motion* motion) {
   if (!c) return ESVIO_FE_EINVAL;
   if (nL == 0 || !left || (nR && !right)) return fail(c, ESVIO_FE_EINVAL, "bad next batch");
   if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
   if (c->ext_right_pending) return fail(c, ESVIO_FE_EINVAL, "not with an imported right image");
-  if ((int)c->announced.size() >= kPrefetchDepth)
-    return fail(c, ESVIO_FE_EINVAL, "at most %d batches can be announced ahead", kPrefetchDepth);
+  if ((int)(c->announced.size() + c->inflight.size()) >= 2 * kPrefetchDepth)
+    return fail(c, ESVIO_FE_EINVAL, "at most %d batches can be announced and not yet tracked", 2 * kPrefetchDepth);
   Batch b;
   b.time = next_cur_time;
   b.left = left;
@@ -1051,7 +1058,49 @@ int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio
   b.nR = nR;
   b.space = space;
   b.pub = pub_hint != 0;
+  if (motion) {
+    b.has_motion = true;
+    b.motion = *motion;
+  }
+  if (space == ESVIO_FE_HOST && stager_enabled(c)) {
+    // the batch starts on its way to the device now: pinned chunks + DMA by the helper threads, under
+    // the frames tracked before it
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (int rc = stager_begin(c, left, nL, right, nR, 1, &b.stage)) return rc;
+  }
   c->announced.push_back(b);
+  return 0;
+}
+
+int esvio_fe_set_next_batch(esvio_fe_handle c, double next_cur_time, const esvio_fe_event* left,
+                            size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                            int pub_hint) {
+  return set_next_batch_impl(c, next_cur_time, left, nL, right, nR, space, pub_hint, nullptr);
+}
+
+int esvio_fe_set_next_batch_mc(esvio_fe_handle c, double next_cur_time, const esvio_fe_event* left,
+                               size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                               int pub_hint, const esvio_fe_motion* motion) {
+  if (!motion) return ESVIO_FE_EINVAL;
+  return set_next_batch_impl(c, next_cur_time, left, nL, right, nR, space, pub_hint, motion);
+}
+
+int esvio_fe_debug_inject(esvio_fe_handle c, int mask) {
+  if (!c || mask < 0 || mask > 15) return ESVIO_FE_EINVAL;
+  c->lim = esvio_fe_ctx::WaitLimits();
+  if (mask & ESVIO_FE_FAULT_TICKET) c->lim.ticket = 0;
+  if (mask & ESVIO_FE_FAULT_LOOKBACK) c->lim.lookback = 0;
+  if (mask & ESVIO_FE_FAULT_SPECULATIVE) c->lim.poll = 0;
+  if (mask & ESVIO_FE_FAULT_CHAINED) c->lim.chain = 0;
+  return 0;
+}
+
+int esvio_fe_debug_counters(esvio_fe_handle c, uint64_t out4[4]) {
+  if (!c || !out4) return ESVIO_FE_EINVAL;
+  out4[0] = c->n_spec_expired;
+  out4[1] = c->n_chain_expired;
+  out4[2] = c->tr_chain_launch;
+  out4[3] = c->tr_chain_used;
   return 0;
 }
 

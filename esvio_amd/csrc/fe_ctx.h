@@ -98,6 +98,9 @@ struct Batch {
   int space = 0;
   double time = 0;
   int pub = 0;  // caller's PUB_THIS_FRAME hint
+  int stage = -1;  // host events: the staging slot they travel through (fe_evstage.cpp), -1: none
+  bool has_motion = false;  // esvio_fe_set_next_batch_mc: the motion-compensated overload
+  esvio_fe_motion motion{};
 };
 // ... and, once its SAE update / images / pyramids (/ Arc*) are enqueued on the prefetch stream,
 // the resources they were given
@@ -108,6 +111,10 @@ struct Inflight : Batch {
   bool arc_done = false;
 };
 constexpr int kPrefetchDepth = 3;
+// host-event staging slots: one per batch the handle can know about at a time (2 * kPrefetchDepth
+// announced or prefetched and not yet tracked, the one being tracked, one spare)
+constexpr int kStageSlots = 2 * kPrefetchDepth + 2;
+struct EventStager;  // fe_evstage.cpp
 constexpr int kLeftSlots = 2 + kPrefetchDepth;   // prev, cur, prefetched...
 constexpr int kRightSlots = 1 + kPrefetchDepth;  // cur, prefetched...
 
@@ -153,6 +160,7 @@ struct esvio_fe_ctx {
   bool tiled = false;
   TileGeom tgeom{};
   EventRec* d_part = nullptr;  // the batch's events partitioned by bucket
+  uint32_t* d_warp = nullptr;  // [part_cap] motion compensation: the pixel each event is warped to
   size_t part_cap = 0;
   uint32_t* d_tile = nullptr;  // TileScratch
   size_t tile_cap = 0;
@@ -186,7 +194,17 @@ struct esvio_fe_ctx {
   std::deque<Batch> announced;     // announced, nothing enqueued yet (<= kPrefetchDepth)
   std::deque<Inflight> inflight;   // SAE update / images / pyramids enqueued on the prefetch stream
   bool cur_prefetched = false;     // the frame being processed came from the prefetch stream
-  EventRec* d_evp[kPrefetchDepth] = {};  // host-event staging, one per prefetch lane
+  EventStager* stager = nullptr;  // host-resident batches: pinned chunks + DMA by helper threads
+  int cur_stage = -1;             // staging slot of the batch being tracked
+  int stage_threads = 0;          // helper threads of the stager (0: off)
+  // bounds of the device-side waits handed to the launches; esvio_fe_debug_inject / ESVIO_FE_FAULT set
+  // chosen ones to 0 (the wait expires the first time it would have to wait)
+  struct WaitLimits {
+    uint32_t lookback = kSpinLookback, ticket = kSpinTicket;
+    unsigned long long poll = kTicksPoll, chain = kTicksChain;
+  } lim;
+  uint64_t n_spec_expired = 0, n_chain_expired = 0;  // speculative / chained temporal LK launches redone
+  EventRec* d_evp[kPrefetchDepth] = {};  // host-event staging, one per prefetch lane (stager off)
   size_t evp_cap[kPrefetchDepth] = {};
   hipEvent_t ev_lane_done[kPrefetchDepth] = {}, ev_lane_arc[kPrefetchDepth] = {};
   PyrStore tmp_pyr[2];  // standalone LK / pyramid taps on arbitrary host images

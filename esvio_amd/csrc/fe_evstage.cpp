@@ -1,0 +1,313 @@
+// fe_evstage.cpp — host-resident event batches (ESVIO_FE_HOST, what the reference's
+// `const dvs_msgs::EventArray&` interface hands over: feature_tracker/src/feature_tracker.h:51-52)
+// on their way to the device.
+//
+// A hipMemcpyAsync from pageable memory is not asynchronous: the runtime stages it through its own
+// bounce buffers on the calling thread (measured: 15 GB/s, 0.35 ms for the 5.3 MB of a C3 batch —
+// almost three times the rest of the frame).  Here the batch is cut into chunks of 256 KiB; helper
+// threads copy them into pinned memory and, when the last chunk of a group is in, enqueue the
+// group's DMA on a copy stream of its own (a DMA costs ~20 us whatever its size, so groups are
+// large: the whole batch when it was announced with esvio_fe_set_next_batch — all of it then
+// happens while the previous frames are tracked — and a few groups when the caller waits for it, so
+// that group k's DMA runs under group k+1's memcpy); the compute streams only wait for an event.
+// A source that already is pinned (hipHostMalloc / hipHostRegister) skips the memcpy: one DMA.
+//
+// Slots: one pinned + one device buffer per batch the handle knows about (announced, prefetched or
+// being tracked).  A slot's device buffer is overwritten only after the kernels that read its
+// previous batch (SAE update / Arc* on the prefetch stream, Arc* on the main stream) are done: the
+// copy stream waits for the events recorded behind them.
+#include "fe_internal.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+namespace esvio {
+namespace fe {
+
+namespace {
+constexpr size_t kChunkBytes = 256 * 1024;
+constexpr int kMaxGroups = 8;
+
+struct Group {
+  size_t off = 0, len = 0;  // byte range of the slot's buffers that one DMA moves
+  std::atomic<uint32_t> chunks_left{0};
+};
+
+struct Slot {
+  uint8_t* pin = nullptr;
+  EventRec* dev = nullptr;
+  size_t cap = 0;  // events
+  hipEvent_t copied = nullptr, pf_done = nullptr, main_done = nullptr;
+  bool pf_rec = false, main_rec = false;
+  bool in_use = false;
+  std::atomic<int> state{0};  // 0 idle, 1 staging, 2 every DMA enqueued and `copied` recorded, -1 failed
+  Group grp[kMaxGroups];
+  std::atomic<uint32_t> groups_left{0};
+};
+
+struct Task {  // one memcpy into the slot's pinned buffer
+  int slot, group;
+  const uint8_t* src;
+  size_t off, len;  // byte offset inside the slot's buffers
+};
+}  // namespace
+
+struct EventStager {
+  esvio_fe_ctx* c = nullptr;
+  hipStream_t stream = nullptr;
+  Slot slot[kStageSlots];
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Task> q;
+  bool stop = false;
+  // (ESVIO_FE_TRACE) batches, bytes, time the calling thread waited for a batch's staging, chunks it
+  // took itself meanwhile, batches a call left for the next one because they had not arrived yet
+  uint64_t batches = 0, bytes_staged = 0, wait_ns = 0, caller_chunks = 0, skipped = 0;
+
+  void run_task(const Task& t) {
+    Slot& s = slot[t.slot];
+    std::memcpy(s.pin + t.off, t.src, t.len);
+    Group& g = s.grp[t.group];
+    if (g.chunks_left.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    // the group's last chunk is in: its DMA
+    if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      s.state.store(-1, std::memory_order_release);
+    }
+    if (s.groups_left.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+      // the last group: every DMA of the batch has been enqueued (by whichever thread) before this record
+      const bool ok = hipEventRecord(s.copied, stream) == hipSuccess;
+      int expect = 1;
+      if (!ok || !s.state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel))
+        s.state.store(-1, std::memory_order_release);
+    }
+  }
+
+  bool try_one() {  // any thread: take one chunk if there is one
+    Task t;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (q.empty()) return false;
+      t = q.front();
+      q.pop_front();
+    }
+    run_task(t);
+    return true;
+  }
+
+  void worker() {
+    (void)hipSetDevice(c->dev);
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return stop || !q.empty(); });
+        if (stop && q.empty()) return;
+        t = q.front();
+        q.pop_front();
+      }
+      run_task(t);
+    }
+  }
+};
+
+int stager_threads_from_env() {
+  if (const char* v = getenv("ESVIO_FE_STAGE_THREADS")) return std::max(0, std::min(8, atoi(v)));
+  return 2;
+}
+
+static int stager_get(esvio_fe_ctx* c, EventStager** out) {
+  if (!c->stager) {
+    EventStager* st = new EventStager();
+    st->c = c;
+    if (hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete st;
+      return fail(c, ESVIO_FE_EHIP, "hipStreamCreate (event staging) failed");
+    }
+    for (Slot& s : st->slot)
+      if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&s.pf_done, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&s.main_done, hipEventDisableTiming) != hipSuccess) {
+        c->stager = st;
+        stager_destroy(c);
+        return fail(c, ESVIO_FE_EHIP, "hipEventCreate (event staging) failed");
+      }
+    for (int i = 0; i < c->stage_threads; i++) st->threads.emplace_back([st] { st->worker(); });
+    c->stager = st;
+  }
+  *out = c->stager;
+  return 0;
+}
+
+static bool host_pointer_is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the runtime)
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// Start staging [left; right] into a free slot: returns at once, the helpers do the work.
+// dma_groups: DMAs the pageable part of the batch is moved with (1: the caller does not wait for it)
+int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
+                 int dma_groups, int* slot_out) {
+  EventStager* st = nullptr;
+  if (int rc = stager_get(c, &st)) return rc;
+  int k = 0;
+  while (k < kStageSlots && st->slot[k].in_use) k++;
+  if (k == kStageSlots) return fail(c, ESVIO_FE_EINTERNAL, "no free event staging slot");
+  Slot& s = st->slot[k];
+  const size_t n = nL + nR;
+  const bool pinL = nL && host_pointer_is_pinned(left), pinR = nR && host_pointer_is_pinned(right);
+  if (n > s.cap) {
+    // (the device buffer's previous readers: hipFree waits for the device)
+    if (s.dev) (void)hipFree(s.dev);
+    if (s.pin) (void)hipHostFree(s.pin);
+    s.dev = nullptr;
+    s.pin = nullptr;
+    s.cap = 0;
+    const size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
+    if (int rc = dev_alloc(c, &s.dev, cap)) return rc;
+    HIPCHK(c, hipHostMalloc((void**)&s.pin, cap * 16, hipHostMallocDefault));
+    s.cap = cap;
+  }
+  // the DMA overwrites the slot's device buffer: behind the kernels that read its previous batch
+  if (s.pf_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.pf_done, 0));
+  if (s.main_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.main_done, 0));
+  s.pf_rec = s.main_rec = false;
+  s.in_use = true;
+  st->bytes_staged += n * 16;
+  st->batches++;
+  // a pinned source: one DMA straight from it, now
+  if (pinL) HIPCHK(c, hipMemcpyAsync(s.dev, left, nL * 16, hipMemcpyHostToDevice, st->stream));
+  if (pinR) HIPCHK(c, hipMemcpyAsync(s.dev + nL, right, nR * 16, hipMemcpyHostToDevice, st->stream));
+  // the pageable part: destination byte range [lo, hi) of the slot's buffers
+  const size_t lo = pinL ? nL * 16 : 0, hi = pinR ? nL * 16 : n * 16;
+  std::vector<Task> tasks;
+  int ng = 0;
+  if (hi > lo) {
+    ng = std::max(1, std::min(dma_groups, kMaxGroups));
+    const size_t chunks = (hi - lo + kChunkBytes - 1) / kChunkBytes;
+    ng = (int)std::min<size_t>(ng, chunks);
+    const size_t per = (chunks + ng - 1) / ng;  // chunks per group
+    ng = (int)((chunks + per - 1) / per);
+    for (int g = 0; g < ng; g++) {
+      const size_t a = lo + (size_t)g * per * kChunkBytes, b = std::min(hi, a + per * kChunkBytes);
+      s.grp[g].off = a;
+      s.grp[g].len = b - a;
+      uint32_t cnt = 0;
+      for (size_t o = a; o < b;) {
+        // a chunk never straddles the boundary between the two source arrays
+        const bool in_left = o < nL * 16;
+        const size_t end = std::min(std::min(o + kChunkBytes, b), in_left ? nL * 16 : b);
+        const uint8_t* src = in_left ? (const uint8_t*)left + o : (const uint8_t*)right + (o - nL * 16);
+        tasks.push_back(Task{k, g, src, o, end - o});
+        cnt++;
+        o = end;
+      }
+      s.grp[g].chunks_left.store(cnt, std::memory_order_relaxed);
+    }
+  }
+  s.groups_left.store((uint32_t)ng, std::memory_order_relaxed);
+  s.state.store(tasks.empty() ? 2 : 1, std::memory_order_release);
+  if (tasks.empty()) HIPCHK(c, hipEventRecord(s.copied, st->stream));
+  {
+    std::lock_guard<std::mutex> g(st->mu);
+    for (const Task& t : tasks) st->q.push_back(t);
+  }
+  st->cv.notify_all();
+  *slot_out = k;
+  return 0;
+}
+
+bool stager_ready(esvio_fe_ctx* c, int slot) {
+  const bool r = c->stager->slot[slot].state.load(std::memory_order_acquire) != 1;
+  if (!r) c->stager->skipped++;
+  return r;
+}
+
+// wait until every DMA of the slot's batch is enqueued (the calling thread takes chunks itself
+// meanwhile), then make stream `s` wait for them; device pointers out
+int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const EventRec** dL, const EventRec** dR) {
+  EventStager* st = c->stager;
+  Slot& sl = st->slot[slot];
+  if (sl.state.load(std::memory_order_acquire) == 1) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (sl.state.load(std::memory_order_acquire) == 1) {
+      if (st->try_one()) st->caller_chunks++;
+      else __builtin_ia32_pause();
+    }
+    st->wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
+  if (sl.state.load(std::memory_order_acquire) != 2) return fail(c, ESVIO_FE_EHIP, "staging the event batch failed");
+  HIPCHK(c, hipStreamWaitEvent(s, sl.copied, 0));
+  *dL = sl.dev;
+  *dR = sl.dev + nL;
+  return 0;
+}
+
+// the kernels enqueued on `s` so far are the last ones on that stream to read the slot's device buffer
+int stager_mark_read(esvio_fe_ctx* c, int slot, hipStream_t s, bool main_stream) {
+  Slot& sl = c->stager->slot[slot];
+  HIPCHK(c, hipEventRecord(main_stream ? sl.main_done : sl.pf_done, s));
+  (main_stream ? sl.main_rec : sl.pf_rec) = true;
+  return 0;
+}
+
+// the batch has been tracked.  The caller's memory is free again when its track call returns: a
+// DMA straight from a pinned source has to be over by then (it long is; the wait costs ~1 us)
+int stager_release(esvio_fe_ctx* c, int slot) {
+  if (slot < 0 || !c->stager) return 0;
+  Slot& sl = c->stager->slot[slot];
+  sl.in_use = false;
+  if (sl.state.load(std::memory_order_acquire) == 2) HIPCHK(c, hipEventSynchronize(sl.copied));
+  return 0;
+}
+
+// every queued chunk done, every slot free (esvio_fe_reset)
+void stager_drain(esvio_fe_ctx* c) {
+  EventStager* st = c->stager;
+  if (!st) return;
+  for (Slot& s : st->slot) {
+    while (s.state.load(std::memory_order_acquire) == 1)
+      if (!st->try_one()) __builtin_ia32_pause();
+    s.in_use = false;
+  }
+  (void)hipStreamSynchronize(st->stream);
+}
+
+void stager_destroy(esvio_fe_ctx* c) {
+  EventStager* st = c->stager;
+  if (!st) return;
+  {
+    std::lock_guard<std::mutex> g(st->mu);
+    st->stop = true;
+  }
+  st->cv.notify_all();
+  for (std::thread& t : st->threads) t.join();
+  if (c->trace && st->batches)
+    fprintf(stderr, "[esvio_fe trace] host-event staging: %llu batches, %.1f MB, %d helper threads; calling thread waited "
+            "%.3f ms per batch (took %llu chunks itself), %llu take-ups postponed to the next call\n",
+            (unsigned long long)st->batches, st->bytes_staged / 1e6, (int)st->threads.size(),
+            st->wait_ns / 1e6 / st->batches, (unsigned long long)st->caller_chunks, (unsigned long long)st->skipped);
+  if (st->stream) {
+    (void)hipStreamSynchronize(st->stream);
+    (void)hipStreamDestroy(st->stream);
+  }
+  for (Slot& s : st->slot) {
+    if (s.copied) (void)hipEventDestroy(s.copied);
+    if (s.pf_done) (void)hipEventDestroy(s.pf_done);
+    if (s.main_done) (void)hipEventDestroy(s.main_done);
+    if (s.dev) (void)hipFree(s.dev);
+    if (s.pin) (void)hipHostFree(s.pin);
+  }
+  delete st;
+  c->stager = nullptr;
+}
+
+}  // namespace fe
+}  // namespace esvio

@@ -72,7 +72,7 @@ int gftt_run(esvio_fe_ctx* c, const PyrDesc& d, int max_corners, double quality,
     for (int p = 0; p < 4; p++) {
       launch_radix_pass(cur_stream(c), c->keys[cur], c->vals[cur], n, 8 * p, 8, ghist + ((size_t)p << 8),
                         lookback + (size_t)p * (nb << 8), tickets + p, c->keys[cur ^ 1],
-                        c->vals[cur ^ 1], c->z_counts + 3);
+                        c->vals[cur ^ 1], c->z_counts + 3, c->lim.lookback);
       cur ^= 1;
     }
     HIPCHK(c, hipMemsetAsync(c->hist, 0, (size_t)head * 4, cur_stream(c)));  // as k_sae_apply leaves it

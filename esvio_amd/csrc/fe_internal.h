@@ -53,8 +53,7 @@ int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n);
 int ensure_arc_capacity(esvio_fe_ctx* c, size_t n, int set);
 int pyr_alloc(esvio_fe_ctx* c, PyrStore& ps, int w, int h, int max_level);
 void pyr_build(esvio_fe_ctx* c, const PyrDesc* p, int nimg);
-McParams make_mc_params(const esvio_fe_motion* m, const esvio_fe_event& first_left);
-int first_event_host(esvio_fe_ctx* c, const esvio_fe_event* left, int space, esvio_fe_event* out);
+McParams make_mc_params(const esvio_fe_motion* m);
 // arc_set >= 0: this batch's Arc* pass will run into candidate set arc_set; *arc_marked tells
 // whether the update has set that set's touched flags on its way (else run_arc does it)
 int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
@@ -96,8 +95,20 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
 hipError_t sync_main(esvio_fe_ctx* c);
 hipError_t sync_event(hipEvent_t ev);
 
+// ---------------------------------------------------------------- fe_evstage.cpp (host-resident batches)
+int stager_threads_from_env();  // ESVIO_FE_STAGE_THREADS (default 2; 0: plain hipMemcpyAsync from the caller's memory)
+inline bool stager_enabled(const esvio_fe_ctx* c) { return c->stage_threads > 0; }
+int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
+                 int dma_groups, int* slot_out);
+bool stager_ready(esvio_fe_ctx* c, int slot);
+int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const EventRec** dL, const EventRec** dR);
+int stager_mark_read(esvio_fe_ctx* c, int slot, hipStream_t s, bool main_stream);
+int stager_release(esvio_fe_ctx* c, int slot);
+void stager_drain(esvio_fe_ctx* c);
+void stager_destroy(esvio_fe_ctx* c);
+
 // ---------------------------------------------------------------- fe_track.cpp
-int prefetch_next(esvio_fe_ctx* c, bool wait_planes);
+int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first = false);
 int cancel_chain(esvio_fe_ctx* c);
 int finalize_right(esvio_fe_ctx* c);
 int finalize_pending(esvio_fe_ctx* c);

@@ -97,6 +97,14 @@ enum KernelId {
 };
 
 // ---- SAE update -------------------------------------------------------------------------
+// Bounds of the device-side waits (every one gives up instead of hanging the GPU; the host then fails
+// the call or redoes the launch).  They are launch parameters so that a test can make a wait expire on
+// demand (esvio_fe_debug_inject, fe_ctx.h: WaitLimits).
+constexpr uint32_t kSpinLookback = 1u << 20;  // k_radix_pass: polls of an earlier tile's look-back word
+constexpr uint32_t kSpinTicket = 1u << 21;    // k_tile_apply: polls of the block's turn ticket
+constexpr unsigned long long kTicksPoll = 2000000ull;   // k_lk waiting for k_select's corner: 20 ms
+constexpr unsigned long long kTicksChain = 4000000ull;  // k_lk waiting for the previous frame's k_lk: 40 ms
+
 constexpr int kRadixTile = 2048;  // keys per block
 constexpr int kRadixMaxBits = 8;
 constexpr int kRadixMaxPasses = 4;
@@ -113,7 +121,8 @@ void launch_sae_keys(hipStream_t s, const EventRec* evL, uint32_t nL, const Even
 // one stable LSD pass on digit (key >> shift) & ((1<<bits)-1) with decoupled look-back
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
                        int shift, int bits, const uint32_t* ghist, uint32_t* lookback,
-                       uint32_t* ticket, uint32_t* keys_out, uint32_t* vals_out, int* err);
+                       uint32_t* ticket, uint32_t* keys_out, uint32_t* vals_out, int* err,
+                       uint32_t spin_limit = kSpinLookback);
 // walk every same-pixel segment of the sorted keys in stream order applying the SAE rule
 // (event_detector.cc:149-166). L2/S2: double2 per (cam,pixel): {L[0],L[1]} and {S[0],S[1]}.
 void launch_sae_apply(hipStream_t s, const uint32_t* keys, const uint32_t* vals, uint32_t n,
@@ -168,17 +177,22 @@ struct TileScratch {
   uint32_t* C;         // [ngroups][nbins] ... of all earlier groups
 };
 // k_tile_hist + k_tile_scan: P, C, totals; out-of-sensor events added to *n_rejected
+// mc (optional, enabled): the motion-compensated overload — buckets by the warped pixel, which is kept
+// in warp_xy[nL + nR] for launch_tile_scatter
 void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected);
-// stable partition of [left; right] into `part` by bucket
+                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected,
+                      const struct McParams* mc = nullptr, uint32_t* warp_xy = nullptr);
+// stable partition of [left; right] into `part` by bucket (warp_xy non-null: the records get the
+// warped pixels launch_tile_hist computed)
 void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                         const TileGeom& g, const TileScratch& sc, EventRec* part);
+                         const TileGeom& g, const TileScratch& sc, EventRec* part, const uint32_t* warp_xy = nullptr);
 // createSAE_left/right (event_detector.cc:149-166, :212-228) per bucket, events in stream order.
 // arc_touched (optional): ArcArgs::touched of the Arc* pass this batch will get — the left camera's
 // touched (pixel, polarity) flags are written here, from the tiles' own bookkeeping, instead of by
 // launch_arc_mark
 void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const TileGeom& g, const TileScratch& sc,
-                       double2* L2, double2* S2, double filter_threshold, uint8_t* arc_touched, int* err);
+                       double2* L2, double2* S2, double filter_threshold, uint8_t* arc_touched, int* err,
+                       uint32_t spin_limit = kSpinTicket);
 
 // ---- time-slice composition (one stream cut into N slices, one per GPU) -------------------
 constexpr double kSliceNone = -1.0;  // "this slice wrote nothing here" (event times are >= 0)
@@ -241,6 +255,7 @@ struct LkArgs {
   unsigned long long* chain_out = nullptr;
   const unsigned long long* chain_in = nullptr;
   uint32_t chain_seq = 0;  // 30 bits, never 0
+  unsigned long long poll_ticks = kTicksPoll, chain_ticks = kTicksChain;  // bounds of the two waits
   int max_level;
   int max_count;
   double eps2;

@@ -171,6 +171,31 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p >= len ? 2 * len - 2 - p : p;
 }
 
+// trackEvent's per-event gate (feature_tracker.cpp:627-641) + createSAE_* with
+// Motion_correction_value (event_detector.cc:102-147): the pixel an in-sensor event is written at.
+// t0 = left.events[0].ts.toSec() (:621) is read from the batch itself, dt = header stamp - t0 (:623).
+struct McBatch {
+  double t0, dt_batch;
+};
+__device__ __forceinline__ McBatch mc_batch(const McParams& mc, const uint4* __restrict__ evL) {
+  McBatch b;
+  const uint4 e0 = evL[0];
+  b.t0 = ev_time(e0.y, e0.z);
+  b.dt_batch = mc.t1 - b.t0;
+  return b;
+}
+__device__ __forceinline__ uint32_t mc_pixel(const McParams& mc, const McBatch& b, int W, int H, const uint4& e) {
+  uint32_t x = e.x & 0xffffu, y = e.x >> 16;
+  const double et = ev_time(e.y, e.z);
+  if (b.dt_batch > 0 && (et - b.t0) / b.dt_batch < 1 && mc.active) {
+    int ox, oy;
+    mc_warp(mc, W, H, (int)x, (int)y, et - b.t0, &ox, &oy);
+    x = (uint32_t)ox;
+    y = (uint32_t)oy;
+  }
+  return x | (y << 16);
+}
+
 // ============================================================================ SAE keys
 // Coalesced 16 B/lane read of the raw AoS stream; one u32 key + one u32 index out per event.
 // Also: per-pass global digit histograms of the keys (LDS pre-aggregation, one global atomic per
@@ -191,21 +216,17 @@ __global__ __launch_bounds__(256) void k_sae_keys(const uint4* __restrict__ evL,
   __syncthreads();
   const uint32_t n = nL + nR;
   const uint32_t P = (uint32_t)W * (uint32_t)H;
+  McBatch mb{};
+  if (MC) mb = mc_batch(mc, evL);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const bool right = i >= nL;
     const uint4 e = right ? evR[i - nL] : evL[i];
     uint32_t x = e.x & 0xffffu, y = e.x >> 16;
     const bool ok = x < (uint32_t)W && y < (uint32_t)H;
-    if (MC && ok) {
-      // trackEvent's per-event gate (feature_tracker.cpp:627-641) + createSAE_* with
-      // Motion_correction_value (event_detector.cc:102-147): the event is written at the warped pixel
-      const double et = ev_time(e.y, e.z);
-      if (mc.dt_batch > 0 && (et - mc.t0) / mc.dt_batch < 1 && mc.active) {
-        int ox, oy;
-        mc_warp(mc, W, H, (int)x, (int)y, et - mc.t0, &ox, &oy);
-        x = (uint32_t)ox;
-        y = (uint32_t)oy;
-      }
+    if (MC && ok) {  // the event is written at the warped pixel
+      const uint32_t xy = mc_pixel(mc, mb, W, H, e);
+      x = xy & 0xffffu;
+      y = xy >> 16;
     }
     const uint32_t key = ok ? (right ? P : 0u) + y * (uint32_t)W + x : invalid_key;
     keys[i] = key;
@@ -265,7 +286,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ ticket,
                                                     uint32_t* __restrict__ keys_out,
                                                     uint32_t* __restrict__ vals_out,
-                                                    int* __restrict__ err) {
+                                                    int* __restrict__ err, uint32_t spin_limit) {
   __shared__ uint32_t wave_cnt_s[4][1 << kRadixMaxBits];
   __shared__ uint32_t bin_base[1 << kRadixMaxBits];
   __shared__ uint32_t s_tile;
@@ -338,7 +359,7 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
                                              __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t st = w & ~kLbMask;
         if (st == 0) {
-          if (++spins > (1u << 20)) {  // bounded: never hang the GPU
+          if (++spins > spin_limit) {  // bounded (kSpinLookback polls): never hang the GPU
             *err = 1;
             break;
           }
@@ -376,9 +397,9 @@ __global__ __launch_bounds__(256) void k_radix_pass(const uint32_t* __restrict__
 
 void launch_radix_pass(hipStream_t s, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n,
                        int shift, int bits, const uint32_t* ghist, uint32_t* lookback,
-                       uint32_t* ticket, uint32_t* keys_out, uint32_t* vals_out, int* err) {
+                       uint32_t* ticket, uint32_t* keys_out, uint32_t* vals_out, int* err, uint32_t spin_limit) {
   launch_k(k_radix_pass, dim3(radix_blocks(n)), dim3(256), 0, s, keys_in, vals_in, n, shift,
-                     bits, ghist, lookback, ticket, keys_out, vals_out, err);
+                     bits, ghist, lookback, ticket, keys_out, vals_out, err, spin_limit);
 }
 
 // ============================================================================ SAE apply
@@ -668,11 +689,31 @@ __device__ __forceinline__ uint32_t tile_bin(const TileGeom& g, uint32_t xy, boo
 // (T[seg][bucket]); k_tile_scan turns the group totals into exclusive prefixes over the groups
 // (C[seg][bucket]) and bucket totals.  k_tile_scatter then knows where every event goes:
 // bucket start + C[group][bucket] + P[block][bucket] + rank inside the block.
+// MC (the motion-compensated overload, feature_tracker.cpp:605-641): the bucket is that of the WARPED
+// pixel, computed by k_mc_warp (one lane per event: the per-event Matrix3f::exp + LU solve is a long
+// dependent chain, so it wants every SIMD full — inside k_tile_hist, whose 1024-thread blocks take
+// 2-4 events per thread one after the other, it cost 28 us at C3, on its own 8) into warp_xy[i]
+// (4 B per event); k_tile_scatter puts the warped pixel into the partitioned records — nothing after
+// the partition knows about the warp.
+__global__ __launch_bounds__(256) void k_mc_warp(const uint4* __restrict__ evL, uint32_t nL,
+                                                 const uint4* __restrict__ evR, uint32_t nR, int W, int H,
+                                                 McParams mc, uint32_t* __restrict__ warp_xy) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nL + nR) return;
+  const McBatch mb = mc_batch(mc, evL);
+  const uint4 e = i >= nL ? evR[i - nL] : evL[i];
+  uint32_t xy = e.x;
+  if ((xy & 0xffffu) < (uint32_t)W && (xy >> 16) < (uint32_t)H) xy = mc_pixel(mc, mb, W, H, e);
+  warp_xy[i] = xy;
+}
+
 constexpr int kTileHistThreads = 1024;
+template <bool MC>
 __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __restrict__ evL, uint32_t nL,
                                                    const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
                                                    uint32_t te, uint32_t nblk, uint32_t group,
-                                                   uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm) {
+                                                   uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm,
+                                                   const uint32_t* __restrict__ warp_xy) {
   constexpr int UB = 4, UE = 4;
   __shared__ uint32_t h[UB][kTileMaxBins], run[kTileMaxBins];  // 40 KiB
   const int nb = g.nbins;
@@ -695,7 +736,7 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
         if (j * kTileHistThreads < (int)te && i < hi) {
           const bool right = i >= nL;
           const uint4 e = right ? evR[i - nL] : evL[i];  // (whole records: one coalesced 1 KiB request per wave)
-          bins[u][j] = tile_bin(g, e.x, right);
+          bins[u][j] = tile_bin(g, MC ? warp_xy[i] : e.x, right);
         }
       }
     }
@@ -761,13 +802,21 @@ __global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* 
 }
 
 void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected) {
+                      const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected, const McParams* mc,
+                      uint32_t* warp_xy) {
   const uint32_t n = nL + nR;
   if (!n) return;
   const uint32_t te = tile_scatter_events_per_block(n), nblk = tile_scatter_blocks(n);
   const uint32_t group = tile_hist_group(nblk), nseg = (nblk + group - 1) / group;
-  launch_k(k_tile_hist, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, te, nblk,
-           group, sc.P, sc.T);
+  if (mc && mc->enabled) {
+    launch_k(k_mc_warp, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g.W, g.H,
+             *mc, warp_xy);
+    launch_k(k_tile_hist<true>, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
+             te, nblk, group, sc.P, sc.T, (const uint32_t*)warp_xy);
+  } else {
+    launch_k(k_tile_hist<false>, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
+             te, nblk, group, sc.P, sc.T, (const uint32_t*)nullptr);
+  }
   launch_k(k_tile_scan, dim3((g.nbins + kTileScanBins - 1) / kTileScanBins), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,
            g.nbins, sc.C, sc.totals, n_rejected);
 }
@@ -775,12 +824,12 @@ void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const Eve
 // Stable partition by bucket: a block ranks its 256 * ROUNDS consecutive events stably (wave-level
 // match-any by ballots keeps stream order inside a bucket) and writes the 16 B records to their
 // final places.
-template <int ROUNDS>
+template <int ROUNDS, bool MC>
 __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
     const uint4* __restrict__ evL, uint32_t nL, const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
     uint32_t group, const uint32_t* __restrict__ Pm, const uint32_t* __restrict__ Cm,
     const uint32_t* __restrict__ totals, uint4* __restrict__ part, uint32_t* __restrict__ tile_off,
-    uint32_t* __restrict__ tile_order) {
+    uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ warp_xy) {
   __shared__ uint32_t wave_cnt[4][kTileMaxBins];  // 32 KiB
   __shared__ uint32_t bin_base[kTileMaxBins];     // 8 KiB
   __shared__ uint32_t wave_tot[4];
@@ -801,6 +850,7 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
   for (int r = 0; r < ROUNDS; r++) {
     const uint32_t i = wbase + r * 64 + lane;
     rec[r] = i < nL ? evL[i] : (i < n ? evR[i - nL] : make_uint4(0xffffffffu, 0, 0, 0));
+    if (MC && i < n) rec[r].x = warp_xy[i];  // (the pixel k_tile_hist warped the event to)
   }
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++) {
@@ -902,18 +952,23 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 }
 
 void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                         const TileGeom& g, const TileScratch& sc, EventRec* part) {
+                         const TileGeom& g, const TileScratch& sc, EventRec* part, const uint32_t* warp_xy) {
   const uint32_t n = nL + nR;
   if (!n) return;
   const uint32_t nblk = tile_scatter_blocks(n), group = tile_hist_group(nblk);
-  if (tile_scatter_events_per_block(n) == 4096u)
-    launch_k(k_tile_scatter<16>, dim3(nblk), dim3(kTileScatterThreads), 0, s, (const uint4*)evL, nL,
-             (const uint4*)evR, nR, g, group, (const uint32_t*)sc.P, (const uint32_t*)sc.C,
-             (const uint32_t*)sc.totals, (uint4*)part, sc.tile_off, sc.tile_order);
-  else
-    launch_k(k_tile_scatter<8>, dim3(nblk), dim3(kTileScatterThreads), 0, s, (const uint4*)evL, nL,
-             (const uint4*)evR, nR, g, group, (const uint32_t*)sc.P, (const uint32_t*)sc.C,
-             (const uint32_t*)sc.totals, (uint4*)part, sc.tile_off, sc.tile_order);
+  const bool big = tile_scatter_events_per_block(n) == 4096u;
+#define ESVIO_TILE_SCATTER(R, M)                                                                          \
+  launch_k(k_tile_scatter<R, M>, dim3(nblk), dim3(kTileScatterThreads), 0, s, (const uint4*)evL, nL,      \
+           (const uint4*)evR, nR, g, group, (const uint32_t*)sc.P, (const uint32_t*)sc.C,                 \
+           (const uint32_t*)sc.totals, (uint4*)part, sc.tile_off, sc.tile_order, warp_xy)
+  if (warp_xy) {
+    if (big) ESVIO_TILE_SCATTER(16, true);
+    else ESVIO_TILE_SCATTER(8, true);
+  } else {
+    if (big) ESVIO_TILE_SCATTER(16, false);
+    else ESVIO_TILE_SCATTER(8, false);
+  }
+#undef ESVIO_TILE_SCATTER
 }
 
 // One block per bucket.  The tile's {L[0],L[1]} sit in LDS; the bucket's events are taken in turns
@@ -932,7 +987,7 @@ template <int kTileApplyThreads, int kPixBits>
 __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
     const uint4* __restrict__ part, const uint32_t* __restrict__ tile_off,
     const uint32_t* __restrict__ tile_order, TileGeom g, double2* __restrict__ L2, double2* __restrict__ S2,
-    double thr, uint8_t* __restrict__ arc_touched, int* __restrict__ err) {
+    double thr, uint8_t* __restrict__ arc_touched, int* __restrict__ err, uint32_t spin_limit) {
   // LDS (dynamic, sized by the tile): Ls[npx] double2 | Sidx[2 npx] (1 + position of the last
   // passing event) | touched[npx / 16] (one bit per (pixel, polarity))  = 24 B + 2 bits per pixel:
   // 12 KiB for 32x16, 48 KiB for 64x32
@@ -1018,7 +1073,7 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
       // other waves give up at once instead of timing out one turn after the other; the host sees
       // *err and fails the call)
       while ((d = __hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != turn) {
-        if (d == 0xffffffffu || ++spins > (1u << 21)) {
+        if (d == 0xffffffffu || ++spins > spin_limit) {  // (kSpinTicket polls)
           *err = 2;
           gave_up = true;
           __hip_atomic_store(&s_done, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1081,7 +1136,8 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
 }
 
 void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const TileGeom& g, const TileScratch& sc,
-                       double2* L2, double2* S2, double filter_threshold, uint8_t* arc_touched, int* err) {
+                       double2* L2, double2* S2, double filter_threshold, uint8_t* arc_touched, int* err,
+                       uint32_t spin_limit) {
   const int npx = g.tw * g.th;
   const unsigned lds = (unsigned)(npx * 24 + npx / 4 + 16);
   // a turn is 256 events: with a few turns per bucket 4 waves are plenty and many blocks fit a CU;
@@ -1091,7 +1147,7 @@ void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const Ti
 #define ESVIO_TILE_APPLY(T, B)                                                                            \
   launch_k(k_tile_apply<T, B>, dim3(2 * g.nt_cam), dim3(T), lds, s, (const uint4*)part,                  \
            (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold,     \
-           arc_touched, err)
+           arc_touched, err, spin_limit)
   static const int force_threads = getenv("ESVIO_FE_APPLY_THREADS") ? atoi(getenv("ESVIO_FE_APPLY_THREADS")) : 0;
   const int threads = force_threads ? force_threads : (big ? 512 : 256);
 #define ESVIO_TILE_APPLY_B(B)                     \
@@ -2271,6 +2327,7 @@ struct LkKernelArgs {
   unsigned long long* chain_out;  // see LkArgs::chain_*
   const unsigned long long* chain_in;
   uint32_t chain_seq;
+  unsigned long long poll_ticks, chain_ticks;  // bounds of the two waits (wall_clock64: 100 MHz)
 };
 
 // producer side of a chained launch: point `pt`'s forward result (alive = its status), or alive = 0
@@ -2303,7 +2360,7 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
       vx = __hip_atomic_load(&a.chain_in[2 * pt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       vy = __hip_atomic_load(&a.chain_in[2 * pt + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((uint32_t)(vx >> 34) == a.chain_seq && (uint32_t)(vy >> 34) == a.chain_seq) break;
-      if (wall_clock64() - t0 > 4000000ull) {  // 40 ms: the producer itself may wait 20 ms
+      if (wall_clock64() - t0 > a.chain_ticks) {  // (kTicksChain = 40 ms: the producer itself may wait 20 ms)
         if (lane == 0) *a.poll_err = 1;
         return;
       }
@@ -2319,7 +2376,7 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
     prev0 = make_float2(__uint_as_float((uint32_t)vx), __uint_as_float((uint32_t)vy));
   } else if (a.poll_slots && pt >= a.poll_from) {
     // this point is a corner k_select may still be about to accept: wait for its slot (or for the
-    // final count to rule it out).  wall_clock64 ticks at 100 MHz: give up after 20 ms.
+    // final count to rule it out).  wall_clock64 ticks at 100 MHz: give up after kTicksPoll = 20 ms.
     const unsigned long long t0 = wall_clock64();
     unsigned long long v;
     for (;;) {
@@ -2330,7 +2387,7 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
         chain_publish(a, pt, lane, make_float2(0.f, 0.f), 0);
         return;
       }
-      if (wall_clock64() - t0 > 2000000ull) {
+      if (wall_clock64() - t0 > a.poll_ticks) {
         if (lane == 0) *a.poll_err = 1;
         chain_publish(a, pt, lane, make_float2(0.f, 0.f), 0);
         return;
@@ -2416,6 +2473,8 @@ void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts
   a.chain_out = f.chain_out;
   a.chain_in = f.chain_in;
   a.chain_seq = f.chain_seq;
+  a.poll_ticks = f.poll_ticks;
+  a.chain_ticks = f.chain_ticks;
   if (f.accum == 2)
     launch_k(k_lk_f32, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
   else

@@ -17,8 +17,8 @@ struct M3f {
 struct McParams {
   int enabled;       // this batch goes through the motion-compensation overload
   int active;        // |accel| > 5 m/s^2 (event_detector.cc:125): the warp is applied
-  double t0;         // first LEFT event time (feature_tracker.cpp:621)
-  double dt_batch;   // header stamp - t0 (:623)
+  double t1;         // event_left.header.stamp (feature_tracker.cpp:622); the kernels read t0, the first
+                     // LEFT event's time (:621), from the batch itself: dt = t1 - t0 (:623)
   float vsum[3];     // tmp_v + tmp_v_pre
   float omega[3];
   M3f K, Kinv;

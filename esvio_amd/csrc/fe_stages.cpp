@@ -151,13 +151,13 @@ void pyr_build(esvio_fe_ctx* c, const PyrDesc* p, int nimg) {
 void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int rawbuf);
 
 // ---------------------------------------------------------------- SAE update (both cameras)
-// Motion_correction_value -> kernel parameters; first_left_host: left.events[0] (host copy)
-McParams make_mc_params(const esvio_fe_motion* m, const esvio_fe_event& first_left) {
+// Motion_correction_value -> kernel parameters (the kernels take t_0, the first left event's time,
+// feature_tracker.cpp:621, from the batch itself: no host copy of an event for a device batch)
+McParams make_mc_params(const esvio_fe_motion* m) {
   McParams p;
   std::memset(&p, 0, sizeof(p));
   p.enabled = 1;
-  p.t0 = (double)first_left.sec + 1e-9 * (double)first_left.nsec;  // ros::Time::toSec()
-  p.dt_batch = m->t1 - p.t0;
+  p.t1 = m->t1;
   const double an = std::sqrt(std::pow((double)m->accel[0], 2) + std::pow((double)m->accel[1], 2) +
                               std::pow((double)m->accel[2], 2));
   p.active = an > 5;  // a_motion_compensation_threshold (event_detector.h:51)
@@ -177,26 +177,21 @@ McParams make_mc_params(const esvio_fe_motion* m, const esvio_fe_event& first_le
   return p;
 }
 
-int first_event_host(esvio_fe_ctx* c, const esvio_fe_event* left, int space, esvio_fe_event* out) {
-  if (space == ESVIO_FE_HOST) {
-    *out = left[0];
-    return 0;
-  }
-  HIPCHK(c, hipMemcpy(out, left, sizeof(*out), hipMemcpyDeviceToHost));
-  return 0;
-}
-
 int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                     double2* L2, double2* S2, uint8_t* arc_touched) {
+                     double2* L2, double2* S2, uint8_t* arc_touched, const McParams* mc) {
   const uint32_t n = nL + nR;
   if (n > c->part_cap) {
     const size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
     if (c->d_part) (void)hipFree(c->d_part);
+    if (c->d_warp) (void)hipFree(c->d_warp);
     c->d_part = nullptr;
+    c->d_warp = nullptr;
     c->part_cap = 0;
     if (int rc = dev_alloc(c, &c->d_part, cap)) return rc;
     c->part_cap = cap;
   }
+  if (mc && !c->d_warp)  // the motion-compensated overload: 4 B per event for the warped pixels
+    if (int rc = dev_alloc(c, &c->d_warp, c->part_cap)) return rc;
   const size_t nblk_cap = (c->part_cap + 2047) / 2048;  // (2048 events per scatter block at least)
   const size_t head = (size_t)3 * kTileMaxBins + 64;
   const size_t need = head + (nblk_cap + 2 * (size_t)kTileMaxGroups) * kTileMaxBins;
@@ -216,16 +211,16 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
   sc.C = sc.T + (size_t)kTileMaxGroups * kTileMaxBins;
   {
     ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
-    launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected);
+    launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected, mc, mc ? c->d_warp : nullptr);
   }
   {
     ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 16 B in, 16 B out
-    launch_tile_scatter(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_part);
+    launch_tile_scatter(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_part, mc ? c->d_warp : nullptr);
   }
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
     launch_tile_apply(cur_stream(c), c->d_part, n, c->tgeom, sc, L2, S2, c->cfg.feature_filter_threshold,
-                      arc_touched, c->z_counts + 3);
+                      arc_touched, c->z_counts + 3, c->lim.ticket);
   }
   return 0;
 }
@@ -239,10 +234,12 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
   if (!L2) L2 = c->L2;  // (other planes: the scratch pair of the time-slice entry points)
   if (!S2) S2 = c->S2;
   if (arc_marked) *arc_marked = false;
-  if (c->tiled && !mc) {
-    uint8_t* mark = arc_set >= 0 && nL ? c->d_touched[arc_set] : nullptr;
+  if (c->tiled) {
+    // (motion compensation: the update happens at the warped pixels, Arc* is asked about the events'
+    // own pixels (feature_tracker.cpp:698 -> :13-38), so the tiles' touched flags are not Arc*'s)
+    uint8_t* mark = arc_set >= 0 && nL && !mc ? c->d_touched[arc_set] : nullptr;
     if (arc_marked) *arc_marked = mark != nullptr;
-    return sae_update_tiled(c, evL, nL, evR, nR, L2, S2, mark);
+    return sae_update_tiled(c, evL, nL, evR, nR, L2, S2, mark, mc);
   }
   if (int rc = ensure_sort_capacity(c, n)) return rc;
   const int passes = (c->key_bits + 6) / 7;
@@ -263,7 +260,7 @@ int sae_update(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec
     ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 16);
     launch_radix_pass(cur_stream(c), c->keys[cur], c->vals[cur], n, p * bits, bits, ghist + ((size_t)p << bits),
                       lookback + (size_t)p * (nblk << bits), tickets + p, c->keys[cur ^ 1],
-                      c->vals[cur ^ 1], c->z_counts + 3);
+                      c->vals[cur ^ 1], c->z_counts + 3, c->lim.lookback);
     cur ^= 1;
   }
   {

@@ -16,12 +16,16 @@ namespace fe {
 // planes nor the raw surfaces there, so the next prefetch only has to follow its own stream.
 // With the caller's PUB hint the Arc* pass of the batch runs here too (into the other candidate
 // set), which takes it off the main stream's per-frame chain.
-int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
+int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first) {
   int rc = 0;
   StreamScope on_prefetch_stream(c->stream2);
   while (!rc && !c->announced.empty() && (int)c->inflight.size() < kPrefetchDepth) {
     Inflight b;
     static_cast<Batch&>(b) = c->announced.front();
+    // host events still on their way through the staging slot: this call does not wait for them, the
+    // batch is taken up by the next one (unless it is the very batch the caller is about to track)
+    if (b.stage >= 0 && !must_take_first && !stager_ready(c, b.stage)) break;
+    must_take_first = false;
     // resources nobody is using: not the current frame's, not another prefetched batch's
     auto taken = [&](int Inflight::*m, int v) {
       for (const Inflight& o : c->inflight)
@@ -52,7 +56,11 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
         rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
         break;
       }
-      if ((rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &b.dL, &b.dR, b.lane))) break;
+      if (b.stage >= 0) {
+        if ((rc = stager_attach(c, b.stage, b.nL, c->stream2, &b.dL, &b.dR))) break;
+      } else if ((rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &b.dL, &b.dR, b.lane))) {
+        break;
+      }
       // the ~11 dependent launches up to the pyramids go out as one graph (fe_kernels.h); with the
       // per-kernel timers on they are launched one by one so that each can be bracketed
       const bool as_graph = c->graphs_enabled && !c->prof_on;
@@ -61,7 +69,9 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
         set_launch_recorder(&c->rec);
       }
       bool arc_marked = false;
-      rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR, nullptr, nullptr, nullptr,
+      McParams mcp;
+      if (b.has_motion) mcp = make_mc_params(&b.motion);
+      rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR, b.has_motion ? &mcp : nullptr, nullptr, nullptr,
                       b.pub && b.nL ? b.cand : -1, &arc_marked);
       if (!rc) {
         render_and_build(c, b.time, b.slotL, b.slotR, b.raw);
@@ -92,6 +102,8 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes) {
         }
         b.arc_done = true;
       }
+      // (the last kernels on this stream that read the batch's events)
+      if (b.stage >= 0 && (rc = stager_mark_read(c, b.stage, c->stream2, false))) break;
       c->inflight.push_back(b);
       c->announced.pop_front();
     } while (0);
@@ -126,6 +138,7 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
     f.poll_seq = c->pub_seq;
     f.poll_from = n_kept;
     f.poll_err = (int*)(c->z_spec + M * 16 + 2 * stM);
+    f.poll_ticks = c->lim.poll;
   }
   // the frame after next, chained to this launch point by point (see esvio_fe_ctx::d_chain)
   const Inflight* nxt2 = nullptr;
@@ -154,6 +167,7 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
                         ESVIO_FE_LK_USE_INITIAL_FLOW);
     f2.chain_in = c->d_chain;
     f2.chain_seq = c->chain_seq;
+    f2.chain_ticks = c->lim.chain;
     f2.poll_err = (int*)(zc + M * 16 + 2 * stM);
     {
       StreamScope on_chain_stream(c->stream4);
@@ -290,6 +304,36 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
                      const esvio_fe_motion* motion) {
   const esvio_fe_config& cfg = c->cfg;
   const int M = cfg.max_cnt;
+  // ---- what can refuse the call comes first: a refused call leaves the handle as it was
+  auto same_motion = [&](const Batch& a) {  // (field by field: the struct has padding)
+    if ((motion != nullptr) != a.has_motion) return false;
+    if (!motion) return true;
+    const esvio_fe_motion &x = *motion, &y = a.motion;
+    bool eq = x.t1 == y.t1 && x.fx == y.fx && x.fy == y.fy && x.cx == y.cx && x.cy == y.cy;
+    for (int i = 0; i < 3; i++)
+      eq = eq && x.v[i] == y.v[i] && x.v_pre[i] == y.v_pre[i] && x.accel[i] == y.accel[i] && x.omega[i] == y.omega[i];
+    return eq;
+  };
+  if (c->inflight.empty() && !c->announced.empty()) {
+    // announced, but an earlier call left it where it was because its host events were still on
+    // their way to the device: it is needed now
+    const Batch& a = c->announced.front();
+    if (left == a.left && nL == a.nL && right == a.right && nR == a.nR && space == a.space) {
+      if (_cur_time != a.time || !same_motion(a))
+        return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
+      if (int rc = prefetch_next(c, true, true)) return rc;
+    }
+  }
+  if (!c->inflight.empty()) {
+    const Inflight& b = c->inflight.front();
+    if (left != b.left || nL != b.nL || right != b.right || nR != b.nR || space != b.space ||
+        _cur_time != b.time || !same_motion(b))
+      return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
+    if (PUB_THIS_FRAME && !b.arc_done && c->inflight.size() > 1)
+      return fail(c, ESVIO_FE_EINVAL,
+                  "PUB hint was 0 for a published frame and a later batch is already applied to "
+                  "the SAE: with more than one batch announced the hint must be exact");
+  }
   // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
   // (lazy mode, pend_right) while this frame's kernels are enqueued
   c->res_set ^= 1;
@@ -310,20 +354,16 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   const bool first = !c->have_img;
   bool arc_done = false, arc_prefetched = false, arc_marked_main = false;
   int arc_lane = 0;
+  bool main_reads_events = false;  // this call enqueues main-stream kernels that read the batch's events
+  c->cur_stage = -1;
   if (!c->inflight.empty()) {
     // this batch was announced with esvio_fe_set_next_batch and its SAE update, images and
     // pyramids were enqueued on the prefetch stream during an earlier call
     const Inflight b = c->inflight.front();
-    if (left != b.left || nL != b.nL || right != b.right || nR != b.nR || space != b.space ||
-        _cur_time != b.time || motion)
-      return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
-    if (PUB_THIS_FRAME && !b.arc_done && c->inflight.size() > 1)
-      return fail(c, ESVIO_FE_EINVAL,
-                  "PUB hint was 0 for a published frame and a later batch is already applied to "
-                  "the SAE: with more than one batch announced the hint must be exact");
     c->inflight.pop_front();
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_done[b.lane], 0));
     c->tr_lane = b.lane;
+    c->cur_stage = b.stage;
     dL = b.dL;
     dR = b.dR;
     c->slot_curL = b.slotL;
@@ -337,7 +377,15 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     }
   } else {
     c->cur_prefetched = false;
-    if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
+    main_reads_events = true;
+    if (space == ESVIO_FE_HOST && stager_enabled(c) && (nL + nR) * 16 >= (256u << 10)) {
+      // not announced: the helpers and this thread stage the chunks together, the DMA of chunk k runs
+      // under the memcpy of chunk k+1
+      if (int rc = stager_begin(c, left, nL, right, nR, 4, &c->cur_stage)) return rc;
+      if (int rc = stager_attach(c, c->cur_stage, nL, c->stream, &dL, &dR)) return rc;
+    } else if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) {
+      return rc;
+    }
     // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
     if (c->ext_sae_pending) {
       // esvio_fe_sae_slice_commit has put this batch into the planes already (its SAE update ran
@@ -345,9 +393,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       if (motion) return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update has no motion-compensated form");
       c->ext_sae_pending = false;
     } else if (motion) {
-      esvio_fe_event first_ev;
-      if (int rc = first_event_host(c, left, space, &first_ev)) return rc;
-      const McParams mc = make_mc_params(motion, first_ev);
+      const McParams mc = make_mc_params(motion);
       if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
     } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, nullptr, nullptr, nullptr,
                                    PUB_THIS_FRAME ? c->cand_cur : -1, &arc_marked_main)) {
@@ -413,6 +459,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       run_compact(c, (uint32_t)nL, c->cand_cur);
       arc_done = true;
       main_reads_planes = true;
+      main_reads_events = true;
     }
     if (!had_announced) return 0;
     if (main_reads_planes) HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
@@ -471,6 +518,12 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       int* wait_expired = (int*)(c->h_spec + (size_t)std::max(M, 1) * 16 + 2 * stM);
       spec_ok = *wait_expired == 0;  // (a wave gave up waiting for k_select: redo the launch below)
       *wait_expired = 0;
+      if (!spec_ok) {
+        c->n_spec_expired++;
+        // its waves have ended without results; nothing of it may still be running when the same
+        // points go through the plain launch below
+        HIPCHK(c, hipStreamSynchronize(c->stream3));
+      }
     }
     std::vector<P2f> g_ptsB, g_ptsC;
     std::vector<uint8_t> g_stA, g_stB;
@@ -487,6 +540,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       spec_ok = *wait_expired == 0;
       *wait_expired = 0;
       c->tr_chain_used += spec_ok;
+      if (!spec_ok) c->n_chain_expired++;
       if (c->trace && spec_ok) {
         float a = 0, b = 0, d = 0;
         if (hipEventElapsedTime(&a, c->ev_dbg_sel_start, c->ev_sel_host) == hipSuccess &&
@@ -759,6 +813,12 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   c->prev_time = c->cur_time;
   c->spec_n = (int)c->prev_pts.size();
   lap(7);
+  if (c->cur_stage >= 0) {  // the staging slot of this batch's host events is free for another batch
+    if (main_reads_events)
+      if (int rc = stager_mark_read(c, c->cur_stage, c->stream, true)) return rc;
+    if (int rc = stager_release(c, c->cur_stage)) return rc;
+    c->cur_stage = -1;
+  }
   c->phase_frames++;
   c->phase_count[PUB_THIS_FRAME ? 1 : 0]++;
   c->tr_surv += (uint64_t)n_surv;

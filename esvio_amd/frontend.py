@@ -79,7 +79,7 @@ ABI_SYMBOLS = [
     "esvio_fe_get_sae", "esvio_fe_set_sae", "esvio_fe_calc_optical_flow_pyr_lk",
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
-    "esvio_fe_set_next_batch", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
+    "esvio_fe_set_next_batch", "esvio_fe_set_next_batch_mc", "esvio_fe_debug_inject", "esvio_fe_debug_counters", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
     "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
@@ -135,6 +135,9 @@ def load_library(build_if_missing=True):
     L.esvio_fe_create_sae_stereo_mc.argtypes = [vp, vp, sz, vp, sz, i, C.POINTER(Motion),
                                                 C.POINTER(C.c_uint64)]
     L.esvio_fe_set_next_batch.argtypes = [vp, d, vp, sz, vp, sz, i, i]
+    L.esvio_fe_set_next_batch_mc.argtypes = [vp, d, vp, sz, vp, sz, i, i, C.POINTER(Motion)]
+    L.esvio_fe_debug_inject.argtypes = [vp, i]
+    L.esvio_fe_debug_counters.argtypes = [vp, vp]
     L.esvio_fe_good_features_to_track.argtypes = [vp, vp, i, d, d, vp, vp, vp, vp]
     L.esvio_fe_track_image.argtypes = [vp, d, vp, vp, i, vp]
     L.esvio_fe_pack_track_records.argtypes = [vp, vp, vp]
@@ -202,6 +205,9 @@ def make_config(W, H, device=-1, **kw):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+FAULT_TICKET, FAULT_LOOKBACK, FAULT_SPECULATIVE, FAULT_CHAINED = 1, 2, 4, 8
 
 
 def _events_arg(ev):
@@ -411,19 +417,34 @@ class FeatureTracker:
         self._hd.check(self._hd.L.esvio_fe_pack_track_records(self._hd.h, _p(out), C.byref(n)))
         return out
 
-    def set_next_batch(self, next_cur_time, event_left, event_right, PUB_NEXT_FRAME=False):
+    def set_next_batch(self, next_cur_time, event_left, event_right, PUB_NEXT_FRAME=False, measurements=None):
         """announce the batch of the FOLLOWING trackEvent call (throughput / replay mode);
-        PUB_NEXT_FRAME is the PUB_THIS_FRAME that call is expected to carry (a hint)"""
+        PUB_NEXT_FRAME is the PUB_THIS_FRAME that call is expected to carry (a hint);
+        `measurements`: the esvio_fe_motion that call will pass (motion-compensated overload)"""
         pl, nl, sl, k1 = _events_arg(event_left)
         pr, nr, sr, k2 = _events_arg(event_right)
         assert sl == sr
-        # host arrays must outlive the prefetch (up to two announced + the one being tracked)
-        self._next_keep = (getattr(self, "_next_keep", []) + [(k1, k2)])[-4:]
-        self._hd.check(self._hd.L.esvio_fe_set_next_batch(self._hd.h, float(next_cur_time), pl, nl,
-                                                          pr, nr, sl, int(bool(PUB_NEXT_FRAME))))
+        # host arrays must outlive the prefetch (up to six announced + the one being tracked)
+        self._next_keep = (getattr(self, "_next_keep", []) + [(k1, k2)])[-8:]
+        if measurements is None:
+            self._hd.check(self._hd.L.esvio_fe_set_next_batch(self._hd.h, float(next_cur_time), pl, nl,
+                                                              pr, nr, sl, int(bool(PUB_NEXT_FRAME))))
+        else:
+            self._hd.check(self._hd.L.esvio_fe_set_next_batch_mc(self._hd.h, float(next_cur_time), pl, nl, pr, nr, sl,
+                                                                 int(bool(PUB_NEXT_FRAME)), C.byref(measurements)))
 
     def reset(self):
         self._hd.check(self._hd.L.esvio_fe_reset(self._hd.h))
+
+    def debug_inject(self, mask):
+        """make device-side waits expire on demand (FAULT_TICKET | FAULT_LOOKBACK | FAULT_SPECULATIVE |
+        FAULT_CHAINED; 0: normal bounds)"""
+        self._hd.check(self._hd.L.esvio_fe_debug_inject(self._hd.h, int(mask)))
+
+    def debug_counters(self):
+        out = (C.c_uint64 * 4)()
+        self._hd.check(self._hd.L.esvio_fe_debug_counters(self._hd.h, out))
+        return dict(spec_redone=out[0], chain_redone=out[1], chain_launched=out[2], chain_used=out[3])
 
     # ---- the handle's own RCCL communicator: asynchronous exchange of the track records
     def comm_init(self, unique_id, rank, world):

@@ -220,9 +220,13 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle h, const esvio_fe_event* left,
  * pass exactly these pointers, sizes, space and cur_time (else ESVIO_FE_EINVAL) and the event memory
  * must stay valid until then.  Results are identical to the non-pipelined sequence.  After a call
  * that prefetched, the get_sae / time-surface taps already reflect the latest prefetched batch.
- * Up to three batches may be announced ahead (call this up to three times before a track call; the
- * calls that follow must come in the announced order): the later ones' SAE updates then run whole
- * frames early.  With more than one batch in flight the hint of a published frame must be exact
+ * Up to three batches are taken up ahead of their track calls (the calls that follow must come in
+ * the announced order): the later ones' SAE updates then run whole frames early; up to six may be
+ * announced and not yet tracked (ESVIO_FE_EINVAL beyond).  Batches in ESVIO_FE_HOST memory start on their way to the
+ * device inside this call: helper threads copy them into pinned chunks and enqueue the DMAs on a copy
+ * stream of the handle (ESVIO_FE_STAGE_THREADS, default 2; a pinned source is DMA'd as it is), and a
+ * track call takes up an announced batch only once that is done — so announce host batches one call
+ * further ahead than device batches.  With more than one batch in flight the hint of a published frame must be exact
  * (the SAE has moved on by the time it is tracked): a published frame whose hint was 0 is refused
  * with ESVIO_FE_EINVAL.  With two batches' pyramids in flight and a next frame that publishes
  * nothing (hint 0: no new corners, no RANSAC — the frame after it tracks exactly its forward LK
@@ -233,6 +237,12 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle h, const esvio_fe_event* left,
 int esvio_fe_set_next_batch(esvio_fe_handle h, double next_cur_time, const esvio_fe_event* left,
                             size_t nL, const esvio_fe_event* right, size_t nR, int space,
                             int pub_hint);
+/* The same for a batch that esvio_fe_track_event_mc will be given (configs with
+ * Do_motion_correction: 1): the Motion_correction_value the node has assembled for it travels with the
+ * announcement (copied), the following esvio_fe_track_event_mc call must pass the same values. */
+int esvio_fe_set_next_batch_mc(esvio_fe_handle h, double next_cur_time, const esvio_fe_event* left,
+                               size_t nL, const esvio_fe_event* right, size_t nR, int space,
+                               int pub_hint, const esvio_fe_motion* motion);
 
 /* ---- image front-end: FeatureTracker::trackImage ------------------------ */
 /* For this path the handle is the image tracker's own instance (stereo_image_tracker_node.cpp:31):
@@ -350,6 +360,22 @@ int esvio_fe_sae_slice_apply(esvio_fe_handle h, const esvio_fe_event* left, size
                              int in_space, double* s_out, int out_space);
 int esvio_fe_sae_slice_commit(esvio_fe_handle h, const double* last_all, const double* s_all,
                               int n_slices, int space);
+
+/* ---- fault injection (tests) ----------------------------------------------------------- */
+/* Every device-side wait is bounded: a wave that gives up raises a host-visible flag and the call
+ * either fails with ESVIO_FE_EINTERNAL (the SAE update's turn ticket and the radix sort's look-back:
+ * the planes are then partially updated; esvio_fe_reset makes the handle usable again) or redoes the
+ * launch the plain way (the speculative / chained temporal LK of replay mode: results unchanged).
+ * esvio_fe_debug_inject makes the chosen waits expire the first time they would have to wait, for the
+ * launches that follow (0: normal bounds again); ESVIO_FE_FAULT=<mask> in the environment does the
+ * same from esvio_fe_create on.  esvio_fe_debug_counters: {speculative launches redone, chained
+ * launches redone, chained launches made, chained launches used}. */
+#define ESVIO_FE_FAULT_TICKET 1
+#define ESVIO_FE_FAULT_LOOKBACK 2
+#define ESVIO_FE_FAULT_SPECULATIVE 4
+#define ESVIO_FE_FAULT_CHAINED 8
+int esvio_fe_debug_inject(esvio_fe_handle h, int mask);
+int esvio_fe_debug_counters(esvio_fe_handle h, uint64_t out4[4]);
 
 /* ---- measurement --------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the handle's stream (off by default; when on, every launch is

@@ -1,0 +1,106 @@
+"""Every device-side wait is bounded and has a give-up path; here each one is made to expire on demand
+(esvio_fe_debug_inject / ESVIO_FE_FAULT: the wait's bound becomes 0, so a wave that would have to wait
+at all gives up) and the documented consequence is checked:
+
+* k_tile_apply's turn ticket, k_radix_pass's look-back: the call fails with ESVIO_FE_EINTERNAL (the
+  planes are partially updated), esvio_fe_reset makes the handle usable again;
+* the speculative temporal LK waiting for k_select's corners, the chained temporal LK waiting for the
+  previous frame's launch: the host notices the flag and redoes the launch the plain way — every frame
+  still equals the sequential oracle's, and the redo counters show that the path was taken."""
+import numpy as np
+import pytest
+
+from esvio_amd import frontend as FE
+from esvio_amd.events import event_times
+from esvio_amd.synth import SceneStream
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("cur_pts", "cur_un_pts", "pts_velocity", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity")
+
+
+def _same(ft, r, tag, off=0):
+    assert np.array_equal(ft.ids, r.ids + off) and np.array_equal(ft.track_cnt, r.track_cnt), tag
+    assert np.array_equal(ft.ids_right, r.ids_right + off), tag
+    for k in KEYS:
+        a, b = getattr(ft, k), getattr(r, k)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (tag, k)
+
+
+@pytest.mark.parametrize("which", ["ticket", "lookback"])
+def test_an_expired_wait_of_the_sae_update_fails_the_call_and_reset_recovers(oracle, monkeypatch, which):
+    if which == "lookback":
+        monkeypatch.setenv("ESVIO_FE_SAE_SORT", "1")  # the radix-sort form of the update
+    W, H = 640, 480
+    kw = dict(max_cnt=150, min_dist=10, f_ransac=1)
+    s = SceneStream(W, H, rate=2e7, seed=6, n_rect=20, size=(40.0, 120.0))  # ~1100 events per tile: several turns
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    L, R, _ = s.next_batch()
+    ft.trackEvent(event_times(L)[-1], L, R, True)  # (a healthy frame first)
+    ft.debug_inject(FE.FAULT_TICKET if which == "ticket" else FE.FAULT_LOOKBACK)
+    L, R, _ = s.next_batch()
+    with pytest.raises(FE.FrontendError, match="rc=-5"):
+        ft.trackEvent(event_times(L)[-1], L, R, True)
+    with pytest.raises(FE.FrontendError, match="rc=-5"):  # the stand-alone entry point reports it as well
+        ft.detector.createSAE_stereo(L, R)
+    ft.debug_inject(0)
+    ft.reset()
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(4):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, True)
+        r = tr.track_event(t, L, R, True)
+        off = int(ft.ids.min() - r.ids.min()) if len(r.ids) else 0  # (ids keep counting across a reset)
+        _same(ft, r, (which, "after reset", f), off)
+        assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+        assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1))
+    assert len(ft.ids) > 60
+    ft.close()
+
+
+@pytest.mark.parametrize("mask,counter", [(FE.FAULT_SPECULATIVE, "spec_redone"), (FE.FAULT_CHAINED, "chain_redone"),
+                                          (FE.FAULT_SPECULATIVE | FE.FAULT_CHAINED, "spec_redone")])
+def test_an_expired_speculative_or_chained_lk_wait_is_redone_with_the_same_results(oracle, mask, counter):
+    W, H = 640, 480
+    kw = dict(max_cnt=200, min_dist=10, f_ransac=1)
+    s = SceneStream(W, H, rate=4e6, seed=23, n_rect=24, size=(40.0, 120.0))
+    batches = [s.next_batch()[:2] for _ in range(36)]
+    pubs = [f % 2 == 0 for f in range(len(batches))]  # every other frame publishes nothing: chains are launched
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(True)
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        if f == 6:
+            base = ft.debug_counters()
+            ft.debug_inject(mask)
+        if f == 18:
+            after = ft.debug_counters()
+            ft.debug_inject(0)
+        while announced < min(f + 3, len(batches) - 1):
+            announced += 1
+            Ln, Rn = batches[announced]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pubs[f])
+        r = tr.track_event(t, L, R, pubs[f])
+        ft.finish()
+        _same(ft, r, ("fault", mask, f))
+    assert after[counter] > base[counter], (base, after)  # the give-up path really ran
+    end = ft.debug_counters()
+    assert end["chain_used"] > after["chain_used"]  # ... and normal service resumed
+    assert len(ft.ids) > 80
+    ft.close()
+
+
+def test_fault_mask_from_the_environment(oracle, monkeypatch):
+    """ESVIO_FE_FAULT=<mask> applies from esvio_fe_create on"""
+    monkeypatch.setenv("ESVIO_FE_FAULT", str(FE.FAULT_TICKET))
+    W, H = 346, 260
+    s = SceneStream(W, H, rate=1e7, seed=2)
+    ft = FE.FeatureTracker(FE.make_config(W, H))
+    L, R, _ = s.next_batch()
+    with pytest.raises(FE.FrontendError, match="rc=-5"):
+        ft.detector.createSAE_stereo(L, R)
+    ft.close()

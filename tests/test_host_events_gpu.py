@@ -1,0 +1,138 @@
+"""Host-resident event batches (ESVIO_FE_HOST — what the reference's `const dvs_msgs::EventArray&`
+interface hands over, feature_tracker.h:51-52) on their way to the device: pinned chunks + DMA by
+helper threads, started by esvio_fe_set_next_batch (fe_evstage.cpp).  Whatever the staging does —
+helper count, a pinned source, batches taken up late because they were still on their way, a reset
+in between, batches below the staging threshold — every frame equals the sequential oracle's."""
+import numpy as np
+import pytest
+
+from esvio_amd import frontend as FE
+from esvio_amd.events import event_times
+from esvio_amd.synth import SceneStream
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("cur_pts", "cur_un_pts", "pts_velocity", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity")
+
+
+def _same(ft, r, tag):
+    assert np.array_equal(ft.ids, r.ids) and np.array_equal(ft.track_cnt, r.track_cnt), tag
+    assert np.array_equal(ft.ids_right, r.ids_right), tag
+    for k in KEYS:
+        a, b = getattr(ft, k), getattr(r, k)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (tag, k)
+
+
+def _batches(W, H, n, rate, seed, thin=True):
+    rng = np.random.default_rng(seed)
+    s = SceneStream(W, H, rate=rate, seed=seed, n_rect=12, size=(30.0, 90.0))
+    out = []
+    for f in range(n):
+        L, R, _ = s.next_batch()
+        if thin and rng.integers(0, 3) == 0:  # sizes change from batch to batch: slots regrow, chunk counts change
+            L, R = L[::5].copy(), R[::5].copy()
+        if f % 9 == 5:
+            R = R[:0]
+        out.append((L, R))
+    return out
+
+
+@pytest.mark.parametrize("threads,ahead,pinned", [(2, 4, False), (1, 3, False), (4, 2, False), (0, 3, False),
+                                                  (2, 4, True), (2, 1, False)])
+def test_host_resident_replay_matches_the_oracle(oracle, monkeypatch, threads, ahead, pinned):
+    """replay schedule over host batches, announced 1..4 ahead (4: one more than the prefetch depth,
+    what bench.py does for host batches), lazy mode, with 0 (stager off: the runtime's own pageable
+    copy), 1, 2 or 4 helper threads, and from a source that is pinned already (one DMA, no memcpy)"""
+    monkeypatch.setenv("ESVIO_FE_STAGE_THREADS", str(threads))
+    W, H = 640, 480
+    batches = _batches(W, H, 30, 4e6, 17)
+    if pinned:  # hipHostMalloc'ed copies (the HIP runtime the library itself is linked to)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        pb = []
+        for L, R in batches:
+            pair = []
+            for a in (L, R):
+                p = ctypes.c_void_p()
+                assert hip.hipHostMalloc(ctypes.byref(p), ctypes.c_size_t(max(a.nbytes, 16)), 0) == 0
+                v = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(max(a.nbytes, 16),))
+                v[:a.nbytes] = a.view(np.uint8).reshape(-1)
+                pair.append(v[:a.nbytes].view(a.dtype))
+            pb.append(tuple(pair))
+        batches = pb  # (left allocated until the process ends)
+    rng = np.random.default_rng(5)
+    pubs = [bool(rng.integers(0, 3) != 0) for _ in batches]
+    kw = dict(max_cnt=200, min_dist=10, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(True)
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        while announced < min(f + ahead, len(batches) - 1):
+            announced += 1
+            Ln, Rn = batches[announced]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pubs[f])
+        r = tr.track_event(t, L, R, pubs[f])
+        if f % 4 == 3:
+            ft.finish()
+            _same(ft, r, ("host replay", threads, ahead, f))
+    ft.finish()
+    _same(ft, r, ("host replay end", threads, ahead))
+    assert len(ft.ids) > 60
+    ft.close()
+
+
+def test_host_batches_without_announcement_and_across_a_reset(oracle):
+    """the drop-in call of INTEGRATION.md: esvio_fe_track_event(ESVIO_FE_HOST) one batch at a time (the
+    helpers and the calling thread stage the chunks together), small batches below the staging
+    threshold in between, announced batches dropped by esvio_fe_reset while they are being staged"""
+    W, H = 346, 260
+    kw = dict(max_cnt=120, min_dist=10, f_ransac=1)
+    batches = _batches(W, H, 14, 2.5e6, 3, thin=False)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f, (L, R) in enumerate(batches[:6]):
+        if f == 3:
+            L, R = L[:3000].copy(), R[:2000].copy()  # 80 KB: plain copy
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, f % 2 == 0)
+        _same(ft, tr.track_event(t, L, R, f % 2 == 0), ("direct", f))
+    # announce three, track one, reset
+    for k in (6, 7, 8):
+        ft.set_next_batch(event_times(batches[k][0])[-1], batches[k][0], batches[k][1], k % 2 == 0)
+    L, R = batches[6]
+    ft.trackEvent(event_times(L)[-1], L, R, True)
+    _same(ft, tr.track_event(event_times(L)[-1], L, R, True), "before reset")
+    ft.reset()
+    tr2 = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f, (L, R) in enumerate(batches[9:]):
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, True)
+        r = tr2.track_event(t, L, R, True)
+        # (ids keep counting across a reset: n_id is a static in the reference, feature_tracker.cpp:9)
+        off = int(ft.ids.min() - r.ids.min()) if len(r.ids) else 0
+        assert np.array_equal(ft.ids, r.ids + off) and np.array_equal(ft.ids_right, r.ids_right + off), ("after reset", f)
+        for k in KEYS:
+            assert np.array_equal(getattr(ft, k).view(np.uint32), getattr(r, k).view(np.uint32)), ("after reset", f, k)
+    assert len(ft.ids) > 30
+    ft.close()
+
+
+def test_a_batch_announced_late_is_taken_up_by_its_own_call(oracle):
+    """announce a big host batch and track it at once: the call that needs it waits for its staging
+    (helping with the chunks) instead of finding it prefetched"""
+    W, H = 640, 480
+    kw = dict(max_cnt=150, min_dist=10, f_ransac=1)
+    s = SceneStream(W, H, rate=8e6, seed=11, n_rect=20, size=(40.0, 120.0))
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    for f in range(6):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        if f:
+            ft.set_next_batch(t, L, R, True)
+        ft.trackEvent(t, L, R, True)
+        _same(ft, tr.track_event(t, L, R, True), ("late", f))
+    ft.close()

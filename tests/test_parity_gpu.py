@@ -529,10 +529,15 @@ def _motion(mod, L, accel=(4.0, 5.0, 3.0), omega=(0.9, -1.4, 2.1), W=640, H=480,
                            fx=0.9 * W, fy=0.9 * W, cx=W / 2.0 + 3.5, cy=H / 2.0 - 2.25)
 
 
-def test_motion_compensated_sae(oracle):
+@pytest.mark.parametrize("path", ["tiled", "sort_walk"])
+def test_motion_compensated_sae(oracle, path, monkeypatch):
     """createSAE_left/right with Motion_correction_value (event_detector.cc:102-147,168-210) under
     trackEvent's per-event gate (feature_tracker.cpp:627-641): planes bit-exact, incl. |a| <= 5
-    (no warp), large rotations (Pade-5 / Pade-7 branches of Matrix3f::exp) and border pixels."""
+    (no warp), large rotations (Pade-5 / Pade-7 branches of Matrix3f::exp) and border pixels.  Through
+    the tiled update (the warp inside k_tile_hist, the warped pixel written into the partitioned
+    record by k_tile_scatter) and through the radix-sort form (k_sae_keys<true>)."""
+    for k, v in SAE_PATHS[path].items():
+        monkeypatch.setenv(k, v)
     W, H = 640, 480
     s = SceneStream(W, H, rate=2e6, seed=31)
     cases = [dict(), dict(accel=(1.0, 2.0, 3.0)), dict(omega=(9.0, -14.0, 21.0)),
@@ -577,6 +582,60 @@ def test_track_event_motion_compensated_end_to_end(oracle):
         _compare_tracks(ft, r, ("mc", f))
     assert len(ft.ids) > 100
     ft.close()
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_motion_compensated_replay_schedule(oracle, space):
+    """the motion-compensated overload announced ahead (esvio_fe_set_next_batch_mc: the warp runs on
+    the prefetch stream with the rest of the batch's SAE update; Arc* is asked about the events' own
+    pixels, not the warped ones), three batches ahead, lazy mode, Motion_correction_values that change
+    from batch to batch incl. |a| <= 5 (no warp): bit-identical to the sequential oracle; a call whose
+    Motion_correction_value differs from the announced one is refused"""
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=5e6, seed=8)
+    batches = [s.next_batch()[:2] for _ in range(14)]
+    keep = []
+    if space == "device":
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+
+        def to_dev(a):
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(max(a.nbytes, 16))) == 0
+            assert hip.hipMemcpy(p, ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 1) == 0
+            keep.append(p)
+            return (p.value, len(a))
+        dev = [(to_dev(L), to_dev(R)) for L, R in batches]
+    pubs = [f % 3 != 1 for f in range(len(batches))]
+
+    def motions(mod, f, L):
+        om = (0.5 + 0.1 * f, -0.8, 1.2 - 0.2 * f)
+        return _motion(mod, L, omega=om, accel=(1.0, 2.0, 3.0) if f % 5 == 4 else (4.0, 5.0, 3.0))
+    ft = FE.FeatureTracker(FE.make_config(W, H))
+    ft.set_lazy_new_stereo(True)
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        arg = (lambda k: dev[k]) if space == "device" else (lambda k: batches[k])
+        while announced < min(f + 3, len(batches) - 1):
+            announced += 1
+            Ln = batches[announced][0]
+            ft.set_next_batch(event_times(Ln)[-1], arg(announced)[0], arg(announced)[1], pubs[announced],
+                              measurements=motions(FE, announced, Ln))
+        t = event_times(L)[-1]
+        if f == 6:  # not the announced Motion_correction_value: refused, nothing consumed
+            with pytest.raises(FE.FrontendError):
+                ft.trackEvent(t, arg(f)[0], arg(f)[1], pubs[f], measurements=motions(FE, f + 1, L))
+        ft.trackEvent(t, arg(f)[0], arg(f)[1], pubs[f], measurements=motions(FE, f, L))
+        r = tr.track_event(t, L, R, pubs[f], motion=motions(oracle, f, L))
+        ft.finish()
+        _compare_tracks(ft, r, ("mc replay", space, f))
+    assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+    assert len(ft.ids) > 100
+    ft.close()
+    if space == "device":
+        for p in keep:
+            hip.hipFree(p)
 
 
 @pytest.mark.parametrize("equalize,hint,depth,lazy", [
@@ -633,20 +692,24 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy)
     ft.close()
 
 
-def test_two_batches_ahead_need_an_exact_pub_hint():
+def test_two_batches_ahead_need_an_exact_pub_hint(monkeypatch):
     """with two batches in flight the SAE has moved past a frame by the time it is tracked, so a
     published frame whose hint was 0 (no prefetched Arc* pass) is refused instead of detecting on
-    the wrong surface; a fourth announcement is refused too"""
+    the wrong surface; a seventh announcement is refused too.  (Host batches staged by the helper
+    threads are taken up when they have arrived, which would make "two in flight" a matter of timing
+    here: the stager is off for this test.)"""
+    monkeypatch.setenv("ESVIO_FE_STAGE_THREADS", "0")
     W, H = 346, 260
     s = SceneStream(W, H, rate=2e6, seed=2)
-    b = [s.next_batch() for _ in range(5)]
+    b = [s.next_batch() for _ in range(8)]
     t = [event_times(x[0])[-1] for x in b]
     ft = FE.FeatureTracker(FE.make_config(W, H))
     ft.set_next_batch(t[1], b[1][0], b[1][1], False)
     ft.set_next_batch(t[2], b[2][0], b[2][1], False)
-    ft.set_next_batch(t[3], b[3][0], b[3][1], False)
+    for k in (3, 4, 5, 6):
+        ft.set_next_batch(t[k], b[k][0], b[k][1], False)
     with pytest.raises(FE.FrontendError):
-        ft.set_next_batch(t[4], b[4][0], b[4][1], False)
+        ft.set_next_batch(t[7], b[7][0], b[7][1], False)
     ft.trackEvent(t[0], b[0][0], b[0][1], True)       # enqueues the prefetch of frames 1 and 2
     with pytest.raises(FE.FrontendError):
         ft.trackEvent(t[1], b[1][0], b[1][1], True)   # hint said "not published"

@@ -411,7 +411,10 @@ int main(int argc, char** argv) {
   node.lazy = kv["lazy"] != 0;
   node.Do_motion_correction = kv["mc"] != 0;
   if (node.Do_motion_correction && node.ahead > 0) {
-    fprintf(stderr, "mc=1 needs ahead=0: an announced batch has no motion-compensated form\n");
+    // (the library can take an announced batch's Motion_correction_value — esvio_fe_set_next_batch_mc —
+    // but this harness assembles it from the IMU / odometry messages that arrive up to the batch, like
+    // the node does, so it only exists when the batch is handled)
+    fprintf(stderr, "mc=1 needs ahead=0: the Motion_correction_value of a batch is assembled when it is handled\n");
     return 2;
   }
   node.K[0] = kv.count("fx") ? kv["fx"] : c.cam[0].fx;
