@@ -1085,6 +1085,31 @@ int esvio_fe_set_next_batch_mc(esvio_fe_handle c, double next_cur_time, const es
   return set_next_batch_impl(c, next_cur_time, left, nL, right, nR, space, pub_hint, motion);
 }
 
+int esvio_fe_mem_alloc(int space, size_t bytes, void** out) {
+  if (!out || (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE)) return ESVIO_FE_EINVAL;
+  *out = nullptr;
+  const size_t b = std::max<size_t>(bytes, 16);
+  const hipError_t e = space == ESVIO_FE_HOST ? hipHostMalloc(out, b, hipHostMallocDefault) : hipMalloc(out, b);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    return ESVIO_FE_EHIP;
+  }
+  return 0;
+}
+
+int esvio_fe_mem_free(int space, void* p) {
+  if (space != ESVIO_FE_HOST && space != ESVIO_FE_DEVICE) return ESVIO_FE_EINVAL;
+  if (!p) return 0;
+  return (space == ESVIO_FE_HOST ? hipHostFree(p) : hipFree(p)) == hipSuccess ? 0 : ESVIO_FE_EHIP;
+}
+
+int esvio_fe_mem_upload(void* dst_device, const void* src_host, size_t bytes) {
+  if (bytes && (!dst_device || !src_host)) return ESVIO_FE_EINVAL;
+  if (!bytes) return 0;
+  return hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : ESVIO_FE_EHIP;
+}
+
 int esvio_fe_debug_inject(esvio_fe_handle c, int mask) {
   if (!c || mask < 0 || mask > 15) return ESVIO_FE_EINVAL;
   c->lim = esvio_fe_ctx::WaitLimits();

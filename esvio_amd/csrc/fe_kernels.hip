@@ -9,6 +9,7 @@
 #include "fe_mc.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <tuple>
@@ -653,10 +654,16 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
 // or the last bin for an out-of-sensor event.
 bool make_tile_geom(int W, int H, TileGeom* g) {
   static const int cand[][2] = {{32, 16}, {32, 32}, {64, 32}};
+  // (ESVIO_FE_TILE=32x32 / 64x32: a larger tile than the smallest that fits — A/B measurements)
+  int min_px = 0;
+  if (const char* v = getenv("ESVIO_FE_TILE")) {
+    int a = 0, b = 0;
+    if (sscanf(v, "%dx%d", &a, &b) == 2) min_px = a * b;
+  }
   for (const auto& c : cand) {
     const int tx = (W + c[0] - 1) / c[0], ty = (H + c[1] - 1) / c[1];
     const int nb = 2 * tx * ty + 1;
-    if (nb > kTileMaxBins || c[0] * c[1] > kTileMaxPx) continue;
+    if (nb > kTileMaxBins || c[0] * c[1] > kTileMaxPx || c[0] * c[1] < min_px) continue;
     g->W = W;
     g->H = H;
     g->tw = c[0];

@@ -79,7 +79,8 @@ ABI_SYMBOLS = [
     "esvio_fe_get_sae", "esvio_fe_set_sae", "esvio_fe_calc_optical_flow_pyr_lk",
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
-    "esvio_fe_set_next_batch", "esvio_fe_set_next_batch_mc", "esvio_fe_debug_inject", "esvio_fe_debug_counters", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
+    "esvio_fe_set_next_batch", "esvio_fe_set_next_batch_mc", "esvio_fe_debug_inject", "esvio_fe_debug_counters",
+    "esvio_fe_mem_alloc", "esvio_fe_mem_free", "esvio_fe_mem_upload", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
     "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
@@ -136,6 +137,9 @@ def load_library(build_if_missing=True):
                                                 C.POINTER(C.c_uint64)]
     L.esvio_fe_set_next_batch.argtypes = [vp, d, vp, sz, vp, sz, i, i]
     L.esvio_fe_set_next_batch_mc.argtypes = [vp, d, vp, sz, vp, sz, i, i, C.POINTER(Motion)]
+    L.esvio_fe_mem_alloc.argtypes = [i, sz, vp]
+    L.esvio_fe_mem_free.argtypes = [i, vp]
+    L.esvio_fe_mem_upload.argtypes = [vp, vp, sz]
     L.esvio_fe_debug_inject.argtypes = [vp, i]
     L.esvio_fe_debug_counters.argtypes = [vp, vp]
     L.esvio_fe_good_features_to_track.argtypes = [vp, vp, i, d, d, vp, vp, vp, vp]
@@ -602,6 +606,37 @@ def comm_unique_id():
     if rc:
         raise FrontendError("esvio_fe_comm_unique_id rc=%d (librccl.so not found?)" % rc)
     return bytes(buf)
+
+
+class EventBuffer:
+    """an event batch in memory from the library's own HIP runtime (esvio_fe_mem_alloc): pinned host memory
+    (`.array`: a numpy view that can be passed wherever a host batch goes — it is DMA'd without the staging
+    copy) or device memory (`.arg`: the (pointer, n) tuple the entry points take for ESVIO_FE_DEVICE)"""
+
+    def __init__(self, events, space=HOST):
+        ev = np.ascontiguousarray(events)
+        assert ev.dtype.itemsize == 16
+        self.space, self.n = space, len(ev)
+        p = C.c_void_p()
+        rc = load_library().esvio_fe_mem_alloc(space, ev.nbytes, C.byref(p))
+        if rc:
+            raise FrontendError("esvio_fe_mem_alloc rc=%d" % rc)
+        self.ptr = p
+        if space == HOST:
+            raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(ev.nbytes, 16),))
+            raw[:ev.nbytes] = ev.view(np.uint8).reshape(-1)
+            self.array = raw[:ev.nbytes].view(ev.dtype)
+        else:
+            rc = load_library().esvio_fe_mem_upload(p, _p(ev), ev.nbytes)
+            if rc:
+                raise FrontendError("esvio_fe_mem_upload rc=%d" % rc)
+            self.arg = (p.value, self.n)
+
+    def free(self):
+        if self.ptr:
+            load_library().esvio_fe_mem_free(self.space, self.ptr)
+            self.ptr = None
+            self.array = None
 
 
 def host_hypot(x, y):

@@ -361,6 +361,17 @@ int esvio_fe_sae_slice_apply(esvio_fe_handle h, const esvio_fe_event* left, size
 int esvio_fe_sae_slice_commit(esvio_fe_handle h, const double* last_all, const double* s_all,
                               int n_slices, int space);
 
+/* ---- event memory ------------------------------------------------------------------------- */
+/* Memory for event batches from the HIP runtime the library itself is linked to (a process may hold a
+ * second one, e.g. the copy PyTorch bundles).  ESVIO_FE_HOST: pinned host memory — a batch kept there
+ * (a dvs_msgs::EventArray_<Allocator> whose allocator calls this, or a buffer the driver's callback
+ * deserialises into) goes to the device as one DMA, without the staging copy pageable memory needs.
+ * ESVIO_FE_DEVICE: device memory on the current device; esvio_fe_mem_upload fills it from host memory
+ * (synchronous).  Freed with esvio_fe_mem_free(space, p). */
+int esvio_fe_mem_alloc(int space, size_t bytes, void** out);
+int esvio_fe_mem_free(int space, void* p);
+int esvio_fe_mem_upload(void* dst_device, const void* src_host, size_t bytes);
+
 /* ---- fault injection (tests) ----------------------------------------------------------- */
 /* Every device-side wait is bounded: a wave that gives up raises a host-visible flag and the call
  * either fails with ESVIO_FE_EINTERNAL (the SAE update's turn ticket and the radix sort's look-back:

@@ -46,20 +46,14 @@ def test_host_resident_replay_matches_the_oracle(oracle, monkeypatch, threads, a
     monkeypatch.setenv("ESVIO_FE_STAGE_THREADS", str(threads))
     W, H = 640, 480
     batches = _batches(W, H, 30, 4e6, 17)
-    if pinned:  # hipHostMalloc'ed copies (the HIP runtime the library itself is linked to)
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
+    bufs = []
+    if pinned:  # copies in pinned memory of the library's own HIP runtime (esvio_fe_mem_alloc)
         pb = []
         for L, R in batches:
-            pair = []
-            for a in (L, R):
-                p = ctypes.c_void_p()
-                assert hip.hipHostMalloc(ctypes.byref(p), ctypes.c_size_t(max(a.nbytes, 16)), 0) == 0
-                v = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(max(a.nbytes, 16),))
-                v[:a.nbytes] = a.view(np.uint8).reshape(-1)
-                pair.append(v[:a.nbytes].view(a.dtype))
-            pb.append(tuple(pair))
-        batches = pb  # (left allocated until the process ends)
+            bl, br = FE.EventBuffer(L), FE.EventBuffer(R)
+            bufs += [bl, br]
+            pb.append((bl.array, br.array))
+        batches = pb
     rng = np.random.default_rng(5)
     pubs = [bool(rng.integers(0, 3) != 0) for _ in batches]
     kw = dict(max_cnt=200, min_dist=10, f_ransac=1)
@@ -82,6 +76,8 @@ def test_host_resident_replay_matches_the_oracle(oracle, monkeypatch, threads, a
     _same(ft, r, ("host replay end", threads, ahead))
     assert len(ft.ids) > 60
     ft.close()
+    for b in bufs:
+        b.free()
 
 
 def test_host_batches_without_announcement_and_across_a_reset(oracle):

@@ -596,15 +596,9 @@ def test_motion_compensated_replay_schedule(oracle, space):
     batches = [s.next_batch()[:2] for _ in range(14)]
     keep = []
     if space == "device":
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-
         def to_dev(a):
-            p = ctypes.c_void_p()
-            assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(max(a.nbytes, 16))) == 0
-            assert hip.hipMemcpy(p, ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 1) == 0
-            keep.append(p)
-            return (p.value, len(a))
+            keep.append(FE.EventBuffer(a, FE.DEVICE))
+            return keep[-1].arg
         dev = [(to_dev(L), to_dev(R)) for L, R in batches]
     pubs = [f % 3 != 1 for f in range(len(batches))]
 
@@ -633,9 +627,8 @@ def test_motion_compensated_replay_schedule(oracle, space):
     assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
     assert len(ft.ids) > 100
     ft.close()
-    if space == "device":
-        for p in keep:
-            hip.hipFree(p)
+    for b in keep:
+        b.free()
 
 
 @pytest.mark.parametrize("equalize,hint,depth,lazy", [

@@ -3,7 +3,6 @@
     python tools/host_events_timing.py [--steps 60] [--ahead 4] [--pinned] [--direct]
 ESVIO_FE_STAGE_THREADS=0/1/2/4 selects the staging (0: the runtime's pageable copy)."""
 import argparse
-import ctypes
 import os
 import sys
 import time
@@ -32,19 +31,11 @@ def main():
     W, H = a.width, a.height
     s = SceneStream(W, H, rate=a.rate, seed=12345)
     n = a.warmup + 3 * a.steps  # three timed passes over the continued stream
-    hip = ctypes.CDLL("libamdhip64.so")
     batches = []
     for _ in range(n):
         L, R, _ = s.next_batch()
-        if a.pinned:
-            pair = []
-            for arr in (L, R):
-                p = ctypes.c_void_p()
-                assert hip.hipHostMalloc(ctypes.byref(p), ctypes.c_size_t(max(arr.nbytes, 16)), 0) == 0
-                v = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(max(arr.nbytes, 16),))
-                v[:arr.nbytes] = arr.view(np.uint8).reshape(-1)
-                pair.append(v[:arr.nbytes].view(arr.dtype))
-            L, R = pair
+        if a.pinned:  # pinned memory of the library's own HIP runtime
+            L, R = FE.EventBuffer(L).array, FE.EventBuffer(R).array
         batches.append((L, R, event_times(L)[-1]))
     fc = FreqControl(15)
     pubs = []
