@@ -166,6 +166,15 @@ __device__ __forceinline__ double ev_time(uint32_t sec, uint32_t nsec) {
   return __dadd_rn((double)sec, __dmul_rn(1e-9, (double)nsec));
 }
 
+// Barrier for data exchanged through LDS only.  __syncthreads() fences every address space, i.e. it
+// waits for the wave's outstanding global loads and stores too (s_waitcnt vmcnt(0)): a kernel that
+// prefetches its next tile from HBM, or lets its stores drain while it goes on, must not use it.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
   // cv::borderInterpolate(p, len, BORDER_REFLECT_101) for -len < p < 2*len-1
   p = p < 0 ? -p : p;
@@ -681,6 +690,37 @@ bool make_tile_geom(int W, int H, TileGeom* g) {
   return false;
 }
 
+// The partitioned records.  Wide: the raw 16-byte dvs_msgs::Event.  Compact (8 bytes; the default
+// whenever the batch allows it, k_tile_scan): x = tile-local pixel (11 bits) | polarity << 11 |
+// (sec - sec_base) << 12 (20 bits), y = nsec (30 bits) — everything k_tile_apply needs, at half
+// the partition's write and the apply's read volume; the event time is rebuilt exactly
+// (ros::Time::toSec() of the same two integers).
+__device__ __forceinline__ uint2 tile_rec_pack(const uint4& e, int tw, int th, int twsh, uint32_t sec_base) {
+  const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
+  const uint32_t pix = ((y & (uint32_t)(th - 1)) << twsh) | (x & (uint32_t)(tw - 1));
+  return make_uint2(pix | ((e.w & 0xffu) ? 1u << 11 : 0u) | ((e.y - sec_base) << 12), e.z);
+}
+template <bool COMPACT>
+struct TileRec;
+template <>
+struct TileRec<false> {
+  typedef uint4 T;
+  static __device__ __forceinline__ T load(const void* part, uint32_t i) { return ((const uint4*)part)[i]; }
+  static __device__ __forceinline__ uint32_t pix(const T& e, int x0, int y0, int twsh) {
+    return (((e.x >> 16) - (uint32_t)y0) << twsh) + ((e.x & 0xffffu) - (uint32_t)x0);
+  }
+  static __device__ __forceinline__ bool pol(const T& e) { return (e.w & 0xffu) != 0; }
+  static __device__ __forceinline__ double time(const T& e, uint32_t) { return ev_time(e.y, e.z); }
+};
+template <>
+struct TileRec<true> {
+  typedef uint2 T;
+  static __device__ __forceinline__ T load(const void* part, uint32_t i) { return ((const uint2*)part)[i]; }
+  static __device__ __forceinline__ uint32_t pix(const T& e, int, int, int) { return e.x & 0x7ffu; }
+  static __device__ __forceinline__ bool pol(const T& e) { return (e.x >> 11) & 1u; }
+  static __device__ __forceinline__ double time(const T& e, uint32_t sec_base) { return ev_time(sec_base + (e.x >> 12), e.y); }
+};
+
 __device__ __forceinline__ uint32_t tile_bin(const TileGeom& g, uint32_t xy, bool right) {
   const uint32_t x = xy & 0xffffu, y = xy >> 16;
   if (x >= (uint32_t)g.W || y >= (uint32_t)g.H) return (uint32_t)g.nbins - 1u;
@@ -720,17 +760,31 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
                                                    const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
                                                    uint32_t te, uint32_t nblk, uint32_t group,
                                                    uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm,
-                                                   const uint32_t* __restrict__ warp_xy) {
+                                                   const uint32_t* __restrict__ warp_xy,
+                                                   uint32_t* __restrict__ meta) {
   constexpr int UB = 4, UE = 4;
   __shared__ uint32_t h[UB][kTileMaxBins], run[kTileMaxBins];  // 40 KiB
+  __shared__ uint32_t s_range[3];
   const int nb = g.nbins;
+  for (int i = threadIdx.x; i < UB * kTileMaxBins; i += kTileHistThreads) (&h[0][0])[i] = 0;
   for (int i = threadIdx.x; i < nb; i += kTileHistThreads) run[i] = 0;
+  if (threadIdx.x == 0) {
+    s_range[0] = 0xffffffffu;
+    s_range[1] = 0;
+    s_range[2] = 0;
+  }
+  // the batch's range of seconds and whether every nsec fits 30 bits (in-sensor events): decides
+  // whether the partitioned records can take the 8-byte form (kTileMeta*, k_tile_scan)
+  uint32_t tmin = 0xffffffffu, tmax = 0, tor = 0;
   const uint32_t n = nL + nR;
   // (te <= 4 * kTileHistThreads: a thread has at most 4 events per scatter block.)  Up to 4 scatter
-  // blocks at a time: their records are requested together, counted into 4 LDS histograms between
-  // one pair of barriers, then the 4 rows of P are written from the running prefix.
+  // blocks per step: their records are requested together, counted into 4 LDS histograms, then the
+  // 4 rows of P are written from the running prefix (and the histograms cleared for the next step).
+  // The barriers order LDS traffic only (lds_barrier): the stores of P drain while the next step's
+  // records are on their way.  Two blocks per CU overlap each other's phases; holding the NEXT step's
+  // 16 records in registers as well was measured and is worse (84 VGPRs: one block per CU, 37 -> 49 us).
+  __syncthreads();
   for (uint32_t k0 = 0; k0 < group; k0 += UB) {
-    for (int i = threadIdx.x; i < UB * kTileMaxBins; i += kTileHistThreads) (&h[0][0])[i] = 0;
     uint32_t bins[UB][UE];
 #pragma unroll
     for (int u = 0; u < UB; u++) {
@@ -744,16 +798,20 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
           const bool right = i >= nL;
           const uint4 e = right ? evR[i - nL] : evL[i];  // (whole records: one coalesced 1 KiB request per wave)
           bins[u][j] = tile_bin(g, MC ? warp_xy[i] : e.x, right);
+          if (bins[u][j] != (uint32_t)nb - 1u) {
+            tmin = min(tmin, e.y);
+            tmax = max(tmax, e.y);
+            tor |= e.z;
+          }
         }
       }
     }
-    __syncthreads();
 #pragma unroll
     for (int u = 0; u < UB; u++)
 #pragma unroll
       for (int j = 0; j < UE; j++)
         if (bins[u][j] != 0xffffffffu) atomicAdd(&h[u][bins[u][j]], 1u);
-    __syncthreads();
+    lds_barrier();
     for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
       uint32_t r = run[i];
 #pragma unroll
@@ -763,44 +821,85 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
           Pm[(size_t)b * nb + i] = r;
           r += h[u][i];
         }
+        h[u][i] = 0;  // (for the next step)
       }
       run[i] = r;
     }
-    __syncthreads();
+    lds_barrier();
+  }
+  for (int i = threadIdx.x; i < nb; i += kTileHistThreads) Tm[(size_t)blockIdx.x * nb + i] = run[i];
+  // wave-level reduction first, then one LDS atomic per wave, one global per block
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    tmin = min(tmin, (uint32_t)__shfl_xor((int)tmin, o));
+    tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, o));
+    tor |= (uint32_t)__shfl_xor((int)tor, o);
+  }
+  if (lane_id() == 0) {
+    atomicMin(&s_range[0], tmin);
+    atomicMax(&s_range[1], tmax);
+    atomicOr(&s_range[2], tor);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nb; i += kTileHistThreads) Tm[(size_t)blockIdx.x * nb + i] = run[i];
+  if (threadIdx.x == 0) {
+    atomicMin(&meta[kTileMetaSecMin], s_range[0]);
+    atomicMax(&meta[kTileMetaSecMax], s_range[1]);
+    atomicOr(&meta[kTileMetaNsecOr], s_range[2]);
+  }
 }
 
-// exclusive prefix of the group totals over the groups, per bucket
-constexpr int kTileScanThreads = 256, kTileScanBins = 16;
+// exclusive prefix of the group totals over the groups, per bucket.  Thread = (one of the block's 64
+// consecutive buckets, one of 16 consecutive ranges of groups): a wave reads 64 consecutive words of a
+// row (the first version took 16 buckets per block: 64-byte pieces of every row, 13-15 us for 3 MB).
+constexpr int kTileScanBins = 64, kTileScanRanges = 16, kTileScanThreads = kTileScanBins * kTileScanRanges;
+constexpr int kTileScanPer = (kTileMaxGroups + kTileScanRanges - 1) / kTileScanRanges;  // groups per thread
 __global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* __restrict__ Tm, uint32_t nseg,
                                                                 int nb, uint32_t* __restrict__ Cm,
                                                                 uint32_t* __restrict__ totals,
-                                                                unsigned long long* n_rejected) {
-  // thread = (bucket of the block's 16, one of 16 consecutive ranges of groups)
-  constexpr int NR = kTileScanThreads / kTileScanBins;
-  __shared__ uint32_t part[NR][kTileScanBins];
+                                                                unsigned long long* n_rejected,
+                                                                uint32_t* __restrict__ meta, int force_wide) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // 8-byte partitioned records (kTileRec*) when the batch's seconds span < 2^20 and every nsec < 2^30
+    // (any ros::Time has nsec < 1e9); else the raw 16-byte records travel.  The accumulators are reset
+    // for the next batch's k_tile_hist.
+    const uint32_t mn = meta[kTileMetaSecMin], mx = meta[kTileMetaSecMax], orr = meta[kTileMetaNsecOr];
+    const bool compact = !force_wide && (mn > mx || (mx - mn < (1u << kTileRecSecBits) && (orr >> 30) == 0));
+    meta[kTileMetaCompact] = compact ? 1u : 0u;
+    meta[kTileMetaSecBase] = mn <= mx ? mn : 0u;
+    meta[kTileMetaSecMin] = 0xffffffffu;
+    meta[kTileMetaSecMax] = 0;
+    meta[kTileMetaNsecOr] = 0;
+  }
+  __shared__ uint32_t part[kTileScanRanges][kTileScanBins];
   const int bl = threadIdx.x % kTileScanBins, r = threadIdx.x / kTileScanBins;
   const int bin = blockIdx.x * kTileScanBins + bl;
   const bool ok = bin < nb;
-  const uint32_t per = (nseg + NR - 1) / NR;
-  const uint32_t s0 = min((uint32_t)r * per, nseg), s1 = min(s0 + per, nseg);
-  uint32_t sum = 0;
-  for (uint32_t sg = s0; sg < s1; sg++) sum += ok ? Tm[(size_t)sg * nb + bin] : 0u;
+  const uint32_t per = (nseg + kTileScanRanges - 1) / kTileScanRanges;
+  const uint32_t s0 = min((uint32_t)r * per, nseg);
+  uint32_t v[kTileScanPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kTileScanPer; k++) {  // (all of a thread's words requested together)
+    const uint32_t sg = s0 + (uint32_t)k;
+    v[k] = (ok && (uint32_t)k < per && sg < nseg) ? Tm[(size_t)sg * nb + bin] : 0u;
+    sum += v[k];
+  }
   part[r][bl] = sum;
   __syncthreads();
   uint32_t carry = 0, tot = 0;
-  for (int w = 0; w < NR; w++) {
-    const uint32_t v = part[w][bl];
-    if (w < r) carry += v;
-    tot += v;
+#pragma unroll
+  for (int w = 0; w < kTileScanRanges; w++) {
+    const uint32_t x = part[w][bl];
+    if (w < r) carry += x;
+    tot += x;
   }
   if (!ok) return;
-  for (uint32_t sg = s0; sg < s1; sg++) {
-    const uint32_t v = Tm[(size_t)sg * nb + bin];
-    Cm[(size_t)sg * nb + bin] = carry;
-    carry += v;
+#pragma unroll
+  for (int k = 0; k < kTileScanPer; k++) {
+    const uint32_t sg = s0 + (uint32_t)k;
+    if ((uint32_t)k < per && sg < nseg) {
+      Cm[(size_t)sg * nb + bin] = carry;
+      carry += v[k];
+    }
   }
   if (r == 0) {
     totals[bin] = tot;
@@ -819,66 +918,55 @@ void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const Eve
     launch_k(k_mc_warp, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g.W, g.H,
              *mc, warp_xy);
     launch_k(k_tile_hist<true>, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
-             te, nblk, group, sc.P, sc.T, (const uint32_t*)warp_xy);
+             te, nblk, group, sc.P, sc.T, (const uint32_t*)warp_xy, sc.meta);
   } else {
     launch_k(k_tile_hist<false>, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
-             te, nblk, group, sc.P, sc.T, (const uint32_t*)nullptr);
+             te, nblk, group, sc.P, sc.T, (const uint32_t*)nullptr, sc.meta);
   }
+  static const int force_wide = getenv("ESVIO_FE_WIDE_RECORDS") ? 1 : 0;  // (A/B and tests)
+  static_assert(kTileMaxGroups <= (uint32_t)(kTileScanPer * kTileScanRanges), "k_tile_scan covers every group");
   launch_k(k_tile_scan, dim3((g.nbins + kTileScanBins - 1) / kTileScanBins), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,
-           g.nbins, sc.C, sc.totals, n_rejected);
+           g.nbins, sc.C, sc.totals, n_rejected, sc.meta, force_wide);
 }
 
-// Stable partition by bucket: a block ranks its 256 * ROUNDS consecutive events stably (wave-level
-// match-any by ballots keeps stream order inside a bucket) and writes the 16 B records to their
-// final places.
+// Stable partition by bucket.  A scatter block of 4 waves owns TE = 256 * ROUNDS consecutive events;
+// wave w takes them in rounds of 64 consecutive events and ranks every event inside its (wave, bucket)
+// pair: rank = events of the bucket this wave has seen in earlier rounds + lanes BELOW this one that
+// hold the same bucket in this round — stream order is kept.  "Which lanes hold my bucket" used to be
+// a match-any by ballots over the 11 bucket bits: ~190 VALU instructions per round, and with 6.7 M
+// events that alone is 32 us of the whole device's issue slots (the kernel took 85-97 us with 3 waves
+// per SIMD; in-kernel timers: 20-29 of a block's 27-36 us in the ranking).  Now the lanes tell each
+// other through LDS: every lane ORs its bit into mask[wave][bucket] (one ds_or per half-wave — the
+// order in which the hardware applies them does not matter, OR commutes), reads the word back (the
+// LDS executes a wave's instructions in order) and has the set of lanes that share its bucket; the
+// lowest of them adds the group to the wave's running count and clears the mask again.  ~25
+// instructions per round.  32-bit masks, so a round is two half-rounds of 32 lanes.
+// LDS: masks 32 KiB + 16-bit running counts 16 KiB + bucket starts and bases 16 KiB: two blocks per
+// CU; the grid is 2 blocks per CU at most, each block walks over its scatter blocks (the masks are zero
+// again after every round, the bucket starts are computed once per block).
+constexpr int kTileScatterMaxGrid = 512;  // (<= 2 resident blocks per CU: ~200 VGPRs with the prefetched records)
 template <int ROUNDS, bool MC>
 __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
     const uint4* __restrict__ evL, uint32_t nL, const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
-    uint32_t group, const uint32_t* __restrict__ Pm, const uint32_t* __restrict__ Cm,
+    uint32_t group, uint32_t nblk, const uint32_t* __restrict__ Pm, const uint32_t* __restrict__ Cm,
     const uint32_t* __restrict__ totals, uint4* __restrict__ part, uint32_t* __restrict__ tile_off,
-    uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ warp_xy) {
-  __shared__ uint32_t wave_cnt[4][kTileMaxBins];  // 32 KiB
-  __shared__ uint32_t bin_base[kTileMaxBins];     // 8 KiB
+    uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ warp_xy, const uint32_t* __restrict__ meta) {
+  // LDS, sized by the bucket count (nbp = nbins rounded up to 64): masks [4][nbp] u32 | bases [nbp] u32
+  // (first position of the current scatter block per bucket) | running counts [4][nbp] u16
+  // = 28 B per bucket: 52 KiB at 1841 buckets, three blocks per CU
+  extern __shared__ uint32_t scatter_lds[];
+  const int nb = g.nbins, nbp = (nb + 63) & ~63;
+  uint32_t* mask_s = scatter_lds;                       // [wave * nbp + bucket]
+  uint32_t* bin_base = scatter_lds + 4 * nbp;
+  uint16_t* cnt_s = (uint16_t*)(scatter_lds + 5 * nbp);  // [wave * nbp + bucket]
   __shared__ uint32_t wave_tot[4];
   constexpr int TE = kTileScatterThreads * ROUNDS;
   constexpr int KB = kTileMaxBins / kTileScatterThreads;  // bins per thread (8)
-  const int nb = g.nbins;
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  for (int i = threadIdx.x; i < 4 * kTileMaxBins; i += kTileScatterThreads) (&wave_cnt[0][0])[i] = 0;
-  __syncthreads();
-  const uint32_t tile = blockIdx.x;
   const uint32_t n = nL + nR;
-
-  uint4 rec[ROUNDS];
-  uint32_t rank[ROUNDS];
-  const uint32_t wbase = tile * TE + wave * (TE / 4);
-  const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int r = 0; r < ROUNDS; r++) {
-    const uint32_t i = wbase + r * 64 + lane;
-    rec[r] = i < nL ? evL[i] : (i < n ? evR[i - nL] : make_uint4(0xffffffffu, 0, 0, 0));
-    if (MC && i < n) rec[r].x = warp_xy[i];  // (the pixel k_tile_hist warped the event to)
-  }
-#pragma unroll
-  for (int r = 0; r < ROUNDS; r++) {
-    const uint32_t i = wbase + r * 64 + lane;
-    const bool ok = i < n;
-    const uint32_t d = tile_bin(g, rec[r].x, i >= nL);
-    // match-any on the bucket: lanes holding the same bucket, in lane (= stream) order
-    unsigned long long m = __ballot(ok);
-    for (int b = 0; b < g.bits; b++) {
-      const unsigned long long bal = __ballot((d >> b) & 1u);
-      m &= ((d >> b) & 1u) ? bal : ~bal;
-    }
-    const uint32_t before = __popcll(m & lt);
-    const uint32_t cnt = __popcll(m);
-    uint32_t base = 0;
-    if (ok) base = wave_cnt[wave][d];
-    rank[r] = base + before;
-    if (ok && before == 0) wave_cnt[wave][d] = base + cnt;  // one leader per bucket
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-  }
-  // exclusive scan of the bucket totals: thread t owns bins [t*KB, t*KB+KB)
+  for (int i = threadIdx.x; i < 4 * nbp; i += kTileScatterThreads) mask_s[i] = 0;
+  uint32_t bstart[KB];  // bucket offsets into `part` of buckets threadIdx.x + k * 256
+  // ---- once per block: exclusive scan of the bucket totals (thread t owns bins [t*KB, t*KB+KB))
   {
     uint32_t loc[KB], sum = 0;
 #pragma unroll
@@ -900,11 +988,11 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #pragma unroll
     for (int k = 0; k < KB; k++) {
       const int b = threadIdx.x * KB + k;
-      bin_base[b] = run;
-      if (tile == 0 && b <= nb) tile_off[b] = run;  // (b == nb: the total)
+      if (b < nbp) bin_base[b] = run;  // (transposed into bstart below)
+      if (blockIdx.x == 0 && b <= nb) tile_off[b] = run;  // (b == nb: the total)
       run += loc[k];
     }
-    if (tile == gridDim.x - 1) {
+    if (blockIdx.x == 0) {
       // the order k_tile_apply takes the buckets in: largest size class (floor(log2(events))) first,
       // so that a bucket with many times the average number of events starts at once and the
       // launch does not end with it (counting sort by class; the order inside a class is arbitrary)
@@ -933,27 +1021,133 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
         if (b < nt) tile_order[atomicAdd(&cls_cnt[loc[k] ? 32 - __clz(loc[k]) : 0], 1u)] = (uint32_t)b;
       }
     }
-  }
-  __syncthreads();
-  // first position of (this block, wave, bucket): bucket start + earlier groups + earlier blocks of
-  // the group + earlier waves of the block
-  const uint32_t* Prow = Pm + (size_t)tile * nb;
-  const uint32_t* Crow = Cm + (size_t)(tile / group) * nb;
-  for (int d = threadIdx.x; d < nb; d += kTileScatterThreads) {
-    uint32_t run = bin_base[d] + Crow[d] + Prow[d];
-    for (int w = 0; w < 4; w++) {
-      const uint32_t t = wave_cnt[w][d];
-      wave_cnt[w][d] = run;
-      run += t;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int d = threadIdx.x + k * kTileScatterThreads;
+      bstart[k] = d < nb ? bin_base[d] : 0u;
     }
   }
-  __syncthreads();
+  // ---- the block's scatter blocks.  Workgroups go to the 8 XCDs round-robin and each XCD has its own
+  // L2; the runs two consecutive scatter blocks write into a bucket are neighbours in memory (a few
+  // records each, less than a cache line), so neighbours should meet in ONE L2: XCD x takes the x-th
+  // contiguous eighth of the scatter blocks, its workgroups take them interleaved.
+  uint32_t t_first, t_end, t_step;
+  if (gridDim.x < 8) {
+    t_first = blockIdx.x;
+    t_end = nblk;
+    t_step = gridDim.x;
+  } else {
+    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, q = nblk >> 3, r = nblk & 7u;
+    t_step = (gridDim.x - x + 7u) >> 3;  // workgroups on this XCD
+    t_first = x * q + min(x, r) + j;
+    t_end = (x + 1u) * q + min(x + 1u, r);
+  }
+  const bool compact = meta[kTileMetaCompact] != 0;  // (uniform)
+  const uint32_t sec_base = meta[kTileMetaSecBase];
+  const int twsh = g.tw == 64 ? 6 : 5;
+  const uint32_t hl = (uint32_t)lane & 31u, hbit = 1u << hl, hlt = hbit - 1u;
+  // The records (and count-matrix rows) of the block's NEXT scatter block are requested while the
+  // current one is ranked and stored; the barriers inside the loop order LDS traffic only
+  // (lds_barrier), so nothing in it waits for HBM except the first use of a record.  (In-kernel
+  // timers before: 3.5-7 us of a scatter block's 11-23 us were the wait for its own loads at the first
+  // __syncthreads.)
+  uint4 nrec[ROUNDS];
+  uint32_t npc[KB];
+  auto request = [&](uint32_t tile) {
+    const uint32_t wb = tile * TE + wave * (TE / 4);
 #pragma unroll
-  for (int r = 0; r < ROUNDS; r++) {
-    const uint32_t i = wbase + r * 64 + lane;
-    if (i < n) {
+    for (int r = 0; r < ROUNDS; r++) {
+      const uint32_t i = wb + r * 64 + lane;
+      nrec[r] = i < nL ? evL[i] : (i < n ? evR[i - nL] : make_uint4(0xffffffffu, 0, 0, 0));
+      if (MC && i < n) nrec[r].x = warp_xy[i];  // (the pixel k_mc_warp warped the event to)
+    }
+    const uint32_t* Prow = Pm + (size_t)tile * nb;
+    const uint32_t* Crow = Cm + (size_t)(tile / group) * nb;
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int d = threadIdx.x + k * kTileScatterThreads;
+      npc[k] = d < nb ? Crow[d] + Prow[d] : 0u;
+    }
+  };
+  if (t_first < t_end) request(t_first);
+  __syncthreads();  // (the set-up above)
+  for (uint32_t tile = t_first; tile < t_end; tile += t_step) {
+    lds_barrier();  // (the previous scatter block's reads of cnt_s / bin_base)
+    for (int i = threadIdx.x; i < 2 * nbp; i += kTileScatterThreads) ((uint32_t*)cnt_s)[i] = 0;
+    uint4 rec[ROUNDS];
+    uint32_t dr[ROUNDS];  // bucket | rank inside (wave, bucket) << 16
+    uint32_t pc[KB];
+    const uint32_t wbase = tile * TE + wave * (TE / 4);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) rec[r] = nrec[r];
+#pragma unroll
+    for (int k = 0; k < KB; k++) pc[k] = npc[k];
+    if (tile + t_step < t_end) request(tile + t_step);
+    lds_barrier();  // cnt_s is zero
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+      const uint32_t i = wbase + r * 64 + lane;
+      const bool ok = i < n;
       const uint32_t d = tile_bin(g, rec[r].x, i >= nL);
-      part[wave_cnt[wave][d] + rank[r]] = rec[r];
+      uint32_t rank = 0;
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        if (ok && (lane >> 5) == half) {
+          uint32_t* mp = mask_s + wave * nbp + d;
+          uint16_t* cp = cnt_s + wave * nbp + d;
+          atomicOr(mp, hbit);     // (no return value: ds_or_b32; the LDS takes a wave's instructions in
+          const uint32_t m = *mp;  //  order: the read sees every lane's bit)
+          const uint32_t c0 = *cp;
+          rank = c0 + __popc(m & hlt);
+          if ((m & hlt) == 0) {  // the group's lowest lane: count it, clear the mask for the next round
+            *cp = (uint16_t)(c0 + __popc(m));
+            *mp = 0;
+          }
+        }
+        // (the other half's ds_or must be ISSUED after these writes — the LDS then performs them in that
+        // order; nothing has to wait for them)
+        __asm__ volatile("" ::: "memory");
+      }
+      dr[r] = d | (rank << 16);
+    }
+    lds_barrier();
+    // first position of (this block, wave, bucket): bucket start + earlier groups + earlier blocks of
+    // the group + earlier waves of the block
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+      const int d = threadIdx.x + k * kTileScatterThreads;
+      if (d < nb) {
+        bin_base[d] = bstart[k] + pc[k];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const uint32_t t = cnt_s[w * nbp + d];
+          cnt_s[w * nbp + d] = (uint16_t)acc;
+          acc += t;
+        }
+      }
+    }
+    lds_barrier();
+    if (compact) {
+      uint2* __restrict__ part2 = (uint2*)part;
+#pragma unroll
+      for (int r = 0; r < ROUNDS; r++) {
+        const uint32_t i = wbase + r * 64 + lane;
+        if (i < n) {
+          const uint32_t d = dr[r] & 0xffffu;
+          part2[bin_base[d] + cnt_s[wave * nbp + d] + (dr[r] >> 16)] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < ROUNDS; r++) {
+        const uint32_t i = wbase + r * 64 + lane;
+        if (i < n) {
+          const uint32_t d = dr[r] & 0xffffu;
+          part[bin_base[d] + cnt_s[wave * nbp + d] + (dr[r] >> 16)] = rec[r];
+        }
+      }
     }
   }
 }
@@ -964,10 +1158,12 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
   if (!n) return;
   const uint32_t nblk = tile_scatter_blocks(n), group = tile_hist_group(nblk);
   const bool big = tile_scatter_events_per_block(n) == 4096u;
+  const uint32_t grid = std::min<uint32_t>(nblk, kTileScatterMaxGrid);
+  const unsigned lds = (unsigned)(((g.nbins + 63) & ~63) * 28);
 #define ESVIO_TILE_SCATTER(R, M)                                                                          \
-  launch_k(k_tile_scatter<R, M>, dim3(nblk), dim3(kTileScatterThreads), 0, s, (const uint4*)evL, nL,      \
-           (const uint4*)evR, nR, g, group, (const uint32_t*)sc.P, (const uint32_t*)sc.C,                 \
-           (const uint32_t*)sc.totals, (uint4*)part, sc.tile_off, sc.tile_order, warp_xy)
+  launch_k(k_tile_scatter<R, M>, dim3(grid), dim3(kTileScatterThreads), lds, s, (const uint4*)evL, nL,    \
+           (const uint4*)evR, nR, g, group, nblk, (const uint32_t*)sc.P, (const uint32_t*)sc.C,           \
+           (const uint32_t*)sc.totals, (uint4*)part, sc.tile_off, sc.tile_order, warp_xy, (const uint32_t*)sc.meta)
   if (warp_xy) {
     if (big) ESVIO_TILE_SCATTER(16, true);
     else ESVIO_TILE_SCATTER(8, true);
@@ -990,11 +1186,12 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
 // kept as the largest passing position (LDS atomic max, any order) and turned into a time at the end.
 // Only touched pixels are written back.
 constexpr int kTileTurn = 4;
-template <int kTileApplyThreads, int kPixBits>
-__global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
-    const uint4* __restrict__ part, const uint32_t* __restrict__ tile_off,
-    const uint32_t* __restrict__ tile_order, TileGeom g, double2* __restrict__ L2, double2* __restrict__ S2,
-    double thr, uint8_t* __restrict__ arc_touched, int* __restrict__ err, uint32_t spin_limit) {
+template <int kTileApplyThreads, int kPixBits, bool COMPACT>
+__device__ __forceinline__ void tile_apply_body(
+    const void* __restrict__ part, const uint32_t* __restrict__ tile_off,
+    const uint32_t* __restrict__ tile_order, const TileGeom& g, double2* __restrict__ L2, double2* __restrict__ S2,
+    double thr, uint8_t* __restrict__ arc_touched, int* __restrict__ err, uint32_t spin_limit, uint32_t sec_base) {
+  typedef TileRec<COMPACT> Rec;
   // LDS (dynamic, sized by the tile): Ls[npx] double2 | Sidx[2 npx] (1 + position of the last
   // passing event) | touched[npx / 16] (one bit per (pixel, polarity))  = 24 B + 2 bits per pixel:
   // 12 KiB for 32x16, 48 KiB for 64x32
@@ -1013,6 +1210,15 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
   const int x0 = tx * g.tw, y0 = ty * g.th;
   const int twsh = g.tw == 64 ? 6 : 5;
   const size_t P = (size_t)g.W * g.H;
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  // (a wave's next turn is requested while it works on the current one; the first one together with
+  // the tile's planes)
+  typename Rec::T nxt[kTileTurn];
+#pragma unroll
+  for (int k = 0; k < kTileTurn; k++) {
+    const uint32_t i = beg + ((uint32_t)wave * kTileTurn + k) * 64u + (uint32_t)lane;
+    nxt[k] = Rec::load(part, i < end ? i : beg);
+  }
   for (int p = threadIdx.x; p < npx; p += kTileApplyThreads) {
     const int gx = x0 + (p & (g.tw - 1)), gy = y0 + (p >> twsh);
     Ls[p] = (gx < g.W && gy < g.H) ? L2[cam * P + (size_t)gy * g.W + gx] : make_double2(0, 0);
@@ -1022,38 +1228,29 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
   for (int i = threadIdx.x; i < npx / 16; i += kTileApplyThreads) touched[i] = 0;
   if (threadIdx.x == 0) s_done = 0;
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = lane_id();
   constexpr int NW = kTileApplyThreads / 64;
   const uint32_t nchunks = (end - beg + 63u) / 64u;
   const uint32_t nturns = (nchunks + kTileTurn - 1) / kTileTurn;
   const unsigned long long self = 1ull << lane, below = self - 1ull, above = ~(below | self);
   auto msb = [](unsigned long long m) { return 63 - __clzll((long long)m); };
-  // (a wave's next turn is requested while it works on the current one)
-  uint4 nxt[kTileTurn];
-#pragma unroll
-  for (int k = 0; k < kTileTurn; k++) {
-    const uint32_t i = beg + ((uint32_t)wave * kTileTurn + k) * 64u + (uint32_t)lane;
-    nxt[k] = part[i < end ? i : beg];
-  }
   for (uint32_t turn = wave; turn < nturns; turn += NW) {
     uint32_t pixk[kTileTurn];
     double tk[kTileTurn], ts_in[kTileTurn], to_in[kTileTurn];
     uint32_t flg[kTileTurn];  // 1 valid, 2 polarity, 4 has same-polarity predecessor in the chunk, 8 other, 16 last
-    uint4 cur[kTileTurn];
+    typename Rec::T cur[kTileTurn];
 #pragma unroll
     for (int k = 0; k < kTileTurn; k++) {
       cur[k] = nxt[k];
       const uint32_t i = beg + ((turn + NW) * kTileTurn + k) * 64u + (uint32_t)lane;
-      nxt[k] = part[i < end ? i : beg];
+      nxt[k] = Rec::load(part, i < end ? i : beg);
     }
 #pragma unroll
     for (int k = 0; k < kTileTurn; k++) {
       const uint32_t i = beg + (turn * kTileTurn + k) * 64u + (uint32_t)lane;
       const bool valid = i < end;
-      const uint4 e = cur[k];
-      const uint32_t pix = (((e.x >> 16) - (uint32_t)y0) << twsh) + ((e.x & 0xffffu) - (uint32_t)x0);
-      const bool pol = (e.w & 0xffu) != 0;
-      const double t = ev_time(e.y, e.z);
+      const uint32_t pix = Rec::pix(cur[k], x0, y0, twsh);
+      const bool pol = Rec::pol(cur[k]);
+      const double t = Rec::time(cur[k], sec_base);
       unsigned long long m = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < kPixBits; b++) {
@@ -1115,9 +1312,29 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
     }
   }
   __syncthreads();
-  for (int p = threadIdx.x; p < npx; p += kTileApplyThreads) {
-    const uint32_t tb = (touched[p >> 4] >> (2 * (p & 15))) & 3u;
-    if (!tb) continue;
+  // write-back of the touched pixels.  The records of the last passing events (for their times) of all
+  // of a thread's pixels are requested together (a loop with a run-time bound fetched them one pixel
+  // per round trip), and S is written per polarity: nothing is read from the planes here.
+  constexpr int kPer = kTileMaxPx / kTileApplyThreads;  // pixels per thread, at most
+  typename Rec::T r0[kPer], r1[kPer];
+  uint32_t sb[kPer];  // touched bits | (has S[0]) << 2 | (has S[1]) << 3
+#pragma unroll
+  for (int q = 0; q < kPer; q++) {
+    const int p = threadIdx.x + q * kTileApplyThreads;
+    sb[q] = 0;
+    if (p < npx) {
+      const uint32_t tb = (touched[p >> 4] >> (2 * (p & 15))) & 3u;
+      const uint32_t s0 = Sidx[2 * p], s1 = Sidx[2 * p + 1];
+      sb[q] = tb | (tb && s0 ? 4u : 0u) | (tb && s1 ? 8u : 0u);
+      r0[q] = Rec::load(part, (sb[q] & 4u) ? beg + s0 - 1u : beg);
+      r1[q] = Rec::load(part, (sb[q] & 8u) ? beg + s1 - 1u : beg);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kPer; q++) {
+    const int p = threadIdx.x + q * kTileApplyThreads;
+    const uint32_t tb = sb[q] & 3u;
+    if (p >= npx || !tb) continue;
     const int gx = x0 + (p & (g.tw - 1)), gy = y0 + (p >> twsh);
     const size_t k = cam * P + (size_t)gy * g.W + gx;
     L2[k] = Ls[p];
@@ -1126,20 +1343,24 @@ __global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
     // store per event
     if (arc_touched && cam == 0)
       ((uint16_t*)arc_touched)[k] = (uint16_t)((tb & 1u) | ((tb & 2u) << 7));
-    const uint32_t s0 = Sidx[2 * p], s1 = Sidx[2 * p + 1];
-    if (s0 | s1) {
-      double2 Sv = S2[k];
-      if (s0) {
-        const uint4 e = part[beg + s0 - 1u];
-        Sv.x = ev_time(e.y, e.z);
-      }
-      if (s1) {
-        const uint4 e = part[beg + s1 - 1u];
-        Sv.y = ev_time(e.y, e.z);
-      }
-      S2[k] = Sv;
-    }
+    if (sb[q] & 4u) ((double*)&S2[k])[0] = Rec::time(r0[q], sec_base);
+    if (sb[q] & 8u) ((double*)&S2[k])[1] = Rec::time(r1[q], sec_base);
   }
+}
+
+template <int kTileApplyThreads, int kPixBits>
+__global__ __launch_bounds__(kTileApplyThreads) void k_tile_apply(
+    const uint4* __restrict__ part, const uint32_t* __restrict__ tile_off,
+    const uint32_t* __restrict__ tile_order, TileGeom g, double2* __restrict__ L2, double2* __restrict__ S2,
+    double thr, uint8_t* __restrict__ arc_touched, int* __restrict__ err, uint32_t spin_limit,
+    const uint32_t* __restrict__ meta) {
+  // (the record format of this batch's partition, decided by k_tile_scan: uniform)
+  if (meta[kTileMetaCompact])
+    tile_apply_body<kTileApplyThreads, kPixBits, true>(part, tile_off, tile_order, g, L2, S2, thr, arc_touched, err,
+                                                       spin_limit, meta[kTileMetaSecBase]);
+  else
+    tile_apply_body<kTileApplyThreads, kPixBits, false>(part, tile_off, tile_order, g, L2, S2, thr, arc_touched, err,
+                                                        spin_limit, 0u);
 }
 
 void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const TileGeom& g, const TileScratch& sc,
@@ -1154,7 +1375,7 @@ void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const Ti
 #define ESVIO_TILE_APPLY(T, B)                                                                            \
   launch_k(k_tile_apply<T, B>, dim3(2 * g.nt_cam), dim3(T), lds, s, (const uint4*)part,                  \
            (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold,     \
-           arc_touched, err, spin_limit)
+           arc_touched, err, spin_limit, (const uint32_t*)sc.meta)
   static const int force_threads = getenv("ESVIO_FE_APPLY_THREADS") ? atoi(getenv("ESVIO_FE_APPLY_THREADS")) : 0;
   const int threads = force_threads ? force_threads : (big ? 512 : 256);
 #define ESVIO_TILE_APPLY_B(B)                     \

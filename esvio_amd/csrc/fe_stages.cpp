@@ -201,8 +201,12 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
     c->tile_cap = 0;
     if (int rc = dev_alloc(c, &c->d_tile, need)) return rc;
     c->tile_cap = need;
+    // the record-format accumulators (kTileMeta*) live in the 32 free words behind tile_order
+    HIPCHK(c, hipMemsetAsync(c->d_tile + 3 * kTileMaxBins + 32, 0, 32 * 4, cur_stream(c)));
+    HIPCHK(c, hipMemsetAsync(c->d_tile + 3 * kTileMaxBins + 32 + kTileMetaSecMin, 0xff, 4, cur_stream(c)));
   }
   TileScratch sc;
+  sc.meta = c->d_tile + 3 * kTileMaxBins + 32;
   sc.totals = c->d_tile;
   sc.tile_off = c->d_tile + kTileMaxBins;
   sc.tile_order = c->d_tile + 2 * kTileMaxBins + 32;

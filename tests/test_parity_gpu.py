@@ -130,6 +130,47 @@ def test_sae_segment_lengths_around_the_wave_path(oracle, path, monkeypatch):
     ft.close()
 
 
+@pytest.mark.parametrize("case", ["span_below", "span_at", "span_above", "big_nsec", "forced_wide", "reversed"])
+def test_sae_partition_record_formats(oracle, case, monkeypatch):
+    """the tiled update partitions 8-byte records (tile-local pixel, polarity, seconds relative to the
+    batch's smallest, nsec) when the batch's seconds span less than 2^20 and every nsec fits 30 bits,
+    else the raw 16-byte records: planes bit-exact on both sides of the rule, with the smallest second
+    not at the start of the stream, with nsec words no ros::Time would hold, and with the wide form
+    forced (ESVIO_FE_WIDE_RECORDS=1)"""
+    if case == "forced_wide":
+        monkeypatch.setenv("ESVIO_FE_WIDE_RECORDS", "1")
+    W, H = 346, 260
+    rng = np.random.default_rng(77)
+    n = 60000
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    for b in range(2):
+        ev = np.zeros(n, EVENT_DTYPE)
+        ev["x"] = rng.integers(0, W, n)
+        ev["y"] = rng.integers(0, H, n)
+        ev["x"][:4000] = rng.integers(0, 8, 4000)          # hot pixels: many events per (pixel, polarity)
+        ev["y"][:4000] = rng.integers(0, 8, 4000)
+        ev["polarity"] = rng.integers(0, 2, n)
+        base = 5000 + 7 * b
+        span = {"span_below": (1 << 20) - 1, "span_at": 1 << 20, "span_above": (1 << 21) + 5}.get(case, 3)
+        sec = base + np.sort(rng.integers(0, span + 1, n))
+        sec[0], sec[-1] = base, base + span                 # the exact span
+        if case == "reversed":
+            sec = sec[::-1].copy()                           # the smallest second comes last
+        ev["sec"] = sec
+        ev["nsec"] = rng.integers(0, 1_000_000_000, n)
+        if case == "big_nsec":
+            ev["nsec"][::97] = 0xC0000000 + rng.integers(0, 1000, len(ev["nsec"][::97]))
+        perm = rng.permutation(n)[:n // 2]
+        L, R = ev, ev[np.sort(perm)].copy()
+        assert ft.detector.createSAE_stereo(L, R) == 0
+        det.create_sae(0, L)
+        det.create_sae(1, R)
+        for cam in (0, 1):
+            _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+    ft.close()
+
+
 def test_time_surface_edge_cases(oracle):
     W, H = 346, 260
     ft = _mk(W, H)
