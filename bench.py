@@ -324,8 +324,21 @@ def main():
         pub_flags.append(fc.pub_this_frame(b[4]))
         if pub_flags[-1]:
             fc.published()
+    helper_spin_us = None
     if args.host_threads <= 0:
-        args.host_threads = max(1, min(8, total_cpus // (2 * max(world, 1))))
+        share = total_cpus / max(world, 1)  # CPUs this rank can count on
+        if share >= 4:  # room for spinning helpers: they never sleep while frames keep coming
+            args.host_threads = max(1, min(8, int(share) // 2))
+        else:
+            # a small share (8 ranks on a 16-CPU quota: 2 each): never more threads than CPUs — a helper
+            # that loses its CPU stalls the job for a scheduler quantum (measured on 2 CPUs: 4 threads
+            # 0.3-4.5 ms per step, 2 threads 0.133, 1 thread 0.165) — and helpers that block between jobs
+            # (30 us of idle spin; the wake-up at the start of a published frame's call has them back
+            # before the RANSAC begins), so that they do not burn the quota while idle
+            args.host_threads = max(1, int(share))
+            helper_spin_us = 30
+    if helper_spin_us is not None:
+        os.environ["ESVIO_FE_HELPER_SPIN_US"] = str(helper_spin_us)
 
     def motion_of(mod, i):
         """the Motion_correction_value of batch i (--mc 1): header stamp = the batch's last event, a
@@ -664,6 +677,7 @@ def main():
                 "pipelined_next_batch": bool(pipeline),
                 "lazy_new_corner_stereo": bool(lazy),
                 "host_threads": int(max(1, args.host_threads)),
+                "helper_idle_spin_us": int(os.environ.get("ESVIO_FE_HELPER_SPIN_US", "2000")),
                 "batches_announced_ahead": int(args.ahead) if pipeline else 0,
                 "track_exchange": ("library (ncclAllGather on the handle's communicator)" if comm_id is not None else
                                    "torch.distributed all_gather_into_tensor" if exch is not None else "none"),

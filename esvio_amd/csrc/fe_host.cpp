@@ -327,7 +327,10 @@ void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
 // made-up rows use the first draw of the sign vector (the same for every system); a lane that
 // would need OpenCV's retry (a zero singular value or a vanished projection) makes the function
 // return false and the caller does those systems with the scalar routine.
-constexpr int kLanes = 8;
+#ifndef ESVIO_RANSAC_LANES
+#define ESVIO_RANSAC_LANES 8
+#endif
+constexpr int kLanes = ESVIO_RANSAC_LANES;
 
 ESVIO_SIMD_CLONES
 bool epipolar_nullspace_lanes(const double (*A)[7][9], double (*f1)[9], double (*f2)[9]) {
@@ -875,6 +878,12 @@ struct RansacPool {
   uint64_t wake_seq = 0;  // (under mu)
   std::atomic<int> sleepers{0};
   std::atomic<bool> quit{false};
+  // how long an idle helper keeps polling before it blocks (ESVIO_FE_HELPER_SPIN_US; default
+  // kIdleSpinUs: longer than the gap between two published frames, so helpers never sleep while a
+  // tracker is busy).  With more threads than CPUs (N ranks sharing a small quota) a few tens of
+  // microseconds is right: the helpers block between jobs and the wake-up at the start of a
+  // published frame's call (ransac_pool_wake) has them back before the RANSAC begins.
+  int idle_spin_us = kIdleSpinUs;
   alignas(64) std::atomic<uint32_t> epoch{0};  // odd while a job is open; job (epoch >> 1) & 1
   RansacJob job[2];
   // helpers are kept on the cores that share the caller's L3 (one CCD): an iteration is ~0.5 us of
@@ -896,7 +905,7 @@ struct RansacPool {
       if (!(e & 1) || e == seen) {
         cpu_relax();
         if ((++spins & 1023) == 0 &&
-            std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(kIdleSpinUs)) {
+            std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(idle_spin_us)) {
           std::unique_lock<std::mutex> lk(mu);
           const uint64_t my = wake_seq;
           sleepers.fetch_add(1, std::memory_order_acq_rel);
@@ -978,8 +987,14 @@ void RansacPool::pin_near_caller() {
   near_of = cpu;
   l3_cpus = l3;
   near_cpus.clear();
+  // only CPUs this process may run on (N ranks on one node: bench.py gives every rank its own block of
+  // cores; a helper pinned to the whole L3 domain would sit on the neighbours' cores)
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  const bool have_allowed = sched_getaffinity(0, sizeof allowed, &allowed) == 0;
   std::vector<int> primary;  // one logical CPU per physical core of the domain, caller's core left out
   for (int v : l3) {
+    if (have_allowed && (v >= CPU_SETSIZE || !CPU_ISSET(v, &allowed))) continue;
     bool mine = v == cpu;
     for (int w : self) mine = mine || v == w;
     if (mine) continue;
@@ -1019,6 +1034,7 @@ RansacPool* ransac_pool_alloc() {
 RansacPool* ransac_pool_create(int helpers) {
   if (helpers <= 0) return nullptr;
   RansacPool* p = ransac_pool_alloc();
+  if (const char* v = getenv("ESVIO_FE_HELPER_SPIN_US")) p->idle_spin_us = std::max(0, atoi(v));
   for (int i = 0; i < helpers; i++) p->th.emplace_back([p] { p->helper(); });
   p->pin_near_caller();
   return p;
