@@ -317,6 +317,10 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       for (PyrStore& ps : rb)
         if ((rc = pyr_alloc(c, ps, c->W, c->H, 0))) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_lut, (size_t)2 * 64 * 256))) return bail(rc);
+    // (CLAHE scratch: d_lut, d_minmax and d_eq_tmp are single buffers shared by the main stream and the
+    // prefetch stream; rendering on one is ordered behind the other's through ev_planes_free /
+    // ev_lane_done, like the SAE planes they are derived from)
+    if ((rc = dev_alloc(c, &c->d_eq_tmp, (size_t)2 * c->P))) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_minmax, 4))) return bail(rc);
   }
   c->h_pin_bytes = pin_bytes(*cfg);
@@ -380,6 +384,7 @@ int esvio_fe_create_sae_stereo(esvio_fe_handle c, const esvio_fe_event* left, si
   if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
   if (!c->inflight.empty()) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
   HIPCHK(c, hipSetDevice(c->dev));
+  c->ext_sae_pending = false;  // (the planes move on: a committed time-sliced batch is not "the next frame's" any more)
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, cur_stream(c)));
@@ -401,6 +406,7 @@ int esvio_fe_create_sae_stereo_mc(esvio_fe_handle c, const esvio_fe_event* left,
   if (!c->inflight.empty()) return fail(c, ESVIO_FE_EINVAL, "a prefetched batch is pending");
   HIPCHK(c, hipSetDevice(c->dev));
   const McParams mc = make_mc_params(motion);
+  c->ext_sae_pending = false;
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_rejected, 0, 8, cur_stream(c)));
@@ -462,6 +468,8 @@ int esvio_fe_sae_slice_last(esvio_fe_handle c, const esvio_fe_event* left, size_
     return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update cannot be mixed with esvio_fe_set_next_batch");
   HIPCHK(c, hipSetDevice(c->dev));
   if (int rc = slice_scratch(c)) return rc;
+  // (a rank that never tracks: the previous batch's commit simply IS its planes by now)
+  c->ext_sae_pending = false;
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
   // L[p] is overwritten by every event whatever the carried-in state is (event_detector.cc:158), so
@@ -480,6 +488,8 @@ int esvio_fe_sae_slice_apply(esvio_fe_handle c, const esvio_fe_event* left, size
   if (!c || !s_out || n_before < 0 || (n_before && !last_before) || (nL && !left) || (nR && !right))
     return ESVIO_FE_EINVAL;
   if (nL + nR >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  if (!c->inflight.empty() || !c->announced.empty())
+    return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update cannot be mixed with esvio_fe_set_next_batch");
   HIPCHK(c, hipSetDevice(c->dev));
   if (int rc = slice_scratch(c)) return rc;
   const size_t nd = (size_t)4 * c->P;
@@ -500,6 +510,8 @@ int esvio_fe_sae_slice_apply(esvio_fe_handle c, const esvio_fe_event* left, size
 int esvio_fe_sae_slice_commit(esvio_fe_handle c, const double* last_all, const double* s_all, int n_slices,
                               int space) {
   if (!c || n_slices < 1 || !last_all || !s_all) return ESVIO_FE_EINVAL;
+  if (!c->inflight.empty() || !c->announced.empty())
+    return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update cannot be mixed with esvio_fe_set_next_batch");
   HIPCHK(c, hipSetDevice(c->dev));
   const size_t nd = (size_t)4 * c->P;
   for (int pass = 0; pass < 2; pass++) {  // (one staging buffer: L first, then S)
@@ -920,6 +932,12 @@ int esvio_fe_exchange_tracks(esvio_fe_handle c, void* nccl_comm, int world, floa
   nccl_allgather_fn all_gather = rccl_all_gather();
   if (!all_gather) return fail(c, ESVIO_FE_ENOTIMPL, "librccl.so not found (dlopen): %s", dlerror());
   const size_t cnt = (size_t)2 * std::max(c->cfg.max_cnt, 1) * 8;
+  // the send / receive areas are shared with the asynchronous exchange of the handle's own
+  // communicator: whatever that one still has packed or in flight goes first and is waited for
+  if (int rc = exchange_flush(c)) return rc;
+  if (c->x_pending) HIPCHK(c, hipEventSynchronize(c->x_done));
+  if (c->x_pending && (size_t)world * cnt > c->x_recv_cap)
+    c->x_pending = false;  // (its gathered block is dropped with the buffer that is about to grow)
   if (int rc = exchange_buffers(c, world)) return rc;
   if (int rc = esvio_fe_pack_track_records(c, c->x_pin, nullptr)) return rc;
   hipStream_t st = c->stream;

@@ -368,8 +368,6 @@ void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int 
   if (fused_eq) {
     // time surfaces -> raw; CLAHE LUTs; CLAHE output -> a linear scratch pair (no in-place normalise:
     // the fused kernel's blocks read their neighbours' pixels); normalise + pyramid levels; borders + Scharr
-    if (!c->d_eq_tmp)
-      if (dev_alloc(c, &c->d_eq_tmp, (size_t)2 * c->P) != 0) return;
     const PyrDesc& rl = c->raw[rawbuf][0].d;
     const PyrDesc& rr = c->raw[rawbuf][1].d;
     render_ts(c, t_sync, rl.img[0], rr.img[0], 2, c->S2);

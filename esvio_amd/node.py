@@ -13,10 +13,26 @@ import numpy as np
 def c_round(x):
     """C `round()` (half away from zero), which the node's frequency control uses (node:177);
     Python's round() is half-to-even and differs when pub_count/dt lands on x.5 with even x."""
-    r = math.floor(x)
-    if x - r >= 0.5:  # (x - floor(x) is exact in binary floating point)
+    a = abs(x)
+    r = math.floor(a)
+    if a - r >= 0.5:  # (a - floor(a) is exact in binary floating point; a + 0.5 is not)
         r += 1
-    return int(r)
+    return int(math.copysign(r, x))
+
+
+def c_rate(pub_count, dt):
+    """`1.0 * pub_count / dt` as C computes it (IEEE division: x/0 is +-inf, 0/0 is NaN)"""
+    dt = float(dt)
+    if dt == 0.0:
+        return math.nan if pub_count == 0 else math.copysign(math.inf, pub_count)
+    return 1.0 * pub_count / dt
+
+
+def rate_allows(rate, freq):
+    """`round(rate) <= FREQ` (node:177): false for inf and NaN — a message whose stamp equals
+    first_image_time (a duplicate stamp right after the first frame or after a frequency-control reset)
+    is simply not published, as in the reference and in tools/replay_node.cpp"""
+    return math.isfinite(rate) and c_round(rate) <= freq
 
 from .events import event_times
 
@@ -38,10 +54,8 @@ class FreqControl:
             self.first_image_time = msg_timestamp
             return False
         dt = msg_timestamp - self.first_image_time
-        if dt <= 0:
-            return False
-        rate = 1.0 * self.pub_count / dt
-        if c_round(rate) <= self.FREQ:
+        rate = c_rate(self.pub_count, dt)
+        if rate_allows(rate, self.FREQ):
             if abs(rate - self.FREQ) < 0.01 * self.FREQ:
                 self.first_image_time = msg_timestamp
                 self.pub_count = 0
@@ -57,9 +71,7 @@ class FreqControl:
         if self.first_image_time is None:
             return False
         dt = msg_timestamp - self.first_image_time
-        if dt <= 0:
-            return False
-        return c_round(1.0 * self.pub_count / dt) <= self.FREQ
+        return rate_allows(c_rate(self.pub_count, dt), self.FREQ)
 
 
 def pack_point_cloud(ft):
@@ -192,8 +204,8 @@ class StereoEventTrackerNode:
                 self.trackerData.reset()
             return None
         self.last_image_time = msg_timestamp
-        rate = 1.0 * self.pub_count / (msg_timestamp - self.first_image_time)
-        if c_round(rate) <= self.FREQ:  # node:177-188
+        rate = c_rate(self.pub_count, msg_timestamp - self.first_image_time)
+        if rate_allows(rate, self.FREQ):  # node:177-188
             pub = True
             if abs(rate - self.FREQ) < 0.01 * self.FREQ:
                 self.first_image_time = msg_timestamp
@@ -250,8 +262,8 @@ class StereoImageTrackerNode:
             self.restart_flag = True
             return None
         self.last_image_time = msg_timestamp
-        rate = 1.0 * self.pub_count / (msg_timestamp - self.first_image_time)
-        if c_round(rate) <= self.FREQ:  # :81-91
+        rate = c_rate(self.pub_count, msg_timestamp - self.first_image_time)
+        if rate_allows(rate, self.FREQ):  # :81-91
             pub = True
             if abs(rate - self.FREQ) < 0.01 * self.FREQ:
                 self.first_image_time = msg_timestamp

@@ -81,3 +81,55 @@ def test_c5_track_event_at_full_rate(oracle, replay):
     assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1))
     assert len(ft.ids) > 200 and len(ft.ids_right) > 100
     ft.close()
+
+
+def test_c5_named_split_eight_time_slices(oracle):
+    """BASELINE C5's own split at its own size: ONE 1280x720 stream at 100 Mev/s per camera (3.3 M events
+    per camera per batch), every batch cut into 8 time slices, one per handle (8 handles in one process
+    — this box has one GPU — exchanging DEVICE plane sets, what 8 ranks all-gather over RCCL):
+    esvio_fe_sae_slice_last / _apply / _commit; every handle's planes after every batch, and the tracks
+    handle 0 derives from them, equal the oracle's"""
+    import ctypes as C
+    from esvio_amd.dist import time_slice
+    N = 8
+    batches = _stream(2, seed=23)
+    kw = dict(max_cnt=500, min_dist=10, f_ransac=1)
+    fts = [FE.FeatureTracker(FE.make_config(W, H, **kw)) for _ in range(N)]
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    nd = fts[0].sae_plane_doubles()
+    assert nd == 4 * W * H
+    lib = FE.load_library()
+    bufs = []
+    for _ in range(2):  # all slices' "last" sets, all slices' "S" sets
+        p = C.c_void_p()
+        assert lib.esvio_fe_mem_alloc(FE.DEVICE, N * nd * 8, C.byref(p)) == 0
+        bufs.append(p)
+    last_all, s_all = bufs[0].value, bufs[1].value
+    for b, (L, R) in enumerate(batches):
+        assert len(L) >= 3_000_000 and len(R) >= 3_000_000
+        pub = b == 0
+        t = event_times(L)[-1]
+        r = tr.track_event(t, L, R, pub)
+        det = tr.detector()
+        cuts = [(L[slice(*time_slice(len(L), N, k))], R[slice(*time_slice(len(R), N, k))]) for k in range(N)]
+        for k, ft in enumerate(fts):
+            ft.sae_slice_last(cuts[k][0], cuts[k][1], (last_all + 8 * k * nd, 1))
+        for k, ft in enumerate(fts):
+            ft.sae_slice_apply(cuts[k][0], cuts[k][1], (last_all, k), k, (s_all + 8 * k * nd, 1))
+        for k, ft in enumerate(fts):
+            ft.sae_slice_commit((last_all, N), (s_all, N), N)
+            for cam in (0, 1):
+                for x, y, name in zip(ft.detector.get_sae(cam), det.get_sae(cam), ("L0", "L1", "S0", "S1")):
+                    assert np.array_equal(x, y), (b, k, cam, name, int((x != y).sum()))
+        # handle 0 (the rank the host feeds) runs the rest of trackEvent on the composed planes
+        fts[0].trackEvent(t, L, R, pub)
+        assert np.array_equal(fts[0].ids, r.ids) and np.array_equal(fts[0].ids_right, r.ids_right), b
+        assert np.array_equal(fts[0].cur_pts.view(np.uint32), r.cur_pts.view(np.uint32)), b
+        assert np.array_equal(fts[0].gettimesurface(0), tr.time_surface(0))
+        # (the other handles took the commit as their update of the planes: drop the one-shot marker the
+        # way a rank that never tracks does — its next slice_last starts from the committed planes)
+    assert len(fts[0].ids) > 200
+    for ft in fts:
+        ft.close()
+    for p in bufs:
+        lib.esvio_fe_mem_free(FE.DEVICE, p)

@@ -278,3 +278,18 @@ def test_handle_stereo_image_flow():
     assert node.handle(img, img, 7.53) is None and len(tr.calls) == n      # treated as first frame
     node.handle(img, img, 7.56)
     assert len(tr.calls) == n + 1
+
+
+def test_frequency_rule_at_a_duplicate_stamp_follows_c():
+    """a message whose stamp equals first_image_time (dt == 0): the reference computes inf or NaN,
+    `round(...) <= FREQ` is false and the frame is not published — no exception, like
+    tools/replay_node.cpp; negative halves round away from zero like C's round()"""
+    from esvio_amd.node import FreqControl, c_rate, c_round, rate_allows
+    assert [c_round(v) for v in (-0.5, -1.5, -2.4, 2.5, 0.49999999999999994)] == [-1, -2, -2, 3, 0]
+    assert not rate_allows(c_rate(3, 0.0), 15) and not rate_allows(c_rate(0, 0.0), 15)
+    assert rate_allows(c_rate(3, np.float64(0.25)), 15) and not rate_allows(c_rate(30, np.float64(0.25)), 15)
+    fc = FreqControl(15)
+    assert fc.pub_this_frame(10.0) is False        # first frame
+    assert fc.pub_this_frame(10.0) is False        # duplicate stamp: dt == 0
+    assert fc.peek(10.0) is False
+    assert fc.pub_this_frame(10.5) is True
