@@ -56,22 +56,30 @@ ESVIO_HD M3f mc_inverse(const M3f& M) {
 
 // denom.partialPivLu().solve(numer)
 ESVIO_HD M3f mc_lu_solve(M3f LU, M3f X) {
+#pragma unroll
   for (int k = 0; k < 3; k++) {
     int piv = k;
     float best = fabsf(LU.m[k][k]);
+#pragma unroll
     for (int i = k + 1; i < 3; i++)
       if (fabsf(LU.m[i][k]) > best) {
         best = fabsf(LU.m[i][k]);
         piv = i;
       }
-    if (piv != k)
-      for (int j = 0; j < 3; j++) {
-        float t = LU.m[k][j];
-        LU.m[k][j] = LU.m[piv][j];
-        LU.m[piv][j] = t;
-        t = X.m[k][j];
-        X.m[k][j] = X.m[piv][j];
-        X.m[piv][j] = t;
+    // row k <-> row piv, written with compile-time row numbers (a run-time row index would put the
+    // matrices into scratch / LDS on the device: 30 us for the 0.33 M events of a C3 batch)
+#pragma unroll
+    for (int r = k + 1; r < 3; r++)
+      if (piv == r) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          float t = LU.m[k][j];
+          LU.m[k][j] = LU.m[r][j];
+          LU.m[r][j] = t;
+          t = X.m[k][j];
+          X.m[k][j] = X.m[r][j];
+          X.m[r][j] = t;
+        }
       }
     if (best != 0.0f)
       for (int i = k + 1; i < 3; i++) LU.m[i][k] /= LU.m[k][k];
