@@ -299,13 +299,59 @@ int finalize_pending(esvio_fe_ctx* c) {
 }
 
 // ---------------------------------------------------------------- trackEvent
-int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* left, size_t nL,
-                     const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME,
-                     const esvio_fe_motion* motion) {
-  const esvio_fe_config& cfg = c->cfg;
-  const int M = cfg.max_cnt;
-  // ---- what can refuse the call comes first: a refused call leaves the handle as it was
-  auto same_motion = [&](const Batch& a) {  // (field by field: the struct has padding)
+// One call of FeatureTracker::trackEvent (feature_tracker.cpp:340-603), phase by phase:
+//   check()      what can refuse the call (a refused call leaves the handle as it was)
+//   take_batch() the batch's SAE update / images / pyramids: taken from the prefetch stream, or enqueued now
+//   temporal()   :405-440  temporal LK forward + backward (speculative / chained / plain launch), filters
+//   survivors_stereo()  the stereo LK of every temporal survivor, on its own stream (+ the next frame's
+//                speculative temporal LK on frames that publish nothing)
+//   publish()    :442-469  rejectWithF_event, Event_setMask, k_select, stereo LK of the new corners
+//   tails()      :463-603  new ids, undistortion / velocities, the right-camera tail, carried state
+// The members are what the phases share; the handle (c) holds what outlives the call.
+namespace {
+using clk = std::chrono::steady_clock;
+
+struct TrackCall {
+  esvio_fe_ctx* c;
+  const double time;
+  const esvio_fe_event *left, *right;
+  const size_t nL, nR;
+  const int space;
+  const bool PUB_THIS_FRAME;
+  const esvio_fe_motion* motion;
+  const int M;
+  Pin pin{};
+  const EventRec *dL = nullptr, *dR = nullptr;
+  bool first = false;
+  bool arc_done = false, arc_prefetched = false, arc_marked_main = false;
+  int arc_lane = 0;
+  bool main_reads_events = false;  // this call enqueues main-stream kernels that read the batch's events
+  // what THIS frame enqueues on the main stream that reads the SAE planes / raw time surfaces: its
+  // own SAE update + rendering unless prefetched, and Arc* unless that ran with the prefetch
+  bool main_reads_planes = false;
+  // the next frame's batch, if it is already in flight (two announced ahead), else once this
+  // frame's early_work has put it there
+  bool have_next = false, had_announced = false;
+  Inflight next_b;
+  bool early_done = false, defer_late = false;
+  bool use_spec = false, use_chain = false, chain_covers_next = false;
+  bool will_spec = false, detect = false;
+  int n_surv = 0, n_kept = 0;
+  clk::time_point tp;
+
+  TrackCall(esvio_fe_ctx* ctx, double t, const esvio_fe_event* l, size_t nl, const esvio_fe_event* r, size_t nr,
+            int sp, bool pub, const esvio_fe_motion* mo)
+      : c(ctx), time(t), left(l), right(r), nL(nl), nR(nr), space(sp), PUB_THIS_FRAME(pub), motion(mo),
+        M(ctx->cfg.max_cnt) {}
+
+  void lap(int i) {
+    if (!c->trace) return;
+    const auto now = clk::now();
+    c->phase_ms[PUB_THIS_FRAME ? 1 : 0][i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    tp = now;
+  }
+
+  bool same_motion(const Batch& a) const {  // (field by field: the struct has padding)
     if ((motion != nullptr) != a.has_motion) return false;
     if (!motion) return true;
     const esvio_fe_motion &x = *motion, &y = a.motion;
@@ -313,115 +359,107 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     for (int i = 0; i < 3; i++)
       eq = eq && x.v[i] == y.v[i] && x.v_pre[i] == y.v_pre[i] && x.accel[i] == y.accel[i] && x.omega[i] == y.omega[i];
     return eq;
-  };
-  if (c->inflight.empty() && !c->announced.empty()) {
-    // announced, but an earlier call left it where it was because its host events were still on
-    // their way to the device: it is needed now
-    const Batch& a = c->announced.front();
-    if (left == a.left && nL == a.nL && right == a.right && nR == a.nR && space == a.space) {
-      if (_cur_time != a.time || !same_motion(a))
-        return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
-      if (int rc = prefetch_next(c, true, true)) return rc;
-    }
   }
-  if (!c->inflight.empty()) {
-    const Inflight& b = c->inflight.front();
-    if (left != b.left || nL != b.nL || right != b.right || nR != b.nR || space != b.space ||
-        _cur_time != b.time || !same_motion(b))
-      return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
-    if (PUB_THIS_FRAME && !b.arc_done && c->inflight.size() > 1)
-      return fail(c, ESVIO_FE_EINVAL,
-                  "PUB hint was 0 for a published frame and a later batch is already applied to "
-                  "the SAE: with more than one batch announced the hint must be exact");
-  }
-  // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
-  // (lazy mode, pend_right) while this frame's kernels are enqueued
-  c->res_set ^= 1;
-  c->frame_no++;
-  Pin pin = pin_of(c, c->res_set);
-  if (PUB_THIS_FRAME && c->pool) host::ransac_pool_wake(c->pool);
-  c->cur_time = _cur_time;
-  using clk = std::chrono::steady_clock;
-  auto tp = clk::now();
-  auto lap = [&](int i) {
-    if (!c->trace) return;
-    auto now = clk::now();
-    c->phase_ms[PUB_THIS_FRAME ? 1 : 0][i] += std::chrono::duration<double, std::milli>(now - tp).count();
-    tp = now;
-  };
 
-  const EventRec *dL = nullptr, *dR = nullptr;
-  const bool first = !c->have_img;
-  bool arc_done = false, arc_prefetched = false, arc_marked_main = false;
-  int arc_lane = 0;
-  bool main_reads_events = false;  // this call enqueues main-stream kernels that read the batch's events
-  c->cur_stage = -1;
-  if (!c->inflight.empty()) {
-    // this batch was announced with esvio_fe_set_next_batch and its SAE update, images and
-    // pyramids were enqueued on the prefetch stream during an earlier call
-    const Inflight b = c->inflight.front();
-    c->inflight.pop_front();
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_done[b.lane], 0));
-    c->tr_lane = b.lane;
-    c->cur_stage = b.stage;
-    dL = b.dL;
-    dR = b.dR;
-    c->slot_curL = b.slotL;
-    c->slot_curR = b.slotR;
-    c->raw_cur = b.raw;
-    c->cur_prefetched = true;
-    if (b.arc_done) {  // candidates of this batch are in its own set
-      c->cand_cur = b.cand;
-      arc_lane = b.lane;
-      arc_done = arc_prefetched = true;
+  int check() {
+    if (c->inflight.empty() && !c->announced.empty()) {
+      // announced, but an earlier call left it where it was because its host events were still on
+      // their way to the device: it is needed now
+      const Batch& a = c->announced.front();
+      if (left == a.left && nL == a.nL && right == a.right && nR == a.nR && space == a.space) {
+        if (time != a.time || !same_motion(a))
+          return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
+        if (int rc = prefetch_next(c, true, true)) return rc;
+      }
     }
-  } else {
-    c->cur_prefetched = false;
-    main_reads_events = true;
-    if (space == ESVIO_FE_HOST && stager_enabled(c) && (nL + nR) * 16 >= (256u << 10)) {
-      // not announced: the helpers and this thread stage the chunks together, the DMA of chunk k runs
-      // under the memcpy of chunk k+1
-      if (int rc = stager_begin(c, left, nL, right, nR, 4, &c->cur_stage)) return rc;
-      if (int rc = stager_attach(c, c->cur_stage, nL, c->stream, &dL, &dR)) return rc;
-    } else if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) {
-      return rc;
+    if (!c->inflight.empty()) {
+      const Inflight& b = c->inflight.front();
+      if (left != b.left || nL != b.nL || right != b.right || nR != b.nR || space != b.space ||
+          time != b.time || !same_motion(b))
+        return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
+      if (PUB_THIS_FRAME && !b.arc_done && c->inflight.size() > 1)
+        return fail(c, ESVIO_FE_EINVAL,
+                    "PUB hint was 0 for a published frame and a later batch is already applied to "
+                    "the SAE: with more than one batch announced the hint must be exact");
     }
-    // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
-    if (c->ext_sae_pending) {
-      // esvio_fe_sae_slice_commit has put this batch into the planes already (its SAE update ran
-      // time-sliced over several GPUs); the events are still needed below for Arc*
-      if (motion) return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update has no motion-compensated form");
-      c->ext_sae_pending = false;
-    } else if (motion) {
-      const McParams mc = make_mc_params(motion);
-      if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
-    } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, nullptr, nullptr, nullptr,
-                                   PUB_THIS_FRAME ? c->cand_cur : -1, &arc_marked_main)) {
-      return rc;
-    }
-    // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; slot rotation replaces the
-    // cv::Mat header swaps of :390-403,:585.  Left slots 0..2: {prev, cur, free}.
-    int sl = 0;
-    while (!first && (sl == c->slot_prevL || sl == c->slot_curL)) sl++;
-    c->slot_curL = sl;
-    // camera split: the right image was imported into slot_curR by esvio_fe_import_image
-    if (!c->ext_right_pending) c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;
-    c->raw_cur = (c->raw_cur + 1) % kRightSlots;
-    if (c->ext_right_pending) {
-      render_lk_images(c, c->cur_time, 1, c->slot_curL, c->slot_curR, c->raw_cur);
-      PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[c->slot_curR].d};
-      pyr_build(c, cur2, 2);
-    } else {
-      render_and_build(c, c->cur_time, c->slot_curL, c->slot_curR, c->raw_cur);
-    }
-    c->ext_right_pending = false;
+    return 0;
   }
-  // the next frame's batch, if it is already in flight (two announced ahead), else once this
-  // frame's early_work has put it there
-  bool have_next = !c->inflight.empty();
-  Inflight next_b = have_next ? c->inflight.front() : Inflight();
-  const bool had_announced = !c->announced.empty();
-  auto next_batch = [&]() -> const Inflight* {
+
+  int take_batch() {
+    first = !c->have_img;
+    c->cur_stage = -1;
+    if (!c->inflight.empty()) {
+      // this batch was announced with esvio_fe_set_next_batch and its SAE update, images and
+      // pyramids were enqueued on the prefetch stream during an earlier call
+      const Inflight b = c->inflight.front();
+      c->inflight.pop_front();
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_done[b.lane], 0));
+      c->tr_lane = b.lane;
+      c->cur_stage = b.stage;
+      dL = b.dL;
+      dR = b.dR;
+      c->slot_curL = b.slotL;
+      c->slot_curR = b.slotR;
+      c->raw_cur = b.raw;
+      c->cur_prefetched = true;
+      if (b.arc_done) {  // candidates of this batch are in its own set
+        c->cand_cur = b.cand;
+        arc_lane = b.lane;
+        arc_done = arc_prefetched = true;
+      }
+    } else {
+      c->cur_prefetched = false;
+      main_reads_events = true;
+      if (space == ESVIO_FE_HOST && stager_enabled(c) && (nL + nR) * 16 >= (256u << 10)) {
+        // not announced: the helpers and this thread stage the chunks together, the DMA of group k runs
+        // under the memcpy of group k+1
+        if (int rc = stager_begin(c, left, nL, right, nR, 4, &c->cur_stage)) return rc;
+        if (int rc = stager_attach(c, c->cur_stage, nL, c->stream, &dL, &dR)) return rc;
+      } else if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) {
+        return rc;
+      }
+      // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
+      if (c->ext_sae_pending) {
+        // esvio_fe_sae_slice_commit has put this batch into the planes already (its SAE update ran
+        // time-sliced over several GPUs); the events are still needed below for Arc*
+        if (motion) return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update has no motion-compensated form");
+        c->ext_sae_pending = false;
+      } else if (motion) {
+        const McParams mc = make_mc_params(motion);
+        if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, &mc)) return rc;
+      } else if (int rc = sae_update(c, dL, (uint32_t)nL, dR, (uint32_t)nR, nullptr, nullptr, nullptr,
+                                     PUB_THIS_FRAME ? c->cand_cur : -1, &arc_marked_main)) {
+        return rc;
+      }
+      // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; slot rotation replaces the
+      // cv::Mat header swaps of :390-403,:585.  Left slots 0..2: {prev, cur, free}.
+      int sl = 0;
+      while (!first && (sl == c->slot_prevL || sl == c->slot_curL)) sl++;
+      c->slot_curL = sl;
+      // camera split: the right image was imported into slot_curR by esvio_fe_import_image
+      if (!c->ext_right_pending) c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;
+      c->raw_cur = (c->raw_cur + 1) % kRightSlots;
+      if (c->ext_right_pending) {
+        render_lk_images(c, c->cur_time, 1, c->slot_curL, c->slot_curR, c->raw_cur);
+        PyrDesc cur2[2] = {c->pyr[c->slot_curL].d, c->pyr[c->slot_curR].d};
+        pyr_build(c, cur2, 2);
+      } else {
+        render_and_build(c, c->cur_time, c->slot_curL, c->slot_curR, c->raw_cur);
+      }
+      c->ext_right_pending = false;
+    }
+    have_next = !c->inflight.empty();
+    next_b = have_next ? c->inflight.front() : Inflight();
+    had_announced = !c->announced.empty();
+    if (first) c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left = img_left (:391)
+    c->have_img = true;
+    main_reads_planes = !c->cur_prefetched;
+    c->cur_pts.clear();
+    c->cur_right_pts.clear();
+    return 0;
+  }
+
+  const Inflight* next_batch() {
     if (!have_next && had_announced) {
       if (!c->inflight.empty()) {
         next_b = c->inflight.front();
@@ -429,27 +467,14 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
       }
     }
     return have_next ? &next_b : nullptr;
-  };
-  if (first) c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left = img_left (:391)
-  c->have_img = true;
-  const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
-  const PyrDesc& curL = c->pyr[c->slot_curL].d;
-  const PyrDesc& curR = c->pyr[c->slot_curR].d;
-  // what THIS frame enqueues on the main stream that reads the SAE planes / raw time surfaces:
-  // its own SAE update + rendering unless prefetched, and Arc* unless that ran with the prefetch
-  bool main_reads_planes = !c->cur_prefetched;
-
-  c->cur_pts.clear();
-  c->cur_right_pts.clear();
-  lap(0);
+  }
 
   // Arc* for every left event does not depend on the tracks: on published frames it is enqueued
   // now (behind the temporal LK) without the blocked-pixel mask, so it runs under the host-side
   // filtering / RANSAC / Event_setMask; the mask becomes k_select's initial bitmap.  After it
   // nothing of this frame reads the planes on the main stream, so the announced next batch is
   // started on the prefetch stream.
-  bool early_done = false;
-  auto early_work = [&]() -> int {
+  int early_work() {
     if (early_done) return 0;
     early_done = true;
     if (PUB_THIS_FRAME && !arc_done) {
@@ -464,191 +489,190 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     if (!had_announced) return 0;
     if (main_reads_planes) HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
     return prefetch_next(c, main_reads_planes);
-  };
-
-  // a speculative launch of this very temporal LK may have been made by the previous call
-  bool use_spec = false;
-  if (c->spec_valid) {
-    c->spec_valid = false;
-    use_spec = c->cur_prefetched && (int)c->prev_pts.size() == c->spec_n;
-    if (!use_spec) HIPCHK(c, hipStreamSynchronize(c->stream3));
   }
-  // ... or a chained one by the call before that; if it was made for the NEXT frame, this frame
-  // is the one in between: it must publish nothing and track with the speculative results
-  bool use_chain = false;
-  if (c->chain_valid && c->chain_for == c->frame_no) {
-    use_chain = !use_spec && c->cur_prefetched && c->chain_map_ok &&
-                c->chain_map.size() == c->prev_pts.size();
-    if (!use_chain)
+
+  // which launch this frame's temporal LK results come from, and when the announced batch's prefetch
+  // is enqueued
+  int plan_temporal() {
+    // a speculative launch of this very temporal LK may have been made by the previous call
+    if (c->spec_valid) {
+      c->spec_valid = false;
+      use_spec = c->cur_prefetched && (int)c->prev_pts.size() == c->spec_n;
+      if (!use_spec) HIPCHK(c, hipStreamSynchronize(c->stream3));
+    }
+    // ... or a chained one by the call before that; if it was made for the NEXT frame, this frame
+    // is the one in between: it must publish nothing and track with the speculative results
+    if (c->chain_valid && c->chain_for == c->frame_no) {
+      use_chain = !use_spec && c->cur_prefetched && c->chain_map_ok &&
+                  c->chain_map.size() == c->prev_pts.size();
+      if (!use_chain)
+        if (int rc = cancel_chain(c)) return rc;
+      c->chain_valid = false;
+    } else if (c->chain_valid && (c->chain_for != c->frame_no + 1 || PUB_THIS_FRAME || !use_spec)) {
       if (int rc = cancel_chain(c)) return rc;
-    c->chain_valid = false;
-  } else if (c->chain_valid && (c->chain_for != c->frame_no + 1 || PUB_THIS_FRAME || !use_spec)) {
-    if (int rc = cancel_chain(c)) return rc;
+    }
+    chain_covers_next = c->chain_valid;  // (then: for frame_no + 1)
+    const bool early_results = use_spec || use_chain;
+    // When to enqueue the ~12 launches of the announced batch's prefetch (early_work):
+    //  * before the wait for this frame's temporal LK when that is a speculative / chained launch
+    //    still running and the frame publishes nothing: the host would only wait there;
+    //  * late — a published frame whose successor is already in flight: after everything else of the
+    //    frame, while the corner selection runs (RANSAC + mask + selection sit behind the temporal
+    //    LK wait, so nothing is put in front of them);
+    //  * else right away (Arc* still has to run on the main stream, or nothing to overlap with).
+    // (Handing them to a second host thread was tried: the two threads' launches serialise inside
+    // the runtime and the frame got slower, so everything stays on the calling thread.)
+    const bool before_sync = early_results && !PUB_THIS_FRAME;
+    defer_late = !(PUB_THIS_FRAME && !arc_done) && have_next && !before_sync;
+    return 0;
   }
-  const bool chain_covers_next = c->chain_valid;  // (then: for frame_no + 1)
-  const bool early_results = use_spec || use_chain;
-  // When to enqueue the ~12 launches of the announced batch's prefetch (early_work):
-  //  * before the wait for this frame's temporal LK when that is a speculative / chained launch
-  //    still running and the frame publishes nothing: the host would only wait there;
-  //  * late — a published frame whose successor is already in flight: after everything else of the
-  //    frame, while the corner selection runs (RANSAC + mask + selection sit behind the temporal
-  //    LK wait, so nothing is put in front of them);
-  //  * else right away (Arc* still has to run on the main stream, or nothing to overlap with).
-  // (Handing them to a second host thread was tried: the two threads' launches serialise inside
-  // the runtime and the frame got slower, so everything stays on the calling thread.)
-  const bool before_sync = early_results && !PUB_THIS_FRAME;
-  const bool defer_late = !(PUB_THIS_FRAME && !arc_done) && have_next && !before_sync;
-  if (c->prev_pts.size() > 0) {  // :405-437
-    const int n = (int)c->prev_pts.size();
-    const uint8_t *t_stA, *t_stB;
-    const P2f *t_ptsB, *t_ptsC;
-    bool spec_ok = false;
-    if (use_spec) {
-      if (!defer_late)
-        if (int rc = early_work()) return rc;
-      lap(1);
-      if (int rc = exchange_flush(c)) return rc;  // (host time that would be spent waiting)
-      HIPCHK(c, sync_event(c->ev_spec_done));
-      lap(2);
-      const size_t stM = ((size_t)std::max(M, 1) + 63) / 64 * 64;
-      t_ptsB = (const P2f*)c->h_spec;
-      t_ptsC = (const P2f*)(c->h_spec + (size_t)std::max(M, 1) * 8);
-      t_stA = c->h_spec + (size_t)std::max(M, 1) * 16;
-      t_stB = t_stA + stM;
-      int* wait_expired = (int*)(c->h_spec + (size_t)std::max(M, 1) * 16 + 2 * stM);
-      spec_ok = *wait_expired == 0;  // (a wave gave up waiting for k_select: redo the launch below)
-      *wait_expired = 0;
+
+  int temporal() {  // :405-440
+    if (int rc = plan_temporal()) return rc;
+    const esvio_fe_config& cfg = c->cfg;
+    const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
+    const PyrDesc& curL = c->pyr[c->slot_curL].d;
+    if (c->prev_pts.size() > 0) {
+      const int n = (int)c->prev_pts.size();
+      const uint8_t *t_stA, *t_stB;
+      const P2f *t_ptsB, *t_ptsC;
+      bool spec_ok = false;
+      if (use_spec) {
+        if (!defer_late)
+          if (int rc = early_work()) return rc;
+        lap(1);
+        if (int rc = exchange_flush(c)) return rc;  // (host time that would be spent waiting)
+        HIPCHK(c, sync_event(c->ev_spec_done));
+        lap(2);
+        const size_t stM = ((size_t)std::max(M, 1) + 63) / 64 * 64;
+        t_ptsB = (const P2f*)c->h_spec;
+        t_ptsC = (const P2f*)(c->h_spec + (size_t)std::max(M, 1) * 8);
+        t_stA = c->h_spec + (size_t)std::max(M, 1) * 16;
+        t_stB = t_stA + stM;
+        int* wait_expired = (int*)(c->h_spec + (size_t)std::max(M, 1) * 16 + 2 * stM);
+        spec_ok = *wait_expired == 0;  // (a wave gave up waiting for k_select: redo the launch below)
+        *wait_expired = 0;
+        if (!spec_ok) {
+          c->n_spec_expired++;
+          // its waves have ended without results; nothing of it may still be running when the same
+          // points go through the plain launch below
+          HIPCHK(c, hipStreamSynchronize(c->stream3));
+        }
+      }
+      std::vector<P2f> g_ptsB, g_ptsC;
+      std::vector<uint8_t> g_stA, g_stB;
+      if (use_chain) {
+        if (!defer_late)
+          if (int rc = early_work()) return rc;
+        lap(1);
+        if (int rc = exchange_flush(c)) return rc;
+        HIPCHK(c, sync_event(c->ev_chain_done));
+        lap(2);
+        const size_t Mx = (size_t)std::max(M, 1), stM = (Mx + 63) / 64 * 64;
+        const uint8_t* hc = c->h_spec + c->spec_bytes;
+        int* wait_expired = (int*)(hc + Mx * 16 + 2 * stM);
+        spec_ok = *wait_expired == 0;
+        *wait_expired = 0;
+        c->tr_chain_used += spec_ok;
+        if (!spec_ok) c->n_chain_expired++;
+        if (c->trace && spec_ok) trace_chain_intervals();
+        if (spec_ok) {  // gather: prev_pts[j] was the producer's point chain_map[j]
+          const P2f *sB = (const P2f*)hc, *sC = (const P2f*)(hc + Mx * 8);
+          const uint8_t *sa = hc + Mx * 16, *sb = sa + stM;
+          g_ptsB.resize(n);
+          g_ptsC.resize(n);
+          g_stA.resize(n);
+          g_stB.resize(n);
+          for (int j = 0; j < n; j++) {
+            const int k = c->chain_map[j];
+            g_ptsB[j] = sB[k];
+            g_ptsC[j] = sC[k];
+            g_stA[j] = sa[k];
+            g_stB[j] = sb[k];
+          }
+          t_ptsB = g_ptsB.data();
+          t_ptsC = g_ptsC.data();
+          t_stA = g_stA.data();
+          t_stB = g_stB.data();
+        }
+      }
       if (!spec_ok) {
-        c->n_spec_expired++;
-        // its waves have ended without results; nothing of it may still be running when the same
-        // points go through the plain launch below
-        HIPCHK(c, hipStreamSynchronize(c->stream3));
-      }
-    }
-    std::vector<P2f> g_ptsB, g_ptsC;
-    std::vector<uint8_t> g_stA, g_stB;
-    if (use_chain) {
-      if (!defer_late)
+        std::memcpy(pin.A, c->prev_pts.data(), (size_t)n * 8);
+        // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
+        // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
+        LkArgs f = make_lk(prevL, curL, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n, 3, 30, 0.01, 0);
+        LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
+                           ESVIO_FE_LK_USE_INITIAL_FLOW);
+        run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
         if (int rc = early_work()) return rc;
-      lap(1);
-      if (int rc = exchange_flush(c)) return rc;
-      HIPCHK(c, sync_event(c->ev_chain_done));
-      lap(2);
-      const size_t Mx = (size_t)std::max(M, 1), stM = (Mx + 63) / 64 * 64;
-      const uint8_t* hc = c->h_spec + c->spec_bytes;
-      int* wait_expired = (int*)(hc + Mx * 16 + 2 * stM);
-      spec_ok = *wait_expired == 0;
-      *wait_expired = 0;
-      c->tr_chain_used += spec_ok;
-      if (!spec_ok) c->n_chain_expired++;
-      if (c->trace && spec_ok) {
-        float a = 0, b = 0, d = 0;
-        if (hipEventElapsedTime(&a, c->ev_dbg_sel_start, c->ev_sel_host) == hipSuccess &&
-            hipEventElapsedTime(&b, c->ev_sel_host, c->ev_spec_done) == hipSuccess &&
-            hipEventElapsedTime(&d, c->ev_sel_host, c->ev_chain_done) == hipSuccess) {
-          c->tr_gpu_sel += a;
-          c->tr_gpu_spec += b;
-          c->tr_gpu_chain += d;
-          float e2 = 0;
-          if (c->tr_lane >= 0 &&
-              hipEventElapsedTime(&e2, c->ev_sel_host, c->ev_lane_done[c->tr_lane]) == hipSuccess)
-            c->tr_gpu_pyr += e2;
+        if (int rc = exchange_flush(c)) return rc;
+        lap(1);
+        HIPCHK(c, sync_main(c));
+        lap(2);
+        t_ptsB = (const P2f*)pin.ptsB;
+        t_ptsC = (const P2f*)pin.ptsC;
+        t_stA = pin.stA;
+        t_stB = pin.stB;
+      }
+      std::vector<uint8_t> status(t_stA, t_stA + n);
+      c->cur_pts.resize(n);
+      std::memcpy(c->cur_pts.data(), t_ptsB, (size_t)n * 8);
+      if (cfg.flow_back) {
+        const P2f* reverse_pts = t_ptsC;
+        for (int i = 0; i < n; i++) {
+          if (status[i] && t_stB[i] && pt_distance(c->prev_pts[i], reverse_pts[i]) <= 0.5)
+            status[i] = 1;
           else
-            (void)hipGetLastError();
-          c->tr_host_chain += std::chrono::duration<double, std::milli>(clk::now() - c->tr_sel_launch).count();
-          c->tr_gpu_n++;
-        } else {
-          (void)hipGetLastError();
+            status[i] = 0;
         }
       }
-      if (spec_ok) {  // gather: prev_pts[j] was the producer's point chain_map[j]
-        const P2f *sB = (const P2f*)hc, *sC = (const P2f*)(hc + Mx * 8);
-        const uint8_t *sa = hc + Mx * 16, *sb = sa + stM;
-        g_ptsB.resize(n);
-        g_ptsC.resize(n);
-        g_stA.resize(n);
-        g_stB.resize(n);
-        for (int j = 0; j < n; j++) {
-          const int k = c->chain_map[j];
-          g_ptsB[j] = sB[k];
-          g_ptsC[j] = sC[k];
-          g_stA[j] = sa[k];
-          g_stB[j] = sb[k];
+      for (int i = 0; i < n; i++)
+        if (status[i] && !in_border_event(c, c->cur_pts[i])) status[i] = 0;
+      if (chain_covers_next) {
+        if (use_spec && spec_ok) {  // (the producer's point i is this frame's prev_pts[i])
+          c->chain_map.clear();
+          for (int i = 0; i < n; i++)
+            if (status[i]) c->chain_map.push_back(i);
+          c->chain_map_ok = true;
+        } else if (int rc = cancel_chain(c)) {
+          return rc;
         }
-        t_ptsB = g_ptsB.data();
-        t_ptsC = g_ptsC.data();
-        t_stA = g_stA.data();
-        t_stB = g_stB.data();
       }
+      reduce_vector(c->prev_pts, status);
+      reduce_vector(c->cur_pts, status);
+      reduce_vector(c->ids, status);
+      reduce_vector(c->track_cnt, status);
+    } else if (chain_covers_next) {
+      if (int rc = cancel_chain(c)) return rc;
     }
-    if (!spec_ok) {
-      std::memcpy(pin.A, c->prev_pts.data(), (size_t)n * 8);
-      // forward: prevL -> curL, maxLevel 3 (:410); reverse: curL -> prevL, maxLevel 1,
-      // USE_INITIAL_FLOW seeded with prev_pts (:416-418) — fused into the same launch
-      LkArgs f = make_lk(prevL, curL, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n, 3, 30, 0.01, 0);
-      LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
-                         ESVIO_FE_LK_USE_INITIAL_FLOW);
-      run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
-      if (int rc = early_work()) return rc;
-      if (int rc = exchange_flush(c)) return rc;
-      lap(1);
-      HIPCHK(c, sync_main(c));
-      lap(2);
-      t_ptsB = (const P2f*)pin.ptsB;
-      t_ptsC = (const P2f*)pin.ptsC;
-      t_stA = pin.stA;
-      t_stB = pin.stB;
-    }
-    std::vector<uint8_t> status(t_stA, t_stA + n);
-    c->cur_pts.resize(n);
-    std::memcpy(c->cur_pts.data(), t_ptsB, (size_t)n * 8);
-    if (cfg.flow_back) {
-      const P2f* reverse_pts = t_ptsC;
-      for (int i = 0; i < n; i++) {
-        if (status[i] && t_stB[i] && pt_distance(c->prev_pts[i], reverse_pts[i]) <= 0.5)
-          status[i] = 1;
-        else
-          status[i] = 0;
-      }
-    }
-    for (int i = 0; i < n; i++)
-      if (status[i] && !in_border_event(c, c->cur_pts[i])) status[i] = 0;
-    if (chain_covers_next) {
-      if (use_spec && spec_ok) {  // (the producer's point i is this frame's prev_pts[i])
-        c->chain_map.clear();
-        for (int i = 0; i < n; i++)
-          if (status[i]) c->chain_map.push_back(i);
-        c->chain_map_ok = true;
-      } else if (int rc = cancel_chain(c)) {
-        return rc;
-      }
-    }
-    reduce_vector(c->prev_pts, status);
-    reduce_vector(c->cur_pts, status);
-    reduce_vector(c->ids, status);
-    reduce_vector(c->track_cnt, status);
-  } else if (chain_covers_next) {
-    if (int rc = cancel_chain(c)) return rc;
+    if (!defer_late)
+      if (int rc = early_work()) return rc;  // (no previous points: nothing was synchronised above)
+    for (auto& n : c->track_cnt) n++;  // :439-440
+    return 0;
   }
 
-  if (!defer_late)
-    if (int rc = early_work()) return rc;  // (no previous points: nothing was synchronised above)
-  for (auto& n : c->track_cnt) n++;  // :439-440
+  // (trace only) device-side intervals of the published frame's chain, from timing events
+  void trace_chain_intervals() {
+    float a = 0, b = 0, d = 0;
+    if (hipEventElapsedTime(&a, c->ev_dbg_sel_start, c->ev_sel_host) == hipSuccess &&
+        hipEventElapsedTime(&b, c->ev_sel_host, c->ev_spec_done) == hipSuccess &&
+        hipEventElapsedTime(&d, c->ev_sel_host, c->ev_chain_done) == hipSuccess) {
+      c->tr_gpu_sel += a;
+      c->tr_gpu_spec += b;
+      c->tr_gpu_chain += d;
+      float e2 = 0;
+      if (c->tr_lane >= 0 && hipEventElapsedTime(&e2, c->ev_sel_host, c->ev_lane_done[c->tr_lane]) == hipSuccess)
+        c->tr_gpu_pyr += e2;
+      else
+        (void)hipGetLastError();
+      c->tr_host_chain += std::chrono::duration<double, std::milli>(clk::now() - c->tr_sel_launch).count();
+      c->tr_gpu_n++;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
 
-  // ---- speculative stereo LK of every temporal survivor (a superset of the points that survive
-  // rejectWithF_event / Event_setMask): per-point results do not depend on the other points, so
-  // this is exactly cv::calcOpticalFlowPyrLK(curL, curR, cur_pts, ...) (:490) and its reverse (:495)
-  // for the kept points — launched now so that it overlaps the host-side RANSAC + mask.
-  const int n_surv = (int)c->cur_pts.size();
-  c->src_idx.resize(n_surv);
-  for (int i = 0; i < n_surv; i++) c->src_idx[i] = i;
-  lap(3);
-  bool detect = false;
-  int n_kept = n_surv;
-  // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
-  // launched as soon as this frame's points are final
-  const bool will_spec = have_next || had_announced;
-  auto upload_kept = [&]() -> int {
+  int upload_kept() {
     if (!will_spec || !n_kept) return 0;
     // pin.news is a single buffer and the previous published frame's lazy stereo LK of its new
     // corners reads its points from there (z_new + its n_kept) in place.  Up to ~1000 points every
@@ -658,179 +682,229 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     if (c->pend.active && M > 1024) HIPCHK(c, sync_event(c->ev_lknew_done));
     std::memcpy(pin.news, c->cur_pts.data(), (size_t)n_kept * 8);  // read in place by the LK
     return 0;
-  };
-  if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
-    if (int rc = upload_kept()) return rc;
-    // (c->chain_valid here: the next frame's temporal LK is already running, chained to this one's)
-    if (will_spec && n_kept && !c->chain_valid)
-      if (const Inflight* nb = next_batch())
-        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
-  }
-  if (n_surv) {
-    std::memcpy(pin.A, c->cur_pts.data(), (size_t)n_surv * 8);
-    LkArgs f = make_lk(curL, curR, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n_surv, 3, 30,
-                       0.01, 0);
-    LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
-    {
-      // on its own stream.  Its inputs are complete without a device-side wait: the host has just
-      // read this frame's temporal LK results, and that launch ran behind the frame's pyramids.
-      StreamScope on_stereo_stream(c->stream4);
-      run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
-      HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], c->stream4));
-    }
-    c->lks_last = c->res_set;
   }
 
-  if (PUB_THIS_FRAME) {  // :442-469
-    if (cfg.f_ransac) reject_with_f_event(c);
-    lap(4);
-    auto tq = clk::now();
-    auto sub = [&](int i) {
+  // ---- speculative stereo LK of every temporal survivor (a superset of the points that survive
+  // rejectWithF_event / Event_setMask): per-point results do not depend on the other points, so
+  // this is exactly cv::calcOpticalFlowPyrLK(curL, curR, cur_pts, ...) (:490) and its reverse (:495)
+  // for the kept points — launched now so that it overlaps the host-side RANSAC + mask.
+  int survivors_stereo() {
+    const esvio_fe_config& cfg = c->cfg;
+    const PyrDesc& curL = c->pyr[c->slot_curL].d;
+    const PyrDesc& curR = c->pyr[c->slot_curR].d;
+    n_surv = (int)c->cur_pts.size();
+    c->src_idx.resize(n_surv);
+    for (int i = 0; i < n_surv; i++) c->src_idx[i] = i;
+    lap(3);
+    n_kept = n_surv;
+    // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
+    // launched as soon as this frame's points are final
+    will_spec = have_next || had_announced;
+    if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
+      if (int rc = upload_kept()) return rc;
+      // (c->chain_valid here: the next frame's temporal LK is already running, chained to this one's)
+      if (will_spec && n_kept && !c->chain_valid)
+        if (const Inflight* nb = next_batch())
+          if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
+    }
+    if (n_surv) {
+      std::memcpy(pin.A, c->cur_pts.data(), (size_t)n_surv * 8);
+      LkArgs f = make_lk(curL, curR, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n_surv, 3, 30,
+                         0.01, 0);
+      LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n_surv, 3, 30, 0.01, 0);
+      {
+        // on its own stream.  Its inputs are complete without a device-side wait: the host has just
+        // read this frame's temporal LK results, and that launch ran behind the frame's pyramids.
+        StreamScope on_stereo_stream(c->stream4);
+        run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
+        HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], c->stream4));
+      }
+      c->lks_last = c->res_set;
+    }
+    return 0;
+  }
+
+  int publish() {  // :442-469
+    const esvio_fe_config& cfg = c->cfg;
+    const PyrDesc& curL = c->pyr[c->slot_curL].d;
+    const PyrDesc& curR = c->pyr[c->slot_curR].d;
+    if (PUB_THIS_FRAME) {
+      if (cfg.f_ransac) reject_with_f_event(c);
+      lap(4);
+      auto tq = clk::now();
+      auto sub = [&](int i) {
+        if (!c->trace) return;
+        const auto now = clk::now();
+        c->pub_ms[i] += std::chrono::duration<double, std::milli>(now - tq).count();
+        tq = now;
+      };
+      event_set_mask(c);
+      sub(0);
+      n_kept = (int)c->cur_pts.size();
+      const int n_max_cnt = M - n_kept;
+      if (int rc = upload_kept()) return rc;
+      if (n_max_cnt <= 0 && will_spec && n_kept)
+        if (const Inflight* nb = next_batch())
+          if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
+      if (n_max_cnt > 0) {
+        detect = true;
+        // Event_setMask's blocked pixels are the discs of the kept points: k_select stamps them
+        // into its bitmap itself from the points just written to pin.news (1-2 KB read in place
+        // instead of a 38 KB bitmap copied over); candidates on them are skipped there
+        if (!will_spec && n_kept) std::memcpy(pin.news, c->cur_pts.data(), (size_t)n_kept * 8);
+        if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
+        // new corners go behind the kept points: z_new = next frame's prev_pts
+        c->pub_seq++;
+        if (c->trace) {
+          HIPCHK(c, hipEventRecord(c->ev_dbg_sel_start, cur_stream(c)));
+          c->tr_sel_launch = clk::now();
+        }
+        run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, nullptr, c->z_counts, will_spec,
+                   c->z_new, n_kept);
+        sub(1);
+        if (will_spec)
+          if (const Inflight* nb = next_batch())
+            if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
+        sub(2);
+        // the selection result is in host memory once k_select is done: an event right behind it lets
+        // the left-camera bookkeeping below run under the stereo LK of the new corners
+        HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
+        if (int rc = finalize_pending(c)) return rc;  // (its results live where this launch writes)
+        if (int rc = finalize_right(c)) return rc;    // (idle time: k_select is running)
+        sub(3);
+        // stereo LK of the new corners only (count known on the device)
+        LkArgs f = make_lk(curL, curR, c->z_new + n_kept, nullptr, c->z_ptsB2, c->z_stA2, c->d_counts,
+                           n_max_cnt, 3, 30, 0.01, 0);
+        LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, c->d_counts, n_max_cnt, 3, 30,
+                           0.01, 0);
+        run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC2, c->z_stB2);
+        if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lknew_done, cur_stream(c)));
+        sub(4);
+      }
+      if (defer_late)
+        if (int rc = early_work()) return rc;
+      sub(5);
+    } else if (defer_late) {
+      if (int rc = early_work()) return rc;
+    }
+    lap(5);
+    if (detect) HIPCHK(c, sync_event(c->ev_sel_host));
+    return 0;
+  }
+
+  int tails() {  // :463-603
+    const esvio_fe_config& cfg = c->cfg;
+    int n_new = 0;
+    if (PUB_THIS_FRAME) {
+      c->n_pts.clear();
+      if (detect) {
+        n_new = pin.counts[0];
+        c->tr_cand += (uint64_t)pin.counts[2];
+        c->tr_new += (uint64_t)n_new;
+        c->tr_detect++;
+        const P2f* np = (const P2f*)pin.news + n_kept;
+        for (int i = 0; i < n_new; i++) c->n_pts.push_back(np[i]);
+      }
+      for (auto& p : c->n_pts) {  // :463-468
+        c->cur_pts.push_back(p);
+        c->ids.push_back(c->n_id++);
+        c->track_cnt.push_back(1);
+      }
+    }
+    auto tt = clk::now();
+    auto tail_lap = [&](int i) {
       if (!c->trace) return;
       const auto now = clk::now();
-      c->pub_ms[i] += std::chrono::duration<double, std::milli>(now - tq).count();
-      tq = now;
+      c->tail_ms[PUB_THIS_FRAME ? 1 : 0][i] += std::chrono::duration<double, std::milli>(now - tt).count();
+      tt = now;
     };
-    event_set_mask(c);
-    sub(0);
-    n_kept = (int)c->cur_pts.size();
-    const int n_max_cnt = M - n_kept;
-    if (int rc = upload_kept()) return rc;
-    if (n_max_cnt <= 0 && will_spec && n_kept)
-      if (const Inflight* nb = next_batch())
-        if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
-    if (n_max_cnt > 0) {
-      detect = true;
-      // Event_setMask's blocked pixels are the discs of the kept points: k_select stamps them
-      // into its bitmap itself from the points just written to pin.news (1-2 KB read in place
-      // instead of a 38 KB bitmap copied over); candidates on them are skipped there
-      if (!will_spec && n_kept) std::memcpy(pin.news, c->cur_pts.data(), (size_t)n_kept * 8);
-      if (arc_prefetched) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_arc[arc_lane], 0));
-      // new corners go behind the kept points: z_new = next frame's prev_pts
-      c->pub_seq++;
-      if (c->trace) {
-        HIPCHK(c, hipEventRecord(c->ev_dbg_sel_start, cur_stream(c)));
-        c->tr_sel_launch = clk::now();
+    c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);  // :470-473
+    c->pts_velocity = pts_velocity_fn(c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map,
+                                      c->cur_time - c->prev_time, c->cur_pts.size());
+    lap(7);
+    tail_lap(0);
+    if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners,
+    if (int rc = finalize_right(c)) return rc;    //  or the previous unpublished frame's whole tail)
+    tail_lap(1);
+    const bool lazy = c->lazy_new && detect;      // leave this frame's new corners to the next call
+    const bool defer_right = c->lazy_new && !PUB_THIS_FRAME;  // ... or its whole right-camera tail
+    if (defer_right) {
+      // (returns with the stereo LK in flight)
+    } else {
+      if (!lazy) HIPCHK(c, sync_main(c));  // stereo LK results of the new corners
+      if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));  // ... of the kept points
+    }
+    lap(6);
+    tt = clk::now();
+    if (!defer_right && (n_surv || detect) && pin.counts[3] != 0)
+      return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
+
+    if (defer_right) {
+      // nothing of this frame is published: its right-camera tail waits for the next call
+      c->pend_right.active = true;
+      c->pend_right.set = c->res_set;
+      c->pend_right.dt = c->cur_time - c->prev_time;
+      c->pend_right.ids = c->ids;
+      c->pend_right.left = c->cur_pts;
+    } else {
+      if (lazy) {
+        c->pend.active = true;
+        c->pend.prev_map_was_empty = c->prev_un_right_pts_map.empty();
+        c->pend.ids.assign(c->ids.begin() + n_kept, c->ids.end());
+        c->pend.left.assign(c->cur_pts.begin() + n_kept, c->cur_pts.end());
       }
-      run_select(c, c->cand_cur, n_max_cnt, c->z_new, n_kept, nullptr, nullptr, c->z_counts, will_spec,
-                 c->z_new, n_kept);
-      sub(1);
-      if (will_spec)
-        if (const Inflight* nb = next_batch())
-          if (int rc = enqueue_spec_temporal(c, *nb, n_kept, true)) return rc;
-      sub(2);
-      // the selection result is in host memory once k_select is done: an event right behind it lets
-      // the left-camera bookkeeping below run under the stereo LK of the new corners
-      HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
-      if (int rc = finalize_pending(c)) return rc;  // (its results live where this launch writes)
-      if (int rc = finalize_right(c)) return rc;    // (idle time: k_select is running)
-      sub(3);
-      // stereo LK of the new corners only (count known on the device)
-      LkArgs f = make_lk(curL, curR, c->z_new + n_kept, nullptr, c->z_ptsB2, c->z_stA2, c->d_counts,
-                         n_max_cnt, 3, 30, 0.01, 0);
-      LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, c->d_counts, n_max_cnt, 3, 30,
-                         0.01, 0);
-      run_lk(c, f, cfg.flow_back ? &b : nullptr, c->z_ptsC2, c->z_stB2);
-      if (c->lazy_new) HIPCHK(c, hipEventRecord(c->ev_lknew_done, cur_stream(c)));
-      sub(4);
+      right_tail(c, pin, c->cur_pts.data(), c->ids.data(), c->src_idx.data(),
+                 lazy ? n_kept : (int)c->cur_pts.size(), n_kept, c->cur_time - c->prev_time,
+                 c->cur_pts.size());
     }
-    if (defer_late)
-      if (int rc = early_work()) return rc;
-    sub(5);
-  } else if (defer_late) {
-    if (int rc = early_work()) return rc;
+    tail_lap(2);
+    c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left (:585)
+    c->prev_pts = c->cur_pts;
+    c->prev_un_pts_map.swap(c->cur_un_pts_map);
+    c->prev_time = c->cur_time;
+    c->spec_n = (int)c->prev_pts.size();
+    lap(7);
+    if (c->cur_stage >= 0) {  // the staging slot of this batch's host events is free for another batch
+      if (main_reads_events)
+        if (int rc = stager_mark_read(c, c->cur_stage, c->stream, true)) return rc;
+      if (int rc = stager_release(c, c->cur_stage)) return rc;
+      c->cur_stage = -1;
+    }
+    c->phase_frames++;
+    c->phase_count[PUB_THIS_FRAME ? 1 : 0]++;
+    c->tr_surv += (uint64_t)n_surv;
+    if (c->prof_on) resolve_profile(c);
+    // esvio_fe_set_auto_exchange: what an earlier published frame left to enqueue goes out now at the
+    // latest (normally it went out above, where this call waited for its temporal LK anyway); this
+    // frame's records, if it publishes, are packed now and enqueued by the next call
+    if (int rc = exchange_flush(c)) return rc;
+    if (c->x_auto && c->x_comm && PUB_THIS_FRAME)
+      if (int rc = exchange_pack(c)) return rc;
+    tail_lap(3);
+    return 0;
   }
-  lap(5);
-  if (detect) HIPCHK(c, sync_event(c->ev_sel_host));
+};
+}  // namespace
 
-  int n_new = 0;
-  if (PUB_THIS_FRAME) {
-    c->n_pts.clear();
-    if (detect) {
-      n_new = pin.counts[0];
-      c->tr_cand += (uint64_t)pin.counts[2];
-      c->tr_new += (uint64_t)n_new;
-      c->tr_detect++;
-      const P2f* np = (const P2f*)pin.news + n_kept;
-      for (int i = 0; i < n_new; i++) c->n_pts.push_back(np[i]);
-    }
-    for (auto& p : c->n_pts) {  // :463-468
-      c->cur_pts.push_back(p);
-      c->ids.push_back(c->n_id++);
-      c->track_cnt.push_back(1);
-    }
-  }
-  auto tt = clk::now();
-  auto tail_lap = [&](int i) {
-    if (!c->trace) return;
-    const auto now = clk::now();
-    c->tail_ms[PUB_THIS_FRAME ? 1 : 0][i] += std::chrono::duration<double, std::milli>(now - tt).count();
-    tt = now;
-  };
-  c->cur_un_pts = undistorted_pts(c->cur_pts, cfg.cam[0]);  // :470-473
-  c->pts_velocity = pts_velocity_fn(c->ids, c->cur_un_pts, c->cur_un_pts_map, c->prev_un_pts_map,
-                                    c->cur_time - c->prev_time, c->cur_pts.size());
-  lap(7);
-  tail_lap(0);
-  if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners,
-  if (int rc = finalize_right(c)) return rc;    //  or the previous unpublished frame's whole tail)
-  tail_lap(1);
-  const bool lazy = c->lazy_new && detect;      // leave this frame's new corners to the next call
-  const bool defer_right = c->lazy_new && !PUB_THIS_FRAME;  // ... or its whole right-camera tail
-  if (defer_right) {
-    // (returns with the stereo LK in flight)
-  } else {
-    if (!lazy) HIPCHK(c, sync_main(c));  // stereo LK results of the new corners
-    if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));  // ... of the kept points
-  }
-  lap(6);
-  tt = clk::now();
-  if (!defer_right && (n_surv || detect) && pin.counts[3] != 0)
-    return fail(c, ESVIO_FE_EINTERNAL, "radix sort look-back spin expired");
-
-  if (defer_right) {
-    // nothing of this frame is published: its right-camera tail waits for the next call
-    c->pend_right.active = true;
-    c->pend_right.set = c->res_set;
-    c->pend_right.dt = c->cur_time - c->prev_time;
-    c->pend_right.ids = c->ids;
-    c->pend_right.left = c->cur_pts;
-  } else {
-    if (lazy) {
-      c->pend.active = true;
-      c->pend.prev_map_was_empty = c->prev_un_right_pts_map.empty();
-      c->pend.ids.assign(c->ids.begin() + n_kept, c->ids.end());
-      c->pend.left.assign(c->cur_pts.begin() + n_kept, c->cur_pts.end());
-    }
-    right_tail(c, pin, c->cur_pts.data(), c->ids.data(), c->src_idx.data(),
-               lazy ? n_kept : (int)c->cur_pts.size(), n_kept, c->cur_time - c->prev_time,
-               c->cur_pts.size());
-  }
-  tail_lap(2);
-  c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left (:585)
-  c->prev_pts = c->cur_pts;
-  c->prev_un_pts_map.swap(c->cur_un_pts_map);
-  c->prev_time = c->cur_time;
-  c->spec_n = (int)c->prev_pts.size();
-  lap(7);
-  if (c->cur_stage >= 0) {  // the staging slot of this batch's host events is free for another batch
-    if (main_reads_events)
-      if (int rc = stager_mark_read(c, c->cur_stage, c->stream, true)) return rc;
-    if (int rc = stager_release(c, c->cur_stage)) return rc;
-    c->cur_stage = -1;
-  }
-  c->phase_frames++;
-  c->phase_count[PUB_THIS_FRAME ? 1 : 0]++;
-  c->tr_surv += (uint64_t)n_surv;
-  if (c->prof_on) resolve_profile(c);
-  // esvio_fe_set_auto_exchange: what an earlier published frame left to enqueue goes out now at the
-  // latest (normally it went out above, where this call waited for its temporal LK anyway); this
-  // frame's records, if it publishes, are packed now and enqueued by the next call
-  if (int rc = exchange_flush(c)) return rc;
-  if (c->x_auto && c->x_comm && PUB_THIS_FRAME)
-    if (int rc = exchange_pack(c)) return rc;
-  tail_lap(3);
-  return 0;
+int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* left, size_t nL,
+                     const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME,
+                     const esvio_fe_motion* motion) {
+  TrackCall t(c, _cur_time, left, nL, right, nR, space, PUB_THIS_FRAME, motion);
+  if (int rc = t.check()) return rc;
+  // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
+  // (lazy mode, pend_right) while this frame's kernels are enqueued
+  c->res_set ^= 1;
+  c->frame_no++;
+  t.pin = pin_of(c, c->res_set);
+  if (PUB_THIS_FRAME && c->pool) host::ransac_pool_wake(c->pool);
+  c->cur_time = _cur_time;
+  t.tp = clk::now();
+  if (int rc = t.take_batch()) return rc;
+  t.lap(0);
+  if (int rc = t.temporal()) return rc;
+  if (int rc = t.survivors_stereo()) return rc;
+  if (int rc = t.publish()) return rc;
+  return t.tails();
 }
 
 
