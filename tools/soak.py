@@ -1,7 +1,9 @@
 """soak.py — randomized end-to-end parity soak on the GPU: for `--minutes` minutes, random sensor sizes,
 event rates, feature budgets, equalize / lk_accum / median settings, publish patterns and replay
-schedules (0..3 batches announced ahead, lazy mode and helper threads switched between calls, finish()
-now and then); every frame's public result vectors are compared bit for bit with the oracle's.
+schedules (0..5 batches announced ahead, lazy mode and helper threads switched between calls, finish()
+now and then; round 3: the batches as pageable host arrays, in pinned host memory or in device memory,
+motion compensation also on announced batches, the speculative / chained LK waits made to expire now
+and then); every frame's public result vectors are compared bit for bit with the oracle's.
 Stops at the first difference and prints the configuration that produced it.
 
     python tools/soak.py --minutes 10 [--seed 1]
@@ -80,8 +82,26 @@ def one_case(rng, case):
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     tr = O.Tracker(O.make_config(W, H, **kw))
     replay = rng.random() < 0.7
-    mc = (not replay) and rng.random() < 0.4  # Do_motion_correction (no announced batches with it)
-    desc["replay"], desc["mc"] = bool(replay), bool(mc)
+    mc = rng.random() < 0.3  # Do_motion_correction
+    where = ["host", "host", "pinned", "device"][int(rng.integers(0, 4))]  # where the caller keeps the batches
+    fault = int(rng.choice([0, 0, 0, 4, 8, 12])) if replay else 0  # expiring speculative / chained waits
+    desc.update(replay=bool(replay), mc=bool(mc), where=where, fault=fault)
+    bufs = []
+
+    def arg(a):
+        if where == "host":
+            return a
+        b = FE.EventBuffer(a, FE.HOST if where == "pinned" else FE.DEVICE)
+        bufs.append(b)
+        return b.array if where == "pinned" else b.arg
+    args = [(arg(L), arg(R)) for L, R in batches]
+    mvs = []
+    for L, _ in batches:
+        te = event_times(L)
+        mvs.append(dict(t1=te[0] + float(rng.uniform(-0.2, 1.3)) * (te[-1] - te[0]), v=tuple(rng.uniform(-1, 1, 3)),
+                        v_pre=tuple(rng.uniform(-1, 1, 3)), accel=tuple(rng.uniform(-6, 6, 3)),
+                        omega=tuple(rng.uniform(-3, 3, 3) * (10 if rng.random() < 0.1 else 1)),
+                        fx=0.9 * W, fy=0.9 * W, cx=W / 2.0 + 1.5, cy=H / 2.0 - 0.75))
     announced = 0
     try:
         for f, (L, R) in enumerate(batches):
@@ -90,23 +110,20 @@ def one_case(rng, case):
                     ft.set_lazy_new_stereo(bool(rng.integers(0, 2)))
                 if rng.random() < 0.15:
                     ft.set_host_threads(int(rng.integers(1, 6)))
+                if fault and rng.random() < 0.3:
+                    ft.debug_inject(fault if rng.random() < 0.5 else 0)
                 announced = max(announced, f)
-                want = min(f + int(rng.integers(0, 4)), len(batches) - 1)
+                want = min(f + int(rng.integers(0, 6)), len(batches) - 1)
                 while announced < want:
                     announced += 1
-                    Ln, Rn = batches[announced]
-                    ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+                    ft.set_next_batch(event_times(batches[announced][0])[-1], args[announced][0], args[announced][1],
+                                      pubs[announced], measurements=FE.make_motion(**mvs[announced]) if mc else None)
             t = event_times(L)[-1]
             if mc:
-                te = event_times(L)
-                mv = dict(t1=te[0] + float(rng.uniform(-0.2, 1.3)) * (te[-1] - te[0]), v=tuple(rng.uniform(-1, 1, 3)),
-                          v_pre=tuple(rng.uniform(-1, 1, 3)), accel=tuple(rng.uniform(-6, 6, 3)),
-                          omega=tuple(rng.uniform(-3, 3, 3) * (10 if rng.random() < 0.1 else 1)),
-                          fx=0.9 * W, fy=0.9 * W, cx=W / 2.0 + 1.5, cy=H / 2.0 - 0.75)
-                ft.trackEvent(t, L, R, pubs[f], measurements=FE.make_motion(**mv))
-                r = tr.track_event(t, L, R, pubs[f], motion=O.make_motion(**mv))
+                ft.trackEvent(t, args[f][0], args[f][1], pubs[f], measurements=FE.make_motion(**mvs[f]))
+                r = tr.track_event(t, L, R, pubs[f], motion=O.make_motion(**mvs[f]))
             else:
-                ft.trackEvent(t, L, R, pubs[f])
+                ft.trackEvent(t, args[f][0], args[f][1], pubs[f])
                 r = tr.track_event(t, L, R, pubs[f])
             left_only = False
             if replay and (rng.random() < 0.5 or f == len(batches) - 1):
@@ -120,6 +137,8 @@ def one_case(rng, case):
             return desc, "time surface differs"
     finally:
         ft.close()
+        for b in bufs:
+            b.free()
     return desc, None
 
 
