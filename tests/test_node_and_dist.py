@@ -293,3 +293,30 @@ def test_frequency_rule_at_a_duplicate_stamp_follows_c():
     assert fc.pub_this_frame(10.0) is False        # duplicate stamp: dt == 0
     assert fc.peek(10.0) is False
     assert fc.pub_this_frame(10.5) is True
+
+
+def test_bench_gpus_n_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher re-executes itself under torch.distributed.run with
+    N ranks on 127.0.0.1 (the command line the driver uses for N > 1); under a launcher (WORLD_SIZE set)
+    it does not"""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_exec(prog, argv, env):
+        seen.update(prog=prog, argv=list(argv), env=dict(env))
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execvpe", fake_exec)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert a[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in a
+    assert a[a.index("--nproc-per-node") + 1] == "8" and a[a.index("--master-addr") + 1] == "127.0.0.1"
+    assert a[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and a[-7].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
