@@ -2,6 +2,7 @@
 TAG=${TAG:-r03}
 python -m pytest tests -q -m gpu -x 2>&1 | tail -8 > gpurun_out/${TAG}_gputests.txt
 cat gpurun_out/${TAG}_gputests.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.json 2> gpurun_out/${TAG}_bench_driver.err
 python - <<PY
 import json
