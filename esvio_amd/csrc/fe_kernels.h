@@ -138,11 +138,12 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
 
 // ---- SAE update, tiled form (default) --------------------------------------------------------
 // The sensor is cut into tiles of tw x th pixels; a tile of one camera is a bucket.  One stable
-// partition of the raw 16 B event records by bucket (k_tile_hist + k_tile_scan + k_tile_scatter:
-// one digit of <= 11 bits, no atomics or spins across blocks), then one block per bucket applies
-// its events in stream order
-// with the tile's L planes in LDS (k_tile_apply).  Replaces key generation + 3 radix passes over
-// (key, index) pairs + a gathering apply: per event 16 B are read three times and written once.
+// partition of the event records by bucket (k_tile_hist + k_tile_scan + k_tile_scatter: one digit of
+// <= 11 bits, no atomics or spins across blocks; the partitioned records are 8 bytes — tile-local
+// pixel, polarity, seconds relative to the batch's smallest, nsec — whenever the batch's stamps allow
+// it, else the raw 16), then one block per bucket applies its events in stream order with the tile's
+// L planes in LDS (k_tile_apply).  Replaces key generation + 3 radix passes over (key, index) pairs +
+// a gathering apply: per event 16 B are read twice, 8 written and 8 read.
 struct TileGeom {
   int W, H;
   int tw, th;            // tile size in pixels (tw * th <= kTileMaxPx)
@@ -167,8 +168,7 @@ inline uint32_t tile_scatter_blocks(uint32_t n) {
 // kTileMaxGroups groups
 constexpr uint32_t kTileMaxGroups = 512;
 inline uint32_t tile_hist_group(uint32_t nblk) { return (nblk + kTileMaxGroups - 1) / kTileMaxGroups; }
-// scratch (uint32 words)
-// meta words (TileScratch::meta): k_tile_hist accumulates the batch's range of seconds and the OR of its
+// scratch (uint32 words).  meta words (TileScratch::meta): k_tile_hist accumulates the batch's range of seconds and the OR of its
 // nsec words, k_tile_scan turns them into the record format of the partition and resets them
 enum { kTileMetaSecMin = 0, kTileMetaSecMax, kTileMetaNsecOr, kTileMetaCompact, kTileMetaSecBase, kTileMetaWords = 8 };
 constexpr int kTileRecSecBits = 20;
