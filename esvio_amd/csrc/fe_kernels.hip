@@ -762,12 +762,14 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
                                                    uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm,
                                                    const uint32_t* __restrict__ warp_xy,
                                                    uint32_t* __restrict__ meta) {
-  constexpr int UB = 4, UE = 4;
-  __shared__ uint32_t h[UB][kTileMaxBins], run[kTileMaxBins];  // 40 KiB
+  constexpr int UE = 4;
+  __shared__ uint32_t h[kTileMaxBins], run[kTileMaxBins];  // 16 KiB
   __shared__ uint32_t s_range[3];
   const int nb = g.nbins;
-  for (int i = threadIdx.x; i < UB * kTileMaxBins; i += kTileHistThreads) (&h[0][0])[i] = 0;
-  for (int i = threadIdx.x; i < nb; i += kTileHistThreads) run[i] = 0;
+  for (int i = threadIdx.x; i < kTileMaxBins; i += kTileHistThreads) {
+    h[i] = 0;
+    run[i] = 0;
+  }
   if (threadIdx.x == 0) {
     s_range[0] = 0xffffffffu;
     s_range[1] = 0;
@@ -777,54 +779,59 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
   // whether the partitioned records can take the 8-byte form (kTileMeta*, k_tile_scan)
   uint32_t tmin = 0xffffffffu, tmax = 0, tor = 0;
   const uint32_t n = nL + nR;
-  // (te <= 4 * kTileHistThreads: a thread has at most 4 events per scatter block.)  Up to 4 scatter
-  // blocks per step: their records are requested together, counted into 4 LDS histograms, then the
-  // 4 rows of P are written from the running prefix (and the histograms cleared for the next step).
-  // The barriers order LDS traffic only (lds_barrier): the stores of P drain while the next step's
-  // records are on their way.  Two blocks per CU overlap each other's phases; holding the NEXT step's
-  // 16 records in registers as well was measured and is worse (84 VGPRs: one block per CU, 37 -> 49 us).
+  // (te <= 4 * kTileHistThreads: a thread has at most 4 events per scatter block.)  One scatter block
+  // per step: its records are counted into the LDS histogram, then its row of P is written from the
+  // running prefix (and the histogram cleared); the NEXT scatter block's records (4 per thread: 16
+  // registers, two blocks still fit a CU) are requested before that, and the barriers order LDS traffic
+  // only (lds_barrier) — so the requests and the stores of P are in flight while a step computes.
+  uint4 ne[UE];
+  uint32_t nw[UE];
+  auto request = [&](uint32_t k) {
+    const uint32_t b = blockIdx.x * group + k;
+    const uint32_t lo = b * te, hi = (k < group && b < nblk) ? min(lo + te, n) : lo;
+#pragma unroll
+    for (int j = 0; j < UE; j++) {
+      const uint32_t i = lo + threadIdx.x + j * kTileHistThreads;
+      ne[j] = make_uint4(0, 0, 0, 0);
+      nw[j] = 0;
+      if (j * kTileHistThreads < (int)te && i < hi) {
+        ne[j] = i >= nL ? evR[i - nL] : evL[i];  // (whole records: one coalesced 1 KiB request per wave)
+        if (MC) nw[j] = warp_xy[i];
+      }
+    }
+  };
+  request(0);
   __syncthreads();
-  for (uint32_t k0 = 0; k0 < group; k0 += UB) {
-    uint32_t bins[UB][UE];
+  for (uint32_t k = 0; k < group; k++) {
+    const uint32_t b = blockIdx.x * group + k;
+    const bool live = b < nblk;
+    const uint32_t lo = b * te, hi = live ? min(lo + te, n) : lo;
+    uint32_t bins[UE];
 #pragma unroll
-    for (int u = 0; u < UB; u++) {
-      const uint32_t b = blockIdx.x * group + k0 + u;
-      const uint32_t lo = b * te, hi = (k0 + u < group && b < nblk) ? min(lo + te, n) : lo;
-#pragma unroll
-      for (int j = 0; j < UE; j++) {
-        const uint32_t i = lo + threadIdx.x + j * kTileHistThreads;
-        bins[u][j] = 0xffffffffu;
-        if (j * kTileHistThreads < (int)te && i < hi) {
-          const bool right = i >= nL;
-          const uint4 e = right ? evR[i - nL] : evL[i];  // (whole records: one coalesced 1 KiB request per wave)
-          bins[u][j] = tile_bin(g, MC ? warp_xy[i] : e.x, right);
-          if (bins[u][j] != (uint32_t)nb - 1u) {
-            tmin = min(tmin, e.y);
-            tmax = max(tmax, e.y);
-            tor |= e.z;
-          }
+    for (int j = 0; j < UE; j++) {
+      const uint32_t i = lo + threadIdx.x + j * kTileHistThreads;
+      bins[j] = 0xffffffffu;
+      if (j * kTileHistThreads < (int)te && i < hi) {
+        bins[j] = tile_bin(g, MC ? nw[j] : ne[j].x, i >= nL);
+        if (bins[j] != (uint32_t)nb - 1u) {
+          tmin = min(tmin, ne[j].y);
+          tmax = max(tmax, ne[j].y);
+          tor |= ne[j].z;
         }
       }
     }
+    if (k + 1 < group) request(k + 1);
 #pragma unroll
-    for (int u = 0; u < UB; u++)
-#pragma unroll
-      for (int j = 0; j < UE; j++)
-        if (bins[u][j] != 0xffffffffu) atomicAdd(&h[u][bins[u][j]], 1u);
+    for (int j = 0; j < UE; j++)
+      if (bins[j] != 0xffffffffu) atomicAdd(&h[bins[j]], 1u);
     lds_barrier();
-    for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
-      uint32_t r = run[i];
-#pragma unroll
-      for (int u = 0; u < UB; u++) {
-        const uint32_t b = blockIdx.x * group + k0 + u;
-        if (k0 + u < group && b < nblk) {
-          Pm[(size_t)b * nb + i] = r;
-          r += h[u][i];
-        }
-        h[u][i] = 0;  // (for the next step)
+    if (live)
+      for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
+        const uint32_t r = run[i];
+        Pm[(size_t)b * nb + i] = r;
+        run[i] = r + h[i];
+        h[i] = 0;  // (for the next step)
       }
-      run[i] = r;
-    }
     lds_barrier();
   }
   for (int i = threadIdx.x; i < nb; i += kTileHistThreads) Tm[(size_t)blockIdx.x * nb + i] = run[i];
