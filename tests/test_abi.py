@@ -176,3 +176,21 @@ def test_host_hypot_is_cv_hypot():
         assert not bad.any(), (int(bad.sum()), a[bad][:3], b[bad][:3])
         differs_from_libm += int((got != libm).sum())
     assert differs_from_libm > 1000
+
+
+def test_round3_entry_points_validate_their_arguments(has_gpu):
+    """the entry points added in round 3 (event memory, fault injection, announced motion compensation)
+    refuse bad arguments with ESVIO_FE_EINVAL and never touch a device for that; without a GPU an
+    allocation fails with ESVIO_FE_EHIP and leaves the out-pointer null"""
+    L = FE.load_library()
+    p = C.c_void_p(1)
+    assert L.esvio_fe_mem_alloc(7, 64, C.byref(p)) == -1          # unknown memory space
+    assert L.esvio_fe_mem_alloc(FE.HOST, 64, None) == -1
+    assert L.esvio_fe_mem_free(7, None) == -1
+    assert L.esvio_fe_mem_free(FE.HOST, None) == 0                 # free(NULL)
+    assert L.esvio_fe_mem_upload(None, None, 0) == 0 and L.esvio_fe_mem_upload(None, None, 16) == -1
+    assert L.esvio_fe_debug_inject(None, 0) == -1 and L.esvio_fe_debug_counters(None, None) == -1
+    assert L.esvio_fe_set_next_batch_mc(None, 0.0, None, 0, None, 0, FE.HOST, 0, None) == -1
+    if not has_gpu:
+        q = C.c_void_p(1)
+        assert L.esvio_fe_mem_alloc(FE.HOST, 4096, C.byref(q)) == -3 and not q
