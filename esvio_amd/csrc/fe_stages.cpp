@@ -193,7 +193,7 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
   if (mc && !c->d_warp)  // the motion-compensated overload: 4 B per event for the warped pixels
     if (int rc = dev_alloc(c, &c->d_warp, c->part_cap)) return rc;
   const size_t nblk_cap = (c->part_cap + 2047) / 2048;  // (2048 events per scatter block at least)
-  const size_t head = (size_t)3 * kTileMaxBins + 64;
+  const size_t head = (size_t)3 * kTileMaxBins + 64 + 4 * (size_t)kTileMaxGroups;
   const size_t need = head + (nblk_cap + 2 * (size_t)kTileMaxGroups) * kTileMaxBins;
   if (need > c->tile_cap) {
     if (c->d_tile) (void)hipFree(c->d_tile);
@@ -201,12 +201,10 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
     c->tile_cap = 0;
     if (int rc = dev_alloc(c, &c->d_tile, need)) return rc;
     c->tile_cap = need;
-    // the record-format accumulators (kTileMeta*) live in the 32 free words behind tile_order
-    HIPCHK(c, hipMemsetAsync(c->d_tile + 3 * kTileMaxBins + 32, 0, 32 * 4, cur_stream(c)));
-    HIPCHK(c, hipMemsetAsync(c->d_tile + 3 * kTileMaxBins + 32 + kTileMetaSecMin, 0xff, 4, cur_stream(c)));
   }
   TileScratch sc;
-  sc.meta = c->d_tile + 3 * kTileMaxBins + 32;
+  sc.meta = c->d_tile + 3 * kTileMaxBins + 32;  // (the 32 free words behind tile_order)
+  sc.ranges = c->d_tile + 3 * kTileMaxBins + 64;
   sc.totals = c->d_tile;
   sc.tile_off = c->d_tile + kTileMaxBins;
   sc.tile_order = c->d_tile + 2 * kTileMaxBins + 32;
