@@ -1237,7 +1237,7 @@ __device__ __forceinline__ void tile_apply_body(
   const int x0 = tx * g.tw, y0 = ty * g.th;
   const int twsh = g.tw == 64 ? 6 : 5;
   const size_t P = (size_t)g.W * g.H;
-  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();  // (wave: scalar, so are the turn loop and the ticket poll)
   // (a wave's next turn is requested while it works on the current one; the first one together with
   // the tile's planes)
   typename Rec::T nxt[kTileTurn];
@@ -1295,37 +1295,79 @@ __device__ __forceinline__ void tile_apply_body(
       flg[k] = (valid ? 1u : 0u) | (pol ? 2u : 0u) | (bs ? 4u : 0u) | (bo ? 8u : 0u) |
                ((valid && (same & above) == 0) ? 16u : 0u);
     }
-    // ---- ordered part: after every earlier turn's
+    // ---- ordered part: after every earlier turn's.  Everything it needs is in registers before the
+    // wait (exec masks of the reads and writes, LDS addresses: the compiler otherwise computes
+    // addresses and predicates while the wave holds the ticket — in-kernel timers on the scene stream's
+    // largest buckets, 35 k events: 26 of a wave's 62 us were waiting for the ticket, ~0.45 us per
+    // hand-off), and the poll is wave-uniform: every lane reads the word, scalar branch.
+    static_assert(kTileTurn == 4, "the ordered section is written for 4 chunks");
+    typedef uint32_t lds_v4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) char lds_char;
+    const uint32_t ls0 = (uint32_t)(size_t)(lds_char*)(char*)Ls, sd0 = (uint32_t)(size_t)(lds_char*)(char*)&s_done;
+    unsigned long long rm[kTileTurn], wm[kTileTurn], svx;
+    uint32_t ra[kTileTurn], wa[kTileTurn];
+#pragma unroll
+    for (int k = 0; k < kTileTurn; k++) {
+      rm[k] = __ballot((flg[k] & 1u) && (flg[k] & 12u) != 12u);
+      wm[k] = __ballot((flg[k] & 16u) != 0);
+      ra[k] = ls0 + (pixk[k] << 4);
+      wa[k] = ra[k] + ((flg[k] & 2u) ? 8u : 0u);
+      __asm__ volatile("" : "+s"(rm[k]), "+s"(wm[k]), "+v"(ra[k]), "+v"(wa[k]));
+    }
     bool gave_up = false;
-    if (lane == 0) {
-      uint32_t spins = 0;
-      uint32_t d;
+    for (uint32_t spins = 0;;) {
+      const uint32_t d =
+          __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (d == turn) break;
       // (bounded: never hang the GPU.  A wave that gives up poisons the ticket, so that the block's
       // other waves give up at once instead of timing out one turn after the other; the host sees
       // *err and fails the call)
-      while ((d = __hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != turn) {
-        if (d == 0xffffffffu || ++spins > spin_limit) {  // (kSpinTicket polls)
+      if (d == 0xffffffffu || ++spins > spin_limit) {  // (kSpinTicket polls)
+        gave_up = true;
+        if (lane == 0) {
           *err = 2;
-          gave_up = true;
           __hip_atomic_store(&s_done, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          break;
         }
+        break;
       }
+      // (waves whose turn is not the next one poll slowly: the LDS pipe is the ticket holder's)
+      if (turn - d > 1u) __builtin_amdgcn_s_sleep(1);
     }
-    __builtin_amdgcn_wave_barrier();
-    __asm__ volatile("" ::: "memory");
+    // While the wave holds the ticket it issues nothing but the LDS instructions themselves: masks
+    // and addresses are operands, exec is switched by hand (reads: lanes that need the value from
+    // before the chunk; writes: the chunk's last event per (pixel, polarity)); the LDS executes a
+    // wave's instructions in order, so the ticket (last) becomes visible after the accesses, and the
+    // wait for the values read comes after it.
+    lds_v4 fv[kTileTurn];
+#pragma unroll
+    for (int k = 0; k < kTileTurn; k++) fv[k] = (lds_v4)(0u);
+    const unsigned long long l0m = __ballot(lane == 0 && !gave_up);  // (exec for the ticket store)
+    const uint32_t nxt_turn = turn + 1u;
+    __asm__ volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[r0]\n\tds_read_b128 %[f0], %[ra0]\n\t"
+        "s_mov_b64 exec, %[w0]\n\tds_write_b64 %[wa0], %[t0]\n\t"
+        "s_mov_b64 exec, %[r1]\n\tds_read_b128 %[f1], %[ra1]\n\t"
+        "s_mov_b64 exec, %[w1]\n\tds_write_b64 %[wa1], %[t1]\n\t"
+        "s_mov_b64 exec, %[r2]\n\tds_read_b128 %[f2], %[ra2]\n\t"
+        "s_mov_b64 exec, %[w2]\n\tds_write_b64 %[wa2], %[t2]\n\t"
+        "s_mov_b64 exec, %[r3]\n\tds_read_b128 %[f3], %[ra3]\n\t"
+        "s_mov_b64 exec, %[w3]\n\tds_write_b64 %[wa3], %[t3]\n\t"
+        "s_mov_b64 exec, %[l0]\n\tds_write_b32 %[sd], %[nx]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [sv] "=&s"(svx), [f0] "+v"(fv[0]), [f1] "+v"(fv[1]), [f2] "+v"(fv[2]), [f3] "+v"(fv[3])
+        : [r0] "s"(rm[0]), [r1] "s"(rm[1]), [r2] "s"(rm[2]), [r3] "s"(rm[3]), [w0] "s"(wm[0]), [w1] "s"(wm[1]),
+          [w2] "s"(wm[2]), [w3] "s"(wm[3]), [l0] "s"(l0m), [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [ra2] "v"(ra[2]),
+          [ra3] "v"(ra[3]), [wa0] "v"(wa[0]), [wa1] "v"(wa[1]), [wa2] "v"(wa[2]), [wa3] "v"(wa[3]), [t0] "v"(tk[0]),
+          [t1] "v"(tk[1]), [t2] "v"(tk[2]), [t3] "v"(tk[3]), [sd] "v"(sd0), [nx] "v"(nxt_turn)
+        : "memory");
     double2 fb[kTileTurn];
 #pragma unroll
     for (int k = 0; k < kTileTurn; k++) {
-      fb[k] = make_double2(0, 0);
-      if ((flg[k] & 1u) && (flg[k] & 12u) != 12u) fb[k] = Ls[pixk[k]];
-      __asm__ volatile("" ::: "memory");
-      if (flg[k] & 16u) ((double*)&Ls[pixk[k]])[(flg[k] >> 1) & 1u] = tk[k];
-      __asm__ volatile("" ::: "memory");
+      fb[k].x = __hiloint2double((int)fv[k].y, (int)fv[k].x);
+      fb[k].y = __hiloint2double((int)fv[k].w, (int)fv[k].z);
     }
-    // (LDS executes a wave's instructions in order: the ticket becomes visible after the accesses above)
-    if (lane == 0 && !gave_up)
-      __hip_atomic_store(&s_done, turn + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // ---- unordered again
 #pragma unroll
     for (int k = 0; k < kTileTurn; k++) {
