@@ -1,4 +1,7 @@
-# A/B of library variants under gpurun_ab/ through the SAE microbench (rocprofv3 kernel trace)
+# A/B of library variants under gpurun_ab/ through the SAE microbench (rocprofv3 kernel trace).  Build the
+# variants here (hipcc with the flags of esvio_amd/build.py + -DSOME_MACRO=n -o gpurun_ab/lib_<name>.so), then
+#   gpurun -- 'bash tools/ab_sae.sh'            (STREAMS="scene poisson" by default)
+# The library in place is restored at the end; gpurun_ab/ is scratch (git-ignored).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cp $R/esvio_amd/libesvio_fe.so /tmp/lib_orig.so

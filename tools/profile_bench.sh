@@ -34,5 +34,16 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE -d $O/c5w -o c5w -- $CMD5 > $O/c5w.log 2>
 T5=$(find $O/c5 -name "*.db" | head -1); F5=$(find $O/c5f -name "*.db" | head -1); W5=$(find $O/c5w -name "*.db" | head -1)
 python tools/rocprof_summary.py --trace $T5 --pmc FETCH_SIZE=$F5 --pmc WRITE_SIZE=$W5 --out $R/gpurun_out/${TAG}_c5shape --note "$TAG, C5's sensor shape on one GPU: $CMD5 (1280x720 stereo, 100 Mev/s per camera, 6.7 M events per step), MI355X" > /dev/null
 grep -h '"value"' $O/c5.log | cut -c1-160
+# the event-proportional chain alone at C5's batch size (tools/sae_microbench.py), scene and uniform stream
+for st in scene poisson; do
+  CMDS="python tools/sae_microbench.py --stream $st --iters 24"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/sae_$st -o sae -- $CMDS > $O/sae_$st.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/saef_$st -o saef -- $CMDS > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/saew_$st -o saew -- $CMDS > /dev/null 2>&1
+  TS=$(find $O/sae_$st -name "*.db" | head -1); FS=$(find $O/saef_$st -name "*.db" | head -1); WS=$(find $O/saew_$st -name "*.db" | head -1)
+  python tools/rocprof_summary.py --trace $TS --pmc FETCH_SIZE=$FS --pmc WRITE_SIZE=$WS --out $R/gpurun_out/${TAG}_sae_microbench_$st --note "$TAG: $CMDS (1280x720 stereo, 6.7 M events per batch, device-resident; createSAE_left/right only), MI355X" > /dev/null
+  grep -h "events per batch" $O/sae_$st.log; grep "k_tile" $R/gpurun_out/${TAG}_sae_microbench_$st.md | cut -c1-120
+  rm -rf $O/sae_$st $O/saef_$st $O/saew_$st
+done
 head -30 $R/gpurun_out/${TAG}_bench_c3_replay_timeline.txt
 rm -rf $O/trace $O/plain $O/fetch $O/write $O/c5 $O/c5f $O/c5w
