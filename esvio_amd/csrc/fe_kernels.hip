@@ -968,9 +968,12 @@ void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const Eve
 // LDS executes a wave's instructions in order) and has the set of lanes that share its bucket; the
 // lowest of them adds the group to the wave's running count and clears the mask again.  ~25
 // instructions per round.  32-bit masks, so a round is two half-rounds of 32 lanes.
-// LDS: masks 32 KiB + 16-bit running counts 16 KiB + bucket starts and bases 16 KiB: two blocks per
-// CU; the grid is 2 blocks per CU at most, each block walks over its scatter blocks (the masks are zero
-// again after every round, the bucket starts are computed once per block).
+// LDS: {mask, running count} pairs, 8 B per (wave, bucket) — the half-round reads both with one
+// ds_read_b64 and the group's lowest lane writes both back with one ds_write_b64 (separate words, the
+// count 16 bits wide, were 5 LDS instructions per half-round instead of 3: 73.7 -> 71.1 us at C5) —
+// + the bases: 36 B per bucket, 65 KiB at 1841 buckets: two blocks per CU, which is what the ~200
+// VGPRs allow anyway; the grid is 2 blocks per CU at most, each block walks over its scatter blocks (the
+// masks are zero again after every round, the bucket starts are computed once per block).
 constexpr int kTileScatterMaxGrid = 512;  // (<= 2 resident blocks per CU: ~200 VGPRs with the prefetched records)
 template <int ROUNDS, bool MC>
 __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
@@ -978,20 +981,19 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
     uint32_t group, uint32_t nblk, const uint32_t* __restrict__ Pm, const uint32_t* __restrict__ Cm,
     const uint32_t* __restrict__ totals, uint4* __restrict__ part, uint32_t* __restrict__ tile_off,
     uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ warp_xy, const uint32_t* __restrict__ meta) {
-  // LDS, sized by the bucket count (nbp = nbins rounded up to 64): masks [4][nbp] u32 | bases [nbp] u32
-  // (first position of the current scatter block per bucket) | running counts [4][nbp] u16
-  // = 28 B per bucket: 52 KiB at 1841 buckets, three blocks per CU
-  extern __shared__ uint32_t scatter_lds[];
+  // LDS, sized by the bucket count (nbp = nbins rounded up to 64): {mask, running count} [4][nbp] 8 B
+  // (one ds_read_b64 / ds_write_b64 per half-round instead of separate words) | bases [nbp] u32
+  // (first position of the current scatter block per bucket) = 36 B per bucket: 65 KiB at 1841 buckets
+  extern __shared__ __attribute__((aligned(16))) uint32_t scatter_lds[];
   const int nb = g.nbins, nbp = (nb + 63) & ~63;
-  uint32_t* mask_s = scatter_lds;                       // [wave * nbp + bucket]
-  uint32_t* bin_base = scatter_lds + 4 * nbp;
-  uint16_t* cnt_s = (uint16_t*)(scatter_lds + 5 * nbp);  // [wave * nbp + bucket]
+  uint2* mc_s = (uint2*)scatter_lds;                    // [wave * nbp + bucket]
+  uint32_t* bin_base = scatter_lds + 8 * nbp;
   __shared__ uint32_t wave_tot[4];
   constexpr int TE = kTileScatterThreads * ROUNDS;
   constexpr int KB = kTileMaxBins / kTileScatterThreads;  // bins per thread (8)
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const uint32_t n = nL + nR;
-  for (int i = threadIdx.x; i < 4 * nbp; i += kTileScatterThreads) mask_s[i] = 0;
+  for (int i = threadIdx.x; i < 2 * nbp; i += kTileScatterThreads) ((uint4*)mc_s)[i] = make_uint4(0, 0, 0, 0);
   uint32_t bstart[KB];  // bucket offsets into `part` of buckets threadIdx.x + k * 256
   // ---- once per block: exclusive scan of the bucket totals (thread t owns bins [t*KB, t*KB+KB))
   {
@@ -1100,8 +1102,8 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
   if (t_first < t_end) request(t_first);
   __syncthreads();  // (the set-up above)
   for (uint32_t tile = t_first; tile < t_end; tile += t_step) {
-    lds_barrier();  // (the previous scatter block's reads of cnt_s / bin_base)
-    for (int i = threadIdx.x; i < 2 * nbp; i += kTileScatterThreads) ((uint32_t*)cnt_s)[i] = 0;
+    lds_barrier();  // (the previous scatter block's reads of the counts / bin_base)
+    for (int i = threadIdx.x; i < 2 * nbp; i += kTileScatterThreads) ((uint4*)mc_s)[i] = make_uint4(0, 0, 0, 0);
     uint4 rec[ROUNDS];
     uint32_t dr[ROUNDS];  // bucket | rank inside (wave, bucket) << 16
     uint32_t pc[KB];
@@ -1111,7 +1113,7 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #pragma unroll
     for (int k = 0; k < KB; k++) pc[k] = npc[k];
     if (tile + t_step < t_end) request(tile + t_step);
-    lds_barrier();  // cnt_s is zero
+    lds_barrier();  // the counts are zero
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
       const uint32_t i = wbase + r * 64 + lane;
@@ -1121,16 +1123,12 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #pragma unroll
       for (int half = 0; half < 2; half++) {
         if (ok && (lane >> 5) == half) {
-          uint32_t* mp = mask_s + wave * nbp + d;
-          uint16_t* cp = cnt_s + wave * nbp + d;
-          atomicOr(mp, hbit);     // (no return value: ds_or_b32; the LDS takes a wave's instructions in
-          const uint32_t m = *mp;  //  order: the read sees every lane's bit)
-          const uint32_t c0 = *cp;
-          rank = c0 + __popc(m & hlt);
-          if ((m & hlt) == 0) {  // the group's lowest lane: count it, clear the mask for the next round
-            *cp = (uint16_t)(c0 + __popc(m));
-            *mp = 0;
-          }
+          uint2* q = mc_s + wave * nbp + d;
+          atomicOr(&q->x, hbit);  // (no return value: ds_or_b32; the LDS takes a wave's instructions in
+          const uint2 v = *q;      //  order: the read sees every lane's bit)
+          rank = v.y + __popc(v.x & hlt);
+          // the group's lowest lane: count it, clear the mask for the next round
+          if ((v.x & hlt) == 0) *q = make_uint2(0u, v.y + __popc(v.x));
         }
         // (the other half's ds_or must be ISSUED after these writes — the LDS then performs them in that
         // order; nothing has to wait for them)
@@ -1149,8 +1147,8 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
         uint32_t acc = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-          const uint32_t t = cnt_s[w * nbp + d];
-          cnt_s[w * nbp + d] = (uint16_t)acc;
+          const uint32_t t = mc_s[w * nbp + d].y;
+          mc_s[w * nbp + d].y = acc;
           acc += t;
         }
       }
@@ -1163,7 +1161,7 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
           const uint32_t d = dr[r] & 0xffffu;
-          part2[bin_base[d] + cnt_s[wave * nbp + d] + (dr[r] >> 16)] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
+          part2[bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16)] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
         }
       }
     } else {
@@ -1172,7 +1170,7 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
           const uint32_t d = dr[r] & 0xffffu;
-          part[bin_base[d] + cnt_s[wave * nbp + d] + (dr[r] >> 16)] = rec[r];
+          part[bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16)] = rec[r];
         }
       }
     }
@@ -1186,7 +1184,7 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
   const uint32_t nblk = tile_scatter_blocks(n), group = tile_hist_group(nblk);
   const bool big = tile_scatter_events_per_block(n) == 4096u;
   const uint32_t grid = std::min<uint32_t>(nblk, kTileScatterMaxGrid);
-  const unsigned lds = (unsigned)(((g.nbins + 63) & ~63) * 28);
+  const unsigned lds = (unsigned)(((g.nbins + 63) & ~63) * 36);
 #define ESVIO_TILE_SCATTER(R, M)                                                                          \
   launch_k(k_tile_scatter<R, M>, dim3(grid), dim3(kTileScatterThreads), lds, s, (const uint4*)evL, nL,    \
            (const uint4*)evR, nR, g, group, nblk, (const uint32_t*)sc.P, (const uint32_t*)sc.C,           \
