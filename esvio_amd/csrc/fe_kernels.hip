@@ -1353,6 +1353,7 @@ __device__ __forceinline__ void tile_apply_body(
         "s_mov_b64 exec, %[w3]\n\tds_write_b64 %[wa3], %[t3]\n\t"
         "s_mov_b64 exec, %[l0]\n\tds_write_b32 %[sd], %[nx]\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
+        "s_nop 4\n\t"  // (exec written by the SALU: 5 wait states before a DPP instruction may follow)
         "s_waitcnt lgkmcnt(0)"
         : [sv] "=&s"(svx), [f0] "+v"(fv[0]), [f1] "+v"(fv[1]), [f2] "+v"(fv[2]), [f3] "+v"(fv[3])
         : [r0] "s"(rm[0]), [r1] "s"(rm[1]), [r2] "s"(rm[2]), [r3] "s"(rm[3]), [w0] "s"(wm[0]), [w1] "s"(wm[1]),
