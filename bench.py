@@ -34,7 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 # stats label (esvio_fe_kernel_name) -> the kernel functions launched under it
 KERNEL_FUNCS = {
-    "k_sae_keys": ["k_sae_keys", "k_tile_hist", "k_tile_scan", "k_mc_warp"], "k_radix_pass": ["k_radix_pass", "k_tile_scatter"],
+    "k_sae_keys": ["k_sae_keys", "k_tile_hist", "k_mc_warp"], "k_tile_scan": ["k_tile_scan"],
+    "k_radix_pass": ["k_radix_pass", "k_tile_scatter"],
     "k_sae_apply": ["k_sae_apply", "k_sae_apply_ev", "k_sae_apply_ev_write", "k_tile_apply"],
     "k_time_surface": ["k_time_surface", "k_ts_pyr", "k_median"], "k_clahe": ["k_clahe_lut", "k_clahe_interp", "k_normalize"],
     "k_pyr_down": ["k_pyr_down"], "k_pyr_pad": ["k_pyr_pad"], "k_scharr": ["k_scharr", "k_pad_scharr"],
@@ -94,6 +95,8 @@ def parse():
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes for the all-cores CPU figure (-1 = os.cpu_count(), 0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-sae-pass", action="store_true",
+                    help="skip the event-proportional chain at C5's batch size (`sae_chain_c5_batch` in the line)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--stream", choices=["scene", "poisson"], default="scene",
                     help="scene (default): edges of a static scene seen from a moving stereo rig plus 7 %% Poisson "
@@ -599,6 +602,53 @@ def main():
                         note="lk_accum 2: LK sums in float in the order of the reference's x86 OpenCV build "
                              "(bit-exact against the oracle's float-order mode); never `value`")
 
+    # ---- the HBM-bound kernels at a batch size where they are HBM-bound: createSAE_left/right of one
+    # stereo batch at C5's sensor shape and rate (1280x720, 100 Mev/s per camera: 6.7 M events), device
+    # resident, nothing else running; per-launch HIP-event pairs on the launching stream (the library's
+    # own, ~2 us of each figure is the pair).  SURVEY.md section 8d's accounting: ingest 16 B/event
+    # (k_tile_hist), SAE update 32 B/event (k_tile_apply); the partition's own traffic is extra.
+    sae_chain = None
+    if rank == 0 and world == 1 and not args.no_sae_pass:
+        sae_chain = {"note": "createSAE_left/right alone, 1280x720 stereo, 100 Mev/s per camera, one 1/30 s batch per launch "
+                             "chain; HIP-event pairs around every launch; algorithmic bytes per SURVEY 8d "
+                             "(k_tile_scatter: its own 16 B in + 8 B out per event, not in SURVEY's table)"}
+        for sname, cls in (("scene", SceneStream), ("uniform", PoissonStream)):
+            st5 = cls(1280, 720, rate=1e8, seed=12345)
+            bat = []
+            for _ in range(2):
+                L5, R5, _t = st5.next_batch()
+                bat.append((FE.EventBuffer(L5, FE.DEVICE), FE.EventBuffer(R5, FE.DEVICE), len(L5) + len(R5)))
+            ft5 = FE.FeatureTracker(FE.make_config(1280, 720))
+            for b5 in bat:  # (buffers grow)
+                ft5.detector.createSAE_stereo(b5[0].arg, b5[1].arg)
+            ft5.set_profiling(True)
+            ft5.reset_kernel_stats()
+            n5, ev5 = 16, 0
+            for i in range(n5):
+                b5 = bat[i % len(bat)]
+                ft5.detector.createSAE_stereo(b5[0].arg, b5[1].arg)
+                ev5 += b5[2]
+            ks5 = ft5.kernel_stats()
+            ft5.close()
+            for b5 in bat:
+                b5[0].free()
+                b5[1].free()
+            per = ev5 / n5
+            row, tot = {}, 0.0
+            for label, func, bpe in (("k_sae_keys", "k_tile_hist", 16), ("k_tile_scan", "k_tile_scan", 0),
+                                     ("k_radix_pass", "k_tile_scatter", 24), ("k_sae_apply", "k_tile_apply", 32)):
+                v = ks5.get(label)
+                if not v or not v["launches"]:
+                    continue
+                us = v["ms"] / v["launches"] * 1e3
+                tot += us
+                row[func] = dict(avg_launch_us=round(us, 2), alg_bytes_per_launch=int(bpe * per),
+                                 achieved_GBs=round(bpe * per / us / 1e3, 1),
+                                 frac=round(bpe * per / us / 1e3 / HBM_PEAK_GBS, 4))
+            row["chain"] = dict(us=round(tot, 2), events_per_batch=int(per), alg_bytes=int(48 * per),
+                                achieved_GBs=round(48 * per / tot / 1e3, 1), frac=round(48 * per / tot / 1e3 / HBM_PEAK_GBS, 4))
+            sae_chain[sname] = row
+
     # ---- CPU baseline: the oracle (single-threaded port of the reference path) on a bounded sample
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:  # (the CPU baseline is an N = 1 figure)
@@ -734,6 +784,7 @@ def main():
             "lk_modes": lk_modes,
             "host_ransac": host_ransac,
             "roofline": roof,
+            "sae_chain_c5_batch": sae_chain,
             "cpu_baseline": cpu,
             "kernels": kernels,
             "kernels_replay_schedule": kernels_pipe,

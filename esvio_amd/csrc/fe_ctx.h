@@ -66,7 +66,7 @@ struct IdMap {
 const char* const kKernelNames[K_COUNT] = {
     "k_sae_keys", "k_radix_pass", "k_sae_apply",
     "k_time_surface", "k_clahe", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select",
-    "k_arc_map"};
+    "k_arc_map", "k_tile_scan"};
 
 struct KStat {
   double ms = 0;

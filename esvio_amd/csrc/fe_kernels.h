@@ -93,6 +93,7 @@ enum KernelId {
   K_COMPACT,
   K_SELECT,
   K_ARC_MAP,
+  K_TILE_SCAN,
   K_COUNT
 };
 
@@ -184,12 +185,15 @@ struct TileScratch {
   uint32_t* T;         // [ngroups][nbins] bucket counts per group
   uint32_t* C;         // [ngroups][nbins] ... of all earlier groups
 };
-// k_tile_hist + k_tile_scan: P, C, totals; out-of-sensor events added to *n_rejected
+// k_tile_hist: P, T and the blocks' ranges; launch_tile_scan: C, totals, the record format; out-of-sensor
+// events added to *n_rejected
 // mc (optional, enabled): the motion-compensated overload — buckets by the warped pixel, which is kept
 // in warp_xy[nL + nR] for launch_tile_scatter
 void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
                       const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected,
                       const struct McParams* mc = nullptr, uint32_t* warp_xy = nullptr);
+void launch_tile_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc,
+                      unsigned long long* n_rejected);
 // stable partition of [left; right] into `part` by bucket (warp_xy non-null: the records get the
 // warped pixels launch_tile_hist computed)
 void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,

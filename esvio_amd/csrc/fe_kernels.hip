@@ -950,6 +950,12 @@ void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const Eve
     launch_k(k_tile_hist<false>, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
              te, nblk, group, sc.P, sc.T, (const uint32_t*)nullptr, (uint4*)sc.ranges);
   }
+}
+
+void launch_tile_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc,
+                      unsigned long long* n_rejected) {
+  if (!n) return;
+  const uint32_t nblk = tile_scatter_blocks(n), group = tile_hist_group(nblk), nseg = (nblk + group - 1) / group;
   static const int force_wide = getenv("ESVIO_FE_WIDE_RECORDS") ? 1 : 0;  // (A/B and tests)
   static_assert(kTileMaxGroups <= (uint32_t)(kTileScanPer * kTileScanRanges), "k_tile_scan covers every group");
   launch_k(k_tile_scan, dim3((g.nbins + kTileScanBins - 1) / kTileScanBins + 1), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,

@@ -216,6 +216,10 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
     launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected, mc, mc ? c->d_warp : nullptr);
   }
   {
+    ScopedKernel k(c, K_TILE_SCAN, 0);  // (the count matrices: not in SURVEY's accounting)
+    launch_tile_scan(cur_stream(c), n, c->tgeom, sc, c->d_rejected);
+  }
+  {
     ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 16 B in, 16 B out
     launch_tile_scatter(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_part, mc ? c->d_warp : nullptr);
   }
