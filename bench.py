@@ -783,7 +783,11 @@ def main():
             "float_order_lk": float_lk,
             "lk_modes": lk_modes,
             "host_ransac": host_ransac,
-            "roofline": roof,
+            "roofline": (dict(roof, hbm_bound_kernels="sae_chain_c5_batch: k_tile_hist %.0f %%, k_tile_apply %.0f %% of the HBM peak "
+                                                      "(uniform stream) at 6.7 M events per launch chain"
+                                                      % (100 * sae_chain["uniform"]["k_tile_hist"]["frac"],
+                                                         100 * sae_chain["uniform"]["k_tile_apply"]["frac"]))
+                         if roof and sae_chain and "uniform" in sae_chain and "k_tile_apply" in sae_chain["uniform"] else roof),
             "sae_chain_c5_batch": sae_chain,
             "cpu_baseline": cpu,
             "kernels": kernels,
