@@ -748,6 +748,13 @@ int esvio_fe_host_hypot(const double* x, const double* y, int n, double* out) {
   return ESVIO_FE_OK;
 }
 
+int esvio_fe_host_nullspace(const double* systems, int n, int lanes, double* f12, int32_t* redone) {
+  if (n < 0 || (n && (!systems || !f12))) return ESVIO_FE_EINVAL;
+  const int r = host::host_nullspace(systems, n, lanes, f12);
+  if (redone) *redone = r;
+  return ESVIO_FE_OK;
+}
+
 int esvio_fe_ransac_stats(uint64_t* out6, int reset) {
   if (!out6) return ESVIO_FE_EINVAL;
   const host::RansacStats r = host::ransac_stats(reset != 0);

@@ -332,6 +332,100 @@ void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
 #endif
 constexpr int kLanes = ESVIO_RANSAC_LANES;
 
+// The cyclic sweep (0,1),(0,2)..(5,6) taken as levels of pairs (i, j) with i + j = level: two rotations
+// that share no row commute exactly — each reads and writes only its own two rows and norms — and the
+// pairs containing a given row r come in the sweep's own order ((0,r)..(r-1,r),(r,r+1)..(r,6): i + j
+// strictly increasing), so every row goes through the same rotations in the same order with the same
+// operands as in the sequential sweep: the result is bit-identical.  What changes is the dependent
+// chain: a pair is dot product -> hypot -> sqrt/div -> rotation -> norms, ~200 cycles of latency with
+// the vector units idle in between; the pairs of a level are independent chains written side by
+// side (K per stage).  Levels 8..11 of a sweep leave rows 0..4 alone, so levels 1..4 of the NEXT
+// sweep go with them: 7 steps of 3 pairs per sweep instead of 21 of one.  (A sweep that turns out to
+// have rotated nothing ends the loop; the next sweep's pairs taken along with its last levels saw
+// the rows and norms this sweep's own tests saw and skipped like them, so nothing has run ahead.)
+
+// The Hestenes rotations of K row pairs that share no row, all lanes at once; bit q of the result:
+// some lane of pair q rotated.  (always_inline: the body is compiled for the ISA of the clone that calls it.)
+template <int K, int I0, int J0, int I1 = 0, int J1 = 0, int I2 = 0, int J2 = 0>
+static inline __attribute__((always_inline)) unsigned jacobi_pairs(double (*R)[9][kLanes], double (*W)[kLanes]) {
+  constexpr int M = 9, L = kLanes;
+  constexpr int ij[3][2] = {{I0, J0}, {I1, J1}, {I2, J2}};
+  constexpr double kEps = DBL_EPSILON * 10;
+  alignas(64) double p[K][L], lim[K][L];
+  alignas(64) int64_t on[K][L];
+  for (int q = 0; q < K; q++)
+    for (int l = 0; l < L; l++) p[q][l] = 0;
+  for (int k = 0; k < M; k++)
+    for (int q = 0; q < K; q++) {
+      const double* __restrict ri = R[ij[q][0]][k];
+      const double* __restrict rj = R[ij[q][1]][k];
+      for (int l = 0; l < L; l++) p[q][l] += ri[l] * rj[l];
+    }
+  unsigned rotated = 0;  // bit q: some lane of pair q rotates
+  for (int q = 0; q < K; q++) {
+    const double* __restrict wi = W[ij[q][0]];
+    const double* __restrict wj = W[ij[q][1]];
+    for (int l = 0; l < L; l++) lim[q][l] = kEps * std::sqrt(wi[l] * wj[l]);
+    int64_t any = 0;
+    for (int l = 0; l < L; l++) {
+      on[q][l] = !(std::fabs(p[q][l]) <= lim[q][l]) ? -1 : 0;
+      any |= on[q][l];
+    }
+    rotated |= any ? 1u << q : 0u;
+  }
+  if (!rotated) return 0;
+  alignas(64) double c[K][L], s[K][L], a[K][L], b[K][L];
+  for (int q = 0; q < K; q++) {
+    const double* __restrict wi = W[ij[q][0]];
+    const double* __restrict wj = W[ij[q][1]];
+    for (int l = 0; l < L; l++) {
+      const double p2 = p[q][l] * 2, beta = wi[l] - wj[l];
+      // gamma = cv_hypot(p2, beta) for the lanes that rotate: hi * sqrt(1 + (lo / hi)^2) with hi / lo the
+      // larger / smaller magnitude is the scalar routine's value on either of its branches (a lane
+      // that rotates has p != 0, so hi > 0); a lane that does not rotate computes on 1.0
+      const double x = on[q][l] ? std::fabs(p2) : 1.0, y = on[q][l] ? std::fabs(beta) : 1.0;
+      const double hi = x > y ? x : y, lo = x > y ? y : x;
+      const double r = lo / hi;
+      const double gamma = hi * std::sqrt(1 + r * r);
+      // beta < 0:  s = sqrt(((gamma - beta) * 0.5) / gamma),  c = p2 / (gamma * s * 2)
+      // else:      c = sqrt((gamma + beta) / (gamma * 2)),    s = p2 / (gamma * c * 2)
+      // — the lane's own branch, operands selected before the division (one sqrt and two divisions
+      // per lane instead of both branches' two and four)
+      const bool neg = beta < 0;
+      const double num = neg ? (gamma - beta) * 0.5 : gamma + beta;
+      const double den = neg ? gamma : gamma * 2;
+      const double first = std::sqrt(num / den);
+      const double second = p2 / (gamma * first * 2);
+      c[q][l] = neg ? second : first;
+      s[q][l] = neg ? first : second;
+      a[q][l] = 0;
+      b[q][l] = 0;
+    }
+  }
+  for (int k = 0; k < M; k++)
+    for (int q = 0; q < K; q++) {
+      double* __restrict ri = R[ij[q][0]][k];
+      double* __restrict rj = R[ij[q][1]][k];
+      for (int l = 0; l < L; l++) {
+        const double x = ri[l], y = rj[l];
+        const double t0 = c[q][l] * x + s[q][l] * y, t1 = -s[q][l] * x + c[q][l] * y;
+        ri[l] = on[q][l] ? t0 : x;
+        rj[l] = on[q][l] ? t1 : y;
+        a[q][l] += t0 * t0;
+        b[q][l] += t1 * t1;
+      }
+    }
+  for (int q = 0; q < K; q++) {
+    double* __restrict wi = W[ij[q][0]];
+    double* __restrict wj = W[ij[q][1]];
+    for (int l = 0; l < L; l++) {
+      wi[l] = on[q][l] ? a[q][l] : wi[l];
+      wj[l] = on[q][l] ? b[q][l] : wj[l];
+    }
+  }
+  return rotated;
+}
+
 ESVIO_SIMD_CLONES
 bool epipolar_nullspace_lanes(const double (*A)[7][9], double (*f1)[9], double (*f2)[9]) {
   constexpr int M = 9, N = 7, L = kLanes;
@@ -348,65 +442,38 @@ bool epipolar_nullspace_lanes(const double (*A)[7][9], double (*f1)[9], double (
       for (int l = 0; l < L; l++) sd[l] += R[i][k][l] * R[i][k][l];
     for (int l = 0; l < L; l++) W[i][l] = sd[l];
   }
-  for (int sweep = 0; sweep < 30; sweep++) {
-    bool changed = false;
-    for (int i = 0; i < N - 1; i++)
-      for (int j = i + 1; j < N; j++) {
-        alignas(64) double p[L], lim[L];
-        alignas(64) int64_t on[L];
-        for (int l = 0; l < L; l++) p[l] = 0;
-        for (int k = 0; k < M; k++)
-          for (int l = 0; l < L; l++) p[l] += R[i][k][l] * R[j][k][l];
-        for (int l = 0; l < L; l++) lim[l] = kEps * std::sqrt(W[i][l] * W[j][l]);
-        int64_t any = 0;
-        for (int l = 0; l < L; l++) {
-          on[l] = !(std::fabs(p[l]) <= lim[l]) ? -1 : 0;
-          any |= on[l];
-        }
-        if (!any) continue;
-        changed = true;
-        alignas(64) double beta[L], gamma[L], c[L], s[L], a[L], b[L];
-        for (int l = 0; l < L; l++) {
-          p[l] *= 2;
-          beta[l] = W[i][l] - W[j][l];
-          gamma[l] = 1;
-        }
-        // gamma = cv_hypot(p, beta) for the lanes that rotate: hi * sqrt(1 + (lo / hi)^2) with hi / lo the
-        // larger / smaller magnitude is the scalar routine's value on either of its branches (a lane
-        // that rotates has p != 0, so hi > 0)
-        for (int l = 0; l < L; l++) {
-          const double x = on[l] ? std::fabs(p[l]) : 1.0, y = on[l] ? std::fabs(beta[l]) : 1.0;
-          const double hi = x > y ? x : y, lo = x > y ? y : x;
-          const double r = lo / hi;
-          gamma[l] = hi * std::sqrt(1 + r * r);
-        }
-        for (int l = 0; l < L; l++) {  // both branches of the scalar code, the lane's own one kept
-          const double delta = (gamma[l] - beta[l]) * 0.5;
-          const double s_neg = std::sqrt(delta / gamma[l]);
-          const double c_neg = p[l] / (gamma[l] * s_neg * 2);
-          const double c_pos = std::sqrt((gamma[l] + beta[l]) / (gamma[l] * 2));
-          const double s_pos = p[l] / (gamma[l] * c_pos * 2);
-          const bool neg = beta[l] < 0;
-          c[l] = neg ? c_neg : c_pos;
-          s[l] = neg ? s_neg : s_pos;
-          a[l] = 0;
-          b[l] = 0;
-        }
-        for (int k = 0; k < M; k++)
-          for (int l = 0; l < L; l++) {
-            const double x = R[i][k][l], y = R[j][k][l];
-            const double t0 = c[l] * x + s[l] * y, t1 = -s[l] * x + c[l] * y;
-            R[i][k][l] = on[l] ? t0 : x;
-            R[j][k][l] = on[l] ? t1 : y;
-            a[l] += t0 * t0;
-            b[l] += t1 * t1;
-          }
-        for (int l = 0; l < L; l++) {
-          W[i][l] = on[l] ? a[l] : W[i][l];
-          W[j][l] = on[l] ? b[l] : W[j][l];
-        }
-      }
-    if (!changed) break;
+  // sweep 0, levels 1..4
+  unsigned cur = jacobi_pairs<1, 0, 1>(R, W);
+  cur |= jacobi_pairs<1, 0, 2>(R, W);
+  cur |= jacobi_pairs<2, 0, 3, 1, 2>(R, W);
+  cur |= jacobi_pairs<2, 0, 4, 1, 3>(R, W);
+  for (int sweep = 0; sweep < 30; sweep++) {  // max(m, 30)
+    cur |= jacobi_pairs<3, 0, 5, 1, 4, 2, 3>(R, W);  // levels 5..7
+    cur |= jacobi_pairs<3, 0, 6, 1, 5, 2, 4>(R, W);
+    cur |= jacobi_pairs<3, 1, 6, 2, 5, 3, 4>(R, W);
+    unsigned next = 0;
+    if (sweep + 1 < 30) {
+      // levels 8..11 of this sweep (the first pair(s)) with levels 1..4 of the next one
+      unsigned r = jacobi_pairs<3, 2, 6, 3, 5, 0, 1>(R, W);
+      cur |= r & 3u;
+      next |= r & 4u;
+      r = jacobi_pairs<3, 3, 6, 4, 5, 0, 2>(R, W);
+      cur |= r & 3u;
+      next |= r & 4u;
+      r = jacobi_pairs<3, 4, 6, 0, 3, 1, 2>(R, W);
+      cur |= r & 1u;
+      next |= r & 6u;
+      r = jacobi_pairs<3, 5, 6, 0, 4, 1, 3>(R, W);
+      cur |= r & 1u;
+      next |= r & 6u;
+    } else {
+      cur |= jacobi_pairs<2, 2, 6, 3, 5>(R, W);
+      cur |= jacobi_pairs<2, 3, 6, 4, 5>(R, W);
+      cur |= jacobi_pairs<1, 4, 6>(R, W);
+      cur |= jacobi_pairs<1, 5, 6>(R, W);
+    }
+    if (!cur) break;
+    cur = next;
   }
   for (int i = 0; i < N; i++) {
     alignas(64) double sd[L];
@@ -1069,6 +1136,29 @@ std::atomic<uint64_t> g_rs_calls{0}, g_rs_iters{0}, g_rs_points{0}, g_rs_ns{0}, 
 
 void host_hypot(const double* x, const double* y, int n, double* out) {
   for (int i = 0; i < n; i++) out[i] = cv_hypot(x[i], y[i]);
+}
+
+int host_nullspace(const double* A, int n, int lanes, double* f) {
+  if (!lanes) {
+    for (int i = 0; i < n; i++)
+      epipolar_nullspace((const double(*)[9])(A + (size_t)i * 63), f + (size_t)i * 18, f + (size_t)i * 18 + 9);
+    return 0;
+  }
+  int redone = 0;
+  for (int i0 = 0; i0 < n; i0 += kLanes) {
+    const int cnt = std::min(kLanes, n - i0);
+    double Al[kLanes][7][9], f1[kLanes][9], f2[kLanes][9];
+    for (int l = 0; l < kLanes; l++) std::memcpy(Al[l], A + (size_t)(i0 + (l < cnt ? l : 0)) * 63, sizeof(Al[l]));
+    if (!epipolar_nullspace_lanes(Al, f1, f2)) {  // (what seven_point_lanes does with such a group)
+      for (int l = 0; l < cnt; l++) epipolar_nullspace(Al[l], f1[l], f2[l]);
+      redone += cnt;
+    }
+    for (int l = 0; l < cnt; l++) {
+      std::memcpy(f + (size_t)(i0 + l) * 18, f1[l], sizeof(f1[l]));
+      std::memcpy(f + (size_t)(i0 + l) * 18 + 9, f2[l], sizeof(f2[l]));
+    }
+  }
+  return redone;
 }
 
 RansacStats ransac_stats(bool reset) {

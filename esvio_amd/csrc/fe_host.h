@@ -44,6 +44,11 @@ void ransac_pool_destroy(RansacPool* p);
 void ransac_pool_wake(RansacPool* p);  // a job is coming: helpers that went to sleep start spinning
 // test tap: the hypot the 7-point solver's Jacobi rotations use (cv::hypot of OpenCV's lapack.cpp)
 void host_hypot(const double* x, const double* y, int n, double* out);
+// test tap: run7Point's null-space basis (rows 7, 8 of cv::SVDecomp's Vt) of n 7x9 systems (63 doubles
+// each) -> f1 | f2 (18 doubles each), by the one-at-a-time routine (lanes = 0) or in groups of
+// vector lanes as the RANSAC loop solves them (lanes = 1; returns how many systems fell back to the
+// one-at-a-time routine)
+int host_nullspace(const double* A, int n, int lanes, double* f);
 // process-wide counters of find_fundamental_mat: its RANSAC branch (>= 15 points) — calls,
 // hypotheses replayed (the loop's iteration count), points, nanoseconds inside the call — and its
 // LMedS branch (8..14 points: a fixed 300 hypotheses) — calls, nanoseconds

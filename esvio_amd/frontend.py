@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "esvio_fe_set_next_batch", "esvio_fe_set_next_batch_mc", "esvio_fe_debug_inject", "esvio_fe_debug_counters",
     "esvio_fe_mem_alloc", "esvio_fe_mem_free", "esvio_fe_mem_upload", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
-    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot",
+    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot", "esvio_fe_host_nullspace",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
@@ -149,6 +149,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_set_host_threads.argtypes = [vp, i]
     L.esvio_fe_ransac_stats.argtypes = [vp, i]
     L.esvio_fe_host_hypot.argtypes = [vp, vp, i, vp]
+    L.esvio_fe_host_nullspace.argtypes = [vp, i, i, vp, C.POINTER(C.c_int32)]
     L.esvio_fe_find_fundamental_mat_mt.argtypes = [vp, vp, i, d, d, i, vp, C.POINTER(C.c_int32)]
     L.esvio_fe_finish.argtypes = [vp, vp]
     L.esvio_fe_get_time_surface.argtypes = [vp, i, vp]
@@ -637,6 +638,18 @@ class EventBuffer:
             load_library().esvio_fe_mem_free(self.space, self.ptr)
             self.ptr = None
             self.array = None
+
+
+def host_nullspace(systems, lanes):
+    """run7Point's null-space basis of n 7x9 systems -> (f[n, 2, 9], systems redone one at a time);
+    lanes False: the one-at-a-time routine, True: the vector-lane form the RANSAC loop uses"""
+    a = np.ascontiguousarray(systems, np.float64).reshape(-1, 7, 9)
+    f = np.empty((a.shape[0], 2, 9), np.float64)
+    redone = C.c_int32(0)
+    rc = load_library().esvio_fe_host_nullspace(_p(a), a.shape[0], int(bool(lanes)), _p(f), C.byref(redone))
+    if rc != 0:
+        raise FrontendError("host_nullspace rc=%d" % rc)
+    return f, redone.value
 
 
 def host_hypot(x, y):

@@ -169,6 +169,13 @@ int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, do
  * unqualified inside namespace cv, which resolves to lapack.cpp's own a*sqrt(1+(b/a)^2) template, not
  * to libm's; IEEE operations only, so the result does not depend on the host's libm. */
 int esvio_fe_host_hypot(const double* x, const double* y, int n, double* out);
+/* Test tap: the basis of the 7x9 epipolar system's null space that run7Point takes from
+ * cv::SVDecomp(A, W, U, Vt, MODIFY_A + FULL_UV) (rows 7 and 8 of Vt; OpenCV calib3d/fundam.cpp, reached
+ * from feature_tracker.cpp:935), for n systems of 63 doubles -> f12 = n x (f1[9] | f2[9]).  lanes = 0:
+ * one system at a time; lanes != 0: side by side in vector lanes with the sweep's independent row pairs
+ * scheduled together, as the RANSAC loop solves its hypotheses — both must give the same bits.
+ * *redone (may be NULL) = systems the lane form handed back to the one-at-a-time routine. */
+int esvio_fe_host_nullspace(const double* systems, int n, int lanes, double* f12, int32_t* redone);
 /* Measurement tap: process-wide counters of that function since the last reset — out6 = {calls,
  * loop iterations, points, nanoseconds inside the calls} of its RANSAC branch (>= 15 points) and
  * {calls, nanoseconds} of its LMedS branch (8..14 points, what OpenCV runs below 15). */
