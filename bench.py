@@ -335,7 +335,7 @@ def main():
         else:
             # a small share (8 ranks on a 16-CPU quota: 2 each): never more threads than CPUs — a helper
             # that loses its CPU stalls the job for a scheduler quantum (measured on 2 CPUs: 4 threads
-            # 0.3-4.5 ms per step, 2 threads 0.133, 1 thread 0.165) — and helpers that block between jobs
+            # 0.3-4.5 ms per step, 2 threads 0.133 -> 0.123, 1 thread 0.165 -> 0.15-0.157) — and helpers that block between jobs
             # (30 us of idle spin; the wake-up at the start of a published frame's call has them back
             # before the RANSAC begins), so that they do not burn the quota while idle
             args.host_threads = max(1, int(share))
