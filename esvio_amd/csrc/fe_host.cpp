@@ -187,6 +187,13 @@ struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-
 // Restated from the published source, unpinned like every OpenCV restatement here.  IEEE division,
 // square root, multiply and add only (mul and add stay separate: -ffp-contract=off): no libm, so the
 // value does not depend on the host's glibc, and the same code runs in the vector lanes.
+// JacobiSVDImpl_'s sweep limit, max(m, 30) = 30 for the 7x9 system.  (A macro only so that
+// tests/jacobi_cap_check.cpp can make the limit bite: real systems converge in ~5 sweeps.)
+#ifndef ESVIO_JACOBI_MAX_SWEEPS
+#define ESVIO_JACOBI_MAX_SWEEPS 30
+#endif
+constexpr int kJacobiMaxSweeps = ESVIO_JACOBI_MAX_SWEEPS;
+
 inline double cv_hypot(double a, double b) {
   a = std::fabs(a);
   b = std::fabs(b);
@@ -229,7 +236,7 @@ void epipolar_nullspace(const double A[7][9], double f1[9], double f2[9]) {
     for (int k = 0; k < M; k++) sd += R[i][k] * R[i][k];
     W[i] = sd;
   }
-  for (int sweep = 0; sweep < 30; sweep++) {  // max(m, 30)
+  for (int sweep = 0; sweep < kJacobiMaxSweeps; sweep++) {  // max(m, 30)
     bool changed = false;
     for (int i = 0; i < N - 1; i++)
       for (int j = i + 1; j < N; j++) {
@@ -447,12 +454,12 @@ bool epipolar_nullspace_lanes(const double (*A)[7][9], double (*f1)[9], double (
   cur |= jacobi_pairs<1, 0, 2>(R, W);
   cur |= jacobi_pairs<2, 0, 3, 1, 2>(R, W);
   cur |= jacobi_pairs<2, 0, 4, 1, 3>(R, W);
-  for (int sweep = 0; sweep < 30; sweep++) {  // max(m, 30)
+  for (int sweep = 0; sweep < kJacobiMaxSweeps; sweep++) {  // max(m, 30)
     cur |= jacobi_pairs<3, 0, 5, 1, 4, 2, 3>(R, W);  // levels 5..7
     cur |= jacobi_pairs<3, 0, 6, 1, 5, 2, 4>(R, W);
     cur |= jacobi_pairs<3, 1, 6, 2, 5, 3, 4>(R, W);
     unsigned next = 0;
-    if (sweep + 1 < 30) {
+    if (sweep + 1 < kJacobiMaxSweeps) {
       // levels 8..11 of this sweep (the first pair(s)) with levels 1..4 of the next one
       unsigned r = jacobi_pairs<3, 2, 6, 3, 5, 0, 1>(R, W);
       cur |= r & 3u;

@@ -92,6 +92,23 @@ def test_lane_form_is_the_one_at_a_time_form_bit_for_bit(oracle):
         assert np.abs(a[t] @ f.T).max() <= 1e-9 * np.abs(a[t]).max()
 
 
+@pytest.mark.parametrize("limit", [2, 4])
+def test_lane_form_at_the_sweep_limit(tmp_path, limit):
+    """OpenCV's limit of 30 Jacobi sweeps is never reached by real systems (~5 sweeps); the lane form
+    overlaps consecutive sweeps, so its behaviour AT the limit is checked with the limit lowered:
+    tests/jacobi_cap_check.cpp compiles fe_host.cpp with -DESVIO_JACOBI_MAX_SWEEPS and compares the two
+    forms' bits on 2003 systems that have not converged by then."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "jacobi_cap_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fno-math-errno", "-pthread",
+                           "-DESVIO_JACOBI_MAX_SWEEPS=%d" % limit, "-I" + os.path.join(here, "..", "include"),
+                           os.path.join(here, "jacobi_cap_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "identical" in out.stdout, out.stdout + out.stderr
+
+
 def _cv_rng_signs(count, state=0x12345678):
     out = []
     for _ in range(count):
