@@ -457,6 +457,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    prime_ms = float(os.environ.get("ESVIO_BENCH_PRIME_MS", "0"))
+    if prime_ms > 0 and xdev == "cuda":  # (experiment: the device kept busy before the warm-up steps)
+        xprime = torch.ones(1 << 24, device="cuda")
+        tp = time.perf_counter()
+        while time.perf_counter() - tp < prime_ms / 1e3:
+            for _ in range(20):
+                xprime.mul_(1.0)
+            torch.cuda.synchronize()
+        del xprime
+    step_times = [] if os.environ.get("ESVIO_BENCH_STEP_TIMES") else None
+    # The interpreter's cyclic garbage collector is kept out of the warm-up and the timed passes (what
+    # timeit does): the set-up above leaves ~10^5 tracked objects (batches, arrays, ctypes wrappers) and a
+    # full collection walking them takes milliseconds — per-step timings (ESVIO_BENCH_STEP_TIMES=1)
+    # showed single steps of 1.8-7 ms at random places in otherwise 0.07-0.19 ms passes.  The step
+    # itself allocates no cycles; the collector is switched back on after the passes.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for i in range(args.warmup):
         main_run.step(i)
     # ---- the timed region: EXACTLY --steps steps (pass 0 is the headline); the same region is then
@@ -471,6 +490,8 @@ def main():
         lo = args.warmup + r * args.steps
         for i in range(lo, lo + args.steps):
             n_events += main_run.step(i)
+            if step_times is not None and r == 0:
+                step_times.append(time.perf_counter())
         if lazy:
             ft.finish(copy=False)  # the last published frame's deferred right-camera entries
         if exch is not None:
@@ -487,7 +508,11 @@ def main():
             dist.all_reduce(tot[1:2], op=dist.ReduceOp.MAX)
         passes.append((float(tot[0].item()), float(tot[1].item()), n_events))
         ransac_passes.append(FE.ransac_stats())
+    gc.enable()
     total_events, max_elapsed, n_events = passes[0]
+    if step_times:
+        print("bench: pass 0 per-step ms:", " ".join("%.3f" % ((b - a) * 1e3) for a, b in zip(step_times, step_times[1:])),
+              file=sys.stderr)
     n_tracks = (len(ft.ids), len(ft.ids_right))
     # rejectWithF_event's host RANSAC inside each timed pass (this rank)
     host_ransac = [None if not rs["calls"] else dict(
