@@ -471,7 +471,7 @@ def main():
     # timeit does): the set-up above leaves ~10^5 tracked objects (batches, arrays, ctypes wrappers) and a
     # full collection walking them takes milliseconds — per-step timings (ESVIO_BENCH_STEP_TIMES=1)
     # showed single steps of 1.8-7 ms at random places in otherwise 0.07-0.19 ms passes.  The step
-    # itself allocates no cycles; the collector is switched back on after the passes.
+    # itself allocates no cycles, and the process ends soon after.
     import gc
     gc.collect()
     gc.freeze()
@@ -508,8 +508,7 @@ def main():
             dist.all_reduce(tot[1:2], op=dist.ReduceOp.MAX)
         passes.append((float(tot[0].item()), float(tot[1].item()), n_events))
         ransac_passes.append(FE.ransac_stats())
-    gc.enable()
-    total_events, max_elapsed, n_events = passes[0]
+    total_events, max_elapsed, n_events = passes[0]  # (the collector stays off for the extra passes below too)
     if step_times:
         print("bench: pass 0 per-step ms:", " ".join("%.3f" % ((b - a) * 1e3) for a, b in zip(step_times, step_times[1:])),
               file=sys.stderr)

@@ -776,11 +776,15 @@ int mark_inliers(const float* m1, const float* m2, int n, const double* F, std::
 }
 
 // RANSAC scoring of one model over points held as double arrays: inlier flags + count for the
-// points [i0, i1) (FMEstimatorCallback::computeError + findInliers, element for element)
+// points [i0, i1) (FMEstimatorCallback::computeError + findInliers, element for element).
+// (Measured and dropped: deciding a point from bounds on d^2 against t (a^2 + b^2) and dividing only in
+// blocks that hold a point within 2^-20 of the threshold — same flags on 2.5 M points, but on the EPYC
+// 9575F, where a zmm division costs little, the extra compares made a RANSAC call slower: 44.6 -> 50.2
+// us on one thread, 10-11 -> 15 us of each bench step with 8.)
 ESVIO_SIMD_CLONES
-int score_block_exact(const double* __restrict x1, const double* __restrict y1, const double* __restrict x2,
-                      const double* __restrict y2, int i0, int i1, const double* F, float t,
-                      uint8_t* __restrict mask) {
+int score_block(const double* __restrict x1, const double* __restrict y1, const double* __restrict x2,
+                const double* __restrict y2, int i0, int i1, const double* F, float t,
+                uint8_t* __restrict mask) {
   const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7],
                F8 = F[8];
   int good = 0;
@@ -800,53 +804,6 @@ int score_block_exact(const double* __restrict x1, const double* __restrict y1, 
     const int f = err <= t;
     mask[i] = (uint8_t)f;
     good += f;
-  }
-  return good;
-}
-
-// The same flags without the two divisions per point.  The reference's test is
-//     (float)max(D1 * (1 / n1), D2 * (1 / n2)) <= t,   D = d * d, n = a * a + b * b   (all double, t a float).
-// With q = D / n exactly, the computed e = fl(D * fl(1 / n)) is q (1 + 3 u) at worst (u = 2^-53; n and D
-// inside [1e-200, 1e200] and t inside [1e-10, 1e10], so no product here leaves the normal range).  Hence
-//   D1 <= fl(t (1 - 2^-20) n1) and D2 <= fl(t (1 - 2^-20) n2)  =>  both e < t  =>  the rounded max is <= t: inlier;
-//   D1 >= fl(t (1 + 2^-20) n1) or  D2 >= fl(t (1 + 2^-20) n2)  =>  that e > t (1 + 2^-21), more than a float
-//                                                                ulp above t: its float is > t: outlier
-// (all values finite, so max() has no NaN case).  A point in neither class — within 2^-20 of the
-// threshold, or with a norm outside the range — makes the block go through score_block_exact; the
-// flags are the reference's either way.  (Zen 5: a zmm division is ~5x a multiplication; scoring was a
-// quarter of a RANSAC iteration.)
-std::atomic<uint64_t> g_score_fallbacks{0};  // blocks that held a point too close to the threshold (tests/score_check.cpp)
-ESVIO_SIMD_CLONES
-int score_block(const double* __restrict x1, const double* __restrict y1, const double* __restrict x2,
-                const double* __restrict y2, int i0, int i1, const double* F, float t,
-                uint8_t* __restrict mask) {
-  const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7],
-               F8 = F[8];
-  const double td = (double)t, tlo = td * (1 - 0x1p-20), thi = td * (1 + 0x1p-20);
-  if (!(td >= 1e-10 && td <= 1e10)) return score_block_exact(x1, y1, x2, y2, i0, i1, F, t, mask);
-  int good = 0, unsure = 0;
-  for (int i = i0; i < i1; i++) {
-    double a = F0 * x1[i] + F1 * y1[i] + F2;
-    double b = F3 * x1[i] + F4 * y1[i] + F5;
-    double c = F6 * x1[i] + F7 * y1[i] + F8;
-    const double n2 = a * a + b * b;
-    const double d2 = x2[i] * a + y2[i] * b + c;
-    a = F0 * x2[i] + F3 * y2[i] + F6;
-    b = F1 * x2[i] + F4 * y2[i] + F7;
-    c = F2 * x2[i] + F5 * y2[i] + F8;
-    const double n1 = a * a + b * b;
-    const double d1 = x1[i] * a + y1[i] * b + c;
-    const double D1 = d1 * d1, D2 = d2 * d2;
-    const int ranged = (n1 >= 1e-200) & (n1 <= 1e200) & (n2 >= 1e-200) & (n2 <= 1e200) & (D1 <= 1e200) & (D2 <= 1e200);
-    const int in = ranged & (D1 <= tlo * n1) & (D2 <= tlo * n2);
-    const int out = ranged & ((D1 >= thi * n1) | (D2 >= thi * n2));
-    unsure |= !(in | out);
-    mask[i] = (uint8_t)in;
-    good += in;
-  }
-  if (unsure) {
-    g_score_fallbacks.fetch_add(1, std::memory_order_relaxed);
-    return score_block_exact(x1, y1, x2, y2, i0, i1, F, t, mask);
   }
   return good;
 }
