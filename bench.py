@@ -457,16 +457,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    prime_ms = float(os.environ.get("ESVIO_BENCH_PRIME_MS", "0"))
-    if prime_ms > 0 and xdev == "cuda":  # (experiment: the device kept busy before the warm-up steps)
-        xprime = torch.ones(1 << 24, device="cuda")
-        tp = time.perf_counter()
-        while time.perf_counter() - tp < prime_ms / 1e3:
-            for _ in range(20):
-                xprime.mul_(1.0)
-            torch.cuda.synchronize()
-        del xprime
-    step_times = [] if os.environ.get("ESVIO_BENCH_STEP_TIMES") else None
+    step_times = [] if os.environ.get("ESVIO_BENCH_STEP_TIMES") else None  # (diagnostic: pass 0's per-step wall times to stderr)
     # The interpreter's cyclic garbage collector is kept out of the warm-up and the timed passes (what
     # timeit does): the set-up above leaves ~10^5 tracked objects (batches, arrays, ctypes wrappers) and a
     # full collection walking them takes milliseconds — per-step timings (ESVIO_BENCH_STEP_TIMES=1)
