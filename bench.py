@@ -479,6 +479,8 @@ def main():
         t0 = time.perf_counter()
         n_events = 0
         lo = args.warmup + r * args.steps
+        if step_times is not None and r == 0:
+            step_times.append(t0)
         for i in range(lo, lo + args.steps):
             n_events += main_run.step(i)
             if step_times is not None and r == 0:
@@ -493,6 +495,8 @@ def main():
         if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if step_times is not None and r == 0:
+            step_times.append(t0 + elapsed)  # (last entry: finish() + the closing synchronize)
         tot = torch.tensor([float(n_events), elapsed], dtype=torch.float64, device=xdev)
         if multi:
             dist.all_reduce(tot[0:1], op=dist.ReduceOp.SUM)
