@@ -179,6 +179,13 @@ struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-
   int uniform(int lo, int hi) { return lo == hi ? lo : (int)(next() % (unsigned)(hi - lo) + lo); }
 };
 
+// JacobiSVDImpl_'s sweep limit, max(m, 30) = 30 for the 7x9 system.  (A macro only so that
+// tests/jacobi_cap_check.cpp can make the limit bite: real systems converge in ~5 sweeps.)
+#ifndef ESVIO_JACOBI_MAX_SWEEPS
+#define ESVIO_JACOBI_MAX_SWEEPS 30
+#endif
+constexpr int kJacobiMaxSweeps = ESVIO_JACOBI_MAX_SWEEPS;
+
 // cv::hypot [OpenCV 4.2 core/src/lapack.cpp]: JacobiSVDImpl_'s `hypot((double)p, beta)` is an
 // unqualified call inside namespace cv, where the file's own
 //     template<typename _Tp> static inline _Tp hypot(_Tp a, _Tp b)
@@ -187,13 +194,6 @@ struct OcvRng {  // cv::RNG multiply-with-carry generator, seeded with (uint64)-
 // Restated from the published source, unpinned like every OpenCV restatement here.  IEEE division,
 // square root, multiply and add only (mul and add stay separate: -ffp-contract=off): no libm, so the
 // value does not depend on the host's glibc, and the same code runs in the vector lanes.
-// JacobiSVDImpl_'s sweep limit, max(m, 30) = 30 for the 7x9 system.  (A macro only so that
-// tests/jacobi_cap_check.cpp can make the limit bite: real systems converge in ~5 sweeps.)
-#ifndef ESVIO_JACOBI_MAX_SWEEPS
-#define ESVIO_JACOBI_MAX_SWEEPS 30
-#endif
-constexpr int kJacobiMaxSweeps = ESVIO_JACOBI_MAX_SWEEPS;
-
 inline double cv_hypot(double a, double b) {
   a = std::fabs(a);
   b = std::fabs(b);

@@ -115,4 +115,3 @@ def test_degenerate_inputs(oracle):
     for name, f in _impls(oracle):
         cnt, status = f(p1, p2)
         assert status[truth == 1].all(), name  # (outliers of a planar scene may fit the chosen F)
-
