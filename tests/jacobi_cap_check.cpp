@@ -24,6 +24,10 @@ int main() {
   host_nullspace(A.data(), n, 0, one.data());
   const int redone = host_nullspace(A.data(), n, 1, lanes.data());
   const bool same = std::memcmp(one.data(), lanes.data(), one.size() * sizeof(double)) == 0;
-  std::printf("sweep limit %d: %s (%d systems redone one at a time)\n", kJacobiMaxSweeps, same ? "identical" : "DIFFERENT", redone);
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over the basis' bytes: compared across builds for other vector widths
+  const unsigned char* bytes = (const unsigned char*)lanes.data();
+  for (size_t i = 0; i < lanes.size() * sizeof(double); i++) h = (h ^ bytes[i]) * 1099511628211ull;
+  std::printf("sweep limit %d: %s (%d systems redone one at a time) basis %016llx\n", kJacobiMaxSweeps,
+              same ? "identical" : "DIFFERENT", redone, (unsigned long long)h);
   return same && redone == 0 ? 0 : 1;
 }

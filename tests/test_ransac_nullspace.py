@@ -92,21 +92,31 @@ def test_lane_form_is_the_one_at_a_time_form_bit_for_bit(oracle):
         assert np.abs(a[t] @ f.T).max() <= 1e-9 * np.abs(a[t]).max()
 
 
-@pytest.mark.parametrize("limit", [2, 4])
-def test_lane_form_at_the_sweep_limit(tmp_path, limit):
+@pytest.mark.parametrize("limit,isa", [(2, []), (4, []), (30, []), (30, ["-DESVIO_NO_SIMD_CLONES"]),
+                                       (30, ["-DESVIO_NO_SIMD_CLONES", "-mavx2"]), (3, ["-DESVIO_NO_SIMD_CLONES", "-mavx2"])])
+def test_lane_form_at_the_sweep_limit_and_on_other_vector_widths(tmp_path, limit, isa):
     """OpenCV's limit of 30 Jacobi sweeps is never reached by real systems (~5 sweeps); the lane form
     overlaps consecutive sweeps, so its behaviour AT the limit is checked with the limit lowered:
     tests/jacobi_cap_check.cpp compiles fe_host.cpp with -DESVIO_JACOBI_MAX_SWEEPS and compares the two
-    forms' bits on 2003 systems that have not converged by then."""
+    forms' bits on 2003 systems that have not converged by then.  The same program without the
+    load-time ISA clones runs the lane form as plain SSE2 and as AVX2 code (every box here has AVX-512,
+    so the library's other two clones would otherwise never execute): mul and add stay separate in all
+    of them, so the bits may not depend on the vector width."""
     import os
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     exe = str(tmp_path / "jacobi_cap_check")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fno-math-errno", "-pthread",
-                           "-DESVIO_JACOBI_MAX_SWEEPS=%d" % limit, "-I" + os.path.join(here, "..", "include"),
-                           os.path.join(here, "jacobi_cap_check.cpp"), "-o", exe])
+                           "-DESVIO_JACOBI_MAX_SWEEPS=%d" % limit] + isa +
+                          ["-I" + os.path.join(here, "..", "include"), os.path.join(here, "jacobi_cap_check.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "identical" in out.stdout, out.stdout + out.stderr
+    if limit == 30:  # the same bits whatever the vector width (the clone this CPU picks / SSE2 / AVX2 builds against each other)
+        _BASIS_HASHES.append(out.stdout.split()[-1])
+        assert len(set(_BASIS_HASHES)) == 1, _BASIS_HASHES
+
+
+_BASIS_HASHES = []
 
 
 def _cv_rng_signs(count, state=0x12345678):
