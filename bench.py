@@ -141,6 +141,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="with one rank: still create the process group and run the track exchange "
                          "(all_gather over RCCL with world size 1) — exercises the N>1 code path on a 1-GPU box")
+    ap.add_argument("--no-reserve", action="store_true",
+                    help="do not size the handle's buffers up front (esvio_fe_reserve): they then grow inside the "
+                         "calls that first need them (A/B of the first-use allocation stalls)")
     ap.add_argument("--no-host-pass", action="store_true",
                     help="skip the extra pass with the events in host memory (host_resident_events)")
     ap.add_argument("--dist-backend", default="nccl",
@@ -164,6 +167,20 @@ def usable_cpus():
         except Exception:
             pass
     return n
+
+
+def cgroup_cpu_stat():
+    """(nr_throttled, throttled_usec) of this process's cgroup (CFS bandwidth control), or None"""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            kv = dict(l.split()[:2] for l in open(path).read().splitlines() if l.strip())
+            if "throttled_usec" in kv:
+                return int(kv.get("nr_throttled", 0)), int(kv["throttled_usec"])
+            if "throttled_time" in kv:  # (cgroup v1: nanoseconds)
+                return int(kv.get("nr_throttled", 0)), int(kv["throttled_time"]) // 1000
+        except Exception:
+            pass
+    return None
 
 
 def bind_rank_to_cores(local_rank, n_local):
@@ -370,6 +387,11 @@ def main():
                 self.ft.set_lazy_new_stereo(True)
             if args.host_threads > 1:
                 self.ft.set_host_threads(args.host_threads)
+            # set-up, not a step: every event-proportional buffer sized for the stream's largest batch, so
+            # that no timed call allocates (`tail_latency.allocs` in the line counts the ones that do)
+            if not args.no_reserve:
+                self.ft.reserve(max(b[2] for b in batches), max(b[3] for b in batches),
+                                host_batches=isinstance(batches[0][0], np.ndarray))
 
         def arg(self, k):
             b = self.batches[k]
@@ -457,39 +479,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step_times = [] if os.environ.get("ESVIO_BENCH_STEP_TIMES") else None  # (diagnostic: pass 0's per-step wall times to stderr)
     # The interpreter's cyclic garbage collector is kept out of the warm-up and the timed passes (what
     # timeit does): the set-up above leaves ~10^5 tracked objects (batches, arrays, ctypes wrappers) and a
-    # full collection walking them takes milliseconds — per-step timings (ESVIO_BENCH_STEP_TIMES=1)
-    # showed single steps of 1.8-7 ms at random places in otherwise 0.07-0.19 ms passes.  The step
-    # itself allocates no cycles, and the process ends soon after.
+    # full collection walking them takes milliseconds.  The step itself allocates no cycles, and the
+    # process ends soon after.
     import gc
     gc.collect()
     gc.freeze()
     gc.disable()
     for i in range(args.warmup):
         main_run.step(i)
-        if i == args.warmup - 2:
-            # one drain of the running pipeline inside the warm-up: in a fifth of cold runs the first step
-            # after the FIRST barrier took 1.9 ms instead of 0.15 (never the first step of a later pass) —
-            # a first-time cost, which is what warm-up steps are for; the step count is still --warmup
-            barrier()
     # ---- the timed region: EXACTLY --steps steps (pass 0 is the headline); the same region is then
-    # repeated over the continued stream (passes 1..R-1) so that the spread can be reported
+    # repeated over the continued stream (passes 1..R-1) so that the spread can be reported.  Every
+    # step's wall time is kept (one perf_counter per step), and the library's own per-call record
+    # (esvio_fe_latency_stats) names where the slowest call of each pass spent its time.
     passes = []
-    ransac_passes = []
+    ransac_passes, ransac_tails = [], []
+    step_ms, lib_lat = [], []
+    throttle0 = cgroup_cpu_stat()
     for r in range(repeats):
         FE.ransac_stats(reset=True)
+        ft.latency_stats(reset=True)
         barrier()
         t0 = time.perf_counter()
         n_events = 0
         lo = args.warmup + r * args.steps
-        if step_times is not None and r == 0:
-            step_times.append(t0)
+        marks = [t0]
         for i in range(lo, lo + args.steps):
             n_events += main_run.step(i)
-            if step_times is not None and r == 0:
-                step_times.append(time.perf_counter())
+            marks.append(time.perf_counter())
         if lazy:
             ft.finish(copy=False)  # the last published frame's deferred right-camera entries
         if exch is not None:
@@ -500,25 +518,35 @@ def main():
         if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if step_times is not None and r == 0:
-            step_times.append(t0 + elapsed)  # (last entry: finish() + the closing synchronize)
+        marks.append(t0 + elapsed)  # (last entry: finish() + the closing synchronize)
+        step_ms.append([(b - a) * 1e3 for a, b in zip(marks, marks[1:])])
         tot = torch.tensor([float(n_events), elapsed], dtype=torch.float64, device=xdev)
         if multi:
             dist.all_reduce(tot[0:1], op=dist.ReduceOp.SUM)
             dist.all_reduce(tot[1:2], op=dist.ReduceOp.MAX)
         passes.append((float(tot[0].item()), float(tot[1].item()), n_events))
+        ransac_tails.append(FE.ransac_tail())
         ransac_passes.append(FE.ransac_stats())
+        lib_lat.append(ft.latency_stats())
+    throttle1 = cgroup_cpu_stat()
+    try:
+        os_threads = len(os.listdir("/proc/self/task"))
+    except Exception:
+        os_threads = None
     total_events, max_elapsed, n_events = passes[0]  # (the collector stays off for the extra passes below too)
-    if step_times:
-        print("bench: pass 0 per-step ms:", " ".join("%.3f" % ((b - a) * 1e3) for a, b in zip(step_times, step_times[1:])),
-              file=sys.stderr)
+    if os.environ.get("ESVIO_BENCH_STEP_TIMES"):  # (diagnostic: every pass's per-step wall times to stderr)
+        for r, sm in enumerate(step_ms):
+            print("bench: pass %d per-step ms:" % r, " ".join("%.3f" % v for v in sm), file=sys.stderr)
+            print("bench: pass %d library latency: %s; ransac tail %s" % (r, lib_lat[r], ransac_tails[r]), file=sys.stderr)
     n_tracks = (len(ft.ids), len(ft.ids_right))
     # rejectWithF_event's host RANSAC inside each timed pass (this rank)
     host_ransac = [None if not rs["calls"] else dict(
         calls=rs["calls"], mean_points=round(rs["points"] / rs["calls"], 1),
         mean_iterations=round(rs["iterations"] / rs["calls"], 1), mean_us=round(rs["us"] / rs["calls"], 2),
         lmeds_calls=rs["lmeds_calls"], lmeds_mean_us=round(rs["lmeds_us"] / max(rs["lmeds_calls"], 1), 2),
-        us_per_step=round((rs["us"] + rs["lmeds_us"]) / args.steps, 2)) for rs in ransac_passes]
+        us_per_step=round((rs["us"] + rs["lmeds_us"]) / args.steps, 2),
+        max_us=round(max(tl["max_us"], tl["lmeds_max_us"]), 1), redone_iterations=tl["redone_iterations"])
+        for rs, tl in zip(ransac_passes, ransac_tails)]
 
     # ---- per-kernel pass (rank 0): HIP events around every launch on the stream it is launched on
     # (kept out of the timed region because the records cost host time).  Two schedules over the
@@ -581,50 +609,57 @@ def main():
                         schedule="one batch in flight, no speculative / chained / lazy launches "
                                  "(clean kernel durations); the timed region uses the replay schedule")
 
-    # ---- the same replay schedule with the events in HOST memory (what the drop-in binding of
-    # INTEGRATION.md passes): every batch then crosses PCIe inside the call that prefetches it
-    host_res = None
-    if rank == 0 and world == 1 and not one_rig and not args.no_host_pass:
-        run = Runner(pipeline, lazy, host_batches)
+    def side_pass(pipe, lz, batches, config=None):
+        """one more tracker over the same frames as pass 0 (its own warm-up, then --steps timed steps);
+        reported beside `value`, never as it"""
+        run = Runner(pipe, lz, batches, config=config)
         for i in range(args.warmup):
             run.step(i, exchange=False)
         torch.cuda.synchronize()
+        run.ft.latency_stats(reset=True)
         th0 = time.perf_counter()
         ev = 0
         for i in range(args.warmup, args.warmup + args.steps):
             ev += run.step(i, exchange=False)
-        if lazy:
+        if lz:
             run.ft.finish(copy=False)
         torch.cuda.synchronize()
         th = time.perf_counter() - th0
+        lt = run.ft.latency_stats()
         run.ft.close()
-        host_res = dict(value=round(ev / th / 1e6, 3), unit="Mevents/s", ms_per_step=round(th / args.steps * 1e3, 4),
-                        h2d_GBs=round(ev * 16 / th / 1e9, 2),
+        return dict(value=round(ev / th / 1e6, 3), unit="Mevents/s", ms_per_step=round(th / args.steps * 1e3, 4),
+                    call_ms_max=round(lt["max_ms"], 4)), ev, th
+
+    extra = rank == 0 and world == 1 and not one_rig and not args.no_host_pass
+    # ---- the same replay schedule with the events in HOST memory (what the drop-in binding of
+    # INTEGRATION.md passes): every batch then crosses PCIe inside the call that prefetches it
+    host_res = None
+    if extra:
+        host_res, ev, th = side_pass(pipeline, lazy, host_batches)
+        host_res.update(h2d_GBs=round(ev * 16 / th / 1e9, 2),
                         note="events handed over as pageable host buffers (ESVIO_FE_HOST); never `value`")
+
+    # ---- the reference's own call pattern: depth-1 queues (stereo_event_tracker_node.cpp:128-142), one
+    # esvio_fe_track_event per message, nothing announced, nothing lazy — INTEGRATION.md section 2's plain call
+    one_batch = None
+    if extra:
+        ob_dev, _, _ = side_pass(False, False, dev_batches)
+        ob_host, ev, th = side_pass(False, False, host_batches)
+        one_batch = dict(device_resident_ms_per_step=ob_dev["ms_per_step"], host_pageable_ms_per_step=ob_host["ms_per_step"],
+                         device_resident_Mev_s=ob_dev["value"], host_pageable_Mev_s=ob_host["value"],
+                         device_resident_call_ms_max=ob_dev["call_ms_max"], host_pageable_call_ms_max=ob_host["call_ms_max"],
+                         note="one batch in flight, no announcement: the reference node's depth-1 pattern; never `value`")
 
     # ---- the same replay schedule with the LK sums accumulated in float in the order of the reference's
     # x86 OpenCV build (lk_accum 2, k_lk_f32): what a caller runs who needs that build's tracks rather
     # than the exact sums.  Reported beside `value`, never as it.
     float_lk = None
-    if rank == 0 and world == 1 and not one_rig and not args.no_host_pass and args.lk_accum == 1:
+    if extra and args.lk_accum == 1:
         fcfg = FE.make_config(W, H, device=dev_index, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1,
                               equalize=args.equalize, lk_accum=2)
-        run = Runner(pipeline, lazy, dev_batches, config=fcfg)
-        for i in range(args.warmup):
-            run.step(i, exchange=False)
-        torch.cuda.synchronize()
-        tf0 = time.perf_counter()
-        ev = 0
-        for i in range(args.warmup, args.warmup + args.steps):
-            ev += run.step(i, exchange=False)
-        if lazy:
-            run.ft.finish(copy=False)
-        torch.cuda.synchronize()
-        tf = time.perf_counter() - tf0
-        run.ft.close()
-        float_lk = dict(value=round(ev / tf / 1e6, 3), unit="Mevents/s", ms_per_step=round(tf / args.steps * 1e3, 4),
-                        note="lk_accum 2: LK sums in float in the order of the reference's x86 OpenCV build "
-                             "(bit-exact against the oracle's float-order mode); never `value`")
+        float_lk, _, _ = side_pass(pipeline, lazy, dev_batches, config=fcfg)
+        float_lk["note"] = ("lk_accum 2: LK sums in float in the order of the reference's x86 OpenCV build "
+                            "(bit-exact against the oracle's float-order mode); never `value`")
 
     # ---- the HBM-bound kernels at a batch size where they are HBM-bound: createSAE_left/right of one
     # stereo batch at C5's sensor shape and rate (1280x720, 100 Mev/s per camera: 6.7 M events), device
@@ -659,8 +694,11 @@ def main():
                 b5[1].free()
             per = ev5 / n5
             row, tot = {}, 0.0
+            # (the partition writes 8-byte records whenever the batch's stamps allow it — these synthetic
+            # streams' always do — unless ESVIO_FE_WIDE_RECORDS forces the 16-byte form)
+            scatter_bpe = 32 if os.environ.get("ESVIO_FE_WIDE_RECORDS") else 24
             for label, func, bpe in (("k_sae_keys", "k_tile_hist", 16), ("k_tile_scan", "k_tile_scan", 0),
-                                     ("k_radix_pass", "k_tile_scatter", 24), ("k_sae_apply", "k_tile_apply", 32)):
+                                     ("k_radix_pass", "k_tile_scatter", scatter_bpe), ("k_sae_apply", "k_tile_apply", 32)):
                 v = ks5.get(label)
                 if not v or not v["launches"]:
                     continue
@@ -765,6 +803,31 @@ def main():
 
     if rank == 0:
         ms_all = sorted(p[1] / args.steps * 1e3 for p in passes)
+        pass_ms = [round(p[1] / args.steps * 1e3, 4) for p in passes]
+        # pass 0's steps as the caller saw them (the last entry of step_ms[0] is finish() + the closing
+        # synchronize, not a step)
+        s0 = np.array(step_ms[0][:-1])
+        all_steps = np.concatenate([np.array(sm[:-1]) for sm in step_ms])
+        l0 = lib_lat[0]
+        tail = dict(
+            step_ms_max=round(float(s0.max()), 4), step_ms_argmax=int(s0.argmax()),
+            step_ms_p99=round(float(np.percentile(s0, 99)), 4), step_ms_median=round(float(np.median(s0)), 4),
+            all_passes_step_ms_max=round(float(all_steps.max()), 4),
+            all_passes_step_ms_p99=round(float(np.percentile(all_steps, 99)), 4),
+            per_pass_step_ms_max=[round(float(max(sm[:-1])), 3) for sm in step_ms],
+            library_call_ms=dict(p50=round(l0["p50_ms"], 4), p99=round(l0["p99_ms"], 4), max=round(l0["max_ms"], 4),
+                                 max_call=l0["max_call"], max_call_phases_ms=l0["max_phase_ms"],
+                                 max_call_cpu=l0["max_cpu"], max_call_invol_switches=l0["max_invol_switches"]),
+            allocs_in_timed_passes=sum(l["allocs"] for l in lib_lat),
+            invol_switches_in_timed_passes=sum(l["invol_switches"] for l in lib_lat),
+            helper_invol_switches_in_timed_passes=sum(t["helper_invol_switches"] for t in ransac_tails),
+            ransac_jobs_on_the_other_buffer=sum(t["skipped_buffers"] for t in ransac_tails),
+            ransac_jobs_without_helpers=sum(t["solo_jobs"] for t in ransac_tails),
+            cgroup_throttled=(None if throttle0 is None or throttle1 is None else
+                              dict(periods=throttle1[0] - throttle0[0], ms=round((throttle1[1] - throttle0[1]) / 1e3, 3))),
+            os_threads_in_process=os_threads,
+            note="wall time of each step of pass 0 as the calling thread saw it (set_next_batch + track_event); "
+                 "library_call_ms: the esvio_fe_track_event calls alone, the slowest one's phases named")
         out = {
             "metric": "Mevents/s through time-surface+detect+track @640x480",
             "value": round(total_events / max_elapsed / 1e6, 3),
@@ -777,13 +840,16 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if one_rig else "weak",
             "vs_baseline": None,
-            "dtype": "f64 timestamps / u8 images / int64 LK sums",
+            "dtype": "f64 timestamps / u8 images / int64 LK sums" if args.lk_accum == 1 else
+                     "f64 timestamps / u8 images / f32 LK sums in the reference build's order",
             "data": "synthetic",
             "config": {
                 "workload": "C3 (superset of C2): stereo %dx%d %s stream, %.1f Mev/s per camera, "
                             "%g Hz batches, full SAE+TS+pyramid+LK(temporal,stereo)+Arc*+select, "
-                            "max_cnt %d min_dist 10 flow_back 1 equalize %d freq %d"
-                            % (W, H, args.stream, args.rate / 1e6, args.batch_hz, args.max_cnt, args.equalize, args.freq),
+                            "max_cnt %d min_dist 10 flow_back 1 equalize %d freq %d, lk_accum %d (%s)"
+                            % (W, H, args.stream, args.rate / 1e6, args.batch_hz, args.max_cnt, args.equalize, args.freq,
+                               args.lk_accum, "exact integer LK sums" if args.lk_accum == 1 else
+                               "float LK sums in the reference's x86 order"),
                 "events_per_step_per_gpu": int(n_events / args.steps),
                 "parallelism": ("left/right camera split, 1 rig on 2 GPUs" if cam_split else
                                 "one stream time-sliced over %d GPUs (SAE update), tracking on rank 0" % world
@@ -797,25 +863,37 @@ def main():
                 "batches_announced_ahead": int(args.ahead) if pipeline else 0,
                 "track_exchange": ("library (ncclAllGather on the handle's communicator)" if comm_id is not None else
                                    "torch.distributed all_gather_into_tensor" if exch is not None else "none"),
+                # compact copies of what sits at the end of the line
+                "pass_ms": " ".join("%.4f" % v for v in pass_ms),
+                "step_ms_max": tail["step_ms_max"],
+                "step_ms_p99": tail["step_ms_p99"],
+                "one_batch_in_flight_ms": (None if one_batch is None else
+                                           "%.4f device-resident, %.4f host-pageable"
+                                           % (one_batch["device_resident_ms_per_step"], one_batch["host_pageable_ms_per_step"])),
+                "float_order_lk_ms": None if float_lk is None else float_lk["ms_per_step"],
             },
-            # the timed --steps region repeated over the continued stream (pass 0 = ms_per_step above)
-            "repeats": dict(passes=repeats, ms_per_step=[round(p[1] / args.steps * 1e3, 4) for p in passes],
-                            median=round(ms_all[len(ms_all) // 2], 4), min=round(ms_all[0], 4),
-                            max=round(ms_all[-1], 4),
-                            value_median=round(passes[0][0] / args.steps / ms_all[len(ms_all) // 2] / 1e3, 3)),
-            "host_resident_events": host_res,
-            "float_order_lk": float_lk,
-            "lk_modes": lk_modes,
-            "host_ransac": host_ransac,
             "roofline": (dict(roof, hbm_bound_kernels="sae_chain_c5_batch: k_tile_hist %.0f %%, k_tile_apply %.0f %% of the HBM peak "
                                                       "(uniform stream) at 6.7 M events per launch chain"
                                                       % (100 * sae_chain["uniform"]["k_tile_hist"]["frac"],
                                                          100 * sae_chain["uniform"]["k_tile_apply"]["frac"]))
-                         if roof and sae_chain and "uniform" in sae_chain and "k_tile_apply" in sae_chain["uniform"] else roof),
-            "sae_chain_c5_batch": sae_chain,
+                         if roof and sae_chain and all(k in sae_chain.get("uniform", {}) for k in ("k_tile_hist", "k_tile_apply"))
+                         else roof),
             "cpu_baseline": cpu,
+            "lk_modes": lk_modes,
             "kernels": kernels,
             "kernels_replay_schedule": kernels_pipe,
+            "sae_chain_c5_batch": sae_chain,
+            "host_ransac": host_ransac,
+            # ---- the driver keeps the END of the line: what a reader needs beside `value` comes last
+            "tail_latency": tail,
+            "one_batch_in_flight": one_batch,
+            "float_order_lk": float_lk,
+            "host_resident_events": host_res,
+            # the timed --steps region repeated over the continued stream (pass 0 = ms_per_step above)
+            "repeats": dict(passes=repeats, ms_per_step=pass_ms,
+                            median=round(ms_all[len(ms_all) // 2], 4), min=round(ms_all[0], 4),
+                            max=round(ms_all[-1], 4),
+                            value_median=round(passes[0][0] / args.steps / ms_all[len(ms_all) // 2] / 1e3, 3)),
         }
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ft.close()

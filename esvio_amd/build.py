@@ -23,22 +23,48 @@ FLAGS = [
 ]
 
 
+OBJ = os.path.join(HERE, "build")  # per-source objects (git-ignored)
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in HEADERS] + [os.path.abspath(__file__)]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES] + _deps()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
+    """one object per source (compiled side by side, re-compiled only when the source or a header is
+    newer), then the link: a host-side edit does not recompile fe_kernels.hip"""
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl") and not f.startswith("-Wl,")]
+    newest_hdr = max(os.path.getmtime(d) for d in _deps())
+    jobs, objs = [], []
+    for f in SOURCES:
+        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            cmd = [hipcc] + cflags + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            for _, q in jobs:
+                q.wait()
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-ldl", "-o", LIB]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB
 
 

@@ -222,6 +222,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   while ((1ull << c->key_bits) <= (unsigned long long)c->invalid_key) c->key_bits++;
   c->hw = host::disc_halfwidths(cfg->min_dist);
   c->trace = getenv("ESVIO_FE_TRACE") != nullptr;
+  if (const char* v = getenv("ESVIO_FE_SLOW_CALL_MS")) c->slow_call_ms = atof(v);
   c->mask_event.reset(c->W, c->H);
 
   auto bail = [&](int rc) {
@@ -343,6 +344,13 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipMemsetAsync(c->d_counts, 0, 64, cur_stream(c)) != hipSuccess ||
       hipStreamSynchronize(cur_stream(c)) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
+  // One kernel of this library on every stream, now: the runtime loads the code object with the first
+  // launch from it and creates a stream's hardware queue with the stream's first use — 2.0-2.4 ms that
+  // would otherwise sit inside the first esvio_fe_track_event call (profiles/r04_stall_forensics.md).
+  for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream4}) {
+    launch_fill_f64(st, (double*)c->d_rejected, 1, 0.0);
+    if (hipStreamSynchronize(st) != hipSuccess) return bail(ESVIO_FE_EHIP);
+  }
   // The greedy selections (Event_FeaturesToTrack, goodFeaturesToTrack's min-distance pass) keep
   // their one-bit-per-pixel map in LDS; above ~1.3 M pixels (the frame cameras of the shipped ESVIO
   // configs go up to 1920x1200) it lives in device memory instead (k_select_gbm)
@@ -357,6 +365,10 @@ int esvio_fe_reset(esvio_fe_handle c) {
   HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream4));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
+  // (the main stream as well: a call that returned early in lazy mode, or one that failed half way,
+  // may have kernels there that still raise the error flag or write into the pinned result words
+  // cleared below)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->announced.clear();
   c->inflight.clear();
   stager_drain(c);
@@ -468,7 +480,12 @@ int esvio_fe_sae_slice_last(esvio_fe_handle c, const esvio_fe_event* left, size_
     return fail(c, ESVIO_FE_EINVAL, "time-sliced SAE update cannot be mixed with esvio_fe_set_next_batch");
   HIPCHK(c, hipSetDevice(c->dev));
   if (int rc = slice_scratch(c)) return rc;
-  // (a rank that never tracks: the previous batch's commit simply IS its planes by now)
+  // A rank that never tracks: the previous batch's commit simply IS its planes by now.  On a rank that
+  // tracks, a committed batch must get its track call before the next batch's slices start — the call
+  // would otherwise apply the batch to the planes a second time.
+  if (c->ext_sae_pending && c->frame_no > 0)
+    return fail(c, ESVIO_FE_EINVAL, "the committed batch has not been tracked yet (slice_last of the next batch "
+                                    "comes after esvio_fe_track_event on a rank that tracks)");
   c->ext_sae_pending = false;
   const EventRec *dL, *dR;
   if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) return rc;
@@ -772,6 +789,19 @@ int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, do
   if (n < 0 || (n && (!p1 || !p2 || !status)) || threads < 1 || threads > 16) return ESVIO_FE_EINVAL;
   host::RansacPool* pool = host::ransac_pool_create(threads - 1);
   const int k = host::find_fundamental_mat(p1, p2, n, thr, conf, status, pool);
+  host::ransac_pool_destroy(pool);
+  if (n_inliers) *n_inliers = k;
+  return 0;
+}
+
+int esvio_fe_find_fundamental_mat_held(const float* p1, const float* p2, int n, double thr, double conf,
+                                       int threads, int hold_mask, uint8_t* status, int32_t* n_inliers) {
+  if (n < 0 || (n && (!p1 || !p2 || !status)) || threads < 2 || threads > 16 || hold_mask < 0 || hold_mask > 3)
+    return ESVIO_FE_EINVAL;
+  host::RansacPool* pool = host::ransac_pool_create(threads - 1);
+  host::ransac_pool_hold(pool, hold_mask, true);
+  const int k = host::find_fundamental_mat(p1, p2, n, thr, conf, status, pool);
+  host::ransac_pool_hold(pool, hold_mask, false);
   host::ransac_pool_destroy(pool);
   if (n_inliers) *n_inliers = k;
   return 0;
@@ -1151,6 +1181,87 @@ int esvio_fe_debug_counters(esvio_fe_handle c, uint64_t out4[4]) {
   out4[1] = c->n_chain_expired;
   out4[2] = c->tr_chain_launch;
   out4[3] = c->tr_chain_used;
+  return 0;
+}
+
+int esvio_fe_reserve(esvio_fe_handle c, size_t max_left, size_t max_right, int host_batches) {
+  if (!c) return ESVIO_FE_EINVAL;
+  const size_t n = max_left + max_right;
+  if (n >= (1ull << 31)) return fail(c, ESVIO_FE_EINVAL, "batch too large");
+  if (!c->inflight.empty() || !c->announced.empty())
+    return fail(c, ESVIO_FE_EINVAL, "esvio_fe_reserve while batches are announced");
+  HIPCHK(c, hipSetDevice(c->dev));
+  // (growing frees the old buffers: nothing may still be using them)
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream3));
+  HIPCHK(c, hipStreamSynchronize(c->stream4));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->tiled) {
+    if (int rc = ensure_part_capacity(c, n, false)) return rc;
+  } else if (int rc = ensure_sort_capacity(c, n)) {
+    return rc;
+  }
+  for (int k = 0; k < kRightSlots; k++)
+    if (int rc = ensure_arc_capacity(c, max_left, k)) return rc;
+  if (host_batches) {
+    if (int rc = ensure_event_capacity(c, n)) return rc;
+    if (stager_enabled(c)) {
+      if (int rc = stager_reserve(c, n)) return rc;
+    } else {
+      for (int lane = 0; lane < kPrefetchDepth; lane++)
+        if (n > c->evp_cap[lane]) {
+          if (c->d_evp[lane]) (void)hipFree(c->d_evp[lane]);
+          c->d_evp[lane] = nullptr;
+          c->evp_cap[lane] = 0;
+          if (int rc = dev_alloc(c, &c->d_evp[lane], n + n / 4)) return rc;
+          c->evp_cap[lane] = n + n / 4;
+        }
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+const char* esvio_fe_latency_phase_name(int i) {
+  static const char* nm[ESVIO_FE_LATENCY_PHASES] = {
+      "enqueue sae+ts+pyr", "enqueue temporal LK", "wait temporal LK", "host filter", "host ransac",
+      "host mask + enqueue detect/stereo", "wait stereo LK", "host tail",
+      "pub: Event_setMask", "pub: points + k_select launch", "pub: speculative + chained LK launches",
+      "pub: previous frame's right tail", "pub: stereo LK of new corners launch", "pub: next batch's prefetch launches",
+      "check + take-up of a late batch", ""};
+  return (i >= 0 && i < ESVIO_FE_LATENCY_PHASES) ? nm[i] : "";
+}
+
+int esvio_fe_latency_stats(esvio_fe_handle c, esvio_fe_latency* out, int reset) {
+  if (!c || !out) return ESVIO_FE_EINVAL;
+  const esvio_fe_ctx::Latency& L = c->lat;
+  std::memset(out, 0, sizeof(*out));
+  out->calls = L.calls;
+  const size_t n = (size_t)std::min<uint64_t>(L.calls, esvio_fe_ctx::Latency::kRing);
+  if (n) {
+    std::vector<float> v(L.ring, L.ring + n);
+    std::sort(v.begin(), v.end());
+    out->mean_ms = L.sum_ms / (double)L.calls;
+    out->p50_ms = v[n / 2];
+    out->p99_ms = v[std::min(n - 1, (size_t)((double)n * 0.99))];
+    out->max_ms = L.max_ms;
+    out->max_call = L.max_call;
+    out->max_published = L.max_pub;
+    out->max_cpu_begin = L.max_cpu0;
+    out->max_cpu_end = L.max_cpu1;
+    out->max_invol_switches = L.max_nivcsw;
+    out->max_allocs = L.max_allocs;
+    std::memcpy(out->max_phase_ms, L.max_phase, sizeof(out->max_phase_ms));
+  }
+  out->allocs = L.allocs;
+  out->invol_switches = L.nivcsw;
+  if (reset) c->lat = esvio_fe_ctx::Latency();
+  return 0;
+}
+
+int esvio_fe_ransac_tail(uint64_t out6[6], int reset) {
+  if (!out6) return ESVIO_FE_EINVAL;
+  host::ransac_tail(out6, reset != 0);
   return 0;
 }
 

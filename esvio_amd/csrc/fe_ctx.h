@@ -356,6 +356,22 @@ struct esvio_fe_ctx {
   uint64_t tr_gpu_n = 0;
   std::chrono::steady_clock::time_point tr_sel_launch;
 
+  // ---- per-call latency record (esvio_fe_latency_stats; always on)
+  struct Latency {
+    static constexpr int kRing = 4096;
+    float ring[kRing] = {};
+    uint64_t calls = 0;
+    double sum_ms = 0, max_ms = 0;
+    uint64_t max_call = 0;
+    int max_pub = 0, max_cpu0 = -1, max_cpu1 = -1;
+    long max_nivcsw = 0, max_allocs = 0;
+    double max_phase[ESVIO_FE_LATENCY_PHASES] = {};
+    uint64_t allocs = 0, nivcsw = 0;
+    double cur_phase[ESVIO_FE_LATENCY_PHASES] = {};  // the call in progress
+  } lat;
+  uint64_t n_allocs = 0;  // hipMalloc / hipHostMalloc calls of this handle so far
+  double slow_call_ms = 0;  // ESVIO_FE_SLOW_CALL_MS: calls slower than this are reported on stderr (0: off)
+
   // ---- profiling
   bool prof_on = false;
   KStat stats[K_COUNT];

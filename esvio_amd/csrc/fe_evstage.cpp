@@ -45,6 +45,7 @@ struct Slot {
   std::atomic<int> state{0};  // 0 idle, 1 staging, 2 every DMA enqueued and `copied` recorded, -1 failed
   Group grp[kMaxGroups];
   std::atomic<uint32_t> groups_left{0};
+  std::atomic<int> busy{0};  // chunks of this slot a thread has taken from the queue and not finished
 };
 
 struct Task {  // one memcpy into the slot's pinned buffer
@@ -93,8 +94,10 @@ struct EventStager {
       if (q.empty()) return false;
       t = q.front();
       q.pop_front();
+      slot[t.slot].busy.fetch_add(1, std::memory_order_acq_rel);
     }
     run_task(t);
+    slot[t.slot].busy.fetch_sub(1, std::memory_order_acq_rel);
     return true;
   }
 
@@ -108,8 +111,10 @@ struct EventStager {
         if (stop && q.empty()) return;
         t = q.front();
         q.pop_front();
+        slot[t.slot].busy.fetch_add(1, std::memory_order_acq_rel);
       }
       run_task(t);
+      slot[t.slot].busy.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
 };
@@ -151,6 +156,33 @@ static bool host_pointer_is_pinned(const void* p) {
   return a.type == hipMemoryTypeHost;
 }
 
+static int slot_capacity(esvio_fe_ctx* c, Slot& s, size_t n) {
+  if (n <= s.cap) return 0;
+  // (the device buffer's previous readers: hipFree waits for the device)
+  if (s.dev) (void)hipFree(s.dev);
+  if (s.pin) (void)hipHostFree(s.pin);
+  s.dev = nullptr;
+  s.pin = nullptr;
+  s.cap = 0;
+  const size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
+  if (int rc = dev_alloc(c, &s.dev, cap)) return rc;
+  HIPCHK(c, hipHostMalloc((void**)&s.pin, cap * 16, hipHostMallocDefault));
+  c->n_allocs++;
+  s.cap = cap;
+  return 0;
+}
+
+// esvio_fe_reserve: every idle slot sized for batches of n events
+int stager_reserve(esvio_fe_ctx* c, size_t n_events) {
+  if (!stager_enabled(c)) return 0;
+  EventStager* st = nullptr;
+  if (int rc = stager_get(c, &st)) return rc;
+  for (Slot& s : st->slot)
+    if (!s.in_use)
+      if (int rc = slot_capacity(c, s, n_events)) return rc;
+  return 0;
+}
+
 // Start staging [left; right] into a free slot: returns at once, the helpers do the work.
 // dma_groups: DMAs the pageable part of the batch is moved with (1: the caller does not wait for it)
 int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
@@ -163,28 +195,18 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
   Slot& s = st->slot[k];
   const size_t n = nL + nR;
   const bool pinL = nL && host_pointer_is_pinned(left), pinR = nR && host_pointer_is_pinned(right);
-  if (n > s.cap) {
-    // (the device buffer's previous readers: hipFree waits for the device)
-    if (s.dev) (void)hipFree(s.dev);
-    if (s.pin) (void)hipHostFree(s.pin);
-    s.dev = nullptr;
-    s.pin = nullptr;
-    s.cap = 0;
-    const size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
-    if (int rc = dev_alloc(c, &s.dev, cap)) return rc;
-    HIPCHK(c, hipHostMalloc((void**)&s.pin, cap * 16, hipHostMallocDefault));
-    s.cap = cap;
-  }
+  if (int rc = slot_capacity(c, s, n)) return rc;
   // the DMA overwrites the slot's device buffer: behind the kernels that read its previous batch
   if (s.pf_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.pf_done, 0));
   if (s.main_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.main_done, 0));
   s.pf_rec = s.main_rec = false;
-  s.in_use = true;
   st->bytes_staged += n * 16;
   st->batches++;
-  // a pinned source: one DMA straight from it, now
+  // a pinned source: one DMA straight from it, now (the slot is taken only once nothing below can fail
+  // before its state is set)
   if (pinL) HIPCHK(c, hipMemcpyAsync(s.dev, left, nL * 16, hipMemcpyHostToDevice, st->stream));
   if (pinR) HIPCHK(c, hipMemcpyAsync(s.dev + nL, right, nR * 16, hipMemcpyHostToDevice, st->stream));
+  s.in_use = true;
   // the pageable part: destination byte range [lo, hi) of the slot's buffers
   const size_t lo = pinL ? nL * 16 : 0, hi = pinR ? nL * 16 : n * 16;
   std::vector<Task> tasks;
@@ -214,7 +236,11 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
   }
   s.groups_left.store((uint32_t)ng, std::memory_order_relaxed);
   s.state.store(tasks.empty() ? 2 : 1, std::memory_order_release);
-  if (tasks.empty()) HIPCHK(c, hipEventRecord(s.copied, st->stream));
+  if (tasks.empty() && hipEventRecord(s.copied, st->stream) != hipSuccess) {
+    s.state.store(0, std::memory_order_release);
+    s.in_use = false;
+    return fail(c, ESVIO_FE_EHIP, "hipEventRecord (event staging) failed");
+  }
   {
     std::lock_guard<std::mutex> g(st->mu);
     for (const Task& t : tasks) st->q.push_back(t);
@@ -243,11 +269,34 @@ int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const Eve
     }
     st->wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   }
-  if (sl.state.load(std::memory_order_acquire) != 2) return fail(c, ESVIO_FE_EHIP, "staging the event batch failed");
+  if (sl.state.load(std::memory_order_acquire) != 2) {
+    // a DMA could not be enqueued: chunks of this slot may still be queued or being copied from the
+    // caller's memory, which is the caller's again once this call has returned — finish them first
+    stager_abandon(c, slot);
+    return fail(c, ESVIO_FE_EHIP, "staging the event batch failed");
+  }
   HIPCHK(c, hipStreamWaitEvent(s, sl.copied, 0));
   *dL = sl.dev;
   *dR = sl.dev + nL;
   return 0;
+}
+
+// give a slot back whose batch will not be tracked (a failed call): nothing of the caller's memory is
+// read after this returns
+void stager_abandon(esvio_fe_ctx* c, int slot) {
+  if (slot < 0 || !c->stager) return;
+  EventStager* st = c->stager;
+  Slot& sl = st->slot[slot];
+  {  // queued chunks of this slot: dropped
+    std::lock_guard<std::mutex> g(st->mu);
+    for (auto it = st->q.begin(); it != st->q.end();) it = it->slot == slot ? st->q.erase(it) : it + 1;
+  }
+  while (sl.busy.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();  // chunks a thread holds: waited for
+  (void)hipStreamSynchronize(st->stream);  // (DMAs straight from a pinned source, groups already enqueued)
+  for (int g2 = 0; g2 < kMaxGroups; g2++) sl.grp[g2].chunks_left.store(0, std::memory_order_relaxed);
+  sl.groups_left.store(0, std::memory_order_relaxed);
+  sl.state.store(0, std::memory_order_release);
+  sl.in_use = false;
 }
 
 // the kernels enqueued on `s` so far are the last ones on that stream to read the slot's device buffer

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <sys/resource.h>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -853,6 +854,16 @@ struct alignas(64) IterResult {
 constexpr uint32_t kCollinear = 0xffffffffu;  // summary code: the drawn subset fails checkSubset
 }  // namespace
 
+namespace {
+std::atomic<uint64_t> g_rs_calls{0}, g_rs_iters{0}, g_rs_points{0}, g_rs_ns{0}, g_rs_lm_calls{0}, g_rs_lm_ns{0};
+std::atomic<uint64_t> g_rs_max_ns{0}, g_rs_lm_max_ns{0}, g_rs_redone{0}, g_rs_solo{0}, g_rs_skipped{0}, g_rs_helper_sw{0};
+void atomic_max(std::atomic<uint64_t>& a, uint64_t v) {
+  uint64_t cur = a.load(std::memory_order_relaxed);
+  while (v > cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {
+  }
+}
+}  // namespace
+
 // State of one job.  Two of them alternate (job parity): a helper that is descheduled in the middle
 // of an iteration keeps working on its own job's buffers and cannot touch the next job's; the
 // caller does not wait for it (it redoes an iteration whose result does not arrive, and only a
@@ -967,8 +978,10 @@ struct RansacPool {
   // helpers are kept on the cores that share the caller's L3 (one CCD): an iteration is ~0.5 us of
   // work, so the hand-over has to cost a same-die cache line transfer, not a cross-socket one
   std::vector<int> near_cpus;  // the caller's L3 domain minus the caller's own core (empty: unknown)
-  std::vector<int> l3_cpus;    // the whole domain
-  int near_of = -1;            // the CPU that set was made for
+  std::vector<int> l3_cpus;    // the whole domain ...
+  std::vector<int> l3_core;    // ... and the core (its first hardware thread) each of them belongs to
+  int near_of = -1;            // the CPU the calling thread was last seen on
+  uint64_t repins = 0;         // times the helpers had to be moved out of the calling thread's way
 
   void pin_near_caller();
 
@@ -977,6 +990,7 @@ struct RansacPool {
     uint32_t seen = 0;
     auto idle_since = std::chrono::steady_clock::now();
     unsigned spins = 0;
+    [[maybe_unused]] long last_nivcsw = 0;
     for (;;) {
       if (quit.load(std::memory_order_acquire)) return;
       const uint32_t e = epoch.load(std::memory_order_acquire);
@@ -1016,6 +1030,15 @@ struct RansacPool {
       J.active.fetch_sub(1, std::memory_order_release);
       seen = e;
       idle_since = std::chrono::steady_clock::now();
+#if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
+      {  // (esvio_fe_ransac_tail: how often the helpers lose their CPU — a syscall per job, off the caller's path)
+        struct rusage ru;
+        if (getrusage(RUSAGE_THREAD, &ru) == 0) {
+          if (ru.ru_nivcsw > last_nivcsw) g_rs_helper_sw.fetch_add((uint64_t)(ru.ru_nivcsw - last_nivcsw), std::memory_order_relaxed);
+          last_nivcsw = ru.ru_nivcsw;
+        }
+      }
+#endif
     }
   }
 };
@@ -1051,11 +1074,24 @@ std::vector<int> read_cpu_list(const char* path) {
 void RansacPool::pin_near_caller() {
 #if defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__)
   const int cpu = sched_getcpu();
-  if (cpu < 0) return;
+  if (cpu < 0 || cpu == near_of) return;
   if (near_of >= 0) {
-    if (cpu == near_of) return;
-    for (int v : l3_cpus)
-      if (v == cpu) return;  // (moved within the die — fine)
+    // The calling thread has moved.  Inside the die that is fine as long as it has not landed on a core
+    // one of the helpers is pinned to: a spinning helper and the caller on one core take turns by the
+    // scheduler's tick — milliseconds — until the load balancer moves the caller again (the helpers
+    // cannot move: their set has exactly one CPU per helper when the domain has 8 cores).
+    bool in_domain = false, on_helper_core = false;
+    for (size_t i = 0; i < l3_cpus.size(); i++)
+      if (l3_cpus[i] == cpu) {
+        in_domain = true;
+        for (int v : near_cpus) on_helper_core = on_helper_core || v == l3_core[i];
+      }
+    static const bool pin_old = getenv("ESVIO_FE_PIN_OLD") != nullptr;  // (A/B of this round; to be removed)
+    if (in_domain && (!on_helper_core || pin_old)) {
+      near_of = cpu;
+      return;
+    }
+    repins++;
   }
   char path[128];
   std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
@@ -1064,6 +1100,7 @@ void RansacPool::pin_near_caller() {
   const std::vector<int> self = read_cpu_list(path);
   near_of = cpu;
   l3_cpus = l3;
+  l3_core.assign(l3.size(), -1);
   near_cpus.clear();
   // only CPUs this process may run on (N ranks on one node: bench.py gives every rank its own block of
   // cores; a helper pinned to the whole L3 domain would sit on the neighbours' cores)
@@ -1071,21 +1108,29 @@ void RansacPool::pin_near_caller() {
   CPU_ZERO(&allowed);
   const bool have_allowed = sched_getaffinity(0, sizeof allowed, &allowed) == 0;
   std::vector<int> primary;  // one logical CPU per physical core of the domain, caller's core left out
-  for (int v : l3) {
+  std::vector<int> all;
+  for (size_t i = 0; i < l3.size(); i++) {
+    const int v = l3[i];
+    std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", v);
+    const std::vector<int> sib = read_cpu_list(path);
+    l3_core[i] = sib.empty() ? v : sib[0];  // (a core is named by its first hardware thread)
     if (have_allowed && (v >= CPU_SETSIZE || !CPU_ISSET(v, &allowed))) continue;
     bool mine = v == cpu;
     for (int w : self) mine = mine || v == w;
     if (mine) continue;
-    near_cpus.push_back(v);
-    std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", v);
-    const std::vector<int> sib = read_cpu_list(path);
+    all.push_back(v);
     if (sib.empty() || sib[0] == v) primary.push_back(v);
   }
   // a spinning helper on the SMT sibling of another helper (or of the caller) takes issue slots
   // from it: keep to one hardware thread per core when the domain has enough cores
-  if (primary.size() >= th.size()) near_cpus = primary;
+  near_cpus = primary.size() >= th.size() ? primary : all;
   if (near_cpus.size() < th.size()) {  // unknown topology or a tiny L3 domain: leave it to the OS
     near_cpus.clear();
+    cpu_set_t any;
+    CPU_ZERO(&any);
+    if (have_allowed) any = allowed;
+    if (have_allowed && repins)  // (they were pinned to another die before)
+      for (auto& t : th) (void)pthread_setaffinity_np(t.native_handle(), sizeof any, &any);
     return;
   }
   cpu_set_t set;
@@ -1129,6 +1174,12 @@ void ransac_pool_wake(RansacPool* p) {
   p->cv.notify_all();
 }
 
+void ransac_pool_hold(RansacPool* p, int mask, bool on) {
+  if (!p) return;
+  for (int b = 0; b < 2; b++)
+    if (mask & (1 << b)) p->job[b].active.fetch_add(on ? 1 : -1, std::memory_order_acq_rel);
+}
+
 void ransac_pool_destroy(RansacPool* p) {
   if (!p) return;
   p->quit.store(true, std::memory_order_release);
@@ -1141,9 +1192,23 @@ void ransac_pool_destroy(RansacPool* p) {
   delete p;
 }
 
-namespace {
-std::atomic<uint64_t> g_rs_calls{0}, g_rs_iters{0}, g_rs_points{0}, g_rs_ns{0}, g_rs_lm_calls{0}, g_rs_lm_ns{0};
-}  // namespace
+
+void ransac_tail(uint64_t out6[6], bool reset) {
+  out6[0] = g_rs_max_ns.load();
+  out6[1] = g_rs_lm_max_ns.load();
+  out6[2] = g_rs_redone.load();
+  out6[3] = g_rs_solo.load();
+  out6[4] = g_rs_skipped.load();
+  out6[5] = g_rs_helper_sw.load();
+  if (reset) {
+    g_rs_skipped = 0;
+    g_rs_helper_sw = 0;
+    g_rs_max_ns = 0;
+    g_rs_lm_max_ns = 0;
+    g_rs_redone = 0;
+    g_rs_solo = 0;
+  }
+}
 
 void host_hypot(const double* x, const double* y, int n, double* out) {
   for (int i = 0; i < n; i++) out[i] = cv_hypot(x[i], y[i]);
@@ -1182,6 +1247,12 @@ RansacStats ransac_stats(bool reset) {
     g_rs_iters = 0;
     g_rs_points = 0;
     g_rs_ns = 0;
+    g_rs_max_ns = 0;
+    g_rs_lm_max_ns = 0;
+    g_rs_redone = 0;
+    g_rs_solo = 0;
+    g_rs_skipped = 0;
+    g_rs_helper_sw = 0;
   }
   return r;
 }
@@ -1232,6 +1303,7 @@ int ransac_pooled(RansacPool* P, const float* m1, const float* m2, int count, do
         // result is simply never looked at
         code = J.evaluate(rp, local, scratch);
         r = &local;
+        g_rs_redone.fetch_add(1, std::memory_order_relaxed);
       } else {
         break;
       }
@@ -1353,6 +1425,7 @@ int lmeds_pooled(RansacPool* P, const float* m1, const float* m2, int count, dou
       }
       J.evaluate(rp, local, scratch);  // (its taker is not delivering)
       r = &local;
+      g_rs_redone.fetch_add(1, std::memory_order_relaxed);
     }
     stalled = 0;
     for (int k = 0; k < r->nm; k++) {
@@ -1391,6 +1464,26 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
   // without helper threads the same loops run on a pool of none: the calling thread draws, solves the
   // subsets kLanes at a time and replays them in order
   static thread_local std::unique_ptr<RansacPool> solo;
+  if (pool) {
+    // This job's buffer (two alternate) may still hold a helper that was descheduled in the middle of
+    // the job before last.  Waiting for it costs a scheduler quantum — the 1.8 ms RANSAC calls and 2-7 ms
+    // steps of round 3's cold runs — so after a few microseconds the job takes the other buffer (the
+    // epoch moves on by two: the held helper finds a foreign epoch when it comes back and leaves), and
+    // if that one is held as well it runs without the helpers (same result, by construction).
+    auto held = [&](uint32_t e) { return pool->job[(e >> 1) & 1].active.load(std::memory_order_acquire) != 0; };
+    const uint32_t e = pool->epoch.load(std::memory_order_relaxed) + 1;
+    int spins = 0;
+    while (held(e) && ++spins < 256) cpu_relax();
+    if (held(e)) {
+      if (!held(e + 2)) {
+        pool->epoch.store(e + 1, std::memory_order_release);  // (even: no job open; the next one is e + 2)
+        g_rs_skipped.fetch_add(1, std::memory_order_relaxed);
+      } else {
+        g_rs_solo.fetch_add(1, std::memory_order_relaxed);
+        pool = nullptr;
+      }
+    }
+  }
   if (!pool) {
     if (!solo) solo.reset(ransac_pool_alloc());
     pool = solo.get();
@@ -1410,16 +1503,20 @@ int find_fundamental_mat(const float* m1, const float* m2, int count, double thr
     g_rs_calls.fetch_add(1, std::memory_order_relaxed);
     g_rs_iters.fetch_add((uint64_t)iters, std::memory_order_relaxed);
     g_rs_points.fetch_add((uint64_t)count, std::memory_order_relaxed);
-    g_rs_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
-                          std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+    const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                            std::chrono::steady_clock::now() - t0).count();
+    g_rs_ns.fetch_add(ns, std::memory_order_relaxed);
+    atomic_max(g_rs_max_ns, ns);
     return good;
   }
   // LMedS for 8..14 points
   const auto t0 = std::chrono::steady_clock::now();
   const int good = lmeds_pooled(pool, m1, m2, count, conf, status);
   g_rs_lm_calls.fetch_add(1, std::memory_order_relaxed);
-  g_rs_lm_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
-                           std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+  const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                          std::chrono::steady_clock::now() - t0).count();
+  g_rs_lm_ns.fetch_add(ns, std::memory_order_relaxed);
+  atomic_max(g_rs_lm_max_ns, ns);
   return good;
 }
 

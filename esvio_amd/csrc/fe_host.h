@@ -56,6 +56,14 @@ struct RansacStats {
   uint64_t calls, iterations, points, ns, lmeds_calls, lmeds_ns;
 };
 RansacStats ransac_stats(bool reset);
+// its tail: {slowest RANSAC call ns, slowest LMedS call ns, iterations the calling thread redid because
+// the helper that had taken them did not deliver, jobs run without the helpers because a helper was
+// still inside both job buffers, jobs that took the other buffer because a helper was still inside
+// theirs, involuntary context switches of the helper threads}
+void ransac_tail(uint64_t out6[6], bool reset);
+// test tap: mark job buffer 0 / 1 (bits of `mask`) of the pool as still holding a helper, as if one had
+// lost its CPU in the middle of a job (on = false: undo)
+void ransac_pool_hold(RansacPool* p, int mask, bool on);
 int find_fundamental_mat(const float* p1, const float* p2, int n, double thr, double conf,
                          uint8_t* status, RansacPool* pool = nullptr);
 

@@ -9,6 +9,7 @@ namespace fe {
 template <class T>
 int dev_alloc(esvio_fe_ctx* c, T** p, size_t count) {
   HIPCHK(c, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+  c->n_allocs++;
   return 0;
 }
 
@@ -49,6 +50,7 @@ T* zdev(esvio_fe_ctx* c, T* host) {
 // ---------------------------------------------------------------- fe_stages.cpp
 int ensure_event_capacity(esvio_fe_ctx* c, size_t n);
 int ensure_sort_capacity(esvio_fe_ctx* c, size_t n);
+int ensure_part_capacity(esvio_fe_ctx* c, size_t n, bool mc);
 int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n);
 int ensure_arc_capacity(esvio_fe_ctx* c, size_t n, int set);
 int pyr_alloc(esvio_fe_ctx* c, PyrStore& ps, int w, int h, int max_level);
@@ -104,6 +106,8 @@ bool stager_ready(esvio_fe_ctx* c, int slot);
 int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const EventRec** dL, const EventRec** dR);
 int stager_mark_read(esvio_fe_ctx* c, int slot, hipStream_t s, bool main_stream);
 int stager_release(esvio_fe_ctx* c, int slot);
+void stager_abandon(esvio_fe_ctx* c, int slot);
+int stager_reserve(esvio_fe_ctx* c, size_t n_events);
 void stager_drain(esvio_fe_ctx* c);
 void stager_destroy(esvio_fe_ctx* c);
 

@@ -51,11 +51,8 @@ int ensure_sort_capacity(esvio_fe_ctx* c, size_t n) {
   return 0;
 }
 
-int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n) {
+static int grow_cand_set(esvio_fe_ctx* c, int set, size_t cap) {
   esvio_fe_ctx::CandSet& s = c->cand[set];
-  if (n <= s.cap) return 0;
-  size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
-  cap = (cap + kArcBlock - 1) / kArcBlock * kArcBlock;
   void* ptrs[] = {s.xy, s.idx, s.cnt, s.comp_xy, s.comp_idx, s.total, s.grp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -68,6 +65,21 @@ int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n) {
   if (int rc = dev_alloc(c, &s.comp_idx, cap)) return rc;
   if (int rc = dev_alloc(c, &s.total, 1)) return rc;
   s.cap = cap;
+  return 0;
+}
+
+int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n) {
+  if (n <= c->cand[set].cap) return 0;
+  size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
+  cap = (cap + kArcBlock - 1) / kArcBlock * kArcBlock;
+  if (int rc = grow_cand_set(c, set, cap)) return rc;
+  // the sets that have never been used get the same size now: in replay mode the Arc* passes rotate
+  // through them, and each one's first use would otherwise put seven hipMallocs into some later call
+  // (a set that holds candidates is left alone: only its own Arc* pass may replace it)
+  static const bool lazy_sets = getenv("ESVIO_FE_LAZY_SETS") != nullptr;  // (A/B of this round; to be removed)
+  for (int k = 0; k < kRightSlots && !lazy_sets; k++)
+    if (k != set && c->cand[k].cap == 0)
+      if (int rc = grow_cand_set(c, k, cap)) return rc;
   return 0;
 }
 
@@ -105,6 +117,7 @@ int pyr_alloc(esvio_fe_ctx* c, PyrStore& ps, int w, int h, int max_level) {
     lh = (lh + 1) / 2;
   }
   HIPCHK(c, hipMalloc(&ps.mem, off));
+  c->n_allocs++;
   HIPCHK(c, hipMemsetAsync(ps.mem, 0, off, cur_stream(c)));  // derivative borders stay 0 forever
   for (int l = 0; l <= levels; l++) {
     ps.d.img[l] = (uint8_t*)ps.mem + img_off[l];
@@ -177,9 +190,8 @@ McParams make_mc_params(const esvio_fe_motion* m) {
   return p;
 }
 
-int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                     double2* L2, double2* S2, uint8_t* arc_touched, const McParams* mc) {
-  const uint32_t n = nL + nR;
+// the partition's buffers for batches of up to n events (d_warp only once a motion-compensated batch comes)
+int ensure_part_capacity(esvio_fe_ctx* c, size_t n, bool mc) {
   if (n > c->part_cap) {
     const size_t cap = std::max<size_t>(n + n / 4, 1 << 16);
     if (c->d_part) (void)hipFree(c->d_part);
@@ -202,6 +214,15 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
     if (int rc = dev_alloc(c, &c->d_tile, need)) return rc;
     c->tile_cap = need;
   }
+  return 0;
+}
+
+int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
+                     double2* L2, double2* S2, uint8_t* arc_touched, const McParams* mc) {
+  const uint32_t n = nL + nR;
+  if (int rc = ensure_part_capacity(c, n, mc != nullptr)) return rc;
+  const size_t nblk_cap = (c->part_cap + 2047) / 2048;
+  const size_t head = (size_t)3 * kTileMaxBins + 64 + 4 * (size_t)kTileMaxGroups;
   TileScratch sc;
   sc.meta = c->d_tile + 3 * kTileMaxBins + 32;  // (the 32 free words behind tile_order)
   sc.ranges = c->d_tile + 3 * kTileMaxBins + 64;
@@ -465,6 +486,7 @@ static int image_stage_slot(esvio_fe_ctx* c, size_t bytes, size_t* off) {
     c->d_img = nullptr;
     c->img_stage_bytes = 0;
     HIPCHK(c, hipHostMalloc((void**)&c->h_img, kSlots * bytes, hipHostMallocDefault));
+    c->n_allocs++;
     if (int rc = dev_alloc(c, &c->d_img, kSlots * bytes)) return rc;
     c->img_stage_bytes = bytes;
   }

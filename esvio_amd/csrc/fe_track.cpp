@@ -4,6 +4,9 @@
 // right-camera tails.  Results are those of the plain sequence in every mode.
 #include "fe_internal.h"
 
+#include <sched.h>
+#include <sys/resource.h>
+
 namespace esvio {
 namespace fe {
 
@@ -344,10 +347,11 @@ struct TrackCall {
       : c(ctx), time(t), left(l), right(r), nL(nl), nR(nr), space(sp), PUB_THIS_FRAME(pub), motion(mo),
         M(ctx->cfg.max_cnt) {}
 
-  void lap(int i) {
-    if (!c->trace) return;
+  void lap(int i) {  // (always on: esvio_fe_latency_stats names the slowest call's phases)
     const auto now = clk::now();
-    c->phase_ms[PUB_THIS_FRAME ? 1 : 0][i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    const double ms = std::chrono::duration<double, std::milli>(now - tp).count();
+    c->lat.cur_phase[i] += ms;
+    if (c->trace) c->phase_ms[PUB_THIS_FRAME ? 1 : 0][i] += ms;
     tp = now;
   }
 
@@ -369,6 +373,12 @@ struct TrackCall {
       if (left == a.left && nL == a.nL && right == a.right && nR == a.nR && space == a.space) {
         if (time != a.time || !same_motion(a))
           return fail(c, ESVIO_FE_EINVAL, "batch differs from the one given to esvio_fe_set_next_batch");
+        // the take-up runs on the prefetch stream and waits for ev_planes_free; early_work only records
+        // that event for batches announced DURING the previous call, so with announce-after-return
+        // (track(k) returns, set_next_batch(k+1), track(k+1)) it would be stale: whatever frame k left
+        // on the main stream (a first, unpublished or lazily returned frame is not synchronised) still
+        // reads the planes and the single partition / CLAHE scratch — order the take-up behind it
+        HIPCHK(c, hipEventRecord(c->ev_planes_free, c->stream));
         if (int rc = prefetch_next(c, true, true)) return rc;
       }
     }
@@ -733,9 +743,10 @@ struct TrackCall {
       lap(4);
       auto tq = clk::now();
       auto sub = [&](int i) {
-        if (!c->trace) return;
         const auto now = clk::now();
-        c->pub_ms[i] += std::chrono::duration<double, std::milli>(now - tq).count();
+        const double ms = std::chrono::duration<double, std::milli>(now - tq).count();
+        c->lat.cur_phase[8 + i] += ms;
+        if (c->trace) c->pub_ms[i] += ms;
         tq = now;
       };
       event_set_mask(c);
@@ -886,10 +897,56 @@ struct TrackCall {
 };
 }  // namespace
 
+namespace {
+long thread_invol_switches() {
+#if defined(__linux__)
+  struct rusage ru;
+  if (getrusage(RUSAGE_THREAD, &ru) == 0) return ru.ru_nivcsw;
+#endif
+  return 0;
+}
+
+// the call's wall time, phases, CPUs, preemptions and allocations into the handle's latency record
+void latency_commit(esvio_fe_ctx* c, bool pub, clk::time_point t0, int cpu0, long sw0, uint64_t allocs0) {
+  esvio_fe_ctx::Latency& L = c->lat;
+  const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+  const long sw = thread_invol_switches() - sw0;
+  const uint64_t al = c->n_allocs - allocs0;
+  L.ring[L.calls % esvio_fe_ctx::Latency::kRing] = (float)ms;
+  L.sum_ms += ms;
+  L.allocs += al;
+  L.nivcsw += (uint64_t)std::max(0l, sw);
+  if (ms > L.max_ms) {
+    L.max_ms = ms;
+    L.max_call = L.calls;
+    L.max_pub = pub;
+    L.max_cpu0 = cpu0;
+    L.max_cpu1 = sched_getcpu();
+    L.max_nivcsw = sw;
+    L.max_allocs = (long)al;
+    std::memcpy(L.max_phase, L.cur_phase, sizeof(L.max_phase));
+  }
+  if (c->slow_call_ms > 0 && ms > c->slow_call_ms) {
+    fprintf(stderr, "[esvio_fe slow call] #%llu (frame %llu, %s) %.3f ms; cpu %d -> %d, %ld involuntary switches, %llu allocations;",
+            (unsigned long long)L.calls, (unsigned long long)c->frame_no, pub ? "published" : "unpublished", ms, cpu0,
+            sched_getcpu(), sw, (unsigned long long)al);
+    for (int i = 0; i < ESVIO_FE_LATENCY_PHASES; i++)
+      if (L.cur_phase[i] > 0.02) fprintf(stderr, " %s=%.3f", esvio_fe_latency_phase_name(i), L.cur_phase[i]);
+    fprintf(stderr, "\n");
+  }
+  L.calls++;
+}
+}  // namespace
+
 int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* left, size_t nL,
                      const esvio_fe_event* right, size_t nR, int space, bool PUB_THIS_FRAME,
                      const esvio_fe_motion* motion) {
   TrackCall t(c, _cur_time, left, nL, right, nR, space, PUB_THIS_FRAME, motion);
+  const auto t0 = clk::now();
+  const int cpu0 = sched_getcpu();
+  const long sw0 = thread_invol_switches();
+  const uint64_t allocs0 = c->n_allocs;
+  std::memset(c->lat.cur_phase, 0, sizeof(c->lat.cur_phase));
   if (int rc = t.check()) return rc;
   // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
   // (lazy mode, pend_right) while this frame's kernels are enqueued
@@ -899,12 +956,27 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   if (PUB_THIS_FRAME && c->pool) host::ransac_pool_wake(c->pool);
   c->cur_time = _cur_time;
   t.tp = clk::now();
-  if (int rc = t.take_batch()) return rc;
-  t.lap(0);
-  if (int rc = t.temporal()) return rc;
-  if (int rc = t.survivors_stereo()) return rc;
-  if (int rc = t.publish()) return rc;
-  return t.tails();
+  c->lat.cur_phase[14] = std::chrono::duration<double, std::milli>(t.tp - t0).count();
+  int rc = t.take_batch();
+  if (!rc) {
+    t.lap(0);
+    rc = t.temporal();
+  }
+  if (!rc) rc = t.survivors_stereo();
+  if (!rc) rc = t.publish();
+  if (!rc) rc = t.tails();
+  if (rc && c->cur_stage >= 0) {
+    // a failed call: its host batch's staging slot goes back (else eight such failures use them all
+    // up).  Kernels of this call may still read the slot's device buffer, and chunks of the batch may
+    // still be on their way out of the caller's memory: both are waited for
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipGetLastError();
+    stager_abandon(c, c->cur_stage);
+    c->cur_stage = -1;
+  }
+  if (!rc) latency_commit(c, PUB_THIS_FRAME, t0, cpu0, sw0, allocs0);
+  return rc;
 }
 
 

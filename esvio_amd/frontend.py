@@ -90,8 +90,20 @@ ABI_SYMBOLS = [
     "esvio_fe_sae_plane_doubles", "esvio_fe_sae_slice_last", "esvio_fe_sae_slice_apply",
     "esvio_fe_sae_slice_commit", "esvio_fe_device_memory", "esvio_fe_exchange_tracks",
     "esvio_fe_comm_unique_id", "esvio_fe_comm_init", "esvio_fe_exchange_begin", "esvio_fe_exchange_end",
-    "esvio_fe_set_auto_exchange",
+    "esvio_fe_set_auto_exchange", "esvio_fe_reserve", "esvio_fe_latency_stats", "esvio_fe_latency_phase_name",
+    "esvio_fe_ransac_tail", "esvio_fe_find_fundamental_mat_held",
 ]
+
+LATENCY_PHASES = 16
+
+
+class Latency(C.Structure):  # esvio_fe_latency
+    _fields_ = [("calls", C.c_uint64), ("mean_ms", C.c_double), ("p50_ms", C.c_double), ("p99_ms", C.c_double),
+                ("max_ms", C.c_double), ("max_call", C.c_uint64), ("max_published", C.c_int32),
+                ("max_cpu_begin", C.c_int32), ("max_cpu_end", C.c_int32), ("max_invol_switches", C.c_int64),
+                ("max_allocs", C.c_int64), ("max_phase_ms", C.c_double * LATENCY_PHASES), ("allocs", C.c_uint64),
+                ("invol_switches", C.c_uint64)]
+
 
 _lib = None
 
@@ -175,6 +187,12 @@ def load_library(build_if_missing=True):
     L.esvio_fe_sae_slice_last.argtypes = [vp, vp, sz, vp, sz, i, vp, i]
     L.esvio_fe_sae_slice_apply.argtypes = [vp, vp, sz, vp, sz, i, vp, i, i, vp, i]
     L.esvio_fe_sae_slice_commit.argtypes = [vp, vp, vp, i, i]
+    L.esvio_fe_reserve.argtypes = [vp, sz, sz, i]
+    L.esvio_fe_latency_stats.argtypes = [vp, C.POINTER(Latency), i]
+    L.esvio_fe_latency_phase_name.restype = C.c_char_p
+    L.esvio_fe_latency_phase_name.argtypes = [i]
+    L.esvio_fe_ransac_tail.argtypes = [vp, i]
+    L.esvio_fe_find_fundamental_mat_held.argtypes = [vp, vp, i, d, d, i, i, vp, C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -441,6 +459,26 @@ class FeatureTracker:
     def reset(self):
         self._hd.check(self._hd.L.esvio_fe_reset(self._hd.h))
 
+    def reserve(self, max_left, max_right, host_batches=False):
+        """size every event-proportional buffer for batches of up to max_left + max_right events now, so
+        that no later call below that size allocates (esvio_fe_reserve)"""
+        self._hd.check(self._hd.L.esvio_fe_reserve(self._hd.h, int(max_left), int(max_right), int(bool(host_batches))))
+
+    def latency_stats(self, reset=False):
+        """wall time of the trackEvent calls since the last reset as the calling thread saw them: count,
+        mean / p50 / p99 / max [ms], and for the slowest call its index, its phases [ms], the CPUs it began
+        and ended on, involuntary context switches and allocations inside it"""
+        o = Latency()
+        L = self._hd.L
+        self._hd.check(L.esvio_fe_latency_stats(self._hd.h, C.byref(o), int(bool(reset))))
+        phases = {L.esvio_fe_latency_phase_name(k).decode(): round(o.max_phase_ms[k], 4)
+                  for k in range(LATENCY_PHASES) if o.max_phase_ms[k] > 0.0005}
+        return dict(calls=int(o.calls), mean_ms=o.mean_ms, p50_ms=o.p50_ms, p99_ms=o.p99_ms, max_ms=o.max_ms,
+                    max_call=int(o.max_call), max_published=bool(o.max_published),
+                    max_cpu=(int(o.max_cpu_begin), int(o.max_cpu_end)), max_invol_switches=int(o.max_invol_switches),
+                    max_allocs=int(o.max_allocs), max_phase_ms=phases, allocs=int(o.allocs),
+                    invol_switches=int(o.invol_switches))
+
     def debug_inject(self, mask):
         """make device-side waits expire on demand (FAULT_TICKET | FAULT_LOOKBACK | FAULT_SPECULATIVE |
         FAULT_CHAINED; 0: normal bounds)"""
@@ -675,15 +713,31 @@ def ransac_stats(reset=False):
             "lmeds_calls": int(out[4]), "lmeds_us": out[5] / 1e3}
 
 
-def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99, threads=1):
-    """cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, conf, status) (host-side stage)."""
+def ransac_tail(reset=False):
+    """the tail of the host findFundamentalMat (process-wide): slowest RANSAC / LMedS call [us], iterations the
+    calling thread redid for a helper that did not deliver, jobs run without the helpers, jobs that took the
+    other job buffer because a helper was stuck in theirs, involuntary context switches of the helper threads"""
+    out = (C.c_uint64 * 6)()
+    rc = load_library().esvio_fe_ransac_tail(out, 1 if reset else 0)
+    if rc != 0:
+        raise FrontendError("ransac_tail rc=%d" % rc)
+    return {"max_us": out[0] / 1e3, "lmeds_max_us": out[1] / 1e3, "redone_iterations": int(out[2]),
+            "solo_jobs": int(out[3]), "skipped_buffers": int(out[4]), "helper_invol_switches": int(out[5])}
+
+
+def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99, threads=1, hold_mask=None):
+    """cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, conf, status) (host-side stage).  hold_mask (test tap,
+    threads >= 2): job buffers of the helper pool marked as still holding a descheduled helper"""
     L = load_library()
     p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
     p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
     n = p1.shape[0]
     status = np.zeros(n, np.uint8)
     k = C.c_int32(0)
-    if threads > 1:
+    if hold_mask is not None:
+        rc = L.esvio_fe_find_fundamental_mat_held(_p(p1), _p(p2), n, thr, conf, threads, int(hold_mask), _p(status),
+                                                  C.byref(k))
+    elif threads > 1:
         rc = L.esvio_fe_find_fundamental_mat_mt(_p(p1), _p(p2), n, thr, conf, threads, _p(status),
                                                 C.byref(k))
     else:

@@ -165,6 +165,12 @@ int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, doubl
  * pool; test tap for esvio_fe_set_host_threads): status and count are those of the call above. */
 int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, double thr,
                                      double conf, int threads, uint8_t* status, int32_t* n_inliers);
+/* Test tap: the same with job buffers of the pool marked as still holding a helper (hold_mask bit 0 / 1:
+ * buffer 0 / 1), as when a helper thread loses its CPU in the middle of a job: the call must not wait for
+ * it — it takes the other buffer, or runs without the helpers when both are held — and must return the
+ * same status and count (esvio_fe_ransac_tail counts both cases).  threads >= 2. */
+int esvio_fe_find_fundamental_mat_held(const float* p1, const float* p2, int n, double thr, double conf,
+                                       int threads, int hold_mask, uint8_t* status, int32_t* n_inliers);
 /* Test tap: the hypot inside that function's 7-point solver: cv::SVD's Jacobi rotations call hypot
  * unqualified inside namespace cv, which resolves to lapack.cpp's own a*sqrt(1+(b/a)^2) template, not
  * to libm's; IEEE operations only, so the result does not depend on the host's libm. */
@@ -395,7 +401,48 @@ int esvio_fe_mem_upload(void* dst_device, const void* src_host, size_t bytes);
 int esvio_fe_debug_inject(esvio_fe_handle h, int mask);
 int esvio_fe_debug_counters(esvio_fe_handle h, uint64_t out4[4]);
 
+/* ---- capacity ----------------------------------------------------------------------------- */
+/* Every event-proportional device buffer (partition scratch, candidate sets, staging lanes) grows on
+ * demand, by a hipFree + hipMalloc inside the call that first needs more — a stall of 0.1-2 ms in the
+ * middle of a stream.  esvio_fe_reserve makes them all large enough for batches of up to
+ * max_events_left + max_events_right events (and for max_events_left Arc* candidates in every candidate
+ * set) now, so that no call below that size allocates (esvio_fe_latency.allocs counts the ones that
+ * do); with host_batches != 0 also the staging slots of batches handed over in ESVIO_FE_HOST memory
+ * (8 slots of 32 B per event, half of it pinned).  Not while batches are announced.  The reference has
+ * no counterpart: its std::vectors grow inside the callbacks. */
+int esvio_fe_reserve(esvio_fe_handle h, size_t max_events_left, size_t max_events_right, int host_batches);
+
 /* ---- measurement --------------------------------------------------------------------- */
+/* Wall time of the esvio_fe_track_event(_mc) calls on this handle since the last reset, as the calling
+ * thread sees them (always on: a dozen clock reads per call).  The percentiles cover the latest 4096
+ * calls.  For the slowest call: its index since the reset, whether it published, where its time went
+ * (esvio_fe_latency_phase_name(i) names max_phase_ms[i]; entries 8.. are parts of entry 5 on published
+ * frames), the CPUs the calling thread was on when it began / ended, the involuntary context switches
+ * the thread suffered inside it (getrusage(RUSAGE_THREAD)) and the device / pinned allocations it
+ * made. */
+#define ESVIO_FE_LATENCY_PHASES 16
+typedef struct esvio_fe_latency {
+  uint64_t calls;
+  double mean_ms, p50_ms, p99_ms, max_ms;
+  uint64_t max_call;
+  int32_t max_published;
+  int32_t max_cpu_begin, max_cpu_end;
+  int64_t max_invol_switches;
+  int64_t max_allocs;
+  double max_phase_ms[ESVIO_FE_LATENCY_PHASES];
+  uint64_t allocs;          /* allocations inside track / announce calls since the reset */
+  uint64_t invol_switches;  /* involuntary context switches inside track calls since the reset */
+} esvio_fe_latency;
+int esvio_fe_latency_stats(esvio_fe_handle h, esvio_fe_latency* out, int reset);
+const char* esvio_fe_latency_phase_name(int i);
+/* Tail of the host RANSAC (process-wide, like esvio_fe_ransac_stats; reset together with it or here):
+ * out6 = {slowest RANSAC call [ns], slowest LMedS call [ns], iterations the calling thread redid because
+ * the helper that took them did not deliver, jobs the calling thread ran alone because helpers were
+ * still inside both job buffers, jobs that took the other buffer because a helper was still inside
+ * theirs (a helper that lost its CPU in the middle of a job), involuntary context switches of the helper
+ * threads}. */
+int esvio_fe_ransac_tail(uint64_t out6[6], int reset);
+
 /* Per-kernel HIP-event timing on the handle's stream (off by default; when on, every launch is
  * bracketed by hipEventRecord and resolved lazily). */
 int esvio_fe_set_profiling(esvio_fe_handle h, int on);

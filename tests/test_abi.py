@@ -131,6 +131,35 @@ def test_host_ransac_with_helper_threads_is_bit_identical(oracle, threads):
             assert cnt_o == cnt_t and np.array_equal(st_o, st_t), (trial, n)
 
 
+def test_host_ransac_does_not_wait_for_a_helper_that_lost_its_cpu(oracle):
+    """A helper thread that is descheduled in the middle of a job keeps that job's buffer marked as in use
+    (round 3's 1.8 ms RANSAC calls: the caller waited for it).  With one buffer held the call takes the
+    other one, with both held it runs without the helpers; flags and count stay those of the sequential
+    loop, for the RANSAC (>= 15 points) and the LMedS (8..14) branch, and the counters show which path ran."""
+    rng = np.random.default_rng(5)
+    K = np.array([[460, 0, 320], [0, 460, 240], [0, 0, 1.0]])
+    for trial in range(24):
+        n = int(rng.integers(15, 200)) if trial % 3 else int(rng.integers(8, 15))
+        X = rng.uniform(-1, 1, (n, 3)) * np.array([2, 1.5, 1]) + np.array([0, 0, 4.0])
+        t = rng.normal(0, 0.05, 3)
+        x = (K @ (X + t).T).T
+        p1 = (K @ X.T).T
+        p1 = (p1[:, :2] / p1[:, 2:]).astype(np.float32)
+        p2 = (x[:, :2] / x[:, 2:]).astype(np.float32) + rng.normal(0, 0.05, (n, 2)).astype(np.float32)
+        k = int(rng.uniform(0.0, 0.5) * n)
+        p2[:k] += rng.normal(0, 8, (k, 2)).astype(np.float32)
+        cnt_1, st_1 = FE.find_fundamental_mat(p1, p2, 1.0, 0.99)
+        for hold in (0, 1, 2, 3):
+            FE.ransac_tail(reset=True)
+            cnt_h, st_h = FE.find_fundamental_mat(p1, p2, 1.0, 0.99, threads=4, hold_mask=hold)
+            assert cnt_h == cnt_1 and np.array_equal(st_h, st_1), (trial, n, hold)
+            tail = FE.ransac_tail()
+            # (a fresh pool's first job is epoch 1 = buffer 0: holding that one makes it move on to buffer 1)
+            assert tail["solo_jobs"] == (1 if hold == 3 else 0), (hold, tail)
+            assert tail["skipped_buffers"] == (1 if hold == 1 else 0), (hold, tail)
+            assert max(tail["max_us"], tail["lmeds_max_us"]) > 0
+
+
 def test_header_is_plain_c(tmp_path):
     """include/esvio_fe.h is the drop-in boundary: it must compile as C99 (no C++ / HIP / torch types)
     and a C translation unit must link against the library's exports"""

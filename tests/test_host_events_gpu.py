@@ -132,3 +132,43 @@ def test_a_batch_announced_late_is_taken_up_by_its_own_call(oracle):
         ft.trackEvent(t, L, R, True)
         _same(ft, tr.track_event(t, L, R, True), ("late", f))
     ft.close()
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+def test_announce_after_return_with_lazy_unpublished_frames(oracle, space):
+    """track(k) returns, THEN batch k+1 is announced and tracked: the take-up of the late announcement
+    runs on the prefetch stream while frame k — a first frame, or an unpublished one that returned lazily,
+    so nobody has synchronised the main stream — may still be using the planes and the partition scratch
+    there (round-3 review: the event the take-up waits for was only recorded for batches announced DURING
+    the previous call).  Every frame must still equal the sequential oracle's."""
+    W, H = 640, 480
+    kw = dict(max_cnt=150, min_dist=10, f_ransac=1)
+    s = SceneStream(W, H, rate=6e6, seed=23, n_rect=20, size=(40.0, 120.0))
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(True)
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    pubs = [False, False, True, False, False, True, True, False, False, False, True, False]
+    bufs = []
+    for f, pub in enumerate(pubs):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        if space == "device":
+            bl, br = FE.EventBuffer(L, FE.DEVICE), FE.EventBuffer(R, FE.DEVICE)
+            bufs += [bl, br]
+            aL, aR = bl.arg, br.arg
+        else:
+            aL, aR = L, R
+        if f:  # (announced only now: the previous call has returned)
+            ft.set_next_batch(t, aL, aR, pub)
+        ft.trackEvent(t, aL, aR, pub)
+        r = tr.track_event(t, L, R, pub)
+        assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0)), ("left surface", f)
+        assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1)), ("right surface", f)
+        if f % 3 == 2:
+            ft.finish()
+            _same(ft, r, ("announce after return", space, f))
+    ft.finish()
+    _same(ft, r, ("announce after return end", space))
+    ft.close()
+    for b in bufs:
+        b.free()

@@ -1,0 +1,130 @@
+"""Tail latency of the replay schedule as a tested quantity (round-3 review: the driver-timed pass had
+steps of 2-7 ms among 0.1 ms ones).  The two causes found (profiles/r04_stall_forensics.md) — a candidate
+set's first use putting seven hipMallocs into some later call, and the calling thread waiting for a RANSAC
+helper that had lost its CPU — are both held here: no allocation after esvio_fe_reserve, and over 1000 replay
+steps no step slower than 5x the median."""
+import time
+
+import numpy as np
+import pytest
+
+from esvio_amd import frontend as FE
+from esvio_amd.events import event_times
+from esvio_amd.node import FreqControl
+from esvio_amd.synth import SceneStream
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480
+
+
+def _stream(n_distinct, cycles, rate, seed):
+    """n_distinct batches of a scene stream, repeated `cycles` times with the stamps moved on by the
+    stream's length each time (the scene jumps back once per cycle: a discontinuity, as after a bag loop)"""
+    s = SceneStream(W, H, rate=rate, seed=seed)
+    base = [s.next_batch()[:2] for _ in range(n_distinct)]
+    span = int(np.ceil(event_times(base[-1][0])[-1] - event_times(base[0][0])[0])) + 1
+    out = []
+    for k in range(cycles):
+        for L, R in base:
+            L2, R2 = L.copy(), R.copy()
+            L2["sec"] += k * span
+            R2["sec"] += k * span
+            out.append((L2, R2))
+    return out
+
+
+def _run(batches, host_threads, steps, warm):
+    bufs, dev = [], []
+    for L, R in batches:
+        bl, br = FE.EventBuffer(L, FE.DEVICE), FE.EventBuffer(R, FE.DEVICE)
+        bufs += [bl, br]
+        dev.append((bl.arg, br.arg, event_times(L)[-1]))
+    fc = FreqControl(15)
+    pubs = []
+    for b in dev:
+        pubs.append(fc.pub_this_frame(b[2]))
+        if pubs[-1]:
+            fc.published()
+    ft = FE.FeatureTracker(FE.make_config(W, H, max_cnt=300, min_dist=10, f_ransac=1))
+    ft.set_lazy_new_stereo(True)
+    if host_threads > 1:
+        ft.set_host_threads(host_threads)
+    ft.reserve(max(len(b[0]) for b in batches), max(len(b[1]) for b in batches))
+    allocs_after_reserve = []
+    announced = 0
+    times = []
+    FE.ransac_tail(reset=True)
+    for i in range(warm + steps):
+        if i == warm:
+            allocs_after_reserve.append(ft.latency_stats(reset=True)["allocs"])
+        t0 = time.perf_counter()
+        while announced < min(i + 3, len(dev) - 1):
+            announced += 1
+            b = dev[announced]
+            ft.set_next_batch(b[2], b[0], b[1], pubs[announced])
+        b = dev[i]
+        ft.trackEvent(b[2], b[0], b[1], pubs[i], copy=False)
+        times.append(time.perf_counter() - t0)
+    ft.finish(copy=False)
+    lat = ft.latency_stats()
+    allocs_after_reserve.append(lat["allocs"])
+    tail = FE.ransac_tail()
+    n_tracks = len(ft.ids)
+    ft.close()
+    for b in bufs:
+        b.free()
+    return np.array(times[warm:]) * 1e3, lat, tail, allocs_after_reserve, n_tracks
+
+
+def test_thousand_replay_steps_without_a_latency_tail():
+    steps, warm = 1000, 40
+    batches = _stream(130, 8, 2.5e6, 4)
+    assert len(batches) >= steps + warm
+    report = []
+    for attempt in range(2):  # (one repeat: a step can still lose its CPU to something else on the box)
+        ms, lat, tail, allocs, n_tracks = _run(batches, 8, steps, warm)
+        med, mx = float(np.median(ms)), float(ms.max())
+        report.append(dict(median_ms=round(med, 4), p99_ms=round(float(np.percentile(ms, 99)), 4), max_ms=round(mx, 4),
+                           argmax=int(ms.argmax()), library=lat, ransac_tail=tail, allocs=allocs))
+        print("tail latency, attempt %d: %s" % (attempt, report[-1]))
+        assert allocs == [0, 0], "allocations after esvio_fe_reserve: %s" % allocs
+        assert n_tracks > 50
+        if mx <= 5.0 * med:
+            break
+    else:
+        pytest.fail("a step slower than 5x the median in both attempts: %s" % report)
+    # the library's own record covers the same calls
+    assert lat["calls"] == steps and lat["max_ms"] <= mx + 1e-3
+
+
+def test_no_allocation_after_reserve_and_a_first_call_like_the_others():
+    """esvio_fe_create has loaded the code object and woken every stream, esvio_fe_reserve has sized the
+    buffers: the first track calls allocate nothing, and host batches (staging slots) neither"""
+    s = SceneStream(W, H, rate=4e6, seed=9)
+    batches = [s.next_batch()[:2] for _ in range(12)]
+    for host in (False, True):
+        ft = FE.FeatureTracker(FE.make_config(W, H, max_cnt=200, min_dist=10, f_ransac=1))
+        ft.reserve(max(len(b[0]) for b in batches), max(len(b[1]) for b in batches), host_batches=host)
+        ft.latency_stats(reset=True)
+        bufs = []
+        for f, (L, R) in enumerate(batches):
+            if host:
+                aL, aR = L, R
+            else:
+                bl, br = FE.EventBuffer(L, FE.DEVICE), FE.EventBuffer(R, FE.DEVICE)
+                bufs += [bl, br]
+                aL, aR = bl.arg, br.arg
+            ft.trackEvent(event_times(L)[-1], aL, aR, f % 2 == 0)
+        lat = ft.latency_stats()
+        assert lat["calls"] == len(batches)
+        assert lat["allocs"] == 0, (host, lat)
+        ft.close()
+        for b in bufs:
+            b.free()
+    # without the reserve the same calls do allocate (the counter counts)
+    ft = FE.FeatureTracker(FE.make_config(W, H, max_cnt=200, min_dist=10, f_ransac=1))
+    L, R = batches[0]
+    ft.trackEvent(event_times(L)[-1], L, R, True)
+    assert ft.latency_stats()["allocs"] > 0
+    ft.close()
