@@ -627,8 +627,12 @@ def main():
         th = time.perf_counter() - th0
         lt = run.ft.latency_stats()
         run.ft.close()
-        return dict(value=round(ev / th / 1e6, 3), unit="Mevents/s", ms_per_step=round(th / args.steps * 1e3, 4),
-                    call_ms_max=round(lt["max_ms"], 4)), ev, th
+        out = dict(value=round(ev / th / 1e6, 3), unit="Mevents/s", ms_per_step=round(th / args.steps * 1e3, 4),
+                   call_ms_max=round(lt["max_ms"], 4))
+        if lt["max_ms"] > 1.0:  # (an outlier: say where it went)
+            out["slowest_call"] = dict(phases_ms=lt["max_phase_ms"], invol_switches=lt["max_invol_switches"],
+                                       allocs=lt["max_allocs"], index=lt["max_call"])
+        return out, ev, th
 
     extra = rank == 0 and world == 1 and not one_rig and not args.no_host_pass
     # ---- the same replay schedule with the events in HOST memory (what the drop-in binding of
@@ -648,6 +652,8 @@ def main():
         one_batch = dict(device_resident_ms_per_step=ob_dev["ms_per_step"], host_pageable_ms_per_step=ob_host["ms_per_step"],
                          device_resident_Mev_s=ob_dev["value"], host_pageable_Mev_s=ob_host["value"],
                          device_resident_call_ms_max=ob_dev["call_ms_max"], host_pageable_call_ms_max=ob_host["call_ms_max"],
+                         slowest_calls={k: v["slowest_call"] for k, v in (("device", ob_dev), ("host", ob_host))
+                                        if "slowest_call" in v} or None,
                          note="one batch in flight, no announcement: the reference node's depth-1 pattern; never `value`")
 
     # ---- the same replay schedule with the LK sums accumulated in float in the order of the reference's

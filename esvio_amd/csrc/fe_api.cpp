@@ -1228,7 +1228,7 @@ const char* esvio_fe_latency_phase_name(int i) {
       "host mask + enqueue detect/stereo", "wait stereo LK", "host tail",
       "pub: Event_setMask", "pub: points + k_select launch", "pub: speculative + chained LK launches",
       "pub: previous frame's right tail", "pub: stereo LK of new corners launch", "pub: next batch's prefetch launches",
-      "check + take-up of a late batch", ""};
+      "check + take-up of a late batch", "sae: staging the host batch (part of enqueue sae+ts+pyr)"};
   return (i >= 0 && i < ESVIO_FE_LATENCY_PHASES) ? nm[i] : "";
 }
 

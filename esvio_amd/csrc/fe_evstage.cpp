@@ -20,6 +20,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -35,7 +36,18 @@ struct Group {
   std::atomic<uint32_t> chunks_left{0};
 };
 
+// one memcpy into a slot's pinned buffer.  st: 0 queued, 1 taken, 2 done — whoever moves it from 1 to 2
+// accounts for the chunk (a helper, or the calling thread redoing the copy of a helper that went away)
+struct Chunk {
+  int group = 0;
+  const uint8_t* src = nullptr;
+  size_t off = 0, len = 0;  // byte offset inside the slot's buffers
+  std::atomic<uint8_t> st{0};
+};
+
 struct Slot {
+  std::unique_ptr<Chunk[]> chunk;
+  size_t n_chunks = 0, chunk_cap = 0;
   uint8_t* pin = nullptr;
   EventRec* dev = nullptr;
   size_t cap = 0;  // events
@@ -48,10 +60,9 @@ struct Slot {
   std::atomic<int> busy{0};  // chunks of this slot a thread has taken from the queue and not finished
 };
 
-struct Task {  // one memcpy into the slot's pinned buffer
-  int slot, group;
-  const uint8_t* src;
-  size_t off, len;  // byte offset inside the slot's buffers
+struct Task {  // chunk `idx` of slot `slot`
+  int slot;
+  uint32_t idx;
 };
 }  // namespace
 
@@ -66,14 +77,13 @@ struct EventStager {
   bool stop = false;
   // (ESVIO_FE_TRACE) batches, bytes, time the calling thread waited for a batch's staging, chunks it
   // took itself meanwhile, batches a call left for the next one because they had not arrived yet
-  uint64_t batches = 0, bytes_staged = 0, wait_ns = 0, caller_chunks = 0, skipped = 0;
+  uint64_t batches = 0, bytes_staged = 0, wait_ns = 0, caller_chunks = 0, skipped = 0, redone = 0;
 
-  void run_task(const Task& t) {
-    Slot& s = slot[t.slot];
-    std::memcpy(s.pin + t.off, t.src, t.len);
-    Group& g = s.grp[t.group];
+  // the chunk is in the pinned buffer: its group's DMA if it was the group's last, the batch's event if
+  // that was the last group
+  void chunk_done(Slot& s, const Chunk& ch) {
+    Group& g = s.grp[ch.group];
     if (g.chunks_left.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
-    // the group's last chunk is in: its DMA
     if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
       (void)hipGetLastError();
       s.state.store(-1, std::memory_order_release);
@@ -85,6 +95,37 @@ struct EventStager {
       if (!ok || !s.state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel))
         s.state.store(-1, std::memory_order_release);
     }
+  }
+
+  void run_task(const Task& t) {
+    Slot& s = slot[t.slot];
+    Chunk& ch = s.chunk[t.idx];
+    uint8_t q = 0;
+    if (!ch.st.compare_exchange_strong(q, 1, std::memory_order_acq_rel)) return;  // (somebody else's already)
+    std::memcpy(s.pin + ch.off, ch.src, ch.len);
+    uint8_t taken = 1;
+    if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) chunk_done(s, ch);
+  }
+
+  // The calling thread, with nothing left in the queue and the batch still not complete: a chunk some
+  // helper has taken and not finished after `patience` polls is copied again here (same bytes to the same
+  // place) and accounted for by whoever finishes first — a helper that has lost its CPU in the middle of
+  // a 10 us memcpy must not cost the call a scheduler quantum (profiles/r04_stall_forensics.md).
+  bool redo_stuck(int k) {
+    Slot& s = slot[k];
+    bool any = false;
+    for (size_t i = 0; i < s.n_chunks; i++) {
+      Chunk& ch = s.chunk[i];
+      if (ch.st.load(std::memory_order_acquire) != 1) continue;
+      std::memcpy(s.pin + ch.off, ch.src, ch.len);
+      uint8_t taken = 1;
+      if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) {
+        chunk_done(s, ch);
+        redone++;
+        any = true;
+      }
+    }
+    return any;
   }
 
   bool try_one() {  // any thread: take one chunk if there is one
@@ -190,7 +231,8 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
   EventStager* st = nullptr;
   if (int rc = stager_get(c, &st)) return rc;
   int k = 0;
-  while (k < kStageSlots && st->slot[k].in_use) k++;
+  // (a slot a straggling helper is still inside — its chunk was redone by the calling thread — is passed over)
+  while (k < kStageSlots && (st->slot[k].in_use || st->slot[k].busy.load(std::memory_order_acquire) != 0)) k++;
   if (k == kStageSlots) return fail(c, ESVIO_FE_EINTERNAL, "no free event staging slot");
   Slot& s = st->slot[k];
   const size_t n = nL + nR;
@@ -211,12 +253,17 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
   const size_t lo = pinL ? nL * 16 : 0, hi = pinR ? nL * 16 : n * 16;
   std::vector<Task> tasks;
   int ng = 0;
+  s.n_chunks = 0;
   if (hi > lo) {
     ng = std::max(1, std::min(dma_groups, kMaxGroups));
     const size_t chunks = (hi - lo + kChunkBytes - 1) / kChunkBytes;
     ng = (int)std::min<size_t>(ng, chunks);
     const size_t per = (chunks + ng - 1) / ng;  // chunks per group
     ng = (int)((chunks + per - 1) / per);
+    if (chunks + 2 > s.chunk_cap) {  // (+1: a chunk never straddles the two source arrays)
+      s.chunk_cap = chunks + 2 + chunks / 4;
+      s.chunk.reset(new Chunk[s.chunk_cap]);
+    }
     for (int g = 0; g < ng; g++) {
       const size_t a = lo + (size_t)g * per * kChunkBytes, b = std::min(hi, a + per * kChunkBytes);
       s.grp[g].off = a;
@@ -227,7 +274,14 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
         const bool in_left = o < nL * 16;
         const size_t end = std::min(std::min(o + kChunkBytes, b), in_left ? nL * 16 : b);
         const uint8_t* src = in_left ? (const uint8_t*)left + o : (const uint8_t*)right + (o - nL * 16);
-        tasks.push_back(Task{k, g, src, o, end - o});
+        Chunk& ch = s.chunk[s.n_chunks];
+        ch.group = g;
+        ch.src = src;
+        ch.off = o;
+        ch.len = end - o;
+        ch.st.store(0, std::memory_order_relaxed);
+        tasks.push_back(Task{k, (uint32_t)s.n_chunks});
+        s.n_chunks++;
         cnt++;
         o = end;
       }
@@ -263,9 +317,17 @@ int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const Eve
   Slot& sl = st->slot[slot];
   if (sl.state.load(std::memory_order_acquire) == 1) {
     const auto t0 = std::chrono::steady_clock::now();
+    unsigned idle = 0;
     while (sl.state.load(std::memory_order_acquire) == 1) {
-      if (st->try_one()) st->caller_chunks++;
-      else __builtin_ia32_pause();
+      if (st->try_one()) {
+        st->caller_chunks++;
+        idle = 0;
+      } else if (++idle > 2000) {  // (~50 us with nothing to take: some helper holds a chunk and is not finishing it)
+        st->redo_stuck(slot);
+        idle = 0;
+      } else {
+        __builtin_ia32_pause();
+      }
     }
     st->wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   }
@@ -314,6 +376,8 @@ int stager_release(esvio_fe_ctx* c, int slot) {
   Slot& sl = c->stager->slot[slot];
   sl.in_use = false;
   if (sl.state.load(std::memory_order_acquire) == 2) HIPCHK(c, hipEventSynchronize(sl.copied));
+  // (a helper whose chunk was redone may still be inside its own copy of it: it reads the caller's memory)
+  while (sl.busy.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
   return 0;
 }
 
@@ -340,9 +404,10 @@ void stager_destroy(esvio_fe_ctx* c) {
   for (std::thread& t : st->threads) t.join();
   if (c->trace && st->batches)
     fprintf(stderr, "[esvio_fe trace] host-event staging: %llu batches, %.1f MB, %d helper threads; calling thread waited "
-            "%.3f ms per batch (took %llu chunks itself), %llu take-ups postponed to the next call\n",
+            "%.3f ms per batch (took %llu chunks itself, redid %llu a helper had not finished), %llu take-ups postponed to the next call\n",
             (unsigned long long)st->batches, st->bytes_staged / 1e6, (int)st->threads.size(),
-            st->wait_ns / 1e6 / st->batches, (unsigned long long)st->caller_chunks, (unsigned long long)st->skipped);
+            st->wait_ns / 1e6 / st->batches, (unsigned long long)st->caller_chunks, (unsigned long long)st->redone,
+            (unsigned long long)st->skipped);
   if (st->stream) {
     (void)hipStreamSynchronize(st->stream);
     (void)hipStreamDestroy(st->stream);

@@ -3389,10 +3389,8 @@ __device__ __forceinline__ uint32_t bm_read(const uint32_t* p) {
 }
 template <bool GBM>
 __device__ __forceinline__ void bm_fence() {  // earlier ORs of this wave are visible to its later reads
-  if (GBM)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-  else
-    bm_fence<GBM>();
+  if (GBM) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  // (LDS: the unit takes a wave's instructions in order, nothing to do)
 }
 template <bool GBM>
 __device__ __forceinline__ void stamp_words(uint32_t* lds, int wpr, int W, int H, int ax, int yy,
@@ -3707,6 +3705,221 @@ __global__ __launch_bounds__(64) void k_select_gbm(SelectArgs a) {
   select_body<true>(a, lds);
 }
 
+
+// ---- the same greedy with 16 waves (default whenever bitmap + queue fit LDS).  What the sequential
+// loop computes is the lexicographically first maximal independent set of the candidates under "lies
+// inside the other's disc" (symmetric for cv::circle's table and for the Euclidean disc), seeded with
+// the blocked pixels and cut off at max_corners: a candidate's fate depends on EARLIER candidates only.
+// One wave walking the stream pays a serial LDS round trip per accepted corner (~0.19 us: k_select was
+// 53-65 us for ~215 corners, on the frame's device chain).  Here
+//   filter  (all waves): the not-yet-decided candidates — the queue's leftovers, then the stream —
+//           are tested against the bitmap, the live ones compacted IN STREAM ORDER into the queue;
+//           repeated until the queue holds 64 live candidates (or the stream ends);
+//   resolve (wave 0): the queue's first <= 64 entries are all live (nothing was stamped since their
+//           test), so their fate depends only on each other: the greedy among them as 64-bit mask
+//           arithmetic (B_j = lanes inside candidate j's disc), accepted ones written out / published /
+//           stamped; what is left in the queue is re-tested by the next filter.
+// The accepted sequence is the sequential loop's: every candidate is decided after all earlier ones,
+// against a bitmap holding exactly the discs accepted before it.  ~6 filter + resolve rounds for 215
+// corners instead of ~200 serial sub-chunk steps; the bitmap clear and the kept points' discs are
+// spread over 1024 threads (they were ~10 us of the one-wave kernel).
+constexpr int kSelMwThreads = 1024;
+constexpr int kSelMwQueue = kSelMwThreads + 64;
+size_t select_mw_extra_lds_bytes() { return (size_t)(2 * kSelMwQueue + 32 + 16 + 128 + 64) * 4; }
+
+__global__ __launch_bounds__(kSelMwThreads) void k_select_mw(SelectArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwords = a.H * a.wpr;
+  uint32_t* const bitmap = lds;
+  int* const hwtab = (int*)(lds + ((nwords + 3) & ~3));
+  uint32_t* const spts = (uint32_t*)(hwtab + 64);
+  uint32_t* const q_xy = spts + ((a.n_stamp + 3) & ~3);
+  uint32_t* const q_ci = q_xy + kSelMwQueue;
+  uint32_t* const wcnt = q_ci + kSelMwQueue;  // [16] live items per wave of the current filter pass
+  uint32_t* const ctrl = wcnt + 16;           // [0] corners accepted so far, [1] by the latest resolve
+  uint32_t* const adj = ctrl + 16;            // [64 x 2] entry j's neighbours among the 64 being resolved
+  uint32_t* const acc_xy = adj + 128;         // [64] the latest resolve's accepted pixels
+  const int r = a.radius;
+  // ---- bitmap: empty or the caller's blocked pixels; the kept points' discs
+  if (a.init_bits) {
+    for (int i = tid * 4; i < nwords; i += kSelMwThreads * 4) {
+      if (i + 3 < nwords) {
+        *(uint4*)(bitmap + i) = *(const uint4*)(a.init_bits + i);
+      } else {
+        for (int k = i; k < nwords; k++) bitmap[k] = a.init_bits[k];
+      }
+    }
+  } else {
+    for (int i = tid * 4; i < nwords; i += kSelMwThreads * 4) {
+      if (i + 3 < nwords) {
+        *(uint4*)(bitmap + i) = make_uint4(0, 0, 0, 0);
+      } else {
+        for (int k = i; k < nwords; k++) bitmap[k] = 0;
+      }
+    }
+  }
+  if (tid < 64) hwtab[tid] = tid <= r ? (int)a.hw[tid] : -1;
+  if (tid == 0) ctrl[0] = 0;
+  if (a.stamp_pts)
+    for (int k = tid; k < a.n_stamp; k += kSelMwThreads) {
+      const float2 p = a.stamp_pts[k];
+      spts[k] = (uint32_t)__float2int_rn(p.x) | ((uint32_t)__float2int_rn(p.y) << 16);  // cvRound
+    }
+  __syncthreads();
+  if (a.stamp_pts) {
+    const int rows = 2 * r + 1;
+    for (int t = tid; t < a.n_stamp * rows; t += kSelMwThreads) {
+      const int p = t / rows, row = t - p * rows;
+      const uint32_t v = spts[p];
+      const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
+      const int hwr = hwtab[row < r ? r - row : row - r];
+      if (r <= 15) {
+        stamp_row_small<false>(bitmap, a.wpr, a.W, a.H, x, y - r + row, hwr);
+      } else {
+        stamp_row<false>(bitmap, a.wpr, a.W, a.H, x, y - r + row, hwr);
+        if (r > 31) stamp_row_tail<false>(bitmap, a.wpr, a.W, a.H, x, y - r + row, hwr);
+      }
+    }
+  }
+  const uint32_t total = *a.total;
+  __syncthreads();
+  // (block-uniform bookkeeping, every thread keeps its own copy)
+  uint32_t pos = 0;      // next candidate of the stream nobody has looked at
+  int qoff = 0, qn = 0;  // the queue's undecided entries: q_*[qoff .. qoff + qn)
+  int accepted = 0;
+  const uint32_t last = total ? total - 1 : 0;
+  while (accepted < a.max_corners && (qn > 0 || pos < total)) {
+    // ---- filter: thread t takes leftover t, or stream candidate pos + (t - qn)
+    for (;;) {
+      const bool from_q = tid < qn;
+      const uint32_t si = pos + (uint32_t)(tid - qn);
+      const bool have = from_q || si < total;
+      uint32_t xy, ci;
+      if (from_q) {
+        xy = q_xy[qoff + tid];
+        ci = q_ci[qoff + tid];
+      } else {
+        xy = a.comp_xy[min(si, last)];
+        ci = a.comp_idx[min(si, last)];
+      }
+      const int x = xy & 0xffff, y = xy >> 16;
+      const bool alive = have && !((bitmap[y * a.wpr + (x >> 5)] >> (x & 31)) & 1u);
+      const lanemask_t m = bal(alive);
+      if (lane == 0) wcnt[wave] = (uint32_t)__builtin_popcountll(m);
+      lds_barrier();  // (every leftover has been read: the queue may be rewritten from its start)
+      uint32_t before = 0, all = 0;
+#pragma unroll
+      for (int w = 0; w < kSelMwThreads / 64; w++) {
+        const uint32_t cw = wcnt[w];
+        before += w < wave ? cw : 0u;
+        all += cw;
+      }
+      if (alive) {
+        const uint32_t o = before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        q_xy[o] = xy;
+        q_ci[o] = ci;
+      }
+      const uint32_t taken = (uint32_t)(kSelMwThreads - qn);  // stream candidates this pass has looked at
+      pos = pos + taken < total ? pos + taken : total;
+      qoff = 0;
+      qn = (int)all;
+      lds_barrier();
+      if (qn >= 64 || pos >= total) break;
+    }
+    if (!qn) break;
+    // ---- resolve: the first n entries, all live, against each other
+    const int n = qn < 64 ? qn : 64;
+    {
+      // (a) who lies in whose disc: wave w tests every entry against the discs of entries 4w .. 4w+3
+      const bool have = lane < n;
+      const uint32_t xy = q_xy[have ? lane : 0], ci = q_ci[have ? lane : 0];
+      const int x = xy & 0xffff, y = xy >> 16;
+#pragma unroll
+      for (int k = 0; k < 64 / (kSelMwThreads / 64); k++) {
+        const int j = wave * (64 / (kSelMwThreads / 64)) + k;
+        const int ax = __builtin_amdgcn_readlane(x, j), ay = __builtin_amdgcn_readlane(y, j);
+        const int dy = (int)__builtin_amdgcn_sad_u16((unsigned)y, (unsigned)ay, 0u);
+        const int dx = (int)__builtin_amdgcn_sad_u16((unsigned)x, (unsigned)ax, 0u);
+        const bool inside = a.disc_c >= 0 ? dx * dx + dy * dy <= a.disc_c : (dy <= r && dx <= hwtab[min(dy, 63)]);
+        const lanemask_t B = bal(have && inside);
+        if (lane == 0) {
+          adj[2 * j] = (uint32_t)B;
+          adj[2 * j + 1] = (uint32_t)(B >> 32);
+        }
+      }
+      lds_barrier();
+      if (wave == 0) {
+        // (b) the greedy among them, as rounds: an undecided entry with an accepted earlier neighbour is
+        // refused, one whose earlier neighbours are all decided (none accepted) is accepted — the
+        // lowest undecided entry is decided in every round, a typical batch takes 3-6 rounds
+        const lanemask_t Bj = (lanemask_t)adj[2 * lane] | ((lanemask_t)adj[2 * lane + 1] << 32);
+        const lanemask_t earlier = Bj & ((1ull << lane) - 1ull);
+        lanemask_t U = bal(have), A = 0;
+        while (U) {
+          const bool und = (U >> lane) & 1ull;
+          const bool rej = und && (earlier & A) != 0;
+          const bool acc1 = und && !rej && (earlier & U) == 0;
+          const lanemask_t ma = bal(acc1), mr = bal(rej);
+          A |= ma;
+          U &= ~(ma | mr);
+        }
+        // only the first (max_corners - accepted) of them count
+        const int room = a.max_corners - accepted;
+        const int before = __builtin_popcountll(A & ((1ull << lane) - 1ull));
+        const bool mine = ((A >> lane) & 1ull) && before < room;
+        if (mine) {
+          a.out_pts[a.out_base + accepted + before] = make_float2((float)x, (float)y);
+          if (a.pub_slots)
+            __hip_atomic_store(&a.pub_slots[a.out_base + accepted + before],
+                               ((unsigned long long)a.pub_seq << 32) | ((unsigned)y << 16) | (unsigned)x,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (a.out_idx) a.out_idx[accepted + before] = (int)ci;
+          acc_xy[before] = xy;
+        }
+        if (lane == 0) {
+          const int cnt = min(__builtin_popcountll(A), room);
+          ctrl[0] = (uint32_t)(accepted + cnt);
+          ctrl[1] = (uint32_t)cnt;
+        }
+      }
+      lds_barrier();
+      const int cnt = (int)ctrl[1];
+      accepted = (int)ctrl[0];
+      if (accepted < a.max_corners) {
+        // (c) their discs, for everything that is still undecided: one thread per (disc, row)
+        const int rows = 2 * r + 1;
+        for (int t = tid; t < cnt * rows; t += kSelMwThreads) {
+          const int d = t / rows, row = t - d * rows;
+          const uint32_t v = acc_xy[d];
+          const int hwr = hwtab[row < r ? r - row : row - r];
+          if (r <= 15) {
+            stamp_row_small<false>(bitmap, a.wpr, a.W, a.H, (int)(v & 0xffffu), (int)(v >> 16) - r + row, hwr);
+          } else {
+            stamp_row<false>(bitmap, a.wpr, a.W, a.H, (int)(v & 0xffffu), (int)(v >> 16) - r + row, hwr);
+            if (r > 31) stamp_row_tail<false>(bitmap, a.wpr, a.W, a.H, (int)(v & 0xffffu), (int)(v >> 16) - r + row, hwr);
+          }
+        }
+        lds_barrier();
+      }
+    }
+    qoff = n;
+    qn -= n;
+  }
+  if (tid == 0) {
+    *a.n_out = accepted;
+    if (a.n_total) *a.n_total = a.out_base + accepted;
+    if (a.pub_done)
+      __hip_atomic_store(a.pub_done, ((unsigned long long)a.pub_seq << 32) | (unsigned)(a.out_base + accepted),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.host_counts) {
+      a.host_counts[0] = accepted;
+      a.host_counts[1] = a.out_base + accepted;
+      a.host_counts[2] = (int)total;
+    }
+  }
+}
+
 int disc_threshold(const int8_t* hw, int radius) {
   long inside = -1, outside = (long)(radius + 1) * (radius + 1);
   for (int dy = 0; dy <= radius && dy <= kMaxDiscR; dy++) {
@@ -3719,8 +3932,11 @@ int disc_threshold(const int8_t* hw, int radius) {
 }
 
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
+  static const bool serial = getenv("ESVIO_FE_SELECT_SERIAL") != nullptr;  // (A/B: the one-wave walk)
   if (a.gbitmap)
     launch_k(k_select_gbm, dim3(1), dim3(64), lds_bytes, s, a);
+  else if (!serial && lds_bytes + select_mw_extra_lds_bytes() <= 160 * 1024)
+    launch_k(k_select_mw, dim3(1), dim3(kSelMwThreads), lds_bytes + select_mw_extra_lds_bytes(), s, a);
   else
     launch_k(k_select, dim3(1), dim3(64), lds_bytes, s, a);
 }

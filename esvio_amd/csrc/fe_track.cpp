@@ -423,8 +423,10 @@ struct TrackCall {
       if (space == ESVIO_FE_HOST && stager_enabled(c) && (nL + nR) * 16 >= (256u << 10)) {
         // not announced: the helpers and this thread stage the chunks together, the DMA of group k runs
         // under the memcpy of group k+1
+        const auto ts0 = clk::now();
         if (int rc = stager_begin(c, left, nL, right, nR, 4, &c->cur_stage)) return rc;
         if (int rc = stager_attach(c, c->cur_stage, nL, c->stream, &dL, &dR)) return rc;
+        c->lat.cur_phase[15] = std::chrono::duration<double, std::milli>(clk::now() - ts0).count();  // (part of phase 0)
       } else if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) {
         return rc;
       }
