@@ -177,6 +177,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
     (void)hipStreamDestroy(c->stream2);
   }
   if (c->ev_planes_free) (void)hipEventDestroy(c->ev_planes_free);
+  if (c->ev_imgs_ready) (void)hipEventDestroy(c->ev_imgs_ready);
+  if (c->ev_arc_side) (void)hipEventDestroy(c->ev_arc_side);
   if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
   if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
   if (c->ev_chain_done) (void)hipEventDestroy(c->ev_chain_done);
@@ -247,7 +249,9 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipEventCreateWithFlags(&c->ev_lks_done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lks_done[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_lknew_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_imgs_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_arc_side, hipEventDisableTiming) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
   for (int i = 0; i < kPrefetchDepth; i++)
     if (hipEventCreateWithFlags(&c->ev_lane_done[i], c->trace ? 0 : hipEventDisableTiming) != hipSuccess ||

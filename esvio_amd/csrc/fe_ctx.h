@@ -139,6 +139,9 @@ struct esvio_fe_ctx {
   // right-camera tail, and on the main stream it would hold up the corner selection behind it
   hipStream_t stream4 = nullptr;
   hipEvent_t ev_planes_free = nullptr;
+  // a plain (not announced) call: the frame's images are built (main stream) -> its Arc* pass on the
+  // prefetch stream and its stereo LK on stream4 start beside the temporal LK; the Arc* pass is done
+  hipEvent_t ev_imgs_ready = nullptr, ev_arc_side = nullptr;
   hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr, ev_sel_host = nullptr;
   std::string err;
   int W = 0, H = 0;

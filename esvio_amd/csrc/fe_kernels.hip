@@ -2210,9 +2210,6 @@ __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
 // wave: the lanes compute the per-pixel integer terms as before, put them into LDS, and a handful
 // of lanes walk their chains (the longest: 105 adds) while the rest idle.  About twice the
 // per-iteration time of the exact-sum mode.
-constexpr int kLkAccZero = 2 * kLkWin * kLkWin;  // index of a word that holds 0 (for the empty slots)
-constexpr int kLkAccWords = kLkAccZero + 4;       // two ints per window pixel + the zero word
-
 // Every chain takes five terms per window row (a vector lane four — or two pair sums — and zeros, the
 // tail its five columns), kept as floats in LDS, T[chain][row][8]: slots a chain does not use hold
 // +0.f (adding it is exact), so that all chain lanes run one loop in lock step — 105 dependent adds,
@@ -2275,65 +2272,143 @@ __device__ __forceinline__ void lk_float_sums_A(float* TA, bool on, int row, int
   A22 = out[2];
 }
 
-// The b vector is summed once per LK iteration, so its chains get one more stage: the 546 float terms
-// (8 vector chains x 21 rows x 2 pair sums, 2 tails x 21 rows x 5 columns) are produced by all 64 lanes
-// from the integer products in LDS — nine terms per lane, sources and destination decoded once per
-// launch — into T[chain][row][8 floats] (slots a chain does not use stay +0.f), and a chain lane then
-// only reads a row (two LDS instructions) and adds its five terms.
-constexpr int kLkChains = 10, kLkTermsPerLane = 9;
-constexpr int kLkTermWords = kLkChains * kLkWin * 8;
+// The b vector is summed once per LK iteration.  Ten chains: vector chains c = 4 comp + k (comp 0: b1,
+// 1: b2; k = column mod 4) take per window row the pair sums of columns (k, k + 4) and (8 + k, 12 + k) —
+// added exactly in int32 (pmaddwd), converted, then ONE float add each, 42 terms —; the tails 8 + comp take
+// columns 16..20 one by one, 105 terms.  A float sum in a prescribed order is a chain of dependent adds;
+// round 3 had ten lanes walk their chains row by row out of LDS: 0.73 us of the 1.23 us iteration
+// (tools/lk_iter_probe.py), every row paying the LDS latency again.  Now:
+//  * the pixel lanes write the INTEGER terms themselves (a lane owns 7 adjacent columns — run 0: 0..6,
+//    run 1: 7..13, run 2: 14..20 — so a pair's two columns sit in one lane except (3, 7), (10, 14),
+//    (11, 15), whose right-hand column is the right neighbour's first / second pixel: one lane shift)
+//    into a table in CHAIN order, cut into segments of 16 words: a vector chain = 3 segments of 7 rows,
+//    a tail = 7 segments of 3 rows (the words a segment does not use stay 0);
+//  * one lane per segment (38 of them) reads its 16 words at once, and they all walk at the same time,
+//    each from a GUESS of what the chain has summed to before its segment: round 1 guesses the exact
+//    integer sum of the earlier segments (three masked lane shifts) — which IS the float chain's value as
+//    long as no add before it rounded, i.e. while the running sum stays below 2^24: 87 % of the
+//    iterations on the bench stream for ALL ten chains (counted with the oracle); then every segment
+//    compares its guess with its left neighbour's end value and, if one differs, all walk again from the
+//    corrected starts.  Segment 0 always starts right, so after r rounds the first r segments are final:
+//    at most 7 rounds = the sequential walk's 105 adds, one round of 16 in the usual case.  The result is
+//    the sequential chain's for any input — the guess only decides how many rounds it takes.
+constexpr int kLkSegWords = 16, kLkVecSegs = 3, kLkTailSegs = 7;
+constexpr int kLkSegStride = 20;  // (16 would put every walking lane's ds_read_b128 on the same four LDS banks)
+constexpr int kLkVecWords = kLkVecSegs * kLkSegStride;     // per vector chain
+constexpr int kLkTailBase = 8 * kLkVecWords;
+constexpr int kLkTailWords = kLkTailSegs * kLkSegStride;   // per tail
+constexpr int kLkTermWords = kLkTailBase + 2 * kLkTailWords;
 
-struct LkTermPlan {  // LDS addresses, fixed for the launch: int sources (b: or the zero word), float destination
-  const int* a[kLkTermsPerLane];
-  const int* b[kLkTermsPerLane];
-  float* d[kLkTermsPerLane];
+struct LkLaneF32 {  // per-lane constants of the float-order sums
+  int wbase;        // pixel lane: word its (row, run) writes from (runs 0 / 1: + 48 per chain; run 2: the tail segment)
+  int run;
+  int rbase;        // walking lane: its segment's first word
+  int g;            // ... its segment's number inside its chain
+  bool walker;
 };
-
-__device__ __forceinline__ LkTermPlan lk_term_plan(int lane, const int* s, float* T) {
-  constexpr int NP2 = kLkWin * kLkWin, kVec = 8 * kLkWin * 2, kAll = kVec + 2 * kLkWin * 5;
-  LkTermPlan p;
-#pragma unroll
-  for (int r = 0; r < kLkTermsPerLane; r++) {
-    const int t = r * 64 + lane;
-    int chain, row, slot, ca, cb;
-    if (t < kVec) {  // vector chains 0..7 (component = chain / 4, k = chain % 4): pair (8 j + k, 8 j + k + 4)
-      chain = t / (kLkWin * 2);
-      const int q = t - chain * (kLkWin * 2);
-      row = q >> 1;
-      slot = q & 1;
-      ca = 8 * slot + (chain & 3);
-      cb = ca + 4;
-    } else {  // tails 8, 9: column 16 + j alone
-      const int u = (t < kAll ? t : kVec) - kVec;
-      chain = 8 + u / (kLkWin * 5);
-      const int q = u - (chain - 8) * (kLkWin * 5);
-      row = q / 5;
-      slot = q - row * 5;
-      ca = 16 + slot;
-      cb = -1;
-    }
-    const int o = (chain < 8 ? chain >> 2 : chain - 8) ? NP2 : 0;
-    p.a[r] = s + o + row * kLkWin + ca;
-    p.b[r] = s + (cb < 0 ? kLkAccZero : o + row * kLkWin + cb);
-    p.d[r] = T + (t < kAll ? (chain * kLkWin + row) * 8 + slot : kLkTermWords);  // (beyond the table: a spare word)
+__device__ __forceinline__ LkLaneF32 lk_lane_f32(int lane) {
+  LkLaneF32 r;
+  const int row = lane < 63 ? lane / 3 : 0;
+  r.run = lane < 63 ? lane - row * 3 : 3;
+  r.wbase = r.run == 2 ? kLkTailBase + (row / 3) * kLkSegStride + (row % 3) * 5
+                       : (row / 7) * kLkSegStride + (row % 7) * 2 + (r.run == 1 ? 1 : 0);
+  if (lane < 16) {  // tails: lanes 0..6 (b1), 8..14 (b2)
+    r.g = lane & 7;
+    r.walker = r.g < kLkTailSegs;
+    r.rbase = kLkTailBase + (lane >> 3) * kLkTailWords + r.g * kLkSegStride;
+  } else if (lane < 48) {  // vector chain c: lanes 16 + 4 c .. + 2
+    r.g = (lane - 16) & 3;
+    r.walker = r.g < kLkVecSegs;
+    r.rbase = ((lane - 16) >> 2) * kLkVecWords + r.g * kLkSegStride;
+  } else {
+    r.g = 0;
+    r.walker = false;
+    r.rbase = 0;
   }
-  return p;
+  if (!r.walker) r.rbase = 0;
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {  // (lanes without a source get 0)
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ void lk_float_sums_b(const int* s, float* T, const LkTermPlan& plan, int lane, float& b1,
-                                                float& b2) {
+__device__ __forceinline__ void lk_float_sums_b(const int (&px)[7], const int (&py)[7], int* Ti, const LkLaneF32& ln,
+                                                float& b1, float& b2) {
+
+  const int nx0 = dpp_mov<0x130>(px[0]), nx1 = dpp_mov<0x130>(px[1]);  // wave_shl:1: the right neighbour's
+  const int ny0 = dpp_mov<0x130>(py[0]), ny1 = dpp_mov<0x130>(py[1]);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous iteration's walkers have read Ti)
+  int* const d = Ti + ln.wbase;
+  if (ln.run == 2) {
 #pragma unroll
-  for (int r = 0; r < kLkTermsPerLane; r++)
-    *plan.d[r] = (float)(*plan.a[r] + *plan.b[r]);  // pmaddwd's int32 pair sum, then v_cvt_f32
+    for (int i = 0; i < 5; i++) {
+      d[i] = px[2 + i];
+      d[kLkTailWords + i] = py[2 + i];
+    }
+  } else if (ln.run < 2) {
+    const bool r1 = ln.run == 1;
+    const int ax[4] = {r1 ? px[1] : px[0], r1 ? px[2] : px[1], r1 ? px[3] : px[2], r1 ? px[4] : px[3]};
+    const int bx[4] = {r1 ? px[5] : px[4], r1 ? px[6] : px[5], r1 ? nx0 : px[6], r1 ? nx1 : nx0};
+    const int ay[4] = {r1 ? py[1] : py[0], r1 ? py[2] : py[1], r1 ? py[3] : py[2], r1 ? py[4] : py[3]};
+    const int by[4] = {r1 ? py[5] : py[4], r1 ? py[6] : py[5], r1 ? ny0 : py[6], r1 ? ny1 : ny0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      d[i * kLkVecWords] = ax[i] + bx[i];  // pmaddwd's int32 pair sum
+      d[(4 + i) * kLkVecWords] = ay[i] + by[i];
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-  // lanes 0..9 walk chains 0..9 (the others walk chain 0 again and are not looked at)
-  const float acc = lk_chain_walk(T, lane < kLkChains ? lane : 0);
+  // ---- the walking lanes
+  int t[kLkSegWords];
+  {
+    const int4* src = (const int4*)(Ti + ln.rbase);
+#pragma unroll
+    for (int q = 0; q < kLkSegWords / 4; q++) {
+      const int4 v = src[q];
+      t[4 * q] = v.x;
+      t[4 * q + 1] = v.y;
+      t[4 * q + 2] = v.z;
+      t[4 * q + 3] = v.w;
+    }
+  }
+  int isum = 0;
+  float f[kLkSegWords];
+#pragma unroll
+  for (int i = 0; i < kLkSegWords; i++) {
+    isum += t[i];
+    f[i] = (float)t[i];  // v_cvt_f32_i32 of the int32 term
+  }
+  // what the chain's earlier segments add up to, exactly (shifts stay inside a chain's lanes: g >= distance)
+  // (the shifts run under full exec — a DPP read of a lane that a branch has switched off returns 0 — and
+  // are masked afterwards)
+  int x = isum;
+  const int m1 = ln.g >= 1 ? -1 : 0, m2 = ln.g >= 2 ? -1 : 0, m4 = ln.g >= 4 ? -1 : 0;
+  x += dpp_mov<0x111>(x) & m1;  // row_shr:1
+  x += dpp_mov<0x112>(x) & m2;  // row_shr:2
+  x += dpp_mov<0x114>(x) & m4;  // row_shr:4
+  float guess = (float)(x - isum), end;
+  for (;;) {
+    float acc = guess;
+#pragma unroll
+    for (int i = 0; i < kLkSegWords; i++) acc = __fadd_rn(acc, f[i]);
+    end = acc;
+    const float start = __int_as_float(dpp_mov<0x111>(__float_as_int(acc)) & m1);  // the left neighbour's end; +0.f for segment 0
+    const bool changed = ln.walker && __float_as_uint(start) != __float_as_uint(guess);
+    guess = start;
+    if (!wave_any(changed)) break;
+  }
+  // chain ends: tails in lanes 6 / 14, vector chain c in lane 18 + 4 c
   const float kScale = 1.f / (float)(1 << 20);
+  const int e = __float_as_int(end);
   float out[2];
 #pragma unroll
   for (int c = 0; c < 2; c++) {
-    const float k0 = __shfl(acc, 4 * c), k1 = __shfl(acc, 4 * c + 1), k2 = __shfl(acc, 4 * c + 2),
-                k3 = __shfl(acc, 4 * c + 3), tail = __shfl(acc, 8 + c);
+    const float k0 = __int_as_float(__builtin_amdgcn_readlane(e, 18 + 16 * c)),
+                k1 = __int_as_float(__builtin_amdgcn_readlane(e, 22 + 16 * c)),
+                k2 = __int_as_float(__builtin_amdgcn_readlane(e, 26 + 16 * c)),
+                k3 = __int_as_float(__builtin_amdgcn_readlane(e, 30 + 16 * c)),
+                tail = __int_as_float(__builtin_amdgcn_readlane(e, 6 + 8 * c));
     const float s0 = __fadd_rn(k0, k2), s2 = __fadd_rn(k1, k3);
     out[c] = __fmul_rn(__fadd_rn(tail, __fadd_rn(__fadd_rn(s0, 0.f), __fadd_rn(s2, 0.f))), kScale);
   }
@@ -2344,8 +2419,8 @@ __device__ __forceinline__ void lk_float_sums_b(const int* s, float* T, const Lk
 // one calcOpticalFlowPyrLK call for one point; returns nextPts[pt] and status
 template <int ACCUM>
 __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, const float2 init,
-                                         uint32_t* regJ, int* acc_s, float* acc_t, float* acc_ta,
-                                         const LkTermPlan* plan, int lane, float2& np_out, int& st_out) {
+                                         uint32_t* regJ, int* acc_t, float* acc_ta, const LkLaneF32* lnf, int lane,
+                                         float2& np_out, int& st_out) {
   constexpr int WIN = kLkWin, NP = 7, NPP = (NP + 1) / 2, NL = kMaxLevels;
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
@@ -2546,30 +2621,22 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       }
       float b1, b2;
       if (ACCUM == 2) {
-        // the per-pixel products diff * Ix, diff * Iy (exact in int32) -> LDS -> the float chains
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+        // the per-pixel products diff * Ix, diff * Iy (exact in int32) -> float terms -> the float chains
+        int px[NP + 1], py[NP + 1];
 #pragma unroll
         for (int m = 0; m < NPP; m++) {
           const uint32_t hi8 = __builtin_amdgcn_perm(t[2 * m + 1], t[2 * m], 0x06050201u);
           const us2 val = __builtin_bit_cast(us2, hi8) >> (unsigned short)1;
           const ss2 diff = __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]);
           const uint32_t ixp = pIxp[L][m], iyp = pIyp[L][m];
-          const int px0 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, ixp & 0x0000ffffu), 0, false);
-          const int py0 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, iyp & 0x0000ffffu), 0, false);
-          const int px1 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, ixp & 0xffff0000u), 0, false);
-          const int py1 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, iyp & 0xffff0000u), 0, false);
-          if (on) {
-            const int i = row * kLkWin + x0 + 2 * m;
-            acc_s[i] = px0;
-            acc_s[kLkWin * kLkWin + i] = py0;
-            if (2 * m + 1 < NP) {
-              acc_s[i + 1] = px1;
-              acc_s[kLkWin * kLkWin + i + 1] = py1;
-            }
-          }
+          px[2 * m] = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, ixp & 0x0000ffffu), 0, false);
+          py[2 * m] = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, iyp & 0x0000ffffu), 0, false);
+          px[2 * m + 1] = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, ixp & 0xffff0000u), 0, false);
+          py[2 * m + 1] = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, iyp & 0xffff0000u), 0, false);
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-        lk_float_sums_b(acc_s, acc_t, *plan, lane, b1, b2);
+        const int (&px7)[7] = *(const int (*)[7])px;
+        const int (&py7)[7] = *(const int (*)[7])py;
+        lk_float_sums_b(px7, py7, acc_t, *lnf, b1, b2);
       } else {
         wave_sum2_exact(sb1, sb2, rl, b1, b2);  // already scaled by FLT_SCALE
       }
@@ -2643,8 +2710,8 @@ __device__ __forceinline__ void chain_publish(const LkKernelArgs& a, int pt, int
 }
 
 template <int ACCUM>
-__device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (*regJ_s)[kLkRegDw], int* acc_s,
-                                               float* acc_t, float* acc_ta, const LkTermPlan* plan) {
+__device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (*regJ_s)[kLkRegDw], int* acc_t,
+                                               float* acc_ta, const LkLaneF32* lnf) {
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int pt = blockIdx.x * 4 + wave;
   const int n = a.n_ptr ? *a.n_ptr : a.n_max;
@@ -2703,7 +2770,7 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
   const float2 init = (a.fwd.flags & 4) ? a.init_pts[pt] : make_float2(0.f, 0.f);
   float2 np;
   int st;
-  lk_point<ACCUM>(a.fwd, prev0, init, regJ_s[wave], acc_s, acc_t, acc_ta, plan, lane, np, st);
+  lk_point<ACCUM>(a.fwd, prev0, init, regJ_s[wave], acc_t, acc_ta, lnf, lane, np, st);
   chain_publish(a, pt, lane, np, st);
   if (lane == 0) {
     a.next_pts[pt] = np;
@@ -2712,7 +2779,7 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
   if (a.have_back) {
     float2 bp;
     int bs;
-    lk_point<ACCUM>(a.back, np, prev0, regJ_s[wave], acc_s, acc_t, acc_ta, plan, lane, bp, bs);
+    lk_point<ACCUM>(a.back, np, prev0, regJ_s[wave], acc_t, acc_ta, lnf, lane, bp, bs);
     if (lane == 0) {
       a.back_pts[pt] = bp;
       a.back_status[pt] = (uint8_t)bs;
@@ -2722,21 +2789,19 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
 
 __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
-  lk_kernel_body<1>(a, regJ_s, nullptr, nullptr, nullptr, nullptr);
+  lk_kernel_body<1>(a, regJ_s, nullptr, nullptr, nullptr);
 }
 // lk_accum 2: float sums in the reference build's order (see lk_float_sums_A / _b)
 __global__ __launch_bounds__(256) void k_lk_f32(LkKernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
-  __shared__ int acc_all[4][kLkAccWords];
-  __shared__ __attribute__((aligned(16))) float term_all[4][kLkTermWords + 4];
+  __shared__ __attribute__((aligned(16))) int term_all[4][kLkTermWords];
   __shared__ __attribute__((aligned(16))) float term_a[4][kLkTermWordsA];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) acc_all[wave][kLkAccZero] = 0;
-  for (int i = lane; i < kLkTermWords; i += 64) term_all[wave][i] = 0.f;  // (unused slots stay +0.f)
+  for (int i = lane; i < kLkTermWords; i += 64) term_all[wave][i] = 0;  // (the words a segment does not use stay 0)
   for (int i = lane; i < kLkTermWordsA; i += 64) term_a[wave][i] = 0.f;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-  const LkTermPlan plan = lk_term_plan(lane, acc_all[wave], term_all[wave]);
-  lk_kernel_body<2>(a, regJ_s, acc_all[wave], term_all[wave], term_a[wave], &plan);
+  const LkLaneF32 lnf = lk_lane_f32(lane);
+  lk_kernel_body<2>(a, regJ_s, term_all[wave], term_a[wave], &lnf);
 }
 
 void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts,

@@ -339,6 +339,11 @@ struct TrackCall {
   bool early_done = false, defer_late = false;
   bool use_spec = false, use_chain = false, chain_covers_next = false;
   bool will_spec = false, detect = false;
+  // a plain call (nothing announced, not lazy): Arc* runs on the prefetch stream beside the temporal LK,
+  // and the stereo LK is launched WITH the temporal one, chained to it point by point on the device
+  bool plain = false, arc_side = false, stereo_chained = false;
+  Pin pin_st{};               // where the frame's stereo LK results of the kept points land
+  std::vector<int> surv_src;  // chained stereo: survivor i was the temporal launch's point surv_src[i]
   int n_surv = 0, n_kept = 0;
   clk::time_point tp;
 
@@ -459,6 +464,7 @@ struct TrackCall {
         render_and_build(c, c->cur_time, c->slot_curL, c->slot_curR, c->raw_cur);
       }
       c->ext_right_pending = false;
+      HIPCHK(c, hipEventRecord(c->ev_imgs_ready, c->stream));
     }
     have_next = !c->inflight.empty();
     next_b = have_next ? c->inflight.front() : Inflight();
@@ -466,6 +472,9 @@ struct TrackCall {
     if (first) c->slot_prevL = c->slot_curL;  // prev_img_left = cur_img_left = img_left (:391)
     c->have_img = true;
     main_reads_planes = !c->cur_prefetched;
+    plain = !c->cur_prefetched && !had_announced && c->inflight.empty() && !c->lazy_new && !c->chain_valid &&
+            !c->spec_valid;
+    pin_st = pin;
     c->cur_pts.clear();
     c->cur_right_pts.clear();
     return 0;
@@ -492,8 +501,19 @@ struct TrackCall {
     if (PUB_THIS_FRAME && !arc_done) {
       if (int rc = ensure_arc_capacity(c, nL, c->cand_cur)) return rc;
       const PyrDesc ts = raw_ts_desc(c, 0);
-      run_arc(c, dL, (uint32_t)nL, &ts, false, false, true, c->cand_cur, arc_marked_main);
-      run_compact(c, (uint32_t)nL, c->cand_cur);
+      if (plain) {
+        // on the prefetch stream (idle in a plain call), behind the frame's images: it runs beside the
+        // temporal LK instead of behind it, and the host's wait for that LK no longer includes it
+        StreamScope on_side_stream(c->stream2);
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_imgs_ready, 0));
+        run_arc(c, dL, (uint32_t)nL, &ts, false, false, true, c->cand_cur, arc_marked_main);
+        run_compact(c, (uint32_t)nL, c->cand_cur);
+        HIPCHK(c, hipEventRecord(c->ev_arc_side, c->stream2));
+        arc_side = true;
+      } else {
+        run_arc(c, dL, (uint32_t)nL, &ts, false, false, true, c->cand_cur, arc_marked_main);
+        run_compact(c, (uint32_t)nL, c->cand_cur);
+      }
       arc_done = true;
       main_reads_planes = true;
       main_reads_events = true;
@@ -615,7 +635,36 @@ struct TrackCall {
         LkArgs f = make_lk(prevL, curL, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n, 3, 30, 0.01, 0);
         LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
                            ESVIO_FE_LK_USE_INITIAL_FLOW);
+        stereo_chained = plain && c->chain_enabled;
+        if (stereo_chained) {
+          c->chain_seq = (c->chain_seq + 1) & 0x3fffffffu;
+          if (!c->chain_seq) c->chain_seq = 1;
+          f.chain_out = c->d_chain;
+          f.chain_seq = c->chain_seq;
+        }
         run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
+        if (stereo_chained) {
+          // cv::calcOpticalFlowPyrLK(curL, curR, cur_pts, ...) (:490) and its reverse (:495) start from the
+          // temporal FORWARD results, point by point: launched now, on the stereo stream, every wave
+          // waiting (bounded) for its point's forward result instead of for the host's round trip; the
+          // points the host's filters drop below are simply not gathered.  Results: the other copy of
+          // set 1 (the temporal launch is still writing this one).
+          const PyrDesc& curR = c->pyr[c->slot_curR].d;
+          pin_st = pin_of(c, c->res_set ^ 1);
+          const size_t Mx = (size_t)std::max(M, 1), stM = (Mx + 63) / 64 * 64;
+          LkArgs f2 = make_lk(curL, curR, nullptr, nullptr, zdev(c, pin_st.ptsB), zdev(c, pin_st.stA), nullptr, n, 3, 30,
+                              0.01, 0);
+          LkArgs b2 = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 3, 30, 0.01, 0);
+          f2.chain_in = c->d_chain;
+          f2.chain_seq = c->chain_seq;
+          f2.chain_ticks = c->lim.chain;
+          f2.poll_err = (int*)(c->z_spec + c->spec_bytes + Mx * 16 + 2 * stM);
+          StreamScope on_stereo_stream(c->stream4);
+          HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_imgs_ready, 0));
+          run_lk(c, f2, cfg.flow_back ? &b2 : nullptr, zdev(c, pin_st.ptsC), zdev(c, pin_st.stB));
+          HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], c->stream4));
+          c->lks_last = c->res_set;
+        }
         if (int rc = early_work()) return rc;
         if (int rc = exchange_flush(c)) return rc;
         lap(1);
@@ -649,6 +698,11 @@ struct TrackCall {
         } else if (int rc = cancel_chain(c)) {
           return rc;
         }
+      }
+      if (stereo_chained) {
+        surv_src.clear();
+        for (int i = 0; i < n; i++)
+          if (status[i]) surv_src.push_back(i);
       }
       reduce_vector(c->prev_pts, status);
       reduce_vector(c->cur_pts, status);
@@ -706,7 +760,7 @@ struct TrackCall {
     const PyrDesc& curR = c->pyr[c->slot_curR].d;
     n_surv = (int)c->cur_pts.size();
     c->src_idx.resize(n_surv);
-    for (int i = 0; i < n_surv; i++) c->src_idx[i] = i;
+    for (int i = 0; i < n_surv; i++) c->src_idx[i] = stereo_chained ? surv_src[i] : i;
     lap(3);
     n_kept = n_surv;
     // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
@@ -719,7 +773,7 @@ struct TrackCall {
         if (const Inflight* nb = next_batch())
           if (int rc = enqueue_spec_temporal(c, *nb, n_kept, false)) return rc;
     }
-    if (n_surv) {
+    if (n_surv && !stereo_chained) {
       std::memcpy(pin.A, c->cur_pts.data(), (size_t)n_surv * 8);
       LkArgs f = make_lk(curL, curR, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n_surv, 3, 30,
                          0.01, 0);
@@ -753,6 +807,9 @@ struct TrackCall {
       };
       event_set_mask(c);
       sub(0);
+      // (a plain call's Arc* pass ran on the prefetch stream: the selection, and whatever the next call
+      // puts on the main stream, follow it)
+      if (arc_side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_arc_side, 0));
       n_kept = (int)c->cur_pts.size();
       const int n_max_cnt = M - n_kept;
       if (int rc = upload_kept()) return rc;
@@ -845,7 +902,29 @@ struct TrackCall {
       // (returns with the stereo LK in flight)
     } else {
       if (!lazy) HIPCHK(c, sync_main(c));  // stereo LK results of the new corners
-      if (n_surv) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));  // ... of the kept points
+      if (n_surv || stereo_chained) HIPCHK(c, sync_event(c->ev_lks_done[c->res_set]));  // ... of the kept points
+      if (stereo_chained) {
+        const size_t Mx = (size_t)std::max(M, 1), stM = (Mx + 63) / 64 * 64;
+        int* wait_expired = (int*)(c->h_spec + c->spec_bytes + Mx * 16 + 2 * stM);
+        if (*wait_expired != 0) {
+          // a wave of the chained stereo launch gave up waiting for its point: the same launch the plain
+          // way, from the temporal forward results (still in this frame's copy of set 1; a point the
+          // filters dropped is tracked for nothing, as in the chained launch)
+          *wait_expired = 0;
+          c->n_chain_expired++;
+          const int n = (int)surv_src.size() ? surv_src.back() + 1 : 0;
+          if (n) {
+            const PyrDesc& curL = c->pyr[c->slot_curL].d;
+            const PyrDesc& curR = c->pyr[c->slot_curR].d;
+            LkArgs f2 = make_lk(curL, curR, zdev(c, pin.ptsB), nullptr, zdev(c, pin_st.ptsB), zdev(c, pin_st.stA), nullptr, n,
+                                3, 30, 0.01, 0);
+            LkArgs b2 = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 3, 30, 0.01, 0);
+            StreamScope on_stereo_stream(c->stream4);
+            run_lk(c, f2, cfg.flow_back ? &b2 : nullptr, zdev(c, pin_st.ptsC), zdev(c, pin_st.stB));
+            HIPCHK(c, hipStreamSynchronize(c->stream4));
+          }
+        }
+      }
     }
     lap(6);
     tt = clk::now();
@@ -866,7 +945,7 @@ struct TrackCall {
         c->pend.ids.assign(c->ids.begin() + n_kept, c->ids.end());
         c->pend.left.assign(c->cur_pts.begin() + n_kept, c->cur_pts.end());
       }
-      right_tail(c, pin, c->cur_pts.data(), c->ids.data(), c->src_idx.data(),
+      right_tail(c, pin_st, c->cur_pts.data(), c->ids.data(), c->src_idx.data(),
                  lazy ? n_kept : (int)c->cur_pts.size(), n_kept, c->cur_time - c->prev_time,
                  c->cur_pts.size());
     }
@@ -880,6 +959,8 @@ struct TrackCall {
     if (c->cur_stage >= 0) {  // the staging slot of this batch's host events is free for another batch
       if (main_reads_events)
         if (int rc = stager_mark_read(c, c->cur_stage, c->stream, true)) return rc;
+      if (arc_side)  // (its k_arc_ev read the batch's events on the prefetch stream)
+        if (int rc = stager_mark_read(c, c->cur_stage, c->stream2, false)) return rc;
       if (int rc = stager_release(c, c->cur_stage)) return rc;
       c->cur_stage = -1;
     }

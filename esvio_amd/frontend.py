@@ -109,7 +109,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "libesvio_fe.so")
+    # (ESVIO_FE_LIB: an experimental build of the library — kernel A/B measurements under tools/_bin)
+    return os.environ.get("ESVIO_FE_LIB") or os.path.join(_HERE, "libesvio_fe.so")
 
 
 def load_library(build_if_missing=True):
@@ -118,7 +119,7 @@ def load_library(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = lib_path()
-    if build_if_missing and _build.needs_build():
+    if build_if_missing and not os.environ.get("ESVIO_FE_LIB") and _build.needs_build():
         _build.build()
     if not os.path.exists(path):
         raise FrontendError("libesvio_fe.so is missing: run `python -m esvio_amd.build`")

@@ -94,6 +94,33 @@ def test_an_expired_speculative_or_chained_lk_wait_is_redone_with_the_same_resul
     ft.close()
 
 
+def test_an_expired_wait_of_the_plain_calls_chained_stereo_lk_is_redone(oracle):
+    """A plain call (nothing announced, the drop-in pattern of INTEGRATION.md) launches the stereo LK of the
+    kept points together with the temporal LK, every wave waiting on the device for its point's forward
+    result; made to give up, the call redoes that launch from the temporal results it has read meanwhile:
+    every frame still equals the sequential oracle's, published or not."""
+    W, H = 640, 480
+    kw = dict(max_cnt=200, min_dist=10, f_ransac=1)
+    s = SceneStream(W, H, rate=4e6, seed=29, n_rect=24, size=(40.0, 120.0))
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    redone = []
+    for f in range(14):
+        if f == 4:
+            ft.debug_inject(FE.FAULT_CHAINED)
+        if f == 10:
+            ft.debug_inject(0)
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        pub = f % 3 != 1
+        ft.trackEvent(t, L, R, pub)
+        _same(ft, tr.track_event(t, L, R, pub), ("plain chained stereo", f))
+        redone.append(ft.debug_counters()["chain_redone"])
+    assert redone[3] == 0 and redone[9] > redone[3] and redone[-1] == redone[9], redone
+    assert len(ft.ids) > 80
+    ft.close()
+
+
 def test_fault_mask_from_the_environment(oracle, monkeypatch):
     """ESVIO_FE_FAULT=<mask> applies from esvio_fe_create on"""
     monkeypatch.setenv("ESVIO_FE_FAULT", str(FE.FAULT_TICKET))
