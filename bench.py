@@ -829,6 +829,14 @@ def main():
             library_call_ms=dict(p50=round(l0["p50_ms"], 4), p99=round(l0["p99_ms"], 4), max=round(l0["max_ms"], 4),
                                  max_call=l0["max_call"], max_call_phases_ms=l0["max_phase_ms"],
                                  max_call_cpu=l0["max_cpu"], max_call_invol_switches=l0["max_invol_switches"]),
+            per_pass_library_call_ms_max=[round(l["max_ms"], 3) for l in lib_lat],
+            worst_pass=(lambda w: dict(index=w, step_ms_max=round(float(max(step_ms[w][:-1])), 3),
+                                       step_argmax=int(np.argmax(step_ms[w][:-1])),
+                                       library_max_call=dict(ms=round(lib_lat[w]["max_ms"], 3), call=lib_lat[w]["max_call"],
+                                                             phases_ms=lib_lat[w]["max_phase_ms"],
+                                                             invol_switches=lib_lat[w]["max_invol_switches"],
+                                                             cpu=lib_lat[w]["max_cpu"])))(
+                int(np.argmax([max(sm[:-1]) for sm in step_ms]))),
             allocs_in_timed_passes=sum(l["allocs"] for l in lib_lat),
             invol_switches_in_timed_passes=sum(l["invol_switches"] for l in lib_lat),
             helper_invol_switches_in_timed_passes=sum(t["helper_invol_switches"] for t in ransac_tails),

@@ -1089,6 +1089,7 @@ int esvio_fe_set_host_threads(esvio_fe_handle c, int threads) {
   if (!c || threads < 1 || threads > 16) return ESVIO_FE_EINVAL;
   host::ransac_pool_destroy(c->pool);
   c->pool = host::ransac_pool_create(threads - 1);
+  stager_share_pool(c);
   return 0;
 }
 

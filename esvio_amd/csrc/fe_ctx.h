@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -198,6 +199,9 @@ struct esvio_fe_ctx {
   std::deque<Inflight> inflight;   // SAE update / images / pyramids enqueued on the prefetch stream
   bool cur_prefetched = false;     // the frame being processed came from the prefetch stream
   EventStager* stager = nullptr;  // host-resident batches: pinned chunks + DMA by helper threads
+  // chunks queued in the stager right now; lives here (not in the stager) because the RANSAC helpers poll
+  // it while they spin, and the handle outlives both
+  std::atomic<int> stage_pending{0};
   int cur_stage = -1;             // staging slot of the batch being tracked
   int stage_threads = 0;          // helper threads of the stager (0: off)
   // bounds of the device-side waits handed to the launches; esvio_fe_debug_inject / ESVIO_FE_FAULT set

@@ -34,9 +34,10 @@ constexpr int kMaxGroups = 8;
 struct Group {
   size_t off = 0, len = 0;  // byte range of the slot's buffers that one DMA moves
   std::atomic<uint32_t> chunks_left{0};
+  std::atomic<bool> dma_enq{false};  // the group's DMA has been enqueued (at least once)
 };
 
-// one memcpy into a slot's pinned buffer.  st: 0 queued, 1 taken, 2 done — whoever moves it from 1 to 2
+// one memcpy into a slot's pinned buffer.  st: 0 not taken, 1 taken, 2 done — whoever moves it from 1 to 2
 // accounts for the chunk (a helper, or the calling thread redoing the copy of a helper that went away)
 struct Chunk {
   int group = 0;
@@ -47,7 +48,10 @@ struct Chunk {
 
 struct Slot {
   std::unique_ptr<Chunk[]> chunk;
-  size_t n_chunks = 0, chunk_cap = 0;
+  size_t chunk_cap = 0;
+  std::atomic<uint32_t> n_chunks{0};  // of the batch being staged
+  std::atomic<uint32_t> next{0};      // the next chunk nobody has taken (>= n_chunks: none left)
+  int n_groups = 0;
   uint8_t* pin = nullptr;
   EventRec* dev = nullptr;
   size_t cap = 0;  // events
@@ -57,49 +61,56 @@ struct Slot {
   std::atomic<int> state{0};  // 0 idle, 1 staging, 2 every DMA enqueued and `copied` recorded, -1 failed
   Group grp[kMaxGroups];
   std::atomic<uint32_t> groups_left{0};
-  std::atomic<int> busy{0};  // chunks of this slot a thread has taken from the queue and not finished
-};
-
-struct Task {  // chunk `idx` of slot `slot`
-  int slot;
-  uint32_t idx;
+  std::atomic<int> busy{0};  // threads inside this slot's chunks (or about to take one)
 };
 }  // namespace
 
+// Work is handed out without a lock (a thread that loses its CPU while holding one would stop every
+// other thread for a scheduler quantum: profiles/r04_stall_forensics.md): a slot's chunks are numbered,
+// `next` is an atomic counter.  Everything a thread does for a chunk may be done twice — the copy writes
+// the same bytes, a group's DMA moves the same bytes, `copied` recorded again only moves the event
+// later — so the calling thread, when it waits for a batch (stager_attach), finishes whatever a helper
+// has started and not finished instead of waiting for that helper.
 struct EventStager {
   esvio_fe_ctx* c = nullptr;
   hipStream_t stream = nullptr;
   Slot slot[kStageSlots];
   std::vector<std::thread> threads;
-  std::mutex mu;
+  std::mutex mu;  // (only the sleeping helpers' condition variable)
   std::condition_variable cv;
-  std::deque<Task> q;
-  bool stop = false;
+  std::atomic<int>* pending = nullptr;  // -> esvio_fe_ctx::stage_pending: chunks nobody has taken yet, all slots
+  std::atomic<bool> stop{false};
   // (ESVIO_FE_TRACE) batches, bytes, time the calling thread waited for a batch's staging, chunks it
   // took itself meanwhile, batches a call left for the next one because they had not arrived yet
   uint64_t batches = 0, bytes_staged = 0, wait_ns = 0, caller_chunks = 0, skipped = 0, redone = 0;
+
+  void enqueue_dma(Slot& s, Group& g) {
+    if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      s.state.store(-1, std::memory_order_release);
+    }
+    g.dma_enq.store(true, std::memory_order_release);
+  }
+  void finish_batch(Slot& s) {  // every group's DMA is enqueued: the event the compute streams wait for
+    const bool ok = hipEventRecord(s.copied, stream) == hipSuccess;
+    int expect = 1;
+    if (!ok)
+      s.state.store(-1, std::memory_order_release);
+    else
+      (void)s.state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel);  // (2 already: a redone batch)
+  }
 
   // the chunk is in the pinned buffer: its group's DMA if it was the group's last, the batch's event if
   // that was the last group
   void chunk_done(Slot& s, const Chunk& ch) {
     Group& g = s.grp[ch.group];
     if (g.chunks_left.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
-    if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
-      (void)hipGetLastError();
-      s.state.store(-1, std::memory_order_release);
-    }
-    if (s.groups_left.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-      // the last group: every DMA of the batch has been enqueued (by whichever thread) before this record
-      const bool ok = hipEventRecord(s.copied, stream) == hipSuccess;
-      int expect = 1;
-      if (!ok || !s.state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel))
-        s.state.store(-1, std::memory_order_release);
-    }
+    enqueue_dma(s, g);
+    if (s.groups_left.fetch_sub(1, std::memory_order_acq_rel) == 1) finish_batch(s);
   }
 
-  void run_task(const Task& t) {
-    Slot& s = slot[t.slot];
-    Chunk& ch = s.chunk[t.idx];
+  void run_chunk(Slot& s, uint32_t idx) {
+    Chunk& ch = s.chunk[idx];
     uint8_t q = 0;
     if (!ch.st.compare_exchange_strong(q, 1, std::memory_order_acq_rel)) return;  // (somebody else's already)
     std::memcpy(s.pin + ch.off, ch.src, ch.len);
@@ -107,14 +118,35 @@ struct EventStager {
     if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) chunk_done(s, ch);
   }
 
-  // The calling thread, with nothing left in the queue and the batch still not complete: a chunk some
-  // helper has taken and not finished after `patience` polls is copied again here (same bytes to the same
-  // place) and accounted for by whoever finishes first — a helper that has lost its CPU in the middle of
-  // a 10 us memcpy must not cost the call a scheduler quantum (profiles/r04_stall_forensics.md).
-  bool redo_stuck(int k) {
+  // any thread: take one chunk of any batch being staged, if there is one
+  bool try_one() {
+    if (pending->load(std::memory_order_acquire) <= 0) return false;
+    for (Slot& s : slot) {
+      if (s.state.load(std::memory_order_acquire) != 1) continue;
+      s.busy.fetch_add(1, std::memory_order_acq_rel);  // (before the claim: stager_abandon / release wait for it)
+      bool did = false;
+      if (s.state.load(std::memory_order_acquire) == 1 &&
+          s.next.load(std::memory_order_relaxed) < s.n_chunks.load(std::memory_order_acquire)) {
+        const uint32_t idx = s.next.fetch_add(1, std::memory_order_acq_rel);
+        if (idx < s.n_chunks.load(std::memory_order_acquire)) {
+          pending->fetch_sub(1, std::memory_order_acq_rel);
+          run_chunk(s, idx);
+          did = true;
+        }
+      }
+      s.busy.fetch_sub(1, std::memory_order_acq_rel);
+      if (did) return true;
+    }
+    return false;
+  }
+
+  // The calling thread, waiting for slot k with nothing left to take: whatever some helper has started
+  // and not finished is done again here — a chunk taken and not copied, a complete group whose DMA is
+  // not enqueued, a complete batch whose event is not recorded.  Returns whether the batch is complete.
+  void finish_for(int k) {
     Slot& s = slot[k];
-    bool any = false;
-    for (size_t i = 0; i < s.n_chunks; i++) {
+    const uint32_t n = s.n_chunks.load(std::memory_order_acquire);
+    for (uint32_t i = 0; i < n; i++) {
       Chunk& ch = s.chunk[i];
       if (ch.st.load(std::memory_order_acquire) != 1) continue;
       std::memcpy(s.pin + ch.off, ch.src, ch.len);
@@ -122,43 +154,52 @@ struct EventStager {
       if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) {
         chunk_done(s, ch);
         redone++;
-        any = true;
       }
     }
-    return any;
-  }
-
-  bool try_one() {  // any thread: take one chunk if there is one
-    Task t;
-    {
-      std::lock_guard<std::mutex> g(mu);
-      if (q.empty()) return false;
-      t = q.front();
-      q.pop_front();
-      slot[t.slot].busy.fetch_add(1, std::memory_order_acq_rel);
+    bool all = true;
+    for (int g = 0; g < s.n_groups; g++) {
+      Group& gr = s.grp[g];
+      if (gr.chunks_left.load(std::memory_order_acquire) != 0) {
+        all = false;
+        continue;
+      }
+      if (!gr.dma_enq.load(std::memory_order_acquire)) {  // (its last chunk's thread has not got to it)
+        enqueue_dma(s, gr);
+        redone++;
+      }
     }
-    run_task(t);
-    slot[t.slot].busy.fetch_sub(1, std::memory_order_acq_rel);
-    return true;
+    if (all && s.state.load(std::memory_order_acquire) == 1) finish_batch(s);
   }
 
   void worker() {
     (void)hipSetDevice(c->dev);
     for (;;) {
-      Task t;
-      {
-        std::unique_lock<std::mutex> g(mu);
-        cv.wait(g, [&] { return stop || !q.empty(); });
-        if (stop && q.empty()) return;
-        t = q.front();
-        q.pop_front();
-        slot[t.slot].busy.fetch_add(1, std::memory_order_acq_rel);
-      }
-      run_task(t);
-      slot[t.slot].busy.fetch_sub(1, std::memory_order_acq_rel);
+      if (try_one()) continue;
+      std::unique_lock<std::mutex> g(mu);
+      cv.wait(g, [&] { return stop.load(std::memory_order_acquire) || pending->load(std::memory_order_acquire) > 0; });
+      if (stop.load(std::memory_order_acquire)) return;
     }
   }
 };
+
+// what a spinning RANSAC helper does between jobs (host::ransac_pool_set_idle_work): one chunk
+static bool stager_idle_work(void* arg) {
+  EventStager* st = (EventStager*)arg;
+  static thread_local int dev_set = -1;
+  if (dev_set != st->c->dev) {  // (the helper enqueues a group's DMA when it copies the group's last chunk)
+    (void)hipSetDevice(st->c->dev);
+    dev_set = st->c->dev;
+  }
+  return st->try_one();
+}
+
+void stager_share_pool(esvio_fe_ctx* c) {
+  if (!c->pool) return;
+  if (c->stager)
+    host::ransac_pool_set_idle_work(c->pool, &c->stage_pending, stager_idle_work, c->stager);
+  else
+    host::ransac_pool_set_idle_work(c->pool, nullptr, nullptr, nullptr);
+}
 
 int stager_threads_from_env() {
   if (const char* v = getenv("ESVIO_FE_STAGE_THREADS")) return std::max(0, std::min(8, atoi(v)));
@@ -169,6 +210,8 @@ static int stager_get(esvio_fe_ctx* c, EventStager** out) {
   if (!c->stager) {
     EventStager* st = new EventStager();
     st->c = c;
+    st->pending = &c->stage_pending;
+    c->stage_pending.store(0, std::memory_order_release);
     if (hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking) != hipSuccess) {
       delete st;
       return fail(c, ESVIO_FE_EHIP, "hipStreamCreate (event staging) failed");
@@ -183,6 +226,7 @@ static int stager_get(esvio_fe_ctx* c, EventStager** out) {
       }
     for (int i = 0; i < c->stage_threads; i++) st->threads.emplace_back([st] { st->worker(); });
     c->stager = st;
+    stager_share_pool(c);  // the RANSAC helpers, spinning between jobs anyway, take chunks as well
   }
   *out = c->stager;
   return 0;
@@ -251,9 +295,10 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
   s.in_use = true;
   // the pageable part: destination byte range [lo, hi) of the slot's buffers
   const size_t lo = pinL ? nL * 16 : 0, hi = pinR ? nL * 16 : n * 16;
-  std::vector<Task> tasks;
   int ng = 0;
-  s.n_chunks = 0;
+  uint32_t nch = 0;
+  s.n_chunks.store(0, std::memory_order_release);
+  s.next.store(0, std::memory_order_release);
   if (hi > lo) {
     ng = std::max(1, std::min(dma_groups, kMaxGroups));
     const size_t chunks = (hi - lo + kChunkBytes - 1) / kChunkBytes;
@@ -268,38 +313,39 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
       const size_t a = lo + (size_t)g * per * kChunkBytes, b = std::min(hi, a + per * kChunkBytes);
       s.grp[g].off = a;
       s.grp[g].len = b - a;
+      s.grp[g].dma_enq.store(false, std::memory_order_relaxed);
       uint32_t cnt = 0;
       for (size_t o = a; o < b;) {
         // a chunk never straddles the boundary between the two source arrays
         const bool in_left = o < nL * 16;
         const size_t end = std::min(std::min(o + kChunkBytes, b), in_left ? nL * 16 : b);
         const uint8_t* src = in_left ? (const uint8_t*)left + o : (const uint8_t*)right + (o - nL * 16);
-        Chunk& ch = s.chunk[s.n_chunks];
+        Chunk& ch = s.chunk[nch];
         ch.group = g;
         ch.src = src;
         ch.off = o;
         ch.len = end - o;
         ch.st.store(0, std::memory_order_relaxed);
-        tasks.push_back(Task{k, (uint32_t)s.n_chunks});
-        s.n_chunks++;
+        nch++;
         cnt++;
         o = end;
       }
       s.grp[g].chunks_left.store(cnt, std::memory_order_relaxed);
     }
   }
+  s.n_groups = ng;
   s.groups_left.store((uint32_t)ng, std::memory_order_relaxed);
-  s.state.store(tasks.empty() ? 2 : 1, std::memory_order_release);
-  if (tasks.empty() && hipEventRecord(s.copied, st->stream) != hipSuccess) {
-    s.state.store(0, std::memory_order_release);
+  if (!nch && hipEventRecord(s.copied, st->stream) != hipSuccess) {
     s.in_use = false;
     return fail(c, ESVIO_FE_EHIP, "hipEventRecord (event staging) failed");
   }
-  {
-    std::lock_guard<std::mutex> g(st->mu);
-    for (const Task& t : tasks) st->q.push_back(t);
+  s.n_chunks.store(nch, std::memory_order_release);
+  s.state.store(nch ? 1 : 2, std::memory_order_release);  // (open for taking)
+  if (nch) {
+    st->pending->fetch_add((int)nch, std::memory_order_acq_rel);
+    { std::lock_guard<std::mutex> g(st->mu); }  // (a helper between its predicate and its sleep sees the count)
+    st->cv.notify_all();
   }
-  st->cv.notify_all();
   *slot_out = k;
   return 0;
 }
@@ -322,8 +368,8 @@ int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const Eve
       if (st->try_one()) {
         st->caller_chunks++;
         idle = 0;
-      } else if (++idle > 2000) {  // (~50 us with nothing to take: some helper holds a chunk and is not finishing it)
-        st->redo_stuck(slot);
+      } else if (++idle > 1000) {  // (~25 us with nothing to take: some helper has started something and is not finishing it)
+        st->finish_for(slot);
         idle = 0;
       } else {
         __builtin_ia32_pause();
@@ -349,9 +395,11 @@ void stager_abandon(esvio_fe_ctx* c, int slot) {
   if (slot < 0 || !c->stager) return;
   EventStager* st = c->stager;
   Slot& sl = st->slot[slot];
-  {  // queued chunks of this slot: dropped
-    std::lock_guard<std::mutex> g(st->mu);
-    for (auto it = st->q.begin(); it != st->q.end();) it = it->slot == slot ? st->q.erase(it) : it + 1;
+  {  // chunks of this slot nobody has taken: never will be
+    const uint32_t n = sl.n_chunks.load(std::memory_order_acquire);
+    const uint32_t nx = sl.next.exchange(n, std::memory_order_acq_rel);
+    if (nx < n) st->pending->fetch_sub((int)(n - nx), std::memory_order_acq_rel);
+    sl.state.store(-1, std::memory_order_release);  // (closed for taking)
   }
   while (sl.busy.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();  // chunks a thread holds: waited for
   (void)hipStreamSynchronize(st->stream);  // (DMAs straight from a pinned source, groups already enqueued)
@@ -385,9 +433,20 @@ int stager_release(esvio_fe_ctx* c, int slot) {
 void stager_drain(esvio_fe_ctx* c) {
   EventStager* st = c->stager;
   if (!st) return;
-  for (Slot& s : st->slot) {
-    while (s.state.load(std::memory_order_acquire) == 1)
-      if (!st->try_one()) __builtin_ia32_pause();
+  for (int k = 0; k < kStageSlots; k++) {
+    Slot& s = st->slot[k];
+    unsigned idle = 0;
+    while (s.state.load(std::memory_order_acquire) == 1) {
+      if (st->try_one()) {
+        idle = 0;
+      } else if (++idle > 1000) {
+        st->finish_for(k);
+        idle = 0;
+      } else {
+        __builtin_ia32_pause();
+      }
+    }
+    while (s.busy.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
     s.in_use = false;
   }
   (void)hipStreamSynchronize(st->stream);
@@ -396,10 +455,9 @@ void stager_drain(esvio_fe_ctx* c) {
 void stager_destroy(esvio_fe_ctx* c) {
   EventStager* st = c->stager;
   if (!st) return;
-  {
-    std::lock_guard<std::mutex> g(st->mu);
-    st->stop = true;
-  }
+  if (c->pool) host::ransac_pool_set_idle_work(c->pool, nullptr, nullptr, nullptr);
+  st->stop.store(true, std::memory_order_release);
+  { std::lock_guard<std::mutex> g(st->mu); }
   st->cv.notify_all();
   for (std::thread& t : st->threads) t.join();
   if (c->trace && st->batches)

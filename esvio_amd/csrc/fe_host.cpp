@@ -973,6 +973,13 @@ struct RansacPool {
   // microseconds is right: the helpers block between jobs and the wake-up at the start of a
   // published frame's call (ransac_pool_wake) has them back before the RANSAC begins.
   int idle_spin_us = kIdleSpinUs;
+  // (ransac_pool_set_idle_work) what a spinning helper takes when no job is open
+  // `idle_pending` points into memory that outlives the pool (the handle): polled without any guard;
+  // only a helper that sees work there enters the guarded section and looks at the function
+  std::atomic<const std::atomic<int>*> idle_pending{nullptr};
+  std::atomic<bool (*)(void*)> idle_fn{nullptr};
+  void* idle_arg = nullptr;
+  alignas(64) std::atomic<int> idle_inside{0};  // helpers inside idle_fn right now
   alignas(64) std::atomic<uint32_t> epoch{0};  // odd while a job is open; job (epoch >> 1) & 1
   RansacJob job[2];
   // helpers are kept on the cores that share the caller's L3 (one CCD): an iteration is ~0.5 us of
@@ -995,6 +1002,17 @@ struct RansacPool {
       if (quit.load(std::memory_order_acquire)) return;
       const uint32_t e = epoch.load(std::memory_order_acquire);
       if (!(e & 1) || e == seen) {
+        const std::atomic<int>* pend = idle_pending.load(std::memory_order_acquire);
+        if (pend && pend->load(std::memory_order_relaxed) > 0) {
+          idle_inside.fetch_add(1, std::memory_order_acq_rel);
+          bool (*fn)(void*) = idle_fn.load(std::memory_order_acquire);  // (still there?)
+          const bool did = fn && fn(idle_arg);
+          idle_inside.fetch_sub(1, std::memory_order_acq_rel);
+          if (did) {
+            idle_since = std::chrono::steady_clock::now();
+            continue;
+          }
+        }
         cpu_relax();
         if ((++spins & 1023) == 0 &&
             std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(idle_spin_us)) {
@@ -1172,6 +1190,16 @@ void ransac_pool_wake(RansacPool* p) {
     p->wake_seq++;
   }
   p->cv.notify_all();
+}
+
+void ransac_pool_set_idle_work(RansacPool* p, const std::atomic<int>* pending, bool (*fn)(void*), void* arg) {
+  if (!p) return;
+  p->idle_fn.store(nullptr, std::memory_order_release);
+  while (p->idle_inside.load(std::memory_order_acquire) != 0) cpu_relax();  // (nobody is left inside the old one)
+  if (!pending || !fn) return;
+  p->idle_arg = arg;
+  p->idle_pending.store(pending, std::memory_order_release);  // (the handle's counter: outlives the pool)
+  p->idle_fn.store(fn, std::memory_order_release);
 }
 
 void ransac_pool_hold(RansacPool* p, int mask, bool on) {

@@ -1,6 +1,7 @@
 // fe_host.h — host-side pieces of trackEvent that stay on the CPU (<= max_cnt points per frame):
 // pinhole lift, cv::circle disc table, the blocked-pixel bitmap, F-matrix RANSAC.
 #pragma once
+#include <atomic>
 #include <stdint.h>
 
 #include <vector>
@@ -64,6 +65,10 @@ void ransac_tail(uint64_t out6[6], bool reset);
 // test tap: mark job buffer 0 / 1 (bits of `mask`) of the pool as still holding a helper, as if one had
 // lost its CPU in the middle of a job (on = false: undo)
 void ransac_pool_hold(RansacPool* p, int mask, bool on);
+// Other work the helpers take while they spin without a RANSAC job (the handle's host-batch staging:
+// chunks of a batch to copy into pinned memory): `pending` is polled without a lock, `fn(arg)` takes one
+// unit and returns whether there was one.  nullptr: none.
+void ransac_pool_set_idle_work(RansacPool* p, const std::atomic<int>* pending, bool (*fn)(void*), void* arg);
 int find_fundamental_mat(const float* p1, const float* p2, int n, double thr, double conf,
                          uint8_t* status, RansacPool* pool = nullptr);
 

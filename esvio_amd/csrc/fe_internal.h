@@ -107,6 +107,7 @@ int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const Eve
 int stager_mark_read(esvio_fe_ctx* c, int slot, hipStream_t s, bool main_stream);
 int stager_release(esvio_fe_ctx* c, int slot);
 void stager_abandon(esvio_fe_ctx* c, int slot);
+void stager_share_pool(esvio_fe_ctx* c);  // (re)connect the RANSAC helpers to the staging queue
 int stager_reserve(esvio_fe_ctx* c, size_t n_events);
 void stager_drain(esvio_fe_ctx* c);
 void stager_destroy(esvio_fe_ctx* c);
