@@ -116,6 +116,9 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not announce the next batch (esvio_fe_set_next_batch): strictly one "
                          "batch in flight, like the reference's depth-1 queues")
+    ap.add_argument("--no-chain", action="store_true",
+                    help="no launch waits on the device for another one (ESVIO_FE_NO_CHAIN=1): with --no-pipeline "
+                         "the schedule whose per-kernel durations are clean (profiles/*_bench_c3)")
     ap.add_argument("--no-lazy", action="store_true",
                     help="wait for the stereo LK of newly detected corners inside the call that detects "
                          "them (default in replay mode: their right-camera entries are completed by "
@@ -267,6 +270,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.no_chain:
+        os.environ["ESVIO_FE_NO_CHAIN"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     # stdout carries exactly ONE line, the JSON: whatever libraries print through C stdio on fd 1

@@ -290,7 +290,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
   c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
-  c->disc_tab_only = getenv("ESVIO_FE_DISC_TABLE") != nullptr;
+  c->select_one_wave = getenv("ESVIO_FE_SELECT_SERIAL") != nullptr;
   if (const char* v = getenv("ESVIO_FE_SAE_EV_MIN")) c->sae_ev_min = (size_t)strtoull(v, nullptr, 10);
   c->tiled = make_tile_geom(c->W, c->H, &c->tgeom) && getenv("ESVIO_FE_SAE_SORT") == nullptr;
   for (int i = 0; i < kRightSlots; i++)

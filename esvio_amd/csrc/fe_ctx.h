@@ -312,9 +312,8 @@ struct esvio_fe_ctx {
   uint32_t* d_cmap[kRightSlots] = {};
   uint8_t* d_touched[kRightSlots] = {};  // (pixel, polarity) pairs a batch's left events hit
   uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
-  bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1: A/B measurements)
-  bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1: k_time_surface + 3 x k_pyr_down)
-  bool disc_tab_only = false;              // (ESVIO_FE_DISC_TABLE=1: k_select's table look-ups)
+  bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1, test-only: the path batches >= 2^20 events take)
+  bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1, test-only: k_time_surface + 3 x k_pyr_down, the median / equalize path)
   int cand_cur = 0;
   size_t arc_cap = 0;
   uint32_t* d_mask_bits = nullptr;
@@ -345,6 +344,7 @@ struct esvio_fe_ctx {
   // sync B, host B
   uint8_t* d_eq_tmp = nullptr;  // equalize: the two CLAHE outputs before normalisation (linear W x H each)
   bool select_ok = true;  // the greedy selection's bitmap fits LDS
+  bool select_one_wave = false;  // (ESVIO_FE_SELECT_SERIAL=1, test-only: the one-wave selection kernel)
   uint32_t* d_sel_bitmap = nullptr;  // ... else it lives here (k_select_gbm)
   bool trace = false;
   double phase_ms[2][8] = {};  // [published?][phase]

@@ -1104,8 +1104,7 @@ void RansacPool::pin_near_caller() {
         in_domain = true;
         for (int v : near_cpus) on_helper_core = on_helper_core || v == l3_core[i];
       }
-    static const bool pin_old = getenv("ESVIO_FE_PIN_OLD") != nullptr;  // (A/B of this round; to be removed)
-    if (in_domain && (!on_helper_core || pin_old)) {
+    if (in_domain && !on_helper_core) {
       near_of = cpu;
       return;
     }

@@ -87,7 +87,7 @@ int gftt_run(esvio_fe_ctx* c, const PyrDesc& d, int max_corners, double quality,
   sa.wpr = (c->W + 31) / 32;
   sa.max_corners = max_corners;
   euclid_halfwidths(min_distance, sa.hw, &sa.radius);
-  sa.disc_c = c->disc_tab_only ? -1 : disc_threshold(sa.hw, sa.radius);
+  sa.disc_c = disc_threshold(sa.hw, sa.radius);
   sa.out_pts = out_pts;
   sa.out_idx = nullptr;
   sa.out_base = out_base;
@@ -99,6 +99,7 @@ int gftt_run(esvio_fe_ctx* c, const PyrDesc& d, int max_corners, double quality,
   sa.pub_slots = nullptr;
   sa.pub_done = nullptr;
   sa.pub_seq = 0;
+  sa.one_wave = c->select_one_wave ? 1 : 0;
   size_t lds = select_lds_bytes(c);
   if (!c->select_ok) {  // a frame camera's size: the min-distance bitmap goes to device memory
     if (!c->d_sel_bitmap)

@@ -401,6 +401,9 @@ struct SelectArgs {
   unsigned long long* pub_slots;
   unsigned long long* pub_done;
   uint32_t pub_seq;
+  // != 0: the one-wave walk (k_select) even where the 16-wave kernel's queue fits LDS beside the bitmap
+  // (sensors between ~1.2 and 1.3 M pixels take it for lack of LDS; ESVIO_FE_SELECT_SERIAL=1, test-only)
+  int one_wave;
 };
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes);
 // the threshold described at SelectArgs::disc_c for a half-width table, or -1 if there is none

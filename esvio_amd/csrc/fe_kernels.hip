@@ -662,17 +662,13 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
 // See fe_kernels.h (TileGeom).  Bucket of an event = camera * nt_cam + (y / th) * tiles_x + x / tw,
 // or the last bin for an out-of-sensor event.
 bool make_tile_geom(int W, int H, TileGeom* g) {
+  // the smallest tile whose bucket count fits (a larger one was measured at C5: 64x32 takes 10 % off the
+  // scatter and adds 50 % to the apply)
   static const int cand[][2] = {{32, 16}, {32, 32}, {64, 32}};
-  // (ESVIO_FE_TILE=32x32 / 64x32: a larger tile than the smallest that fits — A/B measurements)
-  int min_px = 0;
-  if (const char* v = getenv("ESVIO_FE_TILE")) {
-    int a = 0, b = 0;
-    if (sscanf(v, "%dx%d", &a, &b) == 2) min_px = a * b;
-  }
   for (const auto& c : cand) {
     const int tx = (W + c[0] - 1) / c[0], ty = (H + c[1] - 1) / c[1];
     const int nb = 2 * tx * ty + 1;
-    if (nb > kTileMaxBins || c[0] * c[1] > kTileMaxPx || c[0] * c[1] < min_px) continue;
+    if (nb > kTileMaxBins || c[0] * c[1] > kTileMaxPx) continue;
     g->W = W;
     g->H = H;
     g->tw = c[0];
@@ -1450,11 +1446,8 @@ void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const Ti
   launch_k(k_tile_apply<T, B>, dim3(2 * g.nt_cam), dim3(T), lds, s, (const uint4*)part,                  \
            (const uint32_t*)sc.tile_off, (const uint32_t*)sc.tile_order, g, L2, S2, filter_threshold,     \
            arc_touched, err, spin_limit, (const uint32_t*)sc.meta)
-  static const int force_threads = getenv("ESVIO_FE_APPLY_THREADS") ? atoi(getenv("ESVIO_FE_APPLY_THREADS")) : 0;
-  const int threads = force_threads ? force_threads : (big ? 512 : 256);
-#define ESVIO_TILE_APPLY_B(B)                     \
-  if (threads >= 1024) ESVIO_TILE_APPLY(1024, B); \
-  else if (threads >= 512) ESVIO_TILE_APPLY(512, B); \
+#define ESVIO_TILE_APPLY_B(B)           \
+  if (big) ESVIO_TILE_APPLY(512, B);    \
   else ESVIO_TILE_APPLY(256, B)
   if (g.pix_bits == 9) {
     ESVIO_TILE_APPLY_B(9);
@@ -3997,10 +3990,9 @@ int disc_threshold(const int8_t* hw, int radius) {
 }
 
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
-  static const bool serial = getenv("ESVIO_FE_SELECT_SERIAL") != nullptr;  // (A/B: the one-wave walk)
   if (a.gbitmap)
     launch_k(k_select_gbm, dim3(1), dim3(64), lds_bytes, s, a);
-  else if (!serial && lds_bytes + select_mw_extra_lds_bytes() <= 160 * 1024)
+  else if (!a.one_wave && lds_bytes + select_mw_extra_lds_bytes() <= 160 * 1024)
     launch_k(k_select_mw, dim3(1), dim3(kSelMwThreads), lds_bytes + select_mw_extra_lds_bytes(), s, a);
   else
     launch_k(k_select, dim3(1), dim3(64), lds_bytes, s, a);

@@ -76,8 +76,7 @@ int ensure_cand_capacity(esvio_fe_ctx* c, int set, size_t n) {
   // the sets that have never been used get the same size now: in replay mode the Arc* passes rotate
   // through them, and each one's first use would otherwise put seven hipMallocs into some later call
   // (a set that holds candidates is left alone: only its own Arc* pass may replace it)
-  static const bool lazy_sets = getenv("ESVIO_FE_LAZY_SETS") != nullptr;  // (A/B of this round; to be removed)
-  for (int k = 0; k < kRightSlots && !lazy_sets; k++)
+  for (int k = 0; k < kRightSlots; k++)
     if (k != set && c->cand[k].cap == 0)
       if (int rc = grow_cand_set(c, k, cap)) return rc;
   return 0;
@@ -733,7 +732,7 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* o
   s.max_corners = max_corners;
   s.radius = c->cfg.min_dist;
   for (int i = 0; i <= kMaxDiscR; i++) s.hw[i] = i < (int)c->hw.size() ? (int8_t)c->hw[i] : -1;
-  s.disc_c = c->disc_tab_only ? -1 : disc_threshold(s.hw, s.radius);
+  s.disc_c = disc_threshold(s.hw, s.radius);
   s.out_pts = out_pts;
   s.out_idx = out_idx;
   s.out_base = out_base;
@@ -745,6 +744,7 @@ SelectArgs make_select_args(esvio_fe_ctx* c, int set, int max_corners, float2* o
   s.pub_slots = nullptr;
   s.pub_done = nullptr;
   s.pub_seq = 0;
+  s.one_wave = c->select_one_wave ? 1 : 0;
   return s;
 }
 

@@ -970,12 +970,13 @@ def test_replay_random_schedules(oracle, seed):
 
 
 @pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE",
-                                 "ESVIO_FE_SAE_SORT", "ESVIO_FE_SAE_SORT+ESVIO_FE_SAE_EV_MIN"])
+                                 "ESVIO_FE_SAE_SORT", "ESVIO_FE_SAE_SORT+ESVIO_FE_SAE_EV_MIN", "ESVIO_FE_SELECT_SERIAL"])
 def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
     """the measurement switches read at esvio_fe_create (prefetch sequence submitted as a HIP
     graph; no chained temporal LK; no per-pixel dedup of the Arc* candidates; unfused time surface +
     pyrDown kernels; the radix-sort form of the SAE update instead of the tiled one, with the
-    per-pixel walk and with the per-event apply kernels for batches of >= 1 event instead of >= 2^20)
+    per-pixel walk and with the per-event apply kernels for batches of >= 1 event instead of >= 2^20; the
+    one-wave selection kernel that sensors without LDS for the 16-wave kernel's queue take)
     leave every result bit-identical to the oracle"""
     for o in opt.split("+"):
         monkeypatch.setenv(o, "1")

@@ -92,31 +92,49 @@ def test_lane_form_is_the_one_at_a_time_form_bit_for_bit(oracle):
         assert np.abs(a[t] @ f.T).max() <= 1e-9 * np.abs(a[t]).max()
 
 
-@pytest.mark.parametrize("limit,isa", [(2, []), (4, []), (30, []), (30, ["-DESVIO_NO_SIMD_CLONES"]),
-                                       (30, ["-DESVIO_NO_SIMD_CLONES", "-mavx2"]), (3, ["-DESVIO_NO_SIMD_CLONES", "-mavx2"])])
-def test_lane_form_at_the_sweep_limit_and_on_other_vector_widths(tmp_path, limit, isa):
+_ISA_BUILDS = ([], ["-DESVIO_NO_SIMD_CLONES"], ["-DESVIO_NO_SIMD_CLONES", "-mavx2"])
+_cap_check_cache = {}
+
+
+def _run_cap_check(limit, isa):
+    """compile tests/jacobi_cap_check.cpp (fe_host.cpp with -DESVIO_JACOBI_MAX_SWEEPS=limit and the ISA flags),
+    run it and return its stdout (cached per process: a build is shared by the tests below)"""
+    import os
+    import subprocess
+    import tempfile
+    key = (limit, tuple(isa))
+    if key not in _cap_check_cache:
+        here = os.path.dirname(os.path.abspath(__file__))
+        with tempfile.TemporaryDirectory() as d:
+            exe = os.path.join(d, "jacobi_cap_check")
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fno-math-errno", "-pthread",
+                                   "-DESVIO_JACOBI_MAX_SWEEPS=%d" % limit] + list(isa) +
+                                  ["-I" + os.path.join(here, "..", "include"), os.path.join(here, "jacobi_cap_check.cpp"),
+                                   "-o", exe])
+            out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0 and "identical" in out.stdout, out.stdout + out.stderr
+        _cap_check_cache[key] = out.stdout
+    return _cap_check_cache[key]
+
+
+@pytest.mark.parametrize("limit,isa", [(2, _ISA_BUILDS[0]), (4, _ISA_BUILDS[0]), (30, _ISA_BUILDS[0]), (30, _ISA_BUILDS[1]),
+                                       (30, _ISA_BUILDS[2]), (3, _ISA_BUILDS[2])])
+def test_lane_form_at_the_sweep_limit_and_on_other_vector_widths(limit, isa):
     """OpenCV's limit of 30 Jacobi sweeps is never reached by real systems (~5 sweeps); the lane form
     overlaps consecutive sweeps, so its behaviour AT the limit is checked with the limit lowered:
     tests/jacobi_cap_check.cpp compiles fe_host.cpp with -DESVIO_JACOBI_MAX_SWEEPS and compares the two
     forms' bits on 2003 systems that have not converged by then.  The same program without the
     load-time ISA clones runs the lane form as plain SSE2 and as AVX2 code (every box here has AVX-512,
-    so the library's other two clones would otherwise never execute): mul and add stay separate in all
-    of them, so the bits may not depend on the vector width."""
-    import os
-    import subprocess
-    here = os.path.dirname(os.path.abspath(__file__))
-    exe = str(tmp_path / "jacobi_cap_check")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fno-math-errno", "-pthread",
-                           "-DESVIO_JACOBI_MAX_SWEEPS=%d" % limit] + isa +
-                          ["-I" + os.path.join(here, "..", "include"), os.path.join(here, "jacobi_cap_check.cpp"), "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and "identical" in out.stdout, out.stdout + out.stderr
-    if limit == 30:  # the same bits whatever the vector width (the clone this CPU picks / SSE2 / AVX2 builds against each other)
-        _BASIS_HASHES.append(out.stdout.split()[-1])
-        assert len(set(_BASIS_HASHES)) == 1, _BASIS_HASHES
+    so the library's other two clones would otherwise never execute)."""
+    assert "identical" in _run_cap_check(limit, isa)
 
 
-_BASIS_HASHES = []
+def test_basis_bits_do_not_depend_on_the_vector_width():
+    """mul and add stay separate in every build, so the null-space bits may not depend on the vector width:
+    the clone this CPU picks, the SSE2 build and the AVX2 build print the same hash of their 2003 bases
+    (each computed here, whatever tests ran before)"""
+    hashes = [_run_cap_check(30, isa).split()[-1] for isa in _ISA_BUILDS]
+    assert len(set(hashes)) == 1, hashes
 
 
 def _cv_rng_signs(count, state=0x12345678):

@@ -9,12 +9,12 @@ rm -rf $O; mkdir -p $O
 cd $R
 CMD="python bench.py --steps 40 --warmup 5 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- $CMD > $O/trace.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/plain -o plain -- $CMD --no-pipeline > $O/plain.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- $CMD --no-pipeline > $O/fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write -- $CMD --no-pipeline > $O/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/plain -o plain -- $CMD --no-pipeline --no-chain > $O/plain.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- $CMD --no-pipeline --no-chain > $O/fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write -- $CMD --no-pipeline --no-chain > $O/write.log 2>&1
 T=$(find $O/trace -name "*.db" | head -1); P=$(find $O/plain -name "*.db" | head -1)
 F=$(find $O/fetch -name "*.db" | head -1); W=$(find $O/write -name "*.db" | head -1)
-python tools/rocprof_summary.py --trace $P --pmc FETCH_SIZE=$F --pmc WRITE_SIZE=$W --out $R/gpurun_out/${TAG}_bench_c3 --note "$TAG, one batch in flight (--no-pipeline: no speculative / chained / lazy launches, clean kernel durations): $CMD --no-pipeline (C3 640x480 stereo), MI355X; FETCH_SIZE/WRITE_SIZE in KB per dispatch, separate --pmc passes of the same command" > /dev/null
+python tools/rocprof_summary.py --trace $P --pmc FETCH_SIZE=$F --pmc WRITE_SIZE=$W --out $R/gpurun_out/${TAG}_bench_c3 --note "$TAG, one batch in flight (--no-pipeline --no-chain: no speculative / chained / lazy launches, clean kernel durations): $CMD --no-pipeline --no-chain (C3 640x480 stereo), MI355X; FETCH_SIZE/WRITE_SIZE in KB per dispatch, separate --pmc passes of the same command" > /dev/null
 python tools/rocprof_summary.py --trace $T --out $R/gpurun_out/${TAG}_bench_c3_replay --note "$TAG, replay schedule (3 batches announced ahead, lazy): $CMD; the k_lk average contains the time speculative / chained launches wait for their inputs" > /dev/null
 python tools/timeline.py $T > $R/gpurun_out/${TAG}_bench_c3_replay_timeline.txt 2>&1
 grep -h '"value"' $O/trace.log $O/plain.log | cut -c1-160
