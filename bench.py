@@ -130,6 +130,9 @@ def parse():
                          "the result does not depend on it); 1 = the calling thread only; "
                          "0 = min(8, usable CPUs / (2 * ranks)): the helpers spin, so all ranks' "
                          "threads together have to stay inside the CPU quota")
+    ap.add_argument("--launch-thread", type=int, default=-1, choices=[-1, 0, 1],
+                    help="replay mode: a thread of the handle issues the announced batches' prefetch launches "
+                         "(esvio_fe_set_launch_thread); -1 = on when this rank has at least 4 CPUs")
     ap.add_argument("--split", choices=["rigs", "camera", "time"], default="rigs",
                     help="N>1 sharding: one independent stereo rig per GPU (weak scaling, default); "
                          "BASELINE C4: left/right cameras of ONE rig on 2 GPUs; BASELINE C5: ONE stream, "
@@ -364,6 +367,8 @@ def main():
             helper_spin_us = 30
     if helper_spin_us is not None:
         os.environ["ESVIO_FE_HELPER_SPIN_US"] = str(helper_spin_us)
+    if args.launch_thread < 0:  # (one more spinning thread: only where the rank has CPUs to spare)
+        args.launch_thread = 1 if total_cpus / max(world, 1) >= 4 else 0
 
     def motion_of(mod, i):
         """the Motion_correction_value of batch i (--mc 1): header stamp = the batch's last event, a
@@ -392,6 +397,8 @@ def main():
                 self.ft.set_lazy_new_stereo(True)
             if args.host_threads > 1:
                 self.ft.set_host_threads(args.host_threads)
+            if pipeline and args.launch_thread:
+                self.ft.set_launch_thread(True)
             # set-up, not a step: every event-proportional buffer sized for the stream's largest batch, so
             # that no timed call allocates (`tail_latency.allocs` in the line counts the ones that do)
             if not args.no_reserve:
@@ -883,6 +890,7 @@ def main():
                 "pipelined_next_batch": bool(pipeline),
                 "lazy_new_corner_stereo": bool(lazy),
                 "host_threads": int(max(1, args.host_threads)),
+                "launch_thread": bool(pipeline and args.launch_thread),
                 "helper_idle_spin_us": int(os.environ.get("ESVIO_FE_HELPER_SPIN_US", "2000")),
                 "batches_announced_ahead": int(args.ahead) if pipeline else 0,
                 "track_exchange": ("library (ncclAllGather on the handle's communicator)" if comm_id is not None else

@@ -66,6 +66,7 @@ const char* esvio_fe_last_error(esvio_fe_handle h) { return h ? h->err.c_str() :
 int esvio_fe_destroy(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   (void)hipSetDevice(c->dev);
+  (void)launcher_set(c, false);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream4) (void)hipStreamSynchronize(c->stream4);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -366,6 +367,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
 int esvio_fe_reset(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
+  (void)launcher_drain(c);  // (whatever it was still issuing is discarded with the batches below)
   HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream4));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
@@ -1270,9 +1272,16 @@ int esvio_fe_ransac_tail(uint64_t out6[6], int reset) {
   return 0;
 }
 
+int esvio_fe_set_launch_thread(esvio_fe_handle c, int on) {
+  if (!c) return ESVIO_FE_EINVAL;
+  HIPCHK(c, hipSetDevice(c->dev));
+  return launcher_set(c, on != 0);
+}
+
 int esvio_fe_set_profiling(esvio_fe_handle c, int on) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = launcher_drain(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   resolve_profile(c);
   c->prof_on = on != 0;
@@ -1291,6 +1300,7 @@ int esvio_fe_get_kernel_stats(esvio_fe_handle c, int id, double* total_ms, uint6
                               uint64_t* alg_bytes) {
   if (!c || id < 0 || id >= K_COUNT) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
+  if (int rc = launcher_drain(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(cur_stream(c)));
   resolve_profile(c);

@@ -116,6 +116,7 @@ constexpr int kPrefetchDepth = 3;
 // announced or prefetched and not yet tracked, the one being tracked, one spare)
 constexpr int kStageSlots = 2 * kPrefetchDepth + 2;
 struct EventStager;  // fe_evstage.cpp
+struct Launcher;     // fe_track.cpp: the thread that issues announced batches' prefetch sequences
 constexpr int kLeftSlots = 2 + kPrefetchDepth;   // prev, cur, prefetched...
 constexpr int kRightSlots = 1 + kPrefetchDepth;  // cur, prefetched...
 
@@ -204,6 +205,11 @@ struct esvio_fe_ctx {
   std::atomic<int> stage_pending{0};
   int cur_stage = -1;             // staging slot of the batch being tracked
   int stage_threads = 0;          // helper threads of the stager (0: off)
+  // esvio_fe_set_launch_thread: the HIP calls of an announced batch's prefetch sequence (~10 launches and
+  // event calls, 35-45 us of host time per batch) are issued by a thread of the handle; the calling
+  // thread only does the bookkeeping and, before it consumes a lane, checks that its job has been issued
+  Launcher* launcher = nullptr;
+  uint64_t lane_job[kPrefetchDepth] = {};  // job number that (re)records the lane's events
   // bounds of the device-side waits handed to the launches; esvio_fe_debug_inject / ESVIO_FE_FAULT set
   // chosen ones to 0 (the wait expires the first time it would have to wait)
   struct WaitLimits {

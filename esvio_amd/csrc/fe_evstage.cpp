@@ -409,6 +409,13 @@ void stager_abandon(esvio_fe_ctx* c, int slot) {
   sl.in_use = false;
 }
 
+// where the slot's batch will be on the device (known as soon as the slot is taken)
+void stager_ptrs(esvio_fe_ctx* c, int slot, size_t nL, const EventRec** dL, const EventRec** dR) {
+  Slot& sl = c->stager->slot[slot];
+  *dL = sl.dev;
+  *dR = sl.dev + nL;
+}
+
 // the kernels enqueued on `s` so far are the last ones on that stream to read the slot's device buffer
 int stager_mark_read(esvio_fe_ctx* c, int slot, hipStream_t s, bool main_stream) {
   Slot& sl = c->stager->slot[slot];

@@ -109,11 +109,15 @@ int stager_release(esvio_fe_ctx* c, int slot);
 void stager_abandon(esvio_fe_ctx* c, int slot);
 void stager_share_pool(esvio_fe_ctx* c);  // (re)connect the RANSAC helpers to the staging queue
 int stager_reserve(esvio_fe_ctx* c, size_t n_events);
+void stager_ptrs(esvio_fe_ctx* c, int slot, size_t nL, const EventRec** dL, const EventRec** dR);
 void stager_drain(esvio_fe_ctx* c);
 void stager_destroy(esvio_fe_ctx* c);
 
 // ---------------------------------------------------------------- fe_track.cpp
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first = false);
+int launcher_set(esvio_fe_ctx* c, bool on);   // start / stop the launch thread
+int launcher_drain(esvio_fe_ctx* c);          // every job handed over has been issued (returns the first job error)
+int launcher_wait_lane(esvio_fe_ctx* c, int lane);  // ... the job that records this lane's events
 int cancel_chain(esvio_fe_ctx* c);
 int finalize_right(esvio_fe_ctx* c);
 int finalize_pending(esvio_fe_ctx* c);

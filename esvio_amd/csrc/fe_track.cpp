@@ -7,6 +7,11 @@
 #include <sched.h>
 #include <sys/resource.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 namespace esvio {
 namespace fe {
 
@@ -19,11 +24,179 @@ namespace fe {
 // planes nor the raw surfaces there, so the next prefetch only has to follow its own stream.
 // With the caller's PUB hint the Arc* pass of the batch runs here too (into the other candidate
 // set), which takes it off the main stream's per-frame chain.
+// One batch's prefetch sequence = bookkeeping (which lane / pyramid slots / candidate set it gets, buffer
+// capacities, where its events will be on the device: prefetch_next, always on the calling thread) + the
+// HIP calls (prefetch_issue: waits, ~10 launches, event records — 35-45 us of host time).  With
+// esvio_fe_set_launch_thread the second part is handed to the handle's launch thread.
+struct PrefetchJob {
+  Inflight b;
+  bool wait_planes = false;
+  int lks_wait = -1;  // copy of set 1 whose stereo LK (stream4) the batch's right pyramid slot has to follow, -1: none
+};
+
+static int prefetch_issue(esvio_fe_ctx* c, const PrefetchJob& j) {
+  const Inflight& b = j.b;
+  StreamScope on_prefetch_stream(c->stream2);
+  if (j.wait_planes) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_planes_free, 0));
+  // the right-camera pyramid slot this batch gets may be the one an earlier frame's stereo LK
+  // (stream4) still reads — in lazy mode nobody has waited for that launch yet
+  if (j.lks_wait >= 0) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_lks_done[j.lks_wait], 0));
+  const EventRec *dL = b.dL, *dR = b.dR;
+  if (b.stage >= 0) {
+    if (int rc = stager_attach(c, b.stage, b.nL, c->stream2, &dL, &dR)) return rc;
+  } else if (int rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &dL, &dR, b.lane)) {
+    return rc;
+  }
+  // the ~11 dependent launches up to the pyramids go out as one graph (fe_kernels.h); with the
+  // per-kernel timers on they are launched one by one so that each can be bracketed
+  const bool as_graph = c->graphs_enabled && !c->prof_on;
+  if (as_graph) {
+    c->rec.clear();
+    set_launch_recorder(&c->rec);
+  }
+  bool arc_marked = false;
+  McParams mcp;
+  if (b.has_motion) mcp = make_mc_params(&b.motion);
+  int rc = sae_update(c, dL, (uint32_t)b.nL, dR, (uint32_t)b.nR, b.has_motion ? &mcp : nullptr, nullptr, nullptr,
+                      b.pub && b.nL ? b.cand : -1, &arc_marked);
+  if (!rc) {
+    render_and_build(c, b.time, b.slotL, b.slotR, b.raw);
+    if (record_event(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
+      rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
+  }
+  if (as_graph) {
+    set_launch_recorder(nullptr);
+    if (!rc && launch_as_graph(c->pf_graph, c->rec, c->stream2) != hipSuccess) {
+      // (not expected; the plain path still works)
+      (void)hipGetLastError();
+      c->graphs_enabled = false;
+      destroy_launch_graph(c->pf_graph);
+      if (launch_plain(c->rec, c->stream2) != hipSuccess) rc = fail(c, ESVIO_FE_EHIP, "kernel launch failed");
+    }
+  }
+  if (rc) return rc;
+  if (b.arc_done) {  // (decided with the bookkeeping: the PUB hint says the frame will publish)
+    const PyrDesc& ts = c->cfg.equalize ? c->raw[b.raw][0].d : c->pyr[b.slotL].d;
+    run_arc(c, dL, (uint32_t)b.nL, &ts, false, false, true, b.cand, arc_marked);
+    run_compact(c, (uint32_t)b.nL, b.cand);
+    HIPCHK(c, hipEventRecord(c->ev_lane_arc[b.lane], c->stream2));
+  }
+  // (the last kernels on this stream that read the batch's events)
+  if (b.stage >= 0)
+    if (int rc2 = stager_mark_read(c, b.stage, c->stream2, false)) return rc2;
+  return 0;
+}
+
+// ---- the launch thread: a single-producer single-consumer ring of jobs.  It spins while frames keep
+// coming (a wake-up costs more than a job) and blocks after 2 ms without one.
+struct Launcher {
+  static constexpr int kRing = 8;  // (> kPrefetchDepth jobs can never be outstanding)
+  esvio_fe_ctx* c = nullptr;
+  std::thread th;
+  PrefetchJob ring[kRing];
+  alignas(64) std::atomic<uint64_t> submitted{0};
+  alignas(64) std::atomic<uint64_t> done{0};
+  std::atomic<int> first_rc{0};
+  std::atomic<bool> quit{false};
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<bool> sleeping{false};
+
+  void run() {
+    (void)hipSetDevice(c->dev);
+    auto idle_since = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+      const uint64_t d = done.load(std::memory_order_relaxed);
+      if (submitted.load(std::memory_order_acquire) == d) {
+        if (quit.load(std::memory_order_acquire)) return;
+        __builtin_ia32_pause();
+        if ((++spins & 1023) == 0 &&
+            std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(2000)) {
+          std::unique_lock<std::mutex> lk(mu);
+          sleeping.store(true, std::memory_order_release);
+          cv.wait(lk, [&] {
+            return submitted.load(std::memory_order_acquire) != done.load(std::memory_order_relaxed) ||
+                   quit.load(std::memory_order_acquire);
+          });
+          sleeping.store(false, std::memory_order_release);
+          idle_since = std::chrono::steady_clock::now();
+        }
+        continue;
+      }
+      const int rc = prefetch_issue(c, ring[d % kRing]);
+      if (rc) {
+        int zero = 0;
+        (void)first_rc.compare_exchange_strong(zero, rc, std::memory_order_acq_rel);
+      }
+      done.store(d + 1, std::memory_order_release);
+      idle_since = std::chrono::steady_clock::now();
+    }
+  }
+};
+
+int launcher_set(esvio_fe_ctx* c, bool on) {
+  if (on == (c->launcher != nullptr)) return 0;
+  if (on) {
+    Launcher* l = new Launcher();
+    l->c = c;
+    l->th = std::thread([l] { l->run(); });
+    c->launcher = l;
+    return 0;
+  }
+  const int rc = launcher_drain(c);
+  Launcher* l = c->launcher;
+  l->quit.store(true, std::memory_order_release);
+  { std::lock_guard<std::mutex> g(l->mu); }
+  l->cv.notify_all();
+  l->th.join();
+  delete l;
+  c->launcher = nullptr;
+  return rc;
+}
+
+static int launcher_result(esvio_fe_ctx* c) {
+  const int rc = c->launcher->first_rc.exchange(0, std::memory_order_acq_rel);
+  if (rc && c->err.empty()) c->err = "a prefetch job of the launch thread failed";
+  return rc;
+}
+
+int launcher_drain(esvio_fe_ctx* c) {
+  Launcher* l = c->launcher;
+  if (!l) return 0;
+  while (l->done.load(std::memory_order_acquire) != l->submitted.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+  return launcher_result(c);
+}
+
+int launcher_wait_lane(esvio_fe_ctx* c, int lane) {
+  Launcher* l = c->launcher;
+  if (!l) return 0;
+  while (l->done.load(std::memory_order_acquire) < c->lane_job[lane]) __builtin_ia32_pause();
+  return launcher_result(c);
+}
+
+static int launcher_submit(esvio_fe_ctx* c, const PrefetchJob& j) {
+  Launcher* l = c->launcher;
+  const uint64_t s = l->submitted.load(std::memory_order_relaxed);
+  l->ring[s % Launcher::kRing] = j;
+  c->lane_job[j.b.lane] = s + 1;
+  l->submitted.store(s + 1, std::memory_order_release);
+  if (l->sleeping.load(std::memory_order_acquire)) {
+    { std::lock_guard<std::mutex> g(l->mu); }
+    l->cv.notify_all();
+  }
+  return 0;
+}
+
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first) {
   int rc = 0;
-  StreamScope on_prefetch_stream(c->stream2);
+  // per-kernel timers, the graph recorder and the trace's counters are the calling thread's
+  const bool async_ok = c->launcher && !c->prof_on && !c->graphs_enabled && !must_take_first;
+  if (c->launcher && !async_ok)
+    if ((rc = launcher_drain(c))) return rc;  // (this call's own HIP calls go behind the jobs handed over before)
   while (!rc && !c->announced.empty() && (int)c->inflight.size() < kPrefetchDepth) {
-    Inflight b;
+    PrefetchJob job;
+    Inflight& b = job.b;
     static_cast<Batch&>(b) = c->announced.front();
     // host events still on their way through the staging slot: this call does not wait for them, the
     // batch is taken up by the next one (unless it is the very batch the caller is about to track)
@@ -46,70 +219,45 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first) {
     while (b.raw == c->raw_cur || taken(&Inflight::raw, b.raw)) b.raw++;
     b.cand = 0;
     while (b.cand == c->cand_cur || taken(&Inflight::cand, b.cand)) b.cand++;
-    do {
-      if (wait_planes && hipStreamWaitEvent(c->stream2, c->ev_planes_free, 0) != hipSuccess) {
-        rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
-        break;
+    b.arc_done = b.pub && b.nL;
+    job.wait_planes = wait_planes;
+    wait_planes = false;  // later batches simply follow on the same stream
+    job.lks_wait = c->lks_last;
+    // where the events will be; a batch in pageable memory without the stager is copied by the issuing
+    // thread into a lane buffer that may have to grow: that one stays on the calling thread
+    bool async = async_ok;
+    if (b.stage >= 0) {
+      stager_ptrs(c, b.stage, b.nL, &b.dL, &b.dR);
+    } else if (b.space == ESVIO_FE_DEVICE) {
+      b.dL = (const EventRec*)b.left;
+      b.dR = (const EventRec*)b.right;
+    } else {
+      async = false;
+    }
+    // capacities are the calling thread's business (growing frees buffers: nothing handed over may still
+    // be about to use them)
+    const size_t n = b.nL + b.nR;
+    const bool grows = (c->tiled ? n > c->part_cap || (b.has_motion && !c->d_warp) : n > c->sort_cap) ||
+                       (b.arc_done && b.nL > c->cand[b.cand].cap);
+    if ((grows || !async) && c->launcher)
+      if ((rc = launcher_drain(c))) break;
+    {
+      StreamScope on_prefetch_stream(c->stream2);  // (a grown buffer's initialisation precedes its first use there)
+      if (c->tiled ? (rc = ensure_part_capacity(c, n, b.has_motion)) : (rc = ensure_sort_capacity(c, n))) break;
+      if (b.arc_done && (rc = ensure_cand_capacity(c, b.cand, b.nL))) break;
+    }
+    if (async) {
+      rc = launcher_submit(c, job);
+    } else {
+      rc = prefetch_issue(c, job);
+      if (!rc && b.stage < 0 && b.space == ESVIO_FE_HOST) {  // (the lane buffer stage_events copied into)
+        b.dL = c->d_evp[b.lane];
+        b.dR = c->d_evp[b.lane] + b.nL;
       }
-      wait_planes = false;  // later batches simply follow on the same stream
-      // the right-camera pyramid slot this batch gets may be the one an earlier frame's stereo LK
-      // (stream4) still reads — in lazy mode nobody has waited for that launch yet
-      if (c->lks_last >= 0 &&
-          hipStreamWaitEvent(c->stream2, c->ev_lks_done[c->lks_last], 0) != hipSuccess) {
-        rc = fail(c, ESVIO_FE_EHIP, "hipStreamWaitEvent failed");
-        break;
-      }
-      if (b.stage >= 0) {
-        if ((rc = stager_attach(c, b.stage, b.nL, c->stream2, &b.dL, &b.dR))) break;
-      } else if ((rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &b.dL, &b.dR, b.lane))) {
-        break;
-      }
-      // the ~11 dependent launches up to the pyramids go out as one graph (fe_kernels.h); with the
-      // per-kernel timers on they are launched one by one so that each can be bracketed
-      const bool as_graph = c->graphs_enabled && !c->prof_on;
-      if (as_graph) {
-        c->rec.clear();
-        set_launch_recorder(&c->rec);
-      }
-      bool arc_marked = false;
-      McParams mcp;
-      if (b.has_motion) mcp = make_mc_params(&b.motion);
-      rc = sae_update(c, b.dL, (uint32_t)b.nL, b.dR, (uint32_t)b.nR, b.has_motion ? &mcp : nullptr, nullptr, nullptr,
-                      b.pub && b.nL ? b.cand : -1, &arc_marked);
-      if (!rc) {
-        render_and_build(c, b.time, b.slotL, b.slotR, b.raw);
-        if (record_event(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
-          rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
-      }
-      if (as_graph) {
-        set_launch_recorder(nullptr);
-        if (!rc && launch_as_graph(c->pf_graph, c->rec, c->stream2) != hipSuccess) {
-          // (not expected; the plain path still works)
-          (void)hipGetLastError();
-          c->graphs_enabled = false;
-          destroy_launch_graph(c->pf_graph);
-          if (launch_plain(c->rec, c->stream2) != hipSuccess)
-            rc = fail(c, ESVIO_FE_EHIP, "kernel launch failed");
-        }
-      }
-      if (rc) break;
-      b.arc_done = false;
-      if (b.pub && b.nL) {
-        if ((rc = ensure_cand_capacity(c, b.cand, b.nL))) break;
-        const PyrDesc& ts = c->cfg.equalize ? c->raw[b.raw][0].d : c->pyr[b.slotL].d;
-        run_arc(c, b.dL, (uint32_t)b.nL, &ts, false, false, true, b.cand, arc_marked);
-        run_compact(c, (uint32_t)b.nL, b.cand);
-        if (hipEventRecord(c->ev_lane_arc[b.lane], c->stream2) != hipSuccess) {
-          rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
-          break;
-        }
-        b.arc_done = true;
-      }
-      // (the last kernels on this stream that read the batch's events)
-      if (b.stage >= 0 && (rc = stager_mark_read(c, b.stage, c->stream2, false))) break;
-      c->inflight.push_back(b);
-      c->announced.pop_front();
-    } while (0);
+    }
+    if (rc) break;
+    c->inflight.push_back(b);
+    c->announced.pop_front();
   }
   return rc;
 }
@@ -124,6 +272,7 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
   const size_t stM = (M + 63) / 64 * 64;
   // (kept points: already in host memory; new corners: published one by one by the k_select that
   // has just been launched — the waves of points >= n_kept wait for their slot)
+  if (int rc = launcher_wait_lane(c, nxt.lane)) return rc;
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_lane_done[nxt.lane], 0));
   float2* B = (float2*)c->z_spec;  // results land in the pinned block itself
   float2* Cb = B + M;
@@ -161,6 +310,7 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
   HIPCHK(c, hipEventRecord(c->ev_spec_done, c->stream3));
   c->spec_valid = true;
   if (nxt2) {
+    if (int rc = launcher_wait_lane(c, nxt2->lane)) return rc;
     HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt.lane], 0));
     HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt2->lane], 0));
     uint8_t* zc = c->z_spec + c->spec_bytes;
@@ -408,6 +558,8 @@ struct TrackCall {
       // pyramids were enqueued on the prefetch stream during an earlier call
       const Inflight b = c->inflight.front();
       c->inflight.pop_front();
+      // (launch thread: the lane's events must have been recorded by its job before anything waits on them)
+      if (int rc = launcher_wait_lane(c, b.lane)) return rc;
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane_done[b.lane], 0));
       c->tr_lane = b.lane;
       c->cur_stage = b.stage;
@@ -1052,6 +1204,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     // a failed call: its host batch's staging slot goes back (else eight such failures use them all
     // up).  Kernels of this call may still read the slot's device buffer, and chunks of the batch may
     // still be on their way out of the caller's memory: both are waited for
+    (void)launcher_drain(c);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream2);
     (void)hipGetLastError();

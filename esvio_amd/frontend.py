@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "esvio_fe_sae_slice_commit", "esvio_fe_device_memory", "esvio_fe_exchange_tracks",
     "esvio_fe_comm_unique_id", "esvio_fe_comm_init", "esvio_fe_exchange_begin", "esvio_fe_exchange_end",
     "esvio_fe_set_auto_exchange", "esvio_fe_reserve", "esvio_fe_latency_stats", "esvio_fe_latency_phase_name",
-    "esvio_fe_ransac_tail", "esvio_fe_find_fundamental_mat_held",
+    "esvio_fe_ransac_tail", "esvio_fe_find_fundamental_mat_held", "esvio_fe_set_launch_thread",
 ]
 
 LATENCY_PHASES = 16
@@ -189,6 +189,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_sae_slice_apply.argtypes = [vp, vp, sz, vp, sz, i, vp, i, i, vp, i]
     L.esvio_fe_sae_slice_commit.argtypes = [vp, vp, vp, i, i]
     L.esvio_fe_reserve.argtypes = [vp, sz, sz, i]
+    L.esvio_fe_set_launch_thread.argtypes = [vp, i]
     L.esvio_fe_latency_stats.argtypes = [vp, C.POINTER(Latency), i]
     L.esvio_fe_latency_phase_name.restype = C.c_char_p
     L.esvio_fe_latency_phase_name.argtypes = [i]
@@ -425,6 +426,10 @@ class FeatureTracker:
     def set_host_threads(self, threads):
         """host threads for rejectWithF_event's RANSAC (results do not depend on the count)"""
         self._hd.check(self._hd.L.esvio_fe_set_host_threads(self._hd.h, int(threads)))
+
+    def set_launch_thread(self, on=True):
+        """replay mode: a thread of the handle issues the announced batches' prefetch launches"""
+        self._hd.check(self._hd.L.esvio_fe_set_launch_thread(self._hd.h, int(bool(on))))
 
     def finish(self, copy=True):
         """complete a lazily returned frame and refresh the result members"""

@@ -328,6 +328,13 @@ int esvio_fe_set_lazy_new_stereo(esvio_fe_handle h, int on);
  * thread, so the result is bit-identical for any thread count.  Helpers spin while frames keep
  * coming and sleep after 2 ms without work. */
 int esvio_fe_set_host_threads(esvio_fe_handle h, int threads);
+/* Throughput option for replay mode: with `on`, the HIP calls that start an announced batch's SAE update,
+ * rendering, pyramids and Arc* pass (~10 launches and event calls, 35-45 us of host time per batch) are
+ * issued by a thread of the handle instead of by the calling thread — the calling thread, which bounds
+ * the replay rate, keeps only the bookkeeping and checks that a batch's job has been issued before it
+ * consumes that batch (three frames later in the steady state).  Results do not depend on it.  The
+ * thread spins while batches keep coming and blocks after 2 ms without one: one more busy CPU. */
+int esvio_fe_set_launch_thread(esvio_fe_handle h, int on);
 /* complete a lazily returned frame (no-op otherwise) and copy the result members into `out` */
 int esvio_fe_finish(esvio_fe_handle h, esvio_fe_tracks* out);
 

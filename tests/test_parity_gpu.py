@@ -672,11 +672,13 @@ def test_motion_compensated_replay_schedule(oracle, space):
         b.free()
 
 
-@pytest.mark.parametrize("equalize,hint,depth,lazy", [
-    (0, "none", 1, 0), (0, "right", 1, 0), (0, "wrong", 1, 0), (1, "right", 1, 0), (1, "none", 1, 0),
-    (0, "right", 2, 0), (1, "right", 2, 0), (0, "right", 2, 1), (0, "none", 1, 1), (1, "right", 2, 1),
-    (0, "right", 3, 0), (0, "right", 3, 1), (1, "right", 3, 1)])
-def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy):
+@pytest.mark.parametrize("equalize,hint,depth,lazy,launch", [
+    (0, "none", 1, 0, 0), (0, "right", 1, 0, 0), (0, "wrong", 1, 0, 0), (1, "right", 1, 0, 0), (1, "none", 1, 0, 0),
+    (0, "right", 2, 0, 0), (1, "right", 2, 0, 0), (0, "right", 2, 1, 0), (0, "none", 1, 1, 0), (1, "right", 2, 1, 0),
+    (0, "right", 3, 0, 0), (0, "right", 3, 1, 0), (1, "right", 3, 1, 0),
+    # ... and with the prefetch launches issued by the handle's launch thread (esvio_fe_set_launch_thread)
+    (0, "right", 3, 1, 1), (1, "right", 2, 0, 1), (0, "wrong", 1, 0, 1), (0, "none", 1, 1, 1), (0, "right", 3, 0, 1)])
+def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy, launch):
     """esvio_fe_set_next_batch (replay mode: the next one or two batches' SAE update / images — and,
     with the PUB hint, their Arc* pass — run on a second stream, and the next frame's temporal LK
     is launched speculatively on a third) must not change a single result bit, whether the hint is
@@ -687,6 +689,8 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy)
     kw = dict(f_ransac=1, equalize=equalize)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     ft.set_lazy_new_stereo(bool(lazy))
+    if launch:
+        ft.set_launch_thread(True)
     tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
     pubs = [(f % 3) != 1 for f in range(len(batches))]
     announced = 0

@@ -110,6 +110,8 @@ def one_case(rng, case):
                     ft.set_lazy_new_stereo(bool(rng.integers(0, 2)))
                 if rng.random() < 0.15:
                     ft.set_host_threads(int(rng.integers(1, 6)))
+                if rng.random() < 0.25:  # (round 4: the prefetch launches issued by the handle's launch thread)
+                    ft.set_launch_thread(bool(rng.integers(0, 2)))
                 if fault and rng.random() < 0.3:
                     ft.debug_inject(fault if rng.random() < 0.5 else 0)
                 announced = max(announced, f)
