@@ -839,8 +839,7 @@ def main():
             all_passes_step_ms_p99=round(float(np.percentile(all_steps, 99)), 4),
             per_pass_step_ms_max=[round(float(max(sm[:-1])), 3) for sm in step_ms],
             library_call_ms=dict(p50=round(l0["p50_ms"], 4), p99=round(l0["p99_ms"], 4), max=round(l0["max_ms"], 4),
-                                 max_call=l0["max_call"], max_call_phases_ms=l0["max_phase_ms"],
-                                 max_call_cpu=l0["max_cpu"], max_call_invol_switches=l0["max_invol_switches"]),
+                                 max_call=l0["max_call"]),
             per_pass_library_call_ms_max=[round(l["max_ms"], 3) for l in lib_lat],
             worst_pass=(lambda w: dict(index=w, step_ms_max=round(float(max(step_ms[w][:-1])), 3),
                                        step_argmax=int(np.argmax(step_ms[w][:-1])),
@@ -858,7 +857,8 @@ def main():
                               dict(periods=throttle1[0] - throttle0[0], ms=round((throttle1[1] - throttle0[1]) / 1e3, 3))),
             os_threads_in_process=os_threads,
             note="wall time of each step of pass 0 as the calling thread saw it (set_next_batch + track_event); "
-                 "library_call_ms: the esvio_fe_track_event calls alone, the slowest one's phases named")
+                 "library_call_ms: the esvio_fe_track_event calls of pass 0 alone; worst_pass: the pass holding the slowest "
+                 "step of all, its slowest call with the phases named")
         out = {
             "metric": "Mevents/s through time-surface+detect+track @640x480",
             "value": round(total_events / max_elapsed / 1e6, 3),

@@ -34,7 +34,7 @@ def _stream(n_distinct, cycles, rate, seed):
     return out
 
 
-def _run(batches, host_threads, steps, warm):
+def _run(batches, host_threads, steps, warm, launch=False):
     bufs, dev = [], []
     for L, R in batches:
         bl, br = FE.EventBuffer(L, FE.DEVICE), FE.EventBuffer(R, FE.DEVICE)
@@ -50,6 +50,8 @@ def _run(batches, host_threads, steps, warm):
     ft.set_lazy_new_stereo(True)
     if host_threads > 1:
         ft.set_host_threads(host_threads)
+    if launch:
+        ft.set_launch_thread(True)
     ft.reserve(max(len(b[0]) for b in batches), max(len(b[1]) for b in batches))
     allocs_after_reserve = []
     announced = 0
@@ -96,6 +98,17 @@ def test_thousand_replay_steps_without_a_latency_tail():
         pytest.fail("a step slower than 5x the median in both attempts: %s" % report)
     # the library's own record covers the same calls
     assert lat["calls"] == steps and lat["max_ms"] <= mx + 1e-3
+    # the same with the prefetch launches issued by the handle's launch thread (esvio_fe_set_launch_thread)
+    for attempt in range(2):
+        ms, lat, tail, allocs, n_tracks = _run(batches, 8, 400, warm, launch=True)
+        med, mx = float(np.median(ms)), float(ms.max())
+        print("tail latency with the launch thread, attempt %d: median %.4f p99 %.4f max %.4f ms (call %d); %s"
+              % (attempt, med, float(np.percentile(ms, 99)), mx, int(ms.argmax()), lat["max_phase_ms"]))
+        assert allocs == [0, 0] and n_tracks > 50
+        if mx <= 5.0 * med:
+            break
+    else:
+        pytest.fail("launch thread: a step slower than 5x the median in both attempts")
 
 
 def test_no_allocation_after_reserve_and_a_first_call_like_the_others():
