@@ -113,13 +113,16 @@ struct Launcher {
         __builtin_ia32_pause();
         if ((++spins & 1023) == 0 &&
             std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(2000)) {
+          // (seq_cst on both sides: either the submitter sees `sleeping` and notifies under the mutex, or the
+          // predicate below sees its job — a store followed by a load of another word may otherwise pass
+          // each other in the store buffer and both sides miss)
           std::unique_lock<std::mutex> lk(mu);
-          sleeping.store(true, std::memory_order_release);
+          sleeping.store(true, std::memory_order_seq_cst);
           cv.wait(lk, [&] {
-            return submitted.load(std::memory_order_acquire) != done.load(std::memory_order_relaxed) ||
-                   quit.load(std::memory_order_acquire);
+            return submitted.load(std::memory_order_seq_cst) != done.load(std::memory_order_relaxed) ||
+                   quit.load(std::memory_order_seq_cst);
           });
-          sleeping.store(false, std::memory_order_release);
+          sleeping.store(false, std::memory_order_seq_cst);
           idle_since = std::chrono::steady_clock::now();
         }
         continue;
@@ -137,7 +140,10 @@ struct Launcher {
 
 int launcher_set(esvio_fe_ctx* c, bool on) {
   if (on == (c->launcher != nullptr)) return 0;
+  // (job numbers are per launcher: a lane whose events were recorded before — by the calling thread, or by a
+  // launcher that has been drained and is gone — has nothing outstanding)
   if (on) {
+    for (uint64_t& j : c->lane_job) j = 0;
     Launcher* l = new Launcher();
     l->c = c;
     l->th = std::thread([l] { l->run(); });
@@ -145,8 +151,9 @@ int launcher_set(esvio_fe_ctx* c, bool on) {
     return 0;
   }
   const int rc = launcher_drain(c);
+  for (uint64_t& j : c->lane_job) j = 0;
   Launcher* l = c->launcher;
-  l->quit.store(true, std::memory_order_release);
+  l->quit.store(true, std::memory_order_seq_cst);
   { std::lock_guard<std::mutex> g(l->mu); }
   l->cv.notify_all();
   l->th.join();
@@ -180,8 +187,8 @@ static int launcher_submit(esvio_fe_ctx* c, const PrefetchJob& j) {
   const uint64_t s = l->submitted.load(std::memory_order_relaxed);
   l->ring[s % Launcher::kRing] = j;
   c->lane_job[j.b.lane] = s + 1;
-  l->submitted.store(s + 1, std::memory_order_release);
-  if (l->sleeping.load(std::memory_order_acquire)) {
+  l->submitted.store(s + 1, std::memory_order_seq_cst);
+  if (l->sleeping.load(std::memory_order_seq_cst)) {
     { std::lock_guard<std::mutex> g(l->mu); }
     l->cv.notify_all();
   }
@@ -190,6 +197,7 @@ static int launcher_submit(esvio_fe_ctx* c, const PrefetchJob& j) {
 
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first) {
   int rc = 0;
+  const bool only_first = must_take_first;
   // per-kernel timers, the graph recorder and the trace's counters are the calling thread's
   const bool async_ok = c->launcher && !c->prof_on && !c->graphs_enabled && !must_take_first;
   if (c->launcher && !async_ok)
@@ -258,6 +266,10 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first) {
     if (rc) break;
     c->inflight.push_back(b);
     c->announced.pop_front();
+    // the late take-up of the batch about to be tracked takes that batch only: a second one applied to the
+    // planes behind it would make this frame's PUB hint binding ("more than one batch in flight") although
+    // the caller never had more than one announced ahead of its call
+    if (only_first) break;
   }
   return rc;
 }

@@ -707,6 +707,8 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy,
             Ln, Rn, _ = batches[announced]
             h = {"none": False, "right": pubs[announced], "wrong": not pubs[announced]}[hint]
             ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, h)
+        if launch and f in (3, 6, 9):  # (switched off and on again with batches announced and in flight)
+            ft.set_launch_thread(f == 6)
         ft.trackEvent(t, L, R, pubs[f])
         r = tr.track_event(t, L, R, pubs[f])
         if lazy:
