@@ -1128,10 +1128,10 @@ static int set_next_batch_impl(esvio_fe_handle c, double next_cur_time, const es
     // the batch starts on its way to the device now: pinned chunks + DMA by the helper threads, under
     // the frames tracked before it
     HIPCHK(c, hipSetDevice(c->dev));
-    // (two DMAs: the second half is still being copied into pinned memory while the first one crosses PCIe —
-    // 0.17 -> 0.134 ms/step in replay mode at C3, 31 -> 39 GB/s; a second copy stream for the odd groups,
-    // i.e. two DMA engines at once, was measured and is slower: 0.197)
-    if (int rc = stager_begin(c, left, nL, right, nR, 2, &b.stage)) return rc;
+    // (one DMA for the whole batch.  Round 4 measured two to four, and the odd ones on a second copy stream:
+    // no gain in the bench's configuration — 0.136-0.146 ms/step either way — and a loss without the RANSAC
+    // helpers' share of the copying, 0.140 -> 0.165-0.18; two DMA engines at once: 0.197)
+    if (int rc = stager_begin(c, left, nL, right, nR, 1, &b.stage)) return rc;
   }
   c->announced.push_back(b);
   return 0;
