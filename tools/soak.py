@@ -152,6 +152,13 @@ def main():
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     cases = frames = 0
+
+    def on_term(signum, frame):  # (a `timeout` around the run: say how far it got instead of dying silently)
+        print("soak: killed by signal %d after %d cases, %d frames, %.1f min without a difference (a case was in progress)"
+              % (signum, cases, frames, (time.time() - t0) / 60), flush=True)
+        sys.exit(2)
+    import signal
+    signal.signal(signal.SIGTERM, on_term)
     while time.time() - t0 < a.minutes * 60:
         desc, err = one_case(rng, cases)
         cases += 1
