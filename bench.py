@@ -275,6 +275,7 @@ def main():
     args = parse()
     if args.no_chain:
         os.environ["ESVIO_FE_NO_CHAIN"] = "1"
+        os.environ["ESVIO_FE_NO_CAMSPLIT"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     # stdout carries exactly ONE line, the JSON: whatever libraries print through C stdio on fd 1
@@ -572,12 +573,14 @@ def main():
     prof_ms = {}
 
     def kernel_pass(pipe):
-        if not pipe:  # clean durations: no launch of this pass waits on the device for another one
-            os.environ["ESVIO_FE_NO_CHAIN"] = "1"
+        if not pipe:  # clean durations: no launch of this pass waits on the device for another one,
+            os.environ["ESVIO_FE_NO_CHAIN"] = "1"     # ... and none runs beside the other camera's chain
+            os.environ["ESVIO_FE_NO_CAMSPLIT"] = "1"
         try:
             run = Runner(pipe, pipe and lazy, dev_batches)
         finally:
             os.environ.pop("ESVIO_FE_NO_CHAIN", None)
+            os.environ.pop("ESVIO_FE_NO_CAMSPLIT", None)
         for i in range(min(args.warmup, 6)):
             run.step(i, exchange=False)
         torch.cuda.synchronize()

@@ -180,6 +180,8 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->ev_planes_free) (void)hipEventDestroy(c->ev_planes_free);
   if (c->ev_imgs_ready) (void)hipEventDestroy(c->ev_imgs_ready);
   if (c->ev_arc_side) (void)hipEventDestroy(c->ev_arc_side);
+  if (c->ev_sae_left) (void)hipEventDestroy(c->ev_sae_left);
+  if (c->ev_right_ready) (void)hipEventDestroy(c->ev_right_ready);
   if (c->ev_pts_ready) (void)hipEventDestroy(c->ev_pts_ready);
   if (c->ev_spec_done) (void)hipEventDestroy(c->ev_spec_done);
   if (c->ev_chain_done) (void)hipEventDestroy(c->ev_chain_done);
@@ -252,7 +254,9 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipEventCreateWithFlags(&c->ev_lknew_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_planes_free, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_imgs_ready, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_arc_side, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&c->ev_arc_side, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_sae_left, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_right_ready, hipEventDisableTiming) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
   for (int i = 0; i < kPrefetchDepth; i++)
     if (hipEventCreateWithFlags(&c->ev_lane_done[i], c->trace ? 0 : hipEventDisableTiming) != hipSuccess ||
@@ -288,6 +292,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->stage_threads = stager_threads_from_env();
   if (const char* v = getenv("ESVIO_FE_FAULT")) esvio_fe_debug_inject(c, atoi(v));
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
+  c->cam_split_enabled = getenv("ESVIO_FE_NO_CAMSPLIT") == nullptr;
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
   c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
@@ -1191,6 +1196,15 @@ int esvio_fe_debug_counters(esvio_fe_handle c, uint64_t out4[4]) {
   out4[1] = c->n_chain_expired;
   out4[2] = c->tr_chain_launch;
   out4[3] = c->tr_chain_used;
+  return 0;
+}
+
+int esvio_fe_plain_call_counters(esvio_fe_handle c, uint64_t out4[4]) {
+  if (!c || !out4) return ESVIO_FE_EINVAL;
+  out4[0] = c->n_plain_calls;
+  out4[1] = c->n_cam_split;
+  out4[2] = c->n_stereo_chained;
+  out4[3] = c->n_chain_expired;
   return 0;
 }
 

@@ -144,6 +144,10 @@ struct esvio_fe_ctx {
   // a plain (not announced) call: the frame's images are built (main stream) -> its Arc* pass on the
   // prefetch stream and its stereo LK on stream4 start beside the temporal LK; the Arc* pass is done
   hipEvent_t ev_imgs_ready = nullptr, ev_arc_side = nullptr;
+  // ... split by camera: the left camera's update + image on the main stream (ev_imgs_ready: the LEFT image
+  // then), the right camera's behind it on the stereo stream — behind ev_sae_left (the one partition
+  // scratch) and, for a batch in pageable memory, behind the right array's own DMA; ev_right_ready: done
+  hipEvent_t ev_sae_left = nullptr, ev_right_ready = nullptr;
   hipEvent_t ev_pts_ready = nullptr, ev_spec_done = nullptr, ev_sel_host = nullptr;
   std::string err;
   int W = 0, H = 0;
@@ -262,6 +266,8 @@ struct esvio_fe_ctx {
   unsigned long long* d_chain = nullptr;  // [2 * max_cnt] published forward results
   uint32_t chain_seq = 0;
   bool chain_enabled = true;   // (ESVIO_FE_NO_CHAIN=1 turns it off: A/B measurements)
+  bool cam_split_enabled = true;  // a plain call runs the two cameras' updates on two streams (ESVIO_FE_NO_CAMSPLIT=1: one)
+  uint64_t n_plain_calls = 0, n_cam_split = 0, n_stereo_chained = 0;  // esvio_fe_plain_call_counters
   bool chain_valid = false;    // a chained launch has been made ...
   uint64_t chain_for = 0;      // ... for the frame with this number
   bool chain_map_ok = false;

@@ -55,8 +55,13 @@ struct Slot {
   uint8_t* pin = nullptr;
   EventRec* dev = nullptr;
   size_t cap = 0;  // events
-  hipEvent_t copied = nullptr, pf_done = nullptr, main_done = nullptr;
-  bool pf_rec = false, main_rec = false;
+  hipEvent_t copied = nullptr, pf_done = nullptr, main_done = nullptr, aux_done = nullptr;
+  bool pf_rec = false, main_rec = false, aux_rec = false;
+  // by_camera staging (a plain call that starts on the left camera while the right one is still on its
+  // way): the left array is a DMA of its own, `copiedL` is recorded behind it
+  hipEvent_t copiedL = nullptr;
+  int left_group = -1;               // group that is the left array, -1: none (not by camera, or a pinned source)
+  std::atomic<bool> left_enq{false}; // the left array's DMA is enqueued and copiedL recorded
   bool in_use = false;
   std::atomic<int> state{0};  // 0 idle, 1 staging, 2 every DMA enqueued and `copied` recorded, -1 failed
   Group grp[kMaxGroups];
@@ -88,6 +93,10 @@ struct EventStager {
     if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
       (void)hipGetLastError();
       s.state.store(-1, std::memory_order_release);
+    }
+    if ((int)(&g - s.grp) == s.left_group) {
+      if (hipEventRecord(s.copiedL, stream) != hipSuccess) s.state.store(-1, std::memory_order_release);
+      s.left_enq.store(true, std::memory_order_release);
     }
     g.dma_enq.store(true, std::memory_order_release);
   }
@@ -218,7 +227,9 @@ static int stager_get(esvio_fe_ctx* c, EventStager** out) {
     }
     for (Slot& s : st->slot)
       if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&s.copiedL, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&s.pf_done, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&s.aux_done, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&s.main_done, hipEventDisableTiming) != hipSuccess) {
         c->stager = st;
         stager_destroy(c);
@@ -270,8 +281,10 @@ int stager_reserve(esvio_fe_ctx* c, size_t n_events) {
 
 // Start staging [left; right] into a free slot: returns at once, the helpers do the work.
 // dma_groups: DMAs the pageable part of the batch is moved with (1: the caller does not wait for it)
+// by_camera: the left array and the right array are one DMA each (dma_groups is ignored), and the left one's
+// completion can be waited for on its own (stager_attach_left)
 int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
-                 int dma_groups, int* slot_out) {
+                 int dma_groups, int* slot_out, bool by_camera) {
   EventStager* st = nullptr;
   if (int rc = stager_get(c, &st)) return rc;
   int k = 0;
@@ -285,12 +298,19 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
   // the DMA overwrites the slot's device buffer: behind the kernels that read its previous batch
   if (s.pf_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.pf_done, 0));
   if (s.main_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.main_done, 0));
-  s.pf_rec = s.main_rec = false;
+  if (s.aux_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.aux_done, 0));
+  s.pf_rec = s.main_rec = s.aux_rec = false;
+  s.left_group = -1;
+  s.left_enq.store(false, std::memory_order_release);
   st->bytes_staged += n * 16;
   st->batches++;
   // a pinned source: one DMA straight from it, now (the slot is taken only once nothing below can fail
   // before its state is set)
   if (pinL) HIPCHK(c, hipMemcpyAsync(s.dev, left, nL * 16, hipMemcpyHostToDevice, st->stream));
+  if (by_camera && (pinL || !nL)) {  // (the left array is on its way already, or there is none)
+    HIPCHK(c, hipEventRecord(s.copiedL, st->stream));
+    s.left_enq.store(true, std::memory_order_release);
+  }
   if (pinR) HIPCHK(c, hipMemcpyAsync(s.dev + nL, right, nR * 16, hipMemcpyHostToDevice, st->stream));
   s.in_use = true;
   // the pageable part: destination byte range [lo, hi) of the slot's buffers
@@ -303,14 +323,25 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
     ng = std::max(1, std::min(dma_groups, kMaxGroups));
     const size_t chunks = (hi - lo + kChunkBytes - 1) / kChunkBytes;
     ng = (int)std::min<size_t>(ng, chunks);
-    const size_t per = (chunks + ng - 1) / ng;  // chunks per group
+    size_t per = (chunks + ng - 1) / ng;  // chunks per group
     ng = (int)((chunks + per - 1) / per);
+    const bool cam_groups = by_camera && !pinL && !pinR && nL && nR;  // both arrays pageable: one group each
+    if (cam_groups) ng = 2;
+    if (by_camera && !pinL && nL) s.left_group = 0;  // (else: a single group of the right array, or of either one)
+    if (by_camera && !cam_groups) {
+      ng = 1;
+      per = chunks;
+    }
     if (chunks + 2 > s.chunk_cap) {  // (+1: a chunk never straddles the two source arrays)
       s.chunk_cap = chunks + 2 + chunks / 4;
       s.chunk.reset(new Chunk[s.chunk_cap]);
     }
     for (int g = 0; g < ng; g++) {
-      const size_t a = lo + (size_t)g * per * kChunkBytes, b = std::min(hi, a + per * kChunkBytes);
+      size_t a = lo + (size_t)g * per * kChunkBytes, b = std::min(hi, a + per * kChunkBytes);
+      if (cam_groups) {
+        a = g ? nL * 16 : 0;
+        b = g ? n * 16 : nL * 16;
+      }
       s.grp[g].off = a;
       s.grp[g].len = b - a;
       s.grp[g].dma_enq.store(false, std::memory_order_relaxed);
@@ -389,6 +420,32 @@ int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const Eve
   return 0;
 }
 
+// by_camera staging: wait (taking chunks meanwhile) until the LEFT array's DMA is enqueued and make stream
+// `s` wait for it; the right array may still be on its way (stager_attach follows for it)
+int stager_attach_left(esvio_fe_ctx* c, int slot, hipStream_t s, const EventRec** dL) {
+  EventStager* st = c->stager;
+  Slot& sl = st->slot[slot];
+  unsigned idle = 0;
+  while (!sl.left_enq.load(std::memory_order_acquire) && sl.state.load(std::memory_order_acquire) == 1) {
+    if (st->try_one()) {
+      st->caller_chunks++;
+      idle = 0;
+    } else if (++idle > 1000) {
+      st->finish_for(slot);
+      idle = 0;
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+  if (!sl.left_enq.load(std::memory_order_acquire) || sl.state.load(std::memory_order_acquire) < 0) {
+    stager_abandon(c, slot);
+    return fail(c, ESVIO_FE_EHIP, "staging the event batch failed");
+  }
+  HIPCHK(c, hipStreamWaitEvent(s, sl.copiedL, 0));
+  *dL = sl.dev;
+  return 0;
+}
+
 // give a slot back whose batch will not be tracked (a failed call): nothing of the caller's memory is
 // read after this returns
 void stager_abandon(esvio_fe_ctx* c, int slot) {
@@ -421,6 +478,13 @@ int stager_mark_read(esvio_fe_ctx* c, int slot, hipStream_t s, bool main_stream)
   Slot& sl = c->stager->slot[slot];
   HIPCHK(c, hipEventRecord(main_stream ? sl.main_done : sl.pf_done, s));
   (main_stream ? sl.main_rec : sl.pf_rec) = true;
+  return 0;
+}
+// ... and on a third stream (the stereo stream, where a plain call runs the right camera's update)
+int stager_mark_read_aux(esvio_fe_ctx* c, int slot, hipStream_t s) {
+  Slot& sl = c->stager->slot[slot];
+  HIPCHK(c, hipEventRecord(sl.aux_done, s));
+  sl.aux_rec = true;
   return 0;
 }
 
@@ -479,6 +543,8 @@ void stager_destroy(esvio_fe_ctx* c) {
   }
   for (Slot& s : st->slot) {
     if (s.copied) (void)hipEventDestroy(s.copied);
+    if (s.copiedL) (void)hipEventDestroy(s.copiedL);
+    if (s.aux_done) (void)hipEventDestroy(s.aux_done);
     if (s.pf_done) (void)hipEventDestroy(s.pf_done);
     if (s.main_done) (void)hipEventDestroy(s.main_done);
     if (s.dev) (void)hipFree(s.dev);

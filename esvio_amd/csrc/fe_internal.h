@@ -66,6 +66,8 @@ int stage_events(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
 void render_ts(esvio_fe_ctx* c, double t_sync, uint8_t* dst0, uint8_t* dst1, int ncam, const double2* S2);
 void render_lk_images(esvio_fe_ctx* c, double t_sync, int cams, int slotL, int slotR, int rawbuf);
 void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int rawbuf);
+bool render_cam_ok(const esvio_fe_ctx* c);
+void render_and_build_cam(esvio_fe_ctx* c, double t_sync, int cam, int slot);
 const PyrDesc& raw_ts_desc(const esvio_fe_ctx* c, int cam);
 LkArgs make_lk(const PyrDesc& P, const PyrDesc& N, const float2* prev, const float2* init, float2* next,
                uint8_t* status, const int* n_ptr, int n_max, int max_level, int max_count, double eps,
@@ -101,7 +103,9 @@ hipError_t sync_event(hipEvent_t ev);
 int stager_threads_from_env();  // ESVIO_FE_STAGE_THREADS (default 2; 0: plain hipMemcpyAsync from the caller's memory)
 inline bool stager_enabled(const esvio_fe_ctx* c) { return c->stage_threads > 0; }
 int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
-                 int dma_groups, int* slot_out);
+                 int dma_groups, int* slot_out, bool by_camera = false);
+int stager_attach_left(esvio_fe_ctx* c, int slot, hipStream_t s, const EventRec** dL);
+int stager_mark_read_aux(esvio_fe_ctx* c, int slot, hipStream_t s);
 bool stager_ready(esvio_fe_ctx* c, int slot);
 int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const EventRec** dL, const EventRec** dR);
 int stager_mark_read(esvio_fe_ctx* c, int slot, hipStream_t s, bool main_stream);

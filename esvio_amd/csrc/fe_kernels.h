@@ -235,6 +235,8 @@ void launch_clahe(hipStream_t s, const uint8_t* raw0, const uint8_t* raw1, int r
 // ---- pyramid ----------------------------------------------------------------------------
 void launch_pyr_down(hipStream_t s, const PyrDesc* p, int nimg, int src_level);
 // k_time_surface + the three k_pyr_down of both cameras' pyramids in one launch (same bytes)
+void launch_ts_pyr_cam(hipStream_t s, const double2* S2_cam, double t_sync, double decay_sec, int ignore_polarity,
+                       const PyrDesc* p);  // one camera (S2_cam: its planes, p: its pyramid)
 void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay_sec,
                    int ignore_polarity, const PyrDesc* p);
 void launch_pyr_pad(hipStream_t s, const PyrDesc* p, int nimg);

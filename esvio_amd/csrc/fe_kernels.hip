@@ -1883,6 +1883,14 @@ void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay
            t_sync, decay_sec, ignore_polarity, make_pack(p, 2));
 }
 
+// one camera: S2 points at that camera's planes, p at its pyramid
+void launch_ts_pyr_cam(hipStream_t s, const double2* S2_cam, double t_sync, double decay_sec, int ignore_polarity,
+                       const PyrDesc* p) {
+  const int w3 = p[0].w[3], h3 = p[0].h[3];
+  launch_k(k_ts_pyr, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, 1), dim3(kFtThreads), 0, s, S2_cam,
+           t_sync, decay_sec, ignore_polarity, make_pack(p, 1));
+}
+
 // the `equalize: 1` branch: normalize + the three pyrDown levels of both cameras (see EqSrc)
 void launch_norm_pyr(hipStream_t s, const uint8_t* src0, const uint8_t* src1, int src_stride, const int* minmax,
                      const PyrDesc* p) {
@@ -2718,6 +2726,10 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
     // the previous frame's launch is still running (or about to): wait for this point's result
     const unsigned long long t0 = wall_clock64();
     unsigned long long vx, vy;
+    if (!a.chain_ticks) {  // (fault injection: give up without looking, whether the result is there or not)
+      if (lane == 0) *a.poll_err = 1;
+      return;
+    }
     for (;;) {
       vx = __hip_atomic_load(&a.chain_in[2 * pt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       vy = __hip_atomic_load(&a.chain_in[2 * pt + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

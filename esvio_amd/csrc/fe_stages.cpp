@@ -431,6 +431,25 @@ void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int 
   }
 }
 
+// one camera's LK image + pyramid (the fused kernels; the caller has checked render_cam_ok)
+bool render_cam_ok(const esvio_fe_ctx* c) {
+  return c->fuse_ts_pyr && !c->cfg.equalize && c->cfg.median_blur_kernel_size <= 0 && c->pyr[0].d.levels == 3;
+}
+void render_and_build_cam(esvio_fe_ctx* c, double t_sync, int cam, int slot) {
+  const PyrDesc one = c->pyr[slot].d;
+  uint64_t px = 0;
+  for (int l = 0; l <= 3; l++) px += (uint64_t)one.w[l] * one.h[l];
+  {
+    ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 16 + px);
+    launch_ts_pyr_cam(cur_stream(c), c->S2 + (size_t)cam * c->P, t_sync, c->cfg.decay_ms / 1000.0,
+                      c->cfg.ignore_polarity, &one);
+  }
+  {
+    ScopedKernel k(c, K_SCHARR, px * 5);
+    launch_pad_scharr(cur_stream(c), &one, 1);
+  }
+}
+
 const PyrDesc& raw_ts_desc(const esvio_fe_ctx* c, int cam) {
   if (c->cfg.equalize) return c->raw[c->raw_cur][cam].d;
   return cam ? c->pyr[c->slot_curR].d : c->pyr[c->slot_curL].d;

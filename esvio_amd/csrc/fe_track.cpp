@@ -504,6 +504,7 @@ struct TrackCall {
   // a plain call (nothing announced, not lazy): Arc* runs on the prefetch stream beside the temporal LK,
   // and the stereo LK is launched WITH the temporal one, chained to it point by point on the device
   bool plain = false, arc_side = false, stereo_chained = false;
+  bool split_right = false;  // ... and the right camera's update + image run on the stereo stream beside the left one's
   Pin pin_st{};               // where the frame's stereo LK results of the kept points land
   std::vector<int> surv_src;  // chained stereo: survivor i was the temporal launch's point surv_src[i]
   int n_surv = 0, n_kept = 0;
@@ -589,16 +590,61 @@ struct TrackCall {
     } else {
       c->cur_prefetched = false;
       main_reads_events = true;
-      if (space == ESVIO_FE_HOST && stager_enabled(c) && (nL + nR) * 16 >= (256u << 10)) {
+      const bool staged = space == ESVIO_FE_HOST && stager_enabled(c) && (nL + nR) * 16 >= (256u << 10);
+      // A plain call (the reference's pattern) in the plain configuration is split by camera: the temporal
+      // LK needs the LEFT image only, so the left camera's update and image go first on the main stream and
+      // the right camera's follow on the stereo stream, under the temporal LK — and, for a batch in
+      // pageable memory, the left array is a DMA of its own: the left chain starts while the right array is
+      // still crossing PCIe.
+      const bool split = c->cam_split_enabled && c->tiled && render_cam_ok(c) && !motion && !c->ext_sae_pending && !c->ext_right_pending &&
+                         nL && nR && c->announced.empty() && c->inflight.empty() && !c->lazy_new && !c->chain_valid && !c->spec_valid &&
+                         (staged || space == ESVIO_FE_DEVICE);
+      if (staged) {
         // not announced: the helpers and this thread stage the chunks together, the DMA of group k runs
         // under the memcpy of group k+1
         const auto ts0 = clk::now();
-        if (int rc = stager_begin(c, left, nL, right, nR, 4, &c->cur_stage)) return rc;
-        if (int rc = stager_attach(c, c->cur_stage, nL, c->stream, &dL, &dR)) return rc;
+        if (int rc = stager_begin(c, left, nL, right, nR, 4, &c->cur_stage, split)) return rc;
+        if (split) {
+          if (int rc = stager_attach_left(c, c->cur_stage, c->stream, &dL)) return rc;
+        } else if (int rc = stager_attach(c, c->cur_stage, nL, c->stream, &dL, &dR)) {
+          return rc;
+        }
         c->lat.cur_phase[15] = std::chrono::duration<double, std::milli>(clk::now() - ts0).count();  // (part of phase 0)
       } else if (int rc = stage_events(c, left, nL, right, nR, space, &dL, &dR)) {
         return rc;
       }
+      // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; slot rotation replaces the
+      // cv::Mat header swaps of :390-403,:585.  Left slots 0..2: {prev, cur, free}.
+      int sl = 0;
+      while (!first && (sl == c->slot_prevL || sl == c->slot_curL)) sl++;
+      const int new_curL = sl;
+      if (split) {
+        if (int rc = sae_update(c, dL, (uint32_t)nL, nullptr, 0, nullptr, nullptr, nullptr,
+                                PUB_THIS_FRAME ? c->cand_cur : -1, &arc_marked_main))
+          return rc;
+        HIPCHK(c, hipEventRecord(c->ev_sae_left, c->stream));
+        c->slot_curL = new_curL;
+        c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;
+        c->raw_cur = (c->raw_cur + 1) % kRightSlots;
+        render_and_build_cam(c, c->cur_time, 0, c->slot_curL);
+        HIPCHK(c, hipEventRecord(c->ev_imgs_ready, c->stream));
+        // the right camera, on the stereo stream
+        if (staged) {
+          const auto ts1 = clk::now();
+          const EventRec* dl2 = nullptr;
+          if (int rc = stager_attach(c, c->cur_stage, nL, c->stream4, &dl2, &dR)) return rc;
+          c->lat.cur_phase[15] += std::chrono::duration<double, std::milli>(clk::now() - ts1).count();
+        }
+        {
+          StreamScope on_stereo_stream(c->stream4);
+          HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_sae_left, 0));  // (the partition scratch is the left chain's until then)
+          if (int rc = sae_update(c, nullptr, 0, dR, (uint32_t)nR)) return rc;
+          render_and_build_cam(c, c->cur_time, 1, c->slot_curR);
+          HIPCHK(c, hipEventRecord(c->ev_right_ready, c->stream4));
+        }
+        split_right = true;
+        c->n_cam_split++;
+      } else {
       // createSAE_left / createSAE_right loops (:356-362), or their motion-compensated forms (:627-641)
       if (c->ext_sae_pending) {
         // esvio_fe_sae_slice_commit has put this batch into the planes already (its SAE update ran
@@ -612,11 +658,7 @@ struct TrackCall {
                                      PUB_THIS_FRAME ? c->cand_cur : -1, &arc_marked_main)) {
         return rc;
       }
-      // SAEtoTimeSurface_left/right(cur_time) (:367-368) -> cur images; slot rotation replaces the
-      // cv::Mat header swaps of :390-403,:585.  Left slots 0..2: {prev, cur, free}.
-      int sl = 0;
-      while (!first && (sl == c->slot_prevL || sl == c->slot_curL)) sl++;
-      c->slot_curL = sl;
+      c->slot_curL = new_curL;
       // camera split: the right image was imported into slot_curR by esvio_fe_import_image
       if (!c->ext_right_pending) c->slot_curR = c->slot_curR == kLeftSlots ? kLeftSlots + 1 : kLeftSlots;
       c->raw_cur = (c->raw_cur + 1) % kRightSlots;
@@ -629,6 +671,7 @@ struct TrackCall {
       }
       c->ext_right_pending = false;
       HIPCHK(c, hipEventRecord(c->ev_imgs_ready, c->stream));
+      }
     }
     have_next = !c->inflight.empty();
     next_b = have_next ? c->inflight.front() : Inflight();
@@ -638,6 +681,7 @@ struct TrackCall {
     main_reads_planes = !c->cur_prefetched;
     plain = !c->cur_prefetched && !had_announced && c->inflight.empty() && !c->lazy_new && !c->chain_valid &&
             !c->spec_valid;
+    if (plain) c->n_plain_calls++;
     pin_st = pin;
     c->cur_pts.clear();
     c->cur_right_pts.clear();
@@ -801,6 +845,7 @@ struct TrackCall {
                            ESVIO_FE_LK_USE_INITIAL_FLOW);
         stereo_chained = plain && c->chain_enabled;
         if (stereo_chained) {
+          c->n_stereo_chained++;
           c->chain_seq = (c->chain_seq + 1) & 0x3fffffffu;
           if (!c->chain_seq) c->chain_seq = 1;
           f.chain_out = c->d_chain;
@@ -1007,6 +1052,7 @@ struct TrackCall {
         if (int rc = finalize_right(c)) return rc;    // (idle time: k_select is running)
         sub(3);
         // stereo LK of the new corners only (count known on the device)
+        if (split_right) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_right_ready, 0));  // (the right image)
         LkArgs f = make_lk(curL, curR, c->z_new + n_kept, nullptr, c->z_ptsB2, c->z_stA2, c->d_counts,
                            n_max_cnt, 3, 30, 0.01, 0);
         LkArgs b = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, c->d_counts, n_max_cnt, 3, 30,
@@ -1125,9 +1171,14 @@ struct TrackCall {
         if (int rc = stager_mark_read(c, c->cur_stage, c->stream, true)) return rc;
       if (arc_side)  // (its k_arc_ev read the batch's events on the prefetch stream)
         if (int rc = stager_mark_read(c, c->cur_stage, c->stream2, false)) return rc;
+      if (split_right)  // (the right camera's update read its events on the stereo stream)
+        if (int rc = stager_mark_read_aux(c, c->cur_stage, c->stream4)) return rc;
       if (int rc = stager_release(c, c->cur_stage)) return rc;
       c->cur_stage = -1;
     }
+    // whatever comes next on the main stream — the taps, the next call's update, which shares the partition
+    // scratch — follows the right camera's chain
+    if (split_right) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_right_ready, 0));
     c->phase_frames++;
     c->phase_count[PUB_THIS_FRAME ? 1 : 0]++;
     c->tr_surv += (uint64_t)n_surv;
@@ -1219,6 +1270,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     (void)launcher_drain(c);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamSynchronize(c->stream4);
     (void)hipGetLastError();
     stager_abandon(c, c->cur_stage);
     c->cur_stage = -1;

@@ -80,6 +80,7 @@ ABI_SYMBOLS = [
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
     "esvio_fe_set_next_batch", "esvio_fe_set_next_batch_mc", "esvio_fe_debug_inject", "esvio_fe_debug_counters",
+    "esvio_fe_plain_call_counters",
     "esvio_fe_mem_alloc", "esvio_fe_mem_free", "esvio_fe_mem_upload", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
     "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot", "esvio_fe_host_nullspace",
@@ -155,6 +156,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_mem_upload.argtypes = [vp, vp, sz]
     L.esvio_fe_debug_inject.argtypes = [vp, i]
     L.esvio_fe_debug_counters.argtypes = [vp, vp]
+    L.esvio_fe_plain_call_counters.argtypes = [vp, vp]
     L.esvio_fe_good_features_to_track.argtypes = [vp, vp, i, d, d, vp, vp, vp, vp]
     L.esvio_fe_track_image.argtypes = [vp, d, vp, vp, i, vp]
     L.esvio_fe_pack_track_records.argtypes = [vp, vp, vp]
@@ -494,6 +496,11 @@ class FeatureTracker:
         out = (C.c_uint64 * 4)()
         self._hd.check(self._hd.L.esvio_fe_debug_counters(self._hd.h, out))
         return dict(spec_redone=out[0], chain_redone=out[1], chain_launched=out[2], chain_used=out[3])
+
+    def plain_call_counters(self):
+        out = (C.c_uint64 * 4)()
+        self._hd.check(self._hd.L.esvio_fe_plain_call_counters(self._hd.h, out))
+        return dict(plain_calls=out[0], split_by_camera=out[1], stereo_chained=out[2], chained_redone=out[3])
 
     # ---- the handle's own RCCL communicator: asynchronous exchange of the track records
     def comm_init(self, unique_id, rank, world):

@@ -407,6 +407,10 @@ int esvio_fe_mem_upload(void* dst_device, const void* src_host, size_t bytes);
 #define ESVIO_FE_FAULT_CHAINED 8
 int esvio_fe_debug_inject(esvio_fe_handle h, int mask);
 int esvio_fe_debug_counters(esvio_fe_handle h, uint64_t out4[4]);
+/* What the plain calls (nothing announced, not lazy: the reference node's pattern) did since create:
+ * {plain calls, of them with the two cameras' SAE update + image on two streams, stereo LK launches
+ * chained to the temporal one on the device, chained launches redone}. */
+int esvio_fe_plain_call_counters(esvio_fe_handle h, uint64_t out4[4]);
 
 /* ---- capacity ----------------------------------------------------------------------------- */
 /* Every event-proportional device buffer (partition scratch, candidate sets, staging lanes) grows on

@@ -224,6 +224,7 @@ def test_round3_entry_points_validate_their_arguments(has_gpu):
     assert L.esvio_fe_mem_free(FE.HOST, None) == 0                 # free(NULL)
     assert L.esvio_fe_mem_upload(None, None, 0) == 0 and L.esvio_fe_mem_upload(None, None, 16) == -1
     assert L.esvio_fe_debug_inject(None, 0) == -1 and L.esvio_fe_debug_counters(None, None) == -1
+    assert L.esvio_fe_plain_call_counters(None, None) == -1
     assert L.esvio_fe_set_next_batch_mc(None, 0.0, None, 0, None, 0, FE.HOST, 0, None) == -1
     if not has_gpu:
         q = C.c_void_p(1)

@@ -172,3 +172,66 @@ def test_announce_after_return_with_lazy_unpublished_frames(oracle, space):
     ft.close()
     for b in bufs:
         b.free()
+
+
+@pytest.mark.parametrize("space", ["host", "device"])
+@pytest.mark.parametrize("split", [True, False])
+def test_plain_calls_with_the_cameras_on_two_streams(oracle, monkeypatch, space, split):
+    """A plain call (nothing announced, nothing lazy: the reference node's pattern) runs the left camera's
+    SAE update + image on the main stream and the right camera's on the stereo stream, under the temporal
+    LK — for a pageable batch with the left array as a DMA of its own (ESVIO_FE_NO_CAMSPLIT=1: both on the
+    main stream, as before).  Calls that cannot split are mixed in (an empty right array, a batch below the
+    staging threshold, an announced batch, a lazy stretch) and both cameras' surfaces and images are read
+    back right after split calls (the main stream has to follow the stereo stream's right-camera chain):
+    every frame equals the sequential oracle's."""
+    if not split:
+        monkeypatch.setenv("ESVIO_FE_NO_CAMSPLIT", "1")
+    W, H = 640, 480
+    kw = dict(max_cnt=150, min_dist=10, f_ransac=1)
+    s = SceneStream(W, H, rate=5e6, seed=41, n_rect=20, size=(40.0, 120.0))
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    pubs = [True, False, True, True, False, False, True, False, True, True, False, True, True, False, True, True]
+    batches = [s.next_batch()[:2] for _ in pubs]
+    batches[4] = (batches[4][0], batches[4][1][:0])                                   # no right events
+    batches[7] = (batches[7][0][:4000].copy(), batches[7][1][:3000].copy())           # 112 KB: plain copy
+    bufs = []
+
+    def args(L, R):
+        if space == "host":
+            return L, R
+        bl, br = FE.EventBuffer(L, FE.DEVICE), FE.EventBuffer(R, FE.DEVICE)
+        bufs.extend([bl, br])
+        return bl.arg, br.arg
+
+    for f, pub in enumerate(pubs):
+        L, R = batches[f]
+        t = event_times(L)[-1]
+        aL, aR = args(L, R)
+        if f == 9:  # one announced batch in between: calls 9 and 10 are not plain
+            Ln, Rn = batches[10]
+            nL, nR = args(Ln, Rn)
+            ft.set_next_batch(event_times(Ln)[-1], nL, nR, pubs[10])
+        if f == 10:
+            aL, aR = nL, nR
+        if f == 12:
+            ft.set_lazy_new_stereo(True)
+        if f == 14:
+            ft.finish()
+            ft.set_lazy_new_stereo(False)
+        ft.trackEvent(t, aL, aR, pub)
+        r = tr.track_event(t, L, R, pub)
+        if f % 2 == 0:
+            for cam in (0, 1):
+                assert np.array_equal(ft.gettimesurface(cam), tr.time_surface(cam)), ("surface", cam, f)
+        if f in (12, 13):
+            ft.finish()
+        _same(ft, r, ("plain, two streams" if split else "plain, one stream", space, f))
+    n = ft.plain_call_counters()
+    assert n["plain_calls"] >= 10 and n["stereo_chained"] > 0 and n["chained_redone"] == 0, n
+    # (13 plain calls; no. 4 has no right events; no. 7 from pageable memory is below the staging threshold)
+    assert n["split_by_camera"] == ((n["plain_calls"] - (2 if space == "host" else 1)) if split else 0), n
+    assert len(ft.ids) > 60
+    ft.close()
+    for b in bufs:
+        b.free()

@@ -9,6 +9,7 @@ Stops at the first difference and prints the configuration that produced it.
     python tools/soak.py --minutes 10 [--seed 1]
 """
 import argparse
+import os
 import sys
 import time
 
@@ -79,13 +80,19 @@ def one_case(rng, case):
     p_pub = float(rng.choice([0.3, 0.5, 0.8, 1.0]))
     pubs = [bool(rng.random() < p_pub) for _ in batches]
     desc = dict(case=case, W=W, H=H, rate=rate, seed=seed, frames=n, p_pub=p_pub, **kw)
-    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    one_stream = rng.random() < 0.2  # (plain calls: both cameras' updates on the main stream instead of on two)
+    if one_stream:
+        os.environ["ESVIO_FE_NO_CAMSPLIT"] = "1"
+    try:
+        ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    finally:
+        os.environ.pop("ESVIO_FE_NO_CAMSPLIT", None)
     tr = O.Tracker(O.make_config(W, H, **kw))
     replay = rng.random() < 0.7
     mc = rng.random() < 0.3  # Do_motion_correction
     where = ["host", "host", "pinned", "device"][int(rng.integers(0, 4))]  # where the caller keeps the batches
-    fault = int(rng.choice([0, 0, 0, 4, 8, 12])) if replay else 0  # expiring speculative / chained waits
-    desc.update(replay=bool(replay), mc=bool(mc), where=where, fault=fault)
+    fault = int(rng.choice([0, 0, 0, 4, 8, 12] if replay else [0, 0, 8]))  # expiring speculative / chained waits
+    desc.update(replay=bool(replay), mc=bool(mc), where=where, fault=fault, one_stream=bool(one_stream))
     bufs = []
 
     def arg(a):
@@ -120,6 +127,8 @@ def one_case(rng, case):
                     announced += 1
                     ft.set_next_batch(event_times(batches[announced][0])[-1], args[announced][0], args[announced][1],
                                       pubs[announced], measurements=FE.make_motion(**mvs[announced]) if mc else None)
+            elif fault and rng.random() < 0.3:  # (a plain call's chained stereo LK giving up)
+                ft.debug_inject(fault if rng.random() < 0.5 else 0)
             t = event_times(L)[-1]
             if mc:
                 ft.trackEvent(t, args[f][0], args[f][1], pubs[f], measurements=FE.make_motion(**mvs[f]))
