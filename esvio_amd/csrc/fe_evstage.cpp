@@ -4,12 +4,15 @@
 //
 // A hipMemcpyAsync from pageable memory is not asynchronous: the runtime stages it through its own
 // bounce buffers on the calling thread (measured: 15 GB/s, 0.35 ms for the 5.3 MB of a C3 batch —
-// almost three times the rest of the frame).  Here the batch is cut into chunks of 256 KiB; helper
-// threads copy them into pinned memory and, when the last chunk of a group is in, enqueue the
-// group's DMA on a copy stream of its own (a DMA costs ~20 us whatever its size, so groups are
-// large: the whole batch when it was announced with esvio_fe_set_next_batch — all of it then
-// happens while the previous frames are tracked — and a few groups when the caller waits for it, so
-// that group k's DMA runs under group k+1's memcpy); the compute streams only wait for an event.
+// almost three times the rest of the frame).  Here the batch is cut into chunks of 256 KiB (64 KiB when
+// the calling thread waits for it); helper threads copy them into pinned memory with streaming stores and,
+// when the last chunk of a group is in, send the group to the device on a copy stream of its own: an
+// announced batch (esvio_fe_set_next_batch: all of it happens while the previous frames are tracked) as ONE
+// DMA; a plain call's batch in a few groups, each pulled out of the pinned buffer by a small kernel
+// (k_stage_pull) under the memcpy of the next one — lower latency than a copy engine at these sizes, and
+// several DMAs in flight at once make the runtime bring up further copy engines in the middle of a stream
+// (7-9 ms inside whichever hipMemcpyAsync does it, measured round 4; with more engines up the same calls
+// then run 0.08 ms slower).  The compute streams only wait for an event.
 // A source that already is pinned (hipHostMalloc / hipHostRegister) skips the memcpy: one DMA.
 //
 // Slots: one pinned + one device buffer per batch the handle knows about (announced, prefetched or
@@ -24,10 +27,37 @@
 #include <mutex>
 #include <thread>
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#include <emmintrin.h>
+#define ESVIO_STAGE_NT 1
+#endif
+
 namespace esvio {
 namespace fe {
 
 namespace {
+// pageable source -> pinned chunk.  The destination is read next by the DMA engine, never by this core: streaming
+// stores (no read-for-ownership of the destination lines, no cache filled with them); dst is 16-byte aligned (the
+// slot is page-aligned, offsets are multiples of the 16-byte event record)
+inline void stage_copy(uint8_t* dst, const uint8_t* src, size_t len) {
+#ifdef ESVIO_STAGE_NT
+  if (((uintptr_t)dst & 15u) == 0) {
+    size_t i = 0;
+    for (; i + 64 <= len; i += 64) {
+      const __m128i a = _mm_loadu_si128((const __m128i*)(src + i)), b = _mm_loadu_si128((const __m128i*)(src + i + 16)),
+                    c = _mm_loadu_si128((const __m128i*)(src + i + 32)), d = _mm_loadu_si128((const __m128i*)(src + i + 48));
+      _mm_stream_si128((__m128i*)(dst + i), a);
+      _mm_stream_si128((__m128i*)(dst + i + 16), b);
+      _mm_stream_si128((__m128i*)(dst + i + 32), c);
+      _mm_stream_si128((__m128i*)(dst + i + 48), d);
+    }
+    if (i < len) std::memcpy(dst + i, src + i, len - i);
+    _mm_sfence();  // (before the chunk is marked done and its group's DMA enqueued)
+    return;
+  }
+#endif
+  std::memcpy(dst, src, len);
+}
 constexpr size_t kChunkBytes = 256 * 1024;
 constexpr int kMaxGroups = 8;
 
@@ -60,8 +90,10 @@ struct Slot {
   // by_camera staging (a plain call that starts on the left camera while the right one is still on its
   // way): the left array is a DMA of its own, `copiedL` is recorded behind it
   hipEvent_t copiedL = nullptr;
-  int left_group = -1;               // group that is the left array, -1: none (not by camera, or a pinned source)
+  int n_left_groups = 0;             // groups [0, n_left_groups) are the left array's (0: not by camera, or a pinned source)
   std::atomic<bool> left_enq{false}; // the left array's DMA is enqueued and copiedL recorded
+  uint32_t n_left_chunks = 0;        // chunks [0, n_left_chunks) are the left array's (by_camera)
+  bool pull = false;                 // the groups go to the device by k_stage_pull instead of by DMA (a plain call's batch)
   bool in_use = false;
   std::atomic<int> state{0};  // 0 idle, 1 staging, 2 every DMA enqueued and `copied` recorded, -1 failed
   Group grp[kMaxGroups];
@@ -88,17 +120,42 @@ struct EventStager {
   // (ESVIO_FE_TRACE) batches, bytes, time the calling thread waited for a batch's staging, chunks it
   // took itself meanwhile, batches a call left for the next one because they had not arrived yet
   uint64_t batches = 0, bytes_staged = 0, wait_ns = 0, caller_chunks = 0, skipped = 0, redone = 0;
+  // A thread's first HIP calls cost milliseconds (measured: 7 ms inside the call whose DMA a RANSAC helper
+  // was the first to enqueue): every thread that may enqueue a DMA does one dummy copy + event record on the
+  // copy stream before it takes its first chunk
+  uint8_t* warm_pin = nullptr;
+  void* warm_dev = nullptr;
+  hipEvent_t warm_ev = nullptr;
+  void warm_thread() {
+    (void)hipSetDevice(c->dev);
+    if (warm_pin && warm_dev && hipMemcpyAsync(warm_dev, warm_pin, 16, hipMemcpyHostToDevice, stream) != hipSuccess) (void)hipGetLastError();
+    if (warm_ev && hipEventRecord(warm_ev, stream) != hipSuccess) (void)hipGetLastError();
+  }
+  uint64_t begin_ns = 0, left_ns = 0, left_calls = 0, pin_ns = 0;  // (trace) by-camera staging: stager_begin, stager_attach_left
 
   void enqueue_dma(Slot& s, Group& g) {
-    if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
+    if (s.pull) {
+      // a batch the calling thread waits for: the device pulls the group out of the pinned buffer itself
+      // (k_stage_pull: lower latency than a copy engine, and the copy engines' state stays out of the call)
+      launch_stage_pull(stream, s.pin + g.off, (uint8_t*)s.dev + g.off, g.len);
+      if (hipGetLastError() != hipSuccess) s.state.store(-1, std::memory_order_release);
+    } else if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
+      // an announced batch, staged whole frames ahead: one DMA (a 5 MB pull kernel on the copy stream costs the
+      // compute streams 0.025 ms/step in replay mode, the copy engine nothing)
       (void)hipGetLastError();
       s.state.store(-1, std::memory_order_release);
     }
-    if ((int)(&g - s.grp) == s.left_group) {
-      if (hipEventRecord(s.copiedL, stream) != hipSuccess) s.state.store(-1, std::memory_order_release);
-      s.left_enq.store(true, std::memory_order_release);
-    }
     g.dma_enq.store(true, std::memory_order_release);
+    if ((int)(&g - s.grp) < s.n_left_groups) {
+      // the left array's last DMA to be enqueued (whoever sees them all enqueued; twice does no harm: every
+      // DMA whose flag is set is in the stream already)
+      bool all = true;
+      for (int i = 0; i < s.n_left_groups; i++) all = all && s.grp[i].dma_enq.load(std::memory_order_acquire);
+      if (all) {
+        if (hipEventRecord(s.copiedL, stream) != hipSuccess) s.state.store(-1, std::memory_order_release);
+        s.left_enq.store(true, std::memory_order_release);
+      }
+    }
   }
   void finish_batch(Slot& s) {  // every group's DMA is enqueued: the event the compute streams wait for
     const bool ok = hipEventRecord(s.copied, stream) == hipSuccess;
@@ -122,9 +179,28 @@ struct EventStager {
     Chunk& ch = s.chunk[idx];
     uint8_t q = 0;
     if (!ch.st.compare_exchange_strong(q, 1, std::memory_order_acq_rel)) return;  // (somebody else's already)
-    std::memcpy(s.pin + ch.off, ch.src, ch.len);
+    stage_copy(s.pin + ch.off, ch.src, ch.len);
     uint8_t taken = 1;
     if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) chunk_done(s, ch);
+  }
+
+  // the calling thread while it waits for the LEFT array of slot k (by_camera): only that array's chunks — a
+  // right-array chunk taken now would keep it busy past the moment the left DMA is on its way
+  bool try_one_left(int k) {
+    Slot& s = slot[k];
+    if (s.state.load(std::memory_order_acquire) != 1 || s.next.load(std::memory_order_relaxed) >= s.n_left_chunks) return false;
+    s.busy.fetch_add(1, std::memory_order_acq_rel);
+    bool did = false;
+    if (s.state.load(std::memory_order_acquire) == 1 && s.next.load(std::memory_order_relaxed) < s.n_left_chunks) {
+      const uint32_t idx = s.next.fetch_add(1, std::memory_order_acq_rel);  // (may be a right chunk after all: run it)
+      if (idx < s.n_chunks.load(std::memory_order_acquire)) {
+        pending->fetch_sub(1, std::memory_order_acq_rel);
+        run_chunk(s, idx);
+        did = true;
+      }
+    }
+    s.busy.fetch_sub(1, std::memory_order_acq_rel);
+    return did;
   }
 
   // any thread: take one chunk of any batch being staged, if there is one
@@ -158,7 +234,7 @@ struct EventStager {
     for (uint32_t i = 0; i < n; i++) {
       Chunk& ch = s.chunk[i];
       if (ch.st.load(std::memory_order_acquire) != 1) continue;
-      std::memcpy(s.pin + ch.off, ch.src, ch.len);
+      stage_copy(s.pin + ch.off, ch.src, ch.len);
       uint8_t taken = 1;
       if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) {
         chunk_done(s, ch);
@@ -181,7 +257,7 @@ struct EventStager {
   }
 
   void worker() {
-    (void)hipSetDevice(c->dev);
+    warm_thread();
     for (;;) {
       if (try_one()) continue;
       std::unique_lock<std::mutex> g(mu);
@@ -196,7 +272,7 @@ static bool stager_idle_work(void* arg) {
   EventStager* st = (EventStager*)arg;
   static thread_local int dev_set = -1;
   if (dev_set != st->c->dev) {  // (the helper enqueues a group's DMA when it copies the group's last chunk)
-    (void)hipSetDevice(st->c->dev);
+    st->warm_thread();
     dev_set = st->c->dev;
   }
   return st->try_one();
@@ -235,6 +311,14 @@ static int stager_get(esvio_fe_ctx* c, EventStager** out) {
         stager_destroy(c);
         return fail(c, ESVIO_FE_EHIP, "hipEventCreate (event staging) failed");
       }
+    constexpr size_t kWarmBytes = 64;
+    if (hipHostMalloc((void**)&st->warm_pin, kWarmBytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&st->warm_dev, kWarmBytes) != hipSuccess ||
+        hipEventCreateWithFlags(&st->warm_ev, hipEventDisableTiming) != hipSuccess) {
+      c->stager = st;
+      stager_destroy(c);
+      return fail(c, ESVIO_FE_EHIP, "allocation (event staging) failed");
+    }
+    std::memset(st->warm_pin, 0, kWarmBytes);
     for (int i = 0; i < c->stage_threads; i++) st->threads.emplace_back([st] { st->worker(); });
     c->stager = st;
     stager_share_pool(c);  // the RANSAC helpers, spinning between jobs anyway, take chunks as well
@@ -274,17 +358,35 @@ int stager_reserve(esvio_fe_ctx* c, size_t n_events) {
   EventStager* st = nullptr;
   if (int rc = stager_get(c, &st)) return rc;
   for (Slot& s : st->slot)
-    if (!s.in_use)
+    if (!s.in_use) {
       if (int rc = slot_capacity(c, s, n_events)) return rc;
+      const size_t chunks = (n_events * 16 + kChunkBytes / 4 - 1) / (kChunkBytes / 4);  // (the by-camera chunk size)
+      if (chunks + 4 > s.chunk_cap) {
+        s.chunk_cap = chunks + 4 + chunks / 4;
+        s.chunk.reset(new Chunk[s.chunk_cap]);
+      }
+    }
   return 0;
 }
 
 // Start staging [left; right] into a free slot: returns at once, the helpers do the work.
-// dma_groups: DMAs the pageable part of the batch is moved with (1: the caller does not wait for it)
-// by_camera: the left array and the right array are one DMA each (dma_groups is ignored), and the left one's
-// completion can be waited for on its own (stager_attach_left)
+// dma_groups: pieces the pageable part of the batch is moved in (1: an announced batch, nobody waits for it: one
+// DMA; more: a plain call's batch, piece k goes to the device — by k_stage_pull — under the memcpy of piece k+1)
+// by_camera: the left array and the right array are two pieces each (dma_groups is ignored), and the left
+// one's arrival can be waited for on its own (stager_attach_left)
+static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
+                             int dma_groups, int* slot_out, bool by_camera);
 int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
                  int dma_groups, int* slot_out, bool by_camera) {
+  if (!c->trace) return stager_begin_impl(c, left, nL, right, nR, dma_groups, slot_out, by_camera);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = stager_begin_impl(c, left, nL, right, nR, dma_groups, slot_out, by_camera);
+  if (c->stager)
+    c->stager->begin_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
+                             int dma_groups, int* slot_out, bool by_camera) {
   EventStager* st = nullptr;
   if (int rc = stager_get(c, &st)) return rc;
   int k = 0;
@@ -293,14 +395,18 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
   if (k == kStageSlots) return fail(c, ESVIO_FE_EINTERNAL, "no free event staging slot");
   Slot& s = st->slot[k];
   const size_t n = nL + nR;
+  const auto tp0 = std::chrono::steady_clock::now();
   const bool pinL = nL && host_pointer_is_pinned(left), pinR = nR && host_pointer_is_pinned(right);
+  if (c->trace) st->pin_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tp0).count();
   if (int rc = slot_capacity(c, s, n)) return rc;
   // the DMA overwrites the slot's device buffer: behind the kernels that read its previous batch
   if (s.pf_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.pf_done, 0));
   if (s.main_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.main_done, 0));
   if (s.aux_rec) HIPCHK(c, hipStreamWaitEvent(st->stream, s.aux_done, 0));
   s.pf_rec = s.main_rec = s.aux_rec = false;
-  s.left_group = -1;
+  s.n_left_groups = 0;
+  s.n_left_chunks = 0;
+  s.pull = by_camera || dma_groups > 1;  // (a batch the calling thread waits for)
   s.left_enq.store(false, std::memory_order_release);
   st->bytes_staged += n * 16;
   st->batches++;
@@ -320,28 +426,37 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
   s.n_chunks.store(0, std::memory_order_release);
   s.next.store(0, std::memory_order_release);
   if (hi > lo) {
-    ng = std::max(1, std::min(dma_groups, kMaxGroups));
-    const size_t chunks = (hi - lo + kChunkBytes - 1) / kChunkBytes;
-    ng = (int)std::min<size_t>(ng, chunks);
-    size_t per = (chunks + ng - 1) / ng;  // chunks per group
-    ng = (int)((chunks + per - 1) / per);
-    const bool cam_groups = by_camera && !pinL && !pinR && nL && nR;  // both arrays pageable: one group each
-    if (cam_groups) ng = 2;
-    if (by_camera && !pinL && nL) s.left_group = 0;  // (else: a single group of the right array, or of either one)
-    if (by_camera && !cam_groups) {
-      ng = 1;
-      per = chunks;
+    // (by camera: the calling thread waits for the left array: smaller pieces, more threads on it at once)
+    const size_t cb = by_camera ? kChunkBytes / 4 : kChunkBytes;
+    const size_t chunks = (hi - lo + cb - 1) / cb;
+    // the groups (one DMA each): destination byte ranges [a, b)
+    size_t ga[kMaxGroups], gb[kMaxGroups];
+    auto split = [&](size_t a0, size_t b0, int want) {  // [a0, b0) into <= want groups of whole chunks
+      const size_t nc = (b0 - a0 + cb - 1) / cb;
+      const int k = (int)std::min<size_t>((size_t)std::max(1, want), nc);
+      const size_t per = (nc + k - 1) / k;
+      for (size_t o = a0; o < b0 && ng < kMaxGroups; o += per * cb) {
+        ga[ng] = o;
+        gb[ng] = ng == kMaxGroups - 1 ? b0 : std::min(b0, o + per * cb);
+        ng++;
+      }
+    };
+    if (by_camera) {
+      // the left array's DMAs can be waited for on their own; group k's DMA runs under the memcpy of group k+1
+      if (!pinL && nL) {
+        split(0, nL * 16, 2);
+        s.n_left_groups = ng;
+      }
+      if (!pinR && nR) split(nL * 16, n * 16, 2);
+    } else {
+      split(lo, hi, std::min(dma_groups, kMaxGroups));
     }
-    if (chunks + 2 > s.chunk_cap) {  // (+1: a chunk never straddles the two source arrays)
-      s.chunk_cap = chunks + 2 + chunks / 4;
+    if (chunks + 4 > s.chunk_cap) {  // (+: a chunk never straddles the two source arrays)
+      s.chunk_cap = chunks + 4 + chunks / 4;
       s.chunk.reset(new Chunk[s.chunk_cap]);
     }
     for (int g = 0; g < ng; g++) {
-      size_t a = lo + (size_t)g * per * kChunkBytes, b = std::min(hi, a + per * kChunkBytes);
-      if (cam_groups) {
-        a = g ? nL * 16 : 0;
-        b = g ? n * 16 : nL * 16;
-      }
+      const size_t a = ga[g], b = gb[g];
       s.grp[g].off = a;
       s.grp[g].len = b - a;
       s.grp[g].dma_enq.store(false, std::memory_order_relaxed);
@@ -349,7 +464,7 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
       for (size_t o = a; o < b;) {
         // a chunk never straddles the boundary between the two source arrays
         const bool in_left = o < nL * 16;
-        const size_t end = std::min(std::min(o + kChunkBytes, b), in_left ? nL * 16 : b);
+        const size_t end = std::min(std::min(o + cb, b), in_left ? nL * 16 : b);
         const uint8_t* src = in_left ? (const uint8_t*)left + o : (const uint8_t*)right + (o - nL * 16);
         Chunk& ch = s.chunk[nch];
         ch.group = g;
@@ -359,6 +474,7 @@ int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const e
         ch.st.store(0, std::memory_order_relaxed);
         nch++;
         cnt++;
+        if (g < s.n_left_groups) s.n_left_chunks = nch;
         o = end;
       }
       s.grp[g].chunks_left.store(cnt, std::memory_order_relaxed);
@@ -426,8 +542,13 @@ int stager_attach_left(esvio_fe_ctx* c, int slot, hipStream_t s, const EventRec*
   EventStager* st = c->stager;
   Slot& sl = st->slot[slot];
   unsigned idle = 0;
+  const auto tl0 = std::chrono::steady_clock::now();
+  struct Lap {
+    EventStager* st; std::chrono::steady_clock::time_point t0;
+    ~Lap() { st->left_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); st->left_calls++; }
+  } lap{st, tl0};
   while (!sl.left_enq.load(std::memory_order_acquire) && sl.state.load(std::memory_order_acquire) == 1) {
-    if (st->try_one()) {
+    if (st->try_one_left(slot)) {
       st->caller_chunks++;
       idle = 0;
     } else if (++idle > 1000) {
@@ -537,10 +658,18 @@ void stager_destroy(esvio_fe_ctx* c) {
             (unsigned long long)st->batches, st->bytes_staged / 1e6, (int)st->threads.size(),
             st->wait_ns / 1e6 / st->batches, (unsigned long long)st->caller_chunks, (unsigned long long)st->redone,
             (unsigned long long)st->skipped);
+  if (c->trace && st->batches)
+    fprintf(stderr, "[esvio_fe trace] host-event staging, calling thread per batch: stager_begin %.1f us (pinned-or-not query %.1f), "
+            "wait for the left array %.1f us (%llu by-camera batches), wait for the whole batch %.1f us\n",
+            st->begin_ns / 1e3 / st->batches, st->pin_ns / 1e3 / st->batches, st->left_calls ? st->left_ns / 1e3 / st->left_calls : 0.0,
+            (unsigned long long)st->left_calls, st->wait_ns / 1e3 / st->batches);
   if (st->stream) {
     (void)hipStreamSynchronize(st->stream);
     (void)hipStreamDestroy(st->stream);
   }
+  if (st->warm_ev) (void)hipEventDestroy(st->warm_ev);
+  if (st->warm_dev) (void)hipFree(st->warm_dev);
+  if (st->warm_pin) (void)hipHostFree(st->warm_pin);
   for (Slot& s : st->slot) {
     if (s.copied) (void)hipEventDestroy(s.copied);
     if (s.copiedL) (void)hipEventDestroy(s.copiedL);

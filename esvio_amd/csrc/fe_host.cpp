@@ -980,6 +980,7 @@ struct RansacPool {
   std::atomic<bool (*)(void*)> idle_fn{nullptr};
   void* idle_arg = nullptr;
   alignas(64) std::atomic<int> idle_inside{0};  // helpers inside idle_fn right now
+  std::atomic<uint32_t> idle_gen{0};  // bumped when idle_fn is set: every awake helper calls it once at once (per-thread set-up)
   alignas(64) std::atomic<uint32_t> epoch{0};  // odd while a job is open; job (epoch >> 1) & 1
   RansacJob job[2];
   // helpers are kept on the cores that share the caller's L3 (one CCD): an iteration is ~0.5 us of
@@ -997,13 +998,17 @@ struct RansacPool {
     uint32_t seen = 0;
     auto idle_since = std::chrono::steady_clock::now();
     unsigned spins = 0;
+    uint32_t idle_gen_seen = 0;
     [[maybe_unused]] long last_nivcsw = 0;
     for (;;) {
       if (quit.load(std::memory_order_acquire)) return;
       const uint32_t e = epoch.load(std::memory_order_acquire);
       if (!(e & 1) || e == seen) {
         const std::atomic<int>* pend = idle_pending.load(std::memory_order_acquire);
-        if (pend && pend->load(std::memory_order_relaxed) > 0) {
+        const uint32_t ig = idle_gen.load(std::memory_order_acquire);
+        const bool first = ig != idle_gen_seen;
+        idle_gen_seen = ig;
+        if (pend && (first || pend->load(std::memory_order_relaxed) > 0)) {
           idle_inside.fetch_add(1, std::memory_order_acq_rel);
           bool (*fn)(void*) = idle_fn.load(std::memory_order_acquire);  // (still there?)
           const bool did = fn && fn(idle_arg);
@@ -1199,6 +1204,7 @@ void ransac_pool_set_idle_work(RansacPool* p, const std::atomic<int>* pending, b
   p->idle_arg = arg;
   p->idle_pending.store(pending, std::memory_order_release);  // (the handle's counter: outlives the pool)
   p->idle_fn.store(fn, std::memory_order_release);
+  p->idle_gen.fetch_add(1, std::memory_order_acq_rel);
 }
 
 void ransac_pool_hold(RansacPool* p, int mask, bool on) {

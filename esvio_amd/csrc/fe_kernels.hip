@@ -3107,6 +3107,23 @@ __global__ __launch_bounds__(kArcBlock) void k_arc_ev(ArcArgs a) {
   }
 }
 
+// Host batch on its way to the device (fe_evstage.cpp): the staged chunks sit in pinned host memory, which
+// the device reads itself — a few dozen workgroups pulling 16 bytes per lane keep the PCIe link as busy as
+// a copy engine does (tools/h2d_probe.hip on MI355X: 2.7 MB in 54 us = 52 GB/s against 65 us for
+// hipMemcpyAsync, 64 KB in 6 us against 15) and, unlike hipMemcpyAsync, never make the runtime bring up
+// another copy engine in the middle of a stream (7-9 ms inside the call that does, every other thread's copy
+// calls waiting behind it).
+__global__ __launch_bounds__(256) void k_stage_pull(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+void launch_stage_pull(hipStream_t s, const void* pinned_src, void* dst, size_t bytes) {
+  const size_t n = bytes / 16;  // (event records: always whole 16-byte units)
+  if (!n) return;
+  const unsigned grid = (unsigned)std::min<size_t>(64, (n + 255) / 256);
+  launch_k(k_stage_pull, dim3(grid), dim3(256), 0, s, (const uint4*)pinned_src, (uint4*)dst, n);
+}
+
 void launch_arc_mark(hipStream_t s, const ArcArgs& a) {
   if (!a.n) return;
   uint32_t grid = (a.n + 1023) / 1024;
