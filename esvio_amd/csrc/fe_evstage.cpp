@@ -123,6 +123,9 @@ struct EventStager {
   // A thread's first HIP calls cost milliseconds (measured: 7 ms inside the call whose DMA a RANSAC helper
   // was the first to enqueue): every thread that may enqueue a DMA does one dummy copy + event record on the
   // copy stream before it takes its first chunk
+  hipEvent_t gate_ev[4] = {};                    // behind the last four DMAs
+  std::atomic<uint32_t> gate_n{0}, gate_rec[4];  // DMAs issued; gate_rec[t & 3] == t + 1: DMA t's event is recorded
+  std::atomic<uint64_t> gate_expired{0};
   uint8_t* warm_pin = nullptr;
   void* warm_dev = nullptr;
   hipEvent_t warm_ev = nullptr;
@@ -139,11 +142,31 @@ struct EventStager {
       // (k_stage_pull: lower latency than a copy engine, and the copy engines' state stays out of the call)
       launch_stage_pull(stream, s.pin + g.off, (uint8_t*)s.dev + g.off, g.len);
       if (hipGetLastError() != hipSuccess) s.state.store(-1, std::memory_order_release);
-    } else if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
+    } else {
       // an announced batch, staged whole frames ahead: one DMA (a 5 MB pull kernel on the copy stream costs the
-      // compute streams 0.025 ms/step in replay mode, the copy engine nothing)
-      (void)hipGetLastError();
-      s.state.store(-1, std::memory_order_release);
+      // compute streams 0.025 ms/step in replay mode, the copy engine nothing).  Never more than two DMAs in
+      // flight: the third makes the runtime bring up another copy engine inside this very call (7-9 ms) — the
+      // stream runs them one after the other anyway, so DMA number t waits (bounded) for number t - 2 to be over
+      const uint32_t t = gate_n.fetch_add(1, std::memory_order_acq_rel);
+      if (t >= 2) {
+        const auto tg0 = std::chrono::steady_clock::now();
+        const uint32_t w = (t - 2) & 3u;
+        for (unsigned spin = 0;; spin++) {
+          if (gate_rec[w].load(std::memory_order_acquire) == t - 1 && hipEventQuery(gate_ev[w]) == hipSuccess) break;
+          (void)hipGetLastError();  // (hipErrorNotReady)
+          if ((spin & 15) == 15 && std::chrono::steady_clock::now() - tg0 > std::chrono::microseconds(400)) {
+            gate_expired.fetch_add(1, std::memory_order_relaxed);
+            break;
+          }
+          __builtin_ia32_pause();
+        }
+      }
+      if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        s.state.store(-1, std::memory_order_release);
+      }
+      if (hipEventRecord(gate_ev[t & 3u], stream) != hipSuccess) (void)hipGetLastError();
+      gate_rec[t & 3u].store(t + 1, std::memory_order_release);
     }
     g.dma_enq.store(true, std::memory_order_release);
     if ((int)(&g - s.grp) < s.n_left_groups) {
@@ -319,6 +342,14 @@ static int stager_get(esvio_fe_ctx* c, EventStager** out) {
       return fail(c, ESVIO_FE_EHIP, "allocation (event staging) failed");
     }
     std::memset(st->warm_pin, 0, kWarmBytes);
+    for (int i = 0; i < 4; i++) {
+      st->gate_rec[i].store(0, std::memory_order_relaxed);
+      if (hipEventCreateWithFlags(&st->gate_ev[i], hipEventDisableTiming) != hipSuccess) {
+        c->stager = st;
+        stager_destroy(c);
+        return fail(c, ESVIO_FE_EHIP, "hipEventCreate (event staging) failed");
+      }
+    }
     for (int i = 0; i < c->stage_threads; i++) st->threads.emplace_back([st] { st->worker(); });
     c->stager = st;
     stager_share_pool(c);  // the RANSAC helpers, spinning between jobs anyway, take chunks as well
@@ -660,14 +691,16 @@ void stager_destroy(esvio_fe_ctx* c) {
             (unsigned long long)st->skipped);
   if (c->trace && st->batches)
     fprintf(stderr, "[esvio_fe trace] host-event staging, calling thread per batch: stager_begin %.1f us (pinned-or-not query %.1f), "
-            "wait for the left array %.1f us (%llu by-camera batches), wait for the whole batch %.1f us\n",
+            "wait for the left array %.1f us (%llu by-camera batches), wait for the whole batch %.1f us; %llu DMAs went out without waiting for the one two before\n",
             st->begin_ns / 1e3 / st->batches, st->pin_ns / 1e3 / st->batches, st->left_calls ? st->left_ns / 1e3 / st->left_calls : 0.0,
-            (unsigned long long)st->left_calls, st->wait_ns / 1e3 / st->batches);
+            (unsigned long long)st->left_calls, st->wait_ns / 1e3 / st->batches, (unsigned long long)st->gate_expired.load());
   if (st->stream) {
     (void)hipStreamSynchronize(st->stream);
     (void)hipStreamDestroy(st->stream);
   }
   if (st->warm_ev) (void)hipEventDestroy(st->warm_ev);
+  for (hipEvent_t ev : st->gate_ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (st->warm_dev) (void)hipFree(st->warm_dev);
   if (st->warm_pin) (void)hipHostFree(st->warm_pin);
   for (Slot& s : st->slot) {
