@@ -776,6 +776,12 @@ int esvio_fe_host_hypot(const double* x, const double* y, int n, double* out) {
   return ESVIO_FE_OK;
 }
 
+int esvio_fe_host_stage_copy(void* dst, const void* src, size_t len) {
+  if (len && (!dst || !src)) return ESVIO_FE_EINVAL;
+  stager_copy_bytes((uint8_t*)dst, (const uint8_t*)src, len);
+  return ESVIO_FE_OK;
+}
+
 int esvio_fe_host_nullspace(const double* systems, int n, int lanes, double* f12, int32_t* redone) {
   if (n < 0 || (n && (!systems || !f12))) return ESVIO_FE_EINVAL;
   const int r = host::host_nullspace(systems, n, lanes, f12);

@@ -290,6 +290,8 @@ struct EventStager {
   }
 };
 
+void stager_copy_bytes(uint8_t* dst, const uint8_t* src, size_t len) { stage_copy(dst, src, len); }
+
 // what a spinning RANSAC helper does between jobs (host::ransac_pool_set_idle_work): one chunk
 static bool stager_idle_work(void* arg) {
   EventStager* st = (EventStager*)arg;

@@ -116,6 +116,7 @@ int stager_reserve(esvio_fe_ctx* c, size_t n_events);
 void stager_ptrs(esvio_fe_ctx* c, int slot, size_t nL, const EventRec** dL, const EventRec** dR);
 void stager_drain(esvio_fe_ctx* c);
 void stager_destroy(esvio_fe_ctx* c);
+void stager_copy_bytes(uint8_t* dst, const uint8_t* src, size_t len);  // (test tap: a chunk's copy)
 
 // ---------------------------------------------------------------- fe_track.cpp
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first = false);

@@ -83,7 +83,7 @@ ABI_SYMBOLS = [
     "esvio_fe_plain_call_counters",
     "esvio_fe_mem_alloc", "esvio_fe_mem_free", "esvio_fe_mem_upload", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
-    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot", "esvio_fe_host_nullspace",
+    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot", "esvio_fe_host_nullspace", "esvio_fe_host_stage_copy",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
@@ -164,6 +164,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_set_host_threads.argtypes = [vp, i]
     L.esvio_fe_ransac_stats.argtypes = [vp, i]
     L.esvio_fe_host_hypot.argtypes = [vp, vp, i, vp]
+    L.esvio_fe_host_stage_copy.argtypes = [vp, vp, C.c_size_t]
     L.esvio_fe_host_nullspace.argtypes = [vp, i, i, vp, C.POINTER(C.c_int32)]
     L.esvio_fe_find_fundamental_mat_mt.argtypes = [vp, vp, i, d, d, i, vp, C.POINTER(C.c_int32)]
     L.esvio_fe_finish.argtypes = [vp, vp]

@@ -175,6 +175,10 @@ int esvio_fe_find_fundamental_mat_held(const float* p1, const float* p2, int n, 
  * unqualified inside namespace cv, which resolves to lapack.cpp's own a*sqrt(1+(b/a)^2) template, not
  * to libm's; IEEE operations only, so the result does not depend on the host's libm. */
 int esvio_fe_host_hypot(const double* x, const double* y, int n, double* out);
+/* Test tap: the copy the staging threads move a chunk of a host-resident event batch with (pageable source ->
+ * pinned buffer; streaming stores where dst is 16-byte aligned, memcpy otherwise and for the last < 64 bytes):
+ * dst[0, len) = src[0, len), nothing else written.  No device involved. */
+int esvio_fe_host_stage_copy(void* dst, const void* src, size_t len);
 /* Test tap: the basis of the 7x9 epipolar system's null space that run7Point takes from
  * cv::SVDecomp(A, W, U, Vt, MODIFY_A + FULL_UV) (rows 7 and 8 of Vt; OpenCV calib3d/fundam.cpp, reached
  * from feature_tracker.cpp:935), for n systems of 63 doubles -> f12 = n x (f1[9] | f2[9]).  lanes = 0:

@@ -181,6 +181,25 @@ def test_header_is_plain_c(tmp_path):
                            "-I", os.path.join(root, "include"), str(src)])
 
 
+def test_stage_copy_copies_exactly_the_bytes_asked_for():
+    """the chunk copy of the host-batch staging (streaming stores for an aligned destination, memcpy for the
+    rest): every length around the 64-byte step, every source alignment, aligned and unaligned
+    destinations — the bytes arrive and the bytes around them stay"""
+    L = FE.load_library()
+    rng = np.random.default_rng(4)
+    assert L.esvio_fe_host_stage_copy(None, None, 0) == 0 and L.esvio_fe_host_stage_copy(None, None, 16) == -1
+    for n in [0, 1, 15, 16, 17, 63, 64, 65, 127, 128, 200, 4096, 65536, 65536 + 48, 262144 + 16]:
+        for so in (0, 1, 8, 16):
+            for do in (0, 16, 3):
+                src = rng.integers(0, 256, n + so + 64, dtype=np.uint8)
+                buf = np.full(n + 256 + do, 0xA5, np.uint8)
+                base = (-buf.ctypes.data) % 64 + do  # dst = 64-byte aligned + do
+                d = buf[base:base + n]
+                assert L.esvio_fe_host_stage_copy(C.c_void_p(buf.ctypes.data + base), C.c_void_p(src.ctypes.data + so), n) == 0
+                assert np.array_equal(d, src[so:so + n]), (n, so, do)
+                assert (buf[:base] == 0xA5).all() and (buf[base + n:] == 0xA5).all(), (n, so, do)
+
+
 def test_host_hypot_is_cv_hypot():
     """cv::SVD's Jacobi rotations call hypot unqualified inside namespace cv, where lapack.cpp's own
     template (a * sqrt(1 + (b/a)^2)) hides libm's — so the library's rotations use that formula, in IEEE
