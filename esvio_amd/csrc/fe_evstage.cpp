@@ -140,6 +140,7 @@ struct EventStager {
     if (s.pull) {
       // a batch the calling thread waits for: the device pulls the group out of the pinned buffer itself
       // (k_stage_pull: lower latency than a copy engine, and the copy engines' state stays out of the call)
+      (void)hipGetLastError();  // (whatever this thread's earlier calls left behind is not this launch's)
       launch_stage_pull(stream, s.pin + g.off, (uint8_t*)s.dev + g.off, g.len);
       if (hipGetLastError() != hipSuccess) s.state.store(-1, std::memory_order_release);
     } else {
@@ -591,11 +592,15 @@ int stager_attach_left(esvio_fe_ctx* c, int slot, hipStream_t s, const EventRec*
       __builtin_ia32_pause();
     }
   }
-  if (!sl.left_enq.load(std::memory_order_acquire) || sl.state.load(std::memory_order_acquire) < 0) {
+  const int stt = sl.state.load(std::memory_order_acquire);
+  const bool left = sl.left_enq.load(std::memory_order_acquire);
+  if (stt < 0 || (!left && stt != 2)) {
     stager_abandon(c, slot);
-    return fail(c, ESVIO_FE_EHIP, "staging the event batch failed");
+    return fail(c, ESVIO_FE_EHIP, "staging the event batch failed (left array)");
   }
-  HIPCHK(c, hipStreamWaitEvent(s, sl.copiedL, 0));
+  // (the whole batch can be complete — finish_for above closed it — while the thread that sent the last left
+  // group has not got to recording copiedL yet: the batch's own event covers the left array as well)
+  HIPCHK(c, hipStreamWaitEvent(s, left ? sl.copiedL : sl.copied, 0));
   *dL = sl.dev;
   return 0;
 }

@@ -146,6 +146,9 @@ def one_case(rng, case):
                 return desc, "frame %d: %s differs" % (f, bad)
         if not np.array_equal(ft.gettimesurface(0), tr.time_surface(0)):
             return desc, "time surface differs"
+    except Exception:
+        print("EXCEPTION at frame %d of" % f, desc, flush=True)
+        raise
     finally:
         ft.close()
         for b in bufs:
@@ -169,7 +172,11 @@ def main():
     import signal
     signal.signal(signal.SIGTERM, on_term)
     while time.time() - t0 < a.minutes * 60:
-        desc, err = one_case(rng, cases)
+        try:
+            desc, err = one_case(rng, cases)
+        except Exception as e:  # (a library error is a finding as well: say in which case)
+            print("EXCEPTION in case %d (seed %d): %r" % (cases, a.seed, e), flush=True)
+            raise
         cases += 1
         frames += desc["frames"]
         if err:
