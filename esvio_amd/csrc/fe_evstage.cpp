@@ -136,6 +136,31 @@ struct EventStager {
   }
   uint64_t begin_ns = 0, left_ns = 0, left_calls = 0, pin_ns = 0;  // (trace) by-camera staging: stager_begin, stager_attach_left
 
+  // one DMA on the copy stream.  Never more than two in flight: the third makes the runtime bring up another
+  // copy engine inside this very call (7-9 ms) — the stream runs them one after the other anyway, so DMA
+  // number t waits (bounded) for number t - 2 to be over
+  bool dma(void* dst, const void* src, size_t len) {
+    const uint32_t t = gate_n.fetch_add(1, std::memory_order_acq_rel);
+    if (t >= 2) {
+      const auto tg0 = std::chrono::steady_clock::now();
+      const uint32_t w = (t - 2) & 3u;
+      for (unsigned spin = 0;; spin++) {
+        if (gate_rec[w].load(std::memory_order_acquire) == t - 1 && hipEventQuery(gate_ev[w]) == hipSuccess) break;
+        (void)hipGetLastError();  // (hipErrorNotReady)
+        if ((spin & 15) == 15 && std::chrono::steady_clock::now() - tg0 > std::chrono::microseconds(400)) {
+          gate_expired.fetch_add(1, std::memory_order_relaxed);
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+    }
+    const bool ok = hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, stream) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    if (hipEventRecord(gate_ev[t & 3u], stream) != hipSuccess) (void)hipGetLastError();
+    gate_rec[t & 3u].store(t + 1, std::memory_order_release);
+    return ok;
+  }
+
   void enqueue_dma(Slot& s, Group& g) {
     if (s.pull) {
       // a batch the calling thread waits for: the device pulls the group out of the pinned buffer itself
@@ -145,29 +170,8 @@ struct EventStager {
       if (hipGetLastError() != hipSuccess) s.state.store(-1, std::memory_order_release);
     } else {
       // an announced batch, staged whole frames ahead: one DMA (a 5 MB pull kernel on the copy stream costs the
-      // compute streams 0.025 ms/step in replay mode, the copy engine nothing).  Never more than two DMAs in
-      // flight: the third makes the runtime bring up another copy engine inside this very call (7-9 ms) — the
-      // stream runs them one after the other anyway, so DMA number t waits (bounded) for number t - 2 to be over
-      const uint32_t t = gate_n.fetch_add(1, std::memory_order_acq_rel);
-      if (t >= 2) {
-        const auto tg0 = std::chrono::steady_clock::now();
-        const uint32_t w = (t - 2) & 3u;
-        for (unsigned spin = 0;; spin++) {
-          if (gate_rec[w].load(std::memory_order_acquire) == t - 1 && hipEventQuery(gate_ev[w]) == hipSuccess) break;
-          (void)hipGetLastError();  // (hipErrorNotReady)
-          if ((spin & 15) == 15 && std::chrono::steady_clock::now() - tg0 > std::chrono::microseconds(400)) {
-            gate_expired.fetch_add(1, std::memory_order_relaxed);
-            break;
-          }
-          __builtin_ia32_pause();
-        }
-      }
-      if (hipMemcpyAsync((uint8_t*)s.dev + g.off, s.pin + g.off, g.len, hipMemcpyHostToDevice, stream) != hipSuccess) {
-        (void)hipGetLastError();
-        s.state.store(-1, std::memory_order_release);
-      }
-      if (hipEventRecord(gate_ev[t & 3u], stream) != hipSuccess) (void)hipGetLastError();
-      gate_rec[t & 3u].store(t + 1, std::memory_order_release);
+      // compute streams 0.025 ms/step in replay mode, the copy engine nothing)
+      if (!dma((uint8_t*)s.dev + g.off, s.pin + g.off, g.len)) s.state.store(-1, std::memory_order_release);
     }
     g.dma_enq.store(true, std::memory_order_release);
     if ((int)(&g - s.grp) < s.n_left_groups) {
@@ -446,12 +450,12 @@ static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t
   st->batches++;
   // a pinned source: one DMA straight from it, now (the slot is taken only once nothing below can fail
   // before its state is set)
-  if (pinL) HIPCHK(c, hipMemcpyAsync(s.dev, left, nL * 16, hipMemcpyHostToDevice, st->stream));
+  if (pinL && !st->dma(s.dev, left, nL * 16)) return fail(c, ESVIO_FE_EHIP, "hipMemcpyAsync (event staging) failed");
   if (by_camera && (pinL || !nL)) {  // (the left array is on its way already, or there is none)
     HIPCHK(c, hipEventRecord(s.copiedL, st->stream));
     s.left_enq.store(true, std::memory_order_release);
   }
-  if (pinR) HIPCHK(c, hipMemcpyAsync(s.dev + nL, right, nR * 16, hipMemcpyHostToDevice, st->stream));
+  if (pinR && !st->dma(s.dev + nL, right, nR * 16)) return fail(c, ESVIO_FE_EHIP, "hipMemcpyAsync (event staging) failed");
   s.in_use = true;
   // the pageable part: destination byte range [lo, hi) of the slot's buffers
   const size_t lo = pinL ? nL * 16 : 0, hi = pinR ? nL * 16 : n * 16;
