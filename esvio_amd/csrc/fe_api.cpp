@@ -824,6 +824,50 @@ int esvio_fe_find_fundamental_mat_held(const float* p1, const float* p2, int n, 
   return 0;
 }
 
+namespace {
+struct IdleTap {
+  std::atomic<int> pending{0};
+  std::atomic<uint64_t> calls{0}, done{0};
+};
+bool idle_tap_fn(void* arg) {  // what the staging hands the helpers: one unit of work, if there is one
+  IdleTap* t = (IdleTap*)arg;
+  t->calls.fetch_add(1, std::memory_order_relaxed);
+  int v = t->pending.load(std::memory_order_acquire);
+  while (v > 0)
+    if (t->pending.compare_exchange_weak(v, v - 1, std::memory_order_acq_rel)) {
+      const auto t0 = std::chrono::steady_clock::now();  // (a unit: ~5 us, a staging chunk's order of magnitude)
+      while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(5)) {}
+      t->done.fetch_add(1, std::memory_order_relaxed);
+      return true;
+    }
+  return false;
+}
+}  // namespace
+
+int esvio_fe_find_fundamental_mat_idle(const float* p1, const float* p2, int n, double thr, double conf,
+                                       int threads, int repeats, int idle_units, uint8_t* status, int32_t* n_inliers,
+                                       uint64_t out3[3]) {
+  if (n < 0 || (n && (!p1 || !p2 || !status)) || threads < 2 || threads > 16 || repeats < 1 || idle_units < 0 || !out3)
+    return ESVIO_FE_EINVAL;
+  host::RansacPool* pool = host::ransac_pool_create(threads - 1);
+  IdleTap tap;
+  host::ransac_pool_set_idle_work(pool, &tap.pending, idle_tap_fn, &tap);
+  int k = 0;
+  for (int r = 0; r < repeats; r++) {
+    tap.pending.fetch_add(idle_units, std::memory_order_acq_rel);  // (work arrives while the helpers spin)
+    k = host::find_fundamental_mat(p1, p2, n, thr, conf, status, pool);
+  }
+  const auto t0 = std::chrono::steady_clock::now();  // what is left is taken while the helpers idle (bounded wait)
+  while (tap.pending.load(std::memory_order_acquire) > 0 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2)) {}
+  host::ransac_pool_set_idle_work(pool, nullptr, nullptr, nullptr);  // (returns once nobody is inside the hook)
+  out3[0] = tap.calls.load();
+  out3[1] = tap.done.load();
+  out3[2] = (uint64_t)std::max(0, tap.pending.load());
+  host::ransac_pool_destroy(pool);
+  if (n_inliers) *n_inliers = k;
+  return 0;
+}
+
 int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, double* out3) {
   if (!cam || !out3) return ESVIO_FE_EINVAL;
   host::lift_projective(*cam, u, v, out3);

@@ -83,7 +83,7 @@ ABI_SYMBOLS = [
     "esvio_fe_plain_call_counters",
     "esvio_fe_mem_alloc", "esvio_fe_mem_free", "esvio_fe_mem_upload", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
-    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot", "esvio_fe_host_nullspace", "esvio_fe_host_stage_copy",
+    "esvio_fe_set_host_threads", "esvio_fe_find_fundamental_mat_mt", "esvio_fe_ransac_stats", "esvio_fe_host_hypot", "esvio_fe_host_nullspace", "esvio_fe_host_stage_copy", "esvio_fe_find_fundamental_mat_idle",
     "esvio_fe_get_time_surface", "esvio_fe_export_image",
     "esvio_fe_import_image", "esvio_fe_set_profiling",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats",
@@ -198,6 +198,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_latency_phase_name.argtypes = [i]
     L.esvio_fe_ransac_tail.argtypes = [vp, i]
     L.esvio_fe_find_fundamental_mat_held.argtypes = [vp, vp, i, d, d, i, i, vp, C.POINTER(C.c_int32)]
+    L.esvio_fe_find_fundamental_mat_idle.argtypes = [vp, vp, i, d, d, i, i, i, vp, C.POINTER(C.c_int32), vp]
     _lib = L
     return L
 
@@ -759,6 +760,23 @@ def find_fundamental_mat(p1, p2, thr=1.0, conf=0.99, threads=1, hold_mask=None):
     if rc:
         raise FrontendError("find_fundamental_mat rc=%d" % rc)
     return k.value, status
+
+
+def find_fundamental_mat_idle(p1, p2, thr=1.0, conf=0.99, threads=4, repeats=4, idle_units=64):
+    """test tap: findFundamentalMat on a helper pool whose helpers are handed other work between jobs (what the
+    host-batch staging does) -> (inliers, status, {idle_calls, idle_done, idle_left})"""
+    L = load_library()
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    n = p1.shape[0]
+    status = np.zeros(n, np.uint8)
+    k = C.c_int32(0)
+    out = (C.c_uint64 * 3)()
+    rc = L.esvio_fe_find_fundamental_mat_idle(_p(p1), _p(p2), n, thr, conf, threads, repeats, idle_units, _p(status),
+                                              C.byref(k), out)
+    if rc:
+        raise FrontendError("find_fundamental_mat_idle rc=%d" % rc)
+    return k.value, status, dict(idle_calls=int(out[0]), idle_done=int(out[1]), idle_left=int(out[2]))
 
 
 def lift_projective(cam, u, v):

@@ -171,6 +171,13 @@ int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, do
  * same status and count (esvio_fe_ransac_tail counts both cases).  threads >= 2. */
 int esvio_fe_find_fundamental_mat_held(const float* p1, const float* p2, int n, double thr, double conf,
                                        int threads, int hold_mask, uint8_t* status, int32_t* n_inliers);
+/* Test tap: the same while the pool's helpers have other work between jobs, the way the host-batch staging hands
+ * them chunks (fe_evstage.cpp): `repeats` calls, `idle_units` units of ~5 us arriving before each; status and
+ * count must equal esvio_fe_find_fundamental_mat's; out3 = {calls of the idle hook (a helper that is idle when the
+ * hook is registered calls it once then), units done, units left after a bounded wait (0)}.  threads >= 2. */
+int esvio_fe_find_fundamental_mat_idle(const float* p1, const float* p2, int n, double thr, double conf,
+                                       int threads, int repeats, int idle_units, uint8_t* status, int32_t* n_inliers,
+                                       uint64_t out3[3]);
 /* Test tap: the hypot inside that function's 7-point solver: cv::SVD's Jacobi rotations call hypot
  * unqualified inside namespace cv, which resolves to lapack.cpp's own a*sqrt(1+(b/a)^2) template, not
  * to libm's; IEEE operations only, so the result does not depend on the host's libm. */

@@ -165,6 +165,33 @@ def test_host_ransac_does_not_wait_for_a_helper_that_lost_its_cpu(oracle):
             assert max(tail["max_us"], tail["lmeds_max_us"]) > 0
 
 
+def test_ransac_helpers_with_other_work_between_jobs():
+    """The host-batch staging hands the spinning RANSAC helpers its chunks between jobs (and has every awake
+    helper call the hook once when it is registered: a thread's first HIP calls belong there, not into a
+    track call).  With units of other work arriving before every job the flags and the count stay those of
+    the sequential loop and all units get done."""
+    rng = np.random.default_rng(9)
+    K = np.array([[460, 0, 320], [0, 460, 240], [0, 0, 1.0]])
+    for trial in range(8):
+        n = int(rng.integers(15, 200)) if trial % 3 else int(rng.integers(8, 15))
+        X = rng.uniform(-1, 1, (n, 3)) * np.array([2, 1.5, 1]) + np.array([0, 0, 4.0])
+        t = rng.normal(0, 0.05, 3)
+        x = (K @ (X + t).T).T
+        p1 = (K @ X.T).T
+        p1 = (p1[:, :2] / p1[:, 2:]).astype(np.float32)
+        p2 = (x[:, :2] / x[:, 2:]).astype(np.float32) + rng.normal(0, 0.05, (n, 2)).astype(np.float32)
+        k = int(rng.uniform(0.0, 0.5) * n)
+        p2[:k] += rng.normal(0, 8, (k, 2)).astype(np.float32)
+        cnt_1, st_1 = FE.find_fundamental_mat(p1, p2, 1.0, 0.99)
+        for threads, units in ((2, 16), (4, 64), (4, 0)):
+            cnt, st, idle = FE.find_fundamental_mat_idle(p1, p2, 1.0, 0.99, threads=threads, repeats=5, idle_units=units)
+            assert cnt == cnt_1 and np.array_equal(st, st_1), (trial, n, threads, units)
+            assert idle["idle_left"] == 0 and idle["idle_done"] == 5 * units, (idle, threads, units)
+            assert idle["idle_calls"] >= idle["idle_done"], idle  # (+ the call at registration of every helper that was idle then)
+    L = FE.load_library()
+    assert L.esvio_fe_find_fundamental_mat_idle(None, None, 0, 1.0, 0.99, 1, 1, 0, None, None, None) == -1
+
+
 def test_header_is_plain_c(tmp_path):
     """include/esvio_fe.h is the drop-in boundary: it must compile as C99 (no C++ / HIP / torch types)
     and a C translation unit must link against the library's exports"""
