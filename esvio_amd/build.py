@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libesvio_fe.so")
 SOURCES = ["fe_kernels.hip", "fe_stages.cpp", "fe_track.cpp", "fe_image.cpp", "fe_api.cpp", "fe_host.cpp", "fe_evstage.cpp"]
-HEADERS = ["fe_kernels.h", "fe_host.h", "fe_ctx.h", "fe_internal.h", "fe_mc.h", os.path.join("..", "..", "include", "esvio_fe.h")]
+HEADERS = ["fe_kernels.h", "fe_host.h", "fe_ctx.h", "fe_internal.h", "fe_mc.h", os.path.join("..", "..", "include", "esvio_fe.h"),
+           os.path.join("..", "..", "include", "esvio_fe_test.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",          # keep mul+add separate: bit parity with the x86 reference build

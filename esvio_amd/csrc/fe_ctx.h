@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/esvio_fe.h"
+#include "../../include/esvio_fe_test.h"
 #include "fe_host.h"
 #include "fe_kernels.h"
 #include "fe_mc.h"

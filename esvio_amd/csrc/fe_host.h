@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/esvio_fe.h"
+#include "../../include/esvio_fe_test.h"
 
 namespace esvio {
 namespace host {

@@ -161,38 +161,6 @@ int esvio_fe_build_pyramid(esvio_fe_handle h, const uint8_t* img, int w, int hgt
  * (feature_tracker.cpp:935); host-side. Returns the inlier count in *n_inliers. */
 int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, double thr,
                                   double conf, uint8_t* status, int32_t* n_inliers);
-/* The same with `threads` - 1 helper threads solving / scoring the RANSAC iterations (a temporary
- * pool; test tap for esvio_fe_set_host_threads): status and count are those of the call above. */
-int esvio_fe_find_fundamental_mat_mt(const float* p1, const float* p2, int n, double thr,
-                                     double conf, int threads, uint8_t* status, int32_t* n_inliers);
-/* Test tap: the same with job buffers of the pool marked as still holding a helper (hold_mask bit 0 / 1:
- * buffer 0 / 1), as when a helper thread loses its CPU in the middle of a job: the call must not wait for
- * it — it takes the other buffer, or runs without the helpers when both are held — and must return the
- * same status and count (esvio_fe_ransac_tail counts both cases).  threads >= 2. */
-int esvio_fe_find_fundamental_mat_held(const float* p1, const float* p2, int n, double thr, double conf,
-                                       int threads, int hold_mask, uint8_t* status, int32_t* n_inliers);
-/* Test tap: the same while the pool's helpers have other work between jobs, the way the host-batch staging hands
- * them chunks (fe_evstage.cpp): `repeats` calls, `idle_units` units of ~5 us arriving before each; status and
- * count must equal esvio_fe_find_fundamental_mat's; out3 = {calls of the idle hook (a helper that is idle when the
- * hook is registered calls it once then), units done, units left after a bounded wait (0)}.  threads >= 2. */
-int esvio_fe_find_fundamental_mat_idle(const float* p1, const float* p2, int n, double thr, double conf,
-                                       int threads, int repeats, int idle_units, uint8_t* status, int32_t* n_inliers,
-                                       uint64_t out3[3]);
-/* Test tap: the hypot inside that function's 7-point solver: cv::SVD's Jacobi rotations call hypot
- * unqualified inside namespace cv, which resolves to lapack.cpp's own a*sqrt(1+(b/a)^2) template, not
- * to libm's; IEEE operations only, so the result does not depend on the host's libm. */
-int esvio_fe_host_hypot(const double* x, const double* y, int n, double* out);
-/* Test tap: the copy the staging threads move a chunk of a host-resident event batch with (pageable source ->
- * pinned buffer; streaming stores where dst is 16-byte aligned, memcpy otherwise and for the last < 64 bytes):
- * dst[0, len) = src[0, len), nothing else written.  No device involved. */
-int esvio_fe_host_stage_copy(void* dst, const void* src, size_t len);
-/* Test tap: the basis of the 7x9 epipolar system's null space that run7Point takes from
- * cv::SVDecomp(A, W, U, Vt, MODIFY_A + FULL_UV) (rows 7 and 8 of Vt; OpenCV calib3d/fundam.cpp, reached
- * from feature_tracker.cpp:935), for n systems of 63 doubles -> f12 = n x (f1[9] | f2[9]).  lanes = 0:
- * one system at a time; lanes != 0: side by side in vector lanes with the sweep's independent row pairs
- * scheduled together, as the RANSAC loop solves its hypotheses — both must give the same bits.
- * *redone (may be NULL) = systems the lane form handed back to the one-at-a-time routine. */
-int esvio_fe_host_nullspace(const double* systems, int n, int lanes, double* f12, int32_t* redone);
 /* Measurement tap: process-wide counters of that function since the last reset — out6 = {calls,
  * loop iterations, points, nanoseconds inside the calls} of its RANSAC branch (>= 15 points) and
  * {calls, nanoseconds} of its LMedS branch (8..14 points, what OpenCV runs below 15). */
@@ -403,26 +371,6 @@ int esvio_fe_mem_alloc(int space, size_t bytes, void** out);
 int esvio_fe_mem_free(int space, void* p);
 int esvio_fe_mem_upload(void* dst_device, const void* src_host, size_t bytes);
 
-/* ---- fault injection (tests) ----------------------------------------------------------- */
-/* Every device-side wait is bounded: a wave that gives up raises a host-visible flag and the call
- * either fails with ESVIO_FE_EINTERNAL (the SAE update's turn ticket and the radix sort's look-back:
- * the planes are then partially updated; esvio_fe_reset makes the handle usable again) or redoes the
- * launch the plain way (the speculative / chained temporal LK of replay mode: results unchanged).
- * esvio_fe_debug_inject makes the chosen waits expire the first time they would have to wait, for the
- * launches that follow (0: normal bounds again); ESVIO_FE_FAULT=<mask> in the environment does the
- * same from esvio_fe_create on.  esvio_fe_debug_counters: {speculative launches redone, chained
- * launches redone, chained launches made, chained launches used}. */
-#define ESVIO_FE_FAULT_TICKET 1
-#define ESVIO_FE_FAULT_LOOKBACK 2
-#define ESVIO_FE_FAULT_SPECULATIVE 4
-#define ESVIO_FE_FAULT_CHAINED 8
-int esvio_fe_debug_inject(esvio_fe_handle h, int mask);
-int esvio_fe_debug_counters(esvio_fe_handle h, uint64_t out4[4]);
-/* What the plain calls (nothing announced, not lazy: the reference node's pattern) did since create:
- * {plain calls, of them with the two cameras' SAE update + image on two streams, stereo LK launches
- * chained to the temporal one on the device, chained launches redone}. */
-int esvio_fe_plain_call_counters(esvio_fe_handle h, uint64_t out4[4]);
-
 /* ---- capacity ----------------------------------------------------------------------------- */
 /* Every event-proportional device buffer (partition scratch, candidate sets, staging lanes) grows on
  * demand, by a hipFree + hipMalloc inside the call that first needs more — a stall of 0.1-2 ms in the
@@ -457,14 +405,6 @@ typedef struct esvio_fe_latency {
 } esvio_fe_latency;
 int esvio_fe_latency_stats(esvio_fe_handle h, esvio_fe_latency* out, int reset);
 const char* esvio_fe_latency_phase_name(int i);
-/* Tail of the host RANSAC (process-wide, like esvio_fe_ransac_stats; reset together with it or here):
- * out6 = {slowest RANSAC call [ns], slowest LMedS call [ns], iterations the calling thread redid because
- * the helper that took them did not deliver, jobs the calling thread ran alone because helpers were
- * still inside both job buffers, jobs that took the other buffer because a helper was still inside
- * theirs (a helper that lost its CPU in the middle of a job), involuntary context switches of the helper
- * threads}. */
-int esvio_fe_ransac_tail(uint64_t out6[6], int reset);
-
 /* Per-kernel HIP-event timing on the handle's stream (off by default; when on, every launch is
  * bracketed by hipEventRecord and resolved lazily). */
 int esvio_fe_set_profiling(esvio_fe_handle h, int on);

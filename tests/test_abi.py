@@ -12,19 +12,33 @@ from esvio_amd import frontend as FE
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "esvio_fe.h")).read()
+def _declared_symbols(header="esvio_fe.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(esvio_fe_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree():
+    """two headers, two lists: the boundary (esvio_fe.h) and the test taps (esvio_fe_test.h) — disjoint"""
     assert _declared_symbols() == sorted(FE.ABI_SYMBOLS)
+    assert _declared_symbols("esvio_fe_test.h") == sorted(FE.TEST_SYMBOLS)
+    assert not set(FE.ABI_SYMBOLS) & set(FE.TEST_SYMBOLS)
+    # nothing that smells like a tap in the public header
+    assert not [s for s in FE.ABI_SYMBOLS if "_debug_" in s or "_host_" in s.replace("esvio_fe_set_host_threads", "")]
+
+
+def test_integration_md_covers_the_whole_public_header():
+    """INTEGRATION.md section 3 maps every entry point of include/esvio_fe.h to what it replaces"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 3."):doc.index("## 4.")]
+    missing = [s for s in FE.ABI_SYMBOLS if "`%s`" % s not in sec]
+    assert not [s for s in FE.TEST_SYMBOLS if "| `%s`" % s in sec]
+    assert not missing, missing
 
 
 def test_library_exports_every_declared_symbol():
     L = FE.load_library()
-    for s in _declared_symbols():
+    for s in _declared_symbols() + _declared_symbols("esvio_fe_test.h"):
         assert hasattr(L, s), s
     assert b"gfx950" in L.esvio_fe_version()
 
@@ -201,7 +215,7 @@ def test_header_is_plain_c(tmp_path):
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "t.c"
-    src.write_text('#include "esvio_fe.h"\n'
+    src.write_text('#include "esvio_fe.h"\n#include "esvio_fe_test.h"\n'
                    'int main(void) { esvio_fe_config c; esvio_fe_tracks t; esvio_fe_motion m; (void)c; (void)t; (void)m;\n'
                    '  return esvio_fe_kernel_count() > 0 && esvio_fe_version() != 0 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
