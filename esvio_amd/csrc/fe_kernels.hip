@@ -2080,6 +2080,7 @@ constexpr int kLkMargin = 6;
 constexpr int kLkRegW = 40;                              // staged bytes per row (10 dwords)
 constexpr int kLkRegH = kLkWin + 1 + 2 * kLkMargin;      // 34 rows
 constexpr int kLkRegDw = kLkRegW / 4 * kLkRegH;          // 340 dwords per wave
+constexpr int kLkRegStore = kLkRegDw + 4;                // (+ what an 8-column lane of the last row reads past it: unused bytes)
 
 // Exact wave64 sums of two per-lane integers with |v| < 2^28, result as float (one rounding, equal
 // to (float)(int64 sum)) in EVERY lane, VALU only (no readlane / scalar hop):
@@ -2118,7 +2119,7 @@ __device__ __forceinline__ RedLane red_lane(int lane) {
 }
 template <int CTRL>
 __device__ __forceinline__ float quad_bcast(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));  // (every lane has a source)
 }
 // Exact wave64 sums Sa, Sb of two per-lane integers (|v| < 2^28), each passed in with kRedSeed
 // (2^28) added so that the 8-lane sums carry a bias of 2^31; returns RN(Sa * 2^-20) and
@@ -2141,8 +2142,9 @@ __device__ __forceinline__ void wave_sum2_exact(int a, int b, const RedLane& rl,
   x = xor16_add(x);
   x = xor32_add(x);
   const float t = __fmaf_rn((float)x, rl.scale, rl.corr);  // exact
-  fa = quad_bcast<0x55>(t) + quad_bcast<0x00>(t);
-  fb = quad_bcast<0xFF>(t) + quad_bcast<0xAA>(t);
+  const float u = t + quad_bcast<0xB1>(t);  // lanes 0, 1 of a quad: a's lo + hi; lanes 2, 3: b's
+  fa = quad_bcast<0x00>(u);
+  fb = quad_bcast<0xAA>(u);
 }
 
 typedef short ss2 __attribute__((ext_vector_type(2)));
@@ -2208,13 +2210,20 @@ __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
 // products of columns x, x+4 of a step of 8 added in int32 first, converted, then one add), the
 // columns 16..20 go to a scalar accumulator; at the end scalar += horizontal sum of the lanes.
 // A float sum in a prescribed order is a chain of dependent adds, so it cannot be spread over the
-// wave: the lanes compute the per-pixel integer terms as before, put them into LDS, and a handful
-// of lanes walk their chains (the longest: 105 adds) while the rest idle.  About twice the
-// per-iteration time of the exact-sum mode.
-// Every chain takes five terms per window row (a vector lane four — or two pair sums — and zeros, the
-// tail its five columns), kept as floats in LDS, T[chain][row][8]: slots a chain does not use hold
-// +0.f (adding it is exact), so that all chain lanes run one loop in lock step — 105 dependent adds,
-// a row fetched with two LDS instructions while the previous one is added.
+// wave as it is: the pixel lanes compute the per-pixel integer terms, put them into LDS in chain
+// order, and walking lanes add them up in float (lk_float_sums_b below).
+// In this mode a lane owns EIGHT adjacent columns of its window row (runs 0..7, 8..15, 16..20 + three
+// columns that do not exist and contribute nothing), so both columns of every pmaddwd pair (x, x+4) sit
+// in one lane and the tail's five columns in another.
+//
+// A matrix (once per pyramid level): fifteen chains — type t = A11, A12, A22: vector lanes 4 t + k
+// (k = column mod 4, slot = column / 4, columns 0..15), tail 12 + t (columns 16..20).  Every chain takes
+// five terms per window row (a vector lane four and a zero, the tail its five columns), kept as floats in
+// LDS, T[chain][row][8]: slots a chain does not use hold +0.f (adding it is exact), so that all chain
+// lanes run one loop in lock step — 105 dependent adds, a row fetched with two LDS instructions while
+// the previous one is added.  The pixel lanes write their own products (< 2^24: exact in float) straight
+// into TA; the combination is tail + ((q0 + q2) + (q1 + q3)), v_reduce_sum's order, times FLT_SCALE.
+// (These sums grow monotonically past 2^24 on any textured patch, so there is nothing to guess here.)
 __device__ __forceinline__ float lk_chain_walk(const float* T, int chain) {
   const float4* row = (const float4*)(T + chain * kLkWin * 8);
   float acc = 0.f;
@@ -2236,20 +2245,17 @@ __device__ __forceinline__ float lk_chain_walk(const float* T, int chain) {
   return acc;
 }
 
-// A matrix (once per pyramid level): fifteen chains — type t = A11, A12, A22: vector lanes 4 t + k
-// (k = column mod 4, slot = column / 4, columns 0..15), tail 12 + t (columns 16..20).  The pixel
-// lanes write their own products (< 2^24: exact in float) straight into TA; the combination is
-// tail + ((q0 + q2) + (q1 + q3)), v_reduce_sum's order, times FLT_SCALE.
 constexpr int kLkChainsA = 15;
 constexpr int kLkTermWordsA = kLkChainsA * kLkWin * 8;
 
+template <int NP>
 __device__ __forceinline__ void lk_float_sums_A(float* TA, bool on, int row, int x0, const int* pIx, const int* pIy,
                                                 int lane, float& A11, float& A12, float& A22) {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous level's readers)
-  if (on) {
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-      const int x = x0 + k;
+  for (int k = 0; k < NP; k++) {
+    const int x = x0 + k;
+    if (on && x < kLkWin) {
       const bool vec = x < 16;
       const int base = ((vec ? (x & 3) : 12) * kLkWin + row) * 8 + (vec ? x >> 2 : x - 16);
       const int step = (vec ? 4 : 1) * kLkWin * 8;  // from one type's chain to the next type's
@@ -2275,98 +2281,114 @@ __device__ __forceinline__ void lk_float_sums_A(float* TA, bool on, int row, int
 
 // The b vector is summed once per LK iteration.  Ten chains: vector chains c = 4 comp + k (comp 0: b1,
 // 1: b2; k = column mod 4) take per window row the pair sums of columns (k, k + 4) and (8 + k, 12 + k) —
-// added exactly in int32 (pmaddwd), converted, then ONE float add each, 42 terms —; the tails 8 + comp take
-// columns 16..20 one by one, 105 terms.  A float sum in a prescribed order is a chain of dependent adds;
-// round 3 had ten lanes walk their chains row by row out of LDS: 0.73 us of the 1.23 us iteration
-// (tools/lk_iter_probe.py), every row paying the LDS latency again.  Now:
-//  * the pixel lanes write the INTEGER terms themselves (a lane owns 7 adjacent columns — run 0: 0..6,
-//    run 1: 7..13, run 2: 14..20 — so a pair's two columns sit in one lane except (3, 7), (10, 14),
-//    (11, 15), whose right-hand column is the right neighbour's first / second pixel: one lane shift)
-//    into a table in CHAIN order, cut into segments of 16 words: a vector chain = 3 segments of 7 rows,
-//    a tail = 7 segments of 3 rows (the words a segment does not use stay 0);
-//  * one lane per segment (38 of them) reads its 16 words at once, and they all walk at the same time,
-//    each from a GUESS of what the chain has summed to before its segment: round 1 guesses the exact
-//    integer sum of the earlier segments (three masked lane shifts) — which IS the float chain's value as
-//    long as no add before it rounded, i.e. while the running sum stays below 2^24: 87 % of the
-//    iterations on the bench stream for ALL ten chains (counted with the oracle); then every segment
-//    compares its guess with its left neighbour's end value and, if one differs, all walk again from the
-//    corrected starts.  Segment 0 always starts right, so after r rounds the first r segments are final:
-//    at most 7 rounds = the sequential walk's 105 adds, one round of 16 in the usual case.  The result is
-//    the sequential chain's for any input — the guess only decides how many rounds it takes.
-constexpr int kLkSegWords = 16, kLkVecSegs = 3, kLkTailSegs = 7;
-constexpr int kLkSegStride = 20;  // (16 would put every walking lane's ds_read_b128 on the same four LDS banks)
-constexpr int kLkVecWords = kLkVecSegs * kLkSegStride;     // per vector chain
-constexpr int kLkTailBase = 8 * kLkVecWords;
-constexpr int kLkTailWords = kLkTailSegs * kLkSegStride;   // per tail
-constexpr int kLkTermWords = kLkTailBase + 2 * kLkTailWords;
+// added exactly in int32 (pmaddwd), converted, then ONE float add each, 42 terms —; the tails (one per
+// comp) take columns 16..20 one by one, 105 terms.  Round 3 had ten lanes walk their chains row by row out
+// of LDS (0.73 us of a 1.23 us iteration), round 4 38 lanes walking 16-word segments (0.70 us per
+// iteration).  Now:
+//  * the pixel lanes write the INTEGER terms into a table in CHAIN order, cut into segments: a vector
+//    chain = 4 segments of <= 11 terms, a tail = 12 segments of <= 9 terms, each stored in 12 words (the
+//    words a segment does not use stay 0).  Every pixel lane writes five (b1, b2) word pairs with five
+//    ds_write2_b32 at per-lane addresses — lanes of runs 0 / 1 their four pair sums (the fifth pair goes
+//    to a dump word of the lane), lanes of run 2 their five tail products — so one instruction stream
+//    serves both kinds of lane: the (comp 0, k) -> (comp 1, k) distance of the vector chains equals the
+//    tail's comp 0 -> comp 1 distance (kF32CompStride);
+//  * one lane per segment — ALL 64 lanes minus 8: row 0 of the wave = tail b1 (segments 0..11), rows 1 / 2
+//    = vector chains of b1 / b2 (lane = 4 g + k inside its row: segment g of chain k), row 3 = tail b2 —
+//    reads its 12 words (3 ds_read_b128) and they all walk at the same time, each from a GUESS of what
+//    the chain has summed to before its segment: the exact integer sum of the earlier segments (a DPP
+//    scan inside the row: row_shr 1/2/4/8 for the tails, row_shr 4/8 under bank masks for the vector
+//    rows) — which IS the float chain's value as long as no add before it rounded, i.e. while the
+//    running sum stays below 2^24: 87 % of the iterations on the bench stream for ALL ten chains
+//    (counted with the oracle); then every segment compares its guess with its left neighbour's end
+//    value and, if one differs, all walk again from the corrected starts.  Segment 0 always starts right,
+//    so after r rounds the first r segments are final: at most 12 rounds = the sequential walk, one round
+//    of 11 adds in the usual case.  The result is the sequential chain's for any input — the guess only
+//    decides how many rounds it takes;
+//  * the four vector chains of a comp end in one quad ((k0 + k2) + (k1 + k3) = two quad_perm adds).
+constexpr int kF32SegStore = 12;
+constexpr int kF32VecSegs = 4, kF32VecTerms = 11;    // 4 x 11 >= 42
+constexpr int kF32TailSegs = 12, kF32TailTerms = 9;  // 12 x 9 >= 105
+constexpr int kF32VecWords = kF32VecSegs * kF32SegStore;                // 48 words per vector chain
+constexpr int kF32CompStride = 4 * kF32VecWords;                        // 192
+constexpr int kF32TailBase = 8 * kF32VecWords;                          // 384: tail b1; tail b2 at + kF32CompStride
+constexpr int kF32ZeroSeg = kF32TailBase + kF32TailSegs * kF32SegStore;  // 528: twelve words nobody writes
+constexpr int kF32Dump = kF32TailBase + kF32CompStride + kF32TailSegs * kF32SegStore;  // 720: one word per lane (+ kF32CompStride)
+constexpr int kF32TermWords = kF32Dump + kF32CompStride + 64;           // 976
+static_assert(kF32ZeroSeg + kF32SegStore <= kF32TailBase + kF32CompStride, "zero segment inside tail b1's padding");
+constexpr unsigned long long kF32Walkers = 0x0FFFFFFFFFFF0FFFull;       // lanes 0..11, 16..47, 48..59
 
 struct LkLaneF32 {  // per-lane constants of the float-order sums
-  int wbase;        // pixel lane: word its (row, run) writes from (runs 0 / 1: + 48 per chain; run 2: the tail segment)
-  int run;
-  int rbase;        // walking lane: its segment's first word
-  int g;            // ... its segment's number inside its chain
-  bool walker;
+  uint32_t wb[5];   // byte offsets of the five (b1, b2) word pairs this pixel lane writes
+  uint32_t rb;      // byte offset of the segment this lane walks
+  bool run2;        // pixel lane of columns 16..20
 };
 __device__ __forceinline__ LkLaneF32 lk_lane_f32(int lane) {
   LkLaneF32 r;
   const int row = lane < 63 ? lane / 3 : 0;
-  r.run = lane < 63 ? lane - row * 3 : 3;
-  r.wbase = r.run == 2 ? kLkTailBase + (row / 3) * kLkSegStride + (row % 3) * 5
-                       : (row / 7) * kLkSegStride + (row % 7) * 2 + (r.run == 1 ? 1 : 0);
-  if (lane < 16) {  // tails: lanes 0..6 (b1), 8..14 (b2)
-    r.g = lane & 7;
-    r.walker = r.g < kLkTailSegs;
-    r.rbase = kLkTailBase + (lane >> 3) * kLkTailWords + r.g * kLkSegStride;
-  } else if (lane < 48) {  // vector chain c: lanes 16 + 4 c .. + 2
-    r.g = (lane - 16) & 3;
-    r.walker = r.g < kLkVecSegs;
-    r.rbase = ((lane - 16) >> 2) * kLkVecWords + r.g * kLkSegStride;
-  } else {
-    r.g = 0;
-    r.walker = false;
-    r.rbase = 0;
+  const int run = lane < 63 ? lane - row * 3 : 3;
+  r.run2 = run == 2;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    int w = kF32Dump + lane;
+    if (run < 2 && j < 4) {
+      const int idx = 2 * row + run;
+      w = j * kF32VecWords + (idx / kF32VecTerms) * kF32SegStore + idx % kF32VecTerms;
+    } else if (run == 2) {
+      const int idx = 5 * row + j;
+      w = kF32TailBase + (idx / kF32TailTerms) * kF32SegStore + idx % kF32TailTerms;
+    }
+    r.wb[j] = (uint32_t)w * 4u;
   }
-  if (!r.walker) r.rbase = 0;
+  const int wrow = lane >> 4, l16 = lane & 15;
+  int rw = kF32ZeroSeg;
+  if (wrow == 0 || wrow == 3) {
+    if (l16 < kF32TailSegs) rw = kF32TailBase + (wrow == 3 ? kF32CompStride : 0) + l16 * kF32SegStore;
+  } else {
+    rw = ((wrow - 1) * 4 + (l16 & 3)) * kF32VecWords + (l16 >> 2) * kF32SegStore;
+  }
+  r.rb = (uint32_t)rw * 4u;
   return r;
 }
-template <int CTRL>
-__device__ __forceinline__ int dpp_mov(int v) {  // (lanes without a source get 0)
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+// v (+)= the value CTRL brings in, in the rows / banks the masks enable; everywhere else (and in lanes
+// CTRL has no source lane for) v stays
+template <int CTRL, int ROWS, int BANKS>
+__device__ __forceinline__ int dpp_add_masked(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, BANKS, false);
 }
 
-__device__ __forceinline__ void lk_float_sums_b(const int (&px)[7], const int (&py)[7], int* Ti, const LkLaneF32& ln,
-                                                float& b1, float& b2) {
+typedef __attribute__((address_space(3))) int lds_int;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) i32x4 lds_int4;
 
-  const int nx0 = dpp_mov<0x130>(px[0]), nx1 = dpp_mov<0x130>(px[1]);  // wave_shl:1: the right neighbour's
-  const int ny0 = dpp_mov<0x130>(py[0]), ny1 = dpp_mov<0x130>(py[1]);
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous iteration's walkers have read Ti)
-  int* const d = Ti + ln.wbase;
-  if (ln.run == 2) {
+// px / py: the lane's eight per-pixel products diff * Ix, diff * Iy (exact in int32; zero for columns that
+// do not exist); tb: LDS byte address of the wave's term table
+__device__ __forceinline__ void lk_float_sums_b(const int (&px)[8], const int (&py)[8], uint32_t tb, const LkLaneF32& ln,
+                                                float& b1, float& b2) {
+  int vx[5], vy[5];
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-      d[i] = px[2 + i];
-      d[kLkTailWords + i] = py[2 + i];
-    }
-  } else if (ln.run < 2) {
-    const bool r1 = ln.run == 1;
-    const int ax[4] = {r1 ? px[1] : px[0], r1 ? px[2] : px[1], r1 ? px[3] : px[2], r1 ? px[4] : px[3]};
-    const int bx[4] = {r1 ? px[5] : px[4], r1 ? px[6] : px[5], r1 ? nx0 : px[6], r1 ? nx1 : nx0};
-    const int ay[4] = {r1 ? py[1] : py[0], r1 ? py[2] : py[1], r1 ? py[3] : py[2], r1 ? py[4] : py[3]};
-    const int by[4] = {r1 ? py[5] : py[4], r1 ? py[6] : py[5], r1 ? ny0 : py[6], r1 ? ny1 : ny0};
+  for (int j = 0; j < 4; j++) {
+    vx[j] = px[j] + px[j + 4];  // pmaddwd's int32 pair sum (run 2: px[5..7] = 0, so these ARE its products 1..3)
+    vy[j] = py[j] + py[j + 4];
+  }
+  vx[0] = ln.run2 ? px[0] : vx[0];
+  vy[0] = ln.run2 ? py[0] : vy[0];
+  vx[4] = px[4];
+  vy[4] = py[4];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous iteration's walkers have read)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      d[i * kLkVecWords] = ax[i] + bx[i];  // pmaddwd's int32 pair sum
-      d[(4 + i) * kLkVecWords] = ay[i] + by[i];
-    }
+  for (int j = 0; j < 5; j++) {
+    lds_int* d = (lds_int*)(uintptr_t)(tb + ln.wb[j]);
+    d[0] = vx[j];
+    d[kF32CompStride] = vy[j];
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
   // ---- the walking lanes
-  int t[kLkSegWords];
+  int t[kF32SegStore];
   {
-    const int4* src = (const int4*)(Ti + ln.rbase);
+    const lds_int4* src = (const lds_int4*)(uintptr_t)(tb + ln.rb);
 #pragma unroll
-    for (int q = 0; q < kLkSegWords / 4; q++) {
-      const int4 v = src[q];
+    for (int q = 0; q < kF32SegStore / 4; q++) {
+      const i32x4 v = src[q];
       t[4 * q] = v.x;
       t[4 * q + 1] = v.y;
       t[4 * q + 2] = v.z;
@@ -2374,55 +2396,76 @@ __device__ __forceinline__ void lk_float_sums_b(const int (&px)[7], const int (&
     }
   }
   int isum = 0;
-  float f[kLkSegWords];
+  float f[kF32VecTerms];
 #pragma unroll
-  for (int i = 0; i < kLkSegWords; i++) {
+  for (int i = 0; i < kF32VecTerms; i++) {  // (word 11 of a segment is never used)
     isum += t[i];
     f[i] = (float)t[i];  // v_cvt_f32_i32 of the int32 term
   }
-  // what the chain's earlier segments add up to, exactly (shifts stay inside a chain's lanes: g >= distance)
-  // (the shifts run under full exec — a DPP read of a lane that a branch has switched off returns 0 — and
-  // are masked afterwards)
-  int x = isum;
-  const int m1 = ln.g >= 1 ? -1 : 0, m2 = ln.g >= 2 ? -1 : 0, m4 = ln.g >= 4 ? -1 : 0;
-  x += dpp_mov<0x111>(x) & m1;  // row_shr:1
-  x += dpp_mov<0x112>(x) & m2;  // row_shr:2
-  x += dpp_mov<0x114>(x) & m4;  // row_shr:4
-  float guess = (float)(x - isum), end;
+  // what the chain's earlier segments add up to, exactly: inclusive scans inside the rows, minus the own sum
+  int xa = isum, xb = isum;
+  xa = dpp_add_masked<0x111, 0x9, 0xf>(xa);  // row_shr:1, rows 0 and 3 (tails)
+  xb = dpp_add_masked<0x114, 0x6, 0xe>(xb);  // row_shr:4, rows 1 and 2, segments >= 1 (vector chains)
+  xa = dpp_add_masked<0x112, 0x9, 0xf>(xa);
+  xb = dpp_add_masked<0x118, 0x6, 0xc>(xb);  // row_shr:8, segments >= 2
+  xa = dpp_add_masked<0x114, 0x9, 0xf>(xa);
+  xa = dpp_add_masked<0x118, 0x9, 0xf>(xa);
+  // rows 1 / 2 never changed xa, rows 0 / 3 never changed xb: (xa - isum) + (xb - isum) is the lane's own row's
+  float guess = (float)(xa + xb - 2 * isum), end;
   for (;;) {
     float acc = guess;
 #pragma unroll
-    for (int i = 0; i < kLkSegWords; i++) acc = __fadd_rn(acc, f[i]);
+    for (int i = 0; i < kF32VecTerms; i++) acc = __fadd_rn(acc, f[i]);
     end = acc;
-    const float start = __int_as_float(dpp_mov<0x111>(__float_as_int(acc)) & m1);  // the left neighbour's end; +0.f for segment 0
-    const bool changed = ln.walker && __float_as_uint(start) != __float_as_uint(guess);
-    guess = start;
-    if (!wave_any(changed)) break;
+    // the left neighbour's end; +0.f for segment 0
+    int s = __builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0x9, 0xf, false);
+    s = __builtin_amdgcn_update_dpp(s, __float_as_int(acc), 0x114, 0x6, 0xe, false);
+    const lanemask_t changed = bal((uint32_t)s != __float_as_uint(guess)) & kF32Walkers;
+    guess = __int_as_float(s);
+    if (!changed) break;
   }
-  // chain ends: tails in lanes 6 / 14, vector chain c in lane 18 + 4 c
+  // chain ends: tails in lanes 11 / 59, the four vector chains of a comp in lanes 28..31 / 44..47
+  int e = __float_as_int(end);
+  float q = __fadd_rn(end, __int_as_float(__builtin_amdgcn_update_dpp(0, e, 0x4E, 0xf, 0xf, false)));  // k0 + k2 | k1 + k3
+  q = __fadd_rn(q, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), 0xB1, 0xf, 0xf, false)));
+  const int qi = __float_as_int(q);
   const float kScale = 1.f / (float)(1 << 20);
-  const int e = __float_as_int(end);
-  float out[2];
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    const float k0 = __int_as_float(__builtin_amdgcn_readlane(e, 18 + 16 * c)),
-                k1 = __int_as_float(__builtin_amdgcn_readlane(e, 22 + 16 * c)),
-                k2 = __int_as_float(__builtin_amdgcn_readlane(e, 26 + 16 * c)),
-                k3 = __int_as_float(__builtin_amdgcn_readlane(e, 30 + 16 * c)),
-                tail = __int_as_float(__builtin_amdgcn_readlane(e, 6 + 8 * c));
-    const float s0 = __fadd_rn(k0, k2), s2 = __fadd_rn(k1, k3);
-    out[c] = __fmul_rn(__fadd_rn(tail, __fadd_rn(__fadd_rn(s0, 0.f), __fadd_rn(s2, 0.f))), kScale);
-  }
-  b1 = out[0];
-  b2 = out[1];
+  const float t1 = __int_as_float(__builtin_amdgcn_readlane(e, 11)), t2 = __int_as_float(__builtin_amdgcn_readlane(e, 59));
+  const float v1 = __int_as_float(__builtin_amdgcn_readlane(qi, 28)), v2 = __int_as_float(__builtin_amdgcn_readlane(qi, 44));
+  // fb += (s0 + 0.f) + (s2 + 0.f): the two + 0.f only turn a -0.f into +0.f, and no sum here is -0.f (every
+  // chain starts from +0.f and adds converted integers, none of which is -0.f)
+  b1 = __fmul_rn(__fadd_rn(t1, v1), kScale);
+  b2 = __fmul_rn(__fadd_rn(t2, v2), kScale);
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+
+// v_dot2_i32_i16 with the accumulator seed in an SGPR (VOP3P form): the compiler's own choice for a constant
+// seed is v_mov + v_dot2c (the VOP2 form accumulates in place), one more instruction per pixel on a wave
+// that issues one instruction every four cycles whatever it is
+// oy * kLkRegW + ox as ONE v_mad_u32_u24 (left to itself the compiler re-associates the window offsets and
+// ends up with a quarter-rate v_mul_lo_u32)
+__device__ __forceinline__ uint32_t mad_u24_regw(uint32_t oy, uint32_t ox) {
+  uint32_t r;
+  static_assert(kLkRegW <= 64, "inline constant");
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(oy), "n"(kLkRegW), "v"(ox));
+  return r;
+}
+__device__ __forceinline__ int sdot2_seed(uint32_t a, uint32_t b, int seed) {
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(seed));
+  return r;
 }
 
 // one calcOpticalFlowPyrLK call for one point; returns nextPts[pt] and status
 template <int ACCUM>
 __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, const float2 init,
-                                         uint32_t* regJ, int* acc_t, float* acc_ta, const LkLaneF32* lnf, int lane,
+                                         uint32_t* regJ, uint32_t term_base, float* acc_ta, const LkLaneF32* lnf, int lane,
                                          float2& np_out, int& st_out) {
-  constexpr int WIN = kLkWin, NP = 7, NPP = (NP + 1) / 2, NL = kMaxLevels;
+  // pixels per lane: the exact mode's lanes own 7 adjacent columns (3 x 7 = 21); the float-order mode's 8
+  // (0..7, 8..15, 16..23), see lk_float_sums_b
+  constexpr int WIN = kLkWin, NP = ACCUM == 2 ? 8 : 7, NPP = 4, NL = kMaxLevels;
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
   const RedLane rl = red_lane(lane);
@@ -2434,8 +2477,8 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   // ---- phase A: the previous-image side of EVERY level depends only on prevPts, so all
   // levels' patches (I, Ix, Iy in registers) and 2x2 matrices are built up front with the
   // global loads of all levels in flight together (one memory round trip instead of one per level)
-  // the patch is kept as packed int16 pairs {px 2m, px 2m+1} (the 8th half is zero), the form the
-  // v_dot2 / v_pk iteration below consumes
+  // the patch is kept as packed int16 pairs {px 2m, px 2m+1} (halves of columns that do not exist are
+  // zero), the form the v_dot2 / v_pk iteration below consumes
   uint32_t pIp[NL][NPP], pIxp[NL][NPP], pIyp[NL][NPP];
   bool win_ok[NL], eig_ok[NL];
   float A11[NL], A12[NL], A22[NL], Dinv[NL];
@@ -2477,8 +2520,9 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
     for (int L = 0; L < NL; L++) {
       if (L > c.max_level) continue;
       int sA11 = kRedSeed, sA12 = kRedSeed, sA22 = kRedSeed;  // + 7 terms <= 2^24 each
-      int pI[NP + 1], pIx[NP + 1], pIy[NP + 1];
-      pI[NP] = pIx[NP] = pIy[NP] = 0;
+      int pI[2 * NPP], pIx[2 * NPP], pIy[2 * NPP];
+#pragma unroll
+      for (int k = NP; k < 2 * NPP; k++) pI[k] = pIx[k] = pIy[k] = 0;
 #pragma unroll
       for (int k = 0; k < NP; k++) {
         const int ival = CV_DESCALE(__mul24(t0[L][k], w00[L]) + __mul24(t0[L][k + 1], w01[L]) +
@@ -2491,12 +2535,15 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         const int iyval = CV_DESCALE(__mul24(g0[L][k] >> 16, w00[L]) + __mul24(g0[L][k + 1] >> 16, w01[L]) +
                                          __mul24(g1[L][k] >> 16, w10[L]) + __mul24(g1[L][k + 1] >> 16, w11[L]),
                                      W_BITS);
+        const bool col_ok = on && (NP * 3 == WIN || x0 + k < WIN);  // (float-order mode: columns 21..23 of run 2)
         pI[k] = (int)(int16_t)ival;
-        pIx[k] = on ? (int)(int16_t)ixval : 0;
-        pIy[k] = on ? (int)(int16_t)iyval : 0;
-        sA11 += __mul24(pIx[k], pIx[k]);
-        sA12 += __mul24(pIx[k], pIy[k]);
-        sA22 += __mul24(pIy[k], pIy[k]);
+        pIx[k] = col_ok ? (int)(int16_t)ixval : 0;
+        pIy[k] = col_ok ? (int)(int16_t)iyval : 0;
+        if (ACCUM != 2) {
+          sA11 += __mul24(pIx[k], pIx[k]);
+          sA12 += __mul24(pIx[k], pIy[k]);
+          sA22 += __mul24(pIy[k], pIy[k]);
+        }
       }
 #pragma unroll
       for (int m = 0; m < NPP; m++) {
@@ -2505,7 +2552,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         pIyp[L][m] = pack16(pIy[2 * m], pIy[2 * m + 1]);
       }
       if (ACCUM == 2) {
-        lk_float_sums_A(acc_ta, on, row, x0, pIx, pIy, lane, A11[L], A12[L], A22[L]);
+        lk_float_sums_A<NP>(acc_ta, on, row, x0, pIx, pIy, lane, A11[L], A12[L], A22[L]);
       } else {
         float fdummy;
         wave_sum2_exact(sA11, sA12, rl, A11[L], A12[L]);  // already scaled by FLT_SCALE = 2^-20
@@ -2522,6 +2569,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
 
   // ---- phase B: coarse-to-fine iterations
   const float eps_lo = (float)(c.eps2 * (1.0 - 0x1p-20)), eps_hi = (float)(c.eps2 * (1.0 + 0x1p-20));
+  const uint32_t regJ_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)regJ;  // LDS byte address
   float2 np = (c.flags & 4) ? init : make_float2(0.f, 0.f);  // nextPts[ptidx]
   int st = 1;
 #pragma unroll
@@ -2549,123 +2597,180 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       if (L == 0) st = 0;
       continue;
     }
-    nextX -= halfWin;
-    nextY -= halfWin;
-    // stage the search region for the initial window right away
-    int rx0, ry0;
-    {
-      uint32_t reg[(kLkRegDw + 63) / 64];
-      lk_region_load(J, stride, rows, (int)floorf(nextX), (int)floorf(nextY), lane, rx0, ry0, reg);
-      lk_region_store(regJ, lane, reg);
+    // The iteration, shaped for a lone wave (every instruction — scalar ones too — costs an issue slot of
+    // four cycles): ONE loop with ONE exit test at its bottom.  The bottom of iteration j already has the
+    // next window position, so it floors it, takes its offsets (ox, oy) inside the part of the staged
+    // region that is also inside the image — one unsigned compare per axis covers OpenCV's "window left
+    // the image" break and the re-staging — and folds that into the same exit mask as the convergence
+    // pre-test, the oscillation test and the iteration count.  What a stop means is sorted out after the
+    // loop, in OpenCV's order (converged, oscillating, count, outside), and the loop is re-entered after a
+    // re-staging or an fp64 tie-break that said "not converged".
+    f2 nxt = {nextX - halfWin, nextY - halfWin};
+    f2 fl = {floorf(nxt.x), floorf(nxt.y)};
+    int inx = (int)fl.x, iny = (int)fl.y;
+    f2 d = {0.f, 0.f}, prevD = {__builtin_inff(), __builtin_inff()};  // (j == 0: |d + inf| <= 0.01 cannot hold)
+    int j = 0;
+    bool level_done = c.max_count <= 0;  // (a TermCriteria without iterations: the level passes its start on)
+    if (wave_any(inx < -WIN || inx >= cols || iny < -WIN || iny >= rows)) {  // iteration 0's own check
+      if (L == 0) st = 0;
+      level_done = true;
     }
-    int cbo = lane_bo - rx0 - ry0 * kLkRegW;  // window origin (x,y) -> this lane's byte in regJ
-    float prevDx = 0.f, prevDy = 0.f;
-    for (int j = 0; j < c.max_count; j++) {
-      const float flX = floorf(nextX), flY = floorf(nextY);
-      const int inextX = (int)flX, inextY = (int)flY;
-      const int offx = inextX - rx0, offy = inextY - ry0;
-      const lanemask_t outside = bal((unsigned)(inextX + WIN) >= (unsigned)(cols + WIN)) |
-                                 bal((unsigned)(inextY + WIN) >= (unsigned)(rows + WIN));
-      const lanemask_t drifted = bal((unsigned)offx > (unsigned)(kLkRegW - (WIN + 1))) |
-                                 bal((unsigned)offy > (unsigned)(kLkRegH - (WIN + 1)));
-      if (__builtin_expect((outside | drifted) != 0, 0)) {  // one rarely taken branch for both
-        if (outside) {
-          if (L == 0) st = 0;
+    while (!level_done) {
+      // stage the search region around the current window: 34 x 40 B, dword-aligned origin
+      int rx0, ry0;
+      {
+        uint32_t reg[(kLkRegDw + 63) / 64];
+        lk_region_load(J, stride, rows, inx, iny, lane, rx0, ry0, reg);
+        lk_region_store(regJ, lane, reg);
+      }
+      // window origins the region serves AND the image allows: [lox, lox + rngx] x [loy, loy + rngy]
+      const int lox = max(rx0, -WIN), loy = max(ry0, -WIN);
+      const uint32_t rngx = (uint32_t)(min(rx0 + (kLkRegW - (WIN + 1)), cols - 1) - lox);
+      const uint32_t rngy = (uint32_t)(min(ry0 + (kLkRegH - (WIN + 1)), rows - 1) - loy);
+      // LDS byte address of this lane's first tap for the window at (lox, loy)
+      const uint32_t cbo = regJ_b + (uint32_t)(lane_bo + (lox - rx0) + (loy - ry0) * kLkRegW);
+      uint32_t ox = (uint32_t)(inx - lox), oy = (uint32_t)(iny - loy);
+      float d2 = 0.f;
+      f2 osum = {0.f, 0.f};
+      bool restage = false;
+      for (;;) {  // re-entered without re-staging after an undecided tie-break
+        for (;;) {
+          // bilinear weights: rint(w * 2^14) for w in [0,1] is the low half of the bit pattern of
+          // fma(w, 2^14, 2^23) (one RNE rounding to an integer), which v_perm packs straight into
+          // the int16 pairs {iw00,iw01} {iw10,iw11}
+          const f2 fr = nxt - fl, ofr = 1.f - fr;  // {fa, fb}, {1 - fa, 1 - fb}
+          const float kMagic = 8388608.f, kW = (float)(1 << W_BITS);
+          const f2 cross = fr * f2{ofr.y, ofr.x};  // {fa * ofb, fb * ofa}: one v_pk_mul_f32 (op_sel swaps the halves)
+          const f2 bc = __builtin_elementwise_fma(cross, f2{kW, kW}, f2{kMagic, kMagic});  // v_pk_fma_f32: one rounding each
+          const uint32_t b00 = __float_as_uint(__fmaf_rn(ofr.x * ofr.y, kW, kMagic));
+          const uint32_t b01 = __float_as_uint(bc.x);
+          const uint32_t b10 = __float_as_uint(bc.y);
+          const uint32_t iw11 = ((1u << W_BITS) + 3u * 0x4B000000u) - (b00 + b01 + b10);
+          const uint32_t W0 = __builtin_amdgcn_perm(b01, b00, 0x05040100u);
+          const uint32_t W1 = __builtin_amdgcn_perm(iw11, b10, 0x05040100u);
+          // NP + 1 bytes of two consecutive staged rows: 3 aligned dwords per row + funnel shifts
+          // (v_alignbyte_b32 takes the byte count from the low two bits of its third operand)
+          const uint32_t bo = mad_u24_regw(oy, ox) + cbo;
+          lds_cu32* rp = (lds_cu32*)(uintptr_t)(bo & ~3u);
+          const uint32_t a0 = rp[0], a1 = rp[1], a2 = rp[2];
+          const uint32_t c0 = rp[kLkRegW / 4], c1 = rp[kLkRegW / 4 + 1], c2 = rp[kLkRegW / 4 + 2];
+          uint32_t w0[3], w1[3];
+          w0[0] = __builtin_amdgcn_alignbyte(a1, a0, bo);
+          w0[1] = __builtin_amdgcn_alignbyte(a2, a1, bo);
+          w1[0] = __builtin_amdgcn_alignbyte(c1, c0, bo);
+          w1[1] = __builtin_amdgcn_alignbyte(c2, c1, bo);
+          if (NP == 8) {  // the ninth byte
+            w0[2] = __builtin_amdgcn_alignbyte(a2, a2, bo);
+            w1[2] = __builtin_amdgcn_alignbyte(c2, c2, bo);
+          }
+          // per pixel: the two horizontally adjacent bytes of each row as an int16 pair (v_perm_b32)
+          // against the packed weight pairs (v_dot2_i32_i16), rounding constant as the accumulator seed
+          uint32_t t[2 * NPP];
+#pragma unroll
+          for (int k = 0; k < NP; k++) {
+            uint32_t p0, p1;
+            if (k < 7) {
+              const uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
+              p0 = __builtin_amdgcn_perm(w0[1], w0[0], sel);
+              p1 = __builtin_amdgcn_perm(w1[1], w1[0], sel);
+            } else {
+              p0 = __builtin_amdgcn_perm(w0[2], w0[1], 0x0c040c03u);
+              p1 = __builtin_amdgcn_perm(w1[2], w1[1], 0x0c040c03u);
+            }
+            t[k] = (uint32_t)sdot2(p1, W1, sdot2_seed(p0, W0, 1 << (W_BITS - 5 - 1)));  // in [1, 2^22]
+          }
+#pragma unroll
+          for (int k = NP; k < 2 * NPP; k++) t[k] = 0;
+          // CV_DESCALE(.., 9) of two pixels at once: bytes 1..2 of each sum, packed shift by one more
+          // bit, packed subtract of the patch, dot with the packed derivatives
+          float b1, b2;
+          if (ACCUM == 2) {
+            // the per-pixel products diff * Ix, diff * Iy (exact in int32) -> the float chains
+            int px[2 * NPP], py[2 * NPP];
+#pragma unroll
+            for (int m = 0; m < NPP; m++) {
+              const uint32_t hi8 = __builtin_amdgcn_perm(t[2 * m + 1], t[2 * m], 0x06050201u);
+              const us2 val = __builtin_bit_cast(us2, hi8) >> (unsigned short)1;
+              const ss2 diff = __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]);
+              const ss2 ix = __builtin_bit_cast(ss2, pIxp[L][m]), iy = __builtin_bit_cast(ss2, pIyp[L][m]);
+              px[2 * m] = (int)diff.x * (int)ix.x;  // v_mul_i32_i24_sdwa on the sign-extended halves
+              py[2 * m] = (int)diff.x * (int)iy.x;
+              px[2 * m + 1] = (int)diff.y * (int)ix.y;
+              py[2 * m + 1] = (int)diff.y * (int)iy.y;
+            }
+            lk_float_sums_b(px, py, term_base, *lnf, b1, b2);
+          } else {
+            int sb1 = 0, sb2 = 0;  // kRedSeed + 7 terms of <= 2^25 each
+#pragma unroll
+            for (int m = 0; m < NPP; m++) {
+              const uint32_t hi8 = __builtin_amdgcn_perm(t[2 * m + 1], t[2 * m], 0x06050201u);
+              const us2 val = __builtin_bit_cast(us2, hi8) >> (unsigned short)1;
+              const uint32_t diff = __builtin_bit_cast(uint32_t, __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]));
+              if (m == 0) {
+                sb1 = sdot2_seed(diff, pIxp[L][m], kRedSeed);
+                sb2 = sdot2_seed(diff, pIyp[L][m], kRedSeed);
+              } else {
+                sb1 = sdot2(diff, pIxp[L][m], sb1);
+                sb2 = sdot2(diff, pIyp[L][m], sb2);
+              }
+            }
+            wave_sum2_exact(sb1, sb2, rl, b1, b2);  // already scaled by FLT_SCALE
+          }
+          d = f2{(A12[L] * b2 - A22[L] * b1) * Dinv[L], (A12[L] * b1 - A11[L] * b2) * Dinv[L]};
+          // |delta|^2 <= eps^2 is decided in fp64 by OpenCV; an fp32 evaluation (relative error
+          // < 2^-22) settles it unless it lands within 2^-20 of the threshold
+          d2 = __fmaf_rn(d.x, d.x, d.y * d.y);
+          osum = d + prevD;
+          prevD = d;
+          nxt += d;
+          fl = f2{floorf(nxt.x), floorf(nxt.y)};
+          inx = (int)fl.x;
+          iny = (int)fl.y;
+          ox = (uint32_t)(inx - lox);
+          oy = (uint32_t)(iny - loy);
+          j++;
+          // ONE exit test: "out of iterations" rides on the convergence pre-test's threshold (a scalar select; the
+          // negated >= also stops on a NaN, which then runs the count down instead of spinning)
+          const float thr = j >= c.max_count ? __builtin_inff() : eps_hi;
+          // (double)|x| < 0.01  <=>  |x| <= 0.01f: 0.01f is the largest float below the real 0.01
+          if (bal(!(d2 >= thr)) | bal(fmaxf(fabsf(osum.x), fabsf(osum.y)) <= 0.01f) | bal(ox > rngx) | bal(oy > rngy)) break;
+        }
+        // (what follows must not share its compares with the loop's exit test: the compiler would carry every
+        // one of them out of the loop as a mask of its own, a dozen scalar instructions per iteration)
+        asm volatile("" : "+v"(d2), "+v"(ox), "+v"(oy));
+        asm volatile("" : "+v"(osum));
+        np = make_float2(nxt.x + halfWin, nxt.y + halfWin);
+        lanemask_t conv = bal(d2 <= eps_lo);
+        if (__builtin_expect((bal(d2 > eps_lo) & bal(d2 < eps_hi)) != 0, 0)) {
+          asm volatile("; fp64 tie-break" ::: "memory");  // keep this a branch, not a select
+          conv = bal((double)d.x * (double)d.x + (double)d.y * (double)d.y <= c.eps2);
+        }
+        if (conv) {
+          level_done = true;
           break;
         }
-        uint32_t reg[(kLkRegDw + 63) / 64];  // the window drifted out of the staged region
-        lk_region_load(J, stride, rows, inextX, inextY, lane, rx0, ry0, reg);
-        lk_region_store(regJ, lane, reg);
-        cbo = lane_bo - rx0 - ry0 * kLkRegW;
-      }
-      // bilinear weights: rint(w * 2^14) for w in [0,1] is the low half of the bit pattern of
-      // fma(w, 2^14, 2^23) (one RNE rounding to an integer), which v_perm packs straight into
-      // the int16 pairs {iw00,iw01} {iw10,iw11}
-      const float fa = nextX - flX, fb = nextY - flY, ofa = 1.f - fa, ofb = 1.f - fb;
-      const float kMagic = 8388608.f, kW = (float)(1 << W_BITS);
-      const uint32_t b00 = __float_as_uint(__fmaf_rn(ofa * ofb, kW, kMagic));
-      const uint32_t b01 = __float_as_uint(__fmaf_rn(fa * ofb, kW, kMagic));
-      const uint32_t b10 = __float_as_uint(__fmaf_rn(ofa * fb, kW, kMagic));
-      const uint32_t iw11 = ((1u << W_BITS) + 3u * 0x4B000000u) - (b00 + b01 + b10);
-      const uint32_t W0 = __builtin_amdgcn_perm(b01, b00, 0x05040100u);
-      const uint32_t W1 = __builtin_amdgcn_perm(iw11, b10, 0x05040100u);
-      // 8 bytes of two consecutive staged rows: 3 aligned dwords per row + funnel shift (unaligned
-      // ds_read_b64 would do it in one instruction, but measured slower)
-      const int bo = __mul24(inextY, kLkRegW) + (inextX + cbo);
-      const uint32_t* rp = regJ + (bo >> 2);
-      const uint32_t sh = (uint32_t)bo & 3u;
-      const uint32_t a0 = rp[0], a1 = rp[1], a2 = rp[2];
-      const uint32_t c0 = rp[kLkRegW / 4], c1 = rp[kLkRegW / 4 + 1], c2 = rp[kLkRegW / 4 + 2];
-      const uint32_t w0[2] = {__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh)};
-      const uint32_t w1[2] = {__builtin_amdgcn_alignbyte(c1, c0, sh), __builtin_amdgcn_alignbyte(c2, c1, sh)};
-      // per pixel: the two horizontally adjacent bytes of each row as an int16 pair (v_perm_b32)
-      // against the packed weight pairs (v_dot2_i32_i16), rounding constant as the accumulator seed
-      uint32_t t[NP + 1];
-#pragma unroll
-      for (int k = 0; k < NP; k++) {
-        const uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
-        const uint32_t p0 = __builtin_amdgcn_perm(w0[1], w0[0], sel);
-        const uint32_t p1 = __builtin_amdgcn_perm(w1[1], w1[0], sel);
-        t[k] = (uint32_t)sdot2(p1, W1, sdot2(p0, W0, 1 << (W_BITS - 5 - 1)));  // in [1, 2^22]
-      }
-      t[NP] = 0;
-      // CV_DESCALE(.., 9) of two pixels at once: bytes 1..2 of each sum, packed shift by one more
-      // bit, packed subtract of the patch, dot with the packed derivatives
-      int sb1 = kRedSeed, sb2 = kRedSeed;  // + 7 terms of <= 2^25 each
-#pragma unroll
-      for (int m = 0; m < NPP; m++) {
-        const uint32_t hi8 = __builtin_amdgcn_perm(t[2 * m + 1], t[2 * m], 0x06050201u);
-        const us2 val = __builtin_bit_cast(us2, hi8) >> (unsigned short)1;
-        const ss2 diff = __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]);
-        sb1 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, pIxp[L][m]), sb1, false);
-        sb2 = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, pIyp[L][m]), sb2, false);
-      }
-      float b1, b2;
-      if (ACCUM == 2) {
-        // the per-pixel products diff * Ix, diff * Iy (exact in int32) -> float terms -> the float chains
-        int px[NP + 1], py[NP + 1];
-#pragma unroll
-        for (int m = 0; m < NPP; m++) {
-          const uint32_t hi8 = __builtin_amdgcn_perm(t[2 * m + 1], t[2 * m], 0x06050201u);
-          const us2 val = __builtin_bit_cast(us2, hi8) >> (unsigned short)1;
-          const ss2 diff = __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]);
-          const uint32_t ixp = pIxp[L][m], iyp = pIyp[L][m];
-          px[2 * m] = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, ixp & 0x0000ffffu), 0, false);
-          py[2 * m] = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, iyp & 0x0000ffffu), 0, false);
-          px[2 * m + 1] = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, ixp & 0xffff0000u), 0, false);
-          py[2 * m + 1] = __builtin_amdgcn_sdot2(diff, __builtin_bit_cast(ss2, iyp & 0xffff0000u), 0, false);
+        if (bal(fabsf(osum.x) <= 0.01f) & bal(fabsf(osum.y) <= 0.01f)) {
+          np.x -= d.x * 0.5f;
+          np.y -= d.y * 0.5f;
+          level_done = true;
+          break;
         }
-        const int (&px7)[7] = *(const int (*)[7])px;
-        const int (&py7)[7] = *(const int (*)[7])py;
-        lk_float_sums_b(px7, py7, acc_t, *lnf, b1, b2);
-      } else {
-        wave_sum2_exact(sb1, sb2, rl, b1, b2);  // already scaled by FLT_SCALE
-      }
-      const float dx = (A12[L] * b2 - A22[L] * b1) * Dinv[L];
-      const float dy = (A12[L] * b1 - A11[L] * b2) * Dinv[L];
-      nextX += dx;
-      nextY += dy;
-      np = make_float2(nextX + halfWin, nextY + halfWin);
-      // |delta|^2 <= eps^2 is decided in fp64 by OpenCV; an fp32 evaluation (relative error
-      // < 2^-22) settles it unless it lands within 2^-20 of the threshold
-      const float d2 = __fmaf_rn(dx, dx, dy * dy);
-      lanemask_t conv = bal(d2 <= eps_lo);
-      if (__builtin_expect((bal(d2 > eps_lo) & bal(d2 < eps_hi)) != 0, 0)) {
-        asm volatile("; fp64 tie-break" ::: "memory");  // keep this a branch, not a select
-        conv = bal((double)dx * (double)dx + (double)dy * (double)dy <= c.eps2);
-      }
-      // (double)|x| < 0.01  <=>  |x| <= 0.01f: 0.01f is the largest float below the real 0.01
-      const lanemask_t osc =
-          j > 0 ? bal(fabsf(dx + prevDx) <= 0.01f) & bal(fabsf(dy + prevDy) <= 0.01f) : 0;
-      if (conv | osc) {
-        if (!conv) {
-          np.x -= dx * 0.5f;
-          np.y -= dy * 0.5f;
+        if (j >= c.max_count) {
+          level_done = true;
+          break;
         }
-        break;
+        // the next iteration's own checks
+        if (wave_any(inx < -WIN || inx >= cols || iny < -WIN || iny >= rows)) {
+          if (L == 0) st = 0;
+          level_done = true;
+          break;
+        }
+        if (wave_any(ox > rngx || oy > rngy)) {  // the window drifted out of the staged region
+          restage = true;
+          break;
+        }
       }
-      prevDx = dx;
-      prevDy = dy;
+      (void)restage;
     }
     if (st && L == 0) {  // the `err` block of the tracker re-validates the final position
       const float fx = np.x - halfWin, fy = np.y - halfWin;
@@ -2711,7 +2816,7 @@ __device__ __forceinline__ void chain_publish(const LkKernelArgs& a, int pt, int
 }
 
 template <int ACCUM>
-__device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (*regJ_s)[kLkRegDw], int* acc_t,
+__device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (*regJ_s)[kLkRegStore], uint32_t acc_t,
                                                float* acc_ta, const LkLaneF32* lnf) {
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int pt = blockIdx.x * 4 + wave;
@@ -2793,20 +2898,21 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
 }
 
 __global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
-  lk_kernel_body<1>(a, regJ_s, nullptr, nullptr, nullptr);
+  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegStore];
+  lk_kernel_body<1>(a, regJ_s, 0u, nullptr, nullptr);
 }
 // lk_accum 2: float sums in the reference build's order (see lk_float_sums_A / _b)
 __global__ __launch_bounds__(256) void k_lk_f32(LkKernelArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegDw];
-  __shared__ __attribute__((aligned(16))) int term_all[4][kLkTermWords];
+  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegStore];
+  __shared__ __attribute__((aligned(16))) int term_all[4][kF32TermWords];
   __shared__ __attribute__((aligned(16))) float term_a[4][kLkTermWordsA];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = lane; i < kLkTermWords; i += 64) term_all[wave][i] = 0;  // (the words a segment does not use stay 0)
+  for (int i = lane; i < kF32TermWords; i += 64) term_all[wave][i] = 0;  // (the words a segment does not use stay 0)
   for (int i = lane; i < kLkTermWordsA; i += 64) term_a[wave][i] = 0.f;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
   const LkLaneF32 lnf = lk_lane_f32(lane);
-  lk_kernel_body<2>(a, regJ_s, term_all[wave], term_a[wave], &lnf);
+  const uint32_t tb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)term_all[wave];
+  lk_kernel_body<2>(a, regJ_s, tb, term_a[wave], &lnf);
 }
 
 void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts,
