@@ -2360,20 +2360,11 @@ typedef __attribute__((address_space(3))) int lds_int;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) i32x4 lds_int4;
 
-// px / py: the lane's eight per-pixel products diff * Ix, diff * Iy (exact in int32; zero for columns that
-// do not exist); tb: LDS byte address of the wave's term table
-__device__ __forceinline__ void lk_float_sums_b(const int (&px)[8], const int (&py)[8], uint32_t tb, const LkLaneF32& ln,
+// vx / vy: the five (b1, b2) words this pixel lane contributes — runs 0 / 1: the four pmaddwd pair sums
+// diff_j Ix_j + diff_(j+4) Ix_(j+4) (word 4 goes to the lane's dump word); run 2: the products of columns
+// 16..20 — all exact in int32; tb: LDS byte address of the wave's term table
+__device__ __forceinline__ void lk_float_sums_b(const int (&vx)[5], const int (&vy)[5], uint32_t tb, const LkLaneF32& ln,
                                                 float& b1, float& b2) {
-  int vx[5], vy[5];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    vx[j] = px[j] + px[j + 4];  // pmaddwd's int32 pair sum (run 2: px[5..7] = 0, so these ARE its products 1..3)
-    vy[j] = py[j] + py[j + 4];
-  }
-  vx[0] = ln.run2 ? px[0] : vx[0];
-  vy[0] = ln.run2 ? py[0] : vy[0];
-  vx[4] = px[4];
-  vy[4] = py[4];
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous iteration's walkers have read)
 #pragma unroll
   for (int j = 0; j < 5; j++) {
@@ -2452,6 +2443,11 @@ __device__ __forceinline__ uint32_t mad_u24_regw(uint32_t oy, uint32_t ox) {
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(oy), "n"(kLkRegW), "v"(ox));
   return r;
 }
+__device__ __forceinline__ int sdot2_zero(uint32_t a, uint32_t b) {  // a.lo * b.lo + a.hi * b.hi, no accumulator
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ int sdot2_seed(uint32_t a, uint32_t b, int seed) {
   int r;
   asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(seed));
@@ -2480,6 +2476,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   // the patch is kept as packed int16 pairs {px 2m, px 2m+1} (halves of columns that do not exist are
   // zero), the form the v_dot2 / v_pk iteration below consumes
   uint32_t pIp[NL][NPP], pIxp[NL][NPP], pIyp[NL][NPP];
+  uint32_t pIxB[NL], pIyB[NL];  // (float-order mode: the fifth word's derivatives, see lk_float_sums_b)
   bool win_ok[NL], eig_ok[NL];
   float A11[NL], A12[NL], A22[NL], Dinv[NL];
   {
@@ -2547,9 +2544,21 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       }
 #pragma unroll
       for (int m = 0; m < NPP; m++) {
-        pIp[L][m] = pack16(pI[2 * m], pI[2 * m + 1]);
-        pIxp[L][m] = pack16(pIx[2 * m], pIx[2 * m + 1]);
-        pIyp[L][m] = pack16(pIy[2 * m], pIy[2 * m + 1]);
+        // exact mode: horizontally adjacent pixels share a register; float-order mode: the two columns of a
+        // pmaddwd pair (j, j + 4), so that ONE v_dot2 is the pair sum the reference adds in int32
+        const int a = ACCUM == 2 ? m : 2 * m, b = ACCUM == 2 ? m + 4 : 2 * m + 1;
+        pIp[L][m] = pack16(pI[a], pI[b]);
+        pIxp[L][m] = pack16(pIx[a], pIx[b]);
+        pIyp[L][m] = pack16(pIy[a], pIy[b]);
+      }
+      if (ACCUM == 2) {
+        // run 2 (columns 16..20): its pair 0 = columns 16 and 20, both real and both wanted on their own
+        if (lnf->run2) {
+          pIxp[L][0] = pack16(pIx[0], 0);
+          pIyp[L][0] = pack16(pIy[0], 0);
+        }
+        pIxB[L] = pack16(0, pIx[4]);
+        pIyB[L] = pack16(0, pIy[4]);
       }
       if (ACCUM == 2) {
         lk_float_sums_A<NP>(acc_ta, on, row, x0, pIx, pIy, lane, A11[L], A12[L], A22[L]);
@@ -2685,20 +2694,21 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
           // bit, packed subtract of the patch, dot with the packed derivatives
           float b1, b2;
           if (ACCUM == 2) {
-            // the per-pixel products diff * Ix, diff * Iy (exact in int32) -> the float chains
-            int px[2 * NPP], py[2 * NPP];
+            // pair sums diff_j Ix_j + diff_(j+4) Ix_(j+4) (exact in int32: pmaddwd) -> the float chains
+            int vx[5], vy[5];
 #pragma unroll
             for (int m = 0; m < NPP; m++) {
-              const uint32_t hi8 = __builtin_amdgcn_perm(t[2 * m + 1], t[2 * m], 0x06050201u);
+              const uint32_t hi8 = __builtin_amdgcn_perm(t[m + 4], t[m], 0x06050201u);
               const us2 val = __builtin_bit_cast(us2, hi8) >> (unsigned short)1;
-              const ss2 diff = __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]);
-              const ss2 ix = __builtin_bit_cast(ss2, pIxp[L][m]), iy = __builtin_bit_cast(ss2, pIyp[L][m]);
-              px[2 * m] = (int)diff.x * (int)ix.x;  // v_mul_i32_i24_sdwa on the sign-extended halves
-              py[2 * m] = (int)diff.x * (int)iy.x;
-              px[2 * m + 1] = (int)diff.y * (int)ix.y;
-              py[2 * m + 1] = (int)diff.y * (int)iy.y;
+              const uint32_t diff = __builtin_bit_cast(uint32_t, __builtin_bit_cast(ss2, val) - __builtin_bit_cast(ss2, pIp[L][m]));
+              vx[m] = sdot2_zero(diff, pIxp[L][m]);
+              vy[m] = sdot2_zero(diff, pIyp[L][m]);
+              if (m == 0) {
+                vx[4] = sdot2_zero(diff, pIxB[L]);
+                vy[4] = sdot2_zero(diff, pIyB[L]);
+              }
             }
-            lk_float_sums_b(px, py, term_base, *lnf, b1, b2);
+            lk_float_sums_b(vx, vy, term_base, *lnf, b1, b2);
           } else {
             int sb1 = 0, sb2 = 0;  // kRedSeed + 7 terms of <= 2^25 each
 #pragma unroll

@@ -146,6 +146,13 @@ def _ev(ev):
     return ev
 
 
+# How calcOpticalFlowPyrLK's sums are accumulated when a caller does not say: 2 = in float, in the order of the
+# x86 OpenCV build the reference node links (feature_tracker.cpp:410,417-418,490,495) — the reference's own
+# arithmetic; 1 = exact integer sums.  ESVIO_LK_ACCUM=1 in the environment runs everything that does not say
+# (the test suite, tools/) in the exact mode instead.
+DEFAULT_LK_ACCUM = int(os.environ.get("ESVIO_LK_ACCUM", "2"))
+
+
 def make_config(W, H, **kw):
     c = Config()
     c.width, c.height = W, H
@@ -160,7 +167,7 @@ def make_config(W, H, **kw):
     c.equalize = kw.get("equalize", 0)
     c.f_threshold = kw.get("f_threshold", 1.0)
     c.f_ransac = kw.get("f_ransac", 1)
-    c.lk_accum = kw.get("lk_accum", 1)
+    c.lk_accum = kw.get("lk_accum", DEFAULT_LK_ACCUM)
     c.focal_length = kw.get("focal_length", 460)
     cams = kw.get("cams")
     if cams is None:

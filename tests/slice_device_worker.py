@@ -50,7 +50,7 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     ft = FE.FeatureTracker(FE.make_config(W, H, device=0, max_cnt=150))
-    tr = O.Tracker(O.make_config(W, H, lk_accum=1, max_cnt=150))
+    tr = O.Tracker(O.make_config(W, H, max_cnt=150))
     ts = TimeSlicedSae(ft, 0, 1, dist, device="cuda")
     from esvio_amd.synth import SceneStream
     s = SceneStream(W, H, rate=1e6, seed=4, n_rect=12, size=(30.0, 90.0))

@@ -55,7 +55,7 @@ def test_c5_track_event_at_full_rate(oracle, replay):
     pubs = [True, False, True, True]
     kw = dict(max_cnt=500, min_dist=10, f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     if replay:
         ft.set_lazy_new_stereo(True)
         ft.set_host_threads(3)
@@ -95,7 +95,7 @@ def test_c5_named_split_eight_time_slices(oracle):
     batches = _stream(2, seed=23)
     kw = dict(max_cnt=500, min_dist=10, f_ransac=1)
     fts = [FE.FeatureTracker(FE.make_config(W, H, **kw)) for _ in range(N)]
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     nd = fts[0].sae_plane_doubles()
     assert nd == 4 * W * H
     lib = FE.load_library()

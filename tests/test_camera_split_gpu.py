@@ -81,7 +81,7 @@ def test_camera_split_matches_single_gpu(oracle, case):
     c = CASES[case]
     kw = dict(max_cnt=c["max_cnt"], min_dist=c["min_dist"], f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(c["W"], c["H"], device=0, **kw))
-    tr = oracle.Tracker(oracle.make_config(c["W"], c["H"], lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(c["W"], c["H"], **kw))
     ref = []
     for b, (L, R, _) in enumerate(_stream(case)):
         t = event_times(L)[-1]

@@ -45,7 +45,7 @@ def test_an_expired_wait_of_the_sae_update_fails_the_call_and_reset_recovers(ora
         ft.detector.createSAE_stereo(L, R)
     ft.debug_inject(0)
     ft.reset()
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(4):
         L, R, _ = s.next_batch()
         t = event_times(L)[-1]
@@ -69,7 +69,7 @@ def test_an_expired_speculative_or_chained_lk_wait_is_redone_with_the_same_resul
     pubs = [f % 2 == 0 for f in range(len(batches))]  # every other frame publishes nothing: chains are launched
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     ft.set_lazy_new_stereo(True)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     announced = 0
     for f, (L, R) in enumerate(batches):
         if f == 6:
@@ -103,7 +103,7 @@ def test_an_expired_wait_of_the_plain_calls_chained_stereo_lk_is_redone(oracle):
     kw = dict(max_cnt=200, min_dist=10, f_ransac=1)
     s = SceneStream(W, H, rate=4e6, seed=29, n_rect=24, size=(40.0, 120.0))
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     redone = []
     for f in range(14):
         if f == 4:

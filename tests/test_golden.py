@@ -33,7 +33,7 @@ def _check(z, b, ts_l, ts_r, flags, res):
 
 def test_oracle_reproduces_golden(oracle):
     z, W, H, NB, kw = _load()
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for b in range(NB):
         L, R = _events(z, "L%d" % b), _events(z, "R%d" % b)
         r = tr.track_event(float(z["t%d" % b]), L, R, bool(z["pub%d" % b]))

@@ -59,7 +59,7 @@ def test_host_resident_replay_matches_the_oracle(oracle, monkeypatch, threads, a
     kw = dict(max_cnt=200, min_dist=10, f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     ft.set_lazy_new_stereo(True)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     announced = 0
     for f, (L, R) in enumerate(batches):
         while announced < min(f + ahead, len(batches) - 1):
@@ -88,7 +88,7 @@ def test_host_batches_without_announcement_and_across_a_reset(oracle):
     kw = dict(max_cnt=120, min_dist=10, f_ransac=1)
     batches = _batches(W, H, 14, 2.5e6, 3, thin=False)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f, (L, R) in enumerate(batches[:6]):
         if f == 3:
             L, R = L[:3000].copy(), R[:2000].copy()  # 80 KB: plain copy
@@ -102,7 +102,7 @@ def test_host_batches_without_announcement_and_across_a_reset(oracle):
     ft.trackEvent(event_times(L)[-1], L, R, True)
     _same(ft, tr.track_event(event_times(L)[-1], L, R, True), "before reset")
     ft.reset()
-    tr2 = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr2 = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f, (L, R) in enumerate(batches[9:]):
         t = event_times(L)[-1]
         ft.trackEvent(t, L, R, True)
@@ -123,7 +123,7 @@ def test_a_batch_announced_late_is_taken_up_by_its_own_call(oracle):
     kw = dict(max_cnt=150, min_dist=10, f_ransac=1)
     s = SceneStream(W, H, rate=8e6, seed=11, n_rect=20, size=(40.0, 120.0))
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(6):
         L, R, _ = s.next_batch()
         t = event_times(L)[-1]
@@ -146,7 +146,7 @@ def test_announce_after_return_with_lazy_unpublished_frames(oracle, space):
     s = SceneStream(W, H, rate=6e6, seed=23, n_rect=20, size=(40.0, 120.0))
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     ft.set_lazy_new_stereo(True)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     pubs = [False, False, True, False, False, True, True, False, False, False, True, False]
     bufs = []
     for f, pub in enumerate(pubs):
@@ -190,7 +190,7 @@ def test_plain_calls_with_the_cameras_on_two_streams(oracle, monkeypatch, space,
     kw = dict(max_cnt=150, min_dist=10, f_ransac=1)
     s = SceneStream(W, H, rate=5e6, seed=41, n_rect=20, size=(40.0, 120.0))
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     pubs = [True, False, True, True, False, False, True, False, True, True, False, True, True, False, True, True]
     batches = [s.next_batch()[:2] for _ in pubs]
     batches[4] = (batches[4][0], batches[4][1][:0])                                   # no right events

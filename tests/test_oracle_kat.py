@@ -565,7 +565,7 @@ def test_track_image_follows_a_translating_scene(oracle):
     from esvio_amd.synth import ImageStream
     W, H = 320, 240
     s = ImageStream(W, H, velocity=(3, 2), disparity=8, seed=3)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, max_cnt=80, min_dist=20, flow_back=1))
+    tr = oracle.Tracker(oracle.make_config(W, H, max_cnt=80, min_dist=20, flow_back=1))
     prev = None
     for f in range(5):
         L, R, t = s.next_frame()

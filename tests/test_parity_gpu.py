@@ -289,7 +289,7 @@ def test_track_event_end_to_end(oracle):
     s = SceneStream(W, H, rate=5e6, seed=1)
     kw = dict(f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(12):
         L, R, _ = s.next_batch()
         pub = (f % 3) != 2  # mix published and non-published frames
@@ -318,7 +318,7 @@ def test_track_event_at_epoch_timestamps(oracle):
     s = SceneStream(W, H, rate=4e6, seed=9, t0_us=1_700_000_000_000_000)
     kw = dict(f_ransac=1, max_cnt=200)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(6):
         L, R, _ = s.next_batch()
         t = event_times(L)[-1]
@@ -357,7 +357,7 @@ def test_track_event_end_to_end_equalize(oracle):
     s = SceneStream(W, H, rate=5e6, seed=2)
     kw = dict(f_ransac=1, equalize=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(8):
         L, R, _ = s.next_batch()
         pub = (f % 3) != 2
@@ -393,7 +393,7 @@ def test_empty_right_batches_reset_and_capacity_growth(oracle):
     small = SceneStream(W, H, rate=2e5, seed=21, n_rect=8, size=(30.0, 80.0))
     big = SceneStream(W, H, rate=3e6, seed=22, n_rect=12, size=(30.0, 80.0), t0_us=2_000_000_000)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     empty = np.zeros(0, EVENT_DTYPE)
     for f in range(4):  # tiny batches, right camera silent on odd frames
         L, R, _ = small.next_batch()
@@ -404,7 +404,7 @@ def test_empty_right_batches_reset_and_capacity_growth(oracle):
         _compare_tracks(ft, tr.track_event(t, L, R, True), ("small", f))
     ft.reset()
     n_before = int(ft.ids.max()) + 1 if len(ft.ids) else 0
-    tr2 = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr2 = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(4):  # 15x larger batches after the reset: every device buffer is re-grown
         L, R, _ = big.next_batch()
         t = event_times(L)[-1]
@@ -476,7 +476,7 @@ def test_event_path_on_a_sensor_beyond_the_lds_bitmap(oracle):
     W, H = 1920, 1080
     s = SceneStream(W, H, rate=6e6, seed=77)
     ft = _mk(W, H, max_cnt=200, min_dist=25)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, max_cnt=200, min_dist=25, f_ransac=1))
+    tr = oracle.Tracker(oracle.make_config(W, H, max_cnt=200, min_dist=25, f_ransac=1))
     det = oracle.Detector(W, H, min_dist=25)
     for f in range(3):
         L, R, _ = s.next_batch()
@@ -611,7 +611,7 @@ def test_track_event_motion_compensated_end_to_end(oracle):
     W, H = 640, 480
     s = SceneStream(W, H, rate=5e6, seed=5)
     ft = FE.FeatureTracker(FE.make_config(W, H))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1))
+    tr = oracle.Tracker(oracle.make_config(W, H))
     for f in range(6):
         L, R, _ = s.next_batch()
         t = event_times(L)[-1]
@@ -648,7 +648,7 @@ def test_motion_compensated_replay_schedule(oracle, space):
         return _motion(mod, L, omega=om, accel=(1.0, 2.0, 3.0) if f % 5 == 4 else (4.0, 5.0, 3.0))
     ft = FE.FeatureTracker(FE.make_config(W, H))
     ft.set_lazy_new_stereo(True)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1))
+    tr = oracle.Tracker(oracle.make_config(W, H))
     announced = 0
     for f, (L, R) in enumerate(batches):
         arg = (lambda k: dev[k]) if space == "device" else (lambda k: batches[k])
@@ -691,7 +691,7 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy,
     ft.set_lazy_new_stereo(bool(lazy))
     if launch:
         ft.set_launch_thread(True)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     pubs = [(f % 3) != 1 for f in range(len(batches))]
     announced = 0
     for f, (L, R, _) in enumerate(batches):
@@ -800,7 +800,7 @@ def test_track_image_end_to_end_matches_oracle(oracle, equalize):
     s = ImageStream(W, H, velocity=(4, -3), disparity=11, seed=5)
     kw = dict(max_cnt=150, min_dist=30, flow_back=1, equalize=equalize)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(8):
         L, R, t = s.next_frame()
         pub = f % 3 != 1
@@ -821,7 +821,7 @@ def test_track_image_at_the_shipped_frame_camera_sizes(oracle, W, H, max_cnt, mi
     s = ImageStream(W, H, velocity=(5, 3), disparity=14, seed=W)
     kw = dict(max_cnt=max_cnt, min_dist=min_dist, flow_back=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(3):
         L, R, t = s.next_frame()
         ft.trackImage(t, L, R, f != 1)
@@ -838,7 +838,7 @@ def test_median_blur_kernel_size(oracle, k):
     s = SceneStream(W, H, rate=2e6, seed=17, n_rect=14, size=(30.0, 90.0))
     kw = dict(max_cnt=100, min_dist=10, f_ransac=1, median_blur_kernel_size=k)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(5):
         L, R, _ = s.next_batch()
         t = event_times(L)[-1]
@@ -882,7 +882,7 @@ def test_replay_mode_soak(oracle, lazy, threads, ahead):
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     ft.set_lazy_new_stereo(bool(lazy))
     ft.set_host_threads(threads)  # (RANSAC helpers: no effect on any result)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     from esvio_amd.node import pack_track_records
     announced = 0
     for f, (L, R) in enumerate(batches):
@@ -917,7 +917,7 @@ def test_replay_hd_shape(oracle):
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     ft.set_lazy_new_stereo(True)
     ft.set_host_threads(3)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     announced = 0
     for f, (L, R) in enumerate(batches):
         while announced < min(f + 3, len(batches) - 1):
@@ -948,7 +948,7 @@ def test_replay_random_schedules(oracle, seed):
     pubs = [bool(rng.random() < p_pub) for _ in batches]
     kw = dict(max_cnt=100 + 30 * seed, min_dist=8 + 2 * seed, f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     announced = 0
     for f, (L, R) in enumerate(batches):
         if rng.random() < 0.2:
@@ -993,7 +993,7 @@ def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
     kw = dict(max_cnt=150, min_dist=10, f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     ft.set_lazy_new_stereo(True)
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     announced = 0
     for f, (L, R) in enumerate(batches):
         while announced < min(f + 3, len(batches) - 1):
@@ -1033,7 +1033,7 @@ def test_odd_sensor_sizes_end_to_end(oracle, W, H):
     s = SceneStream(W, H, rate=1.5e6, seed=W, n_rect=12, size=(25.0, 80.0))
     kw = dict(max_cnt=100, min_dist=9, f_ransac=1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     batches = [s.next_batch() for _ in range(7)]
     for f, (L, R, _) in enumerate(batches):
         t = event_times(L)[-1]
@@ -1069,8 +1069,8 @@ def test_event_and_image_handles_interleaved(oracle):
     ekw = dict(max_cnt=90, min_dist=10, f_ransac=1)
     ikw = dict(max_cnt=70, min_dist=20, flow_back=1)
     fe, fi = FE.FeatureTracker(FE.make_config(W, H, **ekw)), FE.FeatureTracker(FE.make_config(W, H, **ikw))
-    oe, oi = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **ekw)), oracle.Tracker(
-        oracle.make_config(W, H, lk_accum=1, **ikw))
+    oe, oi = oracle.Tracker(oracle.make_config(W, H, **ekw)), oracle.Tracker(
+        oracle.make_config(W, H, **ikw))
     batches = [es.next_batch() for _ in range(6)]
     for f, (L, R, _) in enumerate(batches):
         if f + 1 < len(batches):

@@ -107,7 +107,7 @@ class _Imu:
 def _oracle_node(oracle, msgs, mc_K=None):
     """stereo_event_tracker_node.cpp:372-418 (pairing) and :145-344 (handle_stereo_event), restated
     here, over the oracle tracker.  mc_K: Do_motion_correction with these fx, fy, cx, cy."""
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **KW))
+    tr = oracle.Tracker(oracle.make_config(W, H, **KW))
     imu = _Imu(mc_K) if mc_K else None
     ql, qr, pairs = [], [], []
     for mi, (cam, stamp, ev) in enumerate(msgs):
@@ -250,7 +250,7 @@ def test_replay_node_motion_compensation(oracle, tmp_path):
 def _oracle_image_node(oracle, msgs, kw):
     """stereo_image_tracker_node.cpp:210-250 (pairing within a second) and :54-183
     (handle_stereo_image), restated here, over the oracle tracker"""
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     il, ir, out = [], [], []
     first, first_t, last_t, pub_count, init_pub = True, 0.0, 0.0, 1, False
     for kind, stamp, img in msgs:

@@ -22,7 +22,7 @@ def test_event_node_parameters(oracle, name):
     kw = dict(max_cnt=p["max_cnt"], min_dist=p["min_dist"], equalize=p["equalize"], flow_back=1,
               f_threshold=1.0, f_ransac=1, cams=list(p["ev_cams"]))
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     s = SceneStream(W, H, rate=2e6 if W < 400 else 5e6, seed=len(name))
     K = p["ev_cams"][0]
     for f in range(5):
@@ -53,7 +53,7 @@ def test_image_node_parameters(oracle, name):
     kw = dict(max_cnt=p["max_cnt_img"], min_dist=p["min_dist_img"], equalize=p["equalize"], flow_back=1,
               f_threshold=1.0, f_ransac=1, cams=list(p["img_cams"]))
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, lk_accum=1, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     s = ImageStream(W, H, velocity=(4, -2), disparity=12, seed=len(name))
     for f in range(3):
         L, R, t = s.next_frame()
