@@ -234,7 +234,7 @@ def cpu_all_cores(batches, args, W, H):
         for k in range(nproc):
             procs.append(subprocess.Popen(
                 [sys.executable, worker, path, str(len(batches)), str(args.freq), str(W), str(H),
-                 os.path.join(d, "ready%d" % k), go], stdout=subprocess.PIPE, text=True))
+                 os.path.join(d, "ready%d" % k), go, str(args.lk_accum)], stdout=subprocess.PIPE, text=True))
         t_wait = time.time()
         while sum(os.path.exists(os.path.join(d, "ready%d" % k)) for k in range(nproc)) < nproc:
             if time.time() - t_wait > 120 or any(p.poll() not in (None, 0) for p in procs):

@@ -20,11 +20,12 @@ from oracle import oracle as O  # noqa: E402
 
 def main():
     path, nfr, freq, W, H, ready, go = sys.argv[1:8]
+    lk_accum = int(sys.argv[8]) if len(sys.argv) > 8 else O.DEFAULT_LK_ACCUM
     nfr, freq, W, H = int(nfr), int(freq), int(W), int(H)
     z = np.load(path, mmap_mode="r")
     batches = [(np.asarray(z["L%d" % i]).view(EVENT_DTYPE).reshape(-1),
                 np.asarray(z["R%d" % i]).view(EVENT_DTYPE).reshape(-1)) for i in range(nfr)]
-    tr = O.Tracker(O.make_config(W, H, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1, lk_accum=1))
+    tr = O.Tracker(O.make_config(W, H, max_cnt=300, min_dist=10, flow_back=1, f_ransac=1, lk_accum=lk_accum))
     fc = FreqControl(freq)
     open(ready, "w").close()
     while not os.path.exists(go):

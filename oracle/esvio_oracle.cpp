@@ -20,6 +20,12 @@
 #include <map>
 #include <utility>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#define ORACLE_LK_SSE2 1
+#else
+#define ORACLE_LK_SSE2 0
+#endif
 
 namespace {
 
@@ -662,11 +668,21 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
           fA11 += (float)(ixval * ixval);
           fA12 += (float)(ixval * iyval);
           fA22 += (float)(iyval * iyval);
-        } else if (accum == 2) {
+        } else if (accum == 2 || accum == 4) {
           // x86 SIMD128 build [OpenCV 4.2 lkpyramid.cpp, `#if CV_SIMD128 && !CV_NEON`, recalled]:
           // the vector loop runs while x <= win - 8 (8 pixels per step as two halves of 4), lane k
           // of qA11/qA12/qA22 takes pixel x = 4m + k; the rest of the row goes to the scalar float
           // accumulator.  (v_muladd without FMA = mul then add; the products are < 2^24: exact.)
+          // accum 4 (and 2 on a host without SSE2): these lanes emulated one by one; accum 2 with SSE2:
+          // real __m128 accumulators, after the row is complete (below).
+          if (accum == 2 && ORACLE_LK_SSE2) {
+            if (x >= (win / 8) * 8) {
+              fA11 += (float)(ixval * ixval);
+              fA12 += (float)(ixval * iyval);
+              fA22 += (float)(iyval * iyval);
+            }
+            continue;
+          }
           const float fx = (float)ixval, fy = (float)iyval;
           if (x < (win / 8) * 8) {
             qA11[x & 3] += fx * fx;
@@ -683,13 +699,31 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
           iA22 += (int64_t)(iyval * iyval);
         }
       }
+#if ORACLE_LK_SSE2
+      if (accum == 2) {  // the row's vector part on real SSE registers: two float32x4 halves per step of 8
+        __m128 a11 = _mm_loadu_ps(qA11), a12 = _mm_loadu_ps(qA12), a22 = _mm_loadu_ps(qA22);
+        const int16_t* dp = &dWinBuf[(size_t)y * win * 2];
+        for (int x = 0; x <= win - 8; x += 8)
+          for (int half = 0; half < 2; half++) {
+            const int16_t* q = dp + 2 * (x + 4 * half);
+            const __m128 fx = _mm_cvtepi32_ps(_mm_setr_epi32(q[0], q[2], q[4], q[6]));
+            const __m128 fy = _mm_cvtepi32_ps(_mm_setr_epi32(q[1], q[3], q[5], q[7]));
+            a22 = _mm_add_ps(_mm_mul_ps(fy, fy), a22);  // v_muladd without FMA
+            a12 = _mm_add_ps(_mm_mul_ps(fx, fy), a12);
+            a11 = _mm_add_ps(_mm_mul_ps(fx, fx), a11);
+          }
+        _mm_storeu_ps(qA11, a11);
+        _mm_storeu_ps(qA12, a12);
+        _mm_storeu_ps(qA22, a22);
+      }
+#endif
     }
     float A11, A12, A22;
     if (accum == 0) {  // typedef float acctype (default OpenCV build, scalar loop order)
       A11 = fA11 * FLT_SCALE;
       A12 = fA12 * FLT_SCALE;
       A22 = fA22 * FLT_SCALE;
-    } else if (accum == 2) {  // iA11 += v_reduce_sum(qA11): SSE horizontal sum (q0+q2)+(q1+q3)
+    } else if (accum == 2 || accum == 4) {  // iA11 += v_reduce_sum(qA11): SSE horizontal sum (q0+q2)+(q1+q3)
       fA11 += (qA11[0] + qA11[2]) + (qA11[1] + qA11[3]);
       fA12 += (qA12[0] + qA12[2]) + (qA12[1] + qA12[3]);
       fA22 += (qA22[0] + qA22[2]) + (qA22[1] + qA22[3]);
@@ -745,7 +779,55 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
             fb1 += (float)(diff * dIptr[0]);
             fb2 += (float)(diff * dIptr[1]);
           }
-        } else if (accum == 2) {
+        } else if (accum == 2 && ORACLE_LK_SSE2) {
+#if ORACLE_LK_SSE2
+          // The x86 SIMD128 build's loop as it is written there [OpenCV 4.2 lkpyramid.cpp, recalled], on real SSE2
+          // registers — the lane order below comes from the hardware's unpack / pmaddwd / cvtdq2ps / addps, not
+          // from an emulation of them (accum 4 is that emulation; tests/test_lk_float_orders.py holds the two
+          // bit-identical): per step of 8 pixels the bilinear sums as pmaddwd of (J[x], J[x+1]) against
+          // (iw00, iw01) and of the row below against (iw10, iw11), + delta, >> 9, packed to int16, minus the
+          // patch; v_zip(diff, diff) / v_zip(dI lo, dI hi) / v_zip again put (It_k, It_k+4) against
+          // (Ix_k, Ix_k+4) and (Iy_k, Iy_k+4); pmaddwd adds each pair in int32, cvtdq2ps rounds, one addps.
+          const __m128i z = _mm_setzero_si128();
+          const __m128i qw0 = _mm_set1_epi32(iw00 + (iw01 << 16)), qw1 = _mm_set1_epi32(iw10 + (iw11 << 16));
+          const __m128i qdelta = _mm_set1_epi32(1 << (W_BITS1 - 5 - 1));
+          __m128 vb0 = _mm_loadu_ps(qb0), vb1 = _mm_loadu_ps(qb1);
+          int x = 0;
+          for (; x <= win - 8; x += 8) {
+            const __m128i v00 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i*)(Jptr + x)), z);
+            const __m128i v01 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i*)(Jptr + x + 1)), z);
+            const __m128i v10 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i*)(Jptr + x + stepJ)), z);
+            const __m128i v11 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i*)(Jptr + x + stepJ + 1)), z);
+            __m128i t0 = _mm_add_epi32(_mm_madd_epi16(_mm_unpacklo_epi16(v00, v01), qw0),
+                                       _mm_madd_epi16(_mm_unpacklo_epi16(v10, v11), qw1));
+            __m128i t1 = _mm_add_epi32(_mm_madd_epi16(_mm_unpackhi_epi16(v00, v01), qw0),
+                                       _mm_madd_epi16(_mm_unpackhi_epi16(v10, v11), qw1));
+            t0 = _mm_srai_epi32(_mm_add_epi32(t0, qdelta), W_BITS1 - 5);
+            t1 = _mm_srai_epi32(_mm_add_epi32(t1, qdelta), W_BITS1 - 5);
+            const __m128i diff0 = _mm_sub_epi16(_mm_packs_epi32(t0, t1), _mm_loadu_si128((const __m128i*)(Iptr + x)));
+            const __m128i diff2 = _mm_unpacklo_epi16(diff0, diff0);  // It0 It0 It1 It1 It2 It2 It3 It3
+            const __m128i diff1 = _mm_unpackhi_epi16(diff0, diff0);  // It4 It4 ... It7 It7
+            const __m128i d00 = _mm_loadu_si128((const __m128i*)(dIptr + 2 * x));      // Ix0 Iy0 ... Ix3 Iy3
+            const __m128i d01 = _mm_loadu_si128((const __m128i*)(dIptr + 2 * x + 8));  // Ix4 Iy4 ... Ix7 Iy7
+            const __m128i d10 = _mm_unpacklo_epi16(d00, d01);  // Ix0 Ix4 Iy0 Iy4 Ix1 Ix5 Iy1 Iy5
+            const __m128i d11 = _mm_unpackhi_epi16(d00, d01);  // Ix2 Ix6 Iy2 Iy6 Ix3 Ix7 Iy3 Iy7
+            const __m128i e00 = _mm_unpacklo_epi16(diff2, diff1);  // It0 It4 It0 It4 It1 It5 It1 It5
+            const __m128i e01 = _mm_unpackhi_epi16(diff2, diff1);  // It2 It6 It2 It6 It3 It7 It3 It7
+            vb0 = _mm_add_ps(vb0, _mm_cvtepi32_ps(_mm_madd_epi16(e00, d10)));
+            vb1 = _mm_add_ps(vb1, _mm_cvtepi32_ps(_mm_madd_epi16(e01, d11)));
+          }
+          _mm_storeu_ps(qb0, vb0);
+          _mm_storeu_ps(qb1, vb1);
+          for (; x < win; x++) {
+            const int diff = CV_DESCALE(Jptr[x] * iw00 + Jptr[x + 1] * iw01 + Jptr[x + stepJ] * iw10 +
+                                            Jptr[x + stepJ + 1] * iw11,
+                                        W_BITS1 - 5) -
+                             Iptr[x];
+            fb1 += (float)(diff * dIptr[2 * x]);
+            fb2 += (float)(diff * dIptr[2 * x + 1]);
+          }
+#endif
+        } else if (accum == 2 || accum == 4) {
           // x86 SIMD128 build [OpenCV 4.2, recalled]: per step of 8 pixels x0..x0+7 the zips put
           // (It_k, It_k+4) against (Ix_k, Ix_k+4) / (Iy_k, Iy_k+4), v_dotprod (pmaddwd) adds each
           // pair exactly in int32, v_cvt_f32 rounds, then one float add per lane:
@@ -788,7 +870,7 @@ void lk_level(const uint8_t* Ipad, const int16_t* dIpad, const uint8_t* Jpad, in
       if (accum == 0) {
         b1 = fb1 * FLT_SCALE;
         b2 = fb2 * FLT_SCALE;
-      } else if (accum == 2) {
+      } else if (accum == 2 || accum == 4) {
         // v_recombine(v_interleave_pairs(qb0 + qb1), 0, qf0, qf1); ib1 += v_reduce_sum(qf0) ...
         const float s0 = qb0[0] + qb1[0], s1 = qb0[1] + qb1[1], s2 = qb0[2] + qb1[2], s3 = qb0[3] + qb1[3];
         fb1 += (s0 + 0.f) + (s2 + 0.f);

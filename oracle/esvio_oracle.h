@@ -52,7 +52,7 @@ typedef struct {
   int32_t equalize;                  /* EQUALIZE: CLAHE + normalize before LK */
   double f_threshold;                /* F_THRESHOLD */
   int32_t f_ransac;                  /* 0: skip rejectWithF_event; 1: restated RANSAC */
-  int32_t lk_accum;                  /* 0: float scalar-order sums; 1: exact int64 sums; 2: float sums in the x86 SIMD128 lane order of OpenCV 4.2 */
+  int32_t lk_accum;                  /* 0: float scalar-order sums; 1: exact int64 sums; 2: float sums in the x86 SIMD128 lane order of OpenCV 4.2, on real SSE2 registers where the host has them; 4: the scalar emulation of those lanes (the cross-check of 2) */
   int32_t focal_length;              /* FOCAL_LENGTH = 460 (parameters.cpp:274) */
   int32_t _pad;
   oracle_camera cam[2];

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/scene_192x144.npz.
+"""Regenerates tests/golden/scene_192x144.npz (lk_accum 1: exact LK sums) and scene_192x144_f32.npz (lk_accum 2:
+the float sums in the order of the reference's x86 OpenCV build — the default mode).
 
 The reference cannot be built or run in this image (its sources for the path need
 Eigen/OpenCV/ROS), and it ships no fixtures, so these are REGRESSION vectors produced by the CPU
@@ -24,10 +25,15 @@ KW = dict(max_cnt=60, min_dist=6, f_ransac=1, flow_back=1)
 
 
 def main():
+    for accum, name in ((1, "scene_192x144.npz"), (2, "scene_192x144_f32.npz")):
+        make(accum, name)
+
+
+def make(accum, fname):
     s = SceneStream(W, H, rate=1.5e5, n_rect=6, seed=2024, size=(25.0, 60.0), speed=(120.0, 260.0),
                     disparity=7, t0_us=1_700_000_000_000_000)
-    tr = O.Tracker(O.make_config(W, H, lk_accum=1, **KW))
-    out = {"W": W, "H": H, "n_batches": NB}
+    tr = O.Tracker(O.make_config(W, H, lk_accum=accum, **KW))
+    out = {"W": W, "H": H, "n_batches": NB, "cfg_lk_accum": accum}
     for k, v in KW.items():
         out["cfg_" + k] = v
     for b in range(NB):
@@ -50,7 +56,7 @@ def main():
             for cam in (0, 1):
                 for name, p in zip(("L0", "L1", "S0", "S1"), det.get_sae(cam)):
                     out["sae_cam%d_%s" % (cam, name)] = p
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scene_192x144.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), fname)
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB; tracks per batch:",
           [len(out["ids%d" % b]) for b in range(NB)], [len(out["ids_right%d" % b]) for b in range(NB)],

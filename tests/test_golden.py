@@ -1,4 +1,5 @@
-"""Committed regression vectors (tests/golden/scene_192x144.npz, made by tests/golden/make_golden.py
+"""Committed regression vectors (tests/golden/scene_192x144.npz and scene_192x144_f32.npz — one per LK
+accumulation mode — made by tests/golden/make_golden.py
 from the CPU oracle — the reference has no fixtures and cannot run here).  CPU: the oracle still
 reproduces them.  GPU: the HIP path reproduces them bit for bit through the C ABI."""
 import os
@@ -8,13 +9,14 @@ import pytest
 
 from esvio_amd.events import EVENT_DTYPE
 
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_192x144.npz")
+GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = ["scene_192x144_f32.npz", "scene_192x144.npz"]  # lk_accum 2 (the default mode), lk_accum 1
 KEYS = ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity", "ids_right", "cur_right_pts",
         "cur_un_right_pts", "right_pts_velocity")
 
 
-def _load():
-    z = np.load(G)
+def _load(name):
+    z = np.load(os.path.join(GDIR, name))
     kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
     return z, int(z["W"]), int(z["H"]), int(z["n_batches"]), kw
 
@@ -31,8 +33,9 @@ def _check(z, b, ts_l, ts_r, flags, res):
         assert a.shape == e.shape and np.array_equal(a, e), (b, k)
 
 
-def test_oracle_reproduces_golden(oracle):
-    z, W, H, NB, kw = _load()
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_oracle_reproduces_golden(oracle, fixture):
+    z, W, H, NB, kw = _load(fixture)
     tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for b in range(NB):
         L, R = _events(z, "L%d" % b), _events(z, "R%d" % b)
@@ -45,9 +48,11 @@ def test_oracle_reproduces_golden(oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_reproduces_golden():
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_gpu_reproduces_golden(fixture):
     from esvio_amd import frontend as FE
-    z, W, H, NB, kw = _load()
+    z, W, H, NB, kw = _load(fixture)
+    assert kw["lk_accum"] == (2 if "f32" in fixture else 1)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     for b in range(NB):
         L, R = _events(z, "L%d" % b), _events(z, "R%d" % b)

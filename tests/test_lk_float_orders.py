@@ -32,3 +32,38 @@ def test_simd_order_mode_sums_the_same_terms(oracle):
     for p, s in out[1:]:
         assert np.array_equal(s, out[0][1])
         assert np.array_equal(p.view(np.uint32), out[0][0].view(np.uint32))
+
+
+def test_sse_registers_and_their_emulation_agree(oracle):
+    """accum 2 runs the x86 build's loop on real __m128 registers (unpack / pmaddwd / cvtdq2ps / addps: the
+    lane order is the hardware's); accum 4 is the scalar emulation of those lanes that accum 2 used to be.
+    Positions and status must be bit-identical on images where the float sums DO round (texture, noise,
+    time surfaces), through every call shape trackEvent makes — this pins the emulated order (and with it
+    k_lk_f32's, which tests/test_lk_float_order_gpu.py holds bit-identical to accum 2) to what SSE does."""
+    rng = np.random.default_rng(5)
+    W, H = 320, 240
+    yy, xx = np.mgrid[0:H, 0:W]
+    tex = (127 + 60 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + 40 * np.sin((xx + 2 * yy) / 11.0)).astype(np.uint8)
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    imgs = [(tex, np.roll(tex, (1, -2), (0, 1))), (noise, np.roll(noise, 1, 1)), (tex, noise)]
+    from esvio_amd.synth import SceneStream
+    s = SceneStream(W, H, rate=1e6, seed=4)
+    tr = oracle.Tracker(oracle.make_config(W, H, max_cnt=100, min_dist=12))
+    surf = []
+    for _ in range(3):
+        L, R, _ = s.next_batch()
+        tr.track_event(float(L["sec"][-1]) + 1e-9 * float(L["nsec"][-1]), L, R, True)
+        surf.append(tr.time_surface(0).copy())
+    imgs += [(surf[0], surf[1]), (surf[1], surf[2])]
+    differ_from_exact = 0
+    for a, b in imgs:
+        pts = np.stack([rng.uniform(-4, W + 4, 200), rng.uniform(-4, H + 4, 200)], 1).astype(np.float32)
+        for ml, flags in ((3, 0), (1, 4), (0, 0)):
+            init = pts + rng.uniform(-2, 2, pts.shape).astype(np.float32)
+            p2, s2 = oracle.lk(a, b, pts, init, max_level=ml, flags=flags, accum=2)
+            p4, s4 = oracle.lk(a, b, pts, init, max_level=ml, flags=flags, accum=4)
+            assert np.array_equal(s2, s4)
+            assert np.array_equal(p2.view(np.uint32), p4.view(np.uint32))
+            p1, _ = oracle.lk(a, b, pts, init, max_level=ml, flags=flags, accum=1)
+            differ_from_exact += int((p2.view(np.uint32) != p1.view(np.uint32)).any(axis=1).sum())
+    assert differ_from_exact > 50  # (the inputs are ones where the order matters)

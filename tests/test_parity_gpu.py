@@ -254,40 +254,46 @@ def _texture(W, H, seed):
     return img
 
 
-def test_lk_parity(oracle):
+@pytest.mark.parametrize("lk_accum", [2, 1])
+def test_lk_parity(oracle, lk_accum):
+    """calcOpticalFlowPyrLK alone, both modes of the sums: lk_accum 2 (k_lk_f32: float, in the order of the
+    reference's x86 OpenCV build) and lk_accum 1 (k_lk: exact integers) — each bit-identical to the oracle's
+    same mode; the exact mode also inside its measured band around the float orders"""
     W, H = 640, 480
     tex = _texture(W, H, 2)
     prev = (tex[8:8 + H, 8:8 + W] * 255).astype(np.uint8)
     nxt = (tex[6:6 + H, 11:11 + W] * 255).astype(np.uint8)  # shift (-3, +2)
     rng = np.random.default_rng(0)
     pts = np.stack([rng.uniform(-5, W + 5, 300), rng.uniform(-5, H + 5, 300)], 1).astype(np.float32)
-    ft = _mk(W, H)
+    ft = _mk(W, H, lk_accum=lk_accum)
     for (ml, flags) in ((3, 0), (1, FE.LK_USE_INITIAL_FLOW), (0, 0)):
         init = pts + rng.uniform(-2, 2, pts.shape).astype(np.float32)
         g_pts, g_st = ft.calcOpticalFlowPyrLK(prev, nxt, pts, init, maxLevel=ml, flags=flags)
-        c_pts, c_st = oracle.lk(prev, nxt, pts, init, max_level=ml, flags=flags, accum=1)
+        c_pts, c_st = oracle.lk(prev, nxt, pts, init, max_level=ml, flags=flags, accum=lk_accum)
         assert np.array_equal(g_st, c_st)
         assert np.array_equal(g_pts.view(np.uint32), c_pts.view(np.uint32)), \
             "max |d| = %g" % np.abs(g_pts - c_pts).max()
-        # float accumulation (what the reference's OpenCV does; order- and SIMD-width-dependent):
-        # a measured band, not an identity — see tests/lk_orders.py for the numbers
-        for accum in (2, 0):
-            f_pts, f_st = oracle.lk(prev, nxt, pts, init, max_level=ml, flags=flags, accum=accum)
-            dist = lk_orders.distribution(g_pts, g_st, f_pts, f_st)
-            print("LK GPU vs float order %d (maxLevel %d flags %d): %s" % (accum, ml, flags, dist))
-            lk_orders.assert_band(dist, accum)
+        if lk_accum == 1:
+            # against float accumulation (what the reference's OpenCV does; order- and SIMD-width-dependent)
+            # the exact sums sit in a measured band, not an identity — see tests/lk_orders.py for the numbers
+            for accum in (2, 0):
+                f_pts, f_st = oracle.lk(prev, nxt, pts, init, max_level=ml, flags=flags, accum=accum)
+                dist = lk_orders.distribution(g_pts, g_st, f_pts, f_st)
+                print("LK GPU vs float order %d (maxLevel %d flags %d): %s" % (accum, ml, flags, dist))
+                lk_orders.assert_band(dist, accum)
     ok = g_st == 1
     assert ok.sum() > 150
     ft.close()
 
 
-def test_track_event_end_to_end(oracle):
+@pytest.mark.parametrize("lk_accum", [2, 1])
+def test_track_event_end_to_end(oracle, lk_accum):
     """12 frames of the stereo scene stream through trackEvent; every public result vector of
-    FeatureTracker must equal the oracle's (ids, track_cnt exact; float vectors bit-exact because
-    LK sums are exact on both sides)."""
+    FeatureTracker must equal the oracle's (ids, track_cnt exact; float vectors bit-exact: the LK sums
+    are accumulated the same way on both sides, in either mode)."""
     W, H = 640, 480
     s = SceneStream(W, H, rate=5e6, seed=1)
-    kw = dict(f_ransac=1)
+    kw = dict(f_ransac=1, lk_accum=lk_accum)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
     tr = oracle.Tracker(oracle.make_config(W, H, **kw))
     for f in range(12):

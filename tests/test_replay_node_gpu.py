@@ -10,6 +10,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from esvio_amd import frontend as FE
 from esvio_amd.events import event_times
 from esvio_amd.synth import SceneStream
 
@@ -177,7 +178,8 @@ def _run(tmp_path, log, name, *opts):
     from esvio_amd import build as B
     tool = B.build_tools()
     dump = str(tmp_path / (name + ".bin"))
-    args = [tool, log, dump, "max_cnt=%d" % KW["max_cnt"], "min_dist=%d" % KW["min_dist"], "freq=%d" % FREQ] + list(opts)
+    args = [tool, log, dump, "max_cnt=%d" % KW["max_cnt"], "min_dist=%d" % KW["min_dist"], "freq=%d" % FREQ,
+            "lk_accum=%d" % FE.DEFAULT_LK_ACCUM] + list(opts)
     p = subprocess.run(args, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     return _read_dump(dump), p.stdout
@@ -325,7 +327,7 @@ def test_replay_image_node(oracle, tmp_path, equalize):
     assert max(f[3].shape[0] for f in ref) > 60
     from esvio_amd import build as B
     dump = str(tmp_path / "img.bin")
-    p = subprocess.run([B.build_tools(), log, dump, "max_cnt=120", "min_dist=20", "freq=%d" % FREQ,
+    p = subprocess.run([B.build_tools(), log, dump, "max_cnt=120", "min_dist=20", "freq=%d" % FREQ, "lk_accum=%d" % FE.DEFAULT_LK_ACCUM,
                         "equalize=%d" % equalize], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     got = _read_dump(dump)

@@ -384,7 +384,7 @@ int main(int argc, char** argv) {
   std::map<std::string, double> kv = {{"max_cnt", 300}, {"min_dist", 10},   {"freq", 15},     {"equalize", 0},
                                       {"flow_back", 1}, {"f_threshold", 1}, {"f_ransac", 1},  {"decay_ms", 20},
                                       {"filter_thr", 0.01}, {"ahead", 0},   {"lazy", 0},      {"threads", 1},
-                                      {"rccl", 0},          {"mc", 0}};
+                                      {"rccl", 0},          {"mc", 0},      {"lk_accum", 2}};
   for (int i = 3; i < argc; i++) {
     const char* eq = std::strchr(argv[i], '=');
     if (!eq) continue;
@@ -403,7 +403,8 @@ int main(int argc, char** argv) {
   c.feature_filter_threshold = kv["filter_thr"]; c.ts_lk_threshold = 128.0;
   c.max_cnt = (int)kv["max_cnt"]; c.min_dist = (int)kv["min_dist"]; c.flow_back = (int)kv["flow_back"];
   c.equalize = (int)kv["equalize"]; c.f_threshold = kv["f_threshold"]; c.f_ransac = (int)kv["f_ransac"];
-  c.lk_accum = 1; c.focal_length = 460; c.device = -1;
+  c.lk_accum = (int)kv["lk_accum"];  // 2: calcOpticalFlowPyrLK's float sums in the x86 OpenCV build's order; 1: exact sums
+  c.focal_length = 460; c.device = -1;
   for (int k = 0; k < 2; k++)  // the tests' synthetic calibration (esvio_amd/frontend.py make_config)
     c.cam[k] = esvio_fe_camera{0.9 * W, 0.9 * W, W / 2.0, H / 2.0, -0.05, 0.01, 1e-4, -2e-4};
   node.FREQ = (int)kv["freq"] == 0 ? 100 : (int)kv["freq"];  // parameters.cpp:278-279

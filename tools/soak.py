@@ -41,7 +41,7 @@ def image_case(rng, case):
     """the image front-end: trackImage over a translating texture, a frame without a right image now and then"""
     W, H = [(346, 260), (640, 480), (1224, 1024), (1440, 1080)][int(rng.integers(0, 4))]
     kw = dict(max_cnt=int(rng.integers(30, 250)), min_dist=int(rng.integers(8, 45)), equalize=int(rng.random() < 0.3),
-              lk_accum=1 + int(rng.random() < 0.3), flow_back=int(rng.random() < 0.85))
+              lk_accum=2 - int(rng.random() < 0.3), flow_back=int(rng.random() < 0.85))
     seed = int(rng.integers(0, 1 << 30))
     s = ImageStream(W, H, velocity=(int(rng.integers(-6, 7)), int(rng.integers(-5, 6))), disparity=int(rng.integers(4, 20)),
                     seed=seed)
@@ -70,7 +70,7 @@ def one_case(rng, case):
     W, H = [(346, 260), (640, 480), (173, 131), (800, 600), (1280, 720)][int(rng.integers(0, 5))]
     rate = float(rng.choice([3e5, 1e6, 3e6, 8e6])) * (W * H / (640 * 480)) ** 0.5
     kw = dict(max_cnt=int(rng.integers(20, 400)), min_dist=int(rng.integers(3, 41)), f_ransac=1,
-              equalize=int(rng.random() < 0.25), lk_accum=1 + int(rng.random() < 0.3), flow_back=int(rng.random() < 0.85),
+              equalize=int(rng.random() < 0.25), lk_accum=2 - int(rng.random() < 0.3), flow_back=int(rng.random() < 0.85),
               median_blur_kernel_size=int(rng.random() < 0.1))
     seed = int(rng.integers(0, 1 << 30))
     stream = (PoissonStream(W, H, rate=rate, seed=seed) if rng.random() < 0.15 else
