@@ -135,7 +135,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->x_done) (void)hipEventDestroy(c->x_done);
   if (c->x_pin) (void)hipHostFree(c->x_pin);
   if (c->x_pin_recv) (void)hipHostFree(c->x_pin_recv);
-  void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_warp, c->d_tile, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
+  void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_warp, c->d_tile, c->d_part2, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx, c->d_sel_bitmap, c->d_eq_tmp,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
@@ -291,6 +291,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if ((rc = dev_alloc(c, &c->d_chain, 2 * std::max<size_t>(M, 1)))) return bail(rc);
   c->stage_threads = stager_threads_from_env();
   if (const char* v = getenv("ESVIO_FE_FAULT")) esvio_fe_debug_inject(c, atoi(v));
+  c->part_two_level = getenv("ESVIO_FE_PART2") != nullptr;  // (measured slower than the one-level partition: opt-in, KERNELS.md)
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
   c->cam_split_enabled = getenv("ESVIO_FE_NO_CAMSPLIT") == nullptr;
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;

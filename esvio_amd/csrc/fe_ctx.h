@@ -174,6 +174,9 @@ struct esvio_fe_ctx {
   size_t part_cap = 0;
   uint32_t* d_tile = nullptr;  // TileScratch
   size_t tile_cap = 0;
+  uint32_t* d_part2 = nullptr;  // PartScratch (the two-level partition)
+  size_t part2_cap = 0;         // ... sized for this many events
+  bool part_two_level = false;  // ESVIO_FE_PART2=1: the two-level partition (k_part_coarse / _scan / _fine) instead of k_tile_hist / _scan / _scatter
   uint8_t* sae_marks = nullptr;         // [sort_cap] its per-event "stores L / stores S" marks
   unsigned long long* d_rejected = nullptr;
   // left: slots 0..kLeftSlots-1 rotate (prev, cur, up to kPrefetchDepth being prefetched);

@@ -151,7 +151,7 @@ struct EventStager {
           gate_expired.fetch_add(1, std::memory_order_relaxed);
           break;
         }
-        __builtin_ia32_pause();
+        cpu_relax();
       }
     }
     const bool ok = hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, stream) == hipSuccess;
@@ -557,7 +557,7 @@ int stager_attach(esvio_fe_ctx* c, int slot, size_t nL, hipStream_t s, const Eve
         st->finish_for(slot);
         idle = 0;
       } else {
-        __builtin_ia32_pause();
+        cpu_relax();
       }
     }
     st->wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -593,7 +593,7 @@ int stager_attach_left(esvio_fe_ctx* c, int slot, hipStream_t s, const EventRec*
       st->finish_for(slot);
       idle = 0;
     } else {
-      __builtin_ia32_pause();
+      cpu_relax();
     }
   }
   const int stt = sl.state.load(std::memory_order_acquire);
@@ -621,7 +621,7 @@ void stager_abandon(esvio_fe_ctx* c, int slot) {
     if (nx < n) st->pending->fetch_sub((int)(n - nx), std::memory_order_acq_rel);
     sl.state.store(-1, std::memory_order_release);  // (closed for taking)
   }
-  while (sl.busy.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();  // chunks a thread holds: waited for
+  while (sl.busy.load(std::memory_order_acquire) != 0) cpu_relax();  // chunks a thread holds: waited for
   (void)hipStreamSynchronize(st->stream);  // (DMAs straight from a pinned source, groups already enqueued)
   for (int g2 = 0; g2 < kMaxGroups; g2++) sl.grp[g2].chunks_left.store(0, std::memory_order_relaxed);
   sl.groups_left.store(0, std::memory_order_relaxed);
@@ -659,7 +659,7 @@ int stager_release(esvio_fe_ctx* c, int slot) {
   sl.in_use = false;
   if (sl.state.load(std::memory_order_acquire) == 2) HIPCHK(c, hipEventSynchronize(sl.copied));
   // (a helper whose chunk was redone may still be inside its own copy of it: it reads the caller's memory)
-  while (sl.busy.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  while (sl.busy.load(std::memory_order_acquire) != 0) cpu_relax();
   return 0;
 }
 
@@ -677,10 +677,10 @@ void stager_drain(esvio_fe_ctx* c) {
         st->finish_for(k);
         idle = 0;
       } else {
-        __builtin_ia32_pause();
+        cpu_relax();
       }
     }
-    while (s.busy.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    while (s.busy.load(std::memory_order_acquire) != 0) cpu_relax();
     s.in_use = false;
   }
   (void)hipStreamSynchronize(st->stream);

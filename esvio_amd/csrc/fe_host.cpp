@@ -840,12 +840,6 @@ constexpr int kRansacMaxIters = 1000;
 constexpr int kRansacWindow = 128;     // iterations drawn ahead of the replay position (>= threads x kLanes)
 constexpr int kIdleSpinUs = 2000;
 
-inline void cpu_relax() {
-#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
-  __builtin_ia32_pause();
-#endif
-}
-
 struct alignas(64) IterResult {
   int nm;
   int good[3];
@@ -1009,8 +1003,8 @@ struct RansacPool {
         const bool first = ig != idle_gen_seen;
         idle_gen_seen = ig;
         if (pend && (first || pend->load(std::memory_order_relaxed) > 0)) {
-          idle_inside.fetch_add(1, std::memory_order_acq_rel);
-          bool (*fn)(void*) = idle_fn.load(std::memory_order_acquire);  // (still there?)
+          idle_inside.fetch_add(1, std::memory_order_seq_cst);
+          bool (*fn)(void*) = idle_fn.load(std::memory_order_seq_cst);  // (still there?)
           const bool did = fn && fn(idle_arg);
           idle_inside.fetch_sub(1, std::memory_order_acq_rel);
           if (did) {
@@ -1198,8 +1192,11 @@ void ransac_pool_wake(RansacPool* p) {
 
 void ransac_pool_set_idle_work(RansacPool* p, const std::atomic<int>* pending, bool (*fn)(void*), void* arg) {
   if (!p) return;
-  p->idle_fn.store(nullptr, std::memory_order_release);
-  while (p->idle_inside.load(std::memory_order_acquire) != 0) cpu_relax();  // (nobody is left inside the old one)
+  // store-then-load against the helpers' add-then-load: both sides sequentially consistent, or the setter's load
+  // could pass its own buffered store and miss a helper that still reads the old hook
+  p->idle_fn.store(nullptr, std::memory_order_seq_cst);
+  while (p->idle_inside.load(std::memory_order_seq_cst) != 0) cpu_relax();  // (nobody is left inside the old one)
+  p->idle_pending.store(nullptr, std::memory_order_release);
   if (!pending || !fn) return;
   p->idle_arg = arg;
   p->idle_pending.store(pending, std::memory_order_release);  // (the handle's counter: outlives the pool)

@@ -10,6 +10,13 @@
 #include "../../include/esvio_fe_test.h"
 
 namespace esvio {
+// one spin-loop hint for every host-side wait (x86: pause; elsewhere: nothing — the host files build for any
+// CPU that has a ROCm)
+inline void cpu_relax() {
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+  __builtin_ia32_pause();
+#endif
+}
 namespace host {
 
 // OpenCV rounding helpers [core/fast_math.hpp]

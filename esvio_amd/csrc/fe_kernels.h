@@ -198,6 +198,48 @@ void launch_tile_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileSc
 // warped pixels launch_tile_hist computed)
 void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
                          const TileGeom& g, const TileScratch& sc, EventRec* part, const uint32_t* warp_xy = nullptr);
+// ---- the same partition in two levels (ESVIO_FE_PART2=1; round 5's attempt at the partition, measured slower than
+// the one-level form on MI355X — 160 against 113 us at 6.7 M events — and kept as an A/B, KERNELS.md): coarse buckets of 32 consecutive buckets first, every block's
+// 2048 events sorted into its own slot of `mid`; then pieces of 2048 records of a coarse bucket into their final
+// places (fe_kernels.hip: k_part_coarse / k_part_scan / k_part_fine).  Leaves `part`, tile_off, tile_order, totals
+// and meta exactly as the three launches above do.
+constexpr int kPartTE = 2048;    // events per block of the coarse pass = records per piece of the fine pass
+constexpr int kPartGridA = 768;  // persistent blocks of the coarse pass (3 per CU: 42 KiB of LDS each)
+struct PartScratch {
+  uint32_t* mid;        // [n][3] {sec, nsec, tile-local pixel | polarity << 11 | bucket inside its coarse bucket << 12}
+  uint32_t* rowpfx;     // [blocks][65] run starts of the coarse buckets inside a block's slot
+  uint32_t* fine_rows;  // [kPartGridA][nbins] bucket counts per persistent block
+  uint32_t* ranges;     // [kPartGridA][4]
+  uint32_t* colpfx;     // [64][blocks + 1] a coarse bucket's run lengths, exclusive prefix over the blocks
+  uint32_t* lookback;   // [pieces][32]
+  uint32_t* ticket;
+};
+inline uint32_t part_blocks(size_t n) { return (uint32_t)((n + kPartTE - 1) / kPartTE); }
+inline uint32_t part_pieces_max(size_t n) { return part_blocks(n) + 64u; }
+inline size_t part_scratch_words(size_t cap) {
+  const size_t nb = part_blocks(cap);
+  return cap * 3 + 4 + nb * 65 + (size_t)kPartGridA * kTileMaxBins + (size_t)kPartGridA * 4 + 64 * (nb + 1) +
+         (size_t)part_pieces_max(cap) * 32 + 4;
+}
+inline PartScratch part_scratch(uint32_t* base, size_t cap) {
+  const size_t nb = part_blocks(cap);
+  PartScratch p;
+  p.ranges = base;  // (16-byte aligned: first)
+  p.mid = p.ranges + (size_t)kPartGridA * 4;
+  p.rowpfx = p.mid + cap * 3 + 4;
+  p.fine_rows = p.rowpfx + nb * 65;
+  p.colpfx = p.fine_rows + (size_t)kPartGridA * kTileMaxBins;
+  p.lookback = p.colpfx + 64 * (nb + 1);
+  p.ticket = p.lookback + (size_t)part_pieces_max(cap) * 32;
+  return p;
+}
+void launch_part_coarse(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
+                        const TileGeom& g, const PartScratch& ps, const struct McParams* mc = nullptr,
+                        uint32_t* warp_xy = nullptr);
+void launch_part_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc, const PartScratch& ps,
+                      unsigned long long* n_rejected);
+void launch_part_fine(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc, const PartScratch& ps,
+                      EventRec* part, int* err, uint32_t spin_limit = kSpinLookback);
 // createSAE_left/right (event_detector.cc:149-166, :212-228) per bucket, events in stream order.
 // arc_touched (optional): ArcArgs::touched of the Arc* pass this batch will get — the left camera's
 // touched (pixel, polarity) flags are written here, from the tiles' own bookkeeping, instead of by

@@ -1201,6 +1201,564 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
 #undef ESVIO_TILE_SCATTER
 }
 
+// ============================================================================ two-level stable partition
+// The partition above (k_tile_hist + k_tile_scan + k_tile_scatter) ranks every event among the <= 2047 buckets
+// at once: 36 B of LDS per bucket and block, two blocks per CU, and stores that reach L2 as runs of ~2
+// records.  This form (ESVIO_FE_PART2=1) never issues a scattered store and never needs per-bucket state of more
+// than 64 entries — and measured SLOWER on MI355X (6.7 M events: 47 + 13 + 100 us against 31 + 9 + 73; KERNELS.md has
+// the account), so it is an opt-in A/B, parity-tested, not the default:
+//   k_part_coarse  one pass over the raw events (16 B read): a block takes 2048 consecutive events, ranks them
+//                  among the <= 64 COARSE buckets (32 consecutive fine buckets each; wave match-any by 6
+//                  ballots, stream order kept), sorts them in LDS and writes its slot of `mid` — the block's
+//                  own 2048 records, 12 B each {sec, nsec, tile-local pixel | polarity | fine bucket inside
+//                  the coarse one}, sorted by coarse bucket — as one contiguous copy, plus the 65 run starts
+//                  of the slot (rowpfx).  Persistent blocks also count the fine buckets in LDS (one row of
+//                  fine_rows per block at the end) and the range of the stamps.
+//   k_part_scan    per coarse bucket the exclusive prefix of its run lengths over the blocks (colpfx: where in
+//                  the bucket's stream-ordered sequence a block's run begins), the fine buckets' totals
+//                  (column sums of fine_rows), the record format of the batch.
+//   k_part_fine    a PIECE = 2048 consecutive records of one coarse bucket's sequence (so hot buckets just get
+//                  more pieces): copies the runs that make it up into LDS (contiguous reads), ranks them among
+//                  the bucket's 32 fine buckets (5 ballots), sorts them in LDS into their final 8-byte form
+//                  and writes each fine bucket's run as a contiguous copy to its place in `part`: bucket
+//                  start + the counts of the bucket's earlier pieces (decoupled look-back over 32-word
+//                  descriptors, tickets in (bucket, piece) order, bounded spin) — the partition k_tile_apply
+//                  reads, bit for bit the one k_tile_scatter wrote.
+// Traffic per event: 16 + 12 | 12 + 8 instead of 16 | 16 + 8 (+ the count matrices).
+constexpr int kPartFineBits = 5, kPartFine = 1 << kPartFineBits;
+constexpr int kPartMaxCoarse = kTileMaxBins >> kPartFineBits;  // 64: one lane per coarse bucket
+static_assert(kPartMaxCoarse == 64, "coarse buckets are scanned by one wave");
+constexpr int kPartRounds = kPartTE / 256;
+static_assert(kPartRounds * 256 == kPartTE && (kPartTE * 12) % 16 == 0, "slot geometry");
+
+// lanes holding the same value of the low BITS bits of v among the lanes of `ok`, in lane (= stream) order
+template <int BITS>
+__device__ __forceinline__ unsigned long long match_any_bits(uint32_t v, bool ok) {
+  unsigned long long m = __ballot(ok);
+#pragma unroll
+  for (int b = 0; b < BITS; b++) {
+    const bool bit = (v >> b) & 1u;
+    const unsigned long long bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane) {  // exclusive prefix over the 64 lanes
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  return incl - v;
+}
+
+template <bool MC>
+__global__ __launch_bounds__(256) void k_part_coarse(const uint4* __restrict__ evL, uint32_t nL,
+                                                     const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
+                                                     uint32_t nblk, uint32_t* __restrict__ mid,
+                                                     uint32_t* __restrict__ rowpfx, uint32_t* __restrict__ fine_rows,
+                                                     uint4* __restrict__ ranges, const uint32_t* __restrict__ warp_xy,
+                                                     uint32_t* __restrict__ lookback, uint32_t lookback_words,
+                                                     uint32_t* __restrict__ ticket) {
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kPartTE * 3];  // the block's slot of `mid`, as it will lie in memory
+  __shared__ uint32_t h[2 * kTileMaxBins];  // fine-bucket counts, two copies by lane parity (runs of one bucket)
+  __shared__ uint32_t wcnt[4][kPartMaxCoarse], cbase[4][kPartMaxCoarse];
+  __shared__ uint32_t s_range[3];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int nb = g.nbins;
+  const uint32_t n = nL + nR;
+  const int twsh = g.tw == 64 ? 6 : 5;
+  for (int i = threadIdx.x; i < 2 * kTileMaxBins; i += 256) h[i] = 0;
+  if (threadIdx.x == 0) {
+    s_range[0] = 0xffffffffu;
+    s_range[1] = 0;
+    s_range[2] = 0;
+  }
+  // (the fine pass's look-back words and ticket: this kernel has ended before that one starts)
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < lookback_words; i += gridDim.x * 256u) lookback[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;
+  __syncthreads();  // (h is zero before any wave counts into it)
+  uint32_t tmin = 0xffffffffu, tmax = 0, tor = 0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // (the block's NEXT 2048 events are requested while the current ones are ranked and stored: the barriers inside
+  // the loop order LDS traffic only, so nothing in it waits for HBM except the first use of a record)
+  uint4 ne[kPartRounds];
+  uint32_t nwxy[kPartRounds];
+  auto request = [&](uint32_t blk) {
+    const uint32_t wb = blk * kPartTE + wave * (kPartTE / 4);
+#pragma unroll
+    for (int r = 0; r < kPartRounds; r++) {  // (whole records: one contiguous 1 KiB request per wave)
+      const uint32_t i = wb + r * 64 + lane;
+      ne[r] = (blk < nblk && i < nL) ? evL[i] : ((blk < nblk && i < n) ? evR[i - nL] : make_uint4(0xffffffffu, 0, 0, 0));
+      nwxy[r] = (MC && blk < nblk && i < n) ? warp_xy[i] : ne[r].x;  // (the pixel k_mc_warp warped the event to)
+    }
+  };
+  request(blockIdx.x);
+  for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    wcnt[wave][lane] = 0;
+    uint32_t r_sec[kPartRounds], r_nsec[kPartRounds], r_meta[kPartRounds], r_dst[kPartRounds];
+    const uint32_t wb = blk * kPartTE + wave * (kPartTE / 4);
+    uint4 e[kPartRounds];
+    uint32_t wxy[kPartRounds];
+#pragma unroll
+    for (int r = 0; r < kPartRounds; r++) {
+      e[r] = ne[r];
+      wxy[r] = nwxy[r];
+    }
+    request(blk + gridDim.x);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (wcnt is this wave's own row)
+#pragma unroll
+    for (int r = 0; r < kPartRounds; r++) {
+      const uint32_t i = wb + r * 64 + lane;
+      const bool ok = i < n;
+      const uint32_t fine = tile_bin(g, wxy[r], i >= nL), coarse = fine >> kPartFineBits;
+      const uint32_t x = wxy[r] & 0xffffu, y = wxy[r] >> 16;
+      const uint32_t pix = ((y & (uint32_t)(g.th - 1)) << twsh) | (x & (uint32_t)(g.tw - 1));
+      r_sec[r] = e[r].y;
+      r_nsec[r] = e[r].z;
+      r_meta[r] = pix | ((e[r].w & 0xffu) ? 1u << 11 : 0u) | ((fine & (uint32_t)(kPartFine - 1)) << 12);
+      if (ok) {
+        atomicAdd(&h[(lane & 1) * kTileMaxBins + fine], 1u);
+        if (fine != (uint32_t)nb - 1u) {
+          tmin = min(tmin, e[r].y);
+          tmax = max(tmax, e[r].y);
+          tor |= e[r].z;
+        }
+      }
+      const unsigned long long m = match_any_bits<6>(coarse, ok);
+      const uint32_t before = __popcll(m & lt);
+      uint32_t base = 0;
+      if (ok) base = wcnt[wave][coarse];
+      if (ok && before == 0) wcnt[wave][coarse] = base + (uint32_t)__popcll(m);  // one leader per bucket
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+      r_dst[r] = (coarse << 16) | (base + before);  // bucket | rank inside (wave, bucket)
+    }
+    lds_barrier();  // every wave's counts; the previous block's copy out of `stage` has been issued and waited for
+    if (wave == 0) {  // lane = coarse bucket: the slot's run starts
+      const uint32_t c0 = wcnt[0][lane], c1 = wcnt[1][lane], c2 = wcnt[2][lane], c3 = wcnt[3][lane];
+      const uint32_t tot = c0 + c1 + c2 + c3, start = wave_excl_scan(tot, lane);
+      cbase[0][lane] = start;
+      cbase[1][lane] = start + c0;
+      cbase[2][lane] = start + c0 + c1;
+      cbase[3][lane] = start + c0 + c1 + c2;
+      // (transposed — [bucket][block] — so that the scan over the blocks and the fine pass's run tables read
+      // consecutive words)
+      rowpfx[(size_t)lane * nblk + blk] = start;
+      if (lane == 63) rowpfx[(size_t)kPartMaxCoarse * nblk + blk] = start + tot;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < kPartRounds; r++) {
+      const uint32_t i = wb + r * 64 + lane;
+      if (i < n) {
+        const uint32_t pos = cbase[wave][r_dst[r] >> 16] + (r_dst[r] & 0xffffu);
+        stage[pos * 3] = r_sec[r];
+        stage[pos * 3 + 1] = r_nsec[r];
+        stage[pos * 3 + 2] = r_meta[r];
+      }
+    }
+    lds_barrier();
+    {  // the slot: one contiguous copy, 16 B per lane
+      const uint32_t cnt = min((uint32_t)kPartTE, n - blk * kPartTE);
+      const uint32_t nq = (cnt * 3 + 3) / 4;
+      uint4* dst = (uint4*)(mid + (size_t)blk * kPartTE * 3);
+      for (uint32_t q = threadIdx.x; q < nq; q += 256) dst[q] = ((const uint4*)stage)[q];
+    }
+    lds_barrier();
+  }
+  for (int i = threadIdx.x; i < nb; i += 256) fine_rows[(size_t)blockIdx.x * nb + i] = h[i] + h[kTileMaxBins + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    tmin = min(tmin, (uint32_t)__shfl_xor((int)tmin, o));
+    tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, o));
+    tor |= (uint32_t)__shfl_xor((int)tor, o);
+  }
+  if (lane == 0) {
+    atomicMin(&s_range[0], tmin);
+    atomicMax(&s_range[1], tmax);
+    atomicOr(&s_range[2], tor);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) ranges[blockIdx.x] = make_uint4(s_range[0], s_range[1], s_range[2], 0);
+}
+
+// block 0: the record format (as k_tile_scan); blocks 1 .. 64: coarse bucket k = blockIdx - 1, exclusive prefix
+// of its run lengths over the coarse pass's blocks; the rest: fine-bucket totals = column sums of fine_rows, 64
+// buckets per block, thread = (bucket, one of 16 ranges of rows), all of a thread's words requested together
+constexpr int kPartScanThreads = 1024, kPartScanRanges = kPartScanThreads / 64;
+constexpr int kPartScanPer = (kPartGridA + kPartScanRanges - 1) / kPartScanRanges;  // rows per thread, at most
+__global__ __launch_bounds__(kPartScanThreads) void k_part_scan(const uint32_t* __restrict__ rowpfx, uint32_t nblk,
+                                                                const uint32_t* __restrict__ fine_rows, uint32_t nrows,
+                                                                int nb, const uint4* __restrict__ ranges,
+                                                                uint32_t* __restrict__ colpfx, uint32_t* __restrict__ totals,
+                                                                uint32_t* __restrict__ meta, unsigned long long* n_rejected,
+                                                                int force_wide) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  if (blockIdx.x == 0) {
+    if (wave) return;
+    uint32_t mn = 0xffffffffu, mx = 0, orr = 0;
+    for (uint32_t i = lane; i < nrows; i += 64) {
+      const uint4 r = ranges[i];
+      mn = min(mn, r.x);
+      mx = max(mx, r.y);
+      orr |= r.z;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+      orr |= (uint32_t)__shfl_xor((int)orr, o);
+    }
+    if (lane == 0) {
+      const bool compact = !force_wide && (mn > mx || (mx - mn < (1u << kTileRecSecBits) && (orr >> 30) == 0));
+      meta[kTileMetaCompact] = compact ? 1u : 0u;
+      meta[kTileMetaSecBase] = mn <= mx ? mn : 0u;
+    }
+    return;
+  }
+  if (blockIdx.x <= kPartMaxCoarse) {
+    const uint32_t k = blockIdx.x - 1;
+    __shared__ uint32_t wsum[kPartScanRanges];
+    __shared__ uint32_t carry_s;
+    uint32_t* out = colpfx + (size_t)k * (nblk + 1);
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    constexpr int PER = 4;  // consecutive blocks of the coarse pass per thread and step
+    for (uint32_t b0 = 0; b0 < nblk; b0 += kPartScanThreads * PER) {
+      uint32_t len[PER], sum = 0;
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const uint32_t b = b0 + threadIdx.x * PER + q;
+        len[q] = 0;
+        if (b < nblk) len[q] = rowpfx[(size_t)(k + 1) * nblk + b] - rowpfx[(size_t)k * nblk + b];
+        sum += len[q];
+      }
+      const uint32_t ex = wave_excl_scan(sum, lane);
+      if (lane == 63) wsum[wave] = ex + sum;
+      __syncthreads();
+      uint32_t off = carry_s + ex;
+      for (int w = 0; w < wave; w++) off += wsum[w];
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        const uint32_t b = b0 + threadIdx.x * PER + q;
+        if (b < nblk) out[b] = off;
+        off += len[q];
+      }
+      __syncthreads();
+      if (threadIdx.x == kPartScanThreads - 1) carry_s = off;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[nblk] = carry_s;
+    return;
+  }
+  {
+    __shared__ uint32_t part[kPartScanRanges][64];
+    const int bin = (int)(blockIdx.x - kPartMaxCoarse - 1) * 64 + lane;
+    const uint32_t per = (nrows + kPartScanRanges - 1) / kPartScanRanges, r0 = (uint32_t)wave * per;
+    uint32_t v[kPartScanPer], s = 0;
+#pragma unroll
+    for (int q = 0; q < kPartScanPer; q++) {
+      const uint32_t r = r0 + (uint32_t)q;
+      v[q] = (bin < nb && (uint32_t)q < per && r < nrows) ? fine_rows[(size_t)r * nb + bin] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < kPartScanPer; q++) s += v[q];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && bin < nb) {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int w = 0; w < kPartScanRanges; w++) tot += part[w][lane];
+      totals[bin] = tot;
+      if (bin == nb - 1 && tot) atomicAdd(n_rejected, (unsigned long long)tot);  // out-of-sensor events
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ mid, const uint32_t* __restrict__ rowpfx,
+                                                   const uint32_t* __restrict__ colpfx, uint32_t nblk, TileGeom g,
+                                                   const uint32_t* __restrict__ totals, const uint32_t* __restrict__ meta,
+                                                   uint32_t* __restrict__ lookback, uint32_t* __restrict__ ticket,
+                                                   uint4* __restrict__ part, uint32_t* __restrict__ tile_off,
+                                                   uint32_t* __restrict__ tile_order, int* __restrict__ err,
+                                                   uint32_t spin_limit) {
+  __shared__ __attribute__((aligned(16))) uint32_t sin_[kPartTE * 3];  // the piece, in the bucket's stream order
+  __shared__ __attribute__((aligned(16))) uint2 sout[kPartTE];         // ... sorted by fine bucket, final 8-byte records
+  __shared__ uint32_t wcnt[4][kPartFine], wbase[4][kPartFine];
+  __shared__ uint32_t f_cnt[kPartFine], f_src[kPartFine], f_dst[kPartFine];
+  __shared__ uint32_t s_t;
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int nb = g.nbins, nbc = (nb + kPartFine - 1) >> kPartFineBits;
+  if (threadIdx.x == 0) s_t = atomicAdd(ticket, 1u);
+  if (threadIdx.x < 4 * kPartFine) (&wcnt[0][0])[threadIdx.x] = 0;
+  // ---- which piece: lane = coarse bucket (every wave computes the same; requested while the ticket is on its way)
+  const uint32_t ctot = lane < nbc ? colpfx[(size_t)lane * (nblk + 1) + nblk] : 0u;
+  const bool compact = meta[kTileMetaCompact] != 0;  // (uniform)
+  const uint32_t sec_base = meta[kTileMetaSecBase];
+  __syncthreads();
+  const uint32_t t = s_t;
+  const uint32_t cnp = (ctot + kPartTE - 1) / kPartTE;
+  const uint32_t cstart = wave_excl_scan(ctot, lane), pstart = wave_excl_scan(cnp, lane);
+  const uint32_t npieces = __shfl(pstart + cnp, 63);
+  if (t == 0) {
+    // the first piece also leaves the bucket offsets and the order k_tile_apply takes the buckets in: largest size
+    // class (floor(log2(events))) first, so that a bucket with many times the average number of events starts
+    // at once and the launch does not end with it (counting sort by class; the order inside a class is arbitrary)
+    __shared__ uint32_t cls_cnt[33], wtot[4];
+    constexpr int KB = kTileMaxBins / 256;
+    uint32_t loc[KB], sum = 0;
+#pragma unroll
+    for (int q = 0; q < KB; q++) {
+      const int b = threadIdx.x * KB + q;
+      loc[q] = b < nb ? totals[b] : 0u;
+      sum += loc[q];
+    }
+    const uint32_t ex = wave_excl_scan(sum, lane);
+    if (lane == 63) wtot[wave] = ex + sum;
+    if (threadIdx.x < 33) cls_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t run = ex;
+    for (int w = 0; w < wave; w++) run += wtot[w];
+    const int nt = nb - 1;
+#pragma unroll
+    for (int q = 0; q < KB; q++) {
+      const int b = threadIdx.x * KB + q;
+      if (b <= nb) tile_off[b] = run;  // (b == nb: the total)
+      run += loc[q];
+      if (b < nt) atomicAdd(&cls_cnt[loc[q] ? 32 - __clz(loc[q]) : 0], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive prefix, largest class first
+      uint32_t acc = 0;
+      for (int c = 32; c >= 0; c--) {
+        const uint32_t x = cls_cnt[c];
+        cls_cnt[c] = acc;
+        acc += x;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < KB; q++) {
+      const int b = threadIdx.x * KB + q;
+      if (b < nt) tile_order[atomicAdd(&cls_cnt[loc[q] ? 32 - __clz(loc[q]) : 0], 1u)] = (uint32_t)b;
+    }
+  }
+  if (t >= npieces) return;  // (the grid is sized for the worst case)
+  const uint32_t k = (uint32_t)__popcll(__ballot(pstart + cnp <= t));  // buckets whose pieces all come before t
+  const uint32_t j = t - __shfl(pstart, (int)k);
+  const uint32_t v0 = j * kPartTE, T = min((uint32_t)kPartTE, __shfl(ctot, (int)k) - v0);
+  const uint32_t bucket_start = __shfl(cstart, (int)k);
+  const uint32_t* col = colpfx + (size_t)k * (nblk + 1);
+  // this piece's fine buckets: their totals (requested now, needed after the ranking)
+  const int fb_lane = (int)k * kPartFine + (lane & (kPartFine - 1));
+  const uint32_t ftot_lane = fb_lane < nb ? totals[fb_lane] : 0u;
+  // the block of the coarse pass whose run holds record v0 of the bucket — the last b with col[b] <= v0 — by
+  // 256 probes at a time (two trips to memory for up to 65 536 blocks; a bisection was twelve)
+  uint32_t lo = 0, hi = nblk + 1;  // col[lo] <= v0, the answer is in [lo, hi)
+  while (hi - lo > 1) {
+    const uint32_t stride = (hi - lo + 255u) / 256u, idx = lo + threadIdx.x * stride;
+    const int c = __syncthreads_count(idx < hi && col[idx] <= v0);  // (col is non-decreasing: a prefix of the probes)
+    lo += (uint32_t)(c - 1) * stride;
+    hi = min(lo + stride, hi);
+  }
+  // ---- copy in.  The piece is made of the runs of bucket k in the blocks b0, b0 + 1, ... of the coarse pass; their
+  // descriptors go to LDS first (one thread per run: the run's first record in `mid`, its place in the piece), then
+  // every thread fetches its 8 records of the piece — all requests in flight together — finding each one's run
+  // by bisection in the table.  (A wave per run, descriptor after descriptor, was three dependent trips to
+  // memory per run.)
+  __shared__ uint32_t run_v[256], run_src[256];  // a run's first record: position in the piece | record index in `mid`
+  __shared__ uint32_t s_nr[4], s_cov;
+  for (uint32_t rb = lo, done = 0; done < T;) {  // (lo: the same in every thread)
+    __syncthreads();  // (the previous table's readers)
+    {
+      const uint32_t b = rb + threadIdx.x;
+      uint32_t vs = 0xffffffffu, r0 = 0, len = 0;
+      if (b < nblk) {
+        vs = col[b];
+        r0 = rowpfx[(size_t)k * nblk + b];
+        len = rowpfx[(size_t)(k + 1) * nblk + b] - r0;
+      }
+      const bool in = b < nblk && vs < v0 + T;
+      // the part of the run that lies inside the piece starts at piece position max(vs, v0) - v0
+      const uint32_t from = (in && vs < v0) ? v0 - vs : 0u;
+      run_v[threadIdx.x] = in ? vs + from - v0 : 0xffffffffu;
+      run_src[threadIdx.x] = b * (uint32_t)kPartTE + r0 + from;
+      const unsigned long long inm = __ballot(in);
+      if (lane == 0) s_nr[wave] = (uint32_t)__popcll(inm);
+      if (in && (b + 1 == nblk || col[b + 1] >= v0 + T)) s_cov = min(T, vs + len - v0);  // the last run of the table: where it ends
+      else if (threadIdx.x == 255 && in) s_cov = min(T, vs + len - v0);
+    }
+    __syncthreads();
+    const uint32_t nrun = s_nr[0] + s_nr[1] + s_nr[2] + s_nr[3], cov = s_cov;
+    // records [done, cov) of the piece
+    uint32_t a[kPartRounds], b2[kPartRounds], c2[kPartRounds];
+#pragma unroll
+    for (int r = 0; r < kPartRounds; r++) {
+      const uint32_t i = done + r * 256 + threadIdx.x;
+      a[r] = b2[r] = c2[r] = 0;
+      if (i < cov) {
+        uint32_t lo = 0, hi = nrun;  // run_v[lo] <= i < run_v[hi]
+        while (hi - lo > 1) {
+          const uint32_t m = (lo + hi) >> 1;
+          if (run_v[m] <= i) lo = m;
+          else hi = m;
+        }
+        const uint32_t* src = mid + (size_t)(run_src[lo] + (i - run_v[lo])) * 3;
+        a[r] = src[0];
+        b2[r] = src[1];
+        c2[r] = src[2];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kPartRounds; r++) {
+      const uint32_t i = done + r * 256 + threadIdx.x;
+      if (i < cov) {
+        sin_[i * 3] = a[r];
+        sin_[i * 3 + 1] = b2[r];
+        sin_[i * 3 + 2] = c2[r];
+      }
+    }
+    done = cov;
+    rb += 256;
+  }
+  __syncthreads();
+  // ---- rank among the 32 fine buckets: wave w takes records [w * 512, (w + 1) * 512) in rounds of 64
+  uint32_t rec_a[kPartRounds], rec_b[kPartRounds], r_dst[kPartRounds];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < kPartRounds; r++) {
+    const uint32_t i = wave * (kPartTE / 4) + r * 64 + lane;
+    const bool ok = i < T;
+    const uint32_t sec = sin_[i * 3], nsec = sin_[i * 3 + 1], m3 = sin_[i * 3 + 2];
+    const uint32_t f = (m3 >> 12) & (uint32_t)(kPartFine - 1);
+    rec_a[r] = compact ? (m3 & 0xfffu) | ((sec - sec_base) << 12) : sec;
+    rec_b[r] = nsec;
+    const unsigned long long m = match_any_bits<kPartFineBits>(f, ok);
+    const uint32_t before = __popcll(m & lt);
+    uint32_t base = 0;
+    if (ok) base = wcnt[wave][f];
+    if (ok && before == 0) wcnt[wave][f] = base + (uint32_t)__popcll(m);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+    r_dst[r] = (m3 << 12) | (base + before);  // (pixel | polarity | fine bucket: 17 bits) << 12 | rank inside (wave, bucket)
+  }
+  __syncthreads();
+  // ---- where the fine buckets' runs go: lane = fine bucket
+  if (wave == 0) {
+    uint32_t excl = 0, cnt = 0, lstart = 0;
+    if (lane < kPartFine) {
+      const uint32_t c0 = wcnt[0][lane], c1 = wcnt[1][lane], c2 = wcnt[2][lane];
+      cnt = c0 + c1 + c2 + wcnt[3][lane];
+      wbase[0][lane] = 0;
+      wbase[1][lane] = c0;
+      wbase[2][lane] = c0 + c1;
+      wbase[3][lane] = c0 + c1 + c2;
+    }
+    lstart = wave_excl_scan(cnt, lane);  // the run's start inside sout
+    // the bucket's earlier fine buckets, all of them
+    const uint32_t fstart = bucket_start + wave_excl_scan(lane < kPartFine ? ftot_lane : 0u, lane);
+    if (lane < kPartFine) {
+      // ... and this fine bucket's records in the coarse bucket's earlier pieces: decoupled look-back
+      uint32_t* my = lookback + (size_t)t * kPartFine + lane;
+      if (j == 0) {
+        __hip_atomic_store(my, kLbPrefix | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        __hip_atomic_store(my, kLbAgg | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t back = 1, spins = 0;
+        while (back <= j) {
+          const uint32_t w = __hip_atomic_load(lookback + (size_t)(t - back) * kPartFine + lane, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t st = w & ~kLbMask;
+          if (st == 0) {
+            if (++spins > spin_limit) {  // bounded (kSpinLookback polls): never hang the GPU
+              *err = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+          }
+          excl += w & kLbMask;
+          if (st == kLbPrefix) break;
+          back++;
+        }
+        __hip_atomic_store(my, kLbPrefix | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      f_cnt[lane] = cnt;
+      f_src[lane] = lstart;
+      f_dst[lane] = fstart + excl;
+    }
+  }
+  __syncthreads();
+  if (compact) {
+#pragma unroll
+    for (int r = 0; r < kPartRounds; r++) {
+      const uint32_t i = wave * (kPartTE / 4) + r * 64 + lane;
+      if (i < T) {
+        const uint32_t f = (r_dst[r] >> 24) & (uint32_t)(kPartFine - 1);
+        sout[f_src[f] + wbase[wave][f] + (r_dst[r] & 0xfffu)] = make_uint2(rec_a[r], rec_b[r]);
+      }
+    }
+    __syncthreads();
+    uint2* __restrict__ part2 = (uint2*)part;
+    for (int f = wave; f < kPartFine; f += 4) {  // every fine bucket's run: one contiguous copy
+      const uint32_t c = f_cnt[f], s0 = f_src[f], d0 = f_dst[f];
+      for (uint32_t q = lane; q < c; q += 64) part2[d0 + q] = sout[s0 + q];
+    }
+  } else {
+    // 16-byte records (a batch whose stamps do not fit the 8-byte form): the raw event rebuilt from the bucket and
+    // the tile-local pixel, stored record by record (the rare form: no staging)
+#pragma unroll
+    for (int r = 0; r < kPartRounds; r++) {
+      const uint32_t i = wave * (kPartTE / 4) + r * 64 + lane;
+      if (i < T) {
+        const uint32_t m3 = r_dst[r] >> 12, f = (m3 >> 12) & (uint32_t)(kPartFine - 1);
+        const uint32_t fb = k * kPartFine + f, cam = fb >= (uint32_t)g.nt_cam ? 1u : 0u, tt = fb - cam * (uint32_t)g.nt_cam;
+        const uint32_t ty = tt / (uint32_t)g.tiles_x, tx = tt - ty * (uint32_t)g.tiles_x;
+        const int twsh = g.tw == 64 ? 6 : 5;
+        const uint32_t pix = m3 & 0x7ffu;
+        const uint32_t x = tx * (uint32_t)g.tw + (pix & (uint32_t)(g.tw - 1)), y = ty * (uint32_t)g.th + (pix >> twsh);
+        part[f_dst[f] + wbase[wave][f] + (r_dst[r] & 0xfffu)] = make_uint4(x | (y << 16), rec_a[r], rec_b[r], (m3 >> 11) & 1u);
+      }
+    }
+  }
+}
+
+void launch_part_coarse(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
+                        const TileGeom& g, const PartScratch& ps, const McParams* mc, uint32_t* warp_xy) {
+  const uint32_t n = nL + nR;
+  if (!n) return;
+  const uint32_t nblk = part_blocks(n), grid = std::min<uint32_t>(nblk, kPartGridA);
+  const uint32_t lb_words = part_pieces_max(n) * 32u;
+  if (mc && mc->enabled) {
+    launch_k(k_mc_warp, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g.W, g.H,
+             *mc, warp_xy);
+    launch_k(k_part_coarse<true>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, nblk,
+             ps.mid, ps.rowpfx, ps.fine_rows, (uint4*)ps.ranges, (const uint32_t*)warp_xy, ps.lookback, lb_words, ps.ticket);
+  } else {
+    launch_k(k_part_coarse<false>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, nblk,
+             ps.mid, ps.rowpfx, ps.fine_rows, (uint4*)ps.ranges, (const uint32_t*)nullptr, ps.lookback, lb_words, ps.ticket);
+  }
+}
+
+void launch_part_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc, const PartScratch& ps,
+                      unsigned long long* n_rejected) {
+  if (!n) return;
+  const uint32_t nblk = part_blocks(n), nrows = std::min<uint32_t>(nblk, kPartGridA);
+  static const int force_wide = getenv("ESVIO_FE_WIDE_RECORDS") ? 1 : 0;  // (A/B and tests)
+  launch_k(k_part_scan, dim3(1 + kPartMaxCoarse + (g.nbins + 63) / 64), dim3(kPartScanThreads), 0, s,
+           (const uint32_t*)ps.rowpfx, nblk, (const uint32_t*)ps.fine_rows, nrows, g.nbins, (const uint4*)ps.ranges,
+           ps.colpfx, sc.totals, sc.meta, n_rejected, force_wide);
+}
+
+void launch_part_fine(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc, const PartScratch& ps,
+                      EventRec* part, int* err, uint32_t spin_limit) {
+  if (!n) return;
+  const uint32_t nblk = part_blocks(n);
+  launch_k(k_part_fine, dim3(part_pieces_max(n)), dim3(256), 0, s, (const uint32_t*)ps.mid, (const uint32_t*)ps.rowpfx,
+           (const uint32_t*)ps.colpfx, nblk, g, (const uint32_t*)sc.totals, (const uint32_t*)sc.meta, ps.lookback, ps.ticket,
+           (uint4*)part, sc.tile_off, sc.tile_order, err, spin_limit);
+}
+
 // One block per bucket.  The tile's {L[0],L[1]} sit in LDS; the bucket's events are taken in turns
 // of kTileTurn chunks of 64, one wave per turn, waves taking the turns round-robin.  What an event
 // needs is the time of the nearest earlier event of its own and of the other polarity at its pixel

@@ -213,6 +213,13 @@ int ensure_part_capacity(esvio_fe_ctx* c, size_t n, bool mc) {
     if (int rc = dev_alloc(c, &c->d_tile, need)) return rc;
     c->tile_cap = need;
   }
+  if (c->part_two_level && c->part2_cap < c->part_cap) {
+    if (c->d_part2) (void)hipFree(c->d_part2);
+    c->d_part2 = nullptr;
+    c->part2_cap = 0;
+    if (int rc = dev_alloc(c, &c->d_part2, part_scratch_words(c->part_cap))) return rc;
+    c->part2_cap = c->part_cap;
+  }
   return 0;
 }
 
@@ -231,17 +238,33 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
   sc.P = c->d_tile + head;
   sc.T = sc.P + nblk_cap * kTileMaxBins;
   sc.C = sc.T + (size_t)kTileMaxGroups * kTileMaxBins;
-  {
-    ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
-    launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected, mc, mc ? c->d_warp : nullptr);
-  }
-  {
-    ScopedKernel k(c, K_TILE_SCAN, 0);  // (the count matrices: not in SURVEY's accounting)
-    launch_tile_scan(cur_stream(c), n, c->tgeom, sc, c->d_rejected);
-  }
-  {
-    ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 16 B in, 16 B out
-    launch_tile_scatter(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_part, mc ? c->d_warp : nullptr);
+  if (c->part_two_level) {
+    const PartScratch ps = part_scratch(c->d_part2, c->part2_cap);
+    {
+      ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
+      launch_part_coarse(cur_stream(c), evL, nL, evR, nR, c->tgeom, ps, mc, mc ? c->d_warp : nullptr);
+    }
+    {
+      ScopedKernel k(c, K_TILE_SCAN, 0);  // (run lengths and bucket totals: not in SURVEY's accounting)
+      launch_part_scan(cur_stream(c), n, c->tgeom, sc, ps, c->d_rejected);
+    }
+    {
+      ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 12 B out, 12 B in, 8 B out
+      launch_part_fine(cur_stream(c), n, c->tgeom, sc, ps, c->d_part, c->z_counts + 3, c->lim.lookback);
+    }
+  } else {
+    {
+      ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
+      launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected, mc, mc ? c->d_warp : nullptr);
+    }
+    {
+      ScopedKernel k(c, K_TILE_SCAN, 0);  // (the count matrices: not in SURVEY's accounting)
+      launch_tile_scan(cur_stream(c), n, c->tgeom, sc, c->d_rejected);
+    }
+    {
+      ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 16 B in, 16 B out
+      launch_tile_scatter(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_part, mc ? c->d_warp : nullptr);
+    }
   }
   {
     ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);

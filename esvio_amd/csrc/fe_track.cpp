@@ -110,7 +110,7 @@ struct Launcher {
       const uint64_t d = done.load(std::memory_order_relaxed);
       if (submitted.load(std::memory_order_acquire) == d) {
         if (quit.load(std::memory_order_acquire)) return;
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((++spins & 1023) == 0 &&
             std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(2000)) {
           // (seq_cst on both sides: either the submitter sees `sleeping` and notifies under the mutex, or the
@@ -171,14 +171,14 @@ static int launcher_result(esvio_fe_ctx* c) {
 int launcher_drain(esvio_fe_ctx* c) {
   Launcher* l = c->launcher;
   if (!l) return 0;
-  while (l->done.load(std::memory_order_acquire) != l->submitted.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+  while (l->done.load(std::memory_order_acquire) != l->submitted.load(std::memory_order_relaxed)) cpu_relax();
   return launcher_result(c);
 }
 
 int launcher_wait_lane(esvio_fe_ctx* c, int lane) {
   Launcher* l = c->launcher;
   if (!l) return 0;
-  while (l->done.load(std::memory_order_acquire) < c->lane_job[lane]) __builtin_ia32_pause();
+  while (l->done.load(std::memory_order_acquire) < c->lane_job[lane]) cpu_relax();
   return launcher_result(c);
 }
 
@@ -199,7 +199,7 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first) {
   int rc = 0;
   const bool only_first = must_take_first;
   // per-kernel timers, the graph recorder and the trace's counters are the calling thread's
-  const bool async_ok = c->launcher && !c->prof_on && !c->graphs_enabled && !must_take_first;
+  const bool async_ok = c->launcher && !c->prof_on && !c->graphs_enabled && !c->trace && !must_take_first;
   if (c->launcher && !async_ok)
     if ((rc = launcher_drain(c))) return rc;  // (this call's own HIP calls go behind the jobs handed over before)
   while (!rc && !c->announced.empty() && (int)c->inflight.size() < kPrefetchDepth) {
@@ -760,8 +760,8 @@ struct TrackCall {
     //    frame, while the corner selection runs (RANSAC + mask + selection sit behind the temporal
     //    LK wait, so nothing is put in front of them);
     //  * else right away (Arc* still has to run on the main stream, or nothing to overlap with).
-    // (Handing them to a second host thread was tried: the two threads' launches serialise inside
-    // the runtime and the frame got slower, so everything stays on the calling thread.)
+    // (With esvio_fe_set_launch_thread the HIP calls of an announced batch's prefetch are issued by the
+    // handle's launch thread instead — Launcher above; the decision WHEN stays here, on the caller.)
     const bool before_sync = early_results && !PUB_THIS_FRAME;
     defer_late = !(PUB_THIS_FRAME && !arc_done) && have_next && !before_sync;
     return 0;

@@ -130,15 +130,19 @@ def test_sae_segment_lengths_around_the_wave_path(oracle, path, monkeypatch):
     ft.close()
 
 
+@pytest.mark.parametrize("two_level", [False, True])
 @pytest.mark.parametrize("case", ["span_below", "span_at", "span_above", "big_nsec", "forced_wide", "reversed"])
-def test_sae_partition_record_formats(oracle, case, monkeypatch):
+def test_sae_partition_record_formats(oracle, case, two_level, monkeypatch):
     """the tiled update partitions 8-byte records (tile-local pixel, polarity, seconds relative to the
     batch's smallest, nsec) when the batch's seconds span less than 2^20 and every nsec fits 30 bits,
     else the raw 16-byte records: planes bit-exact on both sides of the rule, with the smallest second
     not at the start of the stream, with nsec words no ros::Time would hold, and with the wide form
-    forced (ESVIO_FE_WIDE_RECORDS=1)"""
+    forced (ESVIO_FE_WIDE_RECORDS=1).  two_level: the same through the two-level partition (ESVIO_FE_PART2=1:
+    k_part_coarse / _scan / _fine, the opt-in A/B form)"""
     if case == "forced_wide":
         monkeypatch.setenv("ESVIO_FE_WIDE_RECORDS", "1")
+    if two_level:
+        monkeypatch.setenv("ESVIO_FE_PART2", "1")
     W, H = 346, 260
     rng = np.random.default_rng(77)
     n = 60000
@@ -283,6 +287,27 @@ def test_lk_parity(oracle, lk_accum):
                 lk_orders.assert_band(dist, accum)
     ok = g_st == 1
     assert ok.sum() > 150
+    ft.close()
+
+
+def test_two_level_partition_end_to_end(oracle, monkeypatch):
+    """ESVIO_FE_PART2=1 (the two-level partition, an A/B form): trackEvent on 640x480 stereo batches, plain calls
+    (the cameras' chains on two streams) and a motion-compensated batch — planes and tracks as the oracle's"""
+    monkeypatch.setenv("ESVIO_FE_PART2", "1")
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=5e6, seed=11)
+    kw = dict(f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
+    for f in range(6):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, f % 2 == 0)
+        r = tr.track_event(t, L, R, f % 2 == 0)
+        for cam in (0, 1):
+            _planes_equal(ft.detector.get_sae(cam), tr.detector().get_sae(cam))
+        assert np.array_equal(ft.ids, r.ids) and np.array_equal(ft.cur_pts, r.cur_pts)
+        assert np.array_equal(ft.cur_right_pts, r.cur_right_pts)
     ft.close()
 
 
