@@ -281,6 +281,8 @@ void launch_ts_pyr_cam(hipStream_t s, const double2* S2_cam, double t_sync, doub
                        const PyrDesc* p);  // one camera (S2_cam: its planes, p: its pyramid)
 void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay_sec,
                    int ignore_polarity, const PyrDesc* p);
+// levels 1..3 of nimg images whose level 0 is in place, one launch (maxLevel 3)
+void launch_pyr3(hipStream_t s, const PyrDesc* p, int nimg);
 void launch_pyr_pad(hipStream_t s, const PyrDesc* p, int nimg);
 void launch_pad_scharr(hipStream_t s, const PyrDesc* p, int nimg);  // k_pyr_pad + k_scharr, one launch
 void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg);

@@ -2088,11 +2088,37 @@ __global__ __launch_bounds__(256) void k_time_surface(const double2* __restrict_
   dst[(size_t)(y + kPad) * stride + x + kPad] = ts_pixel(s, t_sync, decay_sec, ignore_polarity);
 }
 
+// four consecutive pixels of a row per thread (W a multiple of 4): 64 B of planes in, one dword out — the render
+// at its roof: every S2 word read once, every pixel written once, nothing else
+__global__ __launch_bounds__(256) void k_time_surface4(const double2* __restrict__ S2, int W, int H, double t_sync,
+                                                       double decay_sec, int ignore_polarity,
+                                                       uint8_t* __restrict__ dst0, uint8_t* __restrict__ dst1, int stride) {
+  const int cam = blockIdx.y;
+  const uint32_t P = (uint32_t)W * H;
+  const uint32_t px = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+  if (px >= P) return;
+  uint8_t* dst = cam ? dst1 : dst0;
+  const double2* src = S2 + (size_t)cam * P + px;
+  double2 sv[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) sv[k] = src[k];
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) out |= (uint32_t)ts_pixel(sv[k], t_sync, decay_sec, ignore_polarity) << (8 * k);
+  const uint32_t y = px / (uint32_t)W, x = px - y * (uint32_t)W;
+  *(uint32_t*)(dst + (size_t)(y + kPad) * stride + x + kPad) = out;  // (kPad and the stride are multiples of 4)
+}
+
 void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
                          double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
                          int dst_stride, int ncam) {
   const uint32_t P = (uint32_t)W * H;
-  launch_k(k_time_surface, dim3((P + 255) / 256, ncam), dim3(256), 0, s, S2, W, H,
+  static_assert(kPad % 4 == 0, "dword stores into the padded level");
+  if (W % 4 == 0 && dst_stride % 4 == 0 && ((uintptr_t)dst0 & 3) == 0 && (ncam < 2 || ((uintptr_t)dst1 & 3) == 0))
+    launch_k(k_time_surface4, dim3((P / 4 + 255) / 256, ncam), dim3(256), 0, s, S2, W, H, t_sync, decay_sec,
+             ignore_polarity, dst0, dst1, dst_stride);
+  else
+    launch_k(k_time_surface, dim3((P + 255) / 256, ncam), dim3(256), 0, s, S2, W, H,
                      t_sync, decay_sec, ignore_polarity, dst0, dst1, dst_stride);
 }
 
@@ -2358,7 +2384,9 @@ struct EqSrc {
   const int* minmax;
 };
 
-template <bool FROM_IMG>
+// MODE 0: level 0 rendered from the SAE here; 1 (FROM_IMG): normalised from an image; 2: level 0 is in the
+// pyramid already (k_time_surface4 wrote it) — only the three pyrDown levels
+template <int MODE>
 __device__ __forceinline__ void ts_pyr_body(const double2* __restrict__ S2, double t_sync, double decay_sec,
                                             int ignore_polarity, const EqSrc& eq, const PyrPack& pk) {
   __shared__ uint8_t l0[kFt0y * kFs0];
@@ -2372,6 +2400,16 @@ __device__ __forceinline__ void ts_pyr_body(const double2* __restrict__ S2, doub
   const int o1x = 2 * o2x - 2, o1y = 2 * o2y - 2;
   const int o0x = 2 * o1x - 2, o0y = 2 * o1y - 2;
   constexpr int kN0 = kFt0x * kFt0y;
+  constexpr bool FROM_IMG = MODE == 1;
+  if (MODE == 2) {
+    const uint8_t* src = p.img[0] + (size_t)kPad * p.stride[0] + kPad;
+    for (int i = threadIdx.x; i < kN0; i += kFtThreads) {
+      const int ry = i / kFt0x, rx = i - ry * kFt0x;
+      const int x = o0x + rx, y = o0y + ry;
+      if (x < 0 || y < 0 || x >= W || y >= H) continue;
+      l0[ry * kFs0 + rx] = src[(size_t)y * p.stride[0] + x];
+    }
+  }
   if (FROM_IMG) {
     const double smin = eq.minmax[2 * cam], smax = eq.minmax[2 * cam + 1];
     const double scale = 255.0 * (__dsub_rn(smax, smin) > 2.2204460492503131e-16 ? 1. / __dsub_rn(smax, smin) : 0);
@@ -2390,7 +2428,7 @@ __device__ __forceinline__ void ts_pyr_body(const double2* __restrict__ S2, doub
   }
   const double2* S = S2 + (size_t)cam * W * H;
   // (four pixels per thread and step, loads first: the 16 B gathers are what the loop waits for)
-  for (int i0 = threadIdx.x; !FROM_IMG && i0 < kN0; i0 += 4 * kFtThreads) {
+  for (int i0 = threadIdx.x; MODE == 0 && i0 < kN0; i0 += 4 * kFtThreads) {
     double2 sv[4];
     int xs[4], ys[4];
     bool ok[4];
@@ -2427,10 +2465,15 @@ __device__ __forceinline__ void ts_pyr_body(const double2* __restrict__ S2, doub
 
 __global__ __launch_bounds__(kFtThreads) void k_ts_pyr(const double2* __restrict__ S2, double t_sync,
                                                 double decay_sec, int ignore_polarity, PyrPack pk) {
-  ts_pyr_body<false>(S2, t_sync, decay_sec, ignore_polarity, EqSrc{}, pk);
+  ts_pyr_body<0>(S2, t_sync, decay_sec, ignore_polarity, EqSrc{}, pk);
 }
 __global__ __launch_bounds__(kFtThreads) void k_norm_pyr(EqSrc eq, PyrPack pk) {
-  ts_pyr_body<true>(nullptr, 0.0, 0.0, 0, eq, pk);
+  ts_pyr_body<1>(nullptr, 0.0, 0.0, 0, eq, pk);
+}
+// the three pyrDown levels of images whose level 0 is in place (the split render: k_time_surface4, then this —
+// every S2 word is read once and every level-0 pixel rendered once; the tiles' halos re-read bytes, not planes)
+__global__ __launch_bounds__(kFtThreads) void k_pyr3(PyrPack pk) {
+  ts_pyr_body<2>(nullptr, 0.0, 0.0, 0, EqSrc{}, pk);
 }
 
 // both cameras (p[0], p[1]), maxLevel 3
@@ -2439,6 +2482,12 @@ void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay
   const int w3 = p[0].w[3], h3 = p[0].h[3];
   launch_k(k_ts_pyr, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, 2), dim3(kFtThreads), 0, s, S2,
            t_sync, decay_sec, ignore_polarity, make_pack(p, 2));
+}
+
+void launch_pyr3(hipStream_t s, const PyrDesc* p, int nimg) {
+  const int w3 = p[0].w[3], h3 = p[0].h[3];
+  launch_k(k_pyr3, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, nimg), dim3(kFtThreads), 0, s,
+           make_pack(p, nimg));
 }
 
 // one camera: S2 points at that camera's planes, p at its pyramid

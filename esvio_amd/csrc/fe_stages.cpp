@@ -440,7 +440,17 @@ void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int 
     pyr_build(c, two, 2);
     return;
   }
-  {
+  if (c->split_render) {
+    {
+      ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * 2);
+      launch_time_surface(cur_stream(c), c->S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0, c->cfg.ignore_polarity,
+                          two[0].img[0], two[1].img[0], two[0].stride[0], 2);
+    }
+    uint64_t px = 0;
+    for (int l = 0; l <= 3; l++) px += (uint64_t)two[0].w[l] * two[0].h[l];
+    ScopedKernel k(c, K_PYR_DOWN, px * 2);
+    launch_pyr3(cur_stream(c), two, 2);
+  } else {
     uint64_t px = 0;
     for (int l = 0; l <= 3; l++) px += (uint64_t)two[0].w[l] * two[0].h[l];
     ScopedKernel k(c, K_TIME_SURFACE, ((uint64_t)c->P * 16 + px) * 2);
@@ -462,7 +472,15 @@ void render_and_build_cam(esvio_fe_ctx* c, double t_sync, int cam, int slot) {
   const PyrDesc one = c->pyr[slot].d;
   uint64_t px = 0;
   for (int l = 0; l <= 3; l++) px += (uint64_t)one.w[l] * one.h[l];
-  {
+  if (c->split_render) {
+    {
+      ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17);
+      launch_time_surface(cur_stream(c), c->S2 + (size_t)cam * c->P, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
+                          c->cfg.ignore_polarity, one.img[0], one.img[0], one.stride[0], 1);
+    }
+    ScopedKernel k(c, K_PYR_DOWN, px);
+    launch_pyr3(cur_stream(c), &one, 1);
+  } else {
     ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 16 + px);
     launch_ts_pyr_cam(cur_stream(c), c->S2 + (size_t)cam * c->P, t_sync, c->cfg.decay_ms / 1000.0,
                       c->cfg.ignore_polarity, &one);

@@ -290,6 +290,28 @@ def test_lk_parity(oracle, lk_accum):
     ft.close()
 
 
+@pytest.mark.parametrize("W,H,split", [(640, 480, 1), (346, 260, 1), (1280, 720, 0), (1280, 720, 1)])
+def test_render_in_one_and_in_two_launches(oracle, monkeypatch, W, H, split):
+    """the plain configuration's time surface + pyramid: one launch (k_ts_pyr, the default below 600 k pixels) or two
+    (k_time_surface4 — one pixel per thread where the rows are no multiple of 4 — then k_pyr3, the default
+    above): both forms at sizes where they are not the default, images and tracks as the oracle's"""
+    monkeypatch.setenv("ESVIO_FE_SPLIT_RENDER", str(split))
+    s = SceneStream(W, H, rate=2e6, seed=21)
+    kw = dict(max_cnt=150, min_dist=15)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
+    for f in range(3):
+        L, R, _ = s.next_batch()
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, True)
+        r = tr.track_event(t, L, R, True)
+        assert np.array_equal(ft.gettimesurface(0), tr.time_surface(0))
+        assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1))
+        assert np.array_equal(ft.ids, r.ids) and np.array_equal(ft.cur_pts, r.cur_pts)
+        assert np.array_equal(ft.ids_right, r.ids_right) and np.array_equal(ft.cur_right_pts, r.cur_right_pts)
+    ft.close()
+
+
 def test_two_level_partition_end_to_end(oracle, monkeypatch):
     """ESVIO_FE_PART2=1 (the two-level partition, an A/B form): trackEvent on 640x480 stereo batches, plain calls
     (the cameras' chains on two streams) and a motion-compensated batch — planes and tracks as the oracle's"""
