@@ -1237,6 +1237,24 @@ int esvio_fe_mem_upload(void* dst_device, const void* src_host, size_t bytes) {
   return hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : ESVIO_FE_EHIP;
 }
 
+int esvio_fe_register_host_buffer(void* p, size_t bytes) {
+  if (!p || !bytes) return ESVIO_FE_EINVAL;
+  if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return ESVIO_FE_EHIP;
+  }
+  return 0;
+}
+
+int esvio_fe_unregister_host_buffer(void* p) {
+  if (!p) return ESVIO_FE_EINVAL;
+  if (hipHostUnregister(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return ESVIO_FE_EHIP;
+  }
+  return 0;
+}
+
 int esvio_fe_debug_inject(esvio_fe_handle c, int mask) {
   if (!c || mask < 0 || mask > 15) return ESVIO_FE_EINVAL;
   c->lim = esvio_fe_ctx::WaitLimits();

@@ -661,31 +661,6 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
 // ============================================================================ SAE update, tiled
 // See fe_kernels.h (TileGeom).  Bucket of an event = camera * nt_cam + (y / th) * tiles_x + x / tw,
 // or the last bin for an out-of-sensor event.
-bool make_tile_geom(int W, int H, TileGeom* g) {
-  // the smallest tile whose bucket count fits (a larger one was measured at C5: 64x32 takes 10 % off the
-  // scatter and adds 50 % to the apply)
-  static const int cand[][2] = {{32, 16}, {32, 32}, {64, 32}};
-  for (const auto& c : cand) {
-    const int tx = (W + c[0] - 1) / c[0], ty = (H + c[1] - 1) / c[1];
-    const int nb = 2 * tx * ty + 1;
-    if (nb > kTileMaxBins || c[0] * c[1] > kTileMaxPx) continue;
-    g->W = W;
-    g->H = H;
-    g->tw = c[0];
-    g->th = c[1];
-    g->tiles_x = tx;
-    g->tiles_y = ty;
-    g->nt_cam = tx * ty;
-    g->nbins = nb;
-    g->bits = 1;
-    while ((1 << g->bits) < nb) g->bits++;
-    g->pix_bits = 1;
-    while ((1 << g->pix_bits) < c[0] * c[1]) g->pix_bits++;
-    return true;
-  }
-  return false;
-}
-
 // The partitioned records.  Wide: the raw 16-byte dvs_msgs::Event.  Compact (8 bytes; the default
 // whenever the batch allows it, k_tile_scan): x = tile-local pixel (11 bits) | polarity << 11 |
 // (sec - sec_base) << 12 (20 bits), y = nsec (30 bits) — everything k_tile_apply needs, at half
@@ -4728,17 +4703,6 @@ __global__ __launch_bounds__(kSelMwThreads) void k_select_mw(SelectArgs a) {
       a.host_counts[2] = (int)total;
     }
   }
-}
-
-int disc_threshold(const int8_t* hw, int radius) {
-  long inside = -1, outside = (long)(radius + 1) * (radius + 1);
-  for (int dy = 0; dy <= radius && dy <= kMaxDiscR; dy++) {
-    const long h = hw[dy];
-    if (h >= 0) inside = inside > h * h + (long)dy * dy ? inside : h * h + (long)dy * dy;
-    const long o = (h + 1) * (h + 1) + (long)dy * dy;  // (h = -1: the row's centre pixel is outside)
-    outside = outside < o ? outside : o;
-  }
-  return inside >= 0 && inside < outside ? (int)inside : -1;
 }
 
 void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {

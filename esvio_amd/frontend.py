@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
     "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
     "esvio_fe_set_next_batch", "esvio_fe_set_next_batch_mc", "esvio_fe_mem_alloc", "esvio_fe_mem_free",
-    "esvio_fe_mem_upload", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
+    "esvio_fe_mem_upload", "esvio_fe_register_host_buffer", "esvio_fe_unregister_host_buffer", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
     "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
     "esvio_fe_set_host_threads", "esvio_fe_ransac_stats", "esvio_fe_get_time_surface",
     "esvio_fe_export_image", "esvio_fe_import_image", "esvio_fe_set_profiling", "esvio_fe_kernel_count",
@@ -159,6 +159,8 @@ def load_library(build_if_missing=True):
     L.esvio_fe_mem_alloc.argtypes = [i, sz, vp]
     L.esvio_fe_mem_free.argtypes = [i, vp]
     L.esvio_fe_mem_upload.argtypes = [vp, vp, sz]
+    L.esvio_fe_register_host_buffer.argtypes = [vp, sz]
+    L.esvio_fe_unregister_host_buffer.argtypes = [vp]
     L.esvio_fe_debug_inject.argtypes = [vp, i]
     L.esvio_fe_debug_counters.argtypes = [vp, vp]
     L.esvio_fe_plain_call_counters.argtypes = [vp, vp]
@@ -703,6 +705,24 @@ class EventBuffer:
             load_library().esvio_fe_mem_free(self.space, self.ptr)
             self.ptr = None
             self.array = None
+
+
+class RegisteredEvents:
+    """a caller-owned numpy event array page-locked where it lies (esvio_fe_register_host_buffer): batches handed
+    over from it cross PCIe without the staging copy; `.array` is the array itself"""
+
+    def __init__(self, events):
+        self.array = np.ascontiguousarray(events)
+        assert self.array.dtype.itemsize == 16 and len(self.array)
+        rc = load_library().esvio_fe_register_host_buffer(_p(self.array), self.array.nbytes)
+        if rc:
+            raise FrontendError("esvio_fe_register_host_buffer rc=%d" % rc)
+        self.registered = True
+
+    def free(self):
+        if self.registered:
+            load_library().esvio_fe_unregister_host_buffer(_p(self.array))
+            self.registered = False
 
 
 def host_nullspace(systems, lanes):

@@ -370,6 +370,14 @@ int esvio_fe_sae_slice_commit(esvio_fe_handle h, const double* last_all, const d
 int esvio_fe_mem_alloc(int space, size_t bytes, void** out);
 int esvio_fe_mem_free(int space, void* p);
 int esvio_fe_mem_upload(void* dst_device, const void* src_host, size_t bytes);
+/* ... or the caller's own storage, page-locked where it lies: esvio_fe_register_host_buffer(p, bytes) once for a
+ * buffer that event batches are handed over from again and again (the deserialisation buffer of the driver callback,
+ * a ring of EventArray storage, stereo_event_tracker_node.cpp:128-142,399) — every later batch inside [p, p + bytes)
+ * then crosses PCIe straight from there: no staging copy by the CPU at all.  Registering costs a system call and
+ * a page walk (~0.1 ms per MB): per buffer, not per batch.  esvio_fe_unregister_host_buffer(p) before the memory
+ * is freed.  (hipHostRegister / hipHostUnregister through the library's own HIP runtime.) */
+int esvio_fe_register_host_buffer(void* p, size_t bytes);
+int esvio_fe_unregister_host_buffer(void* p);
 
 /* ---- capacity ----------------------------------------------------------------------------- */
 /* Every event-proportional device buffer (partition scratch, candidate sets, staging lanes) grows on

@@ -174,7 +174,7 @@ def test_announce_after_return_with_lazy_unpublished_frames(oracle, space):
         b.free()
 
 
-@pytest.mark.parametrize("space", ["host", "device"])
+@pytest.mark.parametrize("space", ["host", "device", "registered"])
 @pytest.mark.parametrize("split", [True, False])
 def test_plain_calls_with_the_cameras_on_two_streams(oracle, monkeypatch, space, split):
     """A plain call (nothing announced, nothing lazy: the reference node's pattern) runs the left camera's
@@ -200,6 +200,10 @@ def test_plain_calls_with_the_cameras_on_two_streams(oracle, monkeypatch, space,
     def args(L, R):
         if space == "host":
             return L, R
+        if space == "registered":  # the caller's own arrays, page-locked where they lie (esvio_fe_register_host_buffer)
+            regs = [FE.RegisteredEvents(a) if len(a) else None for a in (L, R)]
+            bufs.extend(r for r in regs if r)
+            return tuple(r.array if r else a for r, a in zip(regs, (L, R)))
         bl, br = FE.EventBuffer(L, FE.DEVICE), FE.EventBuffer(R, FE.DEVICE)
         bufs.extend([bl, br])
         return bl.arg, br.arg
@@ -230,7 +234,7 @@ def test_plain_calls_with_the_cameras_on_two_streams(oracle, monkeypatch, space,
     n = ft.plain_call_counters()
     assert n["plain_calls"] >= 10 and n["stereo_chained"] > 0 and n["chained_redone"] == 0, n
     # (13 plain calls; no. 4 has no right events; no. 7 from pageable memory is below the staging threshold)
-    assert n["split_by_camera"] == ((n["plain_calls"] - (2 if space == "host" else 1)) if split else 0), n
+    assert n["split_by_camera"] == ((n["plain_calls"] - (2 if space in ("host", "registered") else 1)) if split else 0), n
     assert len(ft.ids) > 60
     ft.close()
     for b in bufs:
