@@ -387,7 +387,10 @@ def main():
     class Runner:
         """one tracker + the schedule it is driven with"""
 
-        def __init__(self, pipeline, lazy, batches, exch=None, rig=None, tsl=None, comm=None, config=None):
+        def __init__(self, pipeline, lazy, batches, exch=None, rig=None, tsl=None, comm=None, config=None,
+                     host_threads=None, launch_thread=None):
+            host_threads = args.host_threads if host_threads is None else host_threads
+            launch_thread = args.launch_thread if launch_thread is None else launch_thread
             self.ft = FE.FeatureTracker(config if config is not None else cfg)
             self.comm = comm is not None
             if comm is not None:
@@ -397,9 +400,9 @@ def main():
             self.announced = 0
             if lazy:
                 self.ft.set_lazy_new_stereo(True)
-            if args.host_threads > 1:
-                self.ft.set_host_threads(args.host_threads)
-            if pipeline and args.launch_thread:
+            if host_threads > 1:
+                self.ft.set_host_threads(host_threads)
+            if pipeline and launch_thread:
                 self.ft.set_launch_thread(True)
             # set-up, not a step: every event-proportional buffer sized for the stream's largest batch, so
             # that no timed call allocates (`tail_latency.allocs` in the line counts the ones that do)
@@ -640,10 +643,10 @@ def main():
                         schedule="one batch in flight, no speculative / chained / lazy launches "
                                  "(clean kernel durations); the timed region uses the replay schedule")
 
-    def side_pass(pipe, lz, batches, config=None):
+    def side_pass(pipe, lz, batches, config=None, host_threads=None, launch_thread=None):
         """one more tracker over the same frames as pass 0 (its own warm-up, then --steps timed steps);
         reported beside `value`, never as it"""
-        run = Runner(pipe, lz, batches, config=config)
+        run = Runner(pipe, lz, batches, config=config, host_threads=host_threads, launch_thread=launch_thread)
         for i in range(args.warmup):
             run.step(i, exchange=False)
         torch.cuda.synchronize()
@@ -710,6 +713,34 @@ def main():
                             "reference build's float arithmetic); never `value`" if other == 1 else
                             "lk_accum 2: LK sums in float in the order of the reference's x86 OpenCV build "
                             "(bit-exact against the oracle's float-order mode); never `value`")
+
+    # ---- what a small host gets (a robot's companion computer is not a 256-CPU server): the same replay schedule
+    # (a) with ONE host thread — no RANSAC helpers, no launch thread — on whatever CPUs this process has, and
+    # (b) confined to TWO CPUs with two threads (the caller and one helper that blocks when idle).  Never `value`.
+    low_cpu = None
+    if extra:
+        one, _, _ = side_pass(pipeline, lazy, dev_batches, host_threads=1, launch_thread=0)
+        low_cpu = dict(one_host_thread_ms_per_step=one["ms_per_step"], one_host_thread_call_ms_max=one["call_ms_max"])
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+            if len(cpus) >= 2:
+                spin = os.environ.get("ESVIO_FE_HELPER_SPIN_US")
+                os.environ["ESVIO_FE_HELPER_SPIN_US"] = "30"
+                os.sched_setaffinity(0, set(cpus[:2]))
+                try:
+                    two, _, _ = side_pass(pipeline, lazy, dev_batches, host_threads=2, launch_thread=0)
+                finally:
+                    os.sched_setaffinity(0, set(cpus))
+                    if spin is None:
+                        os.environ.pop("ESVIO_FE_HELPER_SPIN_US", None)
+                    else:
+                        os.environ["ESVIO_FE_HELPER_SPIN_US"] = spin
+                low_cpu.update(two_cpus_two_threads_ms_per_step=two["ms_per_step"], two_cpus_call_ms_max=two["call_ms_max"],
+                               two_cpus=cpus[:2])
+        except OSError as e:  # (no affinity control here)
+            low_cpu["two_cpus_error"] = str(e)
+        low_cpu["note"] = ("replay schedule, device-resident events, lk_accum %d; the headline uses %d host threads%s"
+                           % (args.lk_accum, max(1, args.host_threads), " + the launch thread" if args.launch_thread else ""))
 
     # ---- the HBM-bound kernels at a batch size where they are HBM-bound: createSAE_left/right of one
     # stereo batch at C5's sensor shape and rate (1280x720, 100 Mev/s per camera: 6.7 M events), device
@@ -784,8 +815,9 @@ def main():
         tc = time.perf_counter() - tc0
         st = tr_o.stage_seconds()
         cpu = dict(value=round(ev / tc / 1e6, 3), unit="Mevents/s", cores=1, kind="port",
-                   sample="%d stereo batches (%d events) of the same stream, oracle/liboracle.so, 1 thread"
-                          % (nfr, ev),
+                   sample="%d stereo batches (%d events) of the same stream, oracle/liboracle.so, 1 thread; LK loop: %s"
+                          % (nfr, ev, "lk_accum 2 = the x86 SIMD128 loop on SSE2 registers (b vector and A matrix sums; the "
+                                      "window extraction is scalar)" if args.lk_accum == 2 else "lk_accum 1 = scalar loop, int64 sums"),
                    ms_per_step=round(tc / nfr * 1e3, 3),
                    stage_ms_per_step={k: round(v / nfr * 1e3, 3) for k, v in st.items()},
                    host_cpus=os.cpu_count(), usable_cpus=usable_cpus())
@@ -796,14 +828,18 @@ def main():
             # iteration from the gfx950 ISA of lk_point's loop; issue rate of a lone wave from
             # tools/clock_probe.hip.
             ps = O.lk_pair_stats(True)
-            instr, cyc, ghz = 175, 5.2, 2.4
-            us_iter = instr * cyc / (ghz * 1e3)
+            # round 5's loops (gfx950 ISA of lk_point's inner loop, every instruction counted — a lone wave issues one
+            # instruction of ANY kind per ~4 cycles at best): exact sums 129, float order 185 (one walking round);
+            # us per iteration and the per-launch constant from tools/lk_const_probe.py on this GPU
+            instr, us_iter, const_us = (129, 0.336, 8.5) if args.lk_accum == 1 else (185, 0.507, 11.0)
+            ghz = 2.4
             roof["issue_model"] = dict(
+                lk_accum=args.lk_accum,
                 iterations_slowest_point_per_launch=round(ps["slowest_mean"], 1),
                 iterations_mean_per_point=round(ps["mean_per_point"], 1),
-                instructions_per_iteration=instr, cycles_per_instruction_lone_wave=cyc, clock_GHz=ghz,
-                us_per_iteration=round(us_iter, 3),
-                modeled_us=round(ps["slowest_mean"] * us_iter, 1), measured_us=roof["avg_launch_us"],
+                instructions_per_iteration=instr, cycles_per_instruction_lone_wave=round(us_iter * ghz * 1e3 / instr, 2),
+                clock_GHz=ghz, us_per_iteration=us_iter, launch_constant_us=const_us,
+                modeled_us=round(ps["slowest_mean"] * us_iter + const_us, 1), measured_us=roof["avg_launch_us"],
                 note="latency-bound by construction: the HBM fraction of this kernel says nothing about "
                      "its quality; the streaming kernels' fractions are in `kernels`")
         if args.cpu_procs != 0:
@@ -934,6 +970,9 @@ def main():
                                            "%.4f device-resident, %.4f host-registered, %.4f host-pageable"
                                            % (one_batch["device_resident_ms_per_step"], one_batch["host_registered_ms_per_step"],
                                               one_batch["host_pageable_ms_per_step"])),
+                "low_cpu_ms": (None if low_cpu is None else "1 host thread %.4f; 2 CPUs / 2 threads %s"
+                               % (low_cpu["one_host_thread_ms_per_step"],
+                                  ("%.4f" % low_cpu["two_cpus_two_threads_ms_per_step"]) if "two_cpus_two_threads_ms_per_step" in low_cpu else "n/a")),
                 "other_lk_mode_ms": None if other_lk is None else "lk_accum %d: %.4f" % (other_lk["lk_accum"], other_lk["ms_per_step"]),
                 "kernel_ms_per_step_summed": None if device_activity is None else device_activity["kernel_ms_per_step_summed"],
             },
@@ -953,6 +992,7 @@ def main():
             # ---- the driver keeps the END of the line: what a reader needs beside `value` comes last
             "tail_latency": tail,
             "one_batch_in_flight": one_batch,
+            "low_cpu": low_cpu,
             ("exact_sum_lk" if args.lk_accum == 2 else "float_order_lk"): other_lk,
             "host_resident_events": host_res,
             # the timed --steps region repeated over the continued stream (pass 0 = ms_per_step above)
