@@ -228,11 +228,17 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
 // 2048 events sorted into its own slot of `mid`; then pieces of 2048 records of a coarse bucket into their final
 // places (fe_kernels.hip: k_part_coarse / k_part_scan / k_part_fine).  Leaves `part`, tile_off, tile_order, totals
 // and meta exactly as the three launches above do.
-constexpr int kPartTE = 2048;    // events per block of the coarse pass = records per piece of the fine pass
-constexpr int kPartGridA = 768;  // persistent blocks of the coarse pass (3 per CU: 42 KiB of LDS each)
+constexpr int kPartTE = 2048;     // events per block of the coarse pass
+constexpr int kPartPiece = 2048;  // records per piece of the fine pass (1024: twice the blocks, 115 -> 120 us at 6.7 M events)
+constexpr int kPartGridA = 768;   // persistent blocks of the coarse pass (3 per CU: 42 KiB of LDS each)
+constexpr int kPartRows = 67;     // per block of the coarse pass: 65 run starts, the block's base second, its "wide" flag
 struct PartScratch {
-  uint32_t* mid;        // [n][3] {sec, nsec, tile-local pixel | polarity << 11 | bucket inside its coarse bucket << 12}
-  uint32_t* rowpfx;     // [blocks][65] run starts of the coarse buckets inside a block's slot
+  // a block's slot holds its 2048 events sorted by coarse bucket, 8 bytes each — {tile-local pixel | polarity << 11 |
+  // bucket inside its coarse bucket << 12 | (sec - the block's base second) << 17, nsec} — or, for a block whose
+  // seconds span 2^15 or more, 12 bytes each {sec, nsec, the low 17 bits} in mid12 (same slot number)
+  uint32_t* mid8;       // [n][2]
+  uint32_t* mid12;      // [n][3]
+  uint32_t* rowpfx;     // [kPartRows][blocks]
   uint32_t* fine_rows;  // [kPartGridA][nbins] bucket counts per persistent block
   uint32_t* ranges;     // [kPartGridA][4]
   uint32_t* colpfx;     // [64][blocks + 1] a coarse bucket's run lengths, exclusive prefix over the blocks
@@ -240,19 +246,22 @@ struct PartScratch {
   uint32_t* ticket;
 };
 inline uint32_t part_blocks(size_t n) { return (uint32_t)((n + kPartTE - 1) / kPartTE); }
-inline uint32_t part_pieces_max(size_t n) { return part_blocks(n) + 64u; }
+inline uint32_t part_pieces_max(size_t n) { return (uint32_t)((n + kPartPiece - 1) / kPartPiece) + 64u; }
 inline size_t part_scratch_words(size_t cap) {
-  const size_t nb = part_blocks(cap);
-  return cap * 3 + 4 + nb * 65 + (size_t)kPartGridA * kTileMaxBins + (size_t)kPartGridA * 4 + 64 * (nb + 1) +
-         (size_t)part_pieces_max(cap) * 32 + 4;
+  cap = (cap + 3) & ~(size_t)3;  // (every part 16-byte aligned)
+  const size_t nb = (part_blocks(cap) + 3) & ~(size_t)3;
+  return (size_t)kPartGridA * 4 + cap * 2 + 4 + cap * 3 + 4 + nb * kPartRows + (size_t)kPartGridA * kTileMaxBins +
+         64 * (nb + 1) + (size_t)part_pieces_max(cap) * 32 + 4;
 }
 inline PartScratch part_scratch(uint32_t* base, size_t cap) {
-  const size_t nb = part_blocks(cap);
+  cap = (cap + 3) & ~(size_t)3;
+  const size_t nb = (part_blocks(cap) + 3) & ~(size_t)3;
   PartScratch p;
   p.ranges = base;  // (16-byte aligned: first)
-  p.mid = p.ranges + (size_t)kPartGridA * 4;
-  p.rowpfx = p.mid + cap * 3 + 4;
-  p.fine_rows = p.rowpfx + nb * 65;
+  p.mid8 = p.ranges + (size_t)kPartGridA * 4;
+  p.mid12 = p.mid8 + cap * 2 + 4;
+  p.rowpfx = p.mid12 + cap * 3 + 4;
+  p.fine_rows = p.rowpfx + nb * kPartRows;
   p.colpfx = p.fine_rows + (size_t)kPartGridA * kTileMaxBins;
   p.lookback = p.colpfx + 64 * (nb + 1);
   p.ticket = p.lookback + (size_t)part_pieces_max(cap) * 32;

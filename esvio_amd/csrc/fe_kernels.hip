@@ -1231,15 +1231,15 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane) {  // e
 template <bool MC>
 __global__ __launch_bounds__(256) void k_part_coarse(const uint4* __restrict__ evL, uint32_t nL,
                                                      const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
-                                                     uint32_t nblk, uint32_t* __restrict__ mid,
-                                                     uint32_t* __restrict__ rowpfx, uint32_t* __restrict__ fine_rows,
+                                                     uint32_t nblk, uint32_t* __restrict__ mid8,
+                                                     uint32_t* __restrict__ mid12, uint32_t* __restrict__ rowpfx, uint32_t* __restrict__ fine_rows,
                                                      uint4* __restrict__ ranges, const uint32_t* __restrict__ warp_xy,
                                                      uint32_t* __restrict__ lookback, uint32_t lookback_words,
                                                      uint32_t* __restrict__ ticket) {
   __shared__ __attribute__((aligned(16))) uint32_t stage[kPartTE * 3];  // the block's slot of `mid`, as it will lie in memory
   __shared__ uint32_t h[2 * kTileMaxBins];  // fine-bucket counts, two copies by lane parity (runs of one bucket)
   __shared__ uint32_t wcnt[4][kPartMaxCoarse], cbase[4][kPartMaxCoarse];
-  __shared__ uint32_t s_range[3];
+  __shared__ uint32_t s_range[3], s_wide;
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int nb = g.nbins;
   const uint32_t n = nL + nR;
@@ -1249,6 +1249,7 @@ __global__ __launch_bounds__(256) void k_part_coarse(const uint4* __restrict__ e
     s_range[0] = 0xffffffffu;
     s_range[1] = 0;
     s_range[2] = 0;
+    s_wide = 0;
   }
   // (the fine pass's look-back words and ticket: this kernel has ended before that one starts)
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < lookback_words; i += gridDim.x * 256u) lookback[i] = 0;
@@ -1259,9 +1260,11 @@ __global__ __launch_bounds__(256) void k_part_coarse(const uint4* __restrict__ e
   // (the block's NEXT 2048 events are requested while the current ones are ranked and stored: the barriers inside
   // the loop order LDS traffic only, so nothing in it waits for HBM except the first use of a record)
   uint4 ne[kPartRounds];
-  uint32_t nwxy[kPartRounds];
+  uint32_t nwxy[kPartRounds], nsec0 = 0;
   auto request = [&](uint32_t blk) {
     const uint32_t wb = blk * kPartTE + wave * (kPartTE / 4);
+    // (the block's first event's second: the 8-byte records carry seconds relative to it)
+    if (blk < nblk) nsec0 = blk * kPartTE < nL ? evL[blk * kPartTE].y : evR[blk * kPartTE - nL].y;
 #pragma unroll
     for (int r = 0; r < kPartRounds; r++) {  // (whole records: one contiguous 1 KiB request per wave)
       const uint32_t i = wb + r * 64 + lane;
@@ -1272,6 +1275,7 @@ __global__ __launch_bounds__(256) void k_part_coarse(const uint4* __restrict__ e
   request(blockIdx.x);
   for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     wcnt[wave][lane] = 0;
+    const uint32_t base_sec = nsec0 - (1u << 14);  // seconds [base, base + 2^15) fit the 8-byte record
     uint32_t r_sec[kPartRounds], r_nsec[kPartRounds], r_meta[kPartRounds], r_dst[kPartRounds];
     const uint32_t wb = blk * kPartTE + wave * (kPartTE / 4);
     uint4 e[kPartRounds];
@@ -1296,6 +1300,7 @@ __global__ __launch_bounds__(256) void k_part_coarse(const uint4* __restrict__ e
       if (ok) {
         atomicAdd(&h[(lane & 1) * kTileMaxBins + fine], 1u);
         if (fine != (uint32_t)nb - 1u) {
+          if (e[r].y - base_sec >= (1u << 15)) s_wide = 1;  // (any lane: the whole block then takes 12-byte records)
           tmin = min(tmin, e[r].y);
           tmax = max(tmax, e[r].y);
           tor |= e[r].z;
@@ -1320,24 +1325,36 @@ __global__ __launch_bounds__(256) void k_part_coarse(const uint4* __restrict__ e
       // (transposed — [bucket][block] — so that the scan over the blocks and the fine pass's run tables read
       // consecutive words)
       rowpfx[(size_t)lane * nblk + blk] = start;
-      if (lane == 63) rowpfx[(size_t)kPartMaxCoarse * nblk + blk] = start + tot;
+      if (lane == 63) {
+        rowpfx[(size_t)kPartMaxCoarse * nblk + blk] = start + tot;
+        rowpfx[(size_t)(kPartMaxCoarse + 1) * nblk + blk] = base_sec;
+        rowpfx[(size_t)(kPartMaxCoarse + 2) * nblk + blk] = s_wide;
+      }
     }
     lds_barrier();
+    const bool wide = s_wide != 0;  // (uniform)
 #pragma unroll
     for (int r = 0; r < kPartRounds; r++) {
       const uint32_t i = wb + r * 64 + lane;
       if (i < n) {
         const uint32_t pos = cbase[wave][r_dst[r] >> 16] + (r_dst[r] & 0xffffu);
-        stage[pos * 3] = r_sec[r];
-        stage[pos * 3 + 1] = r_nsec[r];
-        stage[pos * 3 + 2] = r_meta[r];
+        if (wide) {
+          stage[pos * 3] = r_sec[r];
+          stage[pos * 3 + 1] = r_nsec[r];
+          stage[pos * 3 + 2] = r_meta[r];
+        } else {
+          // (an out-of-sensor event's second may be anything: its time is never used)
+          stage[pos * 2] = r_meta[r] | (((r_sec[r] - base_sec) & 0x7fffu) << 17);
+          stage[pos * 2 + 1] = r_nsec[r];
+        }
       }
     }
     lds_barrier();
+    if (threadIdx.x == 0) s_wide = 0;  // (everybody has read it; the barrier below orders this before the next block's rounds)
     {  // the slot: one contiguous copy, 16 B per lane
       const uint32_t cnt = min((uint32_t)kPartTE, n - blk * kPartTE);
-      const uint32_t nq = (cnt * 3 + 3) / 4;
-      uint4* dst = (uint4*)(mid + (size_t)blk * kPartTE * 3);
+      const uint32_t w = wide ? 3u : 2u, nq = (cnt * w + 3) / 4;
+      uint4* dst = (uint4*)((wide ? mid12 : mid8) + (size_t)blk * kPartTE * w);
       for (uint32_t q = threadIdx.x; q < nq; q += 256) dst[q] = ((const uint4*)stage)[q];
     }
     lds_barrier();
@@ -1451,15 +1468,17 @@ __global__ __launch_bounds__(kPartScanThreads) void k_part_scan(const uint32_t* 
   }
 }
 
-__global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ mid, const uint32_t* __restrict__ rowpfx,
+__global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ mid8, const uint32_t* __restrict__ mid12,
+                                                   const uint32_t* __restrict__ rowpfx,
                                                    const uint32_t* __restrict__ colpfx, uint32_t nblk, TileGeom g,
                                                    const uint32_t* __restrict__ totals, const uint32_t* __restrict__ meta,
                                                    uint32_t* __restrict__ lookback, uint32_t* __restrict__ ticket,
                                                    uint4* __restrict__ part, uint32_t* __restrict__ tile_off,
                                                    uint32_t* __restrict__ tile_order, int* __restrict__ err,
                                                    uint32_t spin_limit) {
-  __shared__ __attribute__((aligned(16))) uint32_t sin_[kPartTE * 3];  // the piece, in the bucket's stream order
-  __shared__ __attribute__((aligned(16))) uint2 sout[kPartTE];         // ... sorted by fine bucket, final 8-byte records
+  constexpr int kPieceRounds = kPartPiece / 256;
+  __shared__ __attribute__((aligned(16))) uint32_t sin_[kPartPiece * 3];  // the piece, in the bucket's stream order: {final word 0 (or sec), nsec, low 17 bits}
+  __shared__ __attribute__((aligned(16))) uint2 sout[kPartPiece];         // ... sorted by fine bucket, final 8-byte records
   __shared__ uint32_t wcnt[4][kPartFine], wbase[4][kPartFine];
   __shared__ uint32_t f_cnt[kPartFine], f_src[kPartFine], f_dst[kPartFine];
   __shared__ uint32_t s_t;
@@ -1473,7 +1492,7 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
   const uint32_t sec_base = meta[kTileMetaSecBase];
   __syncthreads();
   const uint32_t t = s_t;
-  const uint32_t cnp = (ctot + kPartTE - 1) / kPartTE;
+  const uint32_t cnp = (ctot + kPartPiece - 1) / kPartPiece;
   const uint32_t cstart = wave_excl_scan(ctot, lane), pstart = wave_excl_scan(cnp, lane);
   const uint32_t npieces = __shfl(pstart + cnp, 63);
   if (t == 0) {
@@ -1522,7 +1541,7 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
   if (t >= npieces) return;  // (the grid is sized for the worst case)
   const uint32_t k = (uint32_t)__popcll(__ballot(pstart + cnp <= t));  // buckets whose pieces all come before t
   const uint32_t j = t - __shfl(pstart, (int)k);
-  const uint32_t v0 = j * kPartTE, T = min((uint32_t)kPartTE, __shfl(ctot, (int)k) - v0);
+  const uint32_t v0 = j * kPartPiece, T = min((uint32_t)kPartPiece, __shfl(ctot, (int)k) - v0);
   const uint32_t bucket_start = __shfl(cstart, (int)k);
   const uint32_t* col = colpfx + (size_t)k * (nblk + 1);
   // this piece's fine buckets: their totals (requested now, needed after the ranking)
@@ -1542,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
   // every thread fetches its 8 records of the piece — all requests in flight together — finding each one's run
   // by bisection in the table.  (A wave per run, descriptor after descriptor, was three dependent trips to
   // memory per run.)
-  __shared__ uint32_t run_v[256], run_src[256];  // a run's first record: position in the piece | record index in `mid`
+  __shared__ uint32_t run_v[256], run_src[256], run_base[256];  // a run's first record: position in the piece | record index in `mid` (bit 31: a 12-byte block) | its block's base second
   __shared__ uint32_t s_nr[4], s_cov;
   for (uint32_t rb = lo, done = 0; done < T;) {  // (lo: the same in every thread)
     __syncthreads();  // (the previous table's readers)
@@ -1558,7 +1577,13 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
       // the part of the run that lies inside the piece starts at piece position max(vs, v0) - v0
       const uint32_t from = (in && vs < v0) ? v0 - vs : 0u;
       run_v[threadIdx.x] = in ? vs + from - v0 : 0xffffffffu;
-      run_src[threadIdx.x] = b * (uint32_t)kPartTE + r0 + from;
+      uint32_t wide_b = 0, base_b = 0;
+      if (in) {
+        base_b = rowpfx[(size_t)(kPartMaxCoarse + 1) * nblk + b];
+        wide_b = rowpfx[(size_t)(kPartMaxCoarse + 2) * nblk + b];
+      }
+      run_src[threadIdx.x] = (b * (uint32_t)kPartTE + r0 + from) | (wide_b ? 1u << 31 : 0u);
+      run_base[threadIdx.x] = base_b;
       const unsigned long long inm = __ballot(in);
       if (lane == 0) s_nr[wave] = (uint32_t)__popcll(inm);
       if (in && (b + 1 == nblk || col[b + 1] >= v0 + T)) s_cov = min(T, vs + len - v0);  // the last run of the table: where it ends
@@ -1567,31 +1592,43 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
     __syncthreads();
     const uint32_t nrun = s_nr[0] + s_nr[1] + s_nr[2] + s_nr[3], cov = s_cov;
     // records [done, cov) of the piece
-    uint32_t a[kPartRounds], b2[kPartRounds], c2[kPartRounds];
+    uint32_t a[kPieceRounds], b2[kPieceRounds], c2[kPieceRounds], rbase[kPieceRounds];
+    bool w12[kPieceRounds];
 #pragma unroll
-    for (int r = 0; r < kPartRounds; r++) {
+    for (int r = 0; r < kPieceRounds; r++) {
       const uint32_t i = done + r * 256 + threadIdx.x;
-      a[r] = b2[r] = c2[r] = 0;
+      a[r] = b2[r] = c2[r] = rbase[r] = 0;
+      w12[r] = false;
       if (i < cov) {
-        uint32_t lo = 0, hi = nrun;  // run_v[lo] <= i < run_v[hi]
-        while (hi - lo > 1) {
-          const uint32_t m = (lo + hi) >> 1;
-          if (run_v[m] <= i) lo = m;
-          else hi = m;
+        uint32_t lo2 = 0, hi2 = nrun;  // run_v[lo2] <= i < run_v[hi2]
+        while (hi2 - lo2 > 1) {
+          const uint32_t m = (lo2 + hi2) >> 1;
+          if (run_v[m] <= i) lo2 = m;
+          else hi2 = m;
         }
-        const uint32_t* src = mid + (size_t)(run_src[lo] + (i - run_v[lo])) * 3;
-        a[r] = src[0];
-        b2[r] = src[1];
-        c2[r] = src[2];
+        const uint32_t rs = run_src[lo2], rec = (rs & 0x7fffffffu) + (i - run_v[lo2]);
+        w12[r] = (rs >> 31) != 0;
+        rbase[r] = run_base[lo2];
+        if (w12[r]) {
+          const uint32_t* src = mid12 + (size_t)rec * 3;
+          a[r] = src[0];
+          b2[r] = src[1];
+          c2[r] = src[2];
+        } else {
+          const uint2 v = ((const uint2*)mid8)[rec];
+          a[r] = v.x;
+          b2[r] = v.y;
+        }
       }
     }
 #pragma unroll
-    for (int r = 0; r < kPartRounds; r++) {
+    for (int r = 0; r < kPieceRounds; r++) {
       const uint32_t i = done + r * 256 + threadIdx.x;
       if (i < cov) {
-        sin_[i * 3] = a[r];
+        const uint32_t sec = w12[r] ? a[r] : rbase[r] + (a[r] >> 17), m3 = w12[r] ? c2[r] : (a[r] & 0x1ffffu);
+        sin_[i * 3] = compact ? (m3 & 0xfffu) | ((sec - sec_base) << 12) : sec;
         sin_[i * 3 + 1] = b2[r];
-        sin_[i * 3 + 2] = c2[r];
+        sin_[i * 3 + 2] = m3;
       }
     }
     done = cov;
@@ -1599,16 +1636,16 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
   }
   __syncthreads();
   // ---- rank among the 32 fine buckets: wave w takes records [w * 512, (w + 1) * 512) in rounds of 64
-  uint32_t rec_a[kPartRounds], rec_b[kPartRounds], r_dst[kPartRounds];
+  uint32_t rec_a[kPieceRounds], rec_b[kPieceRounds], r_dst[kPieceRounds];
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int r = 0; r < kPartRounds; r++) {
-    const uint32_t i = wave * (kPartTE / 4) + r * 64 + lane;
+  for (int r = 0; r < kPieceRounds; r++) {
+    const uint32_t i = wave * (kPartPiece / 4) + r * 64 + lane;
     const bool ok = i < T;
-    const uint32_t sec = sin_[i * 3], nsec = sin_[i * 3 + 1], m3 = sin_[i * 3 + 2];
+    const uint32_t m3 = sin_[i * 3 + 2];
     const uint32_t f = (m3 >> 12) & (uint32_t)(kPartFine - 1);
-    rec_a[r] = compact ? (m3 & 0xfffu) | ((sec - sec_base) << 12) : sec;
-    rec_b[r] = nsec;
+    rec_a[r] = sin_[i * 3];
+    rec_b[r] = sin_[i * 3 + 1];
     const unsigned long long m = match_any_bits<kPartFineBits>(f, ok);
     const uint32_t before = __popcll(m & lt);
     uint32_t base = 0;
@@ -1639,22 +1676,37 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
         __hip_atomic_store(my, kLbPrefix | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         __hip_atomic_store(my, kLbAgg | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a window of 16 predecessors per trip to memory: the pieces of a bucket all run at the same time, so a piece
+        // far down the bucket finds aggregates only, one after the other — one load per trip was 100 dependent trips
+        // for the 100th piece of a bucket)
+        constexpr int LBW = 16;
         uint32_t back = 1, spins = 0;
-        while (back <= j) {
-          const uint32_t w = __hip_atomic_load(lookback + (size_t)(t - back) * kPartFine + lane, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t st = w & ~kLbMask;
-          if (st == 0) {
+        bool found = false;
+        while (!found && back <= j) {
+          uint32_t w[LBW];
+#pragma unroll
+          for (int q = 0; q < LBW; q++)
+            w[q] = back + (uint32_t)q <= j ? __hip_atomic_load(lookback + (size_t)(t - back - (uint32_t)q) * kPartFine + lane,
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : 0u;
+          uint32_t used = 0;
+#pragma unroll
+          for (int q = 0; q < LBW; q++) {
+            if (found || back + (uint32_t)q > j || used != (uint32_t)q) continue;
+            const uint32_t st = w[q] & ~kLbMask;
+            if (st == 0) continue;  // (not published yet: the window is taken up again from here)
+            excl += w[q] & kLbMask;
+            used++;
+            if (st == kLbPrefix) found = true;
+          }
+          back += used;
+          if (!found && used < LBW && back <= j) {
             if (++spins > spin_limit) {  // bounded (kSpinLookback polls): never hang the GPU
               *err = 1;
               break;
             }
             __builtin_amdgcn_s_sleep(1);
-            continue;
           }
-          excl += w & kLbMask;
-          if (st == kLbPrefix) break;
-          back++;
         }
         __hip_atomic_store(my, kLbPrefix | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1666,8 +1718,8 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
   __syncthreads();
   if (compact) {
 #pragma unroll
-    for (int r = 0; r < kPartRounds; r++) {
-      const uint32_t i = wave * (kPartTE / 4) + r * 64 + lane;
+    for (int r = 0; r < kPieceRounds; r++) {
+      const uint32_t i = wave * (kPartPiece / 4) + r * 64 + lane;
       if (i < T) {
         const uint32_t f = (r_dst[r] >> 24) & (uint32_t)(kPartFine - 1);
         sout[f_src[f] + wbase[wave][f] + (r_dst[r] & 0xfffu)] = make_uint2(rec_a[r], rec_b[r]);
@@ -1683,8 +1735,8 @@ __global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ 
     // 16-byte records (a batch whose stamps do not fit the 8-byte form): the raw event rebuilt from the bucket and
     // the tile-local pixel, stored record by record (the rare form: no staging)
 #pragma unroll
-    for (int r = 0; r < kPartRounds; r++) {
-      const uint32_t i = wave * (kPartTE / 4) + r * 64 + lane;
+    for (int r = 0; r < kPieceRounds; r++) {
+      const uint32_t i = wave * (kPartPiece / 4) + r * 64 + lane;
       if (i < T) {
         const uint32_t m3 = r_dst[r] >> 12, f = (m3 >> 12) & (uint32_t)(kPartFine - 1);
         const uint32_t fb = k * kPartFine + f, cam = fb >= (uint32_t)g.nt_cam ? 1u : 0u, tt = fb - cam * (uint32_t)g.nt_cam;
@@ -1708,10 +1760,10 @@ void launch_part_coarse(hipStream_t s, const EventRec* evL, uint32_t nL, const E
     launch_k(k_mc_warp, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g.W, g.H,
              *mc, warp_xy);
     launch_k(k_part_coarse<true>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, nblk,
-             ps.mid, ps.rowpfx, ps.fine_rows, (uint4*)ps.ranges, (const uint32_t*)warp_xy, ps.lookback, lb_words, ps.ticket);
+             ps.mid8, ps.mid12, ps.rowpfx, ps.fine_rows, (uint4*)ps.ranges, (const uint32_t*)warp_xy, ps.lookback, lb_words, ps.ticket);
   } else {
     launch_k(k_part_coarse<false>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, nblk,
-             ps.mid, ps.rowpfx, ps.fine_rows, (uint4*)ps.ranges, (const uint32_t*)nullptr, ps.lookback, lb_words, ps.ticket);
+             ps.mid8, ps.mid12, ps.rowpfx, ps.fine_rows, (uint4*)ps.ranges, (const uint32_t*)nullptr, ps.lookback, lb_words, ps.ticket);
   }
 }
 
@@ -1729,7 +1781,7 @@ void launch_part_fine(hipStream_t s, uint32_t n, const TileGeom& g, const TileSc
                       EventRec* part, int* err, uint32_t spin_limit) {
   if (!n) return;
   const uint32_t nblk = part_blocks(n);
-  launch_k(k_part_fine, dim3(part_pieces_max(n)), dim3(256), 0, s, (const uint32_t*)ps.mid, (const uint32_t*)ps.rowpfx,
+  launch_k(k_part_fine, dim3(part_pieces_max(n)), dim3(256), 0, s, (const uint32_t*)ps.mid8, (const uint32_t*)ps.mid12, (const uint32_t*)ps.rowpfx,
            (const uint32_t*)ps.colpfx, nblk, g, (const uint32_t*)sc.totals, (const uint32_t*)sc.meta, ps.lookback, ps.ticket,
            (uint4*)part, sc.tile_off, sc.tile_order, err, spin_limit);
 }
