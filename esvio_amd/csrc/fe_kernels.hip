@@ -2853,59 +2853,66 @@ __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
 // A matrix (once per pyramid level): fifteen chains — type t = A11, A12, A22: vector lanes 4 t + k
 // (k = column mod 4, slot = column / 4, columns 0..15), tail 12 + t (columns 16..20).  Every chain takes
 // five terms per window row (a vector lane four and a zero, the tail its five columns), kept as floats in
-// LDS, T[chain][row][8]: slots a chain does not use hold +0.f (adding it is exact), so that all chain
+// LDS, T[level][chain][row][5]: slots a chain does not use hold +0.f (adding it is exact), so that all chain
 // lanes run one loop in lock step — 105 dependent adds, a row fetched with two LDS instructions while
 // the previous one is added.  The pixel lanes write their own products (< 2^24: exact in float) straight
 // into TA; the combination is tail + ((q0 + q2) + (q1 + q3)), v_reduce_sum's order, times FLT_SCALE.
 // (These sums grow monotonically past 2^24 on any textured patch, so there is nothing to guess here.)
-__device__ __forceinline__ float lk_chain_walk(const float* T, int chain) {
-  const float4* row = (const float4*)(T + chain * kLkWin * 8);
+// one chain: 21 rows of 5 terms, T -> its first term
+__device__ __forceinline__ float lk_chain_walk(const float* T) {
   float acc = 0.f;
-  float4 c0 = row[0];
-  float c4 = ((const float*)row)[4];
+  float c[5], nx[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) c[q] = T[q];
 #pragma unroll
   for (int y = 0; y < kLkWin; y++) {
     const int yn = y + 1 < kLkWin ? y + 1 : y;
-    const float4 n0 = row[2 * yn];
-    const float n4 = ((const float*)(row + 2 * yn))[4];
-    acc = __fadd_rn(acc, c0.x);
-    acc = __fadd_rn(acc, c0.y);
-    acc = __fadd_rn(acc, c0.z);
-    acc = __fadd_rn(acc, c0.w);
-    acc = __fadd_rn(acc, c4);
-    c0 = n0;
-    c4 = n4;
+#pragma unroll
+    for (int q = 0; q < 5; q++) nx[q] = T[yn * 5 + q];
+#pragma unroll
+    for (int q = 0; q < 5; q++) acc = __fadd_rn(acc, c[q]);
+#pragma unroll
+    for (int q = 0; q < 5; q++) c[q] = nx[q];
   }
   return acc;
 }
 
 constexpr int kLkChainsA = 15;
-constexpr int kLkTermWordsA = kLkChainsA * kLkWin * 8;
+constexpr int kLkTermLevelA = kLkChainsA * kLkWin * 5;     // T[chain][row][5] floats of one pyramid level
+constexpr int kLkTermWordsA = kMaxLevels * kLkTermLevelA;  // all levels side by side: ONE walk sums them all
+static_assert(kMaxLevels * kLkChainsA <= 64, "one lane per (level, chain)");
 
+// the pixel lanes' products of one level into that level's table (< 2^24: exact in float)
 template <int NP>
-__device__ __forceinline__ void lk_float_sums_A(float* TA, bool on, int row, int x0, const int* pIx, const int* pIy,
-                                                int lane, float& A11, float& A12, float& A22) {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous level's readers)
+__device__ __forceinline__ void lk_float_terms_A(float* TA, bool on, int row, int x0, const int* pIx, const int* pIy) {
 #pragma unroll
   for (int k = 0; k < NP; k++) {
     const int x = x0 + k;
     if (on && x < kLkWin) {
       const bool vec = x < 16;
-      const int base = ((vec ? (x & 3) : 12) * kLkWin + row) * 8 + (vec ? x >> 2 : x - 16);
-      const int step = (vec ? 4 : 1) * kLkWin * 8;  // from one type's chain to the next type's
+      const int base = ((vec ? (x & 3) : 12) * kLkWin + row) * 5 + (vec ? x >> 2 : x - 16);
+      const int step = (vec ? 4 : 1) * kLkWin * 5;  // from one type's chain to the next type's
       TA[base] = (float)(pIx[k] * pIx[k]);
       TA[base + step] = (float)(pIx[k] * pIy[k]);
       TA[base + 2 * step] = (float)(pIy[k] * pIy[k]);
     }
   }
+}
+// every level's fifteen chains at once: lane = 15 level + chain walks its 105 terms (round 4 walked level after
+// level, fifteen lanes at a time: 1.1 us per level and call, 8.6 us of a 91 us launch); acc of lane 15 L + c in `acc`
+__device__ __forceinline__ float lk_float_walk_A(const float* TA, int lane) {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-  const float acc = lk_chain_walk(TA, lane < kLkChainsA ? lane : 0);
+  const int l = lane < kMaxLevels * kLkChainsA ? lane : 0;
+  return lk_chain_walk(TA + l * (kLkWin * 5));  // ((15 L + c) * 105 = L * kLkTermLevelA + c * 105)
+}
+__device__ __forceinline__ void lk_float_sums_A(float acc, int L, float& A11, float& A12, float& A22) {
   const float kScale = 1.f / (float)(1 << 20);  // FLT_SCALE
   float out[3];
 #pragma unroll
   for (int t = 0; t < 3; t++) {
-    const float q0 = __shfl(acc, 4 * t), q1 = __shfl(acc, 4 * t + 1), q2 = __shfl(acc, 4 * t + 2),
-                q3 = __shfl(acc, 4 * t + 3), tail = __shfl(acc, 12 + t);
+    const int b = L * kLkChainsA;
+    const float q0 = __shfl(acc, b + 4 * t), q1 = __shfl(acc, b + 4 * t + 1), q2 = __shfl(acc, b + 4 * t + 2),
+                q3 = __shfl(acc, b + 4 * t + 3), tail = __shfl(acc, b + 12 + t);
     out[t] = __fmul_rn(__fadd_rn(tail, __fadd_rn(__fadd_rn(q0, q2), __fadd_rn(q1, q3))), kScale);
   }
   A11 = out[0];
@@ -3116,6 +3123,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   {
     int t0[NL][NP + 1], t1[NL][NP + 1], g0[NL][NP + 1], g1[NL][NP + 1];
     int w00[NL], w01[NL], w10[NL], w11[NL];
+    if (ACCUM == 2) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous call's walk has read its table)
 #pragma unroll
     for (int L = 0; L < NL; L++) {
       win_ok[L] = false;
@@ -3195,12 +3203,19 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         pIyB[L] = pack16(0, pIy[4]);
       }
       if (ACCUM == 2) {
-        lk_float_sums_A<NP>(acc_ta, on, row, x0, pIx, pIy, lane, A11[L], A12[L], A22[L]);
+        lk_float_terms_A<NP>(acc_ta + L * kLkTermLevelA, on, row, x0, pIx, pIy);
       } else {
         float fdummy;
         wave_sum2_exact(sA11, sA12, rl, A11[L], A12[L]);  // already scaled by FLT_SCALE = 2^-20
         wave_sum2_exact(sA22, kRedSeed, rl, A22[L], fdummy);
       }
+    }
+    float accA = 0.f;
+    if (ACCUM == 2) accA = lk_float_walk_A(acc_ta, lane);
+#pragma unroll
+    for (int L = 0; L < NL; L++) {
+      if (L > c.max_level) continue;
+      if (ACCUM == 2) lk_float_sums_A(accA, L, A11[L], A12[L], A22[L]);
       const float D = A11[L] * A22[L] - A12[L] * A12[L];
       const float minEig =
           (A22[L] + A11[L] - sqrtf((A11[L] - A22[L]) * (A11[L] - A22[L]) + 4.f * A12[L] * A12[L])) /
