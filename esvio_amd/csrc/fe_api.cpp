@@ -297,11 +297,12 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
   c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
-  // time surface and pyramid as two launches (k_time_surface4 reads every plane word once: the render at its HBM
-  // roof; k_pyr3) where the planes are large — at 1280x720 the one-launch form's 2.2x re-rendered halos cost 10 us
-  // of 31; at 640x480 the two forms take the same 17.5 us and the single launch is one host call less.
+  // time surface and pyramid as two launches: k_time_surface4 reads every plane word once and renders every pixel
+  // once (the render at its HBM roof), k_pyr3 builds the three pyrDown levels from the rendered level 0.  The
+  // one-launch form (k_ts_pyr) re-renders its tiles' halos, 2.2x the planes' bytes and exps: 31 against 24 us at
+  // 1280x720; at 640x480 the two forms take the same 17.5 us and the same 0.144 ms per step (four cold runs each).
   // ESVIO_FE_SPLIT_RENDER=0 / 1 forces either form (A/B, tests).
-  c->split_render = (size_t)c->P >= (size_t)600000;
+  c->split_render = true;
   if (const char* v = getenv("ESVIO_FE_SPLIT_RENDER")) c->split_render = atoi(v) != 0;
   c->select_one_wave = getenv("ESVIO_FE_SELECT_SERIAL") != nullptr;
   if (const char* v = getenv("ESVIO_FE_SAE_EV_MIN")) c->sae_ev_min = (size_t)strtoull(v, nullptr, 10);

@@ -330,7 +330,7 @@ struct esvio_fe_ctx {
   uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
   bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1, test-only: the path batches >= 2^20 events take)
   bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1, test-only: k_time_surface + 3 x k_pyr_down, the median / equalize path)
-  bool split_render = false;  // the fused render as two launches: k_time_surface4 (every plane word once) + k_pyr3; set by sensor size at create (ESVIO_FE_SPLIT_RENDER=0/1 forces)
+  bool split_render = true;  // the plain configuration's render as two launches: k_time_surface4 (every plane word once) + k_pyr3 (ESVIO_FE_SPLIT_RENDER=0: k_ts_pyr, one launch)
   int cand_cur = 0;
   size_t arc_cap = 0;
   uint32_t* d_mask_bits = nullptr;

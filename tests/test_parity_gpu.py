@@ -290,11 +290,11 @@ def test_lk_parity(oracle, lk_accum):
     ft.close()
 
 
-@pytest.mark.parametrize("W,H,split", [(640, 480, 1), (346, 260, 1), (1280, 720, 0), (1280, 720, 1)])
+@pytest.mark.parametrize("W,H,split", [(640, 480, 0), (346, 260, 0), (346, 260, 1), (1280, 720, 0), (1280, 720, 1)])
 def test_render_in_one_and_in_two_launches(oracle, monkeypatch, W, H, split):
-    """the plain configuration's time surface + pyramid: one launch (k_ts_pyr, the default below 600 k pixels) or two
-    (k_time_surface4 — one pixel per thread where the rows are no multiple of 4 — then k_pyr3, the default
-    above): both forms at sizes where they are not the default, images and tracks as the oracle's"""
+    """the plain configuration's time surface + pyramid: two launches (the default: k_time_surface4 — one pixel per
+    thread where the rows are no multiple of 4 — then k_pyr3) or one (k_ts_pyr, ESVIO_FE_SPLIT_RENDER=0): both
+    forms, images and tracks as the oracle's"""
     monkeypatch.setenv("ESVIO_FE_SPLIT_RENDER", str(split))
     s = SceneStream(W, H, rate=2e6, seed=21)
     kw = dict(max_cnt=150, min_dist=15)
