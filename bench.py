@@ -37,10 +37,11 @@ KERNEL_FUNCS = {
     "k_sae_keys": ["k_sae_keys", "k_tile_hist", "k_mc_warp"], "k_tile_scan": ["k_tile_scan"],
     "k_radix_pass": ["k_radix_pass", "k_tile_scatter"],
     "k_sae_apply": ["k_sae_apply", "k_sae_apply_ev", "k_sae_apply_ev_write", "k_tile_apply"],
-    "k_time_surface": ["k_time_surface", "k_ts_pyr", "k_median"], "k_clahe": ["k_clahe_lut", "k_clahe_interp", "k_normalize"],
-    "k_pyr_down": ["k_pyr_down"], "k_pyr_pad": ["k_pyr_pad"], "k_scharr": ["k_scharr", "k_pad_scharr"],
-    "k_lk": ["k_lk"], "k_arc": ["k_arc_ev"], "k_arc_map": ["k_arc_map", "k_arc_mark"],
-    "k_compact": ["k_compact", "k_dedup"], "k_select": ["k_select"],
+    "k_time_surface": ["k_time_surface", "k_time_surface4", "k_ts_pyr", "k_median"],
+    "k_clahe": ["k_clahe_lut", "k_clahe_interp", "k_normalize"],
+    "k_pyr_down": ["k_pyr_down", "k_pyr3", "k_norm_pyr"], "k_pyr_pad": ["k_pyr_pad"], "k_scharr": ["k_scharr", "k_pad_scharr"],
+    "k_lk": ["k_lk", "k_lk_f32"], "k_arc": ["k_arc_ev"], "k_arc_map": ["k_arc_map", "k_arc_mark"],
+    "k_compact": ["k_compact", "k_dedup"], "k_select": ["k_select", "k_select_mw", "k_select_gbm"],
 }
 # kernels whose reads are per-lane gathers, not wide coalesced streams: the guide calibrates the 2x
 # FETCH_SIZE correction for coalesced reads only
