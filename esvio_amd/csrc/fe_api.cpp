@@ -381,6 +381,7 @@ int esvio_fe_reset(esvio_fe_handle c) {
   if (!c) return ESVIO_FE_EINVAL;
   HIPCHK(c, hipSetDevice(c->dev));
   (void)launcher_drain(c);  // (whatever it was still issuing is discarded with the batches below)
+  launcher_clear_error(c);
   HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream4));
   HIPCHK(c, hipStreamSynchronize(c->stream2));

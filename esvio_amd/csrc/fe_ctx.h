@@ -418,6 +418,12 @@ struct StreamScope {
   ~StreamScope() { t_stream_override = saved; }
 };
 
+// (a thread of the handle that is not the calling thread — the launch thread — gives its error texts a place of its
+// own here: c->err belongs to the calling thread)
+inline std::string*& fail_sink() {
+  static thread_local std::string* sink = nullptr;
+  return sink;
+}
 inline int fail(esvio_fe_ctx* c, int code, const char* fmt, ...) {
   if (c) {
     char buf[512];
@@ -425,7 +431,8 @@ inline int fail(esvio_fe_ctx* c, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    c->err = buf;
+    if (std::string* sink = fail_sink()) *sink = buf;
+    else c->err = buf;
   }
   return code;
 }

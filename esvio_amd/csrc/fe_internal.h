@@ -123,6 +123,7 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first = fals
 int launcher_set(esvio_fe_ctx* c, bool on);   // start / stop the launch thread
 int launcher_drain(esvio_fe_ctx* c);          // every job handed over has been issued (returns the first job error)
 int launcher_wait_lane(esvio_fe_ctx* c, int lane);  // ... the job that records this lane's events
+void launcher_clear_error(esvio_fe_ctx* c);   // esvio_fe_reset: a failed job.s sticky error is dropped with the batches
 int cancel_chain(esvio_fe_ctx* c);
 int finalize_right(esvio_fe_ctx* c);
 int finalize_pending(esvio_fe_ctx* c);

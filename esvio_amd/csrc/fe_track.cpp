@@ -96,7 +96,10 @@ struct Launcher {
   PrefetchJob ring[kRing];
   alignas(64) std::atomic<uint64_t> submitted{0};
   alignas(64) std::atomic<uint64_t> done{0};
+  // the first failure of a job: sticky until esvio_fe_reset (launcher_clear_error) or the thread is stopped — a failed
+  // job has left its batch half applied, so every later wait on this launcher fails too, and nothing more is issued
   std::atomic<int> first_rc{0};
+  std::string err_text;  // written by this thread before first_rc (release), read by the caller after it (acquire)
   std::atomic<bool> quit{false};
   std::mutex mu;
   std::condition_variable cv;
@@ -104,6 +107,7 @@ struct Launcher {
 
   void run() {
     (void)hipSetDevice(c->dev);
+    fail_sink() = &err_text;
     auto idle_since = std::chrono::steady_clock::now();
     unsigned spins = 0;
     for (;;) {
@@ -127,10 +131,9 @@ struct Launcher {
         }
         continue;
       }
-      const int rc = prefetch_issue(c, ring[d % kRing]);
-      if (rc) {
-        int zero = 0;
-        (void)first_rc.compare_exchange_strong(zero, rc, std::memory_order_acq_rel);
+      if (first_rc.load(std::memory_order_relaxed) == 0) {  // (after a failure the jobs are only counted off)
+        const int rc = prefetch_issue(c, ring[d % kRing]);
+        if (rc) first_rc.store(rc, std::memory_order_release);
       }
       done.store(d + 1, std::memory_order_release);
       idle_since = std::chrono::steady_clock::now();
@@ -163,9 +166,14 @@ int launcher_set(esvio_fe_ctx* c, bool on) {
 }
 
 static int launcher_result(esvio_fe_ctx* c) {
-  const int rc = c->launcher->first_rc.exchange(0, std::memory_order_acq_rel);
-  if (rc && c->err.empty()) c->err = "a prefetch job of the launch thread failed";
+  const int rc = c->launcher->first_rc.load(std::memory_order_acquire);
+  if (rc) c->err = c->launcher->err_text.empty() ? "a prefetch job of the launch thread failed" : c->launcher->err_text;
   return rc;
+}
+
+// esvio_fe_reset: the handle starts from a clean slate, so does its launch thread (drained by the caller)
+void launcher_clear_error(esvio_fe_ctx* c) {
+  if (c->launcher) c->launcher->first_rc.store(0, std::memory_order_release);
 }
 
 int launcher_drain(esvio_fe_ctx* c) {

@@ -24,6 +24,13 @@ ihipStream_t* S(hipStream_t s) { return s ? s : &g_null_stream; }
 std::mutex g_mu;
 std::set<const void*> g_pinned;  // hipHostMalloc / hipHostRegister'ed base addresses
 std::atomic<uint64_t> g_allocs{0};
+// HIPSTUB_FAIL_EVERY=n: every n-th hipEventRecord fails (once each) — a launch that fails in the middle of a call,
+// on whichever thread issues it
+std::atomic<long> g_records{0};
+long fail_every() {
+  static const long n = getenv("HIPSTUB_FAIL_EVERY") ? atol(getenv("HIPSTUB_FAIL_EVERY")) : 0;
+  return n;
+}
 }  // namespace
 
 void hipstub_stream_begin(hipStream_t s) {
@@ -120,6 +127,7 @@ hipError_t hipEventCreate(hipEvent_t* e) { *e = new ihipEvent_t; return hipSucce
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  if (fail_every() > 0 && (g_records.fetch_add(1, std::memory_order_relaxed) + 1) % fail_every() == 0) return hipErrorInvalidValue;
   hipstub_stream_op(s);
   e->seq.fetch_add(1, std::memory_order_acq_rel);
   return hipSuccess;

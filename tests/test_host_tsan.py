@@ -45,8 +45,8 @@ def build_driver(tmp_path, tree=ROOT, name="drive_tsan"):
     return exe
 
 
-def run_driver(exe, seed, frames, timeout):
-    env = dict(os.environ, TSAN_OPTIONS="suppressions=%s halt_on_error=0" % os.path.join(STUB, "tsan.supp"))
+def run_driver(exe, seed, frames, timeout, **extra_env):
+    env = dict(os.environ, TSAN_OPTIONS="suppressions=%s halt_on_error=0" % os.path.join(STUB, "tsan.supp"), **extra_env)
     return subprocess.run([exe, str(seed), str(frames)], capture_output=True, text=True, timeout=timeout, env=env)
 
 
@@ -60,3 +60,13 @@ def test_every_host_thread_under_thread_sanitizer(tmp_path):
         assert "drive ok:" in p.stdout, out[-2000:]
         calls = int(p.stdout.split("drive ok:")[1].split()[0])
         assert calls >= 300
+    # launches that fail in the middle of a call, on the calling thread or on the launch thread (whose first error
+    # is sticky until esvio_fe_reset and travels to the caller's error text): every failed call is followed by a
+    # reset in the driver, the stream goes on, nothing hangs, nothing races
+    for every in ("701", "1933"):
+        p = run_driver(exe, 5, 300, 600, HIPSTUB_FAIL_EVERY=every)
+        out = p.stdout + p.stderr
+        assert p.returncode == 0 and "drive ok:" in p.stdout, out[-3000:]
+        assert "WARNING: ThreadSanitizer" not in out, out[-6000:]
+        failed = int(p.stdout.split("handles,")[1].split()[0])
+        assert failed >= 3, p.stdout
