@@ -3121,8 +3121,14 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   bool win_ok[NL], eig_ok[NL];
   float A11[NL], A12[NL], A22[NL], Dinv[NL];
   {
-    int t0[NL][NP + 1], t1[NL][NP + 1], g0[NL][NP + 1], g1[NL][NP + 1];
-    int w00[NL], w01[NL], w10[NL], w11[NL];
+    // the window's image bytes as (unaligned) dwords — NP + 1 bytes of each of the lane's two rows — and its
+    // derivative pairs {Ix, Iy}; the bilinear taps are the iteration's: two horizontally adjacent values as an int16
+    // pair (v_perm_b32) against the packed weight pairs (v_dot2_i32_i16), rounding constant as the accumulator seed
+    constexpr int NW = (NP + 1 + 3) / 4;
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    uint32_t t0[NL][NW], t1[NL][NW];
+    int g0[NL][NP + 1], g1[NL][NP + 1];
+    uint32_t W0p[NL], W1p[NL];
     if (ACCUM == 2) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (the previous call's walk has read its table)
 #pragma unroll
     for (int L = 0; L < NL; L++) {
@@ -3136,10 +3142,12 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       const int iprevX = (int)flx, iprevY = (int)fly;
       win_ok[L] = !(iprevX < -WIN || iprevX >= cols || iprevY < -WIN || iprevY >= rows);
       const float fa = prevX - flx, fb = prevY - fly;
-      w00[L] = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-      w01[L] = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
-      w10[L] = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
-      w11[L] = (1 << W_BITS) - w00[L] - w01[L] - w10[L];
+      const int w00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+      const int w01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+      const int w10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+      const int w11 = (1 << W_BITS) - w00 - w01 - w10;
+      W0p[L] = pack16(w00, w01);  // (<= 2^14 each)
+      W1p[L] = pack16(w10, w11);
       // clamp the window origin for the loads of an out-of-range window (values unused)
       const int lx = min(max(iprevX, -WIN), cols - 1), ly = min(max(iprevY, -WIN), rows - 1);
       const ptrdiff_t o = (ptrdiff_t)(kPad + row + ly) * stride + kPad + lx + x0;
@@ -3148,9 +3156,12 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       const int* d0 = (const int*)c.P.deriv[L] + o;
       const int* d1 = d0 + stride;
 #pragma unroll
+      for (int q = 0; q < NW; q++) {
+        t0[L][q] = ((const u32_unaligned*)s0)[q];
+        t1[L][q] = ((const u32_unaligned*)s1)[q];
+      }
+#pragma unroll
       for (int k = 0; k <= NP; k++) {
-        t0[L][k] = s0[k];
-        t1[L][k] = s1[k];
         g0[L][k] = d0[k];
         g1[L][k] = d1[k];
       }
@@ -3164,20 +3175,31 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       for (int k = NP; k < 2 * NPP; k++) pI[k] = pIx[k] = pIy[k] = 0;
 #pragma unroll
       for (int k = 0; k < NP; k++) {
-        const int ival = CV_DESCALE(__mul24(t0[L][k], w00[L]) + __mul24(t0[L][k + 1], w01[L]) +
-                                        __mul24(t1[L][k], w10[L]) + __mul24(t1[L][k + 1], w11[L]),
-                                    W_BITS - 5);
-        const int ixval = CV_DESCALE(
-            __mul24((int)(int16_t)g0[L][k], w00[L]) + __mul24((int)(int16_t)g0[L][k + 1], w01[L]) +
-                __mul24((int)(int16_t)g1[L][k], w10[L]) + __mul24((int)(int16_t)g1[L][k + 1], w11[L]),
-            W_BITS);
-        const int iyval = CV_DESCALE(__mul24(g0[L][k] >> 16, w00[L]) + __mul24(g0[L][k + 1] >> 16, w01[L]) +
-                                         __mul24(g1[L][k] >> 16, w10[L]) + __mul24(g1[L][k + 1] >> 16, w11[L]),
-                                     W_BITS);
+        uint32_t i0, i1;  // {byte k, byte k + 1} of the two rows
+        if (k < 3) {
+          const uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
+          i0 = __builtin_amdgcn_perm(t0[L][1], t0[L][0], sel);
+          i1 = __builtin_amdgcn_perm(t1[L][1], t1[L][0], sel);
+        } else if (k < 7) {
+          const uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
+          i0 = __builtin_amdgcn_perm(t0[L][1], t0[L][0], sel);
+          i1 = __builtin_amdgcn_perm(t1[L][1], t1[L][0], sel);
+        } else {
+          i0 = __builtin_amdgcn_perm(t0[L][NW - 1], t0[L][1], 0x0c040c03u);
+          i1 = __builtin_amdgcn_perm(t1[L][NW - 1], t1[L][1], 0x0c040c03u);
+        }
+        // CV_DESCALE(x, n) = (x + (1 << (n - 1))) >> n: the rounding constant is the first dot's accumulator
+        const int ival = sdot2(i1, W1p[L], sdot2_seed(i0, W0p[L], 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        const uint32_t x0p = __builtin_amdgcn_perm((uint32_t)g0[L][k + 1], (uint32_t)g0[L][k], 0x05040100u);  // {Ix k, Ix k+1}
+        const uint32_t x1p = __builtin_amdgcn_perm((uint32_t)g1[L][k + 1], (uint32_t)g1[L][k], 0x05040100u);
+        const uint32_t y0p = __builtin_amdgcn_perm((uint32_t)g0[L][k + 1], (uint32_t)g0[L][k], 0x07060302u);  // {Iy k, Iy k+1}
+        const uint32_t y1p = __builtin_amdgcn_perm((uint32_t)g1[L][k + 1], (uint32_t)g1[L][k], 0x07060302u);
+        const int ixval = sdot2(x1p, W1p[L], sdot2_seed(x0p, W0p[L], 1 << (W_BITS - 1))) >> W_BITS;
+        const int iyval = sdot2(y1p, W1p[L], sdot2_seed(y0p, W0p[L], 1 << (W_BITS - 1))) >> W_BITS;
         const bool col_ok = on && (NP * 3 == WIN || x0 + k < WIN);  // (float-order mode: columns 21..23 of run 2)
-        pI[k] = (int)(int16_t)ival;
-        pIx[k] = col_ok ? (int)(int16_t)ixval : 0;
-        pIy[k] = col_ok ? (int)(int16_t)iyval : 0;
+        pI[k] = ival;  // (0 .. 255 * 32; the derivatives: |.| <= 16 * 255 — all inside int16 as they are)
+        pIx[k] = col_ok ? ixval : 0;
+        pIy[k] = col_ok ? iyval : 0;
         if (ACCUM != 2) {
           sA11 += __mul24(pIx[k], pIx[k]);
           sA12 += __mul24(pIx[k], pIy[k]);
