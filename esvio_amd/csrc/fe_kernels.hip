@@ -2850,13 +2850,17 @@ __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
 // columns that do not exist and contribute nothing), so both columns of every pmaddwd pair (x, x+4) sit
 // in one lane and the tail's five columns in another.
 //
-// A matrix (once per pyramid level): fifteen chains — type t = A11, A12, A22: vector lanes 4 t + k
-// (k = column mod 4, slot = column / 4, columns 0..15), tail 12 + t (columns 16..20).  Every chain takes
-// five terms per window row (a vector lane four and a zero, the tail its five columns), kept as floats in
-// LDS, T[level][chain][row][5]: slots a chain does not use hold +0.f (adding it is exact), so that all chain
-// lanes run one loop in lock step — 105 dependent adds, a row fetched with two LDS instructions while
-// the previous one is added.  The pixel lanes write their own products (< 2^24: exact in float) straight
-// into TA; the combination is tail + ((q0 + q2) + (q1 + q3)), v_reduce_sum's order, times FLT_SCALE.
+// A matrix (once per call, every pyramid level at the same time): fifteen chains per level — type t = A11,
+// A12, A22: chain 5 t + k for the vector lane k = column mod 4 (slot = column / 4, columns 0..15), chain
+// 5 t + 4 for the tail (columns 16..20).  Every chain takes five terms per window row (a vector lane four
+// and a zero, the tail its five columns), kept as floats in LDS, T[level][chain][row][5]: slots a chain does
+// not use hold +0.f (adding it is exact), so that all chain lanes run one loop in lock step — 105 dependent
+// adds, a row fetched with two LDS instructions while the previous one is added.  The pixel lanes write
+// their own products (< 2^24: exact in float) straight into T, each column at an address the lane worked
+// out once per launch (type and level are the instruction's immediate offset); the three columns a lane of
+// run 2 owns beyond the window write their zeros into zero slots.  The walker of level L's chain c is lane
+// 16 L + c, so a level is a DPP row and the combination tail + ((q0 + q2) + (q1 + q3)) — v_reduce_sum's
+// order —, the eigenvalue test and 1 / D are done once for all levels, a level per row.
 // (These sums grow monotonically past 2^24 on any textured patch, so there is nothing to guess here.)
 // one chain: 21 rows of 5 terms, T -> its first term
 __device__ __forceinline__ float lk_chain_walk(const float* T) {
@@ -2878,46 +2882,55 @@ __device__ __forceinline__ float lk_chain_walk(const float* T) {
 }
 
 constexpr int kLkChainsA = 15;
-constexpr int kLkTermLevelA = kLkChainsA * kLkWin * 5;     // T[chain][row][5] floats of one pyramid level
+constexpr int kLkChainWordsA = kLkWin * 5;                 // one chain: [row][5]
+constexpr int kLkTypeWordsA = 5 * kLkChainWordsA;          // from a type's chains to the next type's
+constexpr int kLkTermLevelA = kLkChainsA * kLkChainWordsA;  // T[chain][row][5] floats of one pyramid level
 constexpr int kLkTermWordsA = kMaxLevels * kLkTermLevelA;  // all levels side by side: ONE walk sums them all
-static_assert(kMaxLevels * kLkChainsA <= 64, "one lane per (level, chain)");
+static_assert(kMaxLevels * 16 <= 64, "one DPP row of walkers per level");
 
-// the pixel lanes' products of one level into that level's table (< 2^24: exact in float)
+typedef __attribute__((address_space(3))) float lds_f32;
+// word offset (inside a level's table) of column x's A11 term in window row `row`; x >= kLkWin: a zero slot
+__device__ __forceinline__ int lk_term_word_A(int row, int x) {
+  const int chain = x < 16 ? (x & 3) : x < kLkWin ? 4 : (x & 3);
+  const int slot = x < 16 ? (x >> 2) : x < kLkWin ? x - 16 : 4;
+  return (chain * kLkWin + row) * 5 + slot;
+}
+// the pixel lanes' products of one level into that level's table: ta[k] = LDS byte address of column k's A11 term
+// in level 0's table
 template <int NP>
-__device__ __forceinline__ void lk_float_terms_A(float* TA, bool on, int row, int x0, const int* pIx, const int* pIy) {
+__device__ __forceinline__ void lk_float_terms_A(const uint32_t (&ta)[NP], int L, const int* pIx, const int* pIy) {
 #pragma unroll
   for (int k = 0; k < NP; k++) {
-    const int x = x0 + k;
-    if (on && x < kLkWin) {
-      const bool vec = x < 16;
-      const int base = ((vec ? (x & 3) : 12) * kLkWin + row) * 5 + (vec ? x >> 2 : x - 16);
-      const int step = (vec ? 4 : 1) * kLkWin * 5;  // from one type's chain to the next type's
-      TA[base] = (float)(pIx[k] * pIx[k]);
-      TA[base + step] = (float)(pIx[k] * pIy[k]);
-      TA[base + 2 * step] = (float)(pIy[k] * pIy[k]);
-    }
+    lds_f32* d = (lds_f32*)(uintptr_t)ta[k] + L * kLkTermLevelA;
+    const float fx = (float)pIx[k], fy = (float)pIy[k];  // (|.| <= 4080: the products are exact)
+    d[0] = __fmul_rn(fx, fx);
+    d[kLkTypeWordsA] = __fmul_rn(fx, fy);
+    d[2 * kLkTypeWordsA] = __fmul_rn(fy, fy);
   }
 }
-// every level's fifteen chains at once: lane = 15 level + chain walks its 105 terms (round 4 walked level after
-// level, fifteen lanes at a time: 1.1 us per level and call, 8.6 us of a 91 us launch); acc of lane 15 L + c in `acc`
+// every level's fifteen chains at once: lane 16 L + c walks the 105 terms of level L's chain c (round 4 walked level
+// after level, fifteen lanes at a time: 1.1 us per level and call, 8.6 us of a 91 us launch)
 __device__ __forceinline__ float lk_float_walk_A(const float* TA, int lane) {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-  const int l = lane < kMaxLevels * kLkChainsA ? lane : 0;
-  return lk_chain_walk(TA + l * (kLkWin * 5));  // ((15 L + c) * 105 = L * kLkTermLevelA + c * 105)
+  const int c = (lane & 15) < kLkChainsA ? (lane & 15) : 0;
+  return lk_chain_walk(TA + ((lane >> 4) * kLkChainsA + c) * kLkChainWordsA);
 }
-__device__ __forceinline__ void lk_float_sums_A(float acc, int L, float& A11, float& A12, float& A22) {
-  const float kScale = 1.f / (float)(1 << 20);  // FLT_SCALE
-  float out[3];
-#pragma unroll
-  for (int t = 0; t < 3; t++) {
-    const int b = L * kLkChainsA;
-    const float q0 = __shfl(acc, b + 4 * t), q1 = __shfl(acc, b + 4 * t + 1), q2 = __shfl(acc, b + 4 * t + 2),
-                q3 = __shfl(acc, b + 4 * t + 3), tail = __shfl(acc, b + 12 + t);
-    out[t] = __fmul_rn(__fadd_rn(tail, __fadd_rn(__fadd_rn(q0, q2), __fadd_rn(q1, q3))), kScale);
-  }
-  A11 = out[0];
-  A12 = out[1];
-  A22 = out[2];
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_f32(float v) {  // the value CTRL brings in (0 where it has no source lane)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// acc of lane 16 L + c -> level L's sums in lanes 16 L (A11), 16 L + 5 (A12), 16 L + 10 (A22), already scaled by
+// FLT_SCALE; a11 / a12 / a22: all three brought to lane 16 L
+__device__ __forceinline__ float lk_float_sums_A(float acc, float& a11, float& a12, float& a22) {
+  const float kScale = 1.f / (float)(1 << 20);
+  const float s1 = __fadd_rn(acc, dpp_row_f32<0x102>(acc));  // row_shl:2: chain 5 t: q0 + q2, chain 5 t + 1: q1 + q3
+  const float s2 = __fadd_rn(s1, dpp_row_f32<0x101>(s1));    // chain 5 t: (q0 + q2) + (q1 + q3)
+  const float s3 = __fadd_rn(dpp_row_f32<0x104>(acc), s2);   // tail + ...
+  const float out = __fmul_rn(s3, kScale);
+  a11 = out;
+  a12 = dpp_row_f32<0x105>(out);
+  a22 = dpp_row_f32<0x10A>(out);
+  return out;
 }
 
 // The b vector is summed once per LK iteration.  Ten chains: vector chains c = 4 comp + k (comp 0: b1,
@@ -2961,13 +2974,18 @@ constexpr unsigned long long kF32Walkers = 0x0FFFFFFFFFFF0FFFull;       // lanes
 struct LkLaneF32 {  // per-lane constants of the float-order sums
   uint32_t wb[5];   // byte offsets of the five (b1, b2) word pairs this pixel lane writes
   uint32_t rb;      // byte offset of the segment this lane walks
+  uint32_t ta[8];   // LDS byte addresses of the lane's eight columns' A11 terms (level 0; lk_float_terms_A)
   bool run2;        // pixel lane of columns 16..20
 };
-__device__ __forceinline__ LkLaneF32 lk_lane_f32(int lane) {
+__device__ __forceinline__ LkLaneF32 lk_lane_f32(int lane_in, uint32_t ta_base /* LDS byte address of the wave's A table */) {
+  // (lane 63 has no pixels of its own: it is a second lane 62 — same values to the same addresses)
+  const int lane = lane_in < 63 ? lane_in : 62;
   LkLaneF32 r;
-  const int row = lane < 63 ? lane / 3 : 0;
-  const int run = lane < 63 ? lane - row * 3 : 3;
+  const int row = lane / 3;
+  const int run = lane - row * 3;
   r.run2 = run == 2;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.ta[k] = ta_base + 4u * (uint32_t)lk_term_word_A(row, run * 8 + k);
 #pragma unroll
   for (int j = 0; j < 5; j++) {
     int w = kF32Dump + lane;
@@ -2980,7 +2998,7 @@ __device__ __forceinline__ LkLaneF32 lk_lane_f32(int lane) {
     }
     r.wb[j] = (uint32_t)w * 4u;
   }
-  const int wrow = lane >> 4, l16 = lane & 15;
+  const int wrow = lane_in >> 4, l16 = lane_in & 15;
   int rw = kF32ZeroSeg;
   if (wrow == 0 || wrow == 3) {
     if (l16 < kF32TailSegs) rw = kF32TailBase + (wrow == 3 ? kF32CompStride : 0) + l16 * kF32SegStore;
@@ -3106,9 +3124,12 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   const float halfWin = (WIN - 1) * 0.5f;
   const int W_BITS = 14;
   const RedLane rl = red_lane(lane);
-  const bool on = lane < 63;
-  const int row = on ? lane / 3 : 0;
-  const int x0 = on ? (lane - row * 3) * NP : 0;
+  // exact mode: lane 63 is off (its terms are zeros in the wave's sums); float-order mode: lane 63 is a second lane
+  // 62 (every sum goes through tables, where writing the same value to the same address twice is harmless)
+  const bool on = ACCUM == 2 || lane < 63;
+  const int plane = ACCUM == 2 ? min(lane, 62) : lane;
+  const int row = on ? plane / 3 : 0;
+  const int x0 = on ? (plane - row * 3) * NP : 0;
   const int lane_bo = row * kLkRegW + x0;  // this lane's byte offset inside a staged window
 
   // ---- phase A: the previous-image side of EVERY level depends only on prevPts, so all
@@ -3122,7 +3143,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   float A11[NL], A12[NL], A22[NL], Dinv[NL];
   {
     // the window's image bytes as (unaligned) dwords — NP + 1 bytes of each of the lane's two rows — and its
-    // derivative pairs {Ix, Iy}; the bilinear taps are the iteration's: two horizontally adjacent values as an int16
+    // derivative pairs {Ix, Iy}; the bilinear taps are the iteration's: a column's values of the two rows as an int16
     // pair (v_perm_b32) against the packed weight pairs (v_dot2_i32_i16), rounding constant as the accumulator seed
     constexpr int NW = (NP + 1 + 3) / 4;
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
@@ -3146,8 +3167,8 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       const int w01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
       const int w10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
       const int w11 = (1 << W_BITS) - w00 - w01 - w10;
-      W0p[L] = pack16(w00, w01);  // (<= 2^14 each)
-      W1p[L] = pack16(w10, w11);
+      W0p[L] = pack16(w00, w10);  // the LEFT column's weights for the rows (y, y + 1), (<= 2^14 each)
+      W1p[L] = pack16(w01, w11);  // the right column's
       // clamp the window origin for the loads of an out-of-range window (values unused)
       const int lx = min(max(iprevX, -WIN), cols - 1), ly = min(max(iprevY, -WIN), rows - 1);
       const ptrdiff_t o = (ptrdiff_t)(kPad + row + ly) * stride + kPad + lx + x0;
@@ -3173,30 +3194,24 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       int pI[2 * NPP], pIx[2 * NPP], pIy[2 * NPP];
 #pragma unroll
       for (int k = NP; k < 2 * NPP; k++) pI[k] = pIx[k] = pIy[k] = 0;
+      // column k's two rows as an int16 pair — {row y, row y + 1} —: a pixel is its own column against the left
+      // weights plus the next column against the right ones, so NP + 1 v_perm serve NP pixels
+      uint32_t vI[NP + 1], vX[NP + 1], vY[NP + 1];
+#pragma unroll
+      for (int k = 0; k <= NP; k++) {
+        const uint32_t sel = 0x0c000c00u | ((uint32_t)(4 + (k & 3)) << 16) | (uint32_t)(k & 3);
+        vI[k] = __builtin_amdgcn_perm(t1[L][k >> 2], t0[L][k >> 2], sel);
+        vX[k] = __builtin_amdgcn_perm((uint32_t)g1[L][k], (uint32_t)g0[L][k], 0x05040100u);  // {Ix y, Ix y+1}
+        vY[k] = __builtin_amdgcn_perm((uint32_t)g1[L][k], (uint32_t)g0[L][k], 0x07060302u);  // {Iy y, Iy y+1}
+      }
 #pragma unroll
       for (int k = 0; k < NP; k++) {
-        uint32_t i0, i1;  // {byte k, byte k + 1} of the two rows
-        if (k < 3) {
-          const uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
-          i0 = __builtin_amdgcn_perm(t0[L][1], t0[L][0], sel);
-          i1 = __builtin_amdgcn_perm(t1[L][1], t1[L][0], sel);
-        } else if (k < 7) {
-          const uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
-          i0 = __builtin_amdgcn_perm(t0[L][1], t0[L][0], sel);
-          i1 = __builtin_amdgcn_perm(t1[L][1], t1[L][0], sel);
-        } else {
-          i0 = __builtin_amdgcn_perm(t0[L][NW - 1], t0[L][1], 0x0c040c03u);
-          i1 = __builtin_amdgcn_perm(t1[L][NW - 1], t1[L][1], 0x0c040c03u);
-        }
         // CV_DESCALE(x, n) = (x + (1 << (n - 1))) >> n: the rounding constant is the first dot's accumulator
-        const int ival = sdot2(i1, W1p[L], sdot2_seed(i0, W0p[L], 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-        const uint32_t x0p = __builtin_amdgcn_perm((uint32_t)g0[L][k + 1], (uint32_t)g0[L][k], 0x05040100u);  // {Ix k, Ix k+1}
-        const uint32_t x1p = __builtin_amdgcn_perm((uint32_t)g1[L][k + 1], (uint32_t)g1[L][k], 0x05040100u);
-        const uint32_t y0p = __builtin_amdgcn_perm((uint32_t)g0[L][k + 1], (uint32_t)g0[L][k], 0x07060302u);  // {Iy k, Iy k+1}
-        const uint32_t y1p = __builtin_amdgcn_perm((uint32_t)g1[L][k + 1], (uint32_t)g1[L][k], 0x07060302u);
-        const int ixval = sdot2(x1p, W1p[L], sdot2_seed(x0p, W0p[L], 1 << (W_BITS - 1))) >> W_BITS;
-        const int iyval = sdot2(y1p, W1p[L], sdot2_seed(y0p, W0p[L], 1 << (W_BITS - 1))) >> W_BITS;
-        const bool col_ok = on && (NP * 3 == WIN || x0 + k < WIN);  // (float-order mode: columns 21..23 of run 2)
+        const int ival = sdot2(vI[k + 1], W1p[L], sdot2_seed(vI[k], W0p[L], 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        const int ixval = sdot2(vX[k + 1], W1p[L], sdot2_seed(vX[k], W0p[L], 1 << (W_BITS - 1))) >> W_BITS;
+        const int iyval = sdot2(vY[k + 1], W1p[L], sdot2_seed(vY[k], W0p[L], 1 << (W_BITS - 1))) >> W_BITS;
+        // (exact mode: lane 63; float-order mode: columns 21..23 of run 2)
+        const bool col_ok = ACCUM == 2 ? (k < WIN - 16 || !lnf->run2) : on;
         pI[k] = ival;  // (0 .. 255 * 32; the derivatives: |.| <= 16 * 255 — all inside int16 as they are)
         pIx[k] = col_ok ? ixval : 0;
         pIy[k] = col_ok ? iyval : 0;
@@ -3225,25 +3240,41 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
         pIyB[L] = pack16(0, pIy[4]);
       }
       if (ACCUM == 2) {
-        lk_float_terms_A<NP>(acc_ta + L * kLkTermLevelA, on, row, x0, pIx, pIy);
+        lk_float_terms_A<8>(lnf->ta, L, pIx, pIy);
       } else {
         float fdummy;
         wave_sum2_exact(sA11, sA12, rl, A11[L], A12[L]);  // already scaled by FLT_SCALE = 2^-20
         wave_sum2_exact(sA22, kRedSeed, rl, A22[L], fdummy);
       }
     }
-    float accA = 0.f;
-    if (ACCUM == 2) accA = lk_float_walk_A(acc_ta, lane);
+    if (ACCUM == 2) {
+      // the walk and what follows it once for all levels: level L's sums end up in the lanes of DPP row L
+      float a11, a12, a22;
+      const float out = lk_float_sums_A(lk_float_walk_A(acc_ta, lane), a11, a12, a22);
+      const float D = a11 * a22 - a12 * a12;
+      const float minEig = (a22 + a11 - sqrtf((a11 - a22) * (a11 - a22) + 4.f * a12 * a12)) / (float)(2 * WIN * WIN);
+      const lanemask_t ok = bal(!(minEig < 1e-4f || D < 1.1920929e-07f /*FLT_EPSILON*/));
+      const float dinv = 1.f / D;
 #pragma unroll
-    for (int L = 0; L < NL; L++) {
-      if (L > c.max_level) continue;
-      if (ACCUM == 2) lk_float_sums_A(accA, L, A11[L], A12[L], A22[L]);
-      const float D = A11[L] * A22[L] - A12[L] * A12[L];
-      const float minEig =
-          (A22[L] + A11[L] - sqrtf((A11[L] - A22[L]) * (A11[L] - A22[L]) + 4.f * A12[L] * A12[L])) /
-          (float)(2 * WIN * WIN);
-      eig_ok[L] = !(minEig < 1e-4f || D < 1.1920929e-07f /*FLT_EPSILON*/);
-      Dinv[L] = 1.f / D;
+      for (int L = 0; L < NL; L++) {
+        if (L > c.max_level) continue;
+        A11[L] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), 16 * L));
+        A12[L] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), 16 * L + 5));
+        A22[L] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(out), 16 * L + 10));
+        Dinv[L] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dinv), 16 * L));
+        eig_ok[L] = (ok >> (16 * L)) & 1;
+      }
+    } else {
+#pragma unroll
+      for (int L = 0; L < NL; L++) {
+        if (L > c.max_level) continue;
+        const float D = A11[L] * A22[L] - A12[L] * A12[L];
+        const float minEig =
+            (A22[L] + A11[L] - sqrtf((A11[L] - A22[L]) * (A11[L] - A22[L]) + 4.f * A12[L] * A12[L])) /
+            (float)(2 * WIN * WIN);
+        eig_ok[L] = !(minEig < 1e-4f || D < 1.1920929e-07f /*FLT_EPSILON*/);
+        Dinv[L] = 1.f / D;
+      }
     }
   }
 
@@ -3326,8 +3357,8 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
           const uint32_t b01 = __float_as_uint(bc.x);
           const uint32_t b10 = __float_as_uint(bc.y);
           const uint32_t iw11 = ((1u << W_BITS) + 3u * 0x4B000000u) - (b00 + b01 + b10);
-          const uint32_t W0 = __builtin_amdgcn_perm(b01, b00, 0x05040100u);
-          const uint32_t W1 = __builtin_amdgcn_perm(iw11, b10, 0x05040100u);
+          const uint32_t W0 = __builtin_amdgcn_perm(b10, b00, 0x05040100u);   // {iw00, iw10}: the left column's rows
+          const uint32_t W1 = __builtin_amdgcn_perm(iw11, b01, 0x05040100u);  // {iw01, iw11}: the right column's
           // NP + 1 bytes of two consecutive staged rows: 3 aligned dwords per row + funnel shifts
           // (v_alignbyte_b32 takes the byte count from the low two bits of its third operand)
           const uint32_t bo = mad_u24_regw(oy, ox) + cbo;
@@ -3343,22 +3374,18 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
             w0[2] = __builtin_amdgcn_alignbyte(a2, a2, bo);
             w1[2] = __builtin_amdgcn_alignbyte(c2, c2, bo);
           }
-          // per pixel: the two horizontally adjacent bytes of each row as an int16 pair (v_perm_b32)
-          // against the packed weight pairs (v_dot2_i32_i16), rounding constant as the accumulator seed
-          uint32_t t[2 * NPP];
+          // per column: its bytes of the two rows as an int16 pair (v_perm_b32); per pixel: its own column against
+          // the left weights plus the next column against the right ones (v_dot2_i32_i16), rounding constant as
+          // the accumulator seed — NP + 1 v_perm for NP pixels
+          uint32_t t[2 * NPP], vc[NP + 1];
 #pragma unroll
-          for (int k = 0; k < NP; k++) {
-            uint32_t p0, p1;
-            if (k < 7) {
-              const uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
-              p0 = __builtin_amdgcn_perm(w0[1], w0[0], sel);
-              p1 = __builtin_amdgcn_perm(w1[1], w1[0], sel);
-            } else {
-              p0 = __builtin_amdgcn_perm(w0[2], w0[1], 0x0c040c03u);
-              p1 = __builtin_amdgcn_perm(w1[2], w1[1], 0x0c040c03u);
-            }
-            t[k] = (uint32_t)sdot2(p1, W1, sdot2_seed(p0, W0, 1 << (W_BITS - 5 - 1)));  // in [1, 2^22]
+          for (int k = 0; k <= NP; k++) {
+            const uint32_t sel = 0x0c000c00u | ((uint32_t)(4 + (k & 3)) << 16) | (uint32_t)(k & 3);
+            vc[k] = __builtin_amdgcn_perm(w1[k >> 2], w0[k >> 2], sel);
           }
+#pragma unroll
+          for (int k = 0; k < NP; k++)
+            t[k] = (uint32_t)sdot2(vc[k + 1], W1, sdot2_seed(vc[k], W0, 1 << (W_BITS - 5 - 1)));  // in [1, 2^22]
 #pragma unroll
           for (int k = NP; k < 2 * NPP; k++) t[k] = 0;
           // CV_DESCALE(.., 9) of two pixels at once: bytes 1..2 of each sum, packed shift by one more
@@ -3589,9 +3616,18 @@ __global__ __launch_bounds__(256) void k_lk_f32(LkKernelArgs a) {
   __shared__ __attribute__((aligned(16))) float term_a[4][kLkTermWordsA];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int i = lane; i < kF32TermWords; i += 64) term_all[wave][i] = 0;  // (the words a segment does not use stay 0)
-  for (int i = lane; i < kLkTermWordsA; i += 64) term_a[wave][i] = 0.f;
+  // (the A table: only the slots no pixel lane writes — the fifth slot of the vector chains' rows — need their zeros)
+  {
+    const int l = lane < 63 ? lane : 62, t = l / kLkWin, rw = l - t * kLkWin;  // a lane per (type, row)
+    float* z = term_a[wave] + 5 * t * kLkChainWordsA + rw * 5 + 4;
+#pragma unroll
+    for (int L = 0; L < kMaxLevels; L++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) z[L * kLkTermLevelA + k * kLkChainWordsA] = 0.f;
+  }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-  const LkLaneF32 lnf = lk_lane_f32(lane);
+  const LkLaneF32 lnf =
+      lk_lane_f32(lane, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)term_a[wave]);
   const uint32_t tb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)term_all[wave];
   lk_kernel_body<2>(a, regJ_s, tb, term_a[wave], &lnf);
 }
