@@ -96,6 +96,9 @@ def parse():
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes for the all-cores CPU figure (-1 = os.cpu_count(), 0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--call-phases", action="store_true",
+                    help="diagnosis: one more replay pass that prints every call's wall time and the library's phases "
+                         "of it (esvio_fe_latency_stats, reset per call) to stderr")
     ap.add_argument("--no-sae-pass", action="store_true",
                     help="skip the event-proportional chain at C5's batch size (`sae_chain_c5_batch` in the line)")
     ap.add_argument("--seed", type=int, default=12345)
@@ -669,6 +672,23 @@ def main():
                                        allocs=lt["max_allocs"], index=lt["max_call"])
         return out, ev, th
 
+    if args.call_phases and rank == 0 and world == 1:
+        run = Runner(pipeline, lazy, dev_batches)
+        for i in range(args.warmup):
+            run.step(i, exchange=False)
+        run.ft.latency_stats(reset=True)
+        tprev = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            run.step(i, exchange=False)
+            tnow = time.perf_counter()
+            lt = run.ft.latency_stats(reset=True)
+            print("call %3d pub %d step %.1f us call %.1f us: %s" % (
+                i, int(pub_flags[i]), (tnow - tprev) * 1e6, lt["max_ms"] * 1e3,
+                ", ".join("%s %.0f" % (k, v * 1e3) for k, v in lt["max_phase_ms"].items())), file=sys.stderr)
+            tprev = time.perf_counter()
+        if lazy:
+            run.ft.finish(copy=False)
+        run.ft.close()
     extra = rank == 0 and world == 1 and not one_rig and not args.no_host_pass
     # ---- the same replay schedule with the events in HOST memory (what the drop-in binding of
     # INTEGRATION.md passes): every batch then crosses PCIe inside the call that prefetches it

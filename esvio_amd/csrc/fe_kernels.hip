@@ -2714,7 +2714,7 @@ constexpr int kLkMargin = 6;
 constexpr int kLkRegW = 40;                              // staged bytes per row (10 dwords)
 constexpr int kLkRegH = kLkWin + 1 + 2 * kLkMargin;      // 34 rows
 constexpr int kLkRegDw = kLkRegW / 4 * kLkRegH;          // 340 dwords per wave
-constexpr int kLkRegStore = kLkRegDw + 4;                // (+ what an 8-column lane of the last row reads past it: unused bytes)
+constexpr int kLkRegStore = (kLkRegDw + 63) / 64 * 64;   // (every lane stores its six dwords; an 8-column lane of the last row reads up to 4 B past the region: unused bytes)
 
 // Exact wave64 sums of two per-lane integers with |v| < 2^28, result as float (one rounding, equal
 // to (float)(int64 sum)) in EVERY lane, VALU only (no readlane / scalar hop):
@@ -2807,23 +2807,44 @@ struct LkCall {
 };
 
 // dword-aligned 34x40 B region of image J around window origin (wx,wy) -> registers
+struct LkRegionLane {  // where this lane's dwords sit inside a region: row and byte column (the same at every level)
+  int ry[(kLkRegDw + 63) / 64], rb[(kLkRegDw + 63) / 64];
+};
+__device__ __forceinline__ LkRegionLane lk_region_lane(int lane) {
+  LkRegionLane r;
+#pragma unroll
+  for (int k = 0; k < (kLkRegDw + 63) / 64; k++) {
+    const int d = min(k * 64 + lane, kLkRegDw - 1);  // (the lanes past the region's end repeat its last dword)
+    r.ry[k] = d / (kLkRegW / 4);
+    r.rb[k] = 4 * (d - r.ry[k] * (kLkRegW / 4));
+  }
+  return r;
+}
 __device__ __forceinline__ void lk_region_load(const uint8_t* J, int stride, int rows, int wx, int wy,
-                                               int lane, int& rx0, int& ry0,
+                                               int lane, const LkRegionLane& rl, int& rx0, int& ry0,
                                                uint32_t (&reg)[(kLkRegDw + 63) / 64]) {
   rx0 = (wx - kLkMargin) & ~3;
   ry0 = wy - kLkMargin;
+  // (wx, wy) is the same in every lane: a region that lies inside the padded buffer — all but the windows at the
+  // image's edge — is ONE scalar base address and a per-lane offset, row * stride + column
+  const int sx = __builtin_amdgcn_readfirstlane(rx0), sy = __builtin_amdgcn_readfirstlane(ry0);
+  if (sx >= -kPad && sx + kLkRegW <= stride - kPad && sy >= -kPad && sy + kLkRegH <= rows + kPad) {
+    const uint8_t* base = J + (ptrdiff_t)sy * stride + sx;
+#pragma unroll
+    for (int k = 0; k < (kLkRegDw + 63) / 64; k++) {
+      uint32_t off;
+      asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(rl.ry[k]), "s"(stride), "v"(rl.rb[k]));
+      reg[k] = *(const uint32_t*)(base + off);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < (kLkRegDw + 63) / 64; k++) {
-    const int d = k * 64 + lane;
-    reg[k] = 0;
-    if (d < kLkRegDw) {
-      const int ry = d / (kLkRegW / 4), rw = d - ry * (kLkRegW / 4);
-      int gy = ry0 + ry, gx = rx0 + 4 * rw;
-      // clamp into the padded buffer; clamped bytes are never used by a valid window
-      gy = min(max(gy, -kPad), rows + kPad - 1);
-      gx = min(max(gx, -kPad), stride - kPad - 4);
-      reg[k] = *(const uint32_t*)(J + (ptrdiff_t)gy * stride + gx);
-    }
+    int gy = ry0 + rl.ry[k], gx = rx0 + rl.rb[k];
+    // clamp into the padded buffer; clamped bytes are never used by a valid window
+    gy = min(max(gy, -kPad), rows + kPad - 1);
+    gx = min(max(gx, -kPad), stride - kPad - 4);
+    reg[k] = *(const uint32_t*)(J + (ptrdiff_t)gy * stride + gx);
   }
 }
 __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
@@ -2831,8 +2852,7 @@ __device__ __forceinline__ void lk_region_store(uint32_t* regJ, int lane,
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
   for (int k = 0; k < (kLkRegDw + 63) / 64; k++) {
-    const int d = k * 64 + lane;
-    if (d < kLkRegDw) regJ[d] = reg[k];
+    regJ[k * 64 + lane] = reg[k];  // (past the region's end: spare words, any value)
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
@@ -3131,6 +3151,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
   const int row = on ? plane / 3 : 0;
   const int x0 = on ? (plane - row * 3) * NP : 0;
   const int lane_bo = row * kLkRegW + x0;  // this lane's byte offset inside a staged window
+  const LkRegionLane rgl = lk_region_lane(lane);
 
   // ---- phase A: the previous-image side of EVERY level depends only on prevPts, so all
   // levels' patches (I, Ix, Iy in registers) and 2x2 matrices are built up front with the
@@ -3331,7 +3352,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       int rx0, ry0;
       {
         uint32_t reg[(kLkRegDw + 63) / 64];
-        lk_region_load(J, stride, rows, inx, iny, lane, rx0, ry0, reg);
+        lk_region_load(J, stride, rows, inx, iny, lane, rgl, rx0, ry0, reg);
         lk_region_store(regJ, lane, reg);
       }
       // window origins the region serves AND the image allows: [lox, lox + rngx] x [loy, loy + rngy]
@@ -3339,7 +3360,7 @@ __device__ __forceinline__ void lk_point(const LkCall& c, const float2 prev0, co
       const uint32_t rngx = (uint32_t)(min(rx0 + (kLkRegW - (WIN + 1)), cols - 1) - lox);
       const uint32_t rngy = (uint32_t)(min(ry0 + (kLkRegH - (WIN + 1)), rows - 1) - loy);
       // LDS byte address of this lane's first tap for the window at (lox, loy)
-      const uint32_t cbo = regJ_b + (uint32_t)(lane_bo + (lox - rx0) + (loy - ry0) * kLkRegW);
+      const uint32_t cbo = regJ_b + (uint32_t)lane_bo + mad_u24_regw((uint32_t)(loy - ry0), (uint32_t)(lox - rx0));
       uint32_t ox = (uint32_t)(inx - lox), oy = (uint32_t)(iny - loy);
       float d2 = 0.f;
       f2 osum = {0.f, 0.f};
