@@ -676,18 +676,18 @@ def main():
         run = Runner(pipeline, lazy, dev_batches)
         for i in range(args.warmup):
             run.step(i, exchange=False)
-        run.ft.latency_stats(reset=True)
-        tprev = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
             run.step(i, exchange=False)
-            tnow = time.perf_counter()
-            lt = run.ft.latency_stats(reset=True)
-            print("call %3d pub %d step %.1f us call %.1f us: %s" % (
-                i, int(pub_flags[i]), (tnow - tprev) * 1e6, lt["max_ms"] * 1e3,
-                ", ".join("%s %.0f" % (k, v * 1e3) for k, v in lt["max_phase_ms"].items())), file=sys.stderr)
-            tprev = time.perf_counter()
         if lazy:
             run.ft.finish(copy=False)
+        prev_end = None
+        for call, pub, t_begin, ms, ph in run.ft.latency_recent(args.steps):  # (read AFTER the run: nothing is perturbed)
+            gap = 0.0 if prev_end is None else t_begin - prev_end
+            prev_end = t_begin + ms
+            print("call %3d pub %d begins %9.1f us (%5.1f after the previous one's end) takes %6.1f us: %s" % (
+                call, int(pub), t_begin * 1e3, gap * 1e3, ms * 1e3,
+                ", ".join("%s %.0f" % (k, v * 1e3) for k, v in ph.items())), file=sys.stderr)
+        print("counters:", run.ft.debug_counters(), file=sys.stderr)
         run.ft.close()
     extra = rank == 0 and world == 1 and not one_rig and not args.no_host_pass
     # ---- the same replay schedule with the events in HOST memory (what the drop-in binding of

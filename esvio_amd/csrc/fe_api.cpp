@@ -69,6 +69,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   (void)launcher_set(c, false);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+  if (c->stream6) (void)hipStreamSynchronize(c->stream6);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   host::ransac_pool_destroy(c->pool);
@@ -168,6 +169,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->h_spec) (void)hipHostFree(c->h_spec);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
+  if (c->stream6) (void)hipStreamDestroy(c->stream6);
   for (auto& r : c->pending) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
@@ -242,7 +244,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-      hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_least) == hipSuccess;
+      hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_least) == hipSuccess &&
+      hipStreamCreateWithPriority(&c->stream6, hipStreamNonBlocking, prio_least) == hipSuccess;
   if (!streams_ok ||
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, c->trace ? 0 : hipEventDisableTiming) != hipSuccess ||
@@ -365,7 +368,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   // One kernel of this library on every stream, now: the runtime loads the code object with the first
   // launch from it and creates a stream's hardware queue with the stream's first use — 2.0-2.4 ms that
   // would otherwise sit inside the first esvio_fe_track_event call (profiles/r04_stall_forensics.md).
-  for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream4}) {
+  for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream4, c->stream6}) {
     launch_fill_f64(st, (double*)c->d_rejected, 1, 0.0);
     if (hipStreamSynchronize(st) != hipSuccess) return bail(ESVIO_FE_EHIP);
   }
@@ -384,6 +387,7 @@ int esvio_fe_reset(esvio_fe_handle c) {
   launcher_clear_error(c);
   HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream4));
+  HIPCHK(c, hipStreamSynchronize(c->stream6));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   // (the main stream as well: a call that returned early in lazy mode, or one that failed half way,
   // may have kernels there that still raise the error flag or write into the pinned result words
@@ -1296,6 +1300,7 @@ int esvio_fe_reserve(esvio_fe_handle c, size_t max_left, size_t max_right, int h
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream4));
+  HIPCHK(c, hipStreamSynchronize(c->stream6));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->tiled) {
     if (int rc = ensure_part_capacity(c, n, false)) return rc;
@@ -1331,6 +1336,14 @@ const char* esvio_fe_latency_phase_name(int i) {
       "pub: previous frame's right tail", "pub: stereo LK of new corners launch", "pub: next batch's prefetch launches",
       "check + take-up of a late batch", "sae: staging the host batch (part of enqueue sae+ts+pyr)"};
   return (i >= 0 && i < ESVIO_FE_LATENCY_PHASES) ? nm[i] : "";
+}
+
+int esvio_fe_latency_recent(esvio_fe_handle c, int back, esvio_fe_latency_call* out) {
+  if (!c || !out || back < 0) return ESVIO_FE_EINVAL;
+  const esvio_fe_ctx::Latency& L = c->lat;
+  if ((uint64_t)back >= L.total_calls || back >= esvio_fe_ctx::Latency::kRecent) return ESVIO_FE_EINVAL;
+  *out = L.recent[(L.total_calls - 1 - (uint64_t)back) % esvio_fe_ctx::Latency::kRecent];
+  return 0;
 }
 
 int esvio_fe_latency_stats(esvio_fe_handle c, esvio_fe_latency* out, int reset) {

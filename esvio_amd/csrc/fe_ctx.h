@@ -141,6 +141,15 @@ struct esvio_fe_ctx {
   // stereo LK of the temporal survivors: nothing on the frame's chain reads its results before the
   // right-camera tail, and on the main stream it would hold up the corner selection behind it
   hipStream_t stream4 = nullptr;
+  // ... of an UNPUBLISHED frame (stereo_stream() below).  The chained temporal LK of the frame after next sits on
+  // stream4 from the published call that launched it until its last point is done; the unpublished frame's stereo
+  // LK queued behind it, the next published frame's behind that, and the published call waited 35-45 us for its
+  // stereo results at its end (and 10-55 for the previous frame's): with the unpublished frame's launch on a stream
+  // of its own both waits are gone — cycle 272 -> 246 us in the trace, 0.131 -> 0.119 ms/step.  (WHICH launches
+  // share a stream matters more than how many streams there are: the published frame's stereo LK and the chained
+  // launch on the new stream instead — `k_select_mw` 17 -> 40 us, cycle 300 us; KERNELS.md.)
+  hipStream_t stream6 = nullptr;
+  bool stereo_unpub = false;  // the frame being tracked publishes nothing
   hipEvent_t ev_planes_free = nullptr;
   // a plain (not announced) call: the frame's images are built (main stream) -> its Arc* pass on the
   // prefetch stream and its stereo LK on stream4 start beside the temporal LK; the Arc* pass is done
@@ -392,6 +401,12 @@ struct esvio_fe_ctx {
     double max_phase[ESVIO_FE_LATENCY_PHASES] = {};
     uint64_t allocs = 0, nivcsw = 0;
     double cur_phase[ESVIO_FE_LATENCY_PHASES] = {};  // the call in progress
+    // the latest calls, whole (esvio_fe_latency_recent)
+    static constexpr int kRecent = 256;
+    esvio_fe_latency_call recent[kRecent] = {};
+    uint64_t total_calls = 0;  // (never reset)
+    bool have_t0 = false;
+    std::chrono::steady_clock::time_point t0;
   } lat;
   uint64_t n_allocs = 0;  // hipMalloc / hipHostMalloc calls of this handle so far
   double slow_call_ms = 0;  // ESVIO_FE_SLOW_CALL_MS: calls slower than this are reported on stderr (0: off)
@@ -409,6 +424,8 @@ namespace fe {
 // The stream the helpers enqueue on: the main stream unless the calling thread has switched to
 // another one (prefetch -> stream2, speculative LK -> stream3).
 inline thread_local hipStream_t t_stream_override = nullptr;
+// the stereo stream of the frame being tracked
+inline hipStream_t stereo_stream(const esvio_fe_ctx* c) { return c->stereo_unpub ? c->stream6 : c->stream4; }
 inline hipStream_t cur_stream(const esvio_fe_ctx* c) {
   return t_stream_override ? t_stream_override : c->stream;
 }

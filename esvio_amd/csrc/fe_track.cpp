@@ -640,15 +640,15 @@ struct TrackCall {
         if (staged) {
           const auto ts1 = clk::now();
           const EventRec* dl2 = nullptr;
-          if (int rc = stager_attach(c, c->cur_stage, nL, c->stream4, &dl2, &dR)) return rc;
+          if (int rc = stager_attach(c, c->cur_stage, nL, stereo_stream(c), &dl2, &dR)) return rc;
           c->lat.cur_phase[15] += std::chrono::duration<double, std::milli>(clk::now() - ts1).count();
         }
         {
-          StreamScope on_stereo_stream(c->stream4);
-          HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_sae_left, 0));  // (the partition scratch is the left chain's until then)
+          StreamScope on_stereo_stream(stereo_stream(c));
+          HIPCHK(c, hipStreamWaitEvent(stereo_stream(c), c->ev_sae_left, 0));  // (the partition scratch is the left chain's until then)
           if (int rc = sae_update(c, nullptr, 0, dR, (uint32_t)nR)) return rc;
           render_and_build_cam(c, c->cur_time, 1, c->slot_curR);
-          HIPCHK(c, hipEventRecord(c->ev_right_ready, c->stream4));
+          HIPCHK(c, hipEventRecord(c->ev_right_ready, stereo_stream(c)));
         }
         split_right = true;
         c->n_cam_split++;
@@ -876,10 +876,10 @@ struct TrackCall {
           f2.chain_seq = c->chain_seq;
           f2.chain_ticks = c->lim.chain;
           f2.poll_err = (int*)(c->z_spec + c->spec_bytes + Mx * 16 + 2 * stM);
-          StreamScope on_stereo_stream(c->stream4);
-          HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_imgs_ready, 0));
+          StreamScope on_stereo_stream(stereo_stream(c));
+          HIPCHK(c, hipStreamWaitEvent(stereo_stream(c), c->ev_imgs_ready, 0));
           run_lk(c, f2, cfg.flow_back ? &b2 : nullptr, zdev(c, pin_st.ptsC), zdev(c, pin_st.stB));
-          HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], c->stream4));
+          HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], stereo_stream(c)));
           c->lks_last = c->res_set;
         }
         if (int rc = early_work()) return rc;
@@ -998,9 +998,9 @@ struct TrackCall {
       {
         // on its own stream.  Its inputs are complete without a device-side wait: the host has just
         // read this frame's temporal LK results, and that launch ran behind the frame's pyramids.
-        StreamScope on_stereo_stream(c->stream4);
+        StreamScope on_stereo_stream(stereo_stream(c));
         run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
-        HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], c->stream4));
+        HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], stereo_stream(c)));
       }
       c->lks_last = c->res_set;
     }
@@ -1137,9 +1137,9 @@ struct TrackCall {
             LkArgs f2 = make_lk(curL, curR, zdev(c, pin.ptsB), nullptr, zdev(c, pin_st.ptsB), zdev(c, pin_st.stA), nullptr, n,
                                 3, 30, 0.01, 0);
             LkArgs b2 = make_lk(curR, curL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 3, 30, 0.01, 0);
-            StreamScope on_stereo_stream(c->stream4);
+            StreamScope on_stereo_stream(stereo_stream(c));
             run_lk(c, f2, cfg.flow_back ? &b2 : nullptr, zdev(c, pin_st.ptsC), zdev(c, pin_st.stB));
-            HIPCHK(c, hipStreamSynchronize(c->stream4));
+            HIPCHK(c, hipStreamSynchronize(stereo_stream(c)));
           }
         }
       }
@@ -1180,7 +1180,7 @@ struct TrackCall {
       if (arc_side)  // (its k_arc_ev read the batch's events on the prefetch stream)
         if (int rc = stager_mark_read(c, c->cur_stage, c->stream2, false)) return rc;
       if (split_right)  // (the right camera's update read its events on the stereo stream)
-        if (int rc = stager_mark_read_aux(c, c->cur_stage, c->stream4)) return rc;
+        if (int rc = stager_mark_read_aux(c, c->cur_stage, stereo_stream(c))) return rc;
       if (int rc = stager_release(c, c->cur_stage)) return rc;
       c->cur_stage = -1;
     }
@@ -1218,6 +1218,18 @@ void latency_commit(esvio_fe_ctx* c, bool pub, clk::time_point t0, int cpu0, lon
   const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
   const long sw = thread_invol_switches() - sw0;
   const uint64_t al = c->n_allocs - allocs0;
+  {
+    if (!L.have_t0) {
+      L.have_t0 = true;
+      L.t0 = t0;
+    }
+    esvio_fe_latency_call& r = L.recent[L.total_calls % esvio_fe_ctx::Latency::kRecent];
+    r.call = L.total_calls++;
+    r.published = pub ? 1 : 0;
+    r.begin_ms = std::chrono::duration<double, std::milli>(t0 - L.t0).count();
+    r.ms = ms;
+    std::memcpy(r.phase_ms, L.cur_phase, sizeof(r.phase_ms));
+  }
   L.ring[L.calls % esvio_fe_ctx::Latency::kRing] = (float)ms;
   L.sum_ms += ms;
   L.allocs += al;
@@ -1257,6 +1269,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
   // (lazy mode, pend_right) while this frame's kernels are enqueued
   c->res_set ^= 1;
+  c->stereo_unpub = !PUB_THIS_FRAME;
   c->frame_no++;
   t.pin = pin_of(c, c->res_set);
   if (PUB_THIS_FRAME && c->pool) host::ransac_pool_wake(c->pool);
@@ -1279,6 +1292,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream4);
+    (void)hipStreamSynchronize(c->stream6);
     (void)hipGetLastError();
     stager_abandon(c, c->cur_stage);
     c->cur_stage = -1;

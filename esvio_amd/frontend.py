@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "esvio_fe_sae_plane_doubles", "esvio_fe_sae_slice_last", "esvio_fe_sae_slice_apply",
     "esvio_fe_sae_slice_commit", "esvio_fe_device_memory", "esvio_fe_exchange_tracks",
     "esvio_fe_comm_unique_id", "esvio_fe_comm_init", "esvio_fe_exchange_begin", "esvio_fe_exchange_end",
-    "esvio_fe_set_auto_exchange", "esvio_fe_reserve", "esvio_fe_latency_stats", "esvio_fe_latency_phase_name",
+    "esvio_fe_set_auto_exchange", "esvio_fe_reserve", "esvio_fe_latency_stats", "esvio_fe_latency_phase_name", "esvio_fe_latency_recent",
     "esvio_fe_set_launch_thread",
 ]
 # test / measurement taps: include/esvio_fe_test.h (not part of the boundary)
@@ -101,6 +101,11 @@ TEST_SYMBOLS = [
 ]
 
 LATENCY_PHASES = 16
+
+
+class LatencyCall(C.Structure):  # esvio_fe_latency_call
+    _fields_ = [("call", C.c_uint64), ("published", C.c_int32), ("reserved", C.c_int32), ("begin_ms", C.c_double),
+                ("ms", C.c_double), ("phase_ms", C.c_double * 16)]
 
 
 class Latency(C.Structure):  # esvio_fe_latency
@@ -201,6 +206,7 @@ def load_library(build_if_missing=True):
     L.esvio_fe_reserve.argtypes = [vp, sz, sz, i]
     L.esvio_fe_set_launch_thread.argtypes = [vp, i]
     L.esvio_fe_latency_stats.argtypes = [vp, C.POINTER(Latency), i]
+    L.esvio_fe_latency_recent.argtypes = [vp, i, C.POINTER(LatencyCall)]
     L.esvio_fe_latency_phase_name.restype = C.c_char_p
     L.esvio_fe_latency_phase_name.argtypes = [i]
     L.esvio_fe_ransac_tail.argtypes = [vp, i]
@@ -502,6 +508,19 @@ class FeatureTracker:
                     max_cpu=(int(o.max_cpu_begin), int(o.max_cpu_end)), max_invol_switches=int(o.max_invol_switches),
                     max_allocs=int(o.max_allocs), max_phase_ms=phases, allocs=int(o.allocs),
                     invol_switches=int(o.invol_switches))
+
+    def latency_recent(self, n):
+        """the latest n (<= 256) track calls, oldest first: (call, published, begin_ms, ms, {phase: ms})"""
+        L = self._hd.L
+        names = [L.esvio_fe_latency_phase_name(k).decode() for k in range(LATENCY_PHASES)]
+        out = []
+        for back in range(n - 1, -1, -1):
+            o = LatencyCall()
+            if L.esvio_fe_latency_recent(self._hd.h, back, C.byref(o)) != 0:
+                continue
+            out.append((int(o.call), bool(o.published), o.begin_ms, o.ms,
+                        {names[k]: o.phase_ms[k] for k in range(LATENCY_PHASES) if o.phase_ms[k] > 0.0005}))
+        return out
 
     def debug_inject(self, mask):
         """make device-side waits expire on demand (FAULT_TICKET | FAULT_LOOKBACK | FAULT_SPECULATIVE |

@@ -53,6 +53,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(FE.Tracks) == 8 + 9 * 8
     # esvio_fe_latency: u64, 4 doubles, u64, 3 x i32 (+ 4 padding), 2 x i64, 16 doubles, 2 x u64
     assert C.sizeof(FE.Latency) == 8 + 32 + 8 + 16 + 16 + 16 * 8 + 16 and FE.LATENCY_PHASES == 16
+    # esvio_fe_latency_call: u64, 2 x i32, 2 doubles, 16 doubles
+    assert C.sizeof(FE.LatencyCall) == 8 + 8 + 16 + 16 * 8
     L = FE.load_library()
     names = [L.esvio_fe_latency_phase_name(i).decode() for i in range(FE.LATENCY_PHASES)]
     assert names[0].startswith("enqueue") and names[4] == "host ransac" and L.esvio_fe_latency_phase_name(99) == b""
