@@ -97,8 +97,8 @@ def parse():
                     help="processes for the all-cores CPU figure (-1 = os.cpu_count(), 0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--call-phases", action="store_true",
-                    help="diagnosis: one more replay pass that prints every call's wall time and the library's phases "
-                         "of it (esvio_fe_latency_stats, reset per call) to stderr")
+                    help="diagnosis: every call of the last timed pass with its begin time, wall time and the library's "
+                         "phases of it (esvio_fe_latency_recent, read after the passes) to stderr")
     ap.add_argument("--no-sae-pass", action="store_true",
                     help="skip the event-proportional chain at C5's batch size (`sae_chain_c5_batch` in the line)")
     ap.add_argument("--seed", type=int, default=12345)
@@ -550,6 +550,15 @@ def main():
         ransac_passes.append(FE.ransac_stats())
         lib_lat.append(ft.latency_stats())
     throttle1 = cgroup_cpu_stat()
+    if args.call_phases and rank == 0:  # (read AFTER the timed passes: looking changes nothing)
+        prev_end = None
+        for call, pub, t_begin, ms, ph in ft.latency_recent(args.steps):
+            gap = 0.0 if prev_end is None else t_begin - prev_end
+            prev_end = t_begin + ms
+            print("call %3d pub %d begins %9.1f us (%5.1f after the previous one's end) takes %6.1f us: %s" % (
+                call, int(pub), t_begin * 1e3, gap * 1e3, ms * 1e3,
+                ", ".join("%s %.0f" % (k, v * 1e3) for k, v in ph.items())), file=sys.stderr)
+        print("counters:", ft.debug_counters(), file=sys.stderr)
     try:
         os_threads = len(os.listdir("/proc/self/task"))
     except Exception:
@@ -672,23 +681,6 @@ def main():
                                        allocs=lt["max_allocs"], index=lt["max_call"])
         return out, ev, th
 
-    if args.call_phases and rank == 0 and world == 1:
-        run = Runner(pipeline, lazy, dev_batches)
-        for i in range(args.warmup):
-            run.step(i, exchange=False)
-        for i in range(args.warmup, args.warmup + args.steps):
-            run.step(i, exchange=False)
-        if lazy:
-            run.ft.finish(copy=False)
-        prev_end = None
-        for call, pub, t_begin, ms, ph in run.ft.latency_recent(args.steps):  # (read AFTER the run: nothing is perturbed)
-            gap = 0.0 if prev_end is None else t_begin - prev_end
-            prev_end = t_begin + ms
-            print("call %3d pub %d begins %9.1f us (%5.1f after the previous one's end) takes %6.1f us: %s" % (
-                call, int(pub), t_begin * 1e3, gap * 1e3, ms * 1e3,
-                ", ".join("%s %.0f" % (k, v * 1e3) for k, v in ph.items())), file=sys.stderr)
-        print("counters:", run.ft.debug_counters(), file=sys.stderr)
-        run.ft.close()
     extra = rank == 0 and world == 1 and not one_rig and not args.no_host_pass
     # ---- the same replay schedule with the events in HOST memory (what the drop-in binding of
     # INTEGRATION.md passes): every batch then crosses PCIe inside the call that prefetches it
