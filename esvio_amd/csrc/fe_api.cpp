@@ -244,8 +244,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) == hipSuccess &&
       hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-      hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_least) == hipSuccess &&
-      hipStreamCreateWithPriority(&c->stream6, hipStreamNonBlocking, prio_least) == hipSuccess;
+      hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_least) == hipSuccess;
   if (!streams_ok ||
       hipEventCreateWithFlags(&c->ev_pts_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_spec_done, c->trace ? 0 : hipEventDisableTiming) != hipSuccess ||
@@ -295,6 +294,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   c->stage_threads = stager_threads_from_env();
   if (const char* v = getenv("ESVIO_FE_FAULT")) esvio_fe_debug_inject(c, atoi(v));
   c->part_two_level = getenv("ESVIO_FE_PART2") != nullptr;  // (measured slower than the one-level partition: opt-in, KERNELS.md)
+  if (const char* e = getenv("ESVIO_FE_STEREO_SPLIT")) c->stereo_split_env = atoi(e) != 0;  // (else: fe_track.cpp decides)
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
   c->cam_split_enabled = getenv("ESVIO_FE_NO_CAMSPLIT") == nullptr;
   c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
@@ -368,10 +368,35 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   // One kernel of this library on every stream, now: the runtime loads the code object with the first
   // launch from it and creates a stream's hardware queue with the stream's first use — 2.0-2.4 ms that
   // would otherwise sit inside the first esvio_fe_track_event call (profiles/r04_stall_forensics.md).
-  for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream4, c->stream6}) {
+  for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream4}) {
     launch_fill_f64(st, (double*)c->d_rejected, 1, 0.0);
     if (hipStreamSynchronize(st) != hipSuccess) return bail(ESVIO_FE_EHIP);
   }
+  // Which of these streams share a hardware queue?  The runtime hands out at most GPU_MAX_HW_QUEUES (4) queues per
+  // priority level and process, then doubles up — and two streams on one queue run their kernels one after the
+  // other (tools/queue_probe.hip), which for this schedule means a frame's prefetch behind another frame's waiting
+  // LK launch.  Counted once per handle (a 100 us spin on one stream, an empty kernel on the other: ~1.2 ms for
+  // the ten pairs), reported by esvio_fe_debug_counters and, with ESVIO_FE_QUEUE_PROBE=1, on stderr.
+  if (getenv("ESVIO_FE_QUEUE_PROBE")) {
+    const hipStream_t st[5] = {c->stream, c->stream2, c->stream3, c->stream4, c->stream4};
+    const char* nm[5] = {"main", "prefetch", "speculative", "stereo", "stereo-unpublished"};
+    for (int a = 0; a < 5; a++)
+      for (int b = 0; b < 5; b++) {
+        if (a == b) continue;
+        launch_spin(st[a], 10000);
+        const auto t0 = std::chrono::steady_clock::now();
+        launch_fill_f64(st[b], (double*)c->d_rejected, 1, 0.0);
+        (void)hipStreamSynchronize(st[b]);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        (void)hipStreamSynchronize(st[a]);
+        if (us > 60.0) {
+          c->n_queue_conflicts++;
+          fprintf(stderr, "[esvio_fe] streams '%s' and '%s' share a hardware queue (%.0f us behind a 100 us kernel)\n", nm[b], nm[a], us);
+        }
+      }
+    if (!c->n_queue_conflicts) fprintf(stderr, "[esvio_fe] the handle's five streams have a hardware queue each\n");
+  }
+  if (int rc = stereo_split_prepare(c)) return bail(rc);  // (ESVIO_FE_STEREO_SPLIT=1)
   // The greedy selections (Event_FeaturesToTrack, goodFeaturesToTrack's min-distance pass) keep
   // their one-bit-per-pixel map in LDS; above ~1.3 M pixels (the frame cameras of the shipped ESVIO
   // configs go up to 1920x1200) it lives in device memory instead (k_select_gbm)
@@ -387,7 +412,7 @@ int esvio_fe_reset(esvio_fe_handle c) {
   launcher_clear_error(c);
   HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream4));
-  HIPCHK(c, hipStreamSynchronize(c->stream6));
+  if (c->stream6) HIPCHK(c, hipStreamSynchronize(c->stream6));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   // (the main stream as well: a call that returned early in lazy mode, or one that failed half way,
   // may have kernels there that still raise the error flag or write into the pinned result words
@@ -1200,6 +1225,12 @@ static int set_next_batch_impl(esvio_fe_handle c, double next_cur_time, const es
     // no gain in the bench's configuration — 0.136-0.146 ms/step either way — and a loss without the RANSAC
     // helpers' share of the copying, 0.140 -> 0.165-0.18; two DMA engines at once: 0.197)
     if (int rc = stager_begin(c, left, nL, right, nR, 1, &b.stage)) return rc;
+  } else if (space == ESVIO_FE_DEVICE && !c->stream6) {
+    // (the first announcement of a batch that is already on the device: the second stereo stream, if this handle
+    // is going to use it — here and not in esvio_fe_set_launch_thread, because a handle that is fed host batches
+    // never splits and a stream it does not use still takes a hardware queue from the process's pool)
+    HIPCHK(c, hipSetDevice(c->dev));
+    if (int rc = stereo_split_prepare(c)) return rc;
   }
   c->announced.push_back(b);
   return 0;
@@ -1300,7 +1331,7 @@ int esvio_fe_reserve(esvio_fe_handle c, size_t max_left, size_t max_right, int h
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream3));
   HIPCHK(c, hipStreamSynchronize(c->stream4));
-  HIPCHK(c, hipStreamSynchronize(c->stream6));
+  if (c->stream6) HIPCHK(c, hipStreamSynchronize(c->stream6));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->tiled) {
     if (int rc = ensure_part_capacity(c, n, false)) return rc;

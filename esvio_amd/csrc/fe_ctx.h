@@ -149,7 +149,11 @@ struct esvio_fe_ctx {
   // share a stream matters more than how many streams there are: the published frame's stereo LK and the chained
   // launch on the new stream instead — `k_select_mw` 17 -> 40 us, cycle 300 us; KERNELS.md.)
   hipStream_t stream6 = nullptr;
-  bool stereo_unpub = false;  // the frame being tracked publishes nothing
+  bool stereo_unpub = false;  // the frame being tracked publishes nothing (and stereo_split is on)
+  // -1: lk_accum == 2 && launch thread on (decided per call); 0 / 1: ESVIO_FE_STEREO_SPLIT
+  int stereo_split_env = -1;
+  bool stereo_split = false;
+  int n_queue_conflicts = 0;  // pairs of the handle's streams found on one hardware queue (ESVIO_FE_QUEUE_PROBE)
   hipEvent_t ev_planes_free = nullptr;
   // a plain (not announced) call: the frame's images are built (main stream) -> its Arc* pass on the
   // prefetch stream and its stereo LK on stream4 start beside the temporal LK; the Arc* pass is done

@@ -121,6 +121,7 @@ void stager_copy_bytes(uint8_t* dst, const uint8_t* src, size_t len);  // (test 
 // ---------------------------------------------------------------- fe_track.cpp
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first = false);
 int launcher_set(esvio_fe_ctx* c, bool on);   // start / stop the launch thread
+int stereo_split_prepare(esvio_fe_ctx* c);   // the second stereo stream, if this handle may use it (fe_track.cpp)
 int launcher_drain(esvio_fe_ctx* c);          // every job handed over has been issued (returns the first job error)
 int launcher_wait_lane(esvio_fe_ctx* c, int lane);  // ... the job that records this lane's events
 void launcher_clear_error(esvio_fe_ctx* c);   // esvio_fe_reset: a failed job.s sticky error is dropped with the batches

@@ -285,6 +285,7 @@ void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const Ti
 // ---- time-slice composition (one stream cut into N slices, one per GPU) -------------------
 constexpr double kSliceNone = -1.0;  // "this slice wrote nothing here" (event times are >= 0)
 void launch_fill_f64(hipStream_t s, double* p, size_t n, double v);
+void launch_spin(hipStream_t s, unsigned long long ticks);  // (100 MHz ticks)
 // dst[i] = src[i] unless src[i] == none
 void launch_overlay_f64(hipStream_t s, double* dst, const double* src, size_t n, double none);
 

@@ -2062,6 +2062,14 @@ __global__ __launch_bounds__(256) void k_overlay_f64(double* __restrict__ dst, c
   }
 }
 
+// one wave that does nothing for `ticks` of the 100 MHz wall clock (esvio_fe_create's look at which of the handle's
+// streams the runtime has put on one hardware queue)
+__global__ void k_spin(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+void launch_spin(hipStream_t s, unsigned long long ticks) { launch_k(k_spin, dim3(1), dim3(64), 0, s, ticks); }
+
 void launch_fill_f64(hipStream_t s, double* p, size_t n, double v) {
   if (!n) return;
   launch_k(k_fill_f64, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, p, n, v);

@@ -141,6 +141,23 @@ struct Launcher {
   }
 };
 
+// The second stereo stream (esvio_fe_ctx::stream6), made when it is going to be used — at the first announcement of
+// a device-resident batch with the launch thread on and the float-order LK mode, or at creation when
+// ESVIO_FE_STEREO_SPLIT=1 asks for it — never inside a track call (a stream's hardware queue comes with its first
+// launch: 2 ms).  Normal priority: the runtime has four hardware queues per priority
+// level and process, and with a third least-priority stream per handle the second handle of a process finds its
+// prefetch stream on its stereo stream's queue (tools/queue_probe.hip); a handle that never splits keeps the four
+// streams it had.
+int stereo_split_prepare(esvio_fe_ctx* c) {
+  if (c->stream6) return 0;
+  const bool wanted = c->stereo_split_env >= 0 ? c->stereo_split_env != 0 : (c->cfg.lk_accum == 2 && c->launcher != nullptr);
+  if (!wanted) return 0;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->stream6, hipStreamNonBlocking));
+  launch_spin(c->stream6, 0);
+  HIPCHK(c, hipStreamSynchronize(c->stream6));
+  return 0;
+}
+
 int launcher_set(esvio_fe_ctx* c, bool on) {
   if (on == (c->launcher != nullptr)) return 0;
   // (job numbers are per launcher: a lane whose events were recorded before — by the calling thread, or by a
@@ -1269,7 +1286,13 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
   // set 1 alternates between its two copies: the previous frame's stereo LK may still be in flight
   // (lazy mode, pend_right) while this frame's kernels are enqueued
   c->res_set ^= 1;
-  c->stereo_unpub = !PUB_THIS_FRAME;
+  // (measured, KERNELS.md: the second stereo stream pays where the device chain is the bound — the float-order LK's
+  // launches, 1.6x the exact mode's, with the launch thread issuing the prefetch and the events already on the
+  // device; the exact mode's cycle gets 5 % longer with it, and so does a caller that issues every launch itself
+  // or hands over host batches)
+  c->stereo_split = c->stream6 && (c->stereo_split_env >= 0 ? c->stereo_split_env != 0
+                                                            : (c->cfg.lk_accum == 2 && c->launcher != nullptr && c->stager == nullptr));
+  c->stereo_unpub = !PUB_THIS_FRAME && c->stereo_split;
   c->frame_no++;
   t.pin = pin_of(c, c->res_set);
   if (PUB_THIS_FRAME && c->pool) host::ransac_pool_wake(c->pool);
@@ -1292,7 +1315,7 @@ int track_event_impl(esvio_fe_ctx* c, double _cur_time, const esvio_fe_event* le
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamSynchronize(c->stream4);
-    (void)hipStreamSynchronize(c->stream6);
+    if (c->stream6) (void)hipStreamSynchronize(c->stream6);
     (void)hipGetLastError();
     stager_abandon(c, c->cur_stage);
     c->cur_stage = -1;
