@@ -785,6 +785,56 @@ def test_next_batch_prefetch_is_transparent(oracle, equalize, hint, depth, lazy,
     ft.close()
 
 
+@pytest.mark.parametrize("split,lk_accum,pattern", [("1", 2, "alt"), ("1", 2, "2of3"), ("0", 2, "alt"), (None, 2, "alt"),
+                                                     ("1", 1, "alt"), (None, 1, "alt")])
+def test_replay_with_the_unpublished_frames_stereo_lk_on_its_own_stream(oracle, monkeypatch, split, lk_accum, pattern):
+    """the replay schedule the bench runs — device-resident batches announced three ahead, lazy mode, the launch
+    thread — with the stereo LK of the unpublished frames on the second stereo stream (ESVIO_FE_STEREO_SPLIT=1: forced;
+    unset: the library's own rule, float-order LK + launch thread + device-resident batches), switched off, and with
+    publish patterns that put two published / two unpublished frames next to each other: every frame bit-identical to
+    the sequential oracle, lazily returned frames completed by finish() or by the next call"""
+    if split is None:
+        monkeypatch.delenv("ESVIO_FE_STEREO_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("ESVIO_FE_STEREO_SPLIT", split)
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=5e6, seed=21)
+    batches = [s.next_batch()[:2] for _ in range(16)]
+    keep = []
+
+    def to_dev(a):
+        keep.append(FE.EventBuffer(a, FE.DEVICE))
+        return keep[-1].arg
+    dev = [(to_dev(L), to_dev(R)) for L, R in batches]
+    pubs = [f % 2 == 0 for f in range(len(batches))] if pattern == "alt" else [f % 3 != 1 for f in range(len(batches))]
+    kw = dict(f_ransac=1, lk_accum=lk_accum)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(True)
+    ft.set_launch_thread(True)
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        while announced < min(f + 3, len(batches) - 1):
+            announced += 1
+            ft.set_next_batch(event_times(batches[announced][0])[-1], dev[announced][0], dev[announced][1], pubs[announced])
+        t = event_times(L)[-1]
+        if f == 9:  # (the launch thread switched off and on again with batches in flight: the rule follows it)
+            ft.set_launch_thread(False)
+        if f == 11:
+            ft.set_launch_thread(True)
+        ft.trackEvent(t, dev[f][0], dev[f][1], pubs[f])
+        r = tr.track_event(t, L, R, pubs[f])
+        for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"):
+            assert np.array_equal(getattr(ft, k), getattr(r, k)), (k, f)
+        if f % 3 == 2 or f == len(batches) - 1:
+            ft.finish()
+            _compare_tracks(ft, r, ("stereo split", split, lk_accum, pattern, f))
+    assert len(ft.ids) > 100
+    ft.close()
+    for b in keep:
+        b.free()
+
+
 def test_two_batches_ahead_need_an_exact_pub_hint(monkeypatch):
     """with two batches in flight the SAE has moved past a frame by the time it is tracked, so a
     published frame whose hint was 0 (no prefetched Arc* pass) is refused instead of detecting on
