@@ -846,9 +846,11 @@ def main():
             # tools/clock_probe.hip.
             ps = O.lk_pair_stats(True)
             # round 5's loops (gfx950 ISA of lk_point's inner loop, every instruction counted — a lone wave issues one
-            # instruction of ANY kind per ~4 cycles at best): exact sums 129, float order 185 (one walking round);
-            # us per iteration and the per-launch constant from tools/lk_const_probe.py on this GPU
-            instr, us_iter, const_us = (129, 0.336, 8.5) if args.lk_accum == 1 else (185, 0.507, 11.0)
+            # instruction of ANY kind per ~4 cycles at best): exact sums 123, float order 178 (one walking round);
+            # us per iteration (a few points: no straggler statistics in it) and the launch's fixed part — the launch
+            # constant (7 / 9 us) + the six level visits of a forward + backward pair at 2.0 us each — from
+            # tools/lk_const_probe.py on this GPU
+            instr, us_iter, const_us = (123, 0.26, 19.0) if args.lk_accum == 1 else (178, 0.41, 21.0)
             ghz = 2.4
             roof["issue_model"] = dict(
                 lk_accum=args.lk_accum,
