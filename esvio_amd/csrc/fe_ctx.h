@@ -408,7 +408,7 @@ struct esvio_fe_ctx {
     // the latest calls, whole (esvio_fe_latency_recent)
     static constexpr int kRecent = 256;
     esvio_fe_latency_call recent[kRecent] = {};
-    uint64_t total_calls = 0;  // (never reset)
+    uint64_t total_calls = 0;
     bool have_t0 = false;
     std::chrono::steady_clock::time_point t0;
   } lat;

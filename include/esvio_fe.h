@@ -414,11 +414,11 @@ typedef struct esvio_fe_latency {
 int esvio_fe_latency_stats(esvio_fe_handle h, esvio_fe_latency* out, int reset);
 const char* esvio_fe_latency_phase_name(int i);
 /* One of the latest 256 track calls as the record above saw it (back = 0: the last call, 1: the one before ...):
- * when it began (ms since the handle's first track call), how long it took, whether it published, and its phases —
+ * when it began (ms since the first track call after the last reset), how long it took, whether it published, and its phases —
  * read AFTER a run, so that looking does not change the schedule that is looked at.  ESVIO_FE_EINVAL for a call
  * that is not kept (any more). */
 typedef struct esvio_fe_latency_call {
-  uint64_t call;      /* index of the call since the handle was created */
+  uint64_t call;      /* index of the call since the last reset of esvio_fe_latency_stats (as max_call there) */
   int32_t published;
   int32_t reserved;
   double begin_ms, ms;

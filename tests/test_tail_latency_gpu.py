@@ -73,7 +73,7 @@ def _run(batches, host_threads, steps, warm, launch=False):
     # esvio_fe_latency_recent: the latest calls one by one — consecutive indices, one after the other in time, the
     # phases of a call inside its wall time, publish flags as called; the slowest of them no slower than the record's
     rec = ft.latency_recent(64)
-    assert len(rec) == 64 and [r[0] for r in rec] == list(range(warm + steps - 64, warm + steps))
+    assert len(rec) == 64 and [r[0] for r in rec] == list(range(steps - 64, steps))  # (indices since the reset at `warm`)
     assert [r[1] for r in rec] == [bool(p) for p in pubs[warm + steps - 64:warm + steps]]
     for a, b in zip(rec, rec[1:]):
         assert a[2] + a[3] <= b[2] + 1e-6
@@ -81,7 +81,7 @@ def _run(batches, host_threads, steps, warm, launch=False):
         top = {k: v for k, v in r[4].items() if not k.startswith("pub:") and not k.startswith("sae:")}
         assert 0.0 < r[3] and sum(top.values()) <= r[3] + 1e-3, r
     assert max(r[3] for r in rec) <= lat["max_ms"] + 1e-9
-    assert ft.latency_recent(300)[0][0] == warm + steps - 256  # (256 are kept)
+    assert ft.latency_recent(300)[0][0] == steps - 256  # (256 are kept)
     allocs_after_reserve.append(lat["allocs"])
     tail = FE.ransac_tail()
     n_tracks = len(ft.ids)
