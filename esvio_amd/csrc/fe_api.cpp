@@ -137,7 +137,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->x_pin) (void)hipHostFree(c->x_pin);
   if (c->x_pin_recv) (void)hipHostFree(c->x_pin_recv);
   void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_warp, c->d_tile, c->d_part2, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
-                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
+                  c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_lane_gate, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx, c->d_sel_bitmap, c->d_eq_tmp,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
                   c->d_minmax};
@@ -291,6 +291,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     std::memset(c->h_spec, 0, 2 * c->spec_bytes);
   }
   if ((rc = dev_alloc(c, &c->d_chain, 2 * std::max<size_t>(M, 1)))) return bail(rc);
+  if ((rc = dev_alloc(c, &c->d_lane_gate, 16))) return bail(rc);
   c->stage_threads = stager_threads_from_env();
   if (const char* v = getenv("ESVIO_FE_FAULT")) esvio_fe_debug_inject(c, atoi(v));
   c->part_two_level = getenv("ESVIO_FE_PART2") != nullptr;  // (measured slower than the one-level partition: opt-in, KERNELS.md)
@@ -322,7 +323,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   }
   if ((rc = dev_alloc(c, &c->d_pub_slots, std::max<size_t>(M, 1)))) return bail(rc);
   if ((rc = dev_alloc(c, &c->d_pub_done, 1))) return bail(rc);
-  if (hipMemsetAsync(c->d_chain, 0, std::max<size_t>(M, 1) * 16, cur_stream(c)) != hipSuccess ||
+  if (hipMemsetAsync(c->d_lane_gate, 0, 64, cur_stream(c)) != hipSuccess ||
+      hipMemsetAsync(c->d_chain, 0, std::max<size_t>(M, 1) * 16, cur_stream(c)) != hipSuccess ||
       hipMemsetAsync(c->d_pub_slots, 0, std::max<size_t>(M, 1) * 8, cur_stream(c)) != hipSuccess ||
       hipMemsetAsync(c->d_pub_done, 0, 8, cur_stream(c)) != hipSuccess)
     return bail(ESVIO_FE_EHIP);
@@ -395,6 +397,24 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
         }
       }
     if (!c->n_queue_conflicts) fprintf(stderr, "[esvio_fe] the handle's five streams have a hardware queue each\n");
+  }
+  // ... and a burst of launches chained across the streams by events, nothing of it awaited until the end: the
+  // runtime's pools of completion signals and command records grow on demand, a few milliseconds each time and inside
+  // whichever launch needs one more — in a bench process that was a track call around frame 20 of the first timed pass
+  // in one cold run of ten (profiles/r05_stall_hunt.txt: 1.6-4.7 ms in `speculative + chained LK launches` or in the
+  // wait for the launch thread, never a lost CPU, never an allocation of ours).  The replay schedule keeps ~60
+  // launches and ~25 cross-stream waits in flight; this puts 4 x 96 launches and as many waits in flight at once.
+  {
+    const hipStream_t st[4] = {c->stream, c->stream2, c->stream3, c->stream4};
+    hipEvent_t ev[4] = {c->ev_imgs_ready, c->ev_planes_free, c->ev_arc_side, c->ev_sae_left};  // (unused so far)
+    for (int r = 0; r < 96; r++)
+      for (int i = 0; i < 4; i++) {
+        launch_spin(st[i], r == 0 ? 20000 : 0);  // (the first round's kernels hold everything behind them for 200 us)
+        (void)hipEventRecord(ev[i], st[i]);
+        (void)hipStreamWaitEvent(st[(i + 1) & 3], ev[i], 0);
+      }
+    for (int i = 0; i < 4; i++)
+      if (hipStreamSynchronize(st[i]) != hipSuccess) return bail(ESVIO_FE_EHIP);
   }
   if (int rc = stereo_split_prepare(c)) return bail(rc);  // (ESVIO_FE_STEREO_SPLIT=1)
   // The greedy selections (Event_FeaturesToTrack, goodFeaturesToTrack's min-distance pass) keep

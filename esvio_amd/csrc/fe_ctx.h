@@ -111,6 +111,7 @@ struct Inflight : Batch {
   int slotL = 0, slotR = 0, raw = 0, cand = 0;
   const EventRec *dL = nullptr, *dR = nullptr;
   bool arc_done = false;
+  uint32_t gate = 0;  // != 0: the value the batch's prefetch sequence leaves in d_lane_gate[lane] (issued by the launch thread)
 };
 constexpr int kPrefetchDepth = 3;
 // host-event staging slots: one per batch the handle can know about at a time (2 * kPrefetchDepth
@@ -281,6 +282,9 @@ struct esvio_fe_ctx {
   // second half of h_spec, indexed like the producer's points; the intermediate frame's temporal
   // filter gives the map from the final frame's prev_pts to those indices.
   unsigned long long* d_chain = nullptr;  // [2 * max_cnt] published forward results
+  // one word per prefetch lane: the serial number of the last prefetch sequence that has RUN there (LkArgs::gate_*)
+  uint32_t* d_lane_gate = nullptr;
+  uint32_t gate_seq = 0;
   uint32_t chain_seq = 0;
   bool chain_enabled = true;   // (ESVIO_FE_NO_CHAIN=1 turns it off: A/B measurements)
   bool cam_split_enabled = true;  // a plain call runs the two cameras' updates on two streams (ESVIO_FE_NO_CAMSPLIT=1: one)

@@ -286,6 +286,7 @@ void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const Ti
 constexpr double kSliceNone = -1.0;  // "this slice wrote nothing here" (event times are >= 0)
 void launch_fill_f64(hipStream_t s, double* p, size_t n, double v);
 void launch_spin(hipStream_t s, unsigned long long ticks);  // (100 MHz ticks)
+void launch_set_u32(hipStream_t s, uint32_t* p, uint32_t v);  // *p = v, visible device-wide, behind everything enqueued on s so far
 // dst[i] = src[i] unless src[i] == none
 void launch_overlay_f64(hipStream_t s, double* dst, const double* src, size_t n, double none);
 
@@ -349,6 +350,12 @@ struct LkArgs {
   const unsigned long long* chain_in = nullptr;
   uint32_t chain_seq = 0;  // 30 bits, never 0
   unsigned long long poll_ticks = kTicksPoll, chain_ticks = kTicksChain;  // bounds of the two waits
+  // gate: the kernel's waves go on only when *gate_ptr has reached gate_val (serial-number compare) — the `next`
+  // pyramid of a chained launch is built by a prefetch sequence another thread is still issuing, so a stream wait
+  // on that sequence's event cannot be enqueued yet; the sequence's last launch writes the word (launch_set_u32).
+  // Bounded by chain_ticks, failure in *poll_err like the other waits.
+  const uint32_t* gate_ptr = nullptr;
+  uint32_t gate_val = 0;
   int max_level;
   int max_count;
   double eps2;

@@ -2069,6 +2069,10 @@ __global__ void k_spin(unsigned long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 void launch_spin(hipStream_t s, unsigned long long ticks) { launch_k(k_spin, dim3(1), dim3(64), 0, s, ticks); }
+__global__ void k_set_u32(uint32_t* p, uint32_t v) {
+  if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_set_u32(hipStream_t s, uint32_t* p, uint32_t v) { launch_k(k_set_u32, dim3(1), dim3(64), 0, s, p, v); }
 
 void launch_fill_f64(hipStream_t s, double* p, size_t n, double v) {
   if (!n) return;
@@ -3540,6 +3544,8 @@ struct LkKernelArgs {
   const unsigned long long* chain_in;
   uint32_t chain_seq;
   unsigned long long poll_ticks, chain_ticks;  // bounds of the two waits (wall_clock64: 100 MHz)
+  const uint32_t* gate_ptr;  // see LkArgs::gate_*
+  uint32_t gate_val;
 };
 
 // producer side of a chained launch: point `pt`'s forward result (alive = its status), or alive = 0
@@ -3590,6 +3596,19 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
       return;
     }
     prev0 = make_float2(__uint_as_float((uint32_t)vx), __uint_as_float((uint32_t)vy));
+    if (a.gate_ptr) {
+      // ... and for the `next` pyramid: its prefetch sequence may not even have been issued when this launch was made
+      for (;;) {
+        const uint32_t gv = __hip_atomic_load(a.gate_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(gv - a.gate_val) >= 0) break;
+        if (wall_clock64() - t0 > a.chain_ticks) {
+          if (lane == 0) *a.poll_err = 1;
+          return;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (what the sequence's kernels wrote, not what this CU may have cached)
+    }
   } else if (a.poll_slots && pt >= a.poll_from) {
     // this point is a corner k_select may still be about to accept: wait for its slot (or for the
     // final count to rule it out).  wall_clock64 ticks at 100 MHz: give up after kTicksPoll = 20 ms.
@@ -3699,6 +3718,8 @@ void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts
   a.chain_seq = f.chain_seq;
   a.poll_ticks = f.poll_ticks;
   a.chain_ticks = f.chain_ticks;
+  a.gate_ptr = f.gate_ptr;
+  a.gate_val = f.gate_val;
   if (f.accum == 2)
     launch_k(k_lk_f32, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
   else

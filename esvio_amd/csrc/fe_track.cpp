@@ -63,6 +63,8 @@ static int prefetch_issue(esvio_fe_ctx* c, const PrefetchJob& j) {
     render_and_build(c, b.time, b.slotL, b.slotR, b.raw);
     if (record_event(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
       rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
+    // (a sequence issued by the launch thread: the word a chained LK launch made before this point waits for)
+    if (!rc && b.gate) launch_set_u32(c->stream2, c->d_lane_gate + b.lane, b.gate);
   }
   if (as_graph) {
     set_launch_recorder(nullptr);
@@ -84,6 +86,13 @@ static int prefetch_issue(esvio_fe_ctx* c, const PrefetchJob& j) {
   // (the last kernels on this stream that read the batch's events)
   if (b.stage >= 0)
     if (int rc2 = stager_mark_read(c, b.stage, c->stream2, false)) return rc2;
+  // Nobody ever synchronises with this stream (the frames wait for its events), and the runtime retires a stream's
+  // commands only when somebody looks: left alone it does so itself after ~250 launches — frame 19 of a stream — in a
+  // blocking sweep of 1.5-4.5 ms inside whichever call comes next, on this thread or, through the runtime's lock, on
+  // the caller's (4 of 30 cold bench runs, always call 13 or 15 of the timed pass: profiles/r05_stall_hunt.txt).
+  // A query per sequence lets it retire what has completed, a few commands at a time.
+  (void)hipStreamQuery(c->stream2);
+  (void)hipGetLastError();  // (hipErrorNotReady is the normal answer)
   return 0;
 }
 
@@ -280,6 +289,8 @@ int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first) {
       if (b.arc_done && (rc = ensure_cand_capacity(c, b.cand, b.nL))) break;
     }
     if (async) {
+      if (!++c->gate_seq) c->gate_seq = 1;
+      b.gate = c->gate_seq;
       rc = launcher_submit(c, job);
     } else {
       rc = prefetch_issue(c, job);
@@ -347,9 +358,15 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
   HIPCHK(c, hipEventRecord(c->ev_spec_done, c->stream3));
   c->spec_valid = true;
   if (nxt2) {
-    if (int rc = launcher_wait_lane(c, nxt2->lane)) return rc;
+    // The frame after next's pyramids: built by a prefetch sequence the launch thread may still be issuing — waiting
+    // for that here (to enqueue a stream wait on its event) put 25 us into this call whenever the thread was behind,
+    // and the whole cycle into a slower regime (profiles/r05_slow_regime_timeline.txt).  The launch's waves wait on
+    // the device instead, for the word the sequence's last launch writes.
+    const bool gated = c->launcher && nxt2->gate != 0;
+    if (!gated)
+      if (int rc = launcher_wait_lane(c, nxt2->lane)) return rc;
     HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt.lane], 0));
-    HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt2->lane], 0));
+    if (!gated) HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_lane_done[nxt2->lane], 0));
     uint8_t* zc = c->z_spec + c->spec_bytes;
     const PyrDesc& N2 = c->pyr[nxt2->slotL].d;
     LkArgs f2 = make_lk(N, N2, nullptr, nullptr, (float2*)zc, zc + M * 16, nullptr, n_max, 3, 30, 0.01, 0);
@@ -359,6 +376,10 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
     f2.chain_seq = c->chain_seq;
     f2.chain_ticks = c->lim.chain;
     f2.poll_err = (int*)(zc + M * 16 + 2 * stM);
+    if (gated) {
+      f2.gate_ptr = c->d_lane_gate + nxt2->lane;
+      f2.gate_val = nxt2->gate;
+    }
     {
       StreamScope on_chain_stream(c->stream4);
       run_lk(c, f2, c->cfg.flow_back ? &b2 : nullptr, (float2*)zc + M, zc + M * 16 + stM);
