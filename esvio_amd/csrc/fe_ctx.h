@@ -150,6 +150,8 @@ struct esvio_fe_ctx {
   // share a stream matters more than how many streams there are: the published frame's stereo LK and the chained
   // launch on the new stream instead — `k_select_mw` 17 -> 40 us, cycle 300 us; KERNELS.md.)
   hipStream_t stream6 = nullptr;
+  std::vector<double> pre_lx, pre_ly;  // prev_pts lifted through the left camera model under the temporal LK's wait
+  bool pre_lift_valid = false;
   bool stereo_unpub = false;  // the frame being tracked publishes nothing (and stereo_split is on)
   // -1: lk_accum == 2 && launch thread on (decided per call); 0 / 1: ESVIO_FE_STEREO_SPLIT
   int stereo_split_env = -1;

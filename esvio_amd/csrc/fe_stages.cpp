@@ -673,10 +673,15 @@ void reject_with_f_event(esvio_fe_ctx* c) {  // :910-947
     std::vector<double> lx(n), ly(n);
     const double cx = c->W / 2.0, cy = c->H / 2.0;
     const auto tl = std::chrono::steady_clock::now();
-    host::lift_projective_batch(cam, &c->prev_pts[0].x, (int)n, lx.data(), ly.data());
+    // (prev_pts' lifts: done under the temporal LK's wait when the frame publishes, TrackCall::temporal)
+    const bool pre = c->pre_lift_valid && c->pre_lx.size() == n;
+    if (!pre) host::lift_projective_batch(cam, &c->prev_pts[0].x, (int)n, lx.data(), ly.data());
+    const double* plx = pre ? c->pre_lx.data() : lx.data();
+    const double* ply = pre ? c->pre_ly.data() : ly.data();
+    c->pre_lift_valid = false;  // (one use: the vectors belong to the call that made them)
     for (size_t i = 0; i < n; i++) {  // p[2] == 1.0: x / 1.0 is exact
-      un_prev[2 * i] = (float)(FOCAL * lx[i] / 1.0 + cx);
-      un_prev[2 * i + 1] = (float)(FOCAL * ly[i] / 1.0 + cy);
+      un_prev[2 * i] = (float)(FOCAL * plx[i] / 1.0 + cx);
+      un_prev[2 * i + 1] = (float)(FOCAL * ply[i] / 1.0 + cy);
     }
     host::lift_projective_batch(cam, &c->cur_pts[0].x, (int)n, lx.data(), ly.data());
     for (size_t i = 0; i < n; i++) {

@@ -816,6 +816,18 @@ struct TrackCall {
   int temporal() {  // :405-440
     if (int rc = plan_temporal()) return rc;
     const esvio_fe_config& cfg = c->cfg;
+    // rejectWithF_event lifts prev_pts and cur_pts through the camera model before its RANSAC; prev_pts are known
+    // now, and the host is about to wait for the temporal LK anyway: their half of the lifts is done under that wait
+    // (a published frame's RANSAC sits on the replay cycle's critical chain)
+    c->pre_lift_valid = false;
+    auto pre_lift = [&]() {
+      const size_t n = c->prev_pts.size();
+      if (!PUB_THIS_FRAME || !cfg.f_ransac || n < 8 || c->pre_lift_valid) return;
+      c->pre_lx.resize(n);
+      c->pre_ly.resize(n);
+      host::lift_projective_batch(cfg.cam[0], &c->prev_pts[0].x, (int)n, c->pre_lx.data(), c->pre_ly.data());
+      c->pre_lift_valid = true;
+    };
     const PyrDesc& prevL = c->pyr[c->slot_prevL].d;
     const PyrDesc& curL = c->pyr[c->slot_curL].d;
     if (c->prev_pts.size() > 0) {
@@ -826,6 +838,7 @@ struct TrackCall {
       if (use_spec) {
         if (!defer_late)
           if (int rc = early_work()) return rc;
+        pre_lift();
         lap(1);
         if (int rc = exchange_flush(c)) return rc;  // (host time that would be spent waiting)
         HIPCHK(c, sync_event(c->ev_spec_done));
@@ -850,6 +863,7 @@ struct TrackCall {
       if (use_chain) {
         if (!defer_late)
           if (int rc = early_work()) return rc;
+        pre_lift();
         lap(1);
         if (int rc = exchange_flush(c)) return rc;
         HIPCHK(c, sync_event(c->ev_chain_done));
@@ -922,6 +936,7 @@ struct TrackCall {
         }
         if (int rc = early_work()) return rc;
         if (int rc = exchange_flush(c)) return rc;
+        pre_lift();
         lap(1);
         HIPCHK(c, sync_main(c));
         lap(2);
@@ -958,6 +973,10 @@ struct TrackCall {
         surv_src.clear();
         for (int i = 0; i < n; i++)
           if (status[i]) surv_src.push_back(i);
+      }
+      if (c->pre_lift_valid) {
+        reduce_vector(c->pre_lx, status);
+        reduce_vector(c->pre_ly, status);
       }
       reduce_vector(c->prev_pts, status);
       reduce_vector(c->cur_pts, status);
