@@ -86,11 +86,10 @@ static int prefetch_issue(esvio_fe_ctx* c, const PrefetchJob& j) {
   // (the last kernels on this stream that read the batch's events)
   if (b.stage >= 0)
     if (int rc2 = stager_mark_read(c, b.stage, c->stream2, false)) return rc2;
-  // Nobody ever synchronises with this stream (the frames wait for its events), and the runtime retires a stream's
-  // commands only when somebody looks: left alone it does so itself after ~250 launches — frame 19 of a stream — in a
-  // blocking sweep of 1.5-4.5 ms inside whichever call comes next, on this thread or, through the runtime's lock, on
-  // the caller's (4 of 30 cold bench runs, always call 13 or 15 of the timed pass: profiles/r05_stall_hunt.txt).
-  // A query per sequence lets it retire what has completed, a few commands at a time.
+  // Nobody ever synchronises with this stream (the frames wait for its events): a query per sequence lets the runtime
+  // retire the commands that have completed, a few at a time.  (Put in during the hunt for the 1.6-4.7 ms calls of a
+  // cold process's first pass — profiles/r05_stall_hunt.txt; alone it did not remove them, the pool warm-up in
+  // esvio_fe_create did; it was part of the configuration that then ran 30 cold processes without one, and stays.)
   (void)hipStreamQuery(c->stream2);
   (void)hipGetLastError();  // (hipErrorNotReady is the normal answer)
   return 0;
