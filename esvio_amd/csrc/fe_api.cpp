@@ -398,12 +398,13 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
       }
     if (!c->n_queue_conflicts) fprintf(stderr, "[esvio_fe] the handle's five streams have a hardware queue each\n");
   }
-  // ... and a burst of launches chained across the streams by events, nothing of it awaited until the end: the
-  // runtime's pools of completion signals and command records grow on demand, a few milliseconds each time and inside
-  // whichever launch needs one more — in a bench process that was a track call around frame 20 of the first timed pass
-  // in one cold run of ten (profiles/r05_stall_hunt.txt: 1.6-4.7 ms in `speculative + chained LK launches` or in the
-  // wait for the launch thread, never a lost CPU, never an allocation of ours).  The replay schedule keeps ~60
-  // launches and ~25 cross-stream waits in flight; this puts 4 x 96 launches and as many waits in flight at once.
+  // ... and a burst of launches chained across the streams by events, nothing of it awaited until the end.  What it
+  // is for: in one cold bench process of ten ONE track call around frame 20 of the first timed pass took 1.6-4.7 ms,
+  // inside a HIP launch call of the calling thread or in its wait for the launch thread — never a lost CPU, never an
+  // allocation of ours (profiles/r05_stall_hunt.txt).  Read as the runtime growing a pool (completion signals,
+  // command records) inside whichever launch needs one more than it has; the replay schedule keeps ~60 launches and
+  // ~25 cross-stream waits in flight, this puts 4 x 96 launches and as many waits in flight at once — and 30 cold
+  // processes then ran without one call above 0.6 ms (profiles/r05_stall_hunt_after.txt).
   {
     const hipStream_t st[4] = {c->stream, c->stream2, c->stream3, c->stream4};
     hipEvent_t ev[4] = {c->ev_imgs_ready, c->ev_planes_free, c->ev_arc_side, c->ev_sae_left};  // (unused so far)
