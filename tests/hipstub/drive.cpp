@@ -63,6 +63,12 @@ int main(int argc, char** argv) {
   int f = 0;
   while (f < frames) {
     esvio_fe_handle h = nullptr;
+    // (both LK modes, and the batches handed over as host or as "device" memory — the stub's device memory is the
+    // host's: with the launch thread on, the float-order mode and device batches the handle takes its second stereo
+    // stream and the chained launch's device-side gate, fe_track.cpp)
+    const bool split_case = handles == 0;  // (the first handle of a run: exactly that configuration, from its first frame)
+    c.lk_accum = split_case ? 2 : 1 + (int)(rnd() & 1u);
+    const int space = split_case ? ESVIO_FE_DEVICE : (rnd() & 1u) ? ESVIO_FE_HOST : ESVIO_FE_DEVICE;
     if (esvio_fe_create(&c, &h) != ESVIO_FE_OK) { fprintf(stderr, "create failed\n"); return 3; }
     handles++;
     esvio_fe_reserve(h, 1u << 16, 1u << 16, 1);
@@ -72,7 +78,11 @@ int main(int argc, char** argv) {
     std::vector<int> pub((size_t)stretch);
     for (int i = 0; i < stretch; i++) pub[(size_t)i] = (rnd() % 3u) != 0;
     int announced = 0;                                 // batches [i + 1, announced] are announced
-    bool replay = (rnd() & 1u) != 0;
+    bool replay = split_case || (rnd() & 1u) != 0;
+    if (split_case) {
+      esvio_fe_set_launch_thread(h, 1);
+      esvio_fe_set_lazy_new_stereo(h, 1);
+    }
     for (int i = 0; i < stretch; i++) {
       if (rnd() % 7u == 0) esvio_fe_set_launch_thread(h, (int)(rnd() & 1u));
       if (rnd() % 9u == 0) esvio_fe_set_host_threads(h, (int)(rnd() % 8u));
@@ -91,11 +101,11 @@ int main(int argc, char** argv) {
           const Batch& n = bs[(size_t)announced];
           int hint = pub[(size_t)announced];
           if (rnd() % 41u == 0) hint = 0;  // (a wrong hint: with more than one batch ahead the call for it is refused)
-          esvio_fe_set_next_batch(h, n.t, n.L.data(), n.L.size(), n.R.data(), n.R.size(), ESVIO_FE_HOST, hint);
+          esvio_fe_set_next_batch(h, n.t, n.L.data(), n.L.size(), n.R.data(), n.R.size(), space, hint);
         }
       }
       const Batch& b = bs[(size_t)i];
-      const int rc = esvio_fe_track_event(h, b.t, b.L.data(), b.L.size(), b.R.data(), b.R.size(), ESVIO_FE_HOST,
+      const int rc = esvio_fe_track_event(h, b.t, b.L.data(), b.L.size(), b.R.data(), b.R.size(), space,
                                           pub[(size_t)i], &t);
       calls++;
       if (rc != ESVIO_FE_OK) {  // refused (wrong hint) or failed: the handle must be usable after a reset
@@ -106,6 +116,10 @@ int main(int argc, char** argv) {
       if (rnd() % 17u == 0) esvio_fe_finish(h, &t);
     }
     esvio_fe_finish(h, &t);
+    {
+      esvio_fe_latency_call lc;
+      if (esvio_fe_latency_recent(h, 0, &lc) == ESVIO_FE_OK && lc.ms < 0) { fprintf(stderr, "latency record\n"); return 4; }
+    }
     esvio_fe_destroy(h);
     f += stretch;
   }
