@@ -69,4 +69,4 @@ def test_every_host_thread_under_thread_sanitizer(tmp_path):
         assert p.returncode == 0 and "drive ok:" in p.stdout, out[-3000:]
         assert "WARNING: ThreadSanitizer" not in out, out[-6000:]
         failed = int(p.stdout.split("handles,")[1].split()[0])
-        assert failed >= 3, p.stdout
+        assert failed >= 2, p.stdout  # (a failing launch every 701st / 1933rd HIP call of ~330 track calls)
