@@ -954,16 +954,19 @@ static int fill_tracks(esvio_fe_handle c, esvio_fe_tracks* out) {
     out->n_left = (int32_t)c->ids.size();
     out->n_right = (int32_t)c->ids_right.size();
     const size_t nl = c->ids.size(), nr = c->ids_right.size();
-    if (out->ids) std::memcpy(out->ids, c->ids.data(), nl * 4);
-    if (out->track_cnt) std::memcpy(out->track_cnt, c->track_cnt.data(), nl * 4);
-    if (out->cur_pts) std::memcpy(out->cur_pts, c->cur_pts.data(), nl * 8);
-    if (out->cur_un_pts) std::memcpy(out->cur_un_pts, c->cur_un_pts.data(), nl * 8);
-    if (out->pts_velocity) std::memcpy(out->pts_velocity, c->pts_velocity.data(), nl * 8);
-    if (out->ids_right) std::memcpy(out->ids_right, c->ids_right.data(), nr * 4);
-    if (out->cur_right_pts) std::memcpy(out->cur_right_pts, c->cur_right_pts.data(), nr * 8);
-    if (out->cur_un_right_pts) std::memcpy(out->cur_un_right_pts, c->cur_un_right_pts.data(), nr * 8);
-    if (out->right_pts_velocity)
-      std::memcpy(out->right_pts_velocity, c->right_pts_velocity.data(), nr * 8);
+    // (an empty vector's data() may be null, and memcpy's source must not be, whatever the size)
+    auto put = [](void* dst, const void* src, size_t bytes) {
+      if (dst && bytes) std::memcpy(dst, src, bytes);
+    };
+    put(out->ids, c->ids.data(), nl * 4);
+    put(out->track_cnt, c->track_cnt.data(), nl * 4);
+    put(out->cur_pts, c->cur_pts.data(), nl * 8);
+    put(out->cur_un_pts, c->cur_un_pts.data(), nl * 8);
+    put(out->pts_velocity, c->pts_velocity.data(), nl * 8);
+    put(out->ids_right, c->ids_right.data(), nr * 4);
+    put(out->cur_right_pts, c->cur_right_pts.data(), nr * 8);
+    put(out->cur_un_right_pts, c->cur_un_right_pts.data(), nr * 8);
+    put(out->right_pts_velocity, c->right_pts_velocity.data(), nr * 8);
   }
   return 0;
 }
