@@ -417,7 +417,7 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     for (int i = 0; i < 4; i++)
       if (hipStreamSynchronize(st[i]) != hipSuccess) return bail(ESVIO_FE_EHIP);
   }
-  if (int rc = stereo_split_prepare(c)) return bail(rc);  // (ESVIO_FE_STEREO_SPLIT=1)
+  if ((rc = stereo_split_prepare(c))) return bail(rc);  // (ESVIO_FE_STEREO_SPLIT=1)
   // The greedy selections (Event_FeaturesToTrack, goodFeaturesToTrack's min-distance pass) keep
   // their one-bit-per-pixel map in LDS; above ~1.3 M pixels (the frame cameras of the shipped ESVIO
   // configs go up to 1920x1200) it lives in device memory instead (k_select_gbm)
