@@ -83,3 +83,11 @@ def test_host_side_under_address_and_ub_sanitizers(tmp_path):
         out = p.stdout + p.stderr
         assert p.returncode == 0 and "drive ok:" in p.stdout, out[-3000:]
         assert "runtime error" not in out and "AddressSanitizer" not in out and "LeakSanitizer" not in out, out[-6000:]
+    # ... and on the failing exits: every 97th / 701st HIP call fails (calling thread or launch thread), the driver
+    # resets and goes on — error paths are where buffers are forgotten or freed twice
+    for every in ("97", "701"):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", HIPSTUB_FAIL_EVERY=every)
+        p = subprocess.run([exe, "5", "300"], capture_output=True, text=True, timeout=600, env=env)
+        out = p.stdout + p.stderr
+        assert p.returncode == 0 and "drive ok:" in p.stdout, out[-3000:]
+        assert "runtime error" not in out and "AddressSanitizer" not in out and "LeakSanitizer" not in out, out[-6000:]
