@@ -374,17 +374,41 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
     launch_fill_f64(st, (double*)c->d_rejected, 1, 0.0);
     if (hipStreamSynchronize(st) != hipSuccess) return bail(ESVIO_FE_EHIP);
   }
+  // ... and a burst of launches chained across the streams by events, nothing of it awaited until the end.  What it
+  // is for: in one cold bench process of ten ONE track call around frame 20 of the first timed pass took 1.6-4.7 ms,
+  // inside a HIP launch call of the calling thread or in its wait for the launch thread — never a lost CPU, never an
+  // allocation of ours (profiles/r05_stall_hunt.txt).  Read as the runtime growing a pool (completion signals,
+  // command records) inside whichever launch needs one more than it has; the replay schedule keeps ~60 launches and
+  // ~25 cross-stream waits in flight, this puts 4 x 96 launches and as many waits in flight at once — and 30 cold
+  // processes then ran without one call above 0.6 ms (profiles/r05_stall_hunt_after.txt).
+  {
+    const hipStream_t st[4] = {c->stream, c->stream2, c->stream3, c->stream4};
+    hipEvent_t ev[4] = {};  // (events of the warm-up's own: the handle's stay unrecorded until a frame records them)
+    bool ok = true;
+    for (int i = 0; i < 4; i++) ok = ok && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+    for (int r = 0; ok && r < 96; r++)
+      for (int i = 0; ok && i < 4; i++) {
+        launch_spin(st[i], r == 0 ? 20000 : 0);  // (the first round's kernels hold everything behind them for 200 us)
+        ok = hipEventRecord(ev[i], st[i]) == hipSuccess && hipStreamWaitEvent(st[(i + 1) & 3], ev[i], 0) == hipSuccess;
+      }
+    for (int i = 0; i < 4; i++) ok = (hipStreamSynchronize(st[i]) == hipSuccess) && ok;
+    for (int i = 0; i < 4; i++)
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (!ok) return bail(ESVIO_FE_EHIP);
+  }
+  if ((rc = stereo_split_prepare(c))) return bail(rc);  // (ESVIO_FE_STEREO_SPLIT=1)
   // Which of these streams share a hardware queue?  The runtime hands out at most GPU_MAX_HW_QUEUES (4) queues per
   // priority level and process, then doubles up — and two streams on one queue run their kernels one after the
   // other (tools/queue_probe.hip), which for this schedule means a frame's prefetch behind another frame's waiting
   // LK launch.  Counted once per handle (a 100 us spin on one stream, an empty kernel on the other: ~1.2 ms for
   // the ten pairs), reported by esvio_fe_debug_counters and, with ESVIO_FE_QUEUE_PROBE=1, on stderr.
   if (getenv("ESVIO_FE_QUEUE_PROBE")) {
-    const hipStream_t st[5] = {c->stream, c->stream2, c->stream3, c->stream4, c->stream4};
+    const hipStream_t st[5] = {c->stream, c->stream2, c->stream3, c->stream4, c->stream6};  // (stream6: only where the handle splits)
     const char* nm[5] = {"main", "prefetch", "speculative", "stereo", "stereo-unpublished"};
-    for (int a = 0; a < 5; a++)
-      for (int b = 0; b < 5; b++) {
-        if (a == b) continue;
+    const int ns = c->stream6 ? 5 : 4;
+    for (int a = 0; a < ns; a++)
+      for (int b = 0; b < ns; b++) {
+        if (a == b || st[a] == st[b]) continue;
         launch_spin(st[a], 10000);
         const auto t0 = std::chrono::steady_clock::now();
         launch_fill_f64(st[b], (double*)c->d_rejected, 1, 0.0);
@@ -396,28 +420,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
           fprintf(stderr, "[esvio_fe] streams '%s' and '%s' share a hardware queue (%.0f us behind a 100 us kernel)\n", nm[b], nm[a], us);
         }
       }
-    if (!c->n_queue_conflicts) fprintf(stderr, "[esvio_fe] the handle's five streams have a hardware queue each\n");
+    if (!c->n_queue_conflicts) fprintf(stderr, "[esvio_fe] the handle's %d streams have a hardware queue each\n", ns);
   }
-  // ... and a burst of launches chained across the streams by events, nothing of it awaited until the end.  What it
-  // is for: in one cold bench process of ten ONE track call around frame 20 of the first timed pass took 1.6-4.7 ms,
-  // inside a HIP launch call of the calling thread or in its wait for the launch thread — never a lost CPU, never an
-  // allocation of ours (profiles/r05_stall_hunt.txt).  Read as the runtime growing a pool (completion signals,
-  // command records) inside whichever launch needs one more than it has; the replay schedule keeps ~60 launches and
-  // ~25 cross-stream waits in flight, this puts 4 x 96 launches and as many waits in flight at once — and 30 cold
-  // processes then ran without one call above 0.6 ms (profiles/r05_stall_hunt_after.txt).
-  {
-    const hipStream_t st[4] = {c->stream, c->stream2, c->stream3, c->stream4};
-    hipEvent_t ev[4] = {c->ev_imgs_ready, c->ev_planes_free, c->ev_arc_side, c->ev_sae_left};  // (unused so far)
-    for (int r = 0; r < 96; r++)
-      for (int i = 0; i < 4; i++) {
-        launch_spin(st[i], r == 0 ? 20000 : 0);  // (the first round's kernels hold everything behind them for 200 us)
-        (void)hipEventRecord(ev[i], st[i]);
-        (void)hipStreamWaitEvent(st[(i + 1) & 3], ev[i], 0);
-      }
-    for (int i = 0; i < 4; i++)
-      if (hipStreamSynchronize(st[i]) != hipSuccess) return bail(ESVIO_FE_EHIP);
-  }
-  if ((rc = stereo_split_prepare(c))) return bail(rc);  // (ESVIO_FE_STEREO_SPLIT=1)
   // The greedy selections (Event_FeaturesToTrack, goodFeaturesToTrack's min-distance pass) keep
   // their one-bit-per-pixel map in LDS; above ~1.3 M pixels (the frame cameras of the shipped ESVIO
   // configs go up to 1920x1200) it lives in device memory instead (k_select_gbm)

@@ -234,6 +234,8 @@ struct esvio_fe_ctx {
   // thread only does the bookkeeping and, before it consumes a lane, checks that its job has been issued
   Launcher* launcher = nullptr;
   uint64_t lane_job[kPrefetchDepth] = {};  // job number that (re)records the lane's events
+  int launch_err = 0;  // a launch-thread job failed and the thread has been stopped since: sticky until esvio_fe_reset
+  uint64_t lks_wait_job[2] = {};  // latest job whose prefetch sequence waits on ev_lks_done[set] (record_lks_done)
   // bounds of the device-side waits handed to the launches; esvio_fe_debug_inject / ESVIO_FE_FAULT set
   // chosen ones to 0 (the wait expires the first time it would have to wait)
   struct WaitLimits {

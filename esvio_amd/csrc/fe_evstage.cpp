@@ -365,13 +365,19 @@ static int stager_get(esvio_fe_ctx* c, EventStager** out) {
   return 0;
 }
 
-static bool host_pointer_is_pinned(const void* p) {
-  hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-    (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the runtime)
-    return false;
-  }
-  return a.type == hipMemoryTypeHost;
+// [p, p + len) is page-locked memory the runtime knows: first AND last byte (a batch that begins inside a registered
+// range and runs past its end is staged like pageable memory — k_stage_pull reading beyond the mapping would be a fatal
+// queue error, not a return code)
+static bool host_range_is_pinned(const void* p, size_t len) {
+  auto pinned = [](const void* q) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+      (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the runtime)
+      return false;
+    }
+    return a.type == hipMemoryTypeHost;
+  };
+  return len && pinned(p) && pinned((const uint8_t*)p + len - 1);
 }
 
 static int slot_capacity(esvio_fe_ctx* c, Slot& s, size_t n) {
@@ -434,7 +440,7 @@ static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t
   Slot& s = st->slot[k];
   const size_t n = nL + nR;
   const auto tp0 = std::chrono::steady_clock::now();
-  const bool pinL = nL && host_pointer_is_pinned(left), pinR = nR && host_pointer_is_pinned(right);
+  const bool pinL = host_range_is_pinned(left, nL * 16), pinR = host_range_is_pinned(right, nR * 16);
   if (c->trace) st->pin_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tp0).count();
   if (int rc = slot_capacity(c, s, n)) return rc;
   // the DMA overwrites the slot's device buffer: behind the kernels that read its previous batch
@@ -456,8 +462,14 @@ static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t
   auto from_pinned = [&](void* dst, const void* src, size_t len) {
     if (!s.pull) return st->dma(dst, src, len);
     // (hipHostMalloc memory is mapped at its host address; hipHostRegister'ed memory need not be: ask)
-    void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, const_cast<void*>(src), 0) != hipSuccess || !dp) {
+    // The kernel reads uint4s: a source that is not 16-byte aligned (an EventArray inside a deserialisation buffer is
+    // only 8-byte aligned in general), or whose first and last byte are mapped by two different registrations that do
+    // not continue each other on the device side, goes through the copy engine instead.
+    void *dp = nullptr, *dp_last = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void*>(src), 0) != hipSuccess || !dp || ((uintptr_t)dp & 15) != 0 ||
+        ((uintptr_t)dst & 15) != 0 ||
+        hipHostGetDevicePointer(&dp_last, (uint8_t*)const_cast<void*>(src) + len - 1, 0) != hipSuccess ||
+        (uint8_t*)dp_last != (uint8_t*)dp + len - 1) {
       (void)hipGetLastError();
       return st->dma(dst, src, len);
     }

@@ -139,9 +139,17 @@ struct Launcher {
         }
         continue;
       }
+      const PrefetchJob& job = ring[d % kRing];
       if (first_rc.load(std::memory_order_relaxed) == 0) {  // (after a failure the jobs are only counted off)
-        const int rc = prefetch_issue(c, ring[d % kRing]);
+        const int rc = prefetch_issue(c, job);
         if (rc) first_rc.store(rc, std::memory_order_release);
+      }
+      // a failed or counted-off job never runs the launch that writes its gate word: a chained LK already in flight
+      // for it would sit out its whole bound (40 ms) on the stereo stream, and esvio_fe_reset / _destroy behind it.
+      // Its waves are let go (the call that reads their results fails with this launcher's error anyway).
+      if (first_rc.load(std::memory_order_relaxed) != 0 && job.b.gate) {
+        launch_set_u32(c->stream2, c->d_lane_gate + job.b.lane, job.b.gate);
+        (void)hipGetLastError();
       }
       done.store(d + 1, std::memory_order_release);
       idle_since = std::chrono::steady_clock::now();
@@ -172,6 +180,7 @@ int launcher_set(esvio_fe_ctx* c, bool on) {
   // launcher that has been drained and is gone — has nothing outstanding)
   if (on) {
     for (uint64_t& j : c->lane_job) j = 0;
+    c->lks_wait_job[0] = c->lks_wait_job[1] = 0;
     Launcher* l = new Launcher();
     l->c = c;
     l->th = std::thread([l] { l->run(); });
@@ -179,7 +188,11 @@ int launcher_set(esvio_fe_ctx* c, bool on) {
     return 0;
   }
   const int rc = launcher_drain(c);
+  // (a failed job has left its batch half applied: the handle stays failed until esvio_fe_reset — switching the launch
+  // thread off and on again must not make the error disappear)
+  if (rc && !c->launch_err) c->launch_err = rc;
   for (uint64_t& j : c->lane_job) j = 0;
+  c->lks_wait_job[0] = c->lks_wait_job[1] = 0;
   Launcher* l = c->launcher;
   l->quit.store(true, std::memory_order_seq_cst);
   { std::lock_guard<std::mutex> g(l->mu); }
@@ -199,6 +212,7 @@ static int launcher_result(esvio_fe_ctx* c) {
 // esvio_fe_reset: the handle starts from a clean slate, so does its launch thread (drained by the caller)
 void launcher_clear_error(esvio_fe_ctx* c) {
   if (c->launcher) c->launcher->first_rc.store(0, std::memory_order_release);
+  c->launch_err = 0;
 }
 
 int launcher_drain(esvio_fe_ctx* c) {
@@ -215,11 +229,28 @@ int launcher_wait_lane(esvio_fe_ctx* c, int lane) {
   return launcher_result(c);
 }
 
+// Record "the stereo LK that writes copy `set` of set 1 is done" on the frame's stereo stream.  A prefetch job handed to
+// the launch thread waits on this very event object for the record that existed when the job was made
+// (PrefetchJob::lks_wait); a stream wait binds to the event's LATEST record at the time it is enqueued, so the job must
+// have been issued before the event is recorded again — else a lagging launch thread would make the prefetch stream
+// wait for THIS launch, which may sit behind a chained LK whose waves wait for the word that prefetch sequence writes:
+// a cycle only the chained launch's 40 ms bound would break.  The job was submitted a call or more ago: normally no wait.
+int record_lks_done(esvio_fe_ctx* c, int set) {
+  if (Launcher* l = c->launcher) {
+    while (l->done.load(std::memory_order_acquire) < c->lks_wait_job[set]) cpu_relax();
+    if (int rc = launcher_result(c)) return rc;
+  }
+  HIPCHK(c, hipEventRecord(c->ev_lks_done[set], stereo_stream(c)));
+  c->lks_last = set;
+  return 0;
+}
+
 static int launcher_submit(esvio_fe_ctx* c, const PrefetchJob& j) {
   Launcher* l = c->launcher;
   const uint64_t s = l->submitted.load(std::memory_order_relaxed);
   l->ring[s % Launcher::kRing] = j;
   c->lane_job[j.b.lane] = s + 1;
+  if (j.lks_wait >= 0) c->lks_wait_job[j.lks_wait] = s + 1;
   l->submitted.store(s + 1, std::memory_order_seq_cst);
   if (l->sleeping.load(std::memory_order_seq_cst)) {
     { std::lock_guard<std::mutex> g(l->mu); }
@@ -579,6 +610,8 @@ struct TrackCall {
   }
 
   int check() {
+    if (c->launch_err)
+      return fail(c, c->launch_err, "a prefetch job of the launch thread failed earlier: esvio_fe_reset the handle");
     if (c->inflight.empty() && !c->announced.empty()) {
       // announced, but an earlier call left it where it was because its host events were still on
       // their way to the device: it is needed now
@@ -930,8 +963,7 @@ struct TrackCall {
           StreamScope on_stereo_stream(stereo_stream(c));
           HIPCHK(c, hipStreamWaitEvent(stereo_stream(c), c->ev_imgs_ready, 0));
           run_lk(c, f2, cfg.flow_back ? &b2 : nullptr, zdev(c, pin_st.ptsC), zdev(c, pin_st.stB));
-          HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], stereo_stream(c)));
-          c->lks_last = c->res_set;
+          if (int rc = record_lks_done(c, c->res_set)) return rc;
         }
         if (int rc = early_work()) return rc;
         if (int rc = exchange_flush(c)) return rc;
@@ -1056,9 +1088,8 @@ struct TrackCall {
         // read this frame's temporal LK results, and that launch ran behind the frame's pyramids.
         StreamScope on_stereo_stream(stereo_stream(c));
         run_lk(c, f, cfg.flow_back ? &b : nullptr, zdev(c, pin.ptsC), zdev(c, pin.stB));
-        HIPCHK(c, hipEventRecord(c->ev_lks_done[c->res_set], stereo_stream(c)));
+        if (int rc = record_lks_done(c, c->res_set)) return rc;
       }
-      c->lks_last = c->res_set;
     }
     return 0;
   }

@@ -13,6 +13,7 @@
 #include "esvio_fe.h"
 #if __has_include("esvio_fe_test.h")  // (trees from before the header was split have the taps in esvio_fe.h)
 #include "esvio_fe_test.h"
+extern "C" void hipstub_arm_faults(int on);  // tests/hipstub/hip_stub.cpp
 #endif
 
 static uint32_t rs;
@@ -69,7 +70,12 @@ int main(int argc, char** argv) {
     const bool split_case = handles == 0;  // (the first handle of a run: exactly that configuration, from its first frame)
     c.lk_accum = split_case ? 2 : 1 + (int)(rnd() & 1u);
     const int space = split_case ? ESVIO_FE_DEVICE : (rnd() & 1u) ? ESVIO_FE_HOST : ESVIO_FE_DEVICE;
-    if (esvio_fe_create(&c, &h) != ESVIO_FE_OK) { fprintf(stderr, "create failed\n"); return 3; }
+    // (HIPSTUB_FAIL_EVERY: the injected failures are for the calls; a creation — whose warm-up alone records 384
+    // events and checks every return code — is let through)
+    hipstub_arm_faults(0);
+    const int crc = esvio_fe_create(&c, &h);
+    hipstub_arm_faults(1);
+    if (crc != ESVIO_FE_OK) { fprintf(stderr, "create failed\n"); return 3; }
     handles++;
     esvio_fe_reserve(h, 1u << 16, 1u << 16, 1);
     const int stretch = 20 + (int)(rnd() % 40u);  // frames on this handle

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <map>
 #include <set>
 
 struct ihipStream_t {
@@ -22,16 +23,19 @@ namespace {
 ihipStream_t g_null_stream;
 ihipStream_t* S(hipStream_t s) { return s ? s : &g_null_stream; }
 std::mutex g_mu;
-std::set<const void*> g_pinned;  // hipHostMalloc / hipHostRegister'ed base addresses
+std::map<const void*, size_t> g_pinned;  // hipHostMalloc / hipHostRegister'ed ranges: base -> bytes
 std::atomic<uint64_t> g_allocs{0};
 // HIPSTUB_FAIL_EVERY=n: every n-th hipEventRecord fails (once each) — a launch that fails in the middle of a call,
 // on whichever thread issues it
 std::atomic<long> g_records{0};
+std::atomic<int> g_armed{1};
 long fail_every() {
   static const long n = getenv("HIPSTUB_FAIL_EVERY") ? atol(getenv("HIPSTUB_FAIL_EVERY")) : 0;
   return n;
 }
 }  // namespace
+
+extern "C" void hipstub_arm_faults(int on) { g_armed.store(on, std::memory_order_relaxed); }
 
 void hipstub_stream_begin(hipStream_t s) {
   S(s)->mu.lock();
@@ -59,7 +63,7 @@ hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
   *p = calloc(bytes ? bytes : 1, 1);
   if (!*p) return hipErrorOutOfMemory;
   std::lock_guard<std::mutex> lk(g_mu);
-  g_pinned.insert(*p);
+  g_pinned[*p] = bytes ? bytes : 1;
   return hipSuccess;
 }
 hipError_t hipHostFree(void* p) {
@@ -71,9 +75,9 @@ hipError_t hipHostFree(void* p) {
   return hipSuccess;
 }
 hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
-hipError_t hipHostRegister(void* p, size_t, unsigned) {
+hipError_t hipHostRegister(void* p, size_t bytes, unsigned) {
   std::lock_guard<std::mutex> lk(g_mu);
-  g_pinned.insert(p);
+  g_pinned[p] = bytes ? bytes : 1;
   return hipSuccess;
 }
 hipError_t hipHostUnregister(void* p) {
@@ -82,7 +86,10 @@ hipError_t hipHostUnregister(void* p) {
 }
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_pinned.count(p)) return hipErrorInvalidValue;  // (what the real runtime says of malloc'ed memory)
+  auto it = g_pinned.upper_bound(p);  // (the range that contains p, like the real runtime)
+  if (it == g_pinned.begin()) return hipErrorInvalidValue;  // (what the real runtime says of malloc'ed memory)
+  --it;
+  if ((const char*)p >= (const char*)it->first + it->second) return hipErrorInvalidValue;
   a->type = hipMemoryTypeHost;
   a->device = 0;
   a->devicePointer = a->hostPointer = (void*)p;
@@ -127,7 +134,7 @@ hipError_t hipEventCreate(hipEvent_t* e) { *e = new ihipEvent_t; return hipSucce
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
-  if (fail_every() > 0 && (g_records.fetch_add(1, std::memory_order_relaxed) + 1) % fail_every() == 0) return hipErrorInvalidValue;
+  if (fail_every() > 0 && g_armed.load(std::memory_order_relaxed) && (g_records.fetch_add(1, std::memory_order_relaxed) + 1) % fail_every() == 0) return hipErrorInvalidValue;
   hipstub_stream_op(s);
   e->seq.fetch_add(1, std::memory_order_acq_rel);
   return hipSuccess;
