@@ -32,20 +32,31 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-# stats label (esvio_fe_kernel_name) -> the kernel functions launched under it
+# The per-kernel timers' slots are named after the kernel FUNCTION each one brackets (esvio_fe_kernel_name =
+# the name rocprofv3 prints), so `kernels` / `roofline.kernel` match profiles/*.md verbatim.  The few slots that
+# bracket more than one function:
 KERNEL_FUNCS = {
-    "k_sae_keys": ["k_sae_keys", "k_tile_hist", "k_mc_warp"], "k_tile_scan": ["k_tile_scan"],
-    "k_radix_pass": ["k_radix_pass", "k_tile_scatter"],
-    "k_sae_apply": ["k_sae_apply", "k_sae_apply_ev", "k_sae_apply_ev_write", "k_tile_apply"],
-    "k_time_surface": ["k_time_surface", "k_time_surface4", "k_ts_pyr", "k_median"],
-    "k_clahe": ["k_clahe_lut", "k_clahe_interp", "k_normalize"],
-    "k_pyr_down": ["k_pyr_down", "k_pyr3", "k_norm_pyr"], "k_pyr_pad": ["k_pyr_pad"], "k_scharr": ["k_scharr", "k_pad_scharr"],
-    "k_lk": ["k_lk", "k_lk_f32"], "k_arc": ["k_arc_ev"], "k_arc_map": ["k_arc_map", "k_arc_mark"],
-    "k_compact": ["k_compact", "k_dedup"], "k_select": ["k_select", "k_select_mw", "k_select_gbm"],
+    "k_tile_hist": ["k_tile_hist", "k_mc_warp"], "k_clahe": ["k_clahe_lut", "k_clahe_interp", "k_normalize"],
+    "k_sae_apply": ["k_sae_apply", "k_sae_apply_ev", "k_sae_apply_ev_write"], "k_arc_map": ["k_arc_map", "k_arc_mark"],
 }
 # kernels whose reads are per-lane gathers, not wide coalesced streams: the guide calibrates the 2x
 # FETCH_SIZE correction for coalesced reads only
-GATHER_KERNELS = {"k_sae_apply", "k_lk", "k_arc", "k_arc_map", "k_select", "k_compact"}
+GATHER_KERNELS = {"k_tile_apply", "k_sae_apply", "k_lk", "k_lk_f32", "k_arc_ev", "k_arc_map", "k_select", "k_select_mw",
+                  "k_select_gbm", "k_compact", "k_dedup"}
+
+
+def workload_label(W, H, rate, world, split):
+    """BASELINE.json's config the run's shape corresponds to (C1..C5), derived from the shape — not assumed"""
+    if (W, H) == (640, 480):
+        if split == "camera" and world == 2:
+            return "C4 (left/right cameras on 2 GPUs)"
+        return "C3 (superset of C2)" if abs(rate - 5e6) < 1 else "C3's sensor at %.1f Mev/s per camera" % (rate / 1e6)
+    if (W, H) == (346, 260):
+        return "C1's sensor (DAVIS346) on the GPU path"
+    if (W, H) == (1280, 720):
+        return ("C5 (time-sliced over %d GPUs)" % world) if split == "time" and world > 1 else \
+               "C5's sensor shape on %s" % ("one GPU" if world == 1 else "%d GPUs, one rig each" % world)
+    return "custom shape"
 
 
 def pmc_traffic(kernel):
@@ -795,9 +806,8 @@ def main():
             # (the partition writes 8-byte records whenever the batch's stamps allow it — these synthetic
             # streams' always do — unless ESVIO_FE_WIDE_RECORDS forces the 16-byte form)
             scatter_bpe = 32 if os.environ.get("ESVIO_FE_WIDE_RECORDS") else 24
-            for label, func, bpe in (("k_sae_keys", "k_tile_hist", 16), ("k_tile_scan", "k_tile_scan", 0),
-                                     ("k_radix_pass", "k_tile_scatter", scatter_bpe), ("k_sae_apply", "k_tile_apply", 32)):
-                v = ks5.get(label)
+            for func, bpe in (("k_tile_hist", 16), ("k_tile_scan", 0), ("k_tile_scatter", scatter_bpe), ("k_tile_apply", 32)):
+                v = ks5.get(func)
                 if not v or not v["launches"]:
                     continue
                 us = v["ms"] / v["launches"] * 1e3
@@ -808,6 +818,69 @@ def main():
             row["chain"] = dict(us=round(tot, 2), events_per_batch=int(per), alg_bytes=int(48 * per),
                                 achieved_GBs=round(48 * per / tot / 1e3, 1), frac=round(48 * per / tot / 1e3 / HBM_PEAK_GBS, 4))
             sae_chain[sname] = row
+
+    # ---- the whole step at C5's sensor shape and rate on ONE GPU (1280x720, 100 Mev/s per camera: 3.3 M events per
+    # camera and batch), plain calls, device-resident: where the event-proportional kernels are HBM-bound.  Three
+    # timed steps; then the same three with the per-launch event pairs on, for the kernels' live durations.
+    c5_leg = None
+    if rank == 0 and world == 1 and not args.no_sae_pass and (W, H) != (1280, 720):
+        st5 = SceneStream(1280, 720, rate=1e8, batch_hz=args.batch_hz, seed=args.seed)
+        nw5, ns5 = 2, 3
+        bat = []
+        for _ in range(nw5 + ns5):
+            L5, R5, _t = st5.next_batch()
+            bat.append((FE.EventBuffer(L5, FE.DEVICE), FE.EventBuffer(R5, FE.DEVICE), len(L5) + len(R5), event_times(L5)[-1]))
+        cfg5 = FE.make_config(1280, 720, device=dev_index, max_cnt=args.max_cnt, min_dist=10, flow_back=1, f_ransac=1,
+                              lk_accum=args.lk_accum)
+
+        def c5_run(profile):
+            ft5 = FE.FeatureTracker(cfg5)
+            ft5.reserve(max(b[0].n for b in bat), max(b[1].n for b in bat), host_batches=False)
+            if args.host_threads > 1:
+                ft5.set_host_threads(args.host_threads)
+            for k in range(nw5):
+                ft5.trackEvent(bat[k][3], bat[k][0].arg, bat[k][1].arg, k % 2 == 0, copy=False)
+            torch.cuda.synchronize()
+            if profile:
+                ft5.set_profiling(True)
+                ft5.reset_kernel_stats()
+            t5 = time.perf_counter()
+            ev = 0
+            for k in range(nw5, nw5 + ns5):
+                ft5.trackEvent(bat[k][3], bat[k][0].arg, bat[k][1].arg, k % 2 == 0, copy=False)
+                ev += bat[k][2]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t5
+            ks = ft5.kernel_stats() if profile else None
+            ft5.close()
+            return ev, dt, ks
+        ev5, dt5, _ = c5_run(False)
+        _, _, ks5 = c5_run(True)
+        for b5 in bat:
+            b5[0].free()
+            b5[1].free()
+        per5 = ev5 / ns5
+        # SURVEY 8d's per-event / per-pixel accounting of the step: ingest 16 + SAE update 32 B/event, render 17 B/px/camera
+        alg5 = 48 * per5 + 17 * 1280 * 720 * 2
+        kk = {}
+        for name, bpl in (("k_tile_hist", 16 * per5), ("k_tile_scatter", 24 * per5), ("k_tile_apply", 32 * per5),
+                          ("k_time_surface4", 17 * 1280 * 720 * 2), ("k_arc_map", None), ("k_arc_ev", None),
+                          ("k_lk_f32" if args.lk_accum == 2 else "k_lk", None)):
+            v = ks5.get(name)
+            if v and v["launches"]:
+                us = v["ms"] / v["launches"] * 1e3
+                kk[name] = dict(avg_launch_us=round(us, 2), launches=v["launches"])
+                if bpl:
+                    kk[name].update(alg_bytes_per_launch=int(bpl), achieved_GBs=round(bpl / us / 1e3, 1),
+                                    frac=round(bpl / us / 1e3 / HBM_PEAK_GBS, 4))
+        c5_leg = dict(workload="%s: stereo 1280x720 scene stream, 100 Mev/s per camera, %g Hz batches, plain calls, device-resident, "
+                               "lk_accum %d" % (workload_label(1280, 720, 1e8, 1, "rigs"), args.batch_hz, args.lk_accum),
+                      steps=ns5, warmup=nw5, events_per_step=int(per5), ms_per_step=round(dt5 / ns5 * 1e3, 4),
+                      value=round(ev5 / dt5 / 1e6, 1), unit="Mevents/s",
+                      alg_bytes_per_step=int(alg5), alg_GBs=round(alg5 * ns5 / dt5 / 1e9, 1),
+                      alg_frac_of_hbm_peak=round(alg5 * ns5 / dt5 / 1e9 / HBM_PEAK_GBS, 4), kernels=kk,
+                      note="a side figure at BASELINE C5's shape on one GPU, never `value`; kernels: live HIP-event pairs of a second "
+                           "run of the same three steps")
 
     # ---- CPU baseline: the oracle (single-threaded port of the reference path) on a bounded sample
     cpu = None
@@ -838,7 +911,7 @@ def main():
                    ms_per_step=round(tc / nfr * 1e3, 3),
                    stage_ms_per_step={k: round(v / nfr * 1e3, 3) for k, v in st.items()},
                    host_cpus=os.cpu_count(), usable_cpus=usable_cpus())
-        if roof and roof["kernel"] == "k_lk":
+        if roof and roof["kernel"] in ("k_lk", "k_lk_f32"):
             # Issue model of the dominant kernel: one wave per point walks its <= 30 iterations per
             # level serially, the launch lasts as long as its slowest point.  Iteration counts come
             # from the CPU baseline run above (same frames, same arithmetic); instructions per
@@ -956,15 +1029,22 @@ def main():
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong" if one_rig else "weak",
+            "scaling_note": ("capability, not a speed-up: ONE stream, every batch time-sliced over the ranks for the SAE update — "
+                             "two all-gathers of a full plane set per batch cost more than the single-GPU update they divide "
+                             "(DESIGN.md section 6)" if time_split else
+                             "capability, not a speed-up: ONE rig, the right camera's update + render on rank 1, its image broadcast "
+                             "each frame" if cam_split else
+                             "replicas: one independent stereo rig per GPU, no data-path collective; the one exchange is the "
+                             "all-gather of the tracked-corner records (19.2 KB per rank per published frame)"),
             "vs_baseline": None,
             "dtype": "f64 timestamps / u8 images / int64 LK sums" if args.lk_accum == 1 else
                      "f64 timestamps / u8 images / f32 LK sums in the reference build's order",
             "data": "synthetic",
             "config": {
-                "workload": "C3 (superset of C2): stereo %dx%d %s stream, %.1f Mev/s per camera, "
+                "workload": "%s: stereo %dx%d %s stream, %.1f Mev/s per camera, "
                             "%g Hz batches, full SAE+TS+pyramid+LK(temporal,stereo)+Arc*+select, "
                             "max_cnt %d min_dist 10 flow_back 1 equalize %d freq %d, lk_accum %d (%s)"
-                            % (W, H, args.stream, args.rate / 1e6, args.batch_hz, args.max_cnt, args.equalize, args.freq,
+                            % (workload_label(W, H, args.rate, world, args.split), W, H, args.stream, args.rate / 1e6, args.batch_hz, args.max_cnt, args.equalize, args.freq,
                                args.lk_accum, "exact integer LK sums" if args.lk_accum == 1 else
                                "float LK sums in the reference's x86 order"),
                 "events_per_step_per_gpu": int(n_events / args.steps),
@@ -992,6 +1072,10 @@ def main():
                 "low_cpu_ms": (None if low_cpu is None else "1 host thread %.4f; 2 CPUs / 2 threads %s"
                                % (low_cpu["one_host_thread_ms_per_step"],
                                   ("%.4f" % low_cpu["two_cpus_two_threads_ms_per_step"]) if "two_cpus_two_threads_ms_per_step" in low_cpu else "n/a")),
+                "c5_shape_one_gpu": (None if c5_leg is None else "%.4f ms/step, %.0f Mev/s, k_time_surface4 %s of the HBM peak"
+                                     % (c5_leg["ms_per_step"], c5_leg["value"],
+                                        ("%.0f %%" % (100 * c5_leg["kernels"]["k_time_surface4"]["frac"]))
+                                        if "k_time_surface4" in c5_leg["kernels"] else "n/a")),
                 "other_lk_mode_ms": None if other_lk is None else "lk_accum %d: %.4f" % (other_lk["lk_accum"], other_lk["ms_per_step"]),
                 "kernel_ms_per_step_summed": None if device_activity is None else device_activity["kernel_ms_per_step_summed"],
             },
@@ -1006,6 +1090,7 @@ def main():
             "kernels": kernels,
             "kernels_replay_schedule": kernels_pipe,
             "sae_chain_c5_batch": sae_chain,
+            "c5_shape_one_gpu": c5_leg,
             "device_activity": device_activity,
             "host_ransac": host_ransac,
             # ---- the driver keeps the END of the line: what a reader needs beside `value` comes last

@@ -75,7 +75,6 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   host::ransac_pool_destroy(c->pool);
   c->pool = nullptr;
   stager_destroy(c);
-  destroy_launch_graph(c->pf_graph);
   if (c->trace && c->phase_frames) {
     static const char* nm[8] = {"enqueue sae+ts+pyr", "enqueue temporal LK", "sync A", "host filter",
                                 "host ransac", "host mask + enqueue detect/stereo", "sync B", "host tail"};
@@ -136,7 +135,7 @@ int esvio_fe_destroy(esvio_fe_handle c) {
   if (c->x_done) (void)hipEventDestroy(c->x_done);
   if (c->x_pin) (void)hipHostFree(c->x_pin);
   if (c->x_pin_recv) (void)hipHostFree(c->x_pin_recv);
-  void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_warp, c->d_tile, c->d_part2, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
+  void* ptrs[] = {c->x_send, c->x_recv, c->d_part, c->d_warp, c->d_tile, c->L2s, c->S2s, c->slice_stage, c->L2, c->S2, c->d_ev, c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sae_marks,
                   c->d_rejected, c->d_res, c->d_ptsD, c->d_flags, c->d_pub_slots, c->d_pub_done, c->d_chain, c->d_lane_gate, c->d_gftt_cov, c->d_gftt_rowsum, c->d_gftt_eig, c->d_gftt_max,
                   c->d_mask_bits, c->d_sel_idx, c->d_sel_bitmap, c->d_eq_tmp,
                   c->tmp_pyr[0].mem, c->tmp_pyr[1].mem, c->med_tmp[0].mem, c->med_tmp[1].mem, c->d_lut,
@@ -294,20 +293,11 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if ((rc = dev_alloc(c, &c->d_lane_gate, 16))) return bail(rc);
   c->stage_threads = stager_threads_from_env();
   if (const char* v = getenv("ESVIO_FE_FAULT")) esvio_fe_debug_inject(c, atoi(v));
-  c->part_two_level = getenv("ESVIO_FE_PART2") != nullptr;  // (measured slower than the one-level partition: opt-in, KERNELS.md)
   if (const char* e = getenv("ESVIO_FE_STEREO_SPLIT")) c->stereo_split_env = atoi(e) != 0;  // (else: fe_track.cpp decides)
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
   c->cam_split_enabled = getenv("ESVIO_FE_NO_CAMSPLIT") == nullptr;
-  c->graphs_enabled = getenv("ESVIO_FE_GRAPH") != nullptr;
   c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
   c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
-  // time surface and pyramid as two launches: k_time_surface4 reads every plane word once and renders every pixel
-  // once (the render at its HBM roof), k_pyr3 builds the three pyrDown levels from the rendered level 0.  The
-  // one-launch form (k_ts_pyr) re-renders its tiles' halos, 2.2x the planes' bytes and exps: 31 against 24 us at
-  // 1280x720; at 640x480 the two forms take the same 17.5 us and the same 0.144 ms per step (four cold runs each).
-  // ESVIO_FE_SPLIT_RENDER=0 / 1 forces either form (A/B, tests).
-  c->split_render = true;
-  if (const char* v = getenv("ESVIO_FE_SPLIT_RENDER")) c->split_render = atoi(v) != 0;
   c->select_one_wave = getenv("ESVIO_FE_SELECT_SERIAL") != nullptr;
   if (const char* v = getenv("ESVIO_FE_SAE_EV_MIN")) c->sae_ev_min = (size_t)strtoull(v, nullptr, 10);
   c->tiled = make_tile_geom(c->W, c->H, &c->tgeom) && getenv("ESVIO_FE_SAE_SORT") == nullptr;

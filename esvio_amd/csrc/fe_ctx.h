@@ -66,9 +66,10 @@ struct IdMap {
 };
 
 const char* const kKernelNames[K_COUNT] = {
-    "k_sae_keys", "k_radix_pass", "k_sae_apply",
-    "k_time_surface", "k_clahe", "k_pyr_down", "k_pyr_pad", "k_scharr", "k_lk", "k_arc", "k_compact", "k_select",
-    "k_arc_map", "k_tile_scan"};
+    "k_tile_hist", "k_tile_scan", "k_tile_scatter", "k_tile_apply", "k_sae_keys", "k_radix_pass", "k_sae_apply",
+    "k_time_surface4", "k_time_surface", "k_median", "k_clahe", "k_norm_pyr", "k_pyr3", "k_pyr_down", "k_pyr_pad",
+    "k_scharr", "k_pad_scharr", "k_lk_f32", "k_lk", "k_arc_map", "k_arc_ev", "k_dedup", "k_compact", "k_select_mw",
+    "k_select", "k_select_gbm"};
 
 struct KStat {
   double ms = 0;
@@ -190,9 +191,6 @@ struct esvio_fe_ctx {
   size_t part_cap = 0;
   uint32_t* d_tile = nullptr;  // TileScratch
   size_t tile_cap = 0;
-  uint32_t* d_part2 = nullptr;  // PartScratch (the two-level partition)
-  size_t part2_cap = 0;         // ... sized for this many events
-  bool part_two_level = false;  // ESVIO_FE_PART2=1: the two-level partition (k_part_coarse / _scan / _fine) instead of k_tile_hist / _scan / _scatter
   uint8_t* sae_marks = nullptr;         // [sort_cap] its per-event "stores L / stores S" marks
   unsigned long long* d_rejected = nullptr;
   // left: slots 0..kLeftSlots-1 rotate (prev, cur, up to kPrefetchDepth being prefetched);
@@ -325,13 +323,6 @@ struct esvio_fe_ctx {
   } pend_right;
   hipEvent_t ev_lks_done[2] = {nullptr, nullptr}, ev_lknew_done = nullptr;
   host::RansacPool* pool = nullptr;  // esvio_fe_set_host_threads
-  // the prefetch stream's per-batch launch sequence as a HIP graph (fe_kernels.h)
-  // Off by default: measured on MI355X / ROCm 7.2 it saves ~17 us of host time per batch but the
-  // graph's kernels complete ~50 us later than the same kernels launched one by one, and the
-  // chained temporal LK then waits for the pyramids.  ESVIO_FE_GRAPH=1 turns it on.
-  bool graphs_enabled = false;
-  LaunchList rec;
-  LaunchGraph pf_graph;
   // arc / select
   uint8_t* d_flags = nullptr;
   // per-block ordered candidate lists written by k_arc; two sets so that the Arc* of a prefetched
@@ -351,7 +342,6 @@ struct esvio_fe_ctx {
   uint32_t first_epoch[kRightSlots] = {};  // Arc* passes into the set so far
   bool dedup_enabled = true;               // (ESVIO_FE_NO_DEDUP=1, test-only: the path batches >= 2^20 events take)
   bool fuse_ts_pyr = true;                 // (ESVIO_FE_NO_FUSE=1, test-only: k_time_surface + 3 x k_pyr_down, the median / equalize path)
-  bool split_render = true;  // the plain configuration's render as two launches: k_time_surface4 (every plane word once) + k_pyr3 (ESVIO_FE_SPLIT_RENDER=0: k_ts_pyr, one launch)
   int cand_cur = 0;
   size_t arc_cap = 0;
   uint32_t* d_mask_bits = nullptr;

@@ -107,8 +107,8 @@ int gftt_run(esvio_fe_ctx* c, const PyrDesc& d, int max_corners, double quality,
     sa.gbitmap = c->d_sel_bitmap;
     lds = select_tables_lds_bytes(c);
   }
-  ScopedKernel k(c, K_SELECT, 0);
-  launch_select(cur_stream(c), sa, lds);
+  ScopedKernel k(c, K_SELECT_MW, 0);
+  k.id = launch_select(cur_stream(c), sa, lds);
   return 0;
 }
 

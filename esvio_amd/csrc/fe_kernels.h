@@ -8,49 +8,6 @@
 
 namespace esvio {
 
-// ---- launch recording / HIP graphs -------------------------------------------------------------
-// One kernel launch costs ~3 us of host time on this stack, one hipGraphLaunch ~5 us whatever the
-// node count, one hipGraphExecKernelNodeSetParams ~0.7 us.  The per-batch sequence the prefetch
-// stream runs (SAE keys, radix passes, SAE apply, time surfaces, pyramids: 11 dependent launches
-// whose arguments change every batch) is therefore recorded instead of launched — while a
-// LaunchList is installed on the calling thread every launch_* wrapper below appends (kernel,
-// grid, block, argument bytes) to it — and then submitted as one linear graph whose nodes get the
-// new parameters (launch_as_graph).  The kernels and their arguments are exactly those of the
-// plain path.  (Measured: host time per batch drops as expected, but the graph's kernels finish
-// later than plainly launched ones and the frame's device-side chain ends up waiting for them, so
-// the front-end only uses this with ESVIO_FE_GRAPH=1.)
-struct LaunchList {
-  struct Item {
-    void* func;
-    dim3 grid, block;
-    unsigned shmem;
-    uint32_t arg0, nargs;  // into arg_off / arg_size
-    hipEvent_t event;      // func == nullptr: an event record at this point of the sequence
-  };
-  std::vector<Item> items;
-  std::vector<uint32_t> arg_off, arg_size;
-  std::vector<uint8_t> blob;  // argument values, each aligned to 16 B
-  void clear() {
-    items.clear();
-    arg_off.clear();
-    arg_size.clear();
-    blob.clear();
-  }
-};
-void set_launch_recorder(LaunchList* l);  // nullptr: launch normally (per thread)
-// hipEventRecord(e, s), or an event-record node when a recorder is installed
-hipError_t record_event(hipEvent_t e, hipStream_t s);
-struct LaunchGraph {
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  std::vector<hipGraphNode_t> nodes;
-  LaunchList last;  // what the nodes currently hold (unchanged nodes are not touched)
-};
-// Submit the recorded launches to `s` in order: as the cached graph when the kernel sequence is
-// the same as last time (else the graph is rebuilt first).
-hipError_t launch_as_graph(LaunchGraph& g, const LaunchList& l, hipStream_t s);
-hipError_t launch_plain(const LaunchList& l, hipStream_t s);
-void destroy_launch_graph(LaunchGraph& g);
 
 // dvs_msgs::Event, 16 B AoS (reference: feature_tracker/src/dvs_msgs/Event.h:42-52)
 struct __attribute__((aligned(16))) EventRec {
@@ -79,21 +36,37 @@ struct PyrDesc {
 };
 inline int pyr_stride(int w) { return (w + 2 * kPad + 15) & ~15; }
 
+// Slots of the per-kernel timers (esvio_fe_set_profiling): one per kernel FUNCTION, named as rocprofv3 names it
+// (kKernelNames, fe_ctx.h), so that a bench line's `kernels` can be matched with a profile without a table.  A
+// launch site that picks between forms (k_lk / k_lk_f32, k_time_surface4 / k_time_surface, the selection kernels)
+// books the one it launched.  The few slots that cover more than one function say so in their name's comment.
 enum KernelId {
-  K_SAE_KEYS = 0,
+  K_TILE_HIST = 0,   // (+ k_mc_warp in front of it for a motion-compensated batch)
+  K_TILE_SCAN,
+  K_TILE_SCATTER,
+  K_TILE_APPLY,
+  K_SAE_KEYS,        // the radix-sort form of the update: k_sae_keys, k_radix_pass, k_sae_apply (_ev, _ev_write)
   K_RADIX_PASS,
   K_SAE_APPLY,
+  K_TIME_SURFACE4,
   K_TIME_SURFACE,
-  K_CLAHE,
+  K_MEDIAN,
+  K_CLAHE,           // k_clahe_lut, k_clahe_interp (k_normalize in the unfused form)
+  K_NORM_PYR,
+  K_PYR3,
   K_PYR_DOWN,
   K_PYR_PAD,
   K_SCHARR,
+  K_PAD_SCHARR,
+  K_LK_F32,
   K_LK,
-  K_ARC,
+  K_ARC_MAP,         // (+ k_arc_mark where the SAE update has not left the touched flags)
+  K_ARC_EV,
+  K_DEDUP,
   K_COMPACT,
+  K_SELECT_MW,
   K_SELECT,
-  K_ARC_MAP,
-  K_TILE_SCAN,
+  K_SELECT_GBM,
   K_COUNT
 };
 
@@ -223,57 +196,6 @@ void launch_tile_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileSc
 // warped pixels launch_tile_hist computed)
 void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
                          const TileGeom& g, const TileScratch& sc, EventRec* part, const uint32_t* warp_xy = nullptr);
-// ---- the same partition in two levels (ESVIO_FE_PART2=1; round 5's attempt at the partition, measured slower than
-// the one-level form on MI355X — 160 against 113 us at 6.7 M events — and kept as an A/B, KERNELS.md): coarse buckets of 32 consecutive buckets first, every block's
-// 2048 events sorted into its own slot of `mid`; then pieces of 2048 records of a coarse bucket into their final
-// places (fe_kernels.hip: k_part_coarse / k_part_scan / k_part_fine).  Leaves `part`, tile_off, tile_order, totals
-// and meta exactly as the three launches above do.
-constexpr int kPartTE = 2048;     // events per block of the coarse pass
-constexpr int kPartPiece = 2048;  // records per piece of the fine pass (1024: twice the blocks, 115 -> 120 us at 6.7 M events)
-constexpr int kPartGridA = 768;   // persistent blocks of the coarse pass (3 per CU: 42 KiB of LDS each)
-constexpr int kPartRows = 67;     // per block of the coarse pass: 65 run starts, the block's base second, its "wide" flag
-struct PartScratch {
-  // a block's slot holds its 2048 events sorted by coarse bucket, 8 bytes each — {tile-local pixel | polarity << 11 |
-  // bucket inside its coarse bucket << 12 | (sec - the block's base second) << 17, nsec} — or, for a block whose
-  // seconds span 2^15 or more, 12 bytes each {sec, nsec, the low 17 bits} in mid12 (same slot number)
-  uint32_t* mid8;       // [n][2]
-  uint32_t* mid12;      // [n][3]
-  uint32_t* rowpfx;     // [kPartRows][blocks]
-  uint32_t* fine_rows;  // [kPartGridA][nbins] bucket counts per persistent block
-  uint32_t* ranges;     // [kPartGridA][4]
-  uint32_t* colpfx;     // [64][blocks + 1] a coarse bucket's run lengths, exclusive prefix over the blocks
-  uint32_t* lookback;   // [pieces][32]
-  uint32_t* ticket;
-};
-inline uint32_t part_blocks(size_t n) { return (uint32_t)((n + kPartTE - 1) / kPartTE); }
-inline uint32_t part_pieces_max(size_t n) { return (uint32_t)((n + kPartPiece - 1) / kPartPiece) + 64u; }
-inline size_t part_scratch_words(size_t cap) {
-  cap = (cap + 3) & ~(size_t)3;  // (every part 16-byte aligned)
-  const size_t nb = (part_blocks(cap) + 3) & ~(size_t)3;
-  return (size_t)kPartGridA * 4 + cap * 2 + 4 + cap * 3 + 4 + nb * kPartRows + (size_t)kPartGridA * kTileMaxBins +
-         64 * (nb + 1) + (size_t)part_pieces_max(cap) * 32 + 4;
-}
-inline PartScratch part_scratch(uint32_t* base, size_t cap) {
-  cap = (cap + 3) & ~(size_t)3;
-  const size_t nb = (part_blocks(cap) + 3) & ~(size_t)3;
-  PartScratch p;
-  p.ranges = base;  // (16-byte aligned: first)
-  p.mid8 = p.ranges + (size_t)kPartGridA * 4;
-  p.mid12 = p.mid8 + cap * 2 + 4;
-  p.rowpfx = p.mid12 + cap * 3 + 4;
-  p.fine_rows = p.rowpfx + nb * kPartRows;
-  p.colpfx = p.fine_rows + (size_t)kPartGridA * kTileMaxBins;
-  p.lookback = p.colpfx + 64 * (nb + 1);
-  p.ticket = p.lookback + (size_t)part_pieces_max(cap) * 32;
-  return p;
-}
-void launch_part_coarse(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                        const TileGeom& g, const PartScratch& ps, const struct McParams* mc = nullptr,
-                        uint32_t* warp_xy = nullptr);
-void launch_part_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc, const PartScratch& ps,
-                      unsigned long long* n_rejected);
-void launch_part_fine(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc, const PartScratch& ps,
-                      EventRec* part, int* err, uint32_t spin_limit = kSpinLookback);
 // createSAE_left/right (event_detector.cc:149-166, :212-228) per bucket, events in stream order.
 // arc_touched (optional): ArcArgs::touched of the Arc* pass this batch will get — the left camera's
 // touched (pixel, polarity) flags are written here, from the tiles' own bookkeeping, instead of by
@@ -292,7 +214,7 @@ void launch_overlay_f64(hipStream_t s, double* dst, const double* src, size_t n,
 
 // ---- time surface -----------------------------------------------------------------------
 // renders ncam cameras (S2 + cam*P) into level-0 interiors of dst[cam]
-void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
+KernelId launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
                          double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
                          int dst_stride, int ncam);
 
@@ -312,11 +234,6 @@ void launch_clahe(hipStream_t s, const uint8_t* raw0, const uint8_t* raw1, int r
 
 // ---- pyramid ----------------------------------------------------------------------------
 void launch_pyr_down(hipStream_t s, const PyrDesc* p, int nimg, int src_level);
-// k_time_surface + the three k_pyr_down of both cameras' pyramids in one launch (same bytes)
-void launch_ts_pyr_cam(hipStream_t s, const double2* S2_cam, double t_sync, double decay_sec, int ignore_polarity,
-                       const PyrDesc* p);  // one camera (S2_cam: its planes, p: its pyramid)
-void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay_sec,
-                   int ignore_polarity, const PyrDesc* p);
 // levels 1..3 of nimg images whose level 0 is in place, one launch (maxLevel 3)
 void launch_pyr3(hipStream_t s, const PyrDesc* p, int nimg);
 void launch_pyr_pad(hipStream_t s, const PyrDesc* p, int nimg);
@@ -494,7 +411,7 @@ struct SelectArgs {
   // (sensors between ~1.2 and 1.3 M pixels take it for lack of LDS; ESVIO_FE_SELECT_SERIAL=1, test-only)
   int one_wave;
 };
-void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes);
+KernelId launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes);  // (returns the form it launched)
 // the threshold described at SelectArgs::disc_c for a half-width table, or -1 if there is none
 inline int disc_threshold(const int8_t* hw, int radius) {
   long inside = -1, outside = (long)(radius + 1) * (radius + 1);

@@ -16,147 +16,15 @@
 
 namespace esvio {
 
-// ============================================================================ launch recording
+// ============================================================================ launches
 namespace {
-thread_local LaunchList* t_recorder = nullptr;
-
-template <typename T>
-void record_arg(LaunchList& l, const T& v) {
-  const size_t off = (l.blob.size() + 15) & ~(size_t)15;
-  l.blob.resize(off + sizeof(T));
-  std::memcpy(&l.blob[off], &v, sizeof(T));
-  l.arg_off.push_back((uint32_t)off);
-  l.arg_size.push_back((uint32_t)sizeof(T));
-}
-
 // every launch of this file goes through here
 template <typename... P, typename... A>
 void launch_k(void (*kernel)(P...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, A... args) {
   static_assert(sizeof...(P) == sizeof...(A), "argument count");
-  LaunchList* l = t_recorder;
-  if (!l) {
-    hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
-    return;
-  }
-  LaunchList::Item it;
-  it.func = (void*)kernel;
-  it.grid = grid;
-  it.block = block;
-  it.shmem = shmem;
-  it.event = nullptr;
-  it.arg0 = (uint32_t)l->arg_off.size();
-  it.nargs = (uint32_t)sizeof...(P);
-  (record_arg<P>(*l, static_cast<P>(args)), ...);  // (converted to the kernel's parameter types)
-  l->items.push_back(it);
-}
-
-void fill_params(const LaunchList& l, const LaunchList::Item& it, std::vector<void*>& ptrs,
-                 hipKernelNodeParams& kp) {
-  ptrs.resize(it.nargs);
-  for (uint32_t a = 0; a < it.nargs; a++) ptrs[a] = (void*)&l.blob[l.arg_off[it.arg0 + a]];
-  kp = hipKernelNodeParams{};
-  kp.func = it.func;
-  kp.gridDim = it.grid;
-  kp.blockDim = it.block;
-  kp.sharedMemBytes = it.shmem;
-  kp.kernelParams = ptrs.data();
-  kp.extra = nullptr;
-}
-
-bool same_launch(const LaunchList& a, const LaunchList::Item& x, const LaunchList& b,
-                 const LaunchList::Item& y) {
-  if (x.func != y.func || x.nargs != y.nargs || x.shmem != y.shmem || x.grid.x != y.grid.x ||
-      x.grid.y != y.grid.y || x.grid.z != y.grid.z || x.block.x != y.block.x ||
-      x.block.y != y.block.y || x.block.z != y.block.z)
-    return false;
-  for (uint32_t k = 0; k < x.nargs; k++) {
-    const uint32_t sa = a.arg_size[x.arg0 + k];
-    if (sa != b.arg_size[y.arg0 + k] ||
-        std::memcmp(&a.blob[a.arg_off[x.arg0 + k]], &b.blob[b.arg_off[y.arg0 + k]], sa) != 0)
-      return false;
-  }
-  return true;
+  hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
 }
 }  // namespace
-
-void set_launch_recorder(LaunchList* l) { t_recorder = l; }
-
-hipError_t record_event(hipEvent_t e, hipStream_t s) {
-  LaunchList* l = t_recorder;
-  if (!l) return hipEventRecord(e, s);
-  LaunchList::Item it{};
-  it.func = nullptr;
-  it.event = e;
-  it.arg0 = (uint32_t)l->arg_off.size();
-  it.nargs = 0;
-  l->items.push_back(it);
-  return hipSuccess;
-}
-
-hipError_t launch_plain(const LaunchList& l, hipStream_t s) {
-  std::vector<void*> ptrs;
-  for (const LaunchList::Item& it : l.items) {
-    if (!it.func) {
-      const hipError_t e = hipEventRecord(it.event, s);
-      if (e != hipSuccess) return e;
-      continue;
-    }
-    ptrs.resize(it.nargs);
-    for (uint32_t a = 0; a < it.nargs; a++) ptrs[a] = (void*)&l.blob[l.arg_off[it.arg0 + a]];
-    const hipError_t e = hipLaunchKernel(it.func, it.grid, it.block, ptrs.data(), it.shmem, s);
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
-}
-
-void destroy_launch_graph(LaunchGraph& g) {
-  if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  if (g.graph) (void)hipGraphDestroy(g.graph);
-  g.exec = nullptr;
-  g.graph = nullptr;
-  g.nodes.clear();
-  g.last.clear();
-}
-
-hipError_t launch_as_graph(LaunchGraph& g, const LaunchList& l, hipStream_t s) {
-  if (l.items.empty()) return hipSuccess;
-  std::vector<void*> ptrs;
-  hipKernelNodeParams kp;
-  bool same_shape = g.exec && g.last.items.size() == l.items.size();
-  for (size_t i = 0; same_shape && i < l.items.size(); i++)
-    same_shape = g.last.items[i].func == l.items[i].func && g.last.items[i].nargs == l.items[i].nargs;
-  hipError_t e;
-  if (!same_shape) {  // a linear chain of kernel nodes, in launch order
-    destroy_launch_graph(g);
-    if ((e = hipGraphCreate(&g.graph, 0)) != hipSuccess) return e;
-    g.nodes.resize(l.items.size());
-    for (size_t i = 0; i < l.items.size(); i++) {
-      const hipGraphNode_t* dep = i ? &g.nodes[i - 1] : nullptr;
-      if (!l.items[i].func) {
-        e = hipGraphAddEventRecordNode(&g.nodes[i], g.graph, dep, i ? 1 : 0, l.items[i].event);
-      } else {
-        fill_params(l, l.items[i], ptrs, kp);
-        e = hipGraphAddKernelNode(&g.nodes[i], g.graph, dep, i ? 1 : 0, &kp);
-      }
-      if (e != hipSuccess) return e;
-    }
-    if ((e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0)) != hipSuccess) return e;
-  } else {
-    for (size_t i = 0; i < l.items.size(); i++) {
-      if (!l.items[i].func) {
-        if (g.last.items[i].event != l.items[i].event &&
-            (e = hipGraphExecEventRecordNodeSetEvent(g.exec, g.nodes[i], l.items[i].event)) != hipSuccess)
-          return e;
-        continue;
-      }
-      if (same_launch(g.last, g.last.items[i], l, l.items[i])) continue;
-      fill_params(l, l.items[i], ptrs, kp);
-      if ((e = hipGraphExecKernelNodeSetParams(g.exec, g.nodes[i], &kp)) != hipSuccess) return e;
-    }
-  }
-  g.last = l;
-  return hipGraphLaunch(g.exec, s);
-}
 
 // ============================================================================ helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -1176,616 +1044,6 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
 #undef ESVIO_TILE_SCATTER
 }
 
-// ============================================================================ two-level stable partition
-// The partition above (k_tile_hist + k_tile_scan + k_tile_scatter) ranks every event among the <= 2047 buckets
-// at once: 36 B of LDS per bucket and block, two blocks per CU, and stores that reach L2 as runs of ~2
-// records.  This form (ESVIO_FE_PART2=1) never issues a scattered store and never needs per-bucket state of more
-// than 64 entries — and measured SLOWER on MI355X (6.7 M events: 47 + 13 + 100 us against 31 + 9 + 73; KERNELS.md has
-// the account), so it is an opt-in A/B, parity-tested, not the default:
-//   k_part_coarse  one pass over the raw events (16 B read): a block takes 2048 consecutive events, ranks them
-//                  among the <= 64 COARSE buckets (32 consecutive fine buckets each; wave match-any by 6
-//                  ballots, stream order kept), sorts them in LDS and writes its slot of `mid` — the block's
-//                  own 2048 records, 12 B each {sec, nsec, tile-local pixel | polarity | fine bucket inside
-//                  the coarse one}, sorted by coarse bucket — as one contiguous copy, plus the 65 run starts
-//                  of the slot (rowpfx).  Persistent blocks also count the fine buckets in LDS (one row of
-//                  fine_rows per block at the end) and the range of the stamps.
-//   k_part_scan    per coarse bucket the exclusive prefix of its run lengths over the blocks (colpfx: where in
-//                  the bucket's stream-ordered sequence a block's run begins), the fine buckets' totals
-//                  (column sums of fine_rows), the record format of the batch.
-//   k_part_fine    a PIECE = 2048 consecutive records of one coarse bucket's sequence (so hot buckets just get
-//                  more pieces): copies the runs that make it up into LDS (contiguous reads), ranks them among
-//                  the bucket's 32 fine buckets (5 ballots), sorts them in LDS into their final 8-byte form
-//                  and writes each fine bucket's run as a contiguous copy to its place in `part`: bucket
-//                  start + the counts of the bucket's earlier pieces (decoupled look-back over 32-word
-//                  descriptors, tickets in (bucket, piece) order, bounded spin) — the partition k_tile_apply
-//                  reads, bit for bit the one k_tile_scatter wrote.
-// Traffic per event: 16 + 12 | 12 + 8 instead of 16 | 16 + 8 (+ the count matrices).
-constexpr int kPartFineBits = 5, kPartFine = 1 << kPartFineBits;
-constexpr int kPartMaxCoarse = kTileMaxBins >> kPartFineBits;  // 64: one lane per coarse bucket
-static_assert(kPartMaxCoarse == 64, "coarse buckets are scanned by one wave");
-constexpr int kPartRounds = kPartTE / 256;
-static_assert(kPartRounds * 256 == kPartTE && (kPartTE * 12) % 16 == 0, "slot geometry");
-
-// lanes holding the same value of the low BITS bits of v among the lanes of `ok`, in lane (= stream) order
-template <int BITS>
-__device__ __forceinline__ unsigned long long match_any_bits(uint32_t v, bool ok) {
-  unsigned long long m = __ballot(ok);
-#pragma unroll
-  for (int b = 0; b < BITS; b++) {
-    const bool bit = (v >> b) & 1u;
-    const unsigned long long bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
-  }
-  return m;
-}
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane) {  // exclusive prefix over the 64 lanes
-  uint32_t incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
-  }
-  return incl - v;
-}
-
-template <bool MC>
-__global__ __launch_bounds__(256) void k_part_coarse(const uint4* __restrict__ evL, uint32_t nL,
-                                                     const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
-                                                     uint32_t nblk, uint32_t* __restrict__ mid8,
-                                                     uint32_t* __restrict__ mid12, uint32_t* __restrict__ rowpfx, uint32_t* __restrict__ fine_rows,
-                                                     uint4* __restrict__ ranges, const uint32_t* __restrict__ warp_xy,
-                                                     uint32_t* __restrict__ lookback, uint32_t lookback_words,
-                                                     uint32_t* __restrict__ ticket) {
-  __shared__ __attribute__((aligned(16))) uint32_t stage[kPartTE * 3];  // the block's slot of `mid`, as it will lie in memory
-  __shared__ uint32_t h[2 * kTileMaxBins];  // fine-bucket counts, two copies by lane parity (runs of one bucket)
-  __shared__ uint32_t wcnt[4][kPartMaxCoarse], cbase[4][kPartMaxCoarse];
-  __shared__ uint32_t s_range[3], s_wide;
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  const int nb = g.nbins;
-  const uint32_t n = nL + nR;
-  const int twsh = g.tw == 64 ? 6 : 5;
-  for (int i = threadIdx.x; i < 2 * kTileMaxBins; i += 256) h[i] = 0;
-  if (threadIdx.x == 0) {
-    s_range[0] = 0xffffffffu;
-    s_range[1] = 0;
-    s_range[2] = 0;
-    s_wide = 0;
-  }
-  // (the fine pass's look-back words and ticket: this kernel has ended before that one starts)
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < lookback_words; i += gridDim.x * 256u) lookback[i] = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;
-  __syncthreads();  // (h is zero before any wave counts into it)
-  uint32_t tmin = 0xffffffffu, tmax = 0, tor = 0;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  // (the block's NEXT 2048 events are requested while the current ones are ranked and stored: the barriers inside
-  // the loop order LDS traffic only, so nothing in it waits for HBM except the first use of a record)
-  uint4 ne[kPartRounds];
-  uint32_t nwxy[kPartRounds], nsec0 = 0;
-  auto request = [&](uint32_t blk) {
-    const uint32_t wb = blk * kPartTE + wave * (kPartTE / 4);
-    // (the block's first event's second: the 8-byte records carry seconds relative to it)
-    if (blk < nblk) nsec0 = blk * kPartTE < nL ? evL[blk * kPartTE].y : evR[blk * kPartTE - nL].y;
-#pragma unroll
-    for (int r = 0; r < kPartRounds; r++) {  // (whole records: one contiguous 1 KiB request per wave)
-      const uint32_t i = wb + r * 64 + lane;
-      ne[r] = (blk < nblk && i < nL) ? evL[i] : ((blk < nblk && i < n) ? evR[i - nL] : make_uint4(0xffffffffu, 0, 0, 0));
-      nwxy[r] = (MC && blk < nblk && i < n) ? warp_xy[i] : ne[r].x;  // (the pixel k_mc_warp warped the event to)
-    }
-  };
-  request(blockIdx.x);
-  for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    wcnt[wave][lane] = 0;
-    const uint32_t base_sec = nsec0 - (1u << 14);  // seconds [base, base + 2^15) fit the 8-byte record
-    uint32_t r_sec[kPartRounds], r_nsec[kPartRounds], r_meta[kPartRounds], r_dst[kPartRounds];
-    const uint32_t wb = blk * kPartTE + wave * (kPartTE / 4);
-    uint4 e[kPartRounds];
-    uint32_t wxy[kPartRounds];
-#pragma unroll
-    for (int r = 0; r < kPartRounds; r++) {
-      e[r] = ne[r];
-      wxy[r] = nwxy[r];
-    }
-    request(blk + gridDim.x);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // (wcnt is this wave's own row)
-#pragma unroll
-    for (int r = 0; r < kPartRounds; r++) {
-      const uint32_t i = wb + r * 64 + lane;
-      const bool ok = i < n;
-      const uint32_t fine = tile_bin(g, wxy[r], i >= nL), coarse = fine >> kPartFineBits;
-      const uint32_t x = wxy[r] & 0xffffu, y = wxy[r] >> 16;
-      const uint32_t pix = ((y & (uint32_t)(g.th - 1)) << twsh) | (x & (uint32_t)(g.tw - 1));
-      r_sec[r] = e[r].y;
-      r_nsec[r] = e[r].z;
-      r_meta[r] = pix | ((e[r].w & 0xffu) ? 1u << 11 : 0u) | ((fine & (uint32_t)(kPartFine - 1)) << 12);
-      if (ok) {
-        atomicAdd(&h[(lane & 1) * kTileMaxBins + fine], 1u);
-        if (fine != (uint32_t)nb - 1u) {
-          if (e[r].y - base_sec >= (1u << 15)) s_wide = 1;  // (any lane: the whole block then takes 12-byte records)
-          tmin = min(tmin, e[r].y);
-          tmax = max(tmax, e[r].y);
-          tor |= e[r].z;
-        }
-      }
-      const unsigned long long m = match_any_bits<6>(coarse, ok);
-      const uint32_t before = __popcll(m & lt);
-      uint32_t base = 0;
-      if (ok) base = wcnt[wave][coarse];
-      if (ok && before == 0) wcnt[wave][coarse] = base + (uint32_t)__popcll(m);  // one leader per bucket
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-      r_dst[r] = (coarse << 16) | (base + before);  // bucket | rank inside (wave, bucket)
-    }
-    lds_barrier();  // every wave's counts; the previous block's copy out of `stage` has been issued and waited for
-    if (wave == 0) {  // lane = coarse bucket: the slot's run starts
-      const uint32_t c0 = wcnt[0][lane], c1 = wcnt[1][lane], c2 = wcnt[2][lane], c3 = wcnt[3][lane];
-      const uint32_t tot = c0 + c1 + c2 + c3, start = wave_excl_scan(tot, lane);
-      cbase[0][lane] = start;
-      cbase[1][lane] = start + c0;
-      cbase[2][lane] = start + c0 + c1;
-      cbase[3][lane] = start + c0 + c1 + c2;
-      // (transposed — [bucket][block] — so that the scan over the blocks and the fine pass's run tables read
-      // consecutive words)
-      rowpfx[(size_t)lane * nblk + blk] = start;
-      if (lane == 63) {
-        rowpfx[(size_t)kPartMaxCoarse * nblk + blk] = start + tot;
-        rowpfx[(size_t)(kPartMaxCoarse + 1) * nblk + blk] = base_sec;
-        rowpfx[(size_t)(kPartMaxCoarse + 2) * nblk + blk] = s_wide;
-      }
-    }
-    lds_barrier();
-    const bool wide = s_wide != 0;  // (uniform)
-#pragma unroll
-    for (int r = 0; r < kPartRounds; r++) {
-      const uint32_t i = wb + r * 64 + lane;
-      if (i < n) {
-        const uint32_t pos = cbase[wave][r_dst[r] >> 16] + (r_dst[r] & 0xffffu);
-        if (wide) {
-          stage[pos * 3] = r_sec[r];
-          stage[pos * 3 + 1] = r_nsec[r];
-          stage[pos * 3 + 2] = r_meta[r];
-        } else {
-          // (an out-of-sensor event's second may be anything: its time is never used)
-          stage[pos * 2] = r_meta[r] | (((r_sec[r] - base_sec) & 0x7fffu) << 17);
-          stage[pos * 2 + 1] = r_nsec[r];
-        }
-      }
-    }
-    lds_barrier();
-    if (threadIdx.x == 0) s_wide = 0;  // (everybody has read it; the barrier below orders this before the next block's rounds)
-    {  // the slot: one contiguous copy, 16 B per lane
-      const uint32_t cnt = min((uint32_t)kPartTE, n - blk * kPartTE);
-      const uint32_t w = wide ? 3u : 2u, nq = (cnt * w + 3) / 4;
-      uint4* dst = (uint4*)((wide ? mid12 : mid8) + (size_t)blk * kPartTE * w);
-      for (uint32_t q = threadIdx.x; q < nq; q += 256) dst[q] = ((const uint4*)stage)[q];
-    }
-    lds_barrier();
-  }
-  for (int i = threadIdx.x; i < nb; i += 256) fine_rows[(size_t)blockIdx.x * nb + i] = h[i] + h[kTileMaxBins + i];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    tmin = min(tmin, (uint32_t)__shfl_xor((int)tmin, o));
-    tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, o));
-    tor |= (uint32_t)__shfl_xor((int)tor, o);
-  }
-  if (lane == 0) {
-    atomicMin(&s_range[0], tmin);
-    atomicMax(&s_range[1], tmax);
-    atomicOr(&s_range[2], tor);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) ranges[blockIdx.x] = make_uint4(s_range[0], s_range[1], s_range[2], 0);
-}
-
-// block 0: the record format (as k_tile_scan); blocks 1 .. 64: coarse bucket k = blockIdx - 1, exclusive prefix
-// of its run lengths over the coarse pass's blocks; the rest: fine-bucket totals = column sums of fine_rows, 64
-// buckets per block, thread = (bucket, one of 16 ranges of rows), all of a thread's words requested together
-constexpr int kPartScanThreads = 1024, kPartScanRanges = kPartScanThreads / 64;
-constexpr int kPartScanPer = (kPartGridA + kPartScanRanges - 1) / kPartScanRanges;  // rows per thread, at most
-__global__ __launch_bounds__(kPartScanThreads) void k_part_scan(const uint32_t* __restrict__ rowpfx, uint32_t nblk,
-                                                                const uint32_t* __restrict__ fine_rows, uint32_t nrows,
-                                                                int nb, const uint4* __restrict__ ranges,
-                                                                uint32_t* __restrict__ colpfx, uint32_t* __restrict__ totals,
-                                                                uint32_t* __restrict__ meta, unsigned long long* n_rejected,
-                                                                int force_wide) {
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  if (blockIdx.x == 0) {
-    if (wave) return;
-    uint32_t mn = 0xffffffffu, mx = 0, orr = 0;
-    for (uint32_t i = lane; i < nrows; i += 64) {
-      const uint4 r = ranges[i];
-      mn = min(mn, r.x);
-      mx = max(mx, r.y);
-      orr |= r.z;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-      mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-      orr |= (uint32_t)__shfl_xor((int)orr, o);
-    }
-    if (lane == 0) {
-      const bool compact = !force_wide && (mn > mx || (mx - mn < (1u << kTileRecSecBits) && (orr >> 30) == 0));
-      meta[kTileMetaCompact] = compact ? 1u : 0u;
-      meta[kTileMetaSecBase] = mn <= mx ? mn : 0u;
-    }
-    return;
-  }
-  if (blockIdx.x <= kPartMaxCoarse) {
-    const uint32_t k = blockIdx.x - 1;
-    __shared__ uint32_t wsum[kPartScanRanges];
-    __shared__ uint32_t carry_s;
-    uint32_t* out = colpfx + (size_t)k * (nblk + 1);
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    constexpr int PER = 4;  // consecutive blocks of the coarse pass per thread and step
-    for (uint32_t b0 = 0; b0 < nblk; b0 += kPartScanThreads * PER) {
-      uint32_t len[PER], sum = 0;
-#pragma unroll
-      for (int q = 0; q < PER; q++) {
-        const uint32_t b = b0 + threadIdx.x * PER + q;
-        len[q] = 0;
-        if (b < nblk) len[q] = rowpfx[(size_t)(k + 1) * nblk + b] - rowpfx[(size_t)k * nblk + b];
-        sum += len[q];
-      }
-      const uint32_t ex = wave_excl_scan(sum, lane);
-      if (lane == 63) wsum[wave] = ex + sum;
-      __syncthreads();
-      uint32_t off = carry_s + ex;
-      for (int w = 0; w < wave; w++) off += wsum[w];
-#pragma unroll
-      for (int q = 0; q < PER; q++) {
-        const uint32_t b = b0 + threadIdx.x * PER + q;
-        if (b < nblk) out[b] = off;
-        off += len[q];
-      }
-      __syncthreads();
-      if (threadIdx.x == kPartScanThreads - 1) carry_s = off;
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[nblk] = carry_s;
-    return;
-  }
-  {
-    __shared__ uint32_t part[kPartScanRanges][64];
-    const int bin = (int)(blockIdx.x - kPartMaxCoarse - 1) * 64 + lane;
-    const uint32_t per = (nrows + kPartScanRanges - 1) / kPartScanRanges, r0 = (uint32_t)wave * per;
-    uint32_t v[kPartScanPer], s = 0;
-#pragma unroll
-    for (int q = 0; q < kPartScanPer; q++) {
-      const uint32_t r = r0 + (uint32_t)q;
-      v[q] = (bin < nb && (uint32_t)q < per && r < nrows) ? fine_rows[(size_t)r * nb + bin] : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < kPartScanPer; q++) s += v[q];
-    part[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && bin < nb) {
-      uint32_t tot = 0;
-#pragma unroll
-      for (int w = 0; w < kPartScanRanges; w++) tot += part[w][lane];
-      totals[bin] = tot;
-      if (bin == nb - 1 && tot) atomicAdd(n_rejected, (unsigned long long)tot);  // out-of-sensor events
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_part_fine(const uint32_t* __restrict__ mid8, const uint32_t* __restrict__ mid12,
-                                                   const uint32_t* __restrict__ rowpfx,
-                                                   const uint32_t* __restrict__ colpfx, uint32_t nblk, TileGeom g,
-                                                   const uint32_t* __restrict__ totals, const uint32_t* __restrict__ meta,
-                                                   uint32_t* __restrict__ lookback, uint32_t* __restrict__ ticket,
-                                                   uint4* __restrict__ part, uint32_t* __restrict__ tile_off,
-                                                   uint32_t* __restrict__ tile_order, int* __restrict__ err,
-                                                   uint32_t spin_limit) {
-  constexpr int kPieceRounds = kPartPiece / 256;
-  __shared__ __attribute__((aligned(16))) uint32_t sin_[kPartPiece * 3];  // the piece, in the bucket's stream order: {final word 0 (or sec), nsec, low 17 bits}
-  __shared__ __attribute__((aligned(16))) uint2 sout[kPartPiece];         // ... sorted by fine bucket, final 8-byte records
-  __shared__ uint32_t wcnt[4][kPartFine], wbase[4][kPartFine];
-  __shared__ uint32_t f_cnt[kPartFine], f_src[kPartFine], f_dst[kPartFine];
-  __shared__ uint32_t s_t;
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  const int nb = g.nbins, nbc = (nb + kPartFine - 1) >> kPartFineBits;
-  if (threadIdx.x == 0) s_t = atomicAdd(ticket, 1u);
-  if (threadIdx.x < 4 * kPartFine) (&wcnt[0][0])[threadIdx.x] = 0;
-  // ---- which piece: lane = coarse bucket (every wave computes the same; requested while the ticket is on its way)
-  const uint32_t ctot = lane < nbc ? colpfx[(size_t)lane * (nblk + 1) + nblk] : 0u;
-  const bool compact = meta[kTileMetaCompact] != 0;  // (uniform)
-  const uint32_t sec_base = meta[kTileMetaSecBase];
-  __syncthreads();
-  const uint32_t t = s_t;
-  const uint32_t cnp = (ctot + kPartPiece - 1) / kPartPiece;
-  const uint32_t cstart = wave_excl_scan(ctot, lane), pstart = wave_excl_scan(cnp, lane);
-  const uint32_t npieces = __shfl(pstart + cnp, 63);
-  if (t == 0) {
-    // the first piece also leaves the bucket offsets and the order k_tile_apply takes the buckets in: largest size
-    // class (floor(log2(events))) first, so that a bucket with many times the average number of events starts
-    // at once and the launch does not end with it (counting sort by class; the order inside a class is arbitrary)
-    __shared__ uint32_t cls_cnt[33], wtot[4];
-    constexpr int KB = kTileMaxBins / 256;
-    uint32_t loc[KB], sum = 0;
-#pragma unroll
-    for (int q = 0; q < KB; q++) {
-      const int b = threadIdx.x * KB + q;
-      loc[q] = b < nb ? totals[b] : 0u;
-      sum += loc[q];
-    }
-    const uint32_t ex = wave_excl_scan(sum, lane);
-    if (lane == 63) wtot[wave] = ex + sum;
-    if (threadIdx.x < 33) cls_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t run = ex;
-    for (int w = 0; w < wave; w++) run += wtot[w];
-    const int nt = nb - 1;
-#pragma unroll
-    for (int q = 0; q < KB; q++) {
-      const int b = threadIdx.x * KB + q;
-      if (b <= nb) tile_off[b] = run;  // (b == nb: the total)
-      run += loc[q];
-      if (b < nt) atomicAdd(&cls_cnt[loc[q] ? 32 - __clz(loc[q]) : 0], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // exclusive prefix, largest class first
-      uint32_t acc = 0;
-      for (int c = 32; c >= 0; c--) {
-        const uint32_t x = cls_cnt[c];
-        cls_cnt[c] = acc;
-        acc += x;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < KB; q++) {
-      const int b = threadIdx.x * KB + q;
-      if (b < nt) tile_order[atomicAdd(&cls_cnt[loc[q] ? 32 - __clz(loc[q]) : 0], 1u)] = (uint32_t)b;
-    }
-  }
-  if (t >= npieces) return;  // (the grid is sized for the worst case)
-  const uint32_t k = (uint32_t)__popcll(__ballot(pstart + cnp <= t));  // buckets whose pieces all come before t
-  const uint32_t j = t - __shfl(pstart, (int)k);
-  const uint32_t v0 = j * kPartPiece, T = min((uint32_t)kPartPiece, __shfl(ctot, (int)k) - v0);
-  const uint32_t bucket_start = __shfl(cstart, (int)k);
-  const uint32_t* col = colpfx + (size_t)k * (nblk + 1);
-  // this piece's fine buckets: their totals (requested now, needed after the ranking)
-  const int fb_lane = (int)k * kPartFine + (lane & (kPartFine - 1));
-  const uint32_t ftot_lane = fb_lane < nb ? totals[fb_lane] : 0u;
-  // the block of the coarse pass whose run holds record v0 of the bucket — the last b with col[b] <= v0 — by
-  // 256 probes at a time (two trips to memory for up to 65 536 blocks; a bisection was twelve)
-  uint32_t lo = 0, hi = nblk + 1;  // col[lo] <= v0, the answer is in [lo, hi)
-  while (hi - lo > 1) {
-    const uint32_t stride = (hi - lo + 255u) / 256u, idx = lo + threadIdx.x * stride;
-    const int c = __syncthreads_count(idx < hi && col[idx] <= v0);  // (col is non-decreasing: a prefix of the probes)
-    lo += (uint32_t)(c - 1) * stride;
-    hi = min(lo + stride, hi);
-  }
-  // ---- copy in.  The piece is made of the runs of bucket k in the blocks b0, b0 + 1, ... of the coarse pass; their
-  // descriptors go to LDS first (one thread per run: the run's first record in `mid`, its place in the piece), then
-  // every thread fetches its 8 records of the piece — all requests in flight together — finding each one's run
-  // by bisection in the table.  (A wave per run, descriptor after descriptor, was three dependent trips to
-  // memory per run.)
-  __shared__ uint32_t run_v[256], run_src[256], run_base[256];  // a run's first record: position in the piece | record index in `mid` (bit 31: a 12-byte block) | its block's base second
-  __shared__ uint32_t s_nr[4], s_cov;
-  for (uint32_t rb = lo, done = 0; done < T;) {  // (lo: the same in every thread)
-    __syncthreads();  // (the previous table's readers)
-    {
-      const uint32_t b = rb + threadIdx.x;
-      uint32_t vs = 0xffffffffu, r0 = 0, len = 0;
-      if (b < nblk) {
-        vs = col[b];
-        r0 = rowpfx[(size_t)k * nblk + b];
-        len = rowpfx[(size_t)(k + 1) * nblk + b] - r0;
-      }
-      const bool in = b < nblk && vs < v0 + T;
-      // the part of the run that lies inside the piece starts at piece position max(vs, v0) - v0
-      const uint32_t from = (in && vs < v0) ? v0 - vs : 0u;
-      run_v[threadIdx.x] = in ? vs + from - v0 : 0xffffffffu;
-      uint32_t wide_b = 0, base_b = 0;
-      if (in) {
-        base_b = rowpfx[(size_t)(kPartMaxCoarse + 1) * nblk + b];
-        wide_b = rowpfx[(size_t)(kPartMaxCoarse + 2) * nblk + b];
-      }
-      run_src[threadIdx.x] = (b * (uint32_t)kPartTE + r0 + from) | (wide_b ? 1u << 31 : 0u);
-      run_base[threadIdx.x] = base_b;
-      const unsigned long long inm = __ballot(in);
-      if (lane == 0) s_nr[wave] = (uint32_t)__popcll(inm);
-      if (in && (b + 1 == nblk || col[b + 1] >= v0 + T)) s_cov = min(T, vs + len - v0);  // the last run of the table: where it ends
-      else if (threadIdx.x == 255 && in) s_cov = min(T, vs + len - v0);
-    }
-    __syncthreads();
-    const uint32_t nrun = s_nr[0] + s_nr[1] + s_nr[2] + s_nr[3], cov = s_cov;
-    // records [done, cov) of the piece
-    uint32_t a[kPieceRounds], b2[kPieceRounds], c2[kPieceRounds], rbase[kPieceRounds];
-    bool w12[kPieceRounds];
-#pragma unroll
-    for (int r = 0; r < kPieceRounds; r++) {
-      const uint32_t i = done + r * 256 + threadIdx.x;
-      a[r] = b2[r] = c2[r] = rbase[r] = 0;
-      w12[r] = false;
-      if (i < cov) {
-        uint32_t lo2 = 0, hi2 = nrun;  // run_v[lo2] <= i < run_v[hi2]
-        while (hi2 - lo2 > 1) {
-          const uint32_t m = (lo2 + hi2) >> 1;
-          if (run_v[m] <= i) lo2 = m;
-          else hi2 = m;
-        }
-        const uint32_t rs = run_src[lo2], rec = (rs & 0x7fffffffu) + (i - run_v[lo2]);
-        w12[r] = (rs >> 31) != 0;
-        rbase[r] = run_base[lo2];
-        if (w12[r]) {
-          const uint32_t* src = mid12 + (size_t)rec * 3;
-          a[r] = src[0];
-          b2[r] = src[1];
-          c2[r] = src[2];
-        } else {
-          const uint2 v = ((const uint2*)mid8)[rec];
-          a[r] = v.x;
-          b2[r] = v.y;
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < kPieceRounds; r++) {
-      const uint32_t i = done + r * 256 + threadIdx.x;
-      if (i < cov) {
-        const uint32_t sec = w12[r] ? a[r] : rbase[r] + (a[r] >> 17), m3 = w12[r] ? c2[r] : (a[r] & 0x1ffffu);
-        sin_[i * 3] = compact ? (m3 & 0xfffu) | ((sec - sec_base) << 12) : sec;
-        sin_[i * 3 + 1] = b2[r];
-        sin_[i * 3 + 2] = m3;
-      }
-    }
-    done = cov;
-    rb += 256;
-  }
-  __syncthreads();
-  // ---- rank among the 32 fine buckets: wave w takes records [w * 512, (w + 1) * 512) in rounds of 64
-  uint32_t rec_a[kPieceRounds], rec_b[kPieceRounds], r_dst[kPieceRounds];
-  const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int r = 0; r < kPieceRounds; r++) {
-    const uint32_t i = wave * (kPartPiece / 4) + r * 64 + lane;
-    const bool ok = i < T;
-    const uint32_t m3 = sin_[i * 3 + 2];
-    const uint32_t f = (m3 >> 12) & (uint32_t)(kPartFine - 1);
-    rec_a[r] = sin_[i * 3];
-    rec_b[r] = sin_[i * 3 + 1];
-    const unsigned long long m = match_any_bits<kPartFineBits>(f, ok);
-    const uint32_t before = __popcll(m & lt);
-    uint32_t base = 0;
-    if (ok) base = wcnt[wave][f];
-    if (ok && before == 0) wcnt[wave][f] = base + (uint32_t)__popcll(m);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-    r_dst[r] = (m3 << 12) | (base + before);  // (pixel | polarity | fine bucket: 17 bits) << 12 | rank inside (wave, bucket)
-  }
-  __syncthreads();
-  // ---- where the fine buckets' runs go: lane = fine bucket
-  if (wave == 0) {
-    uint32_t excl = 0, cnt = 0, lstart = 0;
-    if (lane < kPartFine) {
-      const uint32_t c0 = wcnt[0][lane], c1 = wcnt[1][lane], c2 = wcnt[2][lane];
-      cnt = c0 + c1 + c2 + wcnt[3][lane];
-      wbase[0][lane] = 0;
-      wbase[1][lane] = c0;
-      wbase[2][lane] = c0 + c1;
-      wbase[3][lane] = c0 + c1 + c2;
-    }
-    lstart = wave_excl_scan(cnt, lane);  // the run's start inside sout
-    // the bucket's earlier fine buckets, all of them
-    const uint32_t fstart = bucket_start + wave_excl_scan(lane < kPartFine ? ftot_lane : 0u, lane);
-    if (lane < kPartFine) {
-      // ... and this fine bucket's records in the coarse bucket's earlier pieces: decoupled look-back
-      uint32_t* my = lookback + (size_t)t * kPartFine + lane;
-      if (j == 0) {
-        __hip_atomic_store(my, kLbPrefix | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        __hip_atomic_store(my, kLbAgg | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (a window of 16 predecessors per trip to memory: the pieces of a bucket all run at the same time, so a piece
-        // far down the bucket finds aggregates only, one after the other — one load per trip was 100 dependent trips
-        // for the 100th piece of a bucket)
-        constexpr int LBW = 16;
-        uint32_t back = 1, spins = 0;
-        bool found = false;
-        while (!found && back <= j) {
-          uint32_t w[LBW];
-#pragma unroll
-          for (int q = 0; q < LBW; q++)
-            w[q] = back + (uint32_t)q <= j ? __hip_atomic_load(lookback + (size_t)(t - back - (uint32_t)q) * kPartFine + lane,
-                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : 0u;
-          uint32_t used = 0;
-#pragma unroll
-          for (int q = 0; q < LBW; q++) {
-            if (found || back + (uint32_t)q > j || used != (uint32_t)q) continue;
-            const uint32_t st = w[q] & ~kLbMask;
-            if (st == 0) continue;  // (not published yet: the window is taken up again from here)
-            excl += w[q] & kLbMask;
-            used++;
-            if (st == kLbPrefix) found = true;
-          }
-          back += used;
-          if (!found && used < LBW && back <= j) {
-            if (++spins > spin_limit) {  // bounded (kSpinLookback polls): never hang the GPU
-              *err = 1;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        __hip_atomic_store(my, kLbPrefix | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      f_cnt[lane] = cnt;
-      f_src[lane] = lstart;
-      f_dst[lane] = fstart + excl;
-    }
-  }
-  __syncthreads();
-  if (compact) {
-#pragma unroll
-    for (int r = 0; r < kPieceRounds; r++) {
-      const uint32_t i = wave * (kPartPiece / 4) + r * 64 + lane;
-      if (i < T) {
-        const uint32_t f = (r_dst[r] >> 24) & (uint32_t)(kPartFine - 1);
-        sout[f_src[f] + wbase[wave][f] + (r_dst[r] & 0xfffu)] = make_uint2(rec_a[r], rec_b[r]);
-      }
-    }
-    __syncthreads();
-    uint2* __restrict__ part2 = (uint2*)part;
-    for (int f = wave; f < kPartFine; f += 4) {  // every fine bucket's run: one contiguous copy
-      const uint32_t c = f_cnt[f], s0 = f_src[f], d0 = f_dst[f];
-      for (uint32_t q = lane; q < c; q += 64) part2[d0 + q] = sout[s0 + q];
-    }
-  } else {
-    // 16-byte records (a batch whose stamps do not fit the 8-byte form): the raw event rebuilt from the bucket and
-    // the tile-local pixel, stored record by record (the rare form: no staging)
-#pragma unroll
-    for (int r = 0; r < kPieceRounds; r++) {
-      const uint32_t i = wave * (kPartPiece / 4) + r * 64 + lane;
-      if (i < T) {
-        const uint32_t m3 = r_dst[r] >> 12, f = (m3 >> 12) & (uint32_t)(kPartFine - 1);
-        const uint32_t fb = k * kPartFine + f, cam = fb >= (uint32_t)g.nt_cam ? 1u : 0u, tt = fb - cam * (uint32_t)g.nt_cam;
-        const uint32_t ty = tt / (uint32_t)g.tiles_x, tx = tt - ty * (uint32_t)g.tiles_x;
-        const int twsh = g.tw == 64 ? 6 : 5;
-        const uint32_t pix = m3 & 0x7ffu;
-        const uint32_t x = tx * (uint32_t)g.tw + (pix & (uint32_t)(g.tw - 1)), y = ty * (uint32_t)g.th + (pix >> twsh);
-        part[f_dst[f] + wbase[wave][f] + (r_dst[r] & 0xfffu)] = make_uint4(x | (y << 16), rec_a[r], rec_b[r], (m3 >> 11) & 1u);
-      }
-    }
-  }
-}
-
-void launch_part_coarse(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
-                        const TileGeom& g, const PartScratch& ps, const McParams* mc, uint32_t* warp_xy) {
-  const uint32_t n = nL + nR;
-  if (!n) return;
-  const uint32_t nblk = part_blocks(n), grid = std::min<uint32_t>(nblk, kPartGridA);
-  const uint32_t lb_words = part_pieces_max(n) * 32u;
-  if (mc && mc->enabled) {
-    launch_k(k_mc_warp, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g.W, g.H,
-             *mc, warp_xy);
-    launch_k(k_part_coarse<true>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, nblk,
-             ps.mid8, ps.mid12, ps.rowpfx, ps.fine_rows, (uint4*)ps.ranges, (const uint32_t*)warp_xy, ps.lookback, lb_words, ps.ticket);
-  } else {
-    launch_k(k_part_coarse<false>, dim3(grid), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g, nblk,
-             ps.mid8, ps.mid12, ps.rowpfx, ps.fine_rows, (uint4*)ps.ranges, (const uint32_t*)nullptr, ps.lookback, lb_words, ps.ticket);
-  }
-}
-
-void launch_part_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc, const PartScratch& ps,
-                      unsigned long long* n_rejected) {
-  if (!n) return;
-  const uint32_t nblk = part_blocks(n), nrows = std::min<uint32_t>(nblk, kPartGridA);
-  static const int force_wide = getenv("ESVIO_FE_WIDE_RECORDS") ? 1 : 0;  // (A/B and tests)
-  launch_k(k_part_scan, dim3(1 + kPartMaxCoarse + (g.nbins + 63) / 64), dim3(kPartScanThreads), 0, s,
-           (const uint32_t*)ps.rowpfx, nblk, (const uint32_t*)ps.fine_rows, nrows, g.nbins, (const uint4*)ps.ranges,
-           ps.colpfx, sc.totals, sc.meta, n_rejected, force_wide);
-}
-
-void launch_part_fine(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc, const PartScratch& ps,
-                      EventRec* part, int* err, uint32_t spin_limit) {
-  if (!n) return;
-  const uint32_t nblk = part_blocks(n);
-  launch_k(k_part_fine, dim3(part_pieces_max(n)), dim3(256), 0, s, (const uint32_t*)ps.mid8, (const uint32_t*)ps.mid12, (const uint32_t*)ps.rowpfx,
-           (const uint32_t*)ps.colpfx, nblk, g, (const uint32_t*)sc.totals, (const uint32_t*)sc.meta, ps.lookback, ps.ticket,
-           (uint4*)part, sc.tile_off, sc.tile_order, err, spin_limit);
-}
-
 // One block per bucket.  The tile's {L[0],L[1]} sit in LDS; the bucket's events are taken in turns
 // of kTileTurn chunks of 64, one wave per turn, waves taking the turns round-robin.  What an event
 // needs is the time of the nearest earlier event of its own and of the other polarity at its pixel
@@ -2148,17 +1406,19 @@ __global__ __launch_bounds__(256) void k_time_surface4(const double2* __restrict
   *(uint32_t*)(dst + (size_t)(y + kPad) * stride + x + kPad) = out;  // (kPad and the stride are multiples of 4)
 }
 
-void launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
-                         double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
-                         int dst_stride, int ncam) {
+KernelId launch_time_surface(hipStream_t s, const double2* S2, int W, int H, double t_sync,
+                             double decay_sec, int ignore_polarity, uint8_t* dst0, uint8_t* dst1,
+                             int dst_stride, int ncam) {
   const uint32_t P = (uint32_t)W * H;
   static_assert(kPad % 4 == 0, "dword stores into the padded level");
-  if (W % 4 == 0 && dst_stride % 4 == 0 && ((uintptr_t)dst0 & 3) == 0 && (ncam < 2 || ((uintptr_t)dst1 & 3) == 0))
+  if (W % 4 == 0 && dst_stride % 4 == 0 && ((uintptr_t)dst0 & 3) == 0 && (ncam < 2 || ((uintptr_t)dst1 & 3) == 0)) {
     launch_k(k_time_surface4, dim3((P / 4 + 255) / 256, ncam), dim3(256), 0, s, S2, W, H, t_sync, decay_sec,
              ignore_polarity, dst0, dst1, dst_stride);
-  else
-    launch_k(k_time_surface, dim3((P + 255) / 256, ncam), dim3(256), 0, s, S2, W, H,
-                     t_sync, decay_sec, ignore_polarity, dst0, dst1, dst_stride);
+    return K_TIME_SURFACE4;
+  }
+  launch_k(k_time_surface, dim3((P + 255) / 256, ncam), dim3(256), 0, s, S2, W, H,
+                   t_sync, decay_sec, ignore_polarity, dst0, dst1, dst_stride);
+  return K_TIME_SURFACE;
 }
 
 // ============================================================================ CLAHE + normalize
@@ -2423,11 +1683,12 @@ struct EqSrc {
   const int* minmax;
 };
 
-// MODE 0: level 0 rendered from the SAE here; 1 (FROM_IMG): normalised from an image; 2: level 0 is in the
-// pyramid already (k_time_surface4 wrote it) — only the three pyrDown levels
+// MODE 1 (FROM_IMG): level 0 normalised from an image; 2: level 0 is in the pyramid already (k_time_surface4
+// wrote it) — only the three pyrDown levels.  (MODE 0, the surface rendered here from the SAE planes — one launch,
+// but every tile re-rendered its halo: 2.2x the planes' bytes and exps — lost to the split form at 1280x720 and
+// tied with it at 640x480 in rounds 4 and 5 and is gone.)
 template <int MODE>
-__device__ __forceinline__ void ts_pyr_body(const double2* __restrict__ S2, double t_sync, double decay_sec,
-                                            int ignore_polarity, const EqSrc& eq, const PyrPack& pk) {
+__device__ __forceinline__ void pyr3_body(const EqSrc& eq, const PyrPack& pk) {
   __shared__ uint8_t l0[kFt0y * kFs0];
   __shared__ uint8_t l1[kFt1y * kFs1];
   __shared__ uint8_t l2[kFt2y * kFs2];
@@ -2465,31 +1726,6 @@ __device__ __forceinline__ void ts_pyr_body(const double2* __restrict__ S2, doub
         p.img[0][(size_t)(y + kPad) * p.stride[0] + x + kPad] = v;
     }
   }
-  const double2* S = S2 + (size_t)cam * W * H;
-  // (four pixels per thread and step, loads first: the 16 B gathers are what the loop waits for)
-  for (int i0 = threadIdx.x; MODE == 0 && i0 < kN0; i0 += 4 * kFtThreads) {
-    double2 sv[4];
-    int xs[4], ys[4];
-    bool ok[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int i = i0 + kFtThreads * k;
-      const int ry = i / kFt0x, rx = i - ry * kFt0x;
-      xs[k] = o0x + rx;
-      ys[k] = o0y + ry;
-      ok[k] = i < kN0 && xs[k] >= 0 && ys[k] >= 0 && xs[k] < W && ys[k] < H;
-      sv[k] = S[ok[k] ? (size_t)ys[k] * W + xs[k] : 0];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (!ok[k]) continue;
-      const int x = xs[k], y = ys[k];
-      const uint8_t v = ts_pixel(sv[k], t_sync, decay_sec, ignore_polarity);
-      l0[(y - o0y) * kFs0 + (x - o0x)] = v;
-      if (x >= 8 * o3x && x < 8 * o3x + 8 * kFt3x && y >= 8 * o3y && y < 8 * o3y + 8 * kFt3y)
-        p.img[0][(size_t)(y + kPad) * p.stride[0] + x + kPad] = v;
-    }
-  }
   __syncthreads();
   fused_down<kFt0x, kFs0, kFt1x, kFt1y, kFs1>(l0, l1, o0x, o0y, W, H, o1x, o1y, p.w[1], p.h[1], p.img[1],
                                                p.stride[1], 4 * o3x, 4 * o3y, 4 * kFt3x, 4 * kFt3y);
@@ -2502,39 +1738,19 @@ __device__ __forceinline__ void ts_pyr_body(const double2* __restrict__ S2, doub
                                                 p.h[3], p.img[3], p.stride[3], o3x, o3y, kFt3x, kFt3y);
 }
 
-__global__ __launch_bounds__(kFtThreads) void k_ts_pyr(const double2* __restrict__ S2, double t_sync,
-                                                double decay_sec, int ignore_polarity, PyrPack pk) {
-  ts_pyr_body<0>(S2, t_sync, decay_sec, ignore_polarity, EqSrc{}, pk);
-}
 __global__ __launch_bounds__(kFtThreads) void k_norm_pyr(EqSrc eq, PyrPack pk) {
-  ts_pyr_body<1>(nullptr, 0.0, 0.0, 0, eq, pk);
+  pyr3_body<1>(eq, pk);
 }
 // the three pyrDown levels of images whose level 0 is in place (the split render: k_time_surface4, then this —
 // every S2 word is read once and every level-0 pixel rendered once; the tiles' halos re-read bytes, not planes)
 __global__ __launch_bounds__(kFtThreads) void k_pyr3(PyrPack pk) {
-  ts_pyr_body<2>(nullptr, 0.0, 0.0, 0, EqSrc{}, pk);
-}
-
-// both cameras (p[0], p[1]), maxLevel 3
-void launch_ts_pyr(hipStream_t s, const double2* S2, double t_sync, double decay_sec,
-                   int ignore_polarity, const PyrDesc* p) {
-  const int w3 = p[0].w[3], h3 = p[0].h[3];
-  launch_k(k_ts_pyr, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, 2), dim3(kFtThreads), 0, s, S2,
-           t_sync, decay_sec, ignore_polarity, make_pack(p, 2));
+  pyr3_body<2>(EqSrc{}, pk);
 }
 
 void launch_pyr3(hipStream_t s, const PyrDesc* p, int nimg) {
   const int w3 = p[0].w[3], h3 = p[0].h[3];
   launch_k(k_pyr3, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, nimg), dim3(kFtThreads), 0, s,
            make_pack(p, nimg));
-}
-
-// one camera: S2 points at that camera's planes, p at its pyramid
-void launch_ts_pyr_cam(hipStream_t s, const double2* S2_cam, double t_sync, double decay_sec, int ignore_polarity,
-                       const PyrDesc* p) {
-  const int w3 = p[0].w[3], h3 = p[0].h[3];
-  launch_k(k_ts_pyr, dim3((w3 + kFt3x - 1) / kFt3x, (h3 + kFt3y - 1) / kFt3y, 1), dim3(kFtThreads), 0, s, S2_cam,
-           t_sync, decay_sec, ignore_polarity, make_pack(p, 1));
 }
 
 // the `equalize: 1` branch: normalize + the three pyrDown levels of both cameras (see EqSrc)
@@ -3735,52 +2951,8 @@ __constant__ int8_t c_large[20][2] = {{0, 4},   {1, 4},   {2, 3},   {3, 2},  {4,
                                       {3, -2},  {2, -3},  {1, -4},  {0, -4}, {-1, -4}, {-2, -3}, {-3, -2},
                                       {-4, -1}, {-4, 0},  {-4, 1},  {-3, 2}, {-2, 3},  {-1, 4}};
 
-// one ring of isCorner (event_detector.cc:337-435 small / :438-541 large). `ring` is this
-// thread's private column of an LDS tile laid out [ring index][thread] (bank-conflict free).
-template <int N, int KMIN, int KMAX>
-__device__ __forceinline__ bool arc_ring(const double* ring, int tstride) {
-  double segment_new_min_t = ring[0];
-  int arc_right_idx = 0;
-#pragma unroll
-  for (int i = 1; i < N; i++) {
-    const double t = ring[i * tstride];
-    if (t > segment_new_min_t) {
-      segment_new_min_t = t;
-      arc_right_idx = i;
-    }
-  }
-  int arc_left_idx = (arc_right_idx - 1 + N) % N;
-  arc_right_idx = (arc_right_idx + 1) % N;
-  double arc_left_value = ring[arc_left_idx * tstride];
-  double arc_right_value = ring[arc_right_idx * tstride];
-  double arc_left_min_t = arc_left_value;
-  double arc_right_min_t = arc_right_value;
-  int newest_segment_size = KMIN;
-  for (int iteration = 1; iteration < N; iteration++) {
-    const bool right = arc_right_value > arc_left_value;
-    const double v = right ? arc_right_value : arc_left_value;
-    const double mn = right ? arc_right_min_t : arc_left_min_t;
-    if (iteration < KMIN) {
-      if (mn < segment_new_min_t) segment_new_min_t = mn;
-    } else if (v >= segment_new_min_t) {
-      newest_segment_size = iteration + 1;
-      if (mn < segment_new_min_t) segment_new_min_t = mn;
-    }
-    if (right) {
-      arc_right_idx = (arc_right_idx + 1) % N;
-      arc_right_value = ring[arc_right_idx * tstride];
-      if (arc_right_value < arc_right_min_t) arc_right_min_t = arc_right_value;
-    } else {
-      arc_left_idx = (arc_left_idx - 1 + N) % N;
-      arc_left_value = ring[arc_left_idx * tstride];
-      if (arc_left_value < arc_left_min_t) arc_left_min_t = arc_left_value;
-    }
-  }
-  return (newest_segment_size <= KMAX) ||
-         ((newest_segment_size >= (N - KMAX)) && (newest_segment_size <= (N - KMIN)));
-}
-
-// The same ring test on RANKS.  isCorner only ever compares ring values with each other (>, >=, <
+// One ring of isCorner (event_detector.cc:337-435 small / :438-541 large), on RANKS:
+// isCorner only ever compares ring values with each other (>, >=, <
 // and minima of them), so replacing every value by the number of ring values strictly below it
 // (equal values get equal ranks) leaves every decision unchanged — and the ranks (4 or 5 bits) of a
 // whole ring fit one or two 64-bit registers, which a lane can index with a variable shift: no LDS
@@ -4880,13 +4052,17 @@ __global__ __launch_bounds__(kSelMwThreads) void k_select_mw(SelectArgs a) {
   }
 }
 
-void launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
-  if (a.gbitmap)
+KernelId launch_select(hipStream_t s, const SelectArgs& a, size_t lds_bytes) {
+  if (a.gbitmap) {
     launch_k(k_select_gbm, dim3(1), dim3(64), lds_bytes, s, a);
-  else if (!a.one_wave && lds_bytes + select_mw_extra_lds_bytes() <= 160 * 1024)
+    return K_SELECT_GBM;
+  }
+  if (!a.one_wave && lds_bytes + select_mw_extra_lds_bytes() <= 160 * 1024) {
     launch_k(k_select_mw, dim3(1), dim3(kSelMwThreads), lds_bytes + select_mw_extra_lds_bytes(), s, a);
-  else
-    launch_k(k_select, dim3(1), dim3(64), lds_bytes, s, a);
+    return K_SELECT_MW;
+  }
+  launch_k(k_select, dim3(1), dim3(64), lds_bytes, s, a);
+  return K_SELECT;
 }
 
 }  // namespace esvio

@@ -213,13 +213,6 @@ int ensure_part_capacity(esvio_fe_ctx* c, size_t n, bool mc) {
     if (int rc = dev_alloc(c, &c->d_tile, need)) return rc;
     c->tile_cap = need;
   }
-  if (c->part_two_level && c->part2_cap < c->part_cap) {
-    if (c->d_part2) (void)hipFree(c->d_part2);
-    c->d_part2 = nullptr;
-    c->part2_cap = 0;
-    if (int rc = dev_alloc(c, &c->d_part2, part_scratch_words(c->part_cap))) return rc;
-    c->part2_cap = c->part_cap;
-  }
   return 0;
 }
 
@@ -238,23 +231,9 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
   sc.P = c->d_tile + head;
   sc.T = sc.P + nblk_cap * kTileMaxBins;
   sc.C = sc.T + (size_t)kTileMaxGroups * kTileMaxBins;
-  if (c->part_two_level) {
-    const PartScratch ps = part_scratch(c->d_part2, c->part2_cap);
+  {
     {
-      ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
-      launch_part_coarse(cur_stream(c), evL, nL, evR, nR, c->tgeom, ps, mc, mc ? c->d_warp : nullptr);
-    }
-    {
-      ScopedKernel k(c, K_TILE_SCAN, 0);  // (run lengths and bucket totals: not in SURVEY's accounting)
-      launch_part_scan(cur_stream(c), n, c->tgeom, sc, ps, c->d_rejected);
-    }
-    {
-      ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 12 B out, 12 B in, 8 B out
-      launch_part_fine(cur_stream(c), n, c->tgeom, sc, ps, c->d_part, c->z_counts + 3, c->lim.lookback);
-    }
-  } else {
-    {
-      ScopedKernel k(c, K_SAE_KEYS, (uint64_t)n * 16);  // ingest: the raw records, read once
+      ScopedKernel k(c, K_TILE_HIST, (uint64_t)n * 16);  // ingest: the raw records, read once
       launch_tile_hist(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_rejected, mc, mc ? c->d_warp : nullptr);
     }
     {
@@ -262,12 +241,12 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
       launch_tile_scan(cur_stream(c), n, c->tgeom, sc, c->d_rejected);
     }
     {
-      ScopedKernel k(c, K_RADIX_PASS, (uint64_t)n * 32);  // the partition's own traffic: 16 B in, 16 B out
+      ScopedKernel k(c, K_TILE_SCATTER, (uint64_t)n * 24);  // the partition's own traffic: 16 B in, 8 B out (16 for wide records)
       launch_tile_scatter(cur_stream(c), evL, nL, evR, nR, c->tgeom, sc, c->d_part, mc ? c->d_warp : nullptr);
     }
   }
   {
-    ScopedKernel k(c, K_SAE_APPLY, (uint64_t)n * 32);
+    ScopedKernel k(c, K_TILE_APPLY, (uint64_t)n * 32);
     launch_tile_apply(cur_stream(c), c->d_part, n, c->tgeom, sc, L2, S2, c->cfg.feature_filter_threshold,
                       arc_touched, c->z_counts + 3, c->lim.ticket);
   }
@@ -358,13 +337,13 @@ void render_ts(esvio_fe_ctx* c, double t_sync, uint8_t* dst0, uint8_t* dst1, int
   uint8_t* r0 = mk > 0 ? c->med_tmp[0].d.img[0] : dst0;
   uint8_t* r1 = mk > 0 ? c->med_tmp[ncam == 2 ? 1 : 0].d.img[0] : dst1;
   {
-    ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * ncam);
-    launch_time_surface(cur_stream(c), S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
-                        c->cfg.ignore_polarity, r0, r1, stride, ncam);
+    ScopedKernel k(c, K_TIME_SURFACE4, (uint64_t)c->P * 17 * ncam);
+    k.id = launch_time_surface(cur_stream(c), S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
+                               c->cfg.ignore_polarity, r0, r1, stride, ncam);
   }
   if (mk > 0) {  // cv::medianBlur(2k+1) of the rendered surface (event_detector.cc:262-264)
     const size_t o = (size_t)kPad * stride + kPad;
-    ScopedKernel k(c, K_TIME_SURFACE, 0);
+    ScopedKernel k(c, K_MEDIAN, 0);
     launch_median(cur_stream(c), r0 + o, r1 + o, stride, dst0 + o, dst1 + o, stride, c->W, c->H, mk, ncam);
   }
 }
@@ -424,13 +403,13 @@ void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int 
     {
       uint64_t px = 0;
       for (int l = 0; l <= 3; l++) px += (uint64_t)two[0].w[l] * two[0].h[l];
-      ScopedKernel k(c, K_PYR_DOWN, ((uint64_t)c->P + px) * 2);
+      ScopedKernel k(c, K_NORM_PYR, ((uint64_t)c->P + px) * 2);
       launch_norm_pyr(cur_stream(c), c->d_eq_tmp, c->d_eq_tmp + c->P, c->W, c->d_minmax, two);
     }
     {
       uint64_t all = 0;
       for (int l = 0; l <= 3; l++) all += (uint64_t)two[0].w[l] * two[0].h[l];
-      ScopedKernel k(c, K_SCHARR, all * 5 * 2);
+      ScopedKernel k(c, K_PAD_SCHARR, all * 5 * 2);
       launch_pad_scharr(cur_stream(c), two, 2);
     }
     return;
@@ -440,26 +419,21 @@ void render_and_build(esvio_fe_ctx* c, double t_sync, int slotL, int slotR, int 
     pyr_build(c, two, 2);
     return;
   }
-  if (c->split_render) {
-    {
-      ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17 * 2);
-      launch_time_surface(cur_stream(c), c->S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0, c->cfg.ignore_polarity,
-                          two[0].img[0], two[1].img[0], two[0].stride[0], 2);
-    }
+  {
+    ScopedKernel k(c, K_TIME_SURFACE4, (uint64_t)c->P * 17 * 2);
+    k.id = launch_time_surface(cur_stream(c), c->S2, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0, c->cfg.ignore_polarity,
+                               two[0].img[0], two[1].img[0], two[0].stride[0], 2);
+  }
+  {
     uint64_t px = 0;
     for (int l = 0; l <= 3; l++) px += (uint64_t)two[0].w[l] * two[0].h[l];
-    ScopedKernel k(c, K_PYR_DOWN, px * 2);
+    ScopedKernel k(c, K_PYR3, px * 2);
     launch_pyr3(cur_stream(c), two, 2);
-  } else {
-    uint64_t px = 0;
-    for (int l = 0; l <= 3; l++) px += (uint64_t)two[0].w[l] * two[0].h[l];
-    ScopedKernel k(c, K_TIME_SURFACE, ((uint64_t)c->P * 16 + px) * 2);
-    launch_ts_pyr(cur_stream(c), c->S2, t_sync, c->cfg.decay_ms / 1000.0, c->cfg.ignore_polarity, two);
   }
   {
     uint64_t all = 0;
     for (int l = 0; l <= 3; l++) all += (uint64_t)two[0].w[l] * two[0].h[l];
-    ScopedKernel k(c, K_SCHARR, all * 5 * 2);
+    ScopedKernel k(c, K_PAD_SCHARR, all * 5 * 2);
     launch_pad_scharr(cur_stream(c), two, 2);
   }
 }
@@ -472,21 +446,17 @@ void render_and_build_cam(esvio_fe_ctx* c, double t_sync, int cam, int slot) {
   const PyrDesc one = c->pyr[slot].d;
   uint64_t px = 0;
   for (int l = 0; l <= 3; l++) px += (uint64_t)one.w[l] * one.h[l];
-  if (c->split_render) {
-    {
-      ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 17);
-      launch_time_surface(cur_stream(c), c->S2 + (size_t)cam * c->P, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
-                          c->cfg.ignore_polarity, one.img[0], one.img[0], one.stride[0], 1);
-    }
-    ScopedKernel k(c, K_PYR_DOWN, px);
-    launch_pyr3(cur_stream(c), &one, 1);
-  } else {
-    ScopedKernel k(c, K_TIME_SURFACE, (uint64_t)c->P * 16 + px);
-    launch_ts_pyr_cam(cur_stream(c), c->S2 + (size_t)cam * c->P, t_sync, c->cfg.decay_ms / 1000.0,
-                      c->cfg.ignore_polarity, &one);
+  {
+    ScopedKernel k(c, K_TIME_SURFACE4, (uint64_t)c->P * 17);
+    k.id = launch_time_surface(cur_stream(c), c->S2 + (size_t)cam * c->P, c->W, c->H, t_sync, c->cfg.decay_ms / 1000.0,
+                               c->cfg.ignore_polarity, one.img[0], one.img[0], one.stride[0], 1);
   }
   {
-    ScopedKernel k(c, K_SCHARR, px * 5);
+    ScopedKernel k(c, K_PYR3, px);
+    launch_pyr3(cur_stream(c), &one, 1);
+  }
+  {
+    ScopedKernel k(c, K_PAD_SCHARR, px * 5);
     launch_pad_scharr(cur_stream(c), &one, 1);
   }
 }
@@ -522,7 +492,7 @@ void run_lk(esvio_fe_ctx* c, const LkArgs& f, const LkArgs* b, float2* back_pts,
             uint8_t* back_status) {
   uint64_t bytes = (uint64_t)f.n_max * (f.max_level + 1) * kLkWin * kLkWin * 5;
   if (b) bytes += (uint64_t)f.n_max * (b->max_level + 1) * kLkWin * kLkWin * 5;
-  ScopedKernel k(c, K_LK, bytes);
+  ScopedKernel k(c, c->cfg.lk_accum == 2 ? K_LK_F32 : K_LK, bytes);
   LkArgs fa = f;
   fa.accum = c->cfg.lk_accum;
   launch_lk(cur_stream(c), fa, b, back_pts, back_status);
@@ -850,8 +820,8 @@ void run_select(esvio_fe_ctx* c, int set, int max_corners, float2* out_pts, int 
     s.gbitmap = c->d_sel_bitmap;
     lds = select_tables_lds_bytes(c);
   }
-  ScopedKernel k(c, K_SELECT, 0);
-  launch_select(cur_stream(c), s, lds);
+  ScopedKernel k(c, K_SELECT_MW, 0);
+  k.id = launch_select(cur_stream(c), s, lds);
 }
 
 // Arc* flags (+ ordered per-block candidate lists into set `set`) for the left events; `ts` is the
@@ -899,11 +869,11 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
     launch_arc_map(cur_stream(c), a);
   }
   {
-    ScopedKernel k(c, K_ARC, (uint64_t)n * 16);
+    ScopedKernel k(c, K_ARC_EV, (uint64_t)n * 16);
     launch_arc(cur_stream(c), a);
   }
   if (dedup) {
-    ScopedKernel k(c, K_COMPACT, 0);
+    ScopedKernel k(c, K_DEDUP, 0);
     launch_dedup(cur_stream(c), a.cand_xy, a.cand_idx, a.cand_cnt, (n + kArcBlock - 1) / kArcBlock,
                  a.first_map, a.first_key, c->W);
   }

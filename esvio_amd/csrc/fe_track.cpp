@@ -47,13 +47,6 @@ static int prefetch_issue(esvio_fe_ctx* c, const PrefetchJob& j) {
   } else if (int rc = stage_events(c, b.left, b.nL, b.right, b.nR, b.space, &dL, &dR, b.lane)) {
     return rc;
   }
-  // the ~11 dependent launches up to the pyramids go out as one graph (fe_kernels.h); with the
-  // per-kernel timers on they are launched one by one so that each can be bracketed
-  const bool as_graph = c->graphs_enabled && !c->prof_on;
-  if (as_graph) {
-    c->rec.clear();
-    set_launch_recorder(&c->rec);
-  }
   bool arc_marked = false;
   McParams mcp;
   if (b.has_motion) mcp = make_mc_params(&b.motion);
@@ -61,20 +54,10 @@ static int prefetch_issue(esvio_fe_ctx* c, const PrefetchJob& j) {
                       b.pub && b.nL ? b.cand : -1, &arc_marked);
   if (!rc) {
     render_and_build(c, b.time, b.slotL, b.slotR, b.raw);
-    if (record_event(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
+    if (hipEventRecord(c->ev_lane_done[b.lane], c->stream2) != hipSuccess)
       rc = fail(c, ESVIO_FE_EHIP, "hipEventRecord failed");
     // (a sequence issued by the launch thread: the word a chained LK launch made before this point waits for)
     if (!rc && b.gate) launch_set_u32(c->stream2, c->d_lane_gate + b.lane, b.gate);
-  }
-  if (as_graph) {
-    set_launch_recorder(nullptr);
-    if (!rc && launch_as_graph(c->pf_graph, c->rec, c->stream2) != hipSuccess) {
-      // (not expected; the plain path still works)
-      (void)hipGetLastError();
-      c->graphs_enabled = false;
-      destroy_launch_graph(c->pf_graph);
-      if (launch_plain(c->rec, c->stream2) != hipSuccess) rc = fail(c, ESVIO_FE_EHIP, "kernel launch failed");
-    }
   }
   if (rc) return rc;
   if (b.arc_done) {  // (decided with the bookkeeping: the PUB hint says the frame will publish)
@@ -262,8 +245,8 @@ static int launcher_submit(esvio_fe_ctx* c, const PrefetchJob& j) {
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first) {
   int rc = 0;
   const bool only_first = must_take_first;
-  // per-kernel timers, the graph recorder and the trace's counters are the calling thread's
-  const bool async_ok = c->launcher && !c->prof_on && !c->graphs_enabled && !c->trace && !must_take_first;
+  // per-kernel timers and the trace's counters are the calling thread's
+  const bool async_ok = c->launcher && !c->prof_on && !c->trace && !must_take_first;
   if (c->launcher && !async_ok)
     if ((rc = launcher_drain(c))) return rc;  // (this call's own HIP calls go behind the jobs handed over before)
   while (!rc && !c->announced.empty() && (int)c->inflight.size() < kPrefetchDepth) {

@@ -75,29 +75,28 @@ class Tracks(C.Structure):
 # the drop-in boundary: every entry point include/esvio_fe.h declares (INTEGRATION.md section 3 maps each to the
 # reference call it replaces)
 ABI_SYMBOLS = [
-    "esvio_fe_create", "esvio_fe_destroy", "esvio_fe_reset", "esvio_fe_last_error", "esvio_fe_version",
-    "esvio_fe_create_sae", "esvio_fe_create_sae_stereo", "esvio_fe_sae_to_time_surface", "esvio_fe_is_corner",
-    "esvio_fe_features_to_track", "esvio_fe_get_sae", "esvio_fe_set_sae", "esvio_fe_calc_optical_flow_pyr_lk",
-    "esvio_fe_build_pyramid", "esvio_fe_find_fundamental_mat", "esvio_fe_lift_projective",
-    "esvio_fe_track_event", "esvio_fe_track_event_mc", "esvio_fe_create_sae_stereo_mc",
-    "esvio_fe_set_next_batch", "esvio_fe_set_next_batch_mc", "esvio_fe_mem_alloc", "esvio_fe_mem_free",
-    "esvio_fe_mem_upload", "esvio_fe_register_host_buffer", "esvio_fe_unregister_host_buffer", "esvio_fe_good_features_to_track", "esvio_fe_track_image",
-    "esvio_fe_pack_track_records", "esvio_fe_set_lazy_new_stereo", "esvio_fe_finish",
-    "esvio_fe_set_host_threads", "esvio_fe_ransac_stats", "esvio_fe_get_time_surface",
-    "esvio_fe_export_image", "esvio_fe_import_image", "esvio_fe_set_profiling", "esvio_fe_kernel_count",
-    "esvio_fe_kernel_name", "esvio_fe_get_kernel_stats", "esvio_fe_reset_kernel_stats", "esvio_fe_stream",
-    "esvio_fe_sae_plane_doubles", "esvio_fe_sae_slice_last", "esvio_fe_sae_slice_apply",
-    "esvio_fe_sae_slice_commit", "esvio_fe_device_memory", "esvio_fe_exchange_tracks",
-    "esvio_fe_comm_unique_id", "esvio_fe_comm_init", "esvio_fe_exchange_begin", "esvio_fe_exchange_end",
-    "esvio_fe_set_auto_exchange", "esvio_fe_reserve", "esvio_fe_latency_stats", "esvio_fe_latency_phase_name", "esvio_fe_latency_recent",
-    "esvio_fe_set_launch_thread",
+    "esvio_fe_calc_optical_flow_pyr_lk", "esvio_fe_comm_init", "esvio_fe_comm_unique_id", "esvio_fe_create",
+    "esvio_fe_create_sae", "esvio_fe_create_sae_stereo", "esvio_fe_create_sae_stereo_mc", "esvio_fe_destroy",
+    "esvio_fe_exchange_begin", "esvio_fe_exchange_end", "esvio_fe_exchange_tracks", "esvio_fe_export_image",
+    "esvio_fe_features_to_track", "esvio_fe_find_fundamental_mat", "esvio_fe_finish", "esvio_fe_get_sae",
+    "esvio_fe_get_time_surface", "esvio_fe_good_features_to_track", "esvio_fe_import_image", "esvio_fe_is_corner",
+    "esvio_fe_last_error", "esvio_fe_mem_alloc", "esvio_fe_mem_free", "esvio_fe_mem_upload",
+    "esvio_fe_pack_track_records", "esvio_fe_register_host_buffer", "esvio_fe_reserve", "esvio_fe_reset",
+    "esvio_fe_sae_plane_doubles", "esvio_fe_sae_slice_apply", "esvio_fe_sae_slice_commit",
+    "esvio_fe_sae_slice_last", "esvio_fe_sae_to_time_surface", "esvio_fe_set_auto_exchange",
+    "esvio_fe_set_host_threads", "esvio_fe_set_launch_thread", "esvio_fe_set_lazy_new_stereo",
+    "esvio_fe_set_next_batch", "esvio_fe_set_next_batch_mc", "esvio_fe_track_event", "esvio_fe_track_event_mc",
+    "esvio_fe_track_image", "esvio_fe_unregister_host_buffer", "esvio_fe_version",
 ]
 # test / measurement taps: include/esvio_fe_test.h (not part of the boundary)
 TEST_SYMBOLS = [
-    "esvio_fe_find_fundamental_mat_mt", "esvio_fe_find_fundamental_mat_held",
-    "esvio_fe_find_fundamental_mat_idle", "esvio_fe_host_hypot", "esvio_fe_host_stage_copy",
-    "esvio_fe_host_nullspace", "esvio_fe_debug_inject", "esvio_fe_debug_counters",
-    "esvio_fe_plain_call_counters", "esvio_fe_ransac_tail",
+    "esvio_fe_build_pyramid", "esvio_fe_debug_counters", "esvio_fe_debug_inject", "esvio_fe_device_memory",
+    "esvio_fe_find_fundamental_mat_held", "esvio_fe_find_fundamental_mat_idle", "esvio_fe_find_fundamental_mat_mt",
+    "esvio_fe_get_kernel_stats", "esvio_fe_host_hypot", "esvio_fe_host_nullspace", "esvio_fe_host_stage_copy",
+    "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_latency_phase_name", "esvio_fe_latency_recent",
+    "esvio_fe_latency_stats", "esvio_fe_lift_projective", "esvio_fe_plain_call_counters", "esvio_fe_ransac_stats",
+    "esvio_fe_ransac_tail", "esvio_fe_reset_kernel_stats", "esvio_fe_set_profiling", "esvio_fe_set_sae",
+    "esvio_fe_stream",
 ]
 
 LATENCY_PHASES = 16

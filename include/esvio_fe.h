@@ -62,10 +62,11 @@ typedef struct esvio_fe_config {
   int32_t equalize;                 /* equalize: 1 = CLAHE(40, 8x8) + normalize(0,255) before LK */
   double f_threshold;               /* F_threshold [px] */
   int32_t f_ransac;                 /* 1: run rejectWithF_event's RANSAC on host; 0: skip */
-  int32_t lk_accum;                 /* how calcOpticalFlowPyrLK's sums are accumulated: 1 = exactly (int64;
-                                     * the default everywhere), 2 = in float in the order of OpenCV 4.2's
-                                     * x86 SIMD128 build, i.e. the reference's own build (restated from
-                                     * recall; 2.5x the LK time) */
+  int32_t lk_accum;                 /* how calcOpticalFlowPyrLK's sums are accumulated: 2 = in float in the
+                                     * order of OpenCV 4.2's x86 SIMD128 build, i.e. the reference's own build
+                                     * (restated from recall) — the default of every caller in this repository;
+                                     * 1 = exactly (int64 sums; 0.65-0.8x the LK time, not that build's
+                                     * arithmetic: within 1e-4 px of it on ~97 % of the points) */
   int32_t focal_length;             /* FOCAL_LENGTH, 460 (parameters.cpp:274) */
   int32_t device;                   /* HIP device ordinal, -1 = current device */
   esvio_fe_camera cam[2];           /* event_left_calib / event_right_calib */
@@ -137,10 +138,10 @@ int esvio_fe_is_corner(esvio_fe_handle h, const esvio_fe_event* ev, size_t n, in
 int esvio_fe_features_to_track(esvio_fe_handle h, const esvio_fe_event* ev, size_t n, int space,
                                int max_corners, const uint8_t* mask, float* out_xy,
                                int32_t* out_idx, int32_t* n_out);
-/* test taps: copy a camera's four planes (each width*height doubles, index x + y*width) */
+/* read-out of a camera's four planes (each width*height doubles, index x + y*width): what the reference's
+ * private sae_[2] / sae_latest_[2] (event_detector.h) hold; the write side (tests) is esvio_fe_set_sae in
+ * esvio_fe_test.h */
 int esvio_fe_get_sae(esvio_fe_handle h, int cam, double* L0, double* L1, double* S0, double* S1);
-int esvio_fe_set_sae(esvio_fe_handle h, int cam, const double* L0, const double* L1,
-                     const double* S0, const double* S1);
 
 /* ---- OpenCV stages used by trackEvent ------------------------------------------------- */
 #define ESVIO_FE_LK_USE_INITIAL_FLOW 4 /* cv::OPTFLOW_USE_INITIAL_FLOW */
@@ -151,22 +152,10 @@ int esvio_fe_calc_optical_flow_pyr_lk(esvio_fe_handle h, const uint8_t* prev_img
                                       const uint8_t* next_img, int w, int hgt,
                                       const float* prev_pts, float* next_pts, uint8_t* status,
                                       int n, int max_level, int max_count, double eps, int flags);
-/* test tap: the pyramid the LK stage builds for a host image: level `level` u8 image
- * (lw*lh bytes) and its Scharr derivatives (lw*lh*2 int16, interleaved Ix,Iy). Either output
- * may be NULL. Returns the number of levels built (maxLevel+1) in *n_levels. */
-int esvio_fe_build_pyramid(esvio_fe_handle h, const uint8_t* img, int w, int hgt, int max_level,
-                           int level, uint8_t* out_img, int16_t* out_deriv, int32_t* lw,
-                           int32_t* lh, int32_t* n_levels);
 /* cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, conf, status) as used by rejectWithF_event
  * (feature_tracker.cpp:935); host-side. Returns the inlier count in *n_inliers. */
 int esvio_fe_find_fundamental_mat(const float* p1, const float* p2, int n, double thr,
                                   double conf, uint8_t* status, int32_t* n_inliers);
-/* Measurement tap: process-wide counters of that function since the last reset — out6 = {calls,
- * loop iterations, points, nanoseconds inside the calls} of its RANSAC branch (>= 15 points) and
- * {calls, nanoseconds} of its LMedS branch (8..14 points, what OpenCV runs below 15). */
-int esvio_fe_ransac_stats(uint64_t* out6, int reset);
-/* camodocal PinholeCamera::liftProjective (PinholeCamera.cc:450-510); host-side. */
-int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, double* out3);
 
 /* ---- the fused per-frame call -------------------------------------------------------- */
 /* FeatureTracker::trackEvent(cur_time, event_left, event_right) (feature_tracker.cpp:340-603)
@@ -389,55 +378,6 @@ int esvio_fe_unregister_host_buffer(void* p);
  * (8 slots of 32 B per event, half of it pinned).  Not while batches are announced.  The reference has
  * no counterpart: its std::vectors grow inside the callbacks. */
 int esvio_fe_reserve(esvio_fe_handle h, size_t max_events_left, size_t max_events_right, int host_batches);
-
-/* ---- measurement --------------------------------------------------------------------- */
-/* Wall time of the esvio_fe_track_event(_mc) calls on this handle since the last reset, as the calling
- * thread sees them (always on: a dozen clock reads per call).  The percentiles cover the latest 4096
- * calls.  For the slowest call: its index since the reset, whether it published, where its time went
- * (esvio_fe_latency_phase_name(i) names max_phase_ms[i]; entries 8.. are parts of entry 5 on published
- * frames), the CPUs the calling thread was on when it began / ended, the involuntary context switches
- * the thread suffered inside it (getrusage(RUSAGE_THREAD)) and the device / pinned allocations it
- * made. */
-#define ESVIO_FE_LATENCY_PHASES 16
-typedef struct esvio_fe_latency {
-  uint64_t calls;
-  double mean_ms, p50_ms, p99_ms, max_ms;
-  uint64_t max_call;
-  int32_t max_published;
-  int32_t max_cpu_begin, max_cpu_end;
-  int64_t max_invol_switches;
-  int64_t max_allocs;
-  double max_phase_ms[ESVIO_FE_LATENCY_PHASES];
-  uint64_t allocs;          /* allocations inside track / announce calls since the reset */
-  uint64_t invol_switches;  /* involuntary context switches inside track calls since the reset */
-} esvio_fe_latency;
-int esvio_fe_latency_stats(esvio_fe_handle h, esvio_fe_latency* out, int reset);
-const char* esvio_fe_latency_phase_name(int i);
-/* One of the latest 256 track calls as the record above saw it (back = 0: the last call, 1: the one before ...):
- * when it began (ms since the first track call after the last reset), how long it took, whether it published, and its phases —
- * read AFTER a run, so that looking does not change the schedule that is looked at.  ESVIO_FE_EINVAL for a call
- * that is not kept (any more). */
-typedef struct esvio_fe_latency_call {
-  uint64_t call;      /* index of the call since the last reset of esvio_fe_latency_stats (as max_call there) */
-  int32_t published;
-  int32_t reserved;
-  double begin_ms, ms;
-  double phase_ms[ESVIO_FE_LATENCY_PHASES];
-} esvio_fe_latency_call;
-int esvio_fe_latency_recent(esvio_fe_handle h, int back, esvio_fe_latency_call* out);
-/* Per-kernel HIP-event timing on the handle's stream (off by default; when on, every launch is
- * bracketed by hipEventRecord and resolved lazily). */
-int esvio_fe_set_profiling(esvio_fe_handle h, int on);
-int esvio_fe_kernel_count(void);
-const char* esvio_fe_kernel_name(int kernel_id);
-/* total_ms / launches / algorithmic bytes accumulated since the last reset_kernel_stats */
-int esvio_fe_get_kernel_stats(esvio_fe_handle h, int kernel_id, double* total_ms,
-                              uint64_t* launches, uint64_t* alg_bytes);
-int esvio_fe_reset_kernel_stats(esvio_fe_handle h);
-/* the hipStream_t the handle launches on (as void*) */
-void* esvio_fe_stream(esvio_fe_handle h);
-/* hipMemGetInfo on the handle's device, through the HIP runtime the library itself is linked to */
-int esvio_fe_device_memory(esvio_fe_handle h, size_t* free_bytes, size_t* total_bytes);
 
 #ifdef __cplusplus
 }

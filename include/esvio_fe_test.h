@@ -76,6 +76,76 @@ int esvio_fe_plain_call_counters(esvio_fe_handle h, uint64_t out4[4]);
 int esvio_fe_ransac_tail(uint64_t out6[6], int reset);
 
 
+
+/* ---- taps on single stages (tests compare them with the oracle; the reference has no such calls) -------- */
+/* write a camera's four planes (each width*height doubles, index x + y*width); the read side is
+ * esvio_fe_get_sae in esvio_fe.h */
+int esvio_fe_set_sae(esvio_fe_handle h, int cam, const double* L0, const double* L1,
+                     const double* S0, const double* S1);
+
+/* test tap: the pyramid the LK stage builds for a host image: level `level` u8 image
+ * (lw*lh bytes) and its Scharr derivatives (lw*lh*2 int16, interleaved Ix,Iy). Either output
+ * may be NULL. Returns the number of levels built (maxLevel+1) in *n_levels. */
+int esvio_fe_build_pyramid(esvio_fe_handle h, const uint8_t* img, int w, int hgt, int max_level,
+                           int level, uint8_t* out_img, int16_t* out_deriv, int32_t* lw,
+                           int32_t* lh, int32_t* n_levels);
+/* camodocal PinholeCamera::liftProjective (PinholeCamera.cc:450-510); host-side. */
+int esvio_fe_lift_projective(const esvio_fe_camera* cam, double u, double v, double* out3);
+
+/* Measurement tap: process-wide counters of that function since the last reset — out6 = {calls,
+ * loop iterations, points, nanoseconds inside the calls} of its RANSAC branch (>= 15 points) and
+ * {calls, nanoseconds} of its LMedS branch (8..14 points, what OpenCV runs below 15). */
+int esvio_fe_ransac_stats(uint64_t* out6, int reset);
+
+/* ---- measurement --------------------------------------------------------------------- */
+/* Wall time of the esvio_fe_track_event(_mc) calls on this handle since the last reset, as the calling
+ * thread sees them (always on: a dozen clock reads per call).  The percentiles cover the latest 4096
+ * calls.  For the slowest call: its index since the reset, whether it published, where its time went
+ * (esvio_fe_latency_phase_name(i) names max_phase_ms[i]; entries 8.. are parts of entry 5 on published
+ * frames), the CPUs the calling thread was on when it began / ended, the involuntary context switches
+ * the thread suffered inside it (getrusage(RUSAGE_THREAD)) and the device / pinned allocations it
+ * made. */
+#define ESVIO_FE_LATENCY_PHASES 16
+typedef struct esvio_fe_latency {
+  uint64_t calls;
+  double mean_ms, p50_ms, p99_ms, max_ms;
+  uint64_t max_call;
+  int32_t max_published;
+  int32_t max_cpu_begin, max_cpu_end;
+  int64_t max_invol_switches;
+  int64_t max_allocs;
+  double max_phase_ms[ESVIO_FE_LATENCY_PHASES];
+  uint64_t allocs;          /* allocations inside track / announce calls since the reset */
+  uint64_t invol_switches;  /* involuntary context switches inside track calls since the reset */
+} esvio_fe_latency;
+int esvio_fe_latency_stats(esvio_fe_handle h, esvio_fe_latency* out, int reset);
+const char* esvio_fe_latency_phase_name(int i);
+/* One of the latest 256 track calls as the record above saw it (back = 0: the last call, 1: the one before ...):
+ * when it began (ms since the first track call after the last reset), how long it took, whether it published, and its phases —
+ * read AFTER a run, so that looking does not change the schedule that is looked at.  ESVIO_FE_EINVAL for a call
+ * that is not kept (any more). */
+typedef struct esvio_fe_latency_call {
+  uint64_t call;      /* index of the call since the last reset of esvio_fe_latency_stats (as max_call there) */
+  int32_t published;
+  int32_t reserved;
+  double begin_ms, ms;
+  double phase_ms[ESVIO_FE_LATENCY_PHASES];
+} esvio_fe_latency_call;
+int esvio_fe_latency_recent(esvio_fe_handle h, int back, esvio_fe_latency_call* out);
+/* Per-kernel HIP-event timing on the handle's stream (off by default; when on, every launch is
+ * bracketed by hipEventRecord and resolved lazily). */
+int esvio_fe_set_profiling(esvio_fe_handle h, int on);
+int esvio_fe_kernel_count(void);
+const char* esvio_fe_kernel_name(int kernel_id);
+/* total_ms / launches / algorithmic bytes accumulated since the last reset_kernel_stats */
+int esvio_fe_get_kernel_stats(esvio_fe_handle h, int kernel_id, double* total_ms,
+                              uint64_t* launches, uint64_t* alg_bytes);
+int esvio_fe_reset_kernel_stats(esvio_fe_handle h);
+/* the hipStream_t the handle launches on (as void*) */
+void* esvio_fe_stream(esvio_fe_handle h);
+/* hipMemGetInfo on the handle's device, through the HIP runtime the library itself is linked to */
+int esvio_fe_device_memory(esvio_fe_handle h, size_t* free_bytes, size_t* total_bytes);
+
 #ifdef __cplusplus
 }
 #endif

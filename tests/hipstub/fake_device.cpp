@@ -7,21 +7,8 @@
 
 namespace esvio {
 namespace {
-thread_local LaunchList* t_recorder = nullptr;
 uint32_t lcg(uint32_t& s) { return s = s * 1664525u + 1013904223u; }
 }  // namespace
-
-void set_launch_recorder(LaunchList* l) { t_recorder = l; }
-hipError_t record_event(hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s); }
-hipError_t launch_as_graph(LaunchGraph&, const LaunchList&, hipStream_t s) {
-  hipstub_stream_op(s);
-  return hipSuccess;
-}
-hipError_t launch_plain(const LaunchList&, hipStream_t s) {
-  hipstub_stream_op(s);
-  return hipSuccess;
-}
-void destroy_launch_graph(LaunchGraph&) {}
 
 // H2D of staged events by a kernel: the pinned buffer the staging threads filled is READ here
 void launch_stage_pull(hipStream_t s, const void* pinned_src, void* dst, size_t bytes) {
@@ -38,7 +25,7 @@ void launch_compact(hipStream_t s, const uint32_t*, const uint32_t*, const uint3
 }
 
 // Event_FeaturesToTrack: fills the free places with corners on a jittered grid (deterministic)
-void launch_select(hipStream_t s, const SelectArgs& a, size_t) {
+KernelId launch_select(hipStream_t s, const SelectArgs& a, size_t) {
   hipstub_stream_begin(s);
   static uint32_t seed = 12345;
   const int want = a.max_corners > 0 ? a.max_corners : 0;
@@ -59,6 +46,7 @@ void launch_select(hipStream_t s, const SelectArgs& a, size_t) {
   }
   if (a.pub_done) *a.pub_done = ((unsigned long long)a.pub_seq << 32) | (uint32_t)(a.out_base + k);
   hipstub_stream_end(s);
+  return K_SELECT_MW;
 }
 
 // calcOpticalFlowPyrLK forward (+ backward): every point found, moved by a fraction of a pixel that depends on the

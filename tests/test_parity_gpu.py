@@ -130,19 +130,15 @@ def test_sae_segment_lengths_around_the_wave_path(oracle, path, monkeypatch):
     ft.close()
 
 
-@pytest.mark.parametrize("two_level", [False, True])
 @pytest.mark.parametrize("case", ["span_below", "span_at", "span_above", "big_nsec", "forced_wide", "reversed"])
-def test_sae_partition_record_formats(oracle, case, two_level, monkeypatch):
+def test_sae_partition_record_formats(oracle, case, monkeypatch):
     """the tiled update partitions 8-byte records (tile-local pixel, polarity, seconds relative to the
     batch's smallest, nsec) when the batch's seconds span less than 2^20 and every nsec fits 30 bits,
     else the raw 16-byte records: planes bit-exact on both sides of the rule, with the smallest second
     not at the start of the stream, with nsec words no ros::Time would hold, and with the wide form
-    forced (ESVIO_FE_WIDE_RECORDS=1).  two_level: the same through the two-level partition (ESVIO_FE_PART2=1:
-    k_part_coarse / _scan / _fine, the opt-in A/B form)"""
+    forced (ESVIO_FE_WIDE_RECORDS=1)"""
     if case == "forced_wide":
         monkeypatch.setenv("ESVIO_FE_WIDE_RECORDS", "1")
-    if two_level:
-        monkeypatch.setenv("ESVIO_FE_PART2", "1")
     W, H = 346, 260
     rng = np.random.default_rng(77)
     n = 60000
@@ -290,12 +286,10 @@ def test_lk_parity(oracle, lk_accum):
     ft.close()
 
 
-@pytest.mark.parametrize("W,H,split", [(640, 480, 0), (346, 260, 0), (346, 260, 1), (1280, 720, 0), (1280, 720, 1)])
-def test_render_in_one_and_in_two_launches(oracle, monkeypatch, W, H, split):
-    """the plain configuration's time surface + pyramid: two launches (the default: k_time_surface4 — one pixel per
-    thread where the rows are no multiple of 4 — then k_pyr3) or one (k_ts_pyr, ESVIO_FE_SPLIT_RENDER=0): both
-    forms, images and tracks as the oracle's"""
-    monkeypatch.setenv("ESVIO_FE_SPLIT_RENDER", str(split))
+@pytest.mark.parametrize("W,H", [(346, 260), (1280, 720), (352, 264)])
+def test_render_then_pyramid(oracle, W, H):
+    """the plain configuration's time surface + pyramid (k_time_surface4 — k_time_surface, one pixel per thread, where
+    the rows are no multiple of 4 — then k_pyr3) at sizes other than the bench's: images and tracks as the oracle's"""
     s = SceneStream(W, H, rate=2e6, seed=21)
     kw = dict(max_cnt=150, min_dist=15)
     ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
@@ -309,27 +303,6 @@ def test_render_in_one_and_in_two_launches(oracle, monkeypatch, W, H, split):
         assert np.array_equal(ft.gettimesurface(1), tr.time_surface(1))
         assert np.array_equal(ft.ids, r.ids) and np.array_equal(ft.cur_pts, r.cur_pts)
         assert np.array_equal(ft.ids_right, r.ids_right) and np.array_equal(ft.cur_right_pts, r.cur_right_pts)
-    ft.close()
-
-
-def test_two_level_partition_end_to_end(oracle, monkeypatch):
-    """ESVIO_FE_PART2=1 (the two-level partition, an A/B form): trackEvent on 640x480 stereo batches, plain calls
-    (the cameras' chains on two streams) and a motion-compensated batch — planes and tracks as the oracle's"""
-    monkeypatch.setenv("ESVIO_FE_PART2", "1")
-    W, H = 640, 480
-    s = SceneStream(W, H, rate=5e6, seed=11)
-    kw = dict(f_ransac=1)
-    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
-    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
-    for f in range(6):
-        L, R, _ = s.next_batch()
-        t = event_times(L)[-1]
-        ft.trackEvent(t, L, R, f % 2 == 0)
-        r = tr.track_event(t, L, R, f % 2 == 0)
-        for cam in (0, 1):
-            _planes_equal(ft.detector.get_sae(cam), tr.detector().get_sae(cam))
-        assert np.array_equal(ft.ids, r.ids) and np.array_equal(ft.cur_pts, r.cur_pts)
-        assert np.array_equal(ft.cur_right_pts, r.cur_right_pts)
     ft.close()
 
 
@@ -360,6 +333,45 @@ def test_track_event_end_to_end(oracle, lk_accum):
             assert a.shape == b.shape, (f, k)
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (f, k, np.abs(a - b).max())
     assert len(ft.ids) > 100 and len(ft.ids_right) > 50 and ft.track_cnt.max() >= 4
+    ft.close()
+
+
+@pytest.mark.parametrize("flow_back,f_ransac", [(0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("replay", [False, True])
+def test_track_event_without_flow_back_or_ransac(oracle, flow_back, f_ransac, replay):
+    """`flow_back: 0` (no backward LK launches, no 0.5 px round-trip filter: feature_tracker.cpp:412-431,:492-510) and
+    `F-RANSAC off` (rejectWithF_event skipped, :442-447) — every shipped config sets both to 1, so only these cases draw
+    the other branches: 10 frames at 640x480 as plain calls and as a replay schedule (batches announced ahead, lazy
+    right-camera tails, launch thread), every public vector against the oracle's"""
+    W, H = 640, 480
+    s = SceneStream(W, H, rate=4e6, seed=31 + 2 * flow_back + f_ransac)
+    kw = dict(flow_back=flow_back, f_ransac=f_ransac, max_cnt=200)
+    batches = [s.next_batch()[:2] for _ in range(10)]
+    pubs = [(f % 3) != 1 for f in range(len(batches))]
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
+    if replay:
+        ft.set_lazy_new_stereo(True)
+        ft.set_launch_thread(True)
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        t = event_times(L)[-1]
+        if replay:
+            while announced < min(f + 2, len(batches) - 1):
+                announced += 1
+                La, Ra = batches[announced]
+                ft.set_next_batch(event_times(La)[-1], La, Ra, pubs[announced])
+        ft.trackEvent(t, L, R, pubs[f])
+        r = tr.track_event(t, L, R, pubs[f])
+        if replay:  # (lazy mode: the right-camera vectors of a frame are complete after the next call / finish)
+            assert np.array_equal(ft.ids, r.ids) and np.array_equal(ft.track_cnt, r.track_cnt), f
+            assert np.array_equal(ft.cur_pts.view(np.uint32), r.cur_pts.view(np.uint32)), f
+        else:
+            _compare_tracks(ft, r, ("plain", flow_back, f_ransac, f))
+    if replay:
+        ft.finish()
+        _compare_tracks(ft, r, ("replay", flow_back, f_ransac, "end"))
+    assert len(ft.ids) > 60 and len(ft.ids_right) > 20 and ft.track_cnt.max() >= 3
     ft.close()
 
 
@@ -1078,11 +1090,10 @@ def test_replay_random_schedules(oracle, seed):
     ft.close()
 
 
-@pytest.mark.parametrize("opt", ["ESVIO_FE_GRAPH", "ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE",
+@pytest.mark.parametrize("opt", ["ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE",
                                  "ESVIO_FE_SAE_SORT", "ESVIO_FE_SAE_SORT+ESVIO_FE_SAE_EV_MIN", "ESVIO_FE_SELECT_SERIAL"])
 def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
-    """the measurement switches read at esvio_fe_create (prefetch sequence submitted as a HIP
-    graph; no chained temporal LK; no per-pixel dedup of the Arc* candidates; unfused time surface +
+    """the measurement switches read at esvio_fe_create (no chained temporal LK; no per-pixel dedup of the Arc* candidates; unfused time surface +
     pyrDown kernels; the radix-sort form of the SAE update instead of the tiled one, with the
     per-pixel walk and with the per-event apply kernels for batches of >= 1 event instead of >= 2^20; the
     one-wave selection kernel that sensors without LDS for the 16-wave kernel's queue take)

@@ -23,7 +23,7 @@ for n in (4, 300):
             ft.reset_kernel_stats()
             for _ in range(8):
                 ft.calcOpticalFlowPyrLK(a, b, pts, maxLevel=ml, max_count=mc)
-            s = ft.kernel_stats()["k_lk"]
+            s = next(v for k, v in ft.kernel_stats().items() if k in ("k_lk", "k_lk_f32") and v["launches"])
             T[(ml, mc)] = s["ms"] / s["launches"] * 1e3
     t0 = (T[(0, 30)] - T[(0, 10)]) / 20          # per iteration, level 0 (raw noise)
     t3 = (T[(3, 30)] - T[(3, 10)]) / 80          # per iteration, mean over the four levels

@@ -20,7 +20,7 @@ for ml in (3, 0):
     ft.reset_kernel_stats()
     for _ in range(8):
         ft.calcOpticalFlowPyrLK(a, b, pts, maxLevel=ml)
-    s = ft.kernel_stats()["k_lk"]
+    s = next(v for k, v in ft.kernel_stats().items() if k in ("k_lk", "k_lk_f32") and v["launches"])
     us = s["ms"] / s["launches"] * 1e3
     print("lib %s accum %d maxLevel %d: k_lk %.1f us per launch" % (os.path.basename(FE.lib_path()), ACC, ml, us))
     if ml == 3:

@@ -25,7 +25,7 @@ for name, (a, b) in {
             ft.reset_kernel_stats()
             for _ in range(5):
                 g, st = ft.calcOpticalFlowPyrLK(a, b, pts, maxLevel=ml)
-            s = ft.kernel_stats()["k_lk"]
+            s = next(v for k, v in ft.kernel_stats().items() if k in ("k_lk", "k_lk_f32") and v["launches"])
             L_.oracle_lk_iter_stats(out, 1)
             c, cs = O.lk(a, b, pts, max_level=ml, accum=ACC)
             L_.oracle_lk_iter_stats(out, 0)

@@ -51,8 +51,7 @@ def main():
     print("%dx%d %s, %.2f M events per batch: %.1f us per batch wall (incl. the call's sync)"
           % (W, H, a.stream, ev / a.iters / 1e6, dt / a.iters * 1e6))
     tot = 0.0
-    # (the library's timing labels are those of the sort form; the tiled kernels report under them)
-    for k, what in (("k_sae_keys", "hist"), ("k_tile_scan", "scan"), ("k_radix_pass", "scatter"), ("k_sae_apply", "apply")):
+    for k, what in (("k_tile_hist", "hist"), ("k_tile_scan", "scan"), ("k_tile_scatter", "scatter"), ("k_tile_apply", "apply")):
         v = st[k]
         if v["launches"]:
             us = v["ms"] / v["launches"] * 1e3

@@ -23,6 +23,8 @@ for mask_frac in (0.0, 0.5):
         for _ in range(5):
             xy, idx = ft.Event_FeaturesToTrack(L, maxc, mask)
         st = ft.kernel_stats()
+        st["k_select"] = next(st[k] for k in ("k_select_mw", "k_select", "k_select_gbm") if st[k]["launches"])
+        st["k_arc"] = st["k_arc_ev"]
         print("mask %.1f maxc %3d -> accepted %3d last_idx %6d | k_select %.1f us  k_arc %.1f  k_compact %.1f" % (
             mask_frac, maxc, len(idx), idx[-1] if len(idx) else -1,
             st["k_select"]["ms"] / st["k_select"]["launches"] * 1e3,

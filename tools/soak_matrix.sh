@@ -6,4 +6,3 @@ run ESVIO_FE_WIDE_RECORDS=1
 run ESVIO_FE_SAE_SORT=1
 run ESVIO_FE_STAGE_THREADS=0
 run ESVIO_FE_STAGE_THREADS=4
-run ESVIO_FE_GRAPH=1
