@@ -965,6 +965,7 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
       const bool ok = i < n;
       const uint32_t d = tile_bin(g, rec[r].x, i >= nL);
       uint32_t rank = 0;
+#ifndef ESVIO_ABL_NORANK  // (measurement builds, tools/build_variant.sh + tools/scatter_ablation.sh: what the kernel costs without its parts)
 #pragma unroll
       for (int half = 0; half < 2; half++) {
         if (ok && (lane >> 5) == half) {
@@ -979,6 +980,7 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
         // order; nothing has to wait for them)
         __asm__ volatile("" ::: "memory");
       }
+#endif
       dr[r] = d | (rank << 16);
     }
     lds_barrier();
@@ -1006,7 +1008,14 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
           const uint32_t d = dr[r] & 0xffffu;
+#if defined(ESVIO_ABL_NOWRITE)
+          if (bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16) == 0xffffffffu)  // (never: the address is still computed)
+#endif
+#if defined(ESVIO_ABL_COALESCED)
+          part2[i + ((bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16)) >> 31)] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
+#else
           part2[bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16)] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
+#endif
         }
       }
     } else {

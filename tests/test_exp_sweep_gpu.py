@@ -52,9 +52,11 @@ def test_every_age_on_the_2_pow_minus_22_grid(oracle, decay_ms, ignore_polarity,
                                % (cam, len(bad), W * H, bad[0], bad[0] * 2.0 ** -22, g.flat[bad[0]], o.flat[bad[0]]))
         # the sweep covers what it claims to: the whole byte range on the decaying side, saturation at age 0
         vals = np.unique(g)
-        if cam == 0 or ignore_polarity:
+        if ignore_polarity:  # 255 * exp(.): every byte value
+            assert g.flat[0] == 255 and vals.min() == 0 and len(vals) == 256
+        elif cam == 0:       # 127.5 * (1 + exp(.))
             assert g.flat[0] == 255 and vals.min() == 128 and len(vals) == 128
-        else:
+        else:                # 127.5 * (1 - exp(.))
             assert g.flat[0] == 0 and vals.max() <= 128 and len(vals) >= 128
     ft.close()
     assert n_diff == 0
