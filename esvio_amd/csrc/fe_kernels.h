@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -157,16 +158,36 @@ inline bool make_tile_geom(int W, int H, TileGeom* g) {
   return false;
 }
 
-inline uint32_t tile_scatter_events_per_block(uint32_t n) { return n >= (1u << 20) ? 4096u : 2048u; }
-inline uint32_t tile_scatter_blocks(uint32_t n) {
-  const uint32_t e = tile_scatter_events_per_block(n);
-  return (n + e - 1) / e;
-}
-// scatter block b owns the events [b*TE, (b+1)*TE); k_tile_hist block `seg` counts the buckets of
-// the `group` scatter blocks seg*group ..., so that the count matrices stay small: at most
-// kTileMaxGroups groups
+// events per scatter block.  (Until round 6: 4096 from 2^20 events on, in 16 rounds per wave — 212 VGPRs, two resident
+// blocks per CU; with one camera's buckets per table (below) the 8-round kernel's 33 KiB and 128 VGPRs let three run,
+// and at 6.7 M events 2048 measured 59-66 us against 70 for 4096, profiles/r06_partition.md.)
+constexpr uint32_t kTileScatterEvents = 2048;
+// The batch is [left array; right array], and every bucket belongs to one camera: a scatter block never mixes the two.
+// Scatter block b < nblkL owns the left events [b*TE, (b+1)*TE), block nblkL + b the right events [b*TE, (b+1)*TE) —
+// so a block's bucket table (LDS in k_tile_scatter, a row of the count matrices) has one camera's nt_cam buckets + the
+// out-of-sensor bin: half the columns the whole batch has (round 6; before, blocks were cut from the concatenated
+// stream and every table had both cameras' buckets).  k_tile_hist block `seg` counts the buckets of `group`
+// consecutive scatter blocks of ONE camera, so that the count matrices stay small: at most kTileMaxGroups groups.
 constexpr uint32_t kTileMaxGroups = 512;
-inline uint32_t tile_hist_group(uint32_t nblk) { return (nblk + kTileMaxGroups - 1) / kTileMaxGroups; }
+struct TileSplit {
+  uint32_t te;            // events per scatter block
+  uint32_t nblkL, nblkR;  // scatter blocks per camera
+  uint32_t group;         // scatter blocks per k_tile_hist block
+  uint32_t nsegL, nsegR;  // k_tile_hist blocks (= groups) per camera
+  __host__ __device__ uint32_t nblk() const { return nblkL + nblkR; }
+  __host__ __device__ uint32_t nseg() const { return nsegL + nsegR; }
+};
+inline TileSplit tile_split(uint32_t nL, uint32_t nR) {
+  TileSplit t;
+  t.te = kTileScatterEvents;
+  t.nblkL = (nL + t.te - 1) / t.te;
+  t.nblkR = (nR + t.te - 1) / t.te;
+  t.group = (t.nblkL + t.nblkR + kTileMaxGroups - 3) / (kTileMaxGroups - 2);  // (each camera's last group may be short)
+  if (!t.group) t.group = 1;
+  t.nsegL = (t.nblkL + t.group - 1) / t.group;
+  t.nsegR = (t.nblkR + t.group - 1) / t.group;
+  return t;
+}
 // scratch (uint32 words).  Every k_tile_hist block leaves the range of seconds and the OR of the nsec words
 // of its events in its own slot of `ranges` (three same-address global atomics per block — 410 blocks
 // ending together — were 6 of the kernel's 32 us at 6.7 M events); k_tile_scan reduces the slots and
@@ -179,9 +200,11 @@ struct TileScratch {
   uint32_t* totals;    // [nbins] events per bucket
   uint32_t* tile_off;  // [nbins + 1] exclusive bucket offsets into `part`, written by k_tile_scatter
   uint32_t* tile_order;  // [nbins - 1] buckets by descending size class, written by k_tile_scatter
-  uint32_t* P;         // [nblk][nbins] bucket counts of the earlier scatter blocks of the same group
-  uint32_t* T;         // [ngroups][nbins] bucket counts per group
-  uint32_t* C;         // [ngroups][nbins] ... of all earlier groups
+  // the count matrices: one row per scatter block / group, one column per bucket of the row's camera (nt_cam + 1: the
+  // last one is the out-of-sensor bin)
+  uint32_t* P;         // [nblk][nt_cam + 1] bucket counts of the earlier scatter blocks of the same group
+  uint32_t* T;         // [ngroups][nt_cam + 1] bucket counts per group
+  uint32_t* C;         // [ngroups][nt_cam + 1] ... of all earlier groups of the camera (out-of-sensor bin: of all earlier groups)
 };
 // k_tile_hist: P, T and the blocks' ranges; launch_tile_scan: C, totals, the record format; out-of-sensor
 // events added to *n_rejected
@@ -190,7 +213,7 @@ struct TileScratch {
 void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const EventRec* evR, uint32_t nR,
                       const TileGeom& g, const TileScratch& sc, unsigned long long* n_rejected,
                       const struct McParams* mc = nullptr, uint32_t* warp_xy = nullptr);
-void launch_tile_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc,
+void launch_tile_scan(hipStream_t s, uint32_t nL, uint32_t nR, const TileGeom& g, const TileScratch& sc,
                       unsigned long long* n_rejected);
 // stable partition of [left; right] into `part` by bucket (warp_xy non-null: the records get the
 // warped pixels launch_tile_hist computed)

@@ -560,21 +560,21 @@ struct TileRec<true> {
   static __device__ __forceinline__ double time(const T& e, uint32_t sec_base) { return ev_time(sec_base + (e.x >> 12), e.y); }
 };
 
-__device__ __forceinline__ uint32_t tile_bin(const TileGeom& g, uint32_t xy, bool right) {
+// bucket of an event INSIDE its camera: tile index, or nt_cam for an out-of-sensor event
+__device__ __forceinline__ uint32_t tile_bin(const TileGeom& g, uint32_t xy) {
   const uint32_t x = xy & 0xffffu, y = xy >> 16;
-  if (x >= (uint32_t)g.W || y >= (uint32_t)g.H) return (uint32_t)g.nbins - 1u;
+  if (x >= (uint32_t)g.W || y >= (uint32_t)g.H) return (uint32_t)g.nt_cam;
   // tw is 32 or 64, th 16 or 32: shifts
   const uint32_t tx = x >> (g.tw == 64 ? 6 : 5), ty = y >> (g.th == 32 ? 5 : 4);
-  return (right ? (uint32_t)g.nt_cam : 0u) + ty * (uint32_t)g.tiles_x + tx;
+  return ty * (uint32_t)g.tiles_x + tx;
 }
 
-// Per-block bucket counts without global atomics or look-back: block `seg` of k_tile_hist walks the
-// `group` scatter blocks seg*group .. seg*group+group-1 one after the other — scatter block b owns
-// the events [b*TE, (b+1)*TE) of the stream — and writes, per scatter block, the exclusive prefix of
-// the bucket counts inside its group (P[b][bucket], one coalesced row) and the group totals
-// (T[seg][bucket]); k_tile_scan turns the group totals into exclusive prefixes over the groups
-// (C[seg][bucket]) and bucket totals.  k_tile_scatter then knows where every event goes:
-// bucket start + C[group][bucket] + P[block][bucket] + rank inside the block.
+// Per-block bucket counts without global atomics or look-back: block `seg` of k_tile_hist walks `group`
+// consecutive scatter blocks of ONE camera one after the other (TileSplit, fe_kernels.h) and writes, per
+// scatter block, the exclusive prefix of the bucket counts inside its group (P[b][bucket], one coalesced row)
+// and the group totals (T[seg][bucket]); k_tile_scan turns the group totals into exclusive prefixes over
+// the camera's groups (C[seg][bucket]) and bucket totals.  k_tile_scatter then knows where every event goes:
+// bucket start + C[group][bucket] + P[block][bucket] + rank inside the block.  Rows have nt_cam + 1 columns.
 // MC (the motion-compensated overload, feature_tracker.cpp:605-641): the bucket is that of the WARPED
 // pixel, computed by k_mc_warp (one lane per event: the per-event Matrix3f::exp + LU solve is a long
 // dependent chain, so it wants every SIMD full — inside k_tile_hist, whose 1024-thread blocks take
@@ -597,18 +597,17 @@ constexpr int kTileHistThreads = 1024;
 template <bool MC>
 __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __restrict__ evL, uint32_t nL,
                                                    const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
-                                                   uint32_t te, uint32_t nblk, uint32_t group,
-                                                   uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm,
+                                                   TileSplit sp, uint32_t* __restrict__ Pm, uint32_t* __restrict__ Tm,
                                                    const uint32_t* __restrict__ warp_xy,
                                                    uint4* __restrict__ ranges) {
-  constexpr int UE = 4;
+  constexpr int UE = kTileScatterEvents / kTileHistThreads;  // a thread's events per scatter block
   // two histograms, by lane parity: the events of a moving edge come in runs of one bucket, and the LDS
   // takes same-address atomics of a wave one after the other (scene stream at C5: 33.7 -> 28.6 us;
   // four copies: 29.1; uniform events: unchanged)
   constexpr int HC = 2;
   __shared__ uint32_t h[HC * kTileMaxBins], run[kTileMaxBins];  // 24 KiB
   __shared__ uint32_t s_range[3];
-  const int nb = g.nbins;
+  const int nbc = g.nt_cam + 1;  // this camera's buckets + the out-of-sensor bin
   uint32_t* const hme = h + (threadIdx.x & (HC - 1)) * kTileMaxBins;
   for (int i = threadIdx.x; i < kTileMaxBins; i += kTileHistThreads) {
 #pragma unroll
@@ -623,42 +622,48 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
   // the batch's range of seconds and whether every nsec fits 30 bits (in-sensor events): decides
   // whether the partitioned records can take the 8-byte form (TileScratch::ranges, k_tile_scan)
   uint32_t tmin = 0xffffffffu, tmax = 0, tor = 0;
-  const uint32_t n = nL + nR;
-  // (te <= 4 * kTileHistThreads: a thread has at most 4 events per scatter block.)  One scatter block
+  // this block's camera, its array, its scatter blocks [b0, b0 + group) (clipped to the camera's)
+  const bool right = blockIdx.x >= sp.nsegL;
+  const uint4* __restrict__ ev = right ? evR : evL;
+  const uint32_t ncam = right ? nR : nL, ioff = right ? nL : 0u;  // (ioff: the array's place in the whole stream, for warp_xy)
+  const uint32_t lb0 = (blockIdx.x - (right ? sp.nsegL : 0u)) * sp.group, nblk_cam = right ? sp.nblkR : sp.nblkL;
+  const uint32_t brow0 = (right ? sp.nblkL : 0u) + lb0;  // row of P of the first one
+  const uint32_t te = sp.te, group = sp.group;
+  // One scatter block
   // per step: its records are counted into the LDS histogram, then its row of P is written from the
-  // running prefix (and the histogram cleared); the NEXT scatter block's records (4 per thread: 16
-  // registers, two blocks still fit a CU) are requested before that, and the barriers order LDS traffic
+  // running prefix (and the histogram cleared); the NEXT scatter block's records (UE per thread)
+  // are requested before that, and the barriers order LDS traffic
   // only (lds_barrier) — so the requests and the stores of P are in flight while a step computes.
   uint4 ne[UE];
   uint32_t nw[UE];
   auto request = [&](uint32_t k) {
-    const uint32_t b = blockIdx.x * group + k;
-    const uint32_t lo = b * te, hi = (k < group && b < nblk) ? min(lo + te, n) : lo;
+    const uint32_t lb = lb0 + k;
+    const uint32_t lo = lb * te, hi = (k < group && lb < nblk_cam) ? min(lo + te, ncam) : lo;
 #pragma unroll
     for (int j = 0; j < UE; j++) {
       const uint32_t i = lo + threadIdx.x + j * kTileHistThreads;
       ne[j] = make_uint4(0, 0, 0, 0);
       nw[j] = 0;
-      if (j * kTileHistThreads < (int)te && i < hi) {
-        ne[j] = i >= nL ? evR[i - nL] : evL[i];  // (whole records: one coalesced 1 KiB request per wave)
-        if (MC) nw[j] = warp_xy[i];
+      if (i < hi) {
+        ne[j] = ev[i];  // (whole records: one coalesced 1 KiB request per wave)
+        if (MC) nw[j] = warp_xy[ioff + i];
       }
     }
   };
   request(0);
   __syncthreads();
   for (uint32_t k = 0; k < group; k++) {
-    const uint32_t b = blockIdx.x * group + k;
-    const bool live = b < nblk;
-    const uint32_t lo = b * te, hi = live ? min(lo + te, n) : lo;
+    const uint32_t lb = lb0 + k;
+    const bool live = lb < nblk_cam;
+    const uint32_t lo = lb * te, hi = live ? min(lo + te, ncam) : lo;
     uint32_t bins[UE];
 #pragma unroll
     for (int j = 0; j < UE; j++) {
       const uint32_t i = lo + threadIdx.x + j * kTileHistThreads;
       bins[j] = 0xffffffffu;
-      if (j * kTileHistThreads < (int)te && i < hi) {
-        bins[j] = tile_bin(g, MC ? nw[j] : ne[j].x, i >= nL);
-        if (bins[j] != (uint32_t)nb - 1u) {
+      if (i < hi) {
+        bins[j] = tile_bin(g, MC ? nw[j] : ne[j].x);
+        if (bins[j] != (uint32_t)g.nt_cam) {
           tmin = min(tmin, ne[j].y);
           tmax = max(tmax, ne[j].y);
           tor |= ne[j].z;
@@ -671,9 +676,9 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
       if (bins[j] != 0xffffffffu) atomicAdd(&hme[bins[j]], 1u);
     lds_barrier();
     if (live)
-      for (int i = threadIdx.x; i < nb; i += kTileHistThreads) {
+      for (int i = threadIdx.x; i < nbc; i += kTileHistThreads) {
         const uint32_t r = run[i];
-        Pm[(size_t)b * nb + i] = r;
+        Pm[(size_t)(brow0 + k) * nbc + i] = r;
         uint32_t cnt = 0;
 #pragma unroll
         for (int q = 0; q < HC; q++) {
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
       }
     lds_barrier();
   }
-  for (int i = threadIdx.x; i < nb; i += kTileHistThreads) Tm[(size_t)blockIdx.x * nb + i] = run[i];
+  for (int i = threadIdx.x; i < nbc; i += kTileHistThreads) Tm[(size_t)blockIdx.x * nbc + i] = run[i];
   // wave-level reduction first, then one LDS atomic per wave, one slot per block
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -701,17 +706,20 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
   if (threadIdx.x == 0) ranges[blockIdx.x] = make_uint4(s_range[0], s_range[1], s_range[2], 0);
 }
 
-// exclusive prefix of the group totals over the groups, per bucket.  Thread = (one of the block's 64
-// consecutive buckets, one of 16 consecutive ranges of groups): a wave reads 64 consecutive words of a
-// row (the first version took 16 buckets per block: 64-byte pieces of every row, 13-15 us for 3 MB).
+// exclusive prefix of the group totals over the camera's groups, per bucket (the out-of-sensor bin: over all groups,
+// the left camera's first).  Thread = (one of the block's 64 consecutive buckets, one of 16 consecutive ranges of
+// groups): a wave reads 64 consecutive words of a row (the first version took 16 buckets per block: 64-byte pieces
+// of every row, 13-15 us for 3 MB).  Buckets are numbered over both cameras here (camera * nt_cam + tile, then the
+// out-of-sensor bin: TileGeom::nbins of them) — the numbering of totals, tile_off, tile_order and k_tile_apply.
 constexpr int kTileScanBins = 64, kTileScanRanges = 16, kTileScanThreads = kTileScanBins * kTileScanRanges;
-constexpr int kTileScanPer = (kTileMaxGroups + kTileScanRanges - 1) / kTileScanRanges;  // groups per thread
-__global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* __restrict__ Tm, uint32_t nseg,
-                                                                int nb, uint32_t* __restrict__ Cm,
+constexpr int kTileScanPer = (kTileMaxGroups + kTileScanRanges - 1) / kTileScanRanges;  // groups per thread, at most
+__global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* __restrict__ Tm, TileSplit sp,
+                                                                int nb, int nt_cam, uint32_t* __restrict__ Cm,
                                                                 uint32_t* __restrict__ totals,
                                                                 unsigned long long* n_rejected,
                                                                 const uint4* __restrict__ ranges,
                                                                 uint32_t* __restrict__ meta, int force_wide) {
+  const uint32_t nseg = sp.nsegL + sp.nsegR;
   if (blockIdx.x == gridDim.x - 1) {  // (a block of its own, beside the scan: one wave)
     if (threadIdx.x >= 64) return;
     // 8-byte partitioned records (kTileRec*) when the batch's seconds span < 2^20 and every nsec < 2^30
@@ -740,13 +748,18 @@ __global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* 
   const int bl = threadIdx.x % kTileScanBins, r = threadIdx.x / kTileScanBins;
   const int bin = blockIdx.x * kTileScanBins + bl;
   const bool ok = bin < nb;
-  const uint32_t per = (nseg + kTileScanRanges - 1) / kTileScanRanges;
-  const uint32_t s0 = min((uint32_t)r * per, nseg);
+  // the bucket's column in its camera's rows, and the rows (groups) that have it
+  const int nbc = nt_cam + 1;
+  const bool reject = bin == nb - 1, right = !reject && bin >= nt_cam;
+  const int col = reject ? nt_cam : bin - (right ? nt_cam : 0);
+  const uint32_t sbeg = right ? sp.nsegL : 0u, scnt = reject ? nseg : (right ? sp.nsegR : sp.nsegL);
+  const uint32_t per = (scnt + kTileScanRanges - 1) / kTileScanRanges;
+  const uint32_t s0 = min((uint32_t)r * per, scnt);
   uint32_t v[kTileScanPer], sum = 0;
 #pragma unroll
   for (int k = 0; k < kTileScanPer; k++) {  // (all of a thread's words requested together)
     const uint32_t sg = s0 + (uint32_t)k;
-    v[k] = (ok && (uint32_t)k < per && sg < nseg) ? Tm[(size_t)sg * nb + bin] : 0u;
+    v[k] = (ok && (uint32_t)k < per && sg < scnt) ? Tm[(size_t)(sbeg + sg) * nbc + col] : 0u;
     sum += v[k];
   }
   part[r][bl] = sum;
@@ -762,14 +775,14 @@ __global__ __launch_bounds__(kTileScanThreads) void k_tile_scan(const uint32_t* 
 #pragma unroll
   for (int k = 0; k < kTileScanPer; k++) {
     const uint32_t sg = s0 + (uint32_t)k;
-    if ((uint32_t)k < per && sg < nseg) {
-      Cm[(size_t)sg * nb + bin] = carry;
+    if ((uint32_t)k < per && sg < scnt) {
+      Cm[(size_t)(sbeg + sg) * nbc + col] = carry;
       carry += v[k];
     }
   }
   if (r == 0) {
     totals[bin] = tot;
-    if (bin == nb - 1 && tot) atomicAdd(n_rejected, (unsigned long long)tot);  // out-of-sensor events
+    if (reject && tot) atomicAdd(n_rejected, (unsigned long long)tot);  // out-of-sensor events
   }
 }
 
@@ -778,30 +791,29 @@ void launch_tile_hist(hipStream_t s, const EventRec* evL, uint32_t nL, const Eve
                       uint32_t* warp_xy) {
   const uint32_t n = nL + nR;
   if (!n) return;
-  const uint32_t te = tile_scatter_events_per_block(n), nblk = tile_scatter_blocks(n);
-  const uint32_t group = tile_hist_group(nblk), nseg = (nblk + group - 1) / group;
+  const TileSplit sp = tile_split(nL, nR);
   if (mc && mc->enabled) {
     launch_k(k_mc_warp, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g.W, g.H,
              *mc, warp_xy);
-    launch_k(k_tile_hist<true>, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
-             te, nblk, group, sc.P, sc.T, (const uint32_t*)warp_xy, (uint4*)sc.ranges);
+    launch_k(k_tile_hist<true>, dim3(sp.nseg()), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
+             sp, sc.P, sc.T, (const uint32_t*)warp_xy, (uint4*)sc.ranges);
   } else {
-    launch_k(k_tile_hist<false>, dim3(nseg), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
-             te, nblk, group, sc.P, sc.T, (const uint32_t*)nullptr, (uint4*)sc.ranges);
+    launch_k(k_tile_hist<false>, dim3(sp.nseg()), dim3(kTileHistThreads), 0, s, (const uint4*)evL, nL, (const uint4*)evR, nR, g,
+             sp, sc.P, sc.T, (const uint32_t*)nullptr, (uint4*)sc.ranges);
   }
 }
 
-void launch_tile_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileScratch& sc,
+void launch_tile_scan(hipStream_t s, uint32_t nL, uint32_t nR, const TileGeom& g, const TileScratch& sc,
                       unsigned long long* n_rejected) {
-  if (!n) return;
-  const uint32_t nblk = tile_scatter_blocks(n), group = tile_hist_group(nblk), nseg = (nblk + group - 1) / group;
+  if (!(nL + nR)) return;
+  const TileSplit sp = tile_split(nL, nR);
   static const int force_wide = getenv("ESVIO_FE_WIDE_RECORDS") ? 1 : 0;  // (A/B and tests)
   static_assert(kTileMaxGroups <= (uint32_t)(kTileScanPer * kTileScanRanges), "k_tile_scan covers every group");
-  launch_k(k_tile_scan, dim3((g.nbins + kTileScanBins - 1) / kTileScanBins + 1), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, nseg,
-           g.nbins, sc.C, sc.totals, n_rejected, (const uint4*)sc.ranges, sc.meta, force_wide);
+  launch_k(k_tile_scan, dim3((g.nbins + kTileScanBins - 1) / kTileScanBins + 1), dim3(kTileScanThreads), 0, s, (const uint32_t*)sc.T, sp,
+           g.nbins, g.nt_cam, sc.C, sc.totals, n_rejected, (const uint4*)sc.ranges, sc.meta, force_wide);
 }
 
-// Stable partition by bucket.  A scatter block of 4 waves owns TE = 256 * ROUNDS consecutive events;
+// Stable partition by bucket.  A scatter block of 4 waves owns TE = 256 * ROUNDS consecutive events of one camera;
 // wave w takes them in rounds of 64 consecutive events and ranks every event inside its (wave, bucket)
 // pair: rank = events of the bucket this wave has seen in earlier rounds + lanes BELOW this one that
 // hold the same bucket in this round — stream order is kept.  "Which lanes hold my bucket" used to be
@@ -813,35 +825,40 @@ void launch_tile_scan(hipStream_t s, uint32_t n, const TileGeom& g, const TileSc
 // LDS executes a wave's instructions in order) and has the set of lanes that share its bucket; the
 // lowest of them adds the group to the wave's running count and clears the mask again.  ~25
 // instructions per round.  32-bit masks, so a round is two half-rounds of 32 lanes.
-// LDS: {mask, running count} pairs, 8 B per (wave, bucket) — the half-round reads both with one
-// ds_read_b64 and the group's lowest lane writes both back with one ds_write_b64 (separate words, the
-// count 16 bits wide, were 5 LDS instructions per half-round instead of 3: 73.7 -> 71.1 us at C5) —
-// + the bases: 36 B per bucket, 65 KiB at 1841 buckets: two blocks per CU, which is what the ~200
-// VGPRs allow anyway; the grid is 2 blocks per CU at most, each block walks over its scatter blocks (the
-// masks are zero again after every round, the bucket starts are computed once per block).
-constexpr int kTileScatterMaxGrid = 512;  // (<= 2 resident blocks per CU: ~200 VGPRs with the prefetched records)
+// LDS: one 8-byte entry per (wave, bucket) — {mask, running count (low half) | the wave's offset inside the scatter
+// block's run of the bucket (high half)} — the half-round reads it with one ds_read_b64 and the group's lowest lane
+// writes it back with one ds_write_b64 — + the bases: 36 B per bucket of ONE camera (33 KiB at 921: round 6; both
+// cameras' buckets, 65 KiB, before).  Nothing is cleared between scatter blocks: the masks are zero again after
+// every round, and the step that turns the four waves' counts into their offsets puts the counts back to zero
+// (round 6: before, a pass over the whole table and a barrier per scatter block).  Each workgroup walks over scatter
+// blocks of one camera; the bucket starts are computed once per workgroup.
+constexpr int kTileScatterMaxGrid = 768;  // (3 resident blocks per CU: 128 VGPRs, 33 KiB of LDS at 921 buckets; 512 / 640 / 896 / 1024 measured slower)
 template <int ROUNDS, bool MC>
 __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
     const uint4* __restrict__ evL, uint32_t nL, const uint4* __restrict__ evR, uint32_t nR, TileGeom g,
-    uint32_t group, uint32_t nblk, const uint32_t* __restrict__ Pm, const uint32_t* __restrict__ Cm,
+    TileSplit sp, uint32_t gridL, const uint32_t* __restrict__ Pm, const uint32_t* __restrict__ Cm,
     const uint32_t* __restrict__ totals, uint4* __restrict__ part, uint32_t* __restrict__ tile_off,
     uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ warp_xy, const uint32_t* __restrict__ meta) {
-  // LDS, sized by the bucket count (nbp = nbins rounded up to 64): {mask, running count} [4][nbp] 8 B
-  // (one ds_read_b64 / ds_write_b64 per half-round instead of separate words) | bases [nbp] u32
-  // (first position of the current scatter block per bucket) = 36 B per bucket: 65 KiB at 1841 buckets
+  // LDS, sized by one camera's bucket count (nbcp = nt_cam + 1 rounded up to 64): the (wave, bucket) entries
+  // [4][nbcp] 8 B | bases [nbcp] u32 (first position of the current scatter block per bucket); the entries' space
+  // first serves the scan of ALL the batch's bucket totals (nb words <= 8 nbcp)
   extern __shared__ __attribute__((aligned(16))) uint32_t scatter_lds[];
-  const int nb = g.nbins, nbp = (nb + 63) & ~63;
-  uint2* mc_s = (uint2*)scatter_lds;                    // [wave * nbp + bucket]
-  uint32_t* bin_base = scatter_lds + 8 * nbp;
+  const int nb = g.nbins, nbc = g.nt_cam + 1, nbcp = (nbc + 63) & ~63;
+  uint2* mc_s = (uint2*)scatter_lds;                    // [wave * nbcp + bucket]
+  uint32_t* bin_base = scatter_lds + 8 * nbcp;
   __shared__ uint32_t wave_tot[4];
   constexpr int TE = kTileScatterThreads * ROUNDS;
   constexpr int KB = kTileMaxBins / kTileScatterThreads;  // bins per thread (8)
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  const uint32_t n = nL + nR;
-  for (int i = threadIdx.x; i < 2 * nbp; i += kTileScatterThreads) ((uint4*)mc_s)[i] = make_uint4(0, 0, 0, 0);
-  uint32_t bstart[KB];  // bucket offsets into `part` of buckets threadIdx.x + k * 256
-  // ---- once per block: exclusive scan of the bucket totals (thread t owns bins [t*KB, t*KB+KB))
+  // this workgroup's camera: the first gridL workgroups take the left camera's scatter blocks
+  const bool right = blockIdx.x >= gridL;
+  const uint4* __restrict__ ev = right ? evR : evL;
+  const uint32_t ncam = right ? nR : nL, ioff = right ? nL : 0u;
+  const uint32_t brow0 = right ? sp.nblkL : 0u, nblk_cam = right ? sp.nblkR : sp.nblkL, seg0 = right ? sp.nsegL : 0u;
+  uint32_t bstart[KB];  // offsets into `part` of this camera's buckets threadIdx.x + k * 256 (bucket nt_cam: the out-of-sensor bin)
+  // ---- once per workgroup: exclusive scan of the batch's bucket totals (thread t owns bins [t*KB, t*KB+KB))
   {
+    uint32_t* all_off = scatter_lds;  // [nb], before the entries live there
     uint32_t loc[KB], sum = 0;
 #pragma unroll
     for (int k = 0; k < KB; k++) {
@@ -862,7 +879,7 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #pragma unroll
     for (int k = 0; k < KB; k++) {
       const int b = threadIdx.x * KB + k;
-      if (b < nbp) bin_base[b] = run;  // (transposed into bstart below)
+      if (b < nb) all_off[b] = run;
       if (blockIdx.x == 0 && b <= nb) tile_off[b] = run;  // (b == nb: the total)
       run += loc[k];
     }
@@ -899,21 +916,25 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #pragma unroll
     for (int k = 0; k < KB; k++) {
       const int d = threadIdx.x + k * kTileScatterThreads;
-      bstart[k] = d < nb ? bin_base[d] : 0u;
+      bstart[k] = d < nbc ? all_off[d < g.nt_cam ? (right ? g.nt_cam : 0) + d : nb - 1] : 0u;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * nbcp; i += kTileScatterThreads) ((uint4*)mc_s)[i] = make_uint4(0, 0, 0, 0);
   }
-  // ---- the block's scatter blocks.  Workgroups go to the 8 XCDs round-robin and each XCD has its own
+  // ---- the workgroup's scatter blocks.  Workgroups go to the 8 XCDs round-robin and each XCD has its own
   // L2; the runs two consecutive scatter blocks write into a bucket are neighbours in memory (a few
   // records each, less than a cache line), so neighbours should meet in ONE L2: XCD x takes the x-th
-  // contiguous eighth of the scatter blocks, its workgroups take them interleaved.
+  // contiguous eighth of the camera's scatter blocks, its workgroups take them interleaved.  (gridL is a multiple
+  // of 8 whenever both cameras have workgroups, so a workgroup's index inside its camera keeps its XCD.)
+  const uint32_t wg = blockIdx.x - (right ? gridL : 0u), nwg = right ? gridDim.x - gridL : gridL;
   uint32_t t_first, t_end, t_step;
-  if (gridDim.x < 8) {
-    t_first = blockIdx.x;
-    t_end = nblk;
-    t_step = gridDim.x;
+  if (nwg < 8) {
+    t_first = wg;
+    t_end = nblk_cam;
+    t_step = nwg;
   } else {
-    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, q = nblk >> 3, r = nblk & 7u;
-    t_step = (gridDim.x - x + 7u) >> 3;  // workgroups on this XCD
+    const uint32_t x = wg & 7u, j = wg >> 3, q = nblk_cam >> 3, r = nblk_cam & 7u;
+    t_step = (nwg - x + 7u) >> 3;  // workgroups of this camera on this XCD
     t_first = x * q + min(x, r) + j;
     t_end = (x + 1u) * q + min(x + 1u, r);
   }
@@ -921,34 +942,32 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
   const uint32_t sec_base = meta[kTileMetaSecBase];
   const int twsh = g.tw == 64 ? 6 : 5;
   const uint32_t hl = (uint32_t)lane & 31u, hbit = 1u << hl, hlt = hbit - 1u;
-  // The records (and count-matrix rows) of the block's NEXT scatter block are requested while the
+  // The records (and count-matrix rows) of the workgroup's NEXT scatter block are requested while the
   // current one is ranked and stored; the barriers inside the loop order LDS traffic only
   // (lds_barrier), so nothing in it waits for HBM except the first use of a record.  (In-kernel
   // timers before: 3.5-7 us of a scatter block's 11-23 us were the wait for its own loads at the first
   // __syncthreads.)
   uint4 nrec[ROUNDS];
   uint32_t npc[KB];
-  auto request = [&](uint32_t tile) {
+  auto request = [&](uint32_t tile) {  // (tile: scatter block inside the camera)
     const uint32_t wb = tile * TE + wave * (TE / 4);
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
       const uint32_t i = wb + r * 64 + lane;
-      nrec[r] = i < nL ? evL[i] : (i < n ? evR[i - nL] : make_uint4(0xffffffffu, 0, 0, 0));
-      if (MC && i < n) nrec[r].x = warp_xy[i];  // (the pixel k_mc_warp warped the event to)
+      nrec[r] = i < ncam ? ev[i] : make_uint4(0xffffffffu, 0, 0, 0);
+      if (MC && i < ncam) nrec[r].x = warp_xy[ioff + i];  // (the pixel k_mc_warp warped the event to)
     }
-    const uint32_t* Prow = Pm + (size_t)tile * nb;
-    const uint32_t* Crow = Cm + (size_t)(tile / group) * nb;
+    const uint32_t* Prow = Pm + (size_t)(brow0 + tile) * nbc;
+    const uint32_t* Crow = Cm + (size_t)(seg0 + tile / sp.group) * nbc;
 #pragma unroll
     for (int k = 0; k < KB; k++) {
       const int d = threadIdx.x + k * kTileScatterThreads;
-      npc[k] = d < nb ? Crow[d] + Prow[d] : 0u;
+      npc[k] = d < nbc ? Crow[d] + Prow[d] : 0u;
     }
   };
   if (t_first < t_end) request(t_first);
   __syncthreads();  // (the set-up above)
   for (uint32_t tile = t_first; tile < t_end; tile += t_step) {
-    lds_barrier();  // (the previous scatter block's reads of the counts / bin_base)
-    for (int i = threadIdx.x; i < 2 * nbp; i += kTileScatterThreads) ((uint4*)mc_s)[i] = make_uint4(0, 0, 0, 0);
     uint4 rec[ROUNDS];
     uint32_t dr[ROUNDS];  // bucket | rank inside (wave, bucket) << 16
     uint32_t pc[KB];
@@ -958,21 +977,22 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #pragma unroll
     for (int k = 0; k < KB; k++) pc[k] = npc[k];
     if (tile + t_step < t_end) request(tile + t_step);
-    lds_barrier();  // the counts are zero
+    // (this wave's entries: counts zero since the previous scatter block's offsets step, the offsets in their high
+    // halves — which this wave's stores of that block have read by now, program order — ride along untouched)
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
       const uint32_t i = wbase + r * 64 + lane;
-      const bool ok = i < n;
-      const uint32_t d = tile_bin(g, rec[r].x, i >= nL);
+      const bool ok = i < ncam;
+      const uint32_t d = tile_bin(g, rec[r].x);
       uint32_t rank = 0;
 #ifndef ESVIO_ABL_NORANK  // (measurement builds, tools/build_variant.sh + tools/scatter_ablation.sh: what the kernel costs without its parts)
 #pragma unroll
       for (int half = 0; half < 2; half++) {
         if (ok && (lane >> 5) == half) {
-          uint2* q = mc_s + wave * nbp + d;
+          uint2* q = mc_s + wave * nbcp + d;
           atomicOr(&q->x, hbit);  // (no return value: ds_or_b32; the LDS takes a wave's instructions in
           const uint2 v = *q;      //  order: the read sees every lane's bit)
-          rank = v.y + __popc(v.x & hlt);
+          rank = (v.y & 0xffffu) + __popc(v.x & hlt);
           // the group's lowest lane: count it, clear the mask for the next round
           if ((v.x & hlt) == 0) *q = make_uint2(0u, v.y + __popc(v.x));
         }
@@ -983,19 +1003,19 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #endif
       dr[r] = d | (rank << 16);
     }
-    lds_barrier();
+    lds_barrier();  // every wave's counts are final — and every wave's stores of the previous scatter block have read bin_base
     // first position of (this block, wave, bucket): bucket start + earlier groups + earlier blocks of
-    // the group + earlier waves of the block
+    // the group (bin_base) + earlier waves of the block (the entry's high half); the counts go back to zero
 #pragma unroll
     for (int k = 0; k < KB; k++) {
       const int d = threadIdx.x + k * kTileScatterThreads;
-      if (d < nb) {
+      if (d < nbc) {
         bin_base[d] = bstart[k] + pc[k];
         uint32_t acc = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-          const uint32_t t = mc_s[w * nbp + d].y;
-          mc_s[w * nbp + d].y = acc;
+          const uint32_t t = mc_s[w * nbcp + d].y & 0xffffu;
+          mc_s[w * nbcp + d].y = acc << 16;
           acc += t;
         }
       }
@@ -1006,15 +1026,16 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #pragma unroll
       for (int r = 0; r < ROUNDS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
-        if (i < n) {
+        if (i < ncam) {
           const uint32_t d = dr[r] & 0xffffu;
+          const uint32_t pos = bin_base[d] + (mc_s[wave * nbcp + d].y >> 16) + (dr[r] >> 16);
 #if defined(ESVIO_ABL_NOWRITE)
-          if (bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16) == 0xffffffffu)  // (never: the address is still computed)
+          if (pos == 0xffffffffu)  // (never: the address is still computed)
 #endif
 #if defined(ESVIO_ABL_COALESCED)
-          part2[i + ((bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16)) >> 31)] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
+          part2[ioff + i + (pos >> 31)] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
 #else
-          part2[bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16)] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
+          part2[pos] = tile_rec_pack(rec[r], g.tw, g.th, twsh, sec_base);
 #endif
         }
       }
@@ -1022,9 +1043,9 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
 #pragma unroll
       for (int r = 0; r < ROUNDS; r++) {
         const uint32_t i = wbase + r * 64 + lane;
-        if (i < n) {
+        if (i < ncam) {
           const uint32_t d = dr[r] & 0xffffu;
-          part[bin_base[d] + mc_s[wave * nbp + d].y + (dr[r] >> 16)] = rec[r];
+          part[bin_base[d] + (mc_s[wave * nbcp + d].y >> 16) + (dr[r] >> 16)] = rec[r];
         }
       }
     }
@@ -1035,21 +1056,24 @@ void launch_tile_scatter(hipStream_t s, const EventRec* evL, uint32_t nL, const 
                          const TileGeom& g, const TileScratch& sc, EventRec* part, const uint32_t* warp_xy) {
   const uint32_t n = nL + nR;
   if (!n) return;
-  const uint32_t nblk = tile_scatter_blocks(n), group = tile_hist_group(nblk);
-  const bool big = tile_scatter_events_per_block(n) == 4096u;
-  const uint32_t grid = std::min<uint32_t>(nblk, kTileScatterMaxGrid);
-  const unsigned lds = (unsigned)(((g.nbins + 63) & ~63) * 36);
+  const TileSplit sp = tile_split(nL, nR);
+  // workgroups per camera in proportion to its scatter blocks; the left camera's share a multiple of 8 when both have
+  // some (the hardware deals workgroups to the 8 XCDs round-robin by index: a workgroup's index inside its camera
+  // then names the same XCD)
+  const uint32_t grid = std::min<uint32_t>(sp.nblk(), kTileScatterMaxGrid);
+  uint32_t gridL = sp.nblkR == 0 ? grid : sp.nblkL == 0 ? 0u : (uint32_t)((uint64_t)grid * sp.nblkL / sp.nblk());
+  if (sp.nblkL && sp.nblkR) {
+    if (grid >= 16) gridL = std::min(std::max(8u, (gridL + 4u) & ~7u), grid - 8u);
+    else gridL = std::min(std::max(1u, gridL), grid - 1u);
+  }
+  const unsigned lds = (unsigned)(((g.nt_cam + 1 + 63) & ~63) * 36);
 #define ESVIO_TILE_SCATTER(R, M)                                                                          \
   launch_k(k_tile_scatter<R, M>, dim3(grid), dim3(kTileScatterThreads), lds, s, (const uint4*)evL, nL,    \
-           (const uint4*)evR, nR, g, group, nblk, (const uint32_t*)sc.P, (const uint32_t*)sc.C,           \
+           (const uint4*)evR, nR, g, sp, gridL, (const uint32_t*)sc.P, (const uint32_t*)sc.C,             \
            (const uint32_t*)sc.totals, (uint4*)part, sc.tile_off, sc.tile_order, warp_xy, (const uint32_t*)sc.meta)
-  if (warp_xy) {
-    if (big) ESVIO_TILE_SCATTER(16, true);
-    else ESVIO_TILE_SCATTER(8, true);
-  } else {
-    if (big) ESVIO_TILE_SCATTER(16, false);
-    else ESVIO_TILE_SCATTER(8, false);
-  }
+  static_assert(kTileScatterEvents == 8 * kTileScatterThreads, "8 rounds of 64 events per wave");
+  if (warp_xy) ESVIO_TILE_SCATTER(8, true);
+  else ESVIO_TILE_SCATTER(8, false);
 #undef ESVIO_TILE_SCATTER
 }
 

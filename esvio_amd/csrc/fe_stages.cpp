@@ -203,7 +203,7 @@ int ensure_part_capacity(esvio_fe_ctx* c, size_t n, bool mc) {
   }
   if (mc && !c->d_warp)  // the motion-compensated overload: 4 B per event for the warped pixels
     if (int rc = dev_alloc(c, &c->d_warp, c->part_cap)) return rc;
-  const size_t nblk_cap = (c->part_cap + 2047) / 2048;  // (2048 events per scatter block at least)
+  const size_t nblk_cap = (c->part_cap + 2047) / 2048 + 2;  // (2048 events per scatter block at least; each camera's last block may be short)
   const size_t head = (size_t)3 * kTileMaxBins + 64 + 4 * (size_t)kTileMaxGroups;
   const size_t need = head + (nblk_cap + 2 * (size_t)kTileMaxGroups) * kTileMaxBins;
   if (need > c->tile_cap) {
@@ -220,7 +220,7 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
                      double2* L2, double2* S2, uint8_t* arc_touched, const McParams* mc) {
   const uint32_t n = nL + nR;
   if (int rc = ensure_part_capacity(c, n, mc != nullptr)) return rc;
-  const size_t nblk_cap = (c->part_cap + 2047) / 2048;
+  const size_t nblk_cap = (c->part_cap + 2047) / 2048 + 2;
   const size_t head = (size_t)3 * kTileMaxBins + 64 + 4 * (size_t)kTileMaxGroups;
   TileScratch sc;
   sc.meta = c->d_tile + 3 * kTileMaxBins + 32;  // (the 32 free words behind tile_order)
@@ -238,7 +238,7 @@ int sae_update_tiled(esvio_fe_ctx* c, const EventRec* evL, uint32_t nL, const Ev
     }
     {
       ScopedKernel k(c, K_TILE_SCAN, 0);  // (the count matrices: not in SURVEY's accounting)
-      launch_tile_scan(cur_stream(c), n, c->tgeom, sc, c->d_rejected);
+      launch_tile_scan(cur_stream(c), nL, nR, c->tgeom, sc, c->d_rejected);
     }
     {
       ScopedKernel k(c, K_TILE_SCATTER, (uint64_t)n * 24);  // the partition's own traffic: 16 B in, 8 B out (16 for wide records)
