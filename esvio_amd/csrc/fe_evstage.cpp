@@ -423,6 +423,10 @@ static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t
 int stager_begin(esvio_fe_ctx* c, const esvio_fe_event* left, size_t nL, const esvio_fe_event* right, size_t nR,
                  int dma_groups, int* slot_out, bool by_camera) {
   if (!c->trace) return stager_begin_impl(c, left, nL, right, nR, dma_groups, slot_out, by_camera);
+  {  // (the stager's one-time set-up — stream, events, threads: ~9 ms — is not part of a batch's figure)
+    EventStager* st = nullptr;
+    if (int rc = stager_get(c, &st)) return rc;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = stager_begin_impl(c, left, nL, right, nR, dma_groups, slot_out, by_camera);
   if (c->stager)

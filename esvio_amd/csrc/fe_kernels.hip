@@ -671,9 +671,13 @@ __global__ __launch_bounds__(kTileHistThreads) void k_tile_hist(const uint4* __r
       }
     }
     if (k + 1 < group) request(k + 1);
+#ifndef ESVIO_ABL_HIST_NOCOUNT  // (measurement build: the kernel as a pure read of the records)
 #pragma unroll
     for (int j = 0; j < UE; j++)
       if (bins[j] != 0xffffffffu) atomicAdd(&hme[bins[j]], 1u);
+#else
+    if (bins[0] == 0xfffffff0u) hme[0] = bins[UE - 1];
+#endif
     lds_barrier();
     if (live)
       for (int i = threadIdx.x; i < nbc; i += kTileHistThreads) {
@@ -1124,7 +1128,11 @@ __device__ __forceinline__ void tile_apply_body(
   }
   for (int p = threadIdx.x; p < npx; p += kTileApplyThreads) {
     const int gx = x0 + (p & (g.tw - 1)), gy = y0 + (p >> twsh);
+#ifdef ESVIO_ABL_APPLY_NOLOAD
+    Ls[p] = make_double2((double)gx, (double)gy);
+#else
     Ls[p] = (gx < g.W && gy < g.H) ? L2[cam * P + (size_t)gy * g.W + gx] : make_double2(0, 0);
+#endif
     Sidx[2 * p] = 0;
     Sidx[2 * p + 1] = 0;
   }
@@ -1155,6 +1163,10 @@ __device__ __forceinline__ void tile_apply_body(
       const bool pol = Rec::pol(cur[k]);
       const double t = Rec::time(cur[k], sec_base);
       unsigned long long m = __ballot(valid);
+#ifdef ESVIO_ABL_APPLY_NOMATCH  // (measurement builds, WRONG results)
+      m &= self;
+      if (false)
+#endif
 #pragma unroll
       for (int b = 0; b < kPixBits; b++) {
         const int sx = ((int)(pix << (31 - b))) >> 31;  // -1 where the bit is set, else 0
@@ -1191,6 +1203,9 @@ __device__ __forceinline__ void tile_apply_body(
       __asm__ volatile("" : "+s"(rm[k]), "+s"(wm[k]), "+v"(ra[k]), "+v"(wa[k]));
     }
     bool gave_up = false;
+#ifdef ESVIO_ABL_APPLY_NOTICKET  // (measurement build, WRONG results: the turns' LDS sections in no particular order)
+    if (false)
+#endif
     for (uint32_t spins = 0;;) {
       const uint32_t d =
           __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1253,8 +1268,18 @@ __device__ __forceinline__ void tile_apply_body(
       const double prev_opp = (flg[k] & 8u) ? to_in[k] : (pol ? fb[k].x : fb[k].y);
       const bool pass = (flg[k] & 1u) && ((tk[k] > __dadd_rn(prev_same, thr)) || (prev_opp > prev_same));
       const uint32_t pos = (turn * kTileTurn + k) * 64u + (uint32_t)lane + 1u;
-      if (pass) atomicMax(&Sidx[2 * pixk[k] + (pol ? 1 : 0)], pos);
-      if (flg[k] & 16u) atomicOr(&touched[pixk[k] >> 4], 1u << (2u * (pixk[k] & 15u) + (pol ? 1u : 0u)));
+#ifdef ESVIO_ABL_APPLY_NOPOST
+      if (pass && pos == 0xffffffffu)
+#else
+      if (pass)
+#endif
+        atomicMax(&Sidx[2 * pixk[k] + (pol ? 1 : 0)], pos);
+#ifdef ESVIO_ABL_APPLY_NOPOST
+      if ((flg[k] & 16u) && pos == 0xffffffffu)
+#else
+      if (flg[k] & 16u)
+#endif
+        atomicOr(&touched[pixk[k] >> 4], 1u << (2u * (pixk[k] & 15u) + (pol ? 1u : 0u)));
     }
   }
   __syncthreads();
@@ -1280,7 +1305,11 @@ __device__ __forceinline__ void tile_apply_body(
   for (int q = 0; q < kPer; q++) {
     const int p = threadIdx.x + q * kTileApplyThreads;
     const uint32_t tb = sb[q] & 3u;
+#ifdef ESVIO_ABL_APPLY_NOWB
+    if (p >= npx || !tb || tb != 7u) continue;
+#else
     if (p >= npx || !tb) continue;
+#endif
     const int gx = x0 + (p & (g.tw - 1)), gy = y0 + (p >> twsh);
     const size_t k = cam * P + (size_t)gy * g.W + gx;
     L2[k] = Ls[p];
