@@ -1099,14 +1099,14 @@ __device__ __forceinline__ void tile_apply_body(
     const uint32_t* __restrict__ tile_order, const TileGeom& g, double2* __restrict__ L2, double2* __restrict__ S2,
     double thr, uint8_t* __restrict__ arc_touched, int* __restrict__ err, uint32_t spin_limit, uint32_t sec_base) {
   typedef TileRec<COMPACT> Rec;
-  // LDS (dynamic, sized by the tile): Ls[npx] double2 | Sidx[2 npx] (1 + position of the last
-  // passing event) | touched[npx / 16] (one bit per (pixel, polarity))  = 24 B + 2 bits per pixel:
-  // 12 KiB for 32x16, 48 KiB for 64x32
+  // LDS (dynamic, sized by the tile): Ls[npx] double2 | Sidx[2 npx], per (pixel, polarity): 0 = no event of the
+  // bucket, 1 = events but none that passed, 2 + position of the last passing event = 24 B per pixel: 12 KiB for
+  // 32x16, 48 KiB for 64x32.  (Round 6: "touched" was a bitmap of its own, set by a second LDS atomic per event —
+  // the ablation, profiles/r06_sae_chain_ablations.md, put the two atomics at 12 us of the kernel's 55-72.)
   extern __shared__ double2 tile_lds[];
   const int npx = g.tw * g.th;
   double2* Ls = tile_lds;
   uint32_t* Sidx = (uint32_t*)(Ls + npx);
-  uint32_t* touched = Sidx + 2 * npx;
   __shared__ uint32_t s_done;
   const uint32_t tile = tile_order[blockIdx.x];
   const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
@@ -1136,7 +1136,6 @@ __device__ __forceinline__ void tile_apply_body(
     Sidx[2 * p] = 0;
     Sidx[2 * p + 1] = 0;
   }
-  for (int i = threadIdx.x; i < npx / 16; i += kTileApplyThreads) touched[i] = 0;
   if (threadIdx.x == 0) s_done = 0;
   __syncthreads();
   constexpr int NW = kTileApplyThreads / 64;
@@ -1267,19 +1266,15 @@ __device__ __forceinline__ void tile_apply_body(
       const double prev_same = (flg[k] & 4u) ? ts_in[k] : (pol ? fb[k].y : fb[k].x);
       const double prev_opp = (flg[k] & 8u) ? to_in[k] : (pol ? fb[k].x : fb[k].y);
       const bool pass = (flg[k] & 1u) && ((tk[k] > __dadd_rn(prev_same, thr)) || (prev_opp > prev_same));
-      const uint32_t pos = (turn * kTileTurn + k) * 64u + (uint32_t)lane + 1u;
+      // one LDS atomic per event that matters: the chunk's last event of a (pixel, polarity) marks the pair as
+      // touched (1), a passing event leaves 2 + its position; the maximum keeps the last passing one
+      const uint32_t pos = (turn * kTileTurn + k) * 64u + (uint32_t)lane;
 #ifdef ESVIO_ABL_APPLY_NOPOST
-      if (pass && pos == 0xffffffffu)
+      if ((pass || (flg[k] & 16u)) && pos == 0xffffffffu)
 #else
-      if (pass)
+      if (pass || (flg[k] & 16u))
 #endif
-        atomicMax(&Sidx[2 * pixk[k] + (pol ? 1 : 0)], pos);
-#ifdef ESVIO_ABL_APPLY_NOPOST
-      if ((flg[k] & 16u) && pos == 0xffffffffu)
-#else
-      if (flg[k] & 16u)
-#endif
-        atomicOr(&touched[pixk[k] >> 4], 1u << (2u * (pixk[k] & 15u) + (pol ? 1u : 0u)));
+        atomicMax(&Sidx[2 * pixk[k] + (pol ? 1 : 0)], pass ? pos + 2u : 1u);
     }
   }
   __syncthreads();
@@ -1294,11 +1289,10 @@ __device__ __forceinline__ void tile_apply_body(
     const int p = threadIdx.x + q * kTileApplyThreads;
     sb[q] = 0;
     if (p < npx) {
-      const uint32_t tb = (touched[p >> 4] >> (2 * (p & 15))) & 3u;
       const uint32_t s0 = Sidx[2 * p], s1 = Sidx[2 * p + 1];
-      sb[q] = tb | (tb && s0 ? 4u : 0u) | (tb && s1 ? 8u : 0u);
-      r0[q] = Rec::load(part, (sb[q] & 4u) ? beg + s0 - 1u : beg);
-      r1[q] = Rec::load(part, (sb[q] & 8u) ? beg + s1 - 1u : beg);
+      sb[q] = (s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s0 >= 2u ? 4u : 0u) | (s1 >= 2u ? 8u : 0u);
+      r0[q] = Rec::load(part, (sb[q] & 4u) ? beg + s0 - 2u : beg);
+      r1[q] = Rec::load(part, (sb[q] & 8u) ? beg + s1 - 2u : beg);
     }
   }
 #pragma unroll
@@ -1342,7 +1336,7 @@ void launch_tile_apply(hipStream_t s, const EventRec* part, uint32_t n, const Ti
                        double2* L2, double2* S2, double filter_threshold, uint8_t* arc_touched, int* err,
                        uint32_t spin_limit) {
   const int npx = g.tw * g.th;
-  const unsigned lds = (unsigned)(npx * 24 + npx / 4 + 16);
+  const unsigned lds = (unsigned)(npx * 24 + 16);
   // a turn is 256 events: with a few turns per bucket 4 waves are plenty and many blocks fit a CU;
   // with thousands of events per bucket 8 waves (measured at 6.7 M events, 1841 buckets: 73 us with
   // 512 threads, 82 with 256, 112 with 1024; turns of 2 / 4 / 8 chunks at 512 threads: 90 / 73 / 111)
