@@ -834,7 +834,14 @@ def main():
                               lk_accum=args.lk_accum)
 
         def c5_run(profile):
-            ft5 = FE.FeatureTracker(cfg5)
+            if profile:  # (as in the C3 kernel pass: one launch per kernel and frame, nothing beside it)
+                os.environ["ESVIO_FE_NO_CHAIN"] = "1"
+                os.environ["ESVIO_FE_NO_CAMSPLIT"] = "1"
+            try:
+                ft5 = FE.FeatureTracker(cfg5)
+            finally:
+                os.environ.pop("ESVIO_FE_NO_CHAIN", None)
+                os.environ.pop("ESVIO_FE_NO_CAMSPLIT", None)
             ft5.reserve(max(b[0].n for b in bat), max(b[1].n for b in bat), host_batches=False)
             if args.host_threads > 1:
                 ft5.set_host_threads(args.host_threads)
@@ -863,14 +870,16 @@ def main():
         # SURVEY 8d's per-event / per-pixel accounting of the step: ingest 16 + SAE update 32 B/event, render 17 B/px/camera
         alg5 = 48 * per5 + 17 * 1280 * 720 * 2
         kk = {}
-        for name, bpl in (("k_tile_hist", 16 * per5), ("k_tile_scatter", 24 * per5), ("k_tile_apply", 32 * per5),
+        # (bytes per launch = the step's bytes over the launches the step made: one per kernel in the profiled run)
+        for name, bps in (("k_tile_hist", 16 * per5), ("k_tile_scatter", 24 * per5), ("k_tile_apply", 32 * per5),
                           ("k_time_surface4", 17 * 1280 * 720 * 2), ("k_arc_map", None), ("k_arc_ev", None),
                           ("k_lk_f32" if args.lk_accum == 2 else "k_lk", None)):
             v = ks5.get(name)
             if v and v["launches"]:
                 us = v["ms"] / v["launches"] * 1e3
                 kk[name] = dict(avg_launch_us=round(us, 2), launches=v["launches"])
-                if bpl:
+                if bps:
+                    bpl = bps * ns5 / v["launches"]
                     kk[name].update(alg_bytes_per_launch=int(bpl), achieved_GBs=round(bpl / us / 1e3, 1),
                                     frac=round(bpl / us / 1e3 / HBM_PEAK_GBS, 4))
         c5_leg = dict(workload="%s: stereo 1280x720 scene stream, 100 Mev/s per camera, %g Hz batches, plain calls, device-resident, "
@@ -880,7 +889,8 @@ def main():
                       alg_bytes_per_step=int(alg5), alg_GBs=round(alg5 * ns5 / dt5 / 1e9, 1),
                       alg_frac_of_hbm_peak=round(alg5 * ns5 / dt5 / 1e9 / HBM_PEAK_GBS, 4), kernels=kk,
                       note="a side figure at BASELINE C5's shape on one GPU, never `value`; kernels: live HIP-event pairs of a second "
-                           "run of the same three steps")
+                           "run of the same three steps with one launch per kernel and frame and nothing beside it "
+                           "(ESVIO_FE_NO_CHAIN / _NO_CAMSPLIT, like `kernels`); the timed steps run the plain call's real schedule")
 
     # ---- CPU baseline: the oracle (single-threaded port of the reference path) on a bounded sample
     cpu = None

@@ -7,7 +7,7 @@ TAG=${TAG:-r02}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
-CMD="python bench.py --steps 40 --warmup 5 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass"
+CMD="python bench.py --steps 40 --warmup 5 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass --no-sae-pass"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- $CMD > $O/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/plain -o plain -- $CMD --no-pipeline --no-chain > $O/plain.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- $CMD --no-pipeline --no-chain > $O/fetch.log 2>&1
@@ -20,14 +20,14 @@ python tools/timeline.py $T > $R/gpurun_out/${TAG}_bench_c3_replay_timeline.txt 
 grep -h '"value"' $O/trace.log $O/plain.log | cut -c1-160
 # the DEFAULT schedule at the headline rate over a long timed region (200 steps, one pass): union-busy per
 # step from the trace against the ms_per_step the same process prints
-CMDH="python bench.py --steps 200 --warmup 20 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass"
+CMDH="python bench.py --steps 200 --warmup 20 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass --no-sae-pass"
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/head -o head -- $CMDH > $O/head.log 2>&1
 TH=$(find $O/head -name "*.db" | head -1)
 python tools/rocprof_summary.py --trace $TH --out $R/gpurun_out/${TAG}_bench_headline --note "$TAG, the default bench schedule over 200 timed steps: $CMDH; ms_per_step printed by the same process: $(grep -h -o '"ms_per_step": [0-9.]*' $O/head.log | head -1)" > /dev/null
 python tools/timeline.py $TH > $R/gpurun_out/${TAG}_bench_headline_timeline.txt 2>&1
 grep -h '"value"' $O/head.log | cut -c1-200; head -8 $R/gpurun_out/${TAG}_bench_headline_timeline.txt
 rm -rf $O/head
-CMD5="python bench.py --width 1280 --height 720 --rate 1e8 --steps 12 --warmup 3 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass"
+CMD5="python bench.py --width 1280 --height 720 --rate 1e8 --steps 12 --warmup 3 --repeats 1 --cpu-frames 0 --no-profile-pass --no-host-pass --no-sae-pass"
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- $CMD5 > $O/c5.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE -d $O/c5f -o c5f -- $CMD5 > $O/c5f.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE -d $O/c5w -o c5w -- $CMD5 > $O/c5w.log 2>&1
