@@ -1,7 +1,11 @@
 """Committed regression vectors (tests/golden/scene_192x144.npz and scene_192x144_f32.npz — one per LK
 accumulation mode — made by tests/golden/make_golden.py
 from the CPU oracle — the reference has no fixtures and cannot run here).  CPU: the oracle still
-reproduces them.  GPU: the HIP path reproduces them bit for bit through the C ABI."""
+reproduces them.  GPU: the HIP path reproduces them bit for bit through the C ABI.
+At BASELINE C3's own size (640x480, the bench stream) the committed fixture is a set of SHA-256 digests of the same
+quantities (tests/golden/c3_640x480_digests.json, tests/golden/make_c3_digests.py)."""
+import importlib.util
+import json
 import os
 
 import numpy as np
@@ -62,3 +66,40 @@ def test_gpu_reproduces_golden(fixture):
         for name, p in zip(("L0", "L1", "S0", "S1"), ft.detector.get_sae(cam)):
             assert np.array_equal(p, z["sae_cam%d_%s" % (cam, name)])
     ft.close()
+
+
+def _c3():
+    spec = importlib.util.spec_from_file_location("make_c3_digests", os.path.join(GDIR, "make_c3_digests.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m, json.load(open(os.path.join(GDIR, "c3_640x480_digests.json")))
+
+
+def _same_digests(got, want, tag):
+    assert len(got) == len(want)
+    for f, (g, w) in enumerate(zip(got, want)):
+        diff = [k for k in w if g[k] != w[k]]
+        assert not diff, (tag, "frame", f, diff)
+
+
+@pytest.mark.parametrize("lk_accum", [2, 1])
+def test_oracle_reproduces_c3_digests(oracle, lk_accum):
+    """8 frames of the bench stream at 640x480: inputs, time surfaces, corner flags and every result vector hash to
+    the committed digests"""
+    m, ref = _c3()
+    assert (ref["W"], ref["H"], ref["seed"]) == (m.W, m.H, m.SEED)
+    tr = oracle.Tracker(oracle.make_config(m.W, m.H, lk_accum=lk_accum, **ref["cfg"]))
+    got = m.run(lambda t, L, R, pub: tr.track_event(t, L, R, pub), tr.time_surface, lambda L: tr.detector().corner_flags(L))
+    _same_digests(got, ref["modes"][str(lk_accum)], ("oracle", lk_accum))
+    assert got[-1]["n_left"] > 100 and got[-1]["n_right"] > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lk_accum", [2, 1])
+def test_gpu_reproduces_c3_digests(lk_accum):
+    from esvio_amd import frontend as FE
+    m, ref = _c3()
+    ft = FE.FeatureTracker(FE.make_config(m.W, m.H, lk_accum=lk_accum, **ref["cfg"]))
+    got = m.run(lambda t, L, R, pub: ft.trackEvent(t, L, R, pub), ft.gettimesurface, ft.detector.isCorner)
+    ft.close()
+    _same_digests(got, ref["modes"][str(lk_accum)], ("gpu", lk_accum))
