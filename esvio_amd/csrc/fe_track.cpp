@@ -1127,7 +1127,13 @@ struct TrackCall {
         // the left-camera bookkeeping below run under the stereo LK of the new corners
         HIPCHK(c, hipEventRecord(c->ev_sel_host, cur_stream(c)));
         if (int rc = finalize_pending(c)) return rc;  // (its results live where this launch writes)
-        if (int rc = finalize_right(c)) return rc;    // (idle time: k_select is running)
+        // (idle time: k_select is running — but only if the previous frame's stereo LK is over; else tails() runs
+        // that frame's right-camera tail, after this frame's own left-camera bookkeeping: waiting HERE was 37-77 us
+        // of every published call once the unpublished frame's call had become short, bench.py --call-phases)
+        if (!c->pend_right.active || c->pend_right.left.empty() ||
+            hipEventQuery(c->ev_lks_done[c->pend_right.set]) != hipErrorNotReady)
+          if (int rc = finalize_right(c)) return rc;
+        (void)hipGetLastError();
         sub(3);
         // stereo LK of the new corners only (count known on the device)
         if (split_right) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_right_ready, 0));  // (the right image)
@@ -1181,11 +1187,24 @@ struct TrackCall {
                                       c->cur_time - c->prev_time, c->cur_pts.size());
     lap(7);
     tail_lap(0);
-    if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners,
-    if (int rc = finalize_right(c)) return rc;    //  or the previous unpublished frame's whole tail)
-    tail_lap(1);
     const bool lazy = c->lazy_new && detect;      // leave this frame's new corners to the next call
     const bool defer_right = c->lazy_new && !PUB_THIS_FRAME;  // ... or its whole right-camera tail
+    // The previous published frame's new corners are completed here — unless this frame itself returns without its
+    // right-camera tail and their stereo LK (main stream, behind that frame's selection: ~80 us) is still running:
+    // the next call completes them before it runs this frame's tail, in the same order (their map entries are what
+    // that tail's velocities read).  Waiting here held the call 40 us on every cycle whose speculative temporal LK
+    // had finished early, and the published call that follows starts when this one ends (bench.py --call-phases,
+    // profiles/r06_replay_cycle_floor.md).
+    bool pending_later = false;
+    if (defer_right && c->pend.active && !c->pend_right.active) {
+      pending_later = hipEventQuery(c->ev_lknew_done) == hipErrorNotReady;
+      (void)hipGetLastError();
+    }
+    if (!pending_later) {
+      if (int rc = finalize_pending(c)) return rc;  // (the previous published frame's new corners,
+      if (int rc = finalize_right(c)) return rc;    //  or the previous unpublished frame's whole tail)
+    }
+    tail_lap(1);
     if (defer_right) {
       // (returns with the stereo LK in flight)
     } else {
