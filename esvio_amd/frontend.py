@@ -380,8 +380,7 @@ class FeatureTracker:
         self._tr = Tracks()
         for k, a in self._bufs.items():
             setattr(self._tr, k, a.ctypes.data)
-        for k in self._bufs:
-            setattr(self, k, self._bufs[k][:0])
+        self._copy = False
 
     def close(self):
         self._hd.close()
@@ -402,15 +401,31 @@ class FeatureTracker:
                 C.byref(measurements), C.byref(self._tr)))
         return self._take(copy)
 
+    _LEFT = frozenset(("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"))
+    _RIGHT = frozenset(("ids_right", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity"))
+    _RESULTS = tuple(sorted(_LEFT | _RIGHT))
+
     def _take(self, copy):
-        nl_, nr_ = self._tr.n_left, self._tr.n_right
-        for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity"):
-            v = self._bufs[k][:nl_]
-            setattr(self, k, v.copy() if copy else v)
-        for k in ("ids_right", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity"):
-            v = self._bufs[k][:nr_]
-            setattr(self, k, v.copy() if copy else v)
+        """the result members (.ids, .cur_pts, ...) are cut out of the call's output buffers when they are READ
+        (__getattr__ below), not after every call: a replaying caller that looks at none of them pays nothing for
+        them — nine slices and attribute stores were ~3 us of Python between two track calls"""
+        d = self.__dict__
+        for k in self._RESULTS:
+            d.pop(k, None)
+        self._copy = copy
         return self
+
+    def __getattr__(self, name):  # (only reached when the attribute is not set: a result member not read yet)
+        if name in FeatureTracker._LEFT:
+            v = self._bufs[name][:self._tr.n_left]
+        elif name in FeatureTracker._RIGHT:
+            v = self._bufs[name][:self._tr.n_right]
+        else:
+            raise AttributeError(name)
+        if self._copy:
+            v = v.copy()
+        self.__dict__[name] = v
+        return v
 
     def trackImage(self, cur_time, img_left, img_right, PUB_THIS_FRAME=True, copy=True):
         """FeatureTracker::trackImage (feature_tracker.cpp:164-338); the handle's width/height/
