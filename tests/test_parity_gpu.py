@@ -130,6 +130,31 @@ def test_sae_segment_lengths_around_the_wave_path(oracle, path, monkeypatch):
     ft.close()
 
 
+@pytest.mark.parametrize("nL,nR", [(0, 5000), (5000, 0), (1, 1), (63, 65), (2047, 2049), (2048, 2048), (4096, 1),
+                                   (2049, 6145), (40000, 3), (0, 1)])
+def test_sae_partition_block_boundaries(oracle, nL, nR):
+    """the partition cuts each camera's array into scatter blocks of 2048 events of its own (round 6): array lengths
+    on, just below and just above the block size, one array empty, one event — and a few hundred events outside the
+    sensor in either camera — planes and the rejected count as the oracle's, over three batches"""
+    W, H = 346, 260
+    rng = np.random.default_rng(1000 * nL + nR)
+    ft = _mk(W, H)
+    det = oracle.Detector(W, H)
+    t0 = 1_700_000_000_000_000
+    for b in range(3):
+        L = uniform_batch(W, H, nL, t0 + b * 33333, 33333, rng)
+        R = uniform_batch(W, H, nR, t0 + b * 33333, 33333, rng)
+        for a in (L, R):  # every 17th event outside the sensor
+            if len(a):
+                a["x"][::17] = W + (np.arange(len(a["x"][::17])) % 5)
+        rej = ft.detector.createSAE_stereo(L, R)
+        want = det.create_sae(0, L) + det.create_sae(1, R)
+        assert rej == want == len(L["x"][::17]) + len(R["x"][::17])
+        for cam in (0, 1):
+            _planes_equal(ft.detector.get_sae(cam), det.get_sae(cam))
+    ft.close()
+
+
 @pytest.mark.parametrize("case", ["span_below", "span_at", "span_above", "big_nsec", "forced_wide", "reversed"])
 def test_sae_partition_record_formats(oracle, case, monkeypatch):
     """the tiled update partitions 8-byte records (tile-local pixel, polarity, seconds relative to the
