@@ -928,8 +928,9 @@ __global__ __launch_bounds__(kTileScatterThreads) void k_tile_scatter(
   // ---- the workgroup's scatter blocks.  Workgroups go to the 8 XCDs round-robin and each XCD has its own
   // L2; the runs two consecutive scatter blocks write into a bucket are neighbours in memory (a few
   // records each, less than a cache line), so neighbours should meet in ONE L2: XCD x takes the x-th
-  // contiguous eighth of the camera's scatter blocks, its workgroups take them interleaved.  (gridL is a multiple
-  // of 8 whenever both cameras have workgroups, so a workgroup's index inside its camera keeps its XCD.)
+  // contiguous eighth of the camera's scatter blocks, its workgroups take them interleaved.  (From 16 workgroups on
+  // gridL is a multiple of 8, so a workgroup's index inside its camera keeps its XCD; below that the split is still a
+  // partition of the blocks, only without the affinity.)
   const uint32_t wg = blockIdx.x - (right ? gridL : 0u), nwg = right ? gridDim.x - gridL : gridL;
   uint32_t t_first, t_end, t_step;
   if (nwg < 8) {
