@@ -1038,6 +1038,9 @@ int esvio_fe_pack_track_records(esvio_fe_handle c, float* out, int32_t* n_rows) 
   if (!c || !out) return ESVIO_FE_EINVAL;
   if (c->pend_right.active) {  // (lazy mode, packing a frame that was not to be published)
     HIPCHK(c, hipSetDevice(c->dev));
+    // (in this order: the previous published frame's new corners — which that frame's call may have left to "the next
+    // call" while their stereo LK was running — extend the map this frame's right-camera velocities read)
+    if (int rc = finalize_pending(c)) return rc;
     if (int rc = finalize_right(c)) return rc;
   }
   const int rows = 2 * std::max(c->cfg.max_cnt, 1);
@@ -1311,8 +1314,9 @@ int esvio_fe_unregister_host_buffer(void* p) {
 }
 
 int esvio_fe_debug_inject(esvio_fe_handle c, int mask) {
-  if (!c || mask < 0 || mask > 15) return ESVIO_FE_EINVAL;
+  if (!c || mask < 0 || mask > 31) return ESVIO_FE_EINVAL;
   c->lim = esvio_fe_ctx::WaitLimits();
+  c->lazy_late = (mask & ESVIO_FE_FAULT_LAZY_LATE) != 0;
   if (mask & ESVIO_FE_FAULT_TICKET) c->lim.ticket = 0;
   if (mask & ESVIO_FE_FAULT_LOOKBACK) c->lim.lookback = 0;
   if (mask & ESVIO_FE_FAULT_SPECULATIVE) c->lim.poll = 0;

@@ -240,6 +240,7 @@ struct esvio_fe_ctx {
     uint32_t lookback = kSpinLookback, ticket = kSpinTicket;
     unsigned long long poll = kTicksPoll, chain = kTicksChain;
   } lim;
+  bool lazy_late = false;  // ESVIO_FE_FAULT_LAZY_LATE (test): the lazy completions always at their latest point
   uint64_t n_spec_expired = 0, n_chain_expired = 0;  // speculative / chained temporal LK launches redone
   EventRec* d_evp[kPrefetchDepth] = {};  // host-event staging, one per prefetch lane (stager off)
   size_t evp_cap[kPrefetchDepth] = {};

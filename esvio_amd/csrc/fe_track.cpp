@@ -1131,7 +1131,7 @@ struct TrackCall {
         // that frame's right-camera tail, after this frame's own left-camera bookkeeping: waiting HERE was 37-77 us
         // of every published call once the unpublished frame's call had become short, bench.py --call-phases)
         if (!c->pend_right.active || c->pend_right.left.empty() ||
-            hipEventQuery(c->ev_lks_done[c->pend_right.set]) != hipErrorNotReady)
+            (!c->lazy_late && hipEventQuery(c->ev_lks_done[c->pend_right.set]) != hipErrorNotReady))
           if (int rc = finalize_right(c)) return rc;
         (void)hipGetLastError();
         sub(3);
@@ -1197,7 +1197,7 @@ struct TrackCall {
     // profiles/r06_replay_cycle_floor.md).
     bool pending_later = false;
     if (defer_right && c->pend.active && !c->pend_right.active) {
-      pending_later = hipEventQuery(c->ev_lknew_done) == hipErrorNotReady;
+      pending_later = c->lazy_late || hipEventQuery(c->ev_lknew_done) == hipErrorNotReady;
       (void)hipGetLastError();
     }
     if (!pending_later) {

@@ -255,7 +255,7 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-FAULT_TICKET, FAULT_LOOKBACK, FAULT_SPECULATIVE, FAULT_CHAINED = 1, 2, 4, 8
+FAULT_TICKET, FAULT_LOOKBACK, FAULT_SPECULATIVE, FAULT_CHAINED, FAULT_LAZY_LATE = 1, 2, 4, 8, 16
 
 
 def _events_arg(ev):
@@ -538,7 +538,8 @@ class FeatureTracker:
 
     def debug_inject(self, mask):
         """make device-side waits expire on demand (FAULT_TICKET | FAULT_LOOKBACK | FAULT_SPECULATIVE |
-        FAULT_CHAINED; 0: normal bounds)"""
+        FAULT_CHAINED; 0: normal bounds), or replay mode's lazy completions always happen at their latest point
+        (FAULT_LAZY_LATE)"""
         self._hd.check(self._hd.L.esvio_fe_debug_inject(self._hd.h, int(mask)))
 
     def debug_counters(self):

@@ -60,6 +60,11 @@ int esvio_fe_host_nullspace(const double* systems, int n, int lanes, double* f12
 #define ESVIO_FE_FAULT_LOOKBACK 2
 #define ESVIO_FE_FAULT_SPECULATIVE 4
 #define ESVIO_FE_FAULT_CHAINED 8
+/* replay mode's lazy completions as late as they may ever happen, whether or not the stereo LK they wait for is over: a
+ * lazily returning call always leaves the previous published frame's new corners to the next call, a published call
+ * always runs the previous frame's right-camera tail in its own tail — the order of the two, not their timing, is what
+ * results depend on */
+#define ESVIO_FE_FAULT_LAZY_LATE 16
 int esvio_fe_debug_inject(esvio_fe_handle h, int mask);
 int esvio_fe_debug_counters(esvio_fe_handle h, uint64_t out4[4]);
 /* What the plain calls (nothing announced, not lazy: the reference node's pattern) did since create:

@@ -131,3 +131,65 @@ def test_fault_mask_from_the_environment(oracle, monkeypatch):
     with pytest.raises(FE.FrontendError, match="rc=-5"):
         ft.detector.createSAE_stereo(L, R)
     ft.close()
+
+
+@pytest.mark.parametrize("late", [False, True])
+def test_lazy_completions_at_their_latest_point_and_packed_in_between(oracle, late):
+    """Replay mode leaves two things for later: the right-camera entries of the corners a published frame has just
+    detected, and the whole right-camera tail of a frame that publishes nothing.  WHEN they are completed depends on
+    whether the stereo LK they wait for is over (round 6); results may only depend on their ORDER — the new corners
+    first: they extend the map the next frame's right-camera velocities read.  FAULT_LAZY_LATE pushes every completion
+    to the latest point it can ever take place at; esvio_fe_pack_track_records after EVERY call (published or not) and
+    esvio_fe_finish now and then complete them from outside the track calls.  Every frame's vectors as the oracle's."""
+    from esvio_amd.node import pack_track_records
+    W, H = 346, 260
+    rng = np.random.default_rng(17)
+    s = SceneStream(W, H, rate=2.5e6, seed=43, n_rect=10, size=(25.0, 80.0))
+    batches = [s.next_batch()[:2] for _ in range(40)]
+    pubs = [bool(rng.integers(0, 3) != 0) for _ in batches]
+    kw = dict(max_cnt=120, min_dist=10, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(True)
+    ft.set_launch_thread(True)
+    if late:
+        ft.debug_inject(FE.FAULT_LAZY_LATE)
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
+    announced = 0
+    for f, (L, R) in enumerate(batches):
+        while announced < min(f + 3, len(batches) - 1):
+            announced += 1
+            Ln, Rn = batches[announced]
+            ft.set_next_batch(event_times(Ln)[-1], Ln, Rn, pubs[announced])
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, pubs[f])
+        r = tr.track_event(t, L, R, pubs[f])
+        assert np.array_equal(ft.ids, r.ids) and np.array_equal(ft.cur_pts.view(np.uint32), r.cur_pts.view(np.uint32)), f
+        mode = int(rng.integers(0, 3))
+        if mode == 0:  # (completes an unpublished frame's tail from outside; a published frame's rows need nothing)
+            rows = ft.pack_track_records()
+            want = _oracle_rows(r, 120)
+            assert np.array_equal(rows.view(np.uint32), want.view(np.uint32)), ("rows", f)
+        elif mode == 1:
+            ft.finish()
+            for k in ("ids_right", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity"):
+                a, b = getattr(ft, k), getattr(r, k)
+                assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (f, k)
+    ft.finish()
+    for k in ("ids_right", "cur_right_pts", "cur_un_right_pts", "right_pts_velocity"):
+        a, b = getattr(ft, k), getattr(r, k)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), ("end", k)
+    assert len(ft.ids) > 40
+    ft.close()
+
+
+def _oracle_rows(r, max_cnt):
+    """the node's PointCloud rows (stereo_event_tracker_node.cpp:273-329) of an oracle result"""
+    from esvio_amd.node import pack_track_records
+
+    class T:
+        pass
+    t = T()
+    for k in ("ids", "track_cnt", "cur_pts", "cur_un_pts", "pts_velocity", "ids_right", "cur_right_pts", "cur_un_right_pts",
+              "right_pts_velocity"):
+        setattr(t, k, getattr(r, k))
+    return pack_track_records(t, max_cnt)
