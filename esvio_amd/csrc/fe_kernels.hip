@@ -1979,6 +1979,13 @@ void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg) {
 }
 
 // ============================================================================ pyramidal LK
+// points (= waves) per block.  (Four: 122 KB of LDS per block in the float-order mode, one block per CU.  One —
+// 40 KB, a straggler holds a SIMD, not a CU — measured slower on average in rounds 5 and 6 (+4 %), two +1 %:
+// tools/build_variant.sh lk2 -DESVIO_LK_WAVES=2, KERNELS.md.)
+#ifndef ESVIO_LK_WAVES
+#define ESVIO_LK_WAVES 4
+#endif
+constexpr int kLkWaves = ESVIO_LK_WAVES;
 // cv::calcOpticalFlowPyrLK's LKTrackerInvoker [OpenCV video/lkpyramid.cpp], one wave64 per point,
 // all levels — and optionally the forward AND the backward call of a forward/backward check — in
 // one launch.  The loop is instruction-latency bound (one wave per SIMD, <=30 dependent
@@ -2835,7 +2842,7 @@ template <int ACCUM>
 __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (*regJ_s)[kLkRegStore], uint32_t acc_t,
                                                float* acc_ta, const LkLaneF32* lnf) {
   const int wave = threadIdx.x >> 6, lane = lane_id();
-  const int pt = blockIdx.x * 4 + wave;
+  const int pt = blockIdx.x * kLkWaves + wave;
   const int n = a.n_ptr ? *a.n_ptr : a.n_max;
   if (pt >= a.n_max) return;
   if (pt >= n) {
@@ -2926,15 +2933,15 @@ __device__ __forceinline__ void lk_kernel_body(const LkKernelArgs& a, uint32_t (
   }
 }
 
-__global__ __launch_bounds__(256) void k_lk(LkKernelArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegStore];
+__global__ __launch_bounds__(64 * kLkWaves) void k_lk(LkKernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[kLkWaves][kLkRegStore];
   lk_kernel_body<1>(a, regJ_s, 0u, nullptr, nullptr);
 }
 // lk_accum 2: float sums in the reference build's order (see lk_float_sums_A / _b)
-__global__ __launch_bounds__(256) void k_lk_f32(LkKernelArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[4][kLkRegStore];
-  __shared__ __attribute__((aligned(16))) int term_all[4][kF32TermWords];
-  __shared__ __attribute__((aligned(16))) float term_a[4][kLkTermWordsA];
+__global__ __launch_bounds__(64 * kLkWaves) void k_lk_f32(LkKernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t regJ_s[kLkWaves][kLkRegStore];
+  __shared__ __attribute__((aligned(16))) int term_all[kLkWaves][kF32TermWords];
+  __shared__ __attribute__((aligned(16))) float term_a[kLkWaves][kLkTermWordsA];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int i = lane; i < kF32TermWords; i += 64) term_all[wave][i] = 0;  // (the words a segment does not use stay 0)
   // (the A table: only the slots no pixel lane writes — the fifth slot of the vector chains' rows — need their zeros)
@@ -2994,9 +3001,9 @@ void launch_lk(hipStream_t s, const LkArgs& f, const LkArgs* b, float2* back_pts
   a.gate_ptr = f.gate_ptr;
   a.gate_val = f.gate_val;
   if (f.accum == 2)
-    launch_k(k_lk_f32, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
+    launch_k(k_lk_f32, dim3((a.n_max + kLkWaves - 1) / kLkWaves), dim3(64 * kLkWaves), 0, s, a);
   else
-    launch_k(k_lk, dim3((a.n_max + 3) / 4), dim3(256), 0, s, a);
+    launch_k(k_lk, dim3((a.n_max + kLkWaves - 1) / kLkWaves), dim3(64 * kLkWaves), 0, s, a);
 }
 
 // ============================================================================ Arc*
