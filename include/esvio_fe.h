@@ -282,8 +282,9 @@ int esvio_fe_set_auto_exchange(esvio_fe_handle h, int on);
  * the stereo LK of the corners it has just detected.  Everything else in its results is complete
  * (the node's PointCloud never contains corners of track_cnt 1, node:289); the right-camera entries
  * of those new corners (ids_right / cur_right_pts / cur_un_right_pts / right_pts_velocity tails) are
- * appended at the start of the next call's right-camera bookkeeping — before they can influence
- * anything — or by esvio_fe_finish, after which the state is bit-identical to the eager sequence.
+ * appended by a later call's right-camera bookkeeping — the next call's, or, when that call itself
+ * returns lazily while their stereo LK is still running, the one after it: always before they can
+ * influence anything — or by esvio_fe_finish, after which the state is bit-identical to the eager sequence.
  * A call with pub_this_frame == 0 (the node publishes nothing of it, stereo_event_tracker_node.cpp
  * :262) returns without waiting for its stereo LK at all: its left-camera members are complete, its
  * right-camera members (feature_tracker.cpp:475-575) still show the previous frame until the next
