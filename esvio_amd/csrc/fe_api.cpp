@@ -835,6 +835,20 @@ int esvio_fe_host_stage_copy(void* dst, const void* src, size_t len) {
   return ESVIO_FE_OK;
 }
 
+int esvio_fe_host_stage_pack(void* dst, const void* src, size_t len, uint32_t* base_sec) {
+  uint32_t b = 0;
+  if (len && (!dst || !src)) return ESVIO_FE_EINVAL;
+  const bool ok = stager_pack_bytes((uint8_t*)dst, (const uint8_t*)src, len, &b);
+  if (base_sec) *base_sec = b;
+  return ok ? 1 : 0;
+}
+
+int esvio_fe_staging_counters(esvio_fe_handle c, uint64_t out4[4]) {
+  if (!c || !out4) return ESVIO_FE_EINVAL;
+  stager_counters(c, out4);
+  return ESVIO_FE_OK;
+}
+
 int esvio_fe_host_nullspace(const double* systems, int n, int lanes, double* f12, int32_t* redone) {
   if (n < 0 || (n && (!systems || !f12))) return ESVIO_FE_EINVAL;
   const int r = host::host_nullspace(systems, n, lanes, f12);

@@ -58,11 +58,51 @@ inline void stage_copy(uint8_t* dst, const uint8_t* src, size_t len) {
 #endif
   std::memcpy(dst, src, len);
 }
+
+// The same chunk as 8 bytes per event, when its events allow it: x | y << 16 as they are, nsec (30 bits) | polarity
+// (!= 0, as every kernel reads it) << 30 | (sec - base) << 31 with base = the chunk's first event's second — so a
+// chunk may cross ONE second boundary forwards; anything else (stamps going backwards across a second, nsec >= 2^30)
+// and the caller copies the chunk raw instead.  Returns whether the packed form was written (dst: the first len / 2
+// bytes of the chunk's place in the pinned buffer); *base_sec: the second the offsets count from.
+inline bool stage_pack(uint8_t* dst, const uint8_t* src, size_t len, uint32_t* base_sec) {
+  const size_t n = len / 16;
+  if (!n || (len & 15u) || ((uintptr_t)dst & 15u)) return false;
+  uint64_t a0;
+  std::memcpy(&a0, src, 8);
+  const uint32_t base = (uint32_t)(a0 >> 32);
+  uint64_t bad = 0;
+  size_t i = 0;
+  auto pack1 = [&](const uint8_t* p) -> uint64_t {
+    uint64_t a, b;  // a = x | y << 16 | sec << 32;  b = nsec | polarity byte << 32 | padding
+    std::memcpy(&a, p, 8);
+    std::memcpy(&b, p + 8, 8);
+    const uint32_t nsec = (uint32_t)b, off = (uint32_t)(a >> 32) - base;
+    bad |= (uint64_t)(nsec >> 30) | (uint64_t)(off >> 1);
+    const uint32_t hi = nsec | (((b >> 32) & 0xffu) ? 1u << 30 : 0u) | (off << 31);
+    return (a & 0xffffffffull) | ((uint64_t)hi << 32);
+  };
+#ifdef ESVIO_STAGE_NT
+  for (; i + 2 <= n; i += 2) {
+    const uint64_t lo = pack1(src + 16 * i), hi = pack1(src + 16 * i + 16);
+    _mm_stream_si128((__m128i*)(dst + 8 * i), _mm_set_epi64x((long long)hi, (long long)lo));
+  }
+#endif
+  for (; i < n; i++) {
+    const uint64_t v = pack1(src + 16 * i);
+    std::memcpy(dst + 8 * i, &v, 8);
+  }
+#ifdef ESVIO_STAGE_NT
+  _mm_sfence();
+#endif
+  *base_sec = base;
+  return bad == 0;
+}
 constexpr size_t kChunkBytes = 256 * 1024;
 constexpr int kMaxGroups = 8;
 
 struct Group {
   size_t off = 0, len = 0;  // byte range of the slot's buffers that one DMA moves
+  uint32_t first_chunk = 0; // its first chunk (Slot::chunk / Slot::desc index)
   std::atomic<uint32_t> chunks_left{0};
   std::atomic<bool> dma_enq{false};  // the group's DMA has been enqueued (at least once)
 };
@@ -94,6 +134,12 @@ struct Slot {
   std::atomic<bool> left_enq{false}; // the left array's DMA is enqueued and copiedL recorded
   uint32_t n_left_chunks = 0;        // chunks [0, n_left_chunks) are the left array's (by_camera)
   bool pull = false;                 // the groups go to the device by k_stage_pull instead of by DMA (a plain call's batch)
+  // ... with the chunks packed to 8 bytes per event where their events allow it (by_camera staging: chunks of one
+  // size, a group = whole chunks of one array): one {base second, packed?} pair per chunk, pinned, read by the kernel
+  bool pack = false;
+  uint32_t pack_epc = 0;             // events per chunk
+  uint32_t* desc = nullptr;          // [2 * desc_cap]
+  size_t desc_cap = 0;
   bool in_use = false;
   std::atomic<int> state{0};  // 0 idle, 1 staging, 2 every DMA enqueued and `copied` recorded, -1 failed
   Group grp[kMaxGroups];
@@ -134,6 +180,8 @@ struct EventStager {
     if (warm_pin && warm_dev && hipMemcpyAsync(warm_dev, warm_pin, 16, hipMemcpyHostToDevice, stream) != hipSuccess) (void)hipGetLastError();
     if (warm_ev && hipEventRecord(warm_ev, stream) != hipSuccess) (void)hipGetLastError();
   }
+  std::atomic<uint64_t> chunks_packed{0}, chunks_raw{0};  // chunks of packing slots that went out packed / raw (esvio_fe_staging_counters)
+  bool pack_enabled = true;  // (ESVIO_FE_STAGE_PACK=0, A/B and tests: every chunk raw)
   uint64_t begin_ns = 0, left_ns = 0, left_calls = 0, pin_ns = 0;  // (trace) by-camera staging: stager_begin, stager_attach_left
 
   // one DMA on the copy stream.  Never more than two in flight: the third makes the runtime bring up another
@@ -166,7 +214,10 @@ struct EventStager {
       // a batch the calling thread waits for: the device pulls the group out of the pinned buffer itself
       // (k_stage_pull: lower latency than a copy engine, and the copy engines' state stays out of the call)
       (void)hipGetLastError();  // (whatever this thread's earlier calls left behind is not this launch's)
-      launch_stage_pull(stream, s.pin + g.off, (uint8_t*)s.dev + g.off, g.len);
+      if (s.pack)
+        launch_stage_pull_packed(stream, s.pin + g.off, (uint8_t*)s.dev + g.off, g.len, s.desc + 2 * (size_t)g.first_chunk, s.pack_epc);
+      else
+        launch_stage_pull(stream, s.pin + g.off, (uint8_t*)s.dev + g.off, g.len);
       if (hipGetLastError() != hipSuccess) s.state.store(-1, std::memory_order_release);
     } else {
       // an announced batch, staged whole frames ahead: one DMA (a 5 MB pull kernel on the copy stream costs the
@@ -207,9 +258,24 @@ struct EventStager {
     Chunk& ch = s.chunk[idx];
     uint8_t q = 0;
     if (!ch.st.compare_exchange_strong(q, 1, std::memory_order_acq_rel)) return;  // (somebody else's already)
-    stage_copy(s.pin + ch.off, ch.src, ch.len);
+    stage_chunk(s, idx);
     uint8_t taken = 1;
     if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) chunk_done(s, ch);
+  }
+
+  // (idempotent like everything a chunk goes through: a chunk done twice writes the same bytes and the same descriptor)
+  void stage_chunk(Slot& s, uint32_t idx) {
+    Chunk& ch = s.chunk[idx];
+    if (s.pack) {
+      uint32_t base = 0;
+      const bool packed = stage_pack(s.pin + ch.off, ch.src, ch.len, &base);
+      if (!packed) stage_copy(s.pin + ch.off, ch.src, ch.len);
+      s.desc[2 * idx] = base;
+      s.desc[2 * idx + 1] = packed ? 1u : 0u;
+      (packed ? chunks_packed : chunks_raw).fetch_add(1, std::memory_order_relaxed);
+      return;
+    }
+    stage_copy(s.pin + ch.off, ch.src, ch.len);
   }
 
   // the calling thread while it waits for the LEFT array of slot k (by_camera): only that array's chunks — a
@@ -262,7 +328,7 @@ struct EventStager {
     for (uint32_t i = 0; i < n; i++) {
       Chunk& ch = s.chunk[i];
       if (ch.st.load(std::memory_order_acquire) != 1) continue;
-      stage_copy(s.pin + ch.off, ch.src, ch.len);
+      stage_chunk(s, i);
       uint8_t taken = 1;
       if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) {
         chunk_done(s, ch);
@@ -296,6 +362,16 @@ struct EventStager {
 };
 
 void stager_copy_bytes(uint8_t* dst, const uint8_t* src, size_t len) { stage_copy(dst, src, len); }
+bool stager_pack_bytes(uint8_t* dst, const uint8_t* src, size_t len, uint32_t* base_sec) { return stage_pack(dst, src, len, base_sec); }
+void stager_counters(esvio_fe_ctx* c, uint64_t out4[4]) {
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  if (EventStager* st = c->stager) {
+    out4[0] = st->batches;
+    out4[1] = st->bytes_staged;
+    out4[2] = st->chunks_packed.load(std::memory_order_relaxed);
+    out4[3] = st->chunks_raw.load(std::memory_order_relaxed);
+  }
+}
 
 // what a spinning RANSAC helper does between jobs (host::ransac_pool_set_idle_work): one chunk
 static bool stager_idle_work(void* arg) {
@@ -357,6 +433,7 @@ static int stager_get(esvio_fe_ctx* c, EventStager** out) {
         return fail(c, ESVIO_FE_EHIP, "hipEventCreate (event staging) failed");
       }
     }
+    if (const char* v = getenv("ESVIO_FE_STAGE_PACK")) st->pack_enabled = atoi(v) != 0;
     for (int i = 0; i < c->stage_threads; i++) st->threads.emplace_back([st] { st->worker(); });
     c->stager = st;
     stager_share_pool(c);  // the RANSAC helpers, spinning between jobs anyway, take chunks as well
@@ -396,6 +473,23 @@ static int slot_capacity(esvio_fe_ctx* c, Slot& s, size_t n) {
   return 0;
 }
 
+// the slot's chunk table (and, beside it, the pinned descriptor pairs of a packed batch) for `chunks` chunks
+static int slot_chunks(esvio_fe_ctx* c, Slot& s, size_t chunks) {
+  if (chunks + 4 > s.chunk_cap) {  // (+: a chunk never straddles the two source arrays)
+    s.chunk_cap = chunks + 4 + chunks / 4;
+    s.chunk.reset(new Chunk[s.chunk_cap]);
+  }
+  if (s.chunk_cap > s.desc_cap) {
+    if (s.desc) (void)hipHostFree(s.desc);
+    s.desc = nullptr;
+    s.desc_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&s.desc, s.chunk_cap * 8, hipHostMallocDefault));
+    c->n_allocs++;
+    s.desc_cap = s.chunk_cap;
+  }
+  return 0;
+}
+
 // esvio_fe_reserve: every idle slot sized for batches of n events
 int stager_reserve(esvio_fe_ctx* c, size_t n_events) {
   if (!stager_enabled(c)) return 0;
@@ -405,10 +499,7 @@ int stager_reserve(esvio_fe_ctx* c, size_t n_events) {
     if (!s.in_use) {
       if (int rc = slot_capacity(c, s, n_events)) return rc;
       const size_t chunks = (n_events * 16 + kChunkBytes / 4 - 1) / (kChunkBytes / 4);  // (the by-camera chunk size)
-      if (chunks + 4 > s.chunk_cap) {
-        s.chunk_cap = chunks + 4 + chunks / 4;
-        s.chunk.reset(new Chunk[s.chunk_cap]);
-      }
+      if (int rc = slot_chunks(c, s, chunks)) return rc;
     }
   return 0;
 }
@@ -455,6 +546,7 @@ static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t
   s.n_left_groups = 0;
   s.n_left_chunks = 0;
   s.pull = by_camera || dma_groups > 1;  // (a batch the calling thread waits for)
+  s.pack = false;
   s.left_enq.store(false, std::memory_order_release);
   st->bytes_staged += n * 16;
   st->batches++;
@@ -520,14 +612,19 @@ static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t
     } else {
       split(lo, hi, std::min(dma_groups, kMaxGroups));
     }
-    if (chunks + 4 > s.chunk_cap) {  // (+: a chunk never straddles the two source arrays)
-      s.chunk_cap = chunks + 4 + chunks / 4;
-      s.chunk.reset(new Chunk[s.chunk_cap]);
+    if (int rc = slot_chunks(c, s, chunks)) {
+      s.in_use = false;
+      return rc;
     }
+    // by-camera staging of a batch the call waits for: chunks of one size, every group whole chunks of one array —
+    // what the packed form needs (k_stage_pull_packed finds an event's chunk by division)
+    s.pack = st->pack_enabled && by_camera && s.pull;
+    s.pack_epc = (uint32_t)(cb / 16);
     for (int g = 0; g < ng; g++) {
       const size_t a = ga[g], b = gb[g];
       s.grp[g].off = a;
       s.grp[g].len = b - a;
+      s.grp[g].first_chunk = nch;
       s.grp[g].dma_enq.store(false, std::memory_order_relaxed);
       uint32_t cnt = 0;
       for (size_t o = a; o < b;) {
@@ -753,6 +850,7 @@ void stager_destroy(esvio_fe_ctx* c) {
     if (s.main_done) (void)hipEventDestroy(s.main_done);
     if (s.dev) (void)hipFree(s.dev);
     if (s.pin) (void)hipHostFree(s.pin);
+    if (s.desc) (void)hipHostFree(s.desc);
   }
   delete st;
   c->stager = nullptr;

@@ -117,6 +117,8 @@ void stager_ptrs(esvio_fe_ctx* c, int slot, size_t nL, const EventRec** dL, cons
 void stager_drain(esvio_fe_ctx* c);
 void stager_destroy(esvio_fe_ctx* c);
 void stager_copy_bytes(uint8_t* dst, const uint8_t* src, size_t len);  // (test tap: a chunk's copy)
+bool stager_pack_bytes(uint8_t* dst, const uint8_t* src, size_t len, uint32_t* base_sec);  // (test tap: a chunk packed to 8 B per event)
+void stager_counters(esvio_fe_ctx* c, uint64_t out4[4]);  // {batches, bytes, chunks sent packed, chunks of packing batches sent raw}
 
 // ---------------------------------------------------------------- fe_track.cpp
 int prefetch_next(esvio_fe_ctx* c, bool wait_planes, bool must_take_first = false);

@@ -342,7 +342,9 @@ struct ArcArgs {
 };
 inline size_t arc_bitmap_words(int W, int H) { return ((size_t)2 * W * H + 31) / 32 + 64; }
 inline size_t arc_flag_bytes(int W, int H) { return (size_t)2 * W * H + 1024; }
-void launch_stage_pull(hipStream_t s, const void* pinned_src, void* dst, size_t bytes);  // H2D of staged events by a kernel
+void launch_stage_pull(hipStream_t s, const void* pinned_src, void* dst, size_t bytes);
+// ... of chunks of `epc` events each, packed to 8 bytes per event or raw as desc[chunk] = {base second, packed?} says
+void launch_stage_pull_packed(hipStream_t s, const void* pinned_src, void* dst, size_t bytes, const void* desc, uint32_t epc);  // H2D of staged events by a kernel
 void launch_arc_mark(hipStream_t s, const ArcArgs& a);  // per event: which (pixel, polarity) pairs occur
 void launch_arc_map(hipStream_t s, const ArcArgs& a);   // per touched pair (rings, L[!p] > L[p], TS, border)
 void launch_arc(hipStream_t s, const ArcArgs& a);       // per event, in stream order (needs the map)

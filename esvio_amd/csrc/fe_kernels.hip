@@ -3226,6 +3226,33 @@ __global__ __launch_bounds__(256) void k_stage_pull(const uint4* __restrict__ sr
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
+// ... and with the chunks PACKED by the staging threads (fe_evstage.cpp stage_pack: 8 bytes per event — x | y << 16,
+// nsec | polarity << 30 | (sec - the chunk's base second) << 31 — whenever a chunk's events allow it): half the bytes
+// over PCIe, unpacked into the 16-byte records every kernel reads while they are written to the device buffer.  One
+// descriptor per chunk of `epc` events says which form its slot of the pinned buffer holds; a packed chunk lies at the
+// start of the 16 * epc bytes its raw form would take.  (Polarity as the reference reads it, != 0; the record's three
+// padding bytes — which no kernel reads — come out as zero.)
+__global__ __launch_bounds__(256) void k_stage_pull_packed(const uint8_t* __restrict__ src, uint4* __restrict__ dst, size_t n,
+                                                           const uint2* __restrict__ desc, uint32_t epc) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t c = i / epc, j = i - c * epc;
+    const uint2 d = desc[c];
+    const uint8_t* base = src + c * (size_t)epc * 16;
+    if (d.y) {
+      const uint2 v = ((const uint2*)base)[j];
+      dst[i] = make_uint4(v.x, d.x + (v.y >> 31), v.y & 0x3fffffffu, (v.y >> 30) & 1u);
+    } else {
+      dst[i] = ((const uint4*)base)[j];
+    }
+  }
+}
+void launch_stage_pull_packed(hipStream_t s, const void* pinned_src, void* dst, size_t bytes, const void* desc, uint32_t epc) {
+  const size_t n = bytes / 16;
+  if (!n) return;
+  const unsigned grid = (unsigned)std::min<size_t>(64, (n + 255) / 256);
+  launch_k(k_stage_pull_packed, dim3(grid), dim3(256), 0, s, (const uint8_t*)pinned_src, (uint4*)dst, n, (const uint2*)desc, epc);
+}
 void launch_stage_pull(hipStream_t s, const void* pinned_src, void* dst, size_t bytes) {
   const size_t n = bytes / 16;  // (event records: always whole 16-byte units)
   if (!n) return;

@@ -93,6 +93,7 @@ TEST_SYMBOLS = [
     "esvio_fe_build_pyramid", "esvio_fe_debug_counters", "esvio_fe_debug_inject", "esvio_fe_device_memory",
     "esvio_fe_find_fundamental_mat_held", "esvio_fe_find_fundamental_mat_idle", "esvio_fe_find_fundamental_mat_mt",
     "esvio_fe_get_kernel_stats", "esvio_fe_host_hypot", "esvio_fe_host_nullspace", "esvio_fe_host_stage_copy",
+    "esvio_fe_host_stage_pack", "esvio_fe_staging_counters",
     "esvio_fe_kernel_count", "esvio_fe_kernel_name", "esvio_fe_latency_phase_name", "esvio_fe_latency_recent",
     "esvio_fe_latency_stats", "esvio_fe_lift_projective", "esvio_fe_plain_call_counters", "esvio_fe_ransac_stats",
     "esvio_fe_ransac_tail", "esvio_fe_reset_kernel_stats", "esvio_fe_set_profiling", "esvio_fe_set_sae",
@@ -541,6 +542,12 @@ class FeatureTracker:
         FAULT_CHAINED; 0: normal bounds), or replay mode's lazy completions always happen at their latest point
         (FAULT_LAZY_LATE)"""
         self._hd.check(self._hd.L.esvio_fe_debug_inject(self._hd.h, int(mask)))
+
+    def staging_counters(self):
+        """host batches staged / bytes / chunks that crossed PCIe packed to 8 B per event / chunks of such batches sent raw"""
+        out = (C.c_uint64 * 4)()
+        self._hd.check(self._hd.L.esvio_fe_staging_counters(self._hd.h, out))
+        return dict(batches=out[0], bytes=out[1], chunks_packed=out[2], chunks_raw=out[3])
 
     def debug_counters(self):
         out = (C.c_uint64 * 4)()

@@ -46,6 +46,14 @@ int esvio_fe_host_stage_copy(void* dst, const void* src, size_t len);
  * scheduled together, as the RANSAC loop solves its hypotheses — both must give the same bits.
  * *redone (may be NULL) = systems the lane form handed back to the one-at-a-time routine. */
 int esvio_fe_host_nullspace(const double* systems, int n, int lanes, double* f12, int32_t* redone);
+/* One chunk of a host batch as the staging threads pack it for a plain call's pull over PCIe (fe_evstage.cpp stage_pack):
+ * len bytes of 16-byte records at src -> len / 2 bytes at dst (16-byte aligned), 8 bytes per event: x | y << 16, then
+ * nsec | (polarity != 0) << 30 | (sec - *base_sec) << 31.  Returns 1 if every event fits that form (nsec < 2^30, second
+ * = the first event's or the one after), 0 if not (the chunk then travels raw; dst's contents are unspecified), < 0 on
+ * bad arguments. */
+int esvio_fe_host_stage_pack(void* dst, const void* src, size_t len, uint32_t* base_sec);
+/* {host batches staged, bytes staged, chunks that went to the device packed, chunks of packing batches that went raw} */
+int esvio_fe_staging_counters(esvio_fe_handle h, uint64_t out4[4]);
 
 /* ---- fault injection (tests) ----------------------------------------------------------- */
 /* Every device-side wait is bounded: a wave that gives up raises a host-visible flag and the call

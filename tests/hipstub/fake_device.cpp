@@ -17,6 +17,29 @@ void launch_stage_pull(hipStream_t s, const void* pinned_src, void* dst, size_t 
   hipstub_stream_end(s);
 }
 
+// ... of packed chunks (fe_evstage.cpp stage_pack): unpacked here as k_stage_pull_packed does
+void launch_stage_pull_packed(hipStream_t s, const void* pinned_src, void* dst, size_t bytes, const void* desc, uint32_t epc) {
+  hipstub_stream_begin(s);
+  const uint32_t* d = (const uint32_t*)desc;
+  const uint8_t* src = (const uint8_t*)pinned_src;
+  uint32_t* out = (uint32_t*)dst;
+  for (size_t i = 0; i < bytes / 16; i++) {
+    const size_t c = i / epc, j = i - c * epc;
+    const uint8_t* base = src + c * (size_t)epc * 16;
+    if (d[2 * c + 1]) {
+      uint32_t v[2];
+      std::memcpy(v, base + 8 * j, 8);
+      out[4 * i] = v[0];
+      out[4 * i + 1] = d[2 * c] + (v[1] >> 31);
+      out[4 * i + 2] = v[1] & 0x3fffffffu;
+      out[4 * i + 3] = (v[1] >> 30) & 1u;
+    } else {
+      std::memcpy(out + 4 * i, base + 16 * j, 16);
+    }
+  }
+  hipstub_stream_end(s);
+}
+
 void launch_compact(hipStream_t s, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, uint32_t*,
                     uint32_t* total, uint32_t*) {
   hipstub_stream_begin(s);

@@ -243,6 +243,53 @@ def test_stage_copy_copies_exactly_the_bytes_asked_for():
                 assert (buf[:base] == 0xA5).all() and (buf[base + n:] == 0xA5).all(), (n, so, do)
 
 
+def test_stage_pack_round_trip_and_refusals():
+    """the 8-byte form a plain call's host batch crosses PCIe in (fe_evstage.cpp stage_pack, unpacked on the device by
+    k_stage_pull_packed): x | y << 16, nsec | (polarity != 0) << 30 | (sec - base) << 31.  Every field a kernel reads
+    comes back (polarity as != 0, the record's padding bytes as zero: no kernel reads them — and a ROS message leaves
+    them uninitialised); a chunk whose stamps step back over a second, jump two, or carry an nsec no ros::Time has is
+    refused (it then travels raw)."""
+    from esvio_amd.events import EVENT_DTYPE
+    L = FE.load_library()
+    L.esvio_fe_host_stage_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(8)
+
+    def pack(ev):
+        raw = np.ascontiguousarray(ev).view(np.uint8).reshape(-1)
+        buf = np.zeros(len(raw) // 2 + 64, np.uint8)
+        off = (-buf.ctypes.data) % 16
+        base = C.c_uint32(0)
+        rc = L.esvio_fe_host_stage_pack(C.c_void_p(buf.ctypes.data + off), C.c_void_p(raw.ctypes.data), len(raw), C.byref(base))
+        return rc, base.value, buf[off:off + len(raw) // 2].view(np.uint32).reshape(-1, 2)
+
+    for n in (1, 2, 3, 4095, 4096, 4097):
+        ev = np.zeros(n, EVENT_DTYPE)
+        ev["x"], ev["y"] = rng.integers(0, 65536, n), rng.integers(0, 65536, n)
+        t = np.sort(rng.integers(0, 1_400_000_000, n)) + 1_700_000_000 * 10 ** 9 + 300_000_000  # crosses one second boundary
+        ev["sec"], ev["nsec"] = t // 10 ** 9, t % 10 ** 9
+        ev["polarity"] = rng.choice([0, 1, 255, 7], n)
+        raw = ev.view(np.uint8).reshape(-1, 16)
+        raw[:, 13:] = rng.integers(0, 256, (n, 3))  # garbage in the padding
+        rc, base, p = pack(ev)
+        assert rc == 1 and base == ev["sec"][0], (n, rc)
+        assert np.array_equal(p[:, 0], ev["x"].astype(np.uint32) | (ev["y"].astype(np.uint32) << 16))
+        assert np.array_equal(p[:, 1] & 0x3fffffff, ev["nsec"]) and np.array_equal((p[:, 1] >> 30) & 1, (ev["polarity"] != 0))
+        assert np.array_equal(base + (p[:, 1] >> 31), ev["sec"])
+    ev = np.zeros(64, EVENT_DTYPE)
+    ev["sec"], ev["nsec"] = 100, np.arange(64) * 1000
+    assert pack(ev)[0] == 1
+    for bad in ("back", "jump", "nsec"):
+        e2 = ev.copy()
+        if bad == "back":
+            e2["sec"][40] = 99
+        elif bad == "jump":
+            e2["sec"][40:] = 102
+        else:
+            e2["nsec"][63] = 1 << 30
+        assert pack(e2)[0] == 0, bad
+    assert L.esvio_fe_host_stage_pack(None, None, 16, None) < 0
+
+
 def test_host_hypot_is_cv_hypot():
     """cv::SVD's Jacobi rotations call hypot unqualified inside namespace cv, where lapack.cpp's own
     template (a * sqrt(1 + (b/a)^2)) hides libm's — so the library's rotations use that formula, in IEEE

@@ -239,3 +239,45 @@ def test_plain_calls_with_the_cameras_on_two_streams(oracle, monkeypatch, space,
     ft.close()
     for b in bufs:
         b.free()
+
+
+@pytest.mark.parametrize("pack", [1, 0])
+def test_plain_calls_from_pageable_memory_cross_pcie_packed(oracle, monkeypatch, pack):
+    """A plain call's batch in pageable host memory is staged by camera in 64 KiB chunks and pulled over PCIe by a
+    kernel; since round 6 the staging threads pack each chunk to 8 bytes per event where its events allow it and the
+    pull kernel unpacks it on the way into the device buffer (ESVIO_FE_STAGE_PACK=0: every chunk raw).  Batches with
+    garbage in the records' padding bytes and polarity bytes other than 0 / 1 (what a deserialised ROS message may
+    hold), one whose stamps cross a second boundary, one that steps BACK over one (those chunks travel raw): every
+    frame as the oracle's, and the counters say which form the chunks took."""
+    monkeypatch.setenv("ESVIO_FE_STAGE_PACK", str(pack))
+    W, H = 640, 480
+    rng = np.random.default_rng(23)
+    s = SceneStream(W, H, rate=4e6, seed=29, n_rect=12, size=(30.0, 90.0), t0_us=1_700_000_000_950_000)  # (frame 1 crosses a second)
+    batches = []
+    for f in range(8):
+        L, R, _ = s.next_batch()
+        for a in (L, R):
+            raw = a.view(np.uint8).reshape(-1, 16)
+            raw[:, 13:] = rng.integers(0, 256, (len(a), 3), dtype=np.uint8)
+            a["polarity"] = np.where(a["polarity"] != 0, rng.integers(1, 256, len(a)), 0)
+        batches.append((L, R))
+    # batch 5: the second half of the left array one second EARLIER (time reversal across a second boundary)
+    L5 = batches[5][0]
+    L5["sec"][len(L5) // 2:] -= 1
+    kw = dict(max_cnt=200, min_dist=10, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
+    for f, (L, R) in enumerate(batches):
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, f % 2 == 0)
+        _same(ft, tr.track_event(t, L, R, f % 2 == 0), ("packed" if pack else "raw", f))
+        for cam in (0, 1):
+            for a, b in zip(ft.detector.get_sae(cam), tr.detector().get_sae(cam)):
+                assert np.array_equal(a, b), (f, cam)
+    n = ft.staging_counters()
+    assert n["batches"] == len(batches)
+    if pack:
+        assert n["chunks_packed"] > 20 * len(batches) and 1 <= n["chunks_raw"] <= 40, n
+    else:
+        assert n["chunks_packed"] == 0 and n["chunks_raw"] == 0, n
+    ft.close()
