@@ -140,6 +140,7 @@ struct Slot {
   uint32_t pack_epc = 0;             // events per chunk
   uint32_t* desc = nullptr;          // [2 * desc_cap]
   size_t desc_cap = 0;
+  std::chrono::steady_clock::time_point t_begin;  // (trace) when stager_begin opened the batch for taking
   bool in_use = false;
   std::atomic<int> state{0};  // 0 idle, 1 staging, 2 every DMA enqueued and `copied` recorded, -1 failed
   Group grp[kMaxGroups];
@@ -181,6 +182,9 @@ struct EventStager {
     if (warm_ev && hipEventRecord(warm_ev, stream) != hipSuccess) (void)hipGetLastError();
   }
   std::atomic<uint64_t> chunks_packed{0}, chunks_raw{0};  // chunks of packing slots that went out packed / raw (esvio_fe_staging_counters)
+  // (trace) time inside stage_chunk, chunks, from a batch's opening to its chunk 0 being taken / its left array's last
+  // group / its last group being on its way
+  std::atomic<uint64_t> chunk_ns{0}, chunk_cnt{0}, first_take_ns{0}, left_sent_ns{0}, all_sent_ns{0};
   bool pack_enabled = true;  // (ESVIO_FE_STAGE_PACK=0, A/B and tests: every chunk raw)
   uint64_t begin_ns = 0, left_ns = 0, left_calls = 0, pin_ns = 0;  // (trace) by-camera staging: stager_begin, stager_attach_left
 
@@ -231,12 +235,14 @@ struct EventStager {
       bool all = true;
       for (int i = 0; i < s.n_left_groups; i++) all = all && s.grp[i].dma_enq.load(std::memory_order_acquire);
       if (all) {
+        if (c->trace) left_sent_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - s.t_begin).count());
         if (hipEventRecord(s.copiedL, stream) != hipSuccess) s.state.store(-1, std::memory_order_release);
         s.left_enq.store(true, std::memory_order_release);
       }
     }
   }
   void finish_batch(Slot& s) {  // every group's DMA is enqueued: the event the compute streams wait for
+    if (c->trace) all_sent_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - s.t_begin).count());
     const bool ok = hipEventRecord(s.copied, stream) == hipSuccess;
     int expect = 1;
     if (!ok)
@@ -258,7 +264,15 @@ struct EventStager {
     Chunk& ch = s.chunk[idx];
     uint8_t q = 0;
     if (!ch.st.compare_exchange_strong(q, 1, std::memory_order_acq_rel)) return;  // (somebody else's already)
-    stage_chunk(s, idx);
+    if (c->trace) {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (idx == 0) first_take_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t0 - s.t_begin).count());
+      stage_chunk(s, idx);
+      chunk_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+      chunk_cnt.fetch_add(1);
+    } else {
+      stage_chunk(s, idx);
+    }
     uint8_t taken = 1;
     if (ch.st.compare_exchange_strong(taken, 2, std::memory_order_acq_rel)) chunk_done(s, ch);
   }
@@ -653,6 +667,7 @@ static int stager_begin_impl(esvio_fe_ctx* c, const esvio_fe_event* left, size_t
     return fail(c, ESVIO_FE_EHIP, "hipEventRecord (event staging) failed");
   }
   s.n_chunks.store(nch, std::memory_order_release);
+  s.t_begin = std::chrono::steady_clock::now();
   s.state.store(nch ? 1 : 2, std::memory_order_release);  // (open for taking)
   if (nch) {
     st->pending->fetch_add((int)nch, std::memory_order_acq_rel);
@@ -833,6 +848,11 @@ void stager_destroy(esvio_fe_ctx* c) {
             "wait for the left array %.1f us (%llu by-camera batches), wait for the whole batch %.1f us; %llu DMAs went out without waiting for the one two before\n",
             st->begin_ns / 1e3 / st->batches, st->pin_ns / 1e3 / st->batches, st->left_calls ? st->left_ns / 1e3 / st->left_calls : 0.0,
             (unsigned long long)st->left_calls, st->wait_ns / 1e3 / st->batches, (unsigned long long)st->gate_expired.load());
+  if (c->trace && st->chunk_cnt.load())
+    fprintf(stderr, "[esvio_fe trace] host-event staging: %.2f us inside a chunk's copy / packing on average (%llu chunks), chunk 0 taken %.1f us after "
+            "the batch's opening, the left array's last group enqueued after %.1f us, the batch's after %.1f us\n",
+            st->chunk_ns.load() / 1e3 / st->chunk_cnt.load(), (unsigned long long)st->chunk_cnt.load(), st->first_take_ns.load() / 1e3 / st->batches,
+            st->left_sent_ns.load() / 1e3 / std::max<uint64_t>(1, st->left_calls), st->all_sent_ns.load() / 1e3 / st->batches);
   if (st->stream) {
     (void)hipStreamSynchronize(st->stream);
     (void)hipStreamDestroy(st->stream);

@@ -278,15 +278,25 @@ def test_stage_pack_round_trip_and_refusals():
     ev = np.zeros(64, EVENT_DTYPE)
     ev["sec"], ev["nsec"] = 100, np.arange(64) * 1000
     assert pack(ev)[0] == 1
-    for bad in ("back", "jump", "nsec"):
+    for k in list(range(40, 48)) + [61, 62, 63]:  # (both events of the loop's round, and the odd last one)
+        for bad in ("back", "jump", "nsec", "nsec_top"):
+            e2 = ev[:63].copy() if k < 63 else ev.copy()
+            k2 = min(k, len(e2) - 1)
+            if bad == "back":
+                e2["sec"][k2] = 99
+            elif bad == "jump":
+                e2["sec"][k2:] = 102
+            elif bad == "nsec":
+                e2["nsec"][k2] = 1 << 30
+            else:
+                e2["nsec"][k2] = (1 << 31) | 5
+            assert pack(e2)[0] == 0, (bad, k)
+    # one step forwards over a second is fine wherever it falls
+    for k in range(1, 64):
         e2 = ev.copy()
-        if bad == "back":
-            e2["sec"][40] = 99
-        elif bad == "jump":
-            e2["sec"][40:] = 102
-        else:
-            e2["nsec"][63] = 1 << 30
-        assert pack(e2)[0] == 0, bad
+        e2["sec"][k:] = 101
+        rc, base, p = pack(e2)
+        assert rc == 1 and base == 100 and np.array_equal(base + (p[:, 1] >> 31), e2["sec"]), k
     assert L.esvio_fe_host_stage_pack(None, None, 16, None) < 0
 
 
