@@ -1410,7 +1410,13 @@ __device__ __forceinline__ uint8_t ts_pixel(double2 s, double t_sync, double dec
   double v = 0.0;
   if (m > 0) {
     const double dt = __dsub_rn(t_sync, m);
+#if defined(ESVIO_ABL_TS_NOEXP)  // (measurement build: the render without its exp and its division)
+    v = dt * decay_sec;
+#elif defined(ESVIO_ABL_TS_NODIV)  // (... with a multiplication by 1 / decay instead of the division: NOT the reference's rounding)
+    v = exp(-dt * (1.0 / decay_sec));
+#else
     v = exp(-dt / decay_sec);
+#endif
     if (!ignore_polarity) v = pos ? v : -v;
   }
   const double sc = ignore_polarity ? __dadd_rn(__dmul_rn(v, 255.0), 0.0)

@@ -59,6 +59,19 @@ def main():
             print("  %-14s %8.2f us  (%.2f TB/s of its algorithmic bytes)" % (what, us, v["alg_bytes"] / v["launches"] / us / 1e6))
     print("  chain          %8.2f us = %.2f TB/s of 48 B/event = %.1f %% of 8 TB/s"
           % (tot, 48.0 * ev / a.iters / tot / 1e6, 48.0 * ev / a.iters / tot / 1e6 / 8 * 100))
+    # SAEtoTimeSurface of one camera on the planes the batches left (esvio_fe_sae_to_time_surface: the render + the
+    # image's way back to the host; the kernel's own time is the library's HIP-event pair)
+    ft.reset_kernel_stats()
+    t_sync = float(max(p.max() for p in ft.detector.get_sae(0)[2:]))  # (the newest event's time)
+    for i in range(a.iters):
+        ft.detector._ts(i & 1, t_sync)
+    st = ft.kernel_stats()
+    for k in ("k_time_surface4", "k_time_surface"):
+        v = st.get(k)
+        if v and v["launches"]:
+            us = v["ms"] / v["launches"] * 1e3
+            print("  %-14s %8.2f us  (%.2f TB/s of 17 B/pixel = %.1f %% of 8 TB/s), %d launches"
+                  % (k, us, 17.0 * W * H / us / 1e6, 17.0 * W * H / us / 1e6 / 8 * 100, v["launches"]))
     ft.close()
 
 
