@@ -160,7 +160,7 @@ inline bool make_tile_geom(int W, int H, TileGeom* g) {
 
 // events per scatter block.  (Until round 6: 4096 from 2^20 events on, in 16 rounds per wave — 212 VGPRs, two resident
 // blocks per CU; with one camera's buckets per table (below) the 8-round kernel's 33 KiB and 128 VGPRs let three run,
-// and at 6.7 M events 2048 measured 59-66 us against 70 for 4096, profiles/r06_partition.md.)
+// and at 6.7 M events 2048 measured 59-66 us against 70 for 4096, profiles/r06_scatter_grid_and_nt_store_sweep.txt.)
 constexpr uint32_t kTileScatterEvents = 2048;
 // The batch is [left array; right array], and every bucket belongs to one camera: a scatter block never mixes the two.
 // Scatter block b < nblkL owns the left events [b*TE, (b+1)*TE), block nblkL + b the right events [b*TE, (b+1)*TE) —
