@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--rate", type=float, default=5e6)
     ap.add_argument("--pinned", action="store_true")
     ap.add_argument("--device", action="store_true", help="the batches already in HBM (torch tensors)")
+    ap.add_argument("--gap-ms", type=float, default=0.0, help="sleep between the calls (a live sensor: 33 ms); the figure is then "
+                    "the mean time INSIDE the calls")
     a = ap.parse_args()
     W, H = 640, 480
     s = SceneStream(W, H, rate=a.rate, seed=12345)
@@ -58,11 +60,17 @@ def main():
                 ft.set_host_threads(int(os.environ.get("HT", "8")))
                 nmax = lambda k: max(b[k][1] if a.device else len(b[k]) for b in batches)  # noqa: E731
                 ft.reserve(nmax(0), nmax(1), host_batches=not a.device)
+                inside = 0.0
                 for i, (L, R, t) in enumerate(batches):
                     if i == a.warmup:
                         t0 = time.perf_counter()
+                        inside = 0.0
+                    tc = time.perf_counter()
                     ft.trackEvent(t, L, R, pubs[i], copy=False)
-                ms = (time.perf_counter() - t0) / a.steps * 1e3
+                    inside += time.perf_counter() - tc
+                    if a.gap_ms:
+                        time.sleep(a.gap_ms * 1e-3)
+                ms = (inside if a.gap_ms else time.perf_counter() - t0) / a.steps * 1e3
                 res[v].append(ms)
                 ft.close()
             finally:
