@@ -8,7 +8,7 @@ import pytest
 
 from esvio_amd import frontend as FE
 from esvio_amd.events import event_times
-from esvio_amd.synth import SceneStream
+from esvio_amd.synth import PoissonStream, SceneStream
 
 pytestmark = pytest.mark.gpu
 
@@ -280,4 +280,27 @@ def test_plain_calls_from_pageable_memory_cross_pcie_packed(oracle, monkeypatch,
         assert n["chunks_packed"] > 20 * len(batches) and 1 <= n["chunks_raw"] <= 40, n
     else:
         assert n["chunks_packed"] == 0 and n["chunks_raw"] == 0, n
+    ft.close()
+
+
+def test_plain_call_whose_groups_have_more_chunks_than_the_descriptor_cache(oracle):
+    """k_stage_pull_packed keeps a group's chunk descriptors in LDS — up to 1024 of them; a larger group reads them
+    from the pinned buffer as it goes.  9.3 M events per camera and batch (1280x720, 280 Mev/s: 2.8 times C5's rate)
+    make 1139 chunks per group: planes and results as the oracle's, every chunk packed."""
+    W, H = 1280, 720
+    s = PoissonStream(W, H, rate=2.8e8, seed=41)
+    kw = dict(max_cnt=120, min_dist=20, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    tr = oracle.Tracker(oracle.make_config(W, H, **kw))
+    for f in range(2):
+        L, R, _ = s.next_batch()
+        assert len(L) * 16 // 65536 // 2 > 1024 and len(R) * 16 // 65536 // 2 > 1024
+        t = event_times(L)[-1]
+        ft.trackEvent(t, L, R, True)
+        _same(ft, tr.track_event(t, L, R, True), ("large groups", f))
+        for cam in (0, 1):
+            for a, b in zip(ft.detector.get_sae(cam), tr.detector().get_sae(cam)):
+                assert np.array_equal(a, b), (f, cam)
+    n = ft.staging_counters()
+    assert n["batches"] == 2 and n["chunks_packed"] > 8000 and n["chunks_raw"] == 0, n
     ft.close()
