@@ -237,6 +237,17 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   };
   // the frame's own chain (LK, selection: few, latency-bound waves) outranks the prefetch stream's
   // wide kernels, which have a whole frame of slack
+  {
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
+      (void)hipGetLastError();
+      n_cu = 64;  // (unknown: assume a small device)
+    }
+    const int lk_blocks = (std::max(cfg->max_cnt, 1) + kLkPointsPerBlock - 1) / kLkPointsPerBlock;
+    c->n_cu = n_cu;
+    c->waits_fit_spec = lk_blocks + 2 <= n_cu;
+    c->waits_fit_chain = 2 * lk_blocks + 2 <= n_cu;
+  }
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   const bool streams_ok =

@@ -288,6 +288,15 @@ struct esvio_fe_ctx {
   // one word per prefetch lane: the serial number of the last prefetch sequence that has RUN there (LkArgs::gate_*)
   uint32_t* d_lane_gate = nullptr;
   uint32_t gate_seq = 0;
+  // LK launches whose waves WAIT on the device for another kernel's results (the speculative temporal launch for
+  // k_select's corners, a chained launch for its producer's points) hold their CU while they wait — in the float-order
+  // mode one workgroup of four points per CU.  If the waiting workgroups can fill the device, the kernel they wait for
+  // may find no CU: with max_cnt 1000 (250 workgroups per launch on 256 CUs) one step in ~20 ran into the wait's 20-40 ms
+  // bound and was redone (correct, but 40 ms).  So: a speculative launch only if one launch's workgroups leave two CUs
+  // free (k_select_mw's up to 160 KB of LDS need a CU without an LK workgroup), a chained one (two waiting launches at
+  // once) only if two do.  (max_cnt <= 1016 / <= 508 on MI355X's 256 CUs.)
+  int n_cu = 0;
+  bool waits_fit_spec = true, waits_fit_chain = true;
   uint32_t chain_seq = 0;
   bool chain_enabled = true;   // (ESVIO_FE_NO_CHAIN=1 turns it off: A/B measurements)
   bool cam_split_enabled = true;  // a plain call runs the two cameras' updates on two streams (ESVIO_FE_NO_CAMSPLIT=1: one)

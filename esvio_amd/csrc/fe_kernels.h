@@ -119,6 +119,13 @@ void launch_sae_apply_ev(hipStream_t s, const uint32_t* keys, const uint32_t* va
 // it, else the raw 16), then one block per bucket applies its events in stream order with the tile's
 // L planes in LDS (k_tile_apply).  Replaces key generation + 3 radix passes over (key, index) pairs +
 // a gathering apply: per event 16 B are read twice, 8 written and 8 read.
+// points (= waves) of an LK launch per workgroup; in the float-order mode a workgroup's 122 KB of LDS make it the only
+// one on its CU (fe_kernels.hip kLkWaves; what the host needs it for: esvio_fe_ctx::waits_fit_*)
+#ifndef ESVIO_LK_WAVES
+#define ESVIO_LK_WAVES 4
+#endif
+constexpr int kLkPointsPerBlock = ESVIO_LK_WAVES;
+
 struct TileGeom {
   int W, H;
   int tw, th;            // tile size in pixels (tw * th <= kTileMaxPx)

@@ -1988,10 +1988,7 @@ void launch_scharr(hipStream_t s, const PyrDesc* p, int nimg) {
 // points (= waves) per block.  (Four: 122 KB of LDS per block in the float-order mode, one block per CU.  One —
 // 40 KB, a straggler holds a SIMD, not a CU — measured slower on average in rounds 5 and 6 (+4 %), two +1 %:
 // tools/build_variant.sh lk2 -DESVIO_LK_WAVES=2, KERNELS.md.)
-#ifndef ESVIO_LK_WAVES
-#define ESVIO_LK_WAVES 4
-#endif
-constexpr int kLkWaves = ESVIO_LK_WAVES;
+constexpr int kLkWaves = kLkPointsPerBlock;  // (ESVIO_LK_WAVES, fe_kernels.h)
 // cv::calcOpticalFlowPyrLK's LKTrackerInvoker [OpenCV video/lkpyramid.cpp], one wave64 per point,
 // all levels — and optionally the forward AND the backward call of a forward/backward check — in
 // one launch.  The loop is instruction-latency bound (one wave per SIMD, <=30 dependent

@@ -355,7 +355,7 @@ int enqueue_spec_temporal(esvio_fe_ctx* c, const Inflight& nxt /* the next frame
   }
   // the frame after next, chained to this launch point by point (see esvio_fe_ctx::d_chain)
   const Inflight* nxt2 = nullptr;
-  if (c->chain_enabled && !nxt.pub && c->inflight.size() >= 2 && c->inflight[0].lane == nxt.lane &&
+  if (c->chain_enabled && c->waits_fit_chain && !nxt.pub && c->inflight.size() >= 2 && c->inflight[0].lane == nxt.lane &&
       !c->chain_valid)
     nxt2 = &c->inflight[1];
   if (nxt2) {
@@ -918,7 +918,7 @@ struct TrackCall {
         LkArgs f = make_lk(prevL, curL, zdev(c, pin.A), nullptr, zdev(c, pin.ptsB), zdev(c, pin.stA), nullptr, n, 3, 30, 0.01, 0);
         LkArgs b = make_lk(curL, prevL, nullptr, nullptr, nullptr, nullptr, nullptr, n, 1, 30, 0.01,
                            ESVIO_FE_LK_USE_INITIAL_FLOW);
-        stereo_chained = plain && c->chain_enabled;
+        stereo_chained = plain && c->chain_enabled && c->waits_fit_chain;
         if (stereo_chained) {
           c->n_stereo_chained++;
           c->chain_seq = (c->chain_seq + 1) & 0x3fffffffu;
@@ -1053,7 +1053,7 @@ struct TrackCall {
     n_kept = n_surv;
     // the next batch's pyramids are in flight on the prefetch stream: next frame's temporal LK can be
     // launched as soon as this frame's points are final
-    will_spec = have_next || had_announced;
+    will_spec = (have_next || had_announced) && c->waits_fit_spec;
     if (!PUB_THIS_FRAME) {  // (ahead of the stereo LK so that the two launches overlap)
       if (int rc = upload_kept()) return rc;
       // (c->chain_valid here: the next frame's temporal LK is already running, chained to this one's)

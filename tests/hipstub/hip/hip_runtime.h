@@ -53,6 +53,8 @@ hipError_t hipGetDevice(int* d);
 hipError_t hipGetLastError(void);
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int dev);
 hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b);
 hipError_t hipMalloc(void** p, size_t bytes);
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc((void**)p, bytes); }

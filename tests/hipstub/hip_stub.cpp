@@ -52,6 +52,7 @@ hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "hipstub"; }
 hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)64 << 30; *t = (size_t)288 << 30; return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t bytes) {
   *p = calloc(bytes ? bytes : 1, 1);

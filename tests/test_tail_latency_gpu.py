@@ -153,3 +153,62 @@ def test_no_allocation_after_reserve_and_a_first_call_like_the_others():
     ft.trackEvent(event_times(L)[-1], L, R, True)
     assert ft.latency_stats()["allocs"] > 0
     ft.close()
+
+
+@pytest.mark.parametrize("max_cnt", [600, 1000])
+def test_replay_with_more_points_than_waiting_launches_fit(max_cnt):
+    """An LK launch whose waves wait on the device (the speculative launch for k_select's corners, a chained launch for
+    its producer's points) holds one CU per four points while it waits; with max_cnt 1000 a launch is 250 workgroups on
+    256 CUs, and one step in ~20 of the replay schedule ran into a wait's 20-40 ms bound and was redone (round 6,
+    bench.py --max-cnt 1000: passes of 1.2-3.3 ms per step).  The handle now makes such launches only while they leave
+    room (esvio_fe_ctx::waits_fit_*): 100 replay steps with the launch thread, none slower than 5 ms, results as the
+    oracle's, no wait expired; the speculative launch still runs (250 workgroups leave room for k_select_mw), the chained
+    one does not."""
+    from oracle import oracle as O
+    O.build()
+    s = SceneStream(W, H, rate=5e6, seed=77)
+    batches = [s.next_batch()[:2] for _ in range(100)]
+    bufs, dev = [], []
+    for L, R in batches:
+        bl, br = FE.EventBuffer(L, FE.DEVICE), FE.EventBuffer(R, FE.DEVICE)
+        bufs += [bl, br]
+        dev.append((bl.arg, br.arg, event_times(L)[-1]))
+    fc = FreqControl(15)
+    pubs = []
+    for b in dev:
+        pubs.append(fc.pub_this_frame(b[2]))
+        if pubs[-1]:
+            fc.published()
+    kw = dict(max_cnt=max_cnt, min_dist=10, f_ransac=1)
+    ft = FE.FeatureTracker(FE.make_config(W, H, **kw))
+    ft.set_lazy_new_stereo(True)
+    ft.set_host_threads(8)
+    ft.set_launch_thread(True)
+    ft.reserve(max(len(b[0]) for b in batches), max(len(b[1]) for b in batches))
+    tr = O.Tracker(O.make_config(W, H, **kw))
+    announced = 0
+    slow = []
+    for i, b in enumerate(dev):
+        while announced < min(i + 3, len(dev) - 1):
+            announced += 1
+            a = dev[announced]
+            ft.set_next_batch(a[2], a[0], a[1], pubs[announced])
+        t0 = time.perf_counter()
+        ft.trackEvent(b[2], b[0], b[1], pubs[i])
+        ms = (time.perf_counter() - t0) * 1e3
+        if i >= 5 and ms > 5.0:
+            slow.append((i, round(ms, 2)))
+        r = tr.track_event(b[2], batches[i][0], batches[i][1], pubs[i])
+        assert np.array_equal(ft.ids, r.ids) and np.array_equal(ft.cur_pts.view(np.uint32), r.cur_pts.view(np.uint32)), i
+        if i % 10 == 9:  # (the right camera's results of a lazily returned frame: complete them now and then)
+            ft.finish()
+            assert np.array_equal(ft.ids_right, r.ids_right), i
+            assert np.array_equal(ft.cur_right_pts.view(np.uint32), r.cur_right_pts.view(np.uint32)), i
+    ft.finish()
+    cnt = ft.debug_counters()
+    ft.close()
+    for b in bufs:
+        b.free()
+    assert not slow, slow
+    assert cnt["spec_redone"] == 0 and cnt["chain_redone"] == 0, cnt
+    assert cnt["chain_launched"] == 0, cnt  # (two waiting launches of 150 / 250 workgroups each do not fit 256 CUs)
