@@ -307,7 +307,8 @@ int esvio_fe_create(const esvio_fe_config* cfg, esvio_fe_handle* out) {
   if (const char* e = getenv("ESVIO_FE_STEREO_SPLIT")) c->stereo_split_env = atoi(e) != 0;  // (else: fe_track.cpp decides)
   c->chain_enabled = getenv("ESVIO_FE_NO_CHAIN") == nullptr;
   c->cam_split_enabled = getenv("ESVIO_FE_NO_CAMSPLIT") == nullptr;
-  c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr;
+  // (the per-pixel dedup of the Arc* candidates pays only where the selection digs deep into its list: fe_stages.cpp run_arc)
+  c->dedup_enabled = getenv("ESVIO_FE_NO_DEDUP") == nullptr && (cfg->max_cnt > 500 || getenv("ESVIO_FE_DEDUP") != nullptr);
   c->fuse_ts_pyr = getenv("ESVIO_FE_NO_FUSE") == nullptr;
   c->select_one_wave = getenv("ESVIO_FE_SELECT_SERIAL") != nullptr;
   if (const char* v = getenv("ESVIO_FE_SAE_EV_MIN")) c->sae_ev_min = (size_t)strtoull(v, nullptr, 10);

@@ -846,9 +846,12 @@ void run_arc(esvio_fe_ctx* c, const EventRec* ev, uint32_t n, const PyrDesc* ts,
   a.cand_xy = want_cand ? c->cand[set].xy : nullptr;
   a.cand_idx = want_cand ? c->cand[set].idx : nullptr;
   a.cand_cnt = want_cand ? c->cand[set].cnt : nullptr;
-  // Worth it for batches of the usual size (k_select, on the frame's device chain, sees half the
-  // candidates: 54 against 57 us at 0.17 M left events, the atomics and k_dedup run on the prefetch
-  // stream); at 3.3 M left events the 0.8 M atomics cost k_arc_ev 43 us and save k_select 8.
+  // Only a pixel's earliest candidate can be accepted (a later one finds the pixel blocked whatever happened to the
+  // first): an atomicMin per candidate here + k_dedup halve the list k_select walks.  That paid with the one-wave
+  // k_select (54 against 57 us at 0.17 M left events); k_select_mw does not care until it has to dig through the
+  // whole list — max_cnt 1000: 63 us with, 98 without — while the atomics cost k_arc_ev 2.4 us at C3, 9 at 20 Mev/s
+  // (0.131 -> 0.1225 ms per replay step without them), 43 at 3.3 M left events, and most of its HBM writes.  So:
+  // handles with max_cnt > 500 only (esvio_fe_create; ESVIO_FE_DEDUP=1 / ESVIO_FE_NO_DEDUP=1 force it), batches < 2^20.
   const bool dedup = want_cand && c->dedup_enabled && c->d_first[set] && n < (1u << 20);
   if (dedup) {
     // keys count down from launch to launch: 0xfe.. for the first, 0x01.. for the 254th, then the

@@ -1115,10 +1115,11 @@ def test_replay_random_schedules(oracle, seed):
     ft.close()
 
 
-@pytest.mark.parametrize("opt", ["ESVIO_FE_NO_CHAIN", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE",
+@pytest.mark.parametrize("opt", ["ESVIO_FE_NO_CHAIN", "ESVIO_FE_DEDUP", "ESVIO_FE_NO_DEDUP", "ESVIO_FE_NO_FUSE",
                                  "ESVIO_FE_SAE_SORT", "ESVIO_FE_SAE_SORT+ESVIO_FE_SAE_EV_MIN", "ESVIO_FE_SELECT_SERIAL"])
 def test_replay_options_do_not_change_results(oracle, opt, monkeypatch):
-    """the measurement switches read at esvio_fe_create (no chained temporal LK; no per-pixel dedup of the Arc* candidates; unfused time surface +
+    """the measurement switches read at esvio_fe_create (no chained temporal LK; the per-pixel dedup of the Arc* candidates forced on
+    (handles with max_cnt <= 500 run without it) / off; unfused time surface +
     pyrDown kernels; the radix-sort form of the SAE update instead of the tiled one, with the
     per-pixel walk and with the per-event apply kernels for batches of >= 1 event instead of >= 2^20; the
     one-wave selection kernel that sensors without LDS for the 16-wave kernel's queue take)
